@@ -1,0 +1,75 @@
+"""ctypes binding of the gfx950 C-ABI library (``aqualora_amd/csrc/libaqualora_hip.so``).
+
+The library is the product: there is no CPU or PyTorch fallback behind these entry points.  If the shared
+object is missing or a symbol declared in ``include/aqualora_hip.h`` cannot be resolved, importing the
+compute path raises immediately.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported first so that libamdhip64.so.7 resolves to torch's HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libaqualora_hip.so")
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_l = ctypes.c_long
+c_f = ctypes.c_float
+c_sz = ctypes.c_size_t
+
+# name -> argtypes.  Mirrors include/aqualora_hip.h (tests/test_abi.py checks the two stay in sync).
+SIGNATURES = {
+    "aql_gemm_bf16": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_i, c_p, c_l, c_p, c_l,
+                      c_p, c_sz, c_p],
+    "aql_lora_down": [c_p, c_l, c_l, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p],
+    "aql_conv3x3_fwd": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_sz, c_p],
+    "aql_conv3x3_bwd_data": [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_sz, c_p],
+    "aql_gemm_tn_f32": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_f, c_p, c_l, c_p],
+}
+
+_lib = None
+
+
+class AqlError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared object once and attach argtypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AqlError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C aqualora_amd/csrc`). There is no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.aql_last_error.restype = ctypes.c_char_p
+    lib.aql_last_error.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = ABI drift, fail loudly
+        fn.argtypes = argtypes
+        fn.restype = c_i
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = load().aql_last_error().decode("utf-8", "replace")
+        raise AqlError(f"{what} failed with status {status}: {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (or NULL for None)."""
+    return None if t is None else c_p(t.data_ptr())
+
+
+def stream_ptr():
+    return c_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    lib = load()
+    check(getattr(lib, name)(*args), name)

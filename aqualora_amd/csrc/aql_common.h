@@ -1,0 +1,68 @@
+// Shared device/host helpers for the aqualora_hip C-ABI library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits; no torch / hip_bf16 types cross the ABI
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment (8 bf16 = 4 VGPR)
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // 16x16 accumulator
+
+#define AQL_OK 0
+#define AQL_ERR_ARG 1
+#define AQL_ERR_HIP 2
+
+// Thread-local last-error text, returned by aql_last_error().
+extern "C" const char* aql_last_error(void);
+void aql_set_error(const char* fmt, ...);
+
+#define AQL_CHECK_ARG(cond, ...)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      aql_set_error(__VA_ARGS__);                \
+      return AQL_ERR_ARG;                        \
+    }                                            \
+  } while (0)
+
+#define AQL_CHECK_LAUNCH(name)                                                   \
+  do {                                                                           \
+    hipError_t _e = hipGetLastError();                                           \
+    if (_e != hipSuccess) {                                                      \
+      aql_set_error("%s: launch failed: %s", name, hipGetErrorString(_e));       \
+      return AQL_ERR_HIP;                                                        \
+    }                                                                            \
+  } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, NaN preserved as quiet NaN
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int aql_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

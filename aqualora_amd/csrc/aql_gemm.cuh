@@ -1,0 +1,471 @@
+// bf16 MFMA GEMM core for gfx950 (CDNA4): one templated main loop shared by
+//   * the fused LoRA linear  Y = X.W^T + b + (T*S).Bup^T      (two K segments, one accumulator)
+//   * the 3x3 NHWC convolution as an implicit GEMM (gather loader, nearest-x2 upsample and stride folded in)
+//   * its backward-data form, and
+//   * the weight-gradient GEMMs dA/dB (reduction over tokens, transposing loader).
+//
+// Tile: BM x BN outputs per 256-thread workgroup (4 wavefronts of 64), K tile 64 bf16, double-buffered LDS,
+// v_mfma_f32_32x32x16_bf16 with the *weight-side* tile as MFMA operand A and the *activation-side* tile as
+// operand B, so a lane ends up with 4 consecutive output columns of one output row (8-byte packed stores).
+// LDS rows are 128 B (8 chunks of 16 B); chunk index is XOR-swizzled with (row & 7) so that both the 16-byte
+// staging writes and the ds_read_b128 fragment reads are bank-conflict free (guide T2).
+#pragma once
+#include "aql_common.h"
+
+namespace aqlgemm {
+
+constexpr int BK = 64;
+constexpr int NTHREADS = 256;
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+__device__ __forceinline__ uint4 zero4() { return make_uint4(0u, 0u, 0u, 0u); }
+
+// ------------------------------------------------------------------------------------------------
+// Loaders.  A loader describes one GEMM operand as "rows x K" and hands out 16-byte chunks (8 bf16
+// along K).  kTrans loaders read a [K][rows] source instead and are staged through a register transpose.
+// ------------------------------------------------------------------------------------------------
+struct PlainLoader {
+  static constexpr bool kTrans = false;
+  const bf16_t* base;
+  long ld;
+  int rows;
+  int K;
+  struct Row {
+    const bf16_t* p;
+  };
+  struct KInfo {
+    int k;
+  };
+  __device__ __forceinline__ Row row(int r) const {
+    Row x;
+    x.p = (r < rows) ? base + (long)r * ld : nullptr;
+    return x;
+  }
+  __device__ __forceinline__ KInfo kinfo(int k) const { return KInfo{k < K ? k : -1}; }
+  __device__ __forceinline__ uint4 load(const Row& x, const KInfo& ki) const {
+    if (x.p != nullptr && ki.k >= 0) return *reinterpret_cast<const uint4*>(x.p + ki.k);
+    return zero4();
+  }
+};
+
+// Forward 3x3 conv, NHWC input [B,Hin,Win,Cin]; row r = (b,ho,wo); k = (kh*3+kw)*Cin + ci.
+// ups=1 reads the input through a nearest x2 upsample (diffusers Upsample2D) without materialising it.
+struct ConvFwdLoader {
+  static constexpr bool kTrans = false;
+  const bf16_t* base;
+  int B, Hin, Win, Cin, Hout, Wout, stride, ups;
+  int rows, K;
+  struct Row {
+    int b, h, w;
+  };
+  struct KInfo {
+    int kh, kw, ci;
+  };
+  __device__ __forceinline__ Row row(int r) const {
+    Row x;
+    if (r >= rows) {
+      x.b = -1;
+      x.h = x.w = 0;
+      return x;
+    }
+    int hw = Hout * Wout;
+    x.b = r / hw;
+    int rem = r - x.b * hw;
+    int ho = rem / Wout;
+    x.h = ho * stride - 1;
+    x.w = (rem - ho * Wout) * stride - 1;
+    return x;
+  }
+  __device__ __forceinline__ KInfo kinfo(int k) const {
+    KInfo ki;
+    if (k >= K) {
+      ki.kh = -100;
+      ki.kw = 0;
+      ki.ci = 0;
+      return ki;
+    }
+    int tap = k / Cin;
+    ki.ci = k - tap * Cin;
+    ki.kh = tap / 3;
+    ki.kw = tap - ki.kh * 3;
+    return ki;
+  }
+  __device__ __forceinline__ uint4 load(const Row& x, const KInfo& ki) const {
+    int hi = x.h + ki.kh, wi = x.w + ki.kw;
+    int Hl = Hin << ups, Wl = Win << ups;
+    if (x.b < 0 || hi < 0 || wi < 0 || hi >= Hl || wi >= Wl) return zero4();
+    hi >>= ups;
+    wi >>= ups;
+    return *reinterpret_cast<const uint4*>(base + (((long)x.b * Hin + hi) * Win + wi) * Cin + ki.ci);
+  }
+};
+
+// Backward-data 3x3 conv: rows are input pixels (b,hi,wi) of dX; source is dY [B,Hout,Wout,Cout];
+// k = (kh*3+kw)*Cout + co;  hi = ho*stride + kh - 1.
+struct ConvBwdLoader {
+  static constexpr bool kTrans = false;
+  const bf16_t* base;
+  int B, Hin, Win, Cout, Hout, Wout, stride;
+  int rows, K;
+  struct Row {
+    int b, h, w;
+  };
+  struct KInfo {
+    int kh, kw, co;
+  };
+  __device__ __forceinline__ Row row(int r) const {
+    Row x;
+    if (r >= rows) {
+      x.b = -1;
+      x.h = x.w = 0;
+      return x;
+    }
+    int hw = Hin * Win;
+    x.b = r / hw;
+    int rem = r - x.b * hw;
+    int hi = rem / Win;
+    x.h = hi + 1;
+    x.w = (rem - hi * Win) + 1;
+    return x;
+  }
+  __device__ __forceinline__ KInfo kinfo(int k) const {
+    KInfo ki;
+    if (k >= K) {
+      ki.kh = 100000;
+      ki.kw = 0;
+      ki.co = 0;
+      return ki;
+    }
+    int tap = k / Cout;
+    ki.co = k - tap * Cout;
+    ki.kh = tap / 3;
+    ki.kw = tap - ki.kh * 3;
+    return ki;
+  }
+  __device__ __forceinline__ uint4 load(const Row& x, const KInfo& ki) const {
+    int th = x.h - ki.kh, tw = x.w - ki.kw;
+    if (x.b < 0 || th < 0 || tw < 0) return zero4();
+    if (stride == 2) {
+      if ((th | tw) & 1) return zero4();
+      th >>= 1;
+      tw >>= 1;
+    }
+    if (th >= Hout || tw >= Wout) return zero4();
+    return *reinterpret_cast<const uint4*>(base + (((long)x.b * Hout + th) * Wout + tw) * Cout + ki.co);
+  }
+};
+
+// Transposed source: element (row, k) lives at base[k*ld + row]  (rows contiguous).  Used for the
+// token-reduction GEMMs dB = dY^T.Ts and dA = dT^T.X.  rows % 8 == 0 required.
+struct TransLoader {
+  static constexpr bool kTrans = true;
+  const bf16_t* base;
+  long ld;
+  int rows;
+  int K;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Epilogue descriptors
+// ------------------------------------------------------------------------------------------------
+enum { EPI_BF16 = 0, EPI_SLAB = 1, EPI_ATOMIC = 2 };
+
+struct EpiParams {
+  // EPI_BF16: C[m][n] = bf16(bf16(acc + bias[n]) + residual[m][n]);  optional C2 = bf16(C * rowscale[m/rps][n])
+  bf16_t* C;
+  long ldc;
+  const bf16_t* bias;      // [N] or null
+  const bf16_t* residual;  // [M][ldr] or null
+  long ldr;
+  bf16_t* C2;              // second output (row-scaled) or null
+  long ldc2;
+  const bf16_t* rowscale;  // [nsamples][N]
+  const bf16_t* rowbias;   // [nsamples][N] added (bf16 add) after bias, before the residual; or null
+  int rows_per_sample;
+  int act;                 // 0 none, 1 GEGLU pairs (col j: value, col j+BN/2 inside tile: gate)  [reserved]
+  // EPI_SLAB / EPI_ATOMIC: fp32 output
+  float* Cf;               // slab base [splits][M][ldcf] or atomic target [M][ldcf]
+  long ldcf;
+  float alpha;             // scale applied to fp32 outputs
+};
+
+struct Segment {
+  int ktiles;  // number of BK tiles of this K segment
+};
+
+template <class LA, class LB>
+struct GemmArgs {
+  LA a0;  // activation-side operand (rows = M), segment 0
+  LB b0;  // weight-side operand (rows = N), segment 0
+  LA a1;  // optional segment 1 (LoRA:  Ts [M,r]  x  Bup [N,r])
+  LB b1;
+  int ktiles0, ktiles1;
+  int M, N;
+  int splits;  // grid.z; k tiles of the concatenated K range are divided evenly
+  EpiParams epi;
+};
+
+// --------------------------------------------------------------------------------------------
+// staging helpers
+// --------------------------------------------------------------------------------------------
+template <int R, class L>
+struct Stager {
+  // non-transposed: thread owns chunk c = tid&7 of rows (tid>>3) + 32*i
+  static constexpr int NL = R / 32;
+  typename L::Row rows[NL];
+  uint4 regs[NL];
+  __device__ __forceinline__ void init(const L& l, int row0, int tid) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) rows[i] = l.row(row0 + (tid >> 3) + 32 * i);
+  }
+  __device__ __forceinline__ void fetch(const L& l, int k0, int tid) {
+    typename L::KInfo ki = l.kinfo(k0 + (tid & 7) * 8);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) regs[i] = l.load(rows[i], ki);
+  }
+  __device__ __forceinline__ void commit(char* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      *reinterpret_cast<uint4*>(lds + lds_off((tid >> 3) + 32 * i, tid & 7)) = regs[i];
+  }
+};
+
+template <int R>
+struct Stager<R, TransLoader> {
+  // transposed: task t -> kq = t&15 (4 consecutive k), rg = t>>4 (8 consecutive rows)
+  static constexpr int TASKS = (R / 8) * 16;
+  static constexpr int NL = (TASKS + NTHREADS - 1) / NTHREADS;
+  uint4 regs[NL][4];
+  int row0_;
+  __device__ __forceinline__ void init(const TransLoader&, int row0, int) { row0_ = row0; }
+  __device__ __forceinline__ void fetch(const TransLoader& l, int k0, int tid) {
+#pragma unroll
+    for (int t = 0; t < NL; ++t) {
+      int task = tid + t * NTHREADS;
+      int kq = task & 15, rg = task >> 4;
+      int r = row0_ + rg * 8;
+      bool rok = (task < TASKS) && (r < l.rows);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int k = k0 + kq * 4 + i;
+        regs[t][i] = (rok && k < l.K) ? *reinterpret_cast<const uint4*>(l.base + (long)k * l.ld + r) : zero4();
+      }
+    }
+  }
+  __device__ __forceinline__ void commit(char* lds, int tid) const {
+#pragma unroll
+    for (int t = 0; t < NL; ++t) {
+      int task = tid + t * NTHREADS;
+      if (task >= TASKS) continue;
+      int kq = task & 15, rg = task >> 4;
+      const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&regs[t][0]);
+      const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&regs[t][1]);
+      const uint32_t* w2 = reinterpret_cast<const uint32_t*>(&regs[t][2]);
+      const uint32_t* w3 = reinterpret_cast<const uint32_t*>(&regs[t][3]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int w = j >> 1;
+        uint32_t lo, hi;
+        if (j & 1) {
+          lo = (w0[w] >> 16) | (w1[w] & 0xffff0000u);
+          hi = (w2[w] >> 16) | (w3[w] & 0xffff0000u);
+        } else {
+          lo = (w0[w] & 0xffffu) | (w1[w] << 16);
+          hi = (w2[w] & 0xffffu) | (w3[w] << 16);
+        }
+        int row = rg * 8 + j;
+        *reinterpret_cast<uint2*>(lds + lds_off(row, kq >> 1) + (kq & 1) * 8) = make_uint2(lo, hi);
+      }
+    }
+  }
+};
+
+// --------------------------------------------------------------------------------------------
+// the kernel
+// --------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs<LA, LB> g) {
+  constexpr int FM = WM / 32, FN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * (BN / WN) == 4, "4 wavefronts per workgroup");
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int C_PITCH = (BN + 8) * 2;  // bytes per row of the bf16 C tile staged in LDS
+  constexpr int LDS_BYTES = (2 * STAGE > BM * C_PITCH) ? 2 * STAGE : BM * C_PITCH;
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm0 = (wave / WAVES_N) * WM;
+  const int wn0 = (wave % WAVES_N) * WN;
+
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int tile_m = blockIdx.x / tiles_n;
+  const int tile_n = blockIdx.x - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // K range of this split
+  const int kt_total = g.ktiles0 + g.ktiles1;
+  const int kt_begin = (int)(((long)kt_total * blockIdx.z) / g.splits);
+  const int kt_end = (int)(((long)kt_total * (blockIdx.z + 1)) / g.splits);
+
+  Stager<BM, LA> sa;
+  Stager<BN, LB> sb;
+  sa.init(g.a0, m0, tid);
+  sb.init(g.b0, n0, tid);
+
+  f32x16_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  auto fetch = [&](int kt) {
+    if (kt < g.ktiles0) {
+      sa.fetch(g.a0, kt * BK, tid);
+      sb.fetch(g.b0, kt * BK, tid);
+    } else {
+      if (kt == g.ktiles0 || kt == kt_begin) {  // switch row descriptors to segment 1
+        sa.init(g.a1, m0, tid);
+        sb.init(g.b1, n0, tid);
+      }
+      sa.fetch(g.a1, (kt - g.ktiles0) * BK, tid);
+      sb.fetch(g.b1, (kt - g.ktiles0) * BK, tid);
+    }
+  };
+
+  if (kt_begin < kt_end) {
+    fetch(kt_begin);
+    sa.commit(lds, tid);
+    sb.commit(lds + A_BYTES, tid);
+  }
+  __syncthreads();
+
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    char* sA = lds + cur * STAGE;
+    char* sB = sA + A_BYTES;
+    const bool more = (kt + 1 < kt_end);
+    if (more) fetch(kt + 1);
+
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8_t fa[FM], fb[FN];
+      const int chunk = ks * 2 + (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+        fa[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(wm0 + i * 32 + (lane & 31), chunk));
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        fb[j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(wn0 + j * 32 + (lane & 31), chunk));
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+
+    if (more) {
+      char* nA = lds + (cur ^ 1) * STAGE;
+      sa.commit(nA, tid);
+      sb.commit(nA + A_BYTES, tid);
+    }
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  // acc[i][j][e]: output row m = m0+wm0+i*32+(lane&31); col n = n0+wn0+j*32 + (e&3) + 8*(e>>2) + 4*(lane>>5)
+  const EpiParams& ep = g.epi;
+  if constexpr (EPI == EPI_BF16) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int row = wm0 + i * 32 + (lane & 31);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = wn0 + j * 32 + q * 8 + (lane >> 5) * 4;
+          float v0 = acc[i][j][q * 4 + 0], v1 = acc[i][j][q * 4 + 1];
+          float v2 = acc[i][j][q * 4 + 2], v3 = acc[i][j][q * 4 + 3];
+          if (ep.bias != nullptr && (n0 + col) < g.N) {
+            const uint2 bb = *reinterpret_cast<const uint2*>(ep.bias + n0 + col);
+            v0 += bf16lo(bb.x);
+            v1 += bf16hi(bb.x);
+            v2 += bf16lo(bb.y);
+            v3 += bf16hi(bb.y);
+          }
+          *reinterpret_cast<uint2*>(lds + row * C_PITCH + col * 2) =
+              make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+        }
+      }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;  // 16-byte chunks per row
+    for (int id = tid; id < BM * CPR; id += NTHREADS) {
+      const int row = id / CPR, cc = id - row * CPR;
+      const int m = m0 + row, n = n0 + cc * 8;
+      if (m >= g.M || n >= g.N) continue;
+      uint4 v = *reinterpret_cast<const uint4*>(lds + row * C_PITCH + cc * 16);
+      if (ep.rowbias != nullptr) {
+        const uint4 r = *reinterpret_cast<const uint4*>(ep.rowbias + (long)(m / ep.rows_per_sample) * g.N + n);
+        v.x = pack_bf16x2(bf16lo(v.x) + bf16lo(r.x), bf16hi(v.x) + bf16hi(r.x));
+        v.y = pack_bf16x2(bf16lo(v.y) + bf16lo(r.y), bf16hi(v.y) + bf16hi(r.y));
+        v.z = pack_bf16x2(bf16lo(v.z) + bf16lo(r.z), bf16hi(v.z) + bf16hi(r.z));
+        v.w = pack_bf16x2(bf16lo(v.w) + bf16lo(r.w), bf16hi(v.w) + bf16hi(r.w));
+      }
+      if (ep.residual != nullptr) {
+        const uint4 r = *reinterpret_cast<const uint4*>(ep.residual + (long)m * ep.ldr + n);
+        v.x = pack_bf16x2(bf16lo(v.x) + bf16lo(r.x), bf16hi(v.x) + bf16hi(r.x));
+        v.y = pack_bf16x2(bf16lo(v.y) + bf16lo(r.y), bf16hi(v.y) + bf16hi(r.y));
+        v.z = pack_bf16x2(bf16lo(v.z) + bf16lo(r.z), bf16hi(v.z) + bf16hi(r.z));
+        v.w = pack_bf16x2(bf16lo(v.w) + bf16lo(r.w), bf16hi(v.w) + bf16hi(r.w));
+      }
+      if (ep.C != nullptr) *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + n) = v;
+      if (ep.C2 != nullptr) {
+        const uint4 s =
+            *reinterpret_cast<const uint4*>(ep.rowscale + (long)(m / ep.rows_per_sample) * g.N + n);
+        uint4 o;
+        o.x = pack_bf16x2(bf16lo(v.x) * bf16lo(s.x), bf16hi(v.x) * bf16hi(s.x));
+        o.y = pack_bf16x2(bf16lo(v.y) * bf16lo(s.y), bf16hi(v.y) * bf16hi(s.y));
+        o.z = pack_bf16x2(bf16lo(v.z) * bf16lo(s.z), bf16hi(v.z) * bf16hi(s.z));
+        o.w = pack_bf16x2(bf16lo(v.w) * bf16lo(s.w), bf16hi(v.w) * bf16hi(s.w));
+        *reinterpret_cast<uint4*>(ep.C2 + (long)m * ep.ldc2 + n) = o;
+      }
+    }
+  } else {
+    float* out = ep.Cf;
+    if constexpr (EPI == EPI_SLAB) out += (long)blockIdx.z * g.M * ep.ldcf;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int m = m0 + wm0 + i * 32 + (lane & 31);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn0 + j * 32 + q * 8 + (lane >> 5) * 4;
+          if (m >= g.M || n >= g.N) continue;
+          float* p = out + (long)m * ep.ldcf + n;
+          if constexpr (EPI == EPI_SLAB) {
+            *reinterpret_cast<float4*>(p) =
+                make_float4(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(p + e, ep.alpha * acc[i][j][q * 4 + e]);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI>
+inline void launch_gemm(const GemmArgs<LA, LB>& g, hipStream_t stream) {
+  dim3 grid(aql_cdiv(g.M, BM) * aql_cdiv(g.N, BN), 1, g.splits);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LA, LB, EPI>), grid, dim3(NTHREADS), 0, stream, g);
+}
+
+}  // namespace aqlgemm

@@ -1,0 +1,338 @@
+// GroupNorm(+SiLU) and LayerNorm, forward and backward-data, on channels-last bf16 activations.
+// HBM-bound kernels: 16-byte vector loads, fp32 statistics, wavefront (64-lane) reductions.
+// Reference semantics: torch.nn.GroupNorm(32, C, eps) / F.silu / torch.nn.LayerNorm(C) as used by the U-Net
+// twin (scripts/lib/original_unet.py:423-453, 779-783, 826).  Base weights are frozen in PPFT, so backward
+// produces the input gradient only.
+#include "aql_common.h"
+
+namespace {
+
+constexpr int G = 32;  // NORM_GROUPS
+
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  f[0] = bf16lo(v.x); f[1] = bf16hi(v.x); f[2] = bf16lo(v.y); f[3] = bf16hi(v.y);
+  f[4] = bf16lo(v.z); f[5] = bf16hi(v.z); f[6] = bf16lo(v.w); f[7] = bf16hi(v.w);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+}
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + __expf(-z)); }
+
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm pass 1: per-(sample, group) partial sums over a slab of pixels.
+// Block = cols*rp threads (cols = C/8 chunk columns, rp pixel rows in flight); thread owns one chunk column.
+// MODE 0 (forward):  s1 = sum x,        s2 = sum x^2
+// MODE 1 (backward): s1 = sum dxhat,    s2 = sum dxhat*xhat   with dxhat = dy*silu'(z)*gamma
+// partial layout: [B][nslab][G][2]
+// ---------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void gn_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                  const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
+                                  const float* __restrict__ stats, int HW, int C, int rows_per_slab, int silu,
+                                  float* __restrict__ partial) {
+  __shared__ float sg[G][2];
+  const int cols = C >> 3;
+  const int rp = blockDim.x / cols;
+  const int col = threadIdx.x % cols;
+  const int rr = threadIdx.x / cols;
+  const int b = blockIdx.y, slab = blockIdx.x;
+  const int cpg = C / G;
+  for (int i = threadIdx.x; i < G * 2; i += blockDim.x) (&sg[0][0])[i] = 0.f;
+  __syncthreads();
+  float a1[8], a2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a1[j] = a2[j] = 0.f;
+  float ga[8], be[8], mu[8], rs[8];
+  if (MODE == 1) {
+    unpack8(*reinterpret_cast<const uint4*>(gamma + col * 8), ga);
+    unpack8(*reinterpret_cast<const uint4*>(beta + col * 8), be);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int g = (col * 8 + j) / cpg;
+      mu[j] = stats[(b * G + g) * 2 + 0];
+      rs[j] = stats[(b * G + g) * 2 + 1];
+    }
+  }
+  const int r0 = slab * rows_per_slab;
+  const int r1 = min(HW, r0 + rows_per_slab);
+  for (int r = r0 + rr; r < r1; r += rp) {
+    const long off = ((long)b * HW + r) * C + col * 8;
+    float xv[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + off), xv);
+    if (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a1[j] += xv[j];
+        a2[j] += xv[j] * xv[j];
+      }
+    } else {
+      float dv[8];
+      unpack8(*reinterpret_cast<const uint4*>(dy + off), dv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (xv[j] - mu[j]) * rs[j];
+        float d = dv[j];
+        if (silu) {
+          const float z = xh * ga[j] + be[j];
+          const float s = sigmoidf_(z);
+          d *= s * (1.f + z * (1.f - s));
+        }
+        d *= ga[j];
+        a1[j] += d;
+        a2[j] += d * xh;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int g = (col * 8 + j) / cpg;
+    atomicAdd(&sg[g][0], a1[j]);
+    atomicAdd(&sg[g][1], a2[j]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < G * 2; i += blockDim.x)
+    partial[(((long)b * gridDim.x + slab) * G) * 2 + i] = (&sg[0][0])[i];
+}
+
+// pass 1.5: reduce slabs.  MODE 0 -> stats = (mean, rstd);  MODE 1 -> (mean dxhat, mean dxhat*xhat)
+template <int MODE>
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nslab, float inv_count, float eps,
+                                   float* __restrict__ out) {
+  const int b = blockIdx.x, g = threadIdx.x;
+  if (g >= G) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int s = 0; s < nslab; ++s) {
+    s1 += partial[(((long)b * nslab + s) * G + g) * 2 + 0];
+    s2 += partial[(((long)b * nslab + s) * G + g) * 2 + 1];
+  }
+  if (MODE == 0) {
+    const float mean = s1 * inv_count;
+    const float var = fmaxf(s2 * inv_count - mean * mean, 0.f);
+    out[(b * G + g) * 2 + 0] = mean;
+    out[(b * G + g) * 2 + 1] = rsqrtf(var + eps);
+  } else {
+    out[(b * G + g) * 2 + 0] = s1 * inv_count;
+    out[(b * G + g) * 2 + 1] = s2 * inv_count;
+  }
+}
+
+// pass 2.  MODE 0: y = act(xhat*gamma+beta).  MODE 1: dx = rstd*(dxhat - m1 - xhat*m2)
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                       const bf16_t* __restrict__ gamma,
+                                                       const bf16_t* __restrict__ beta,
+                                                       const float* __restrict__ stats,
+                                                       const float* __restrict__ dstats, int HW, int C, int silu,
+                                                       bf16_t* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int cols = C >> 3;
+  const int cpg = C / G;
+  const long nchunk = (long)HW * cols;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < nchunk; id += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(id % cols);
+    const long off = (long)b * HW * C + id * 8;
+    float xv[8], ga[8], be[8], o[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + off), xv);
+    unpack8(*reinterpret_cast<const uint4*>(gamma + col * 8), ga);
+    unpack8(*reinterpret_cast<const uint4*>(beta + col * 8), be);
+    float dv[8];
+    if (MODE == 1) unpack8(*reinterpret_cast<const uint4*>(dy + off), dv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int g = (col * 8 + j) / cpg;
+      const float mu = stats[(b * G + g) * 2 + 0], rs = stats[(b * G + g) * 2 + 1];
+      const float xh = (xv[j] - mu) * rs;
+      const float z = xh * ga[j] + be[j];
+      if (MODE == 0) {
+        o[j] = silu ? z * sigmoidf_(z) : z;
+      } else {
+        float d = dv[j];
+        if (silu) {
+          const float s = sigmoidf_(z);
+          d *= s * (1.f + z * (1.f - s));
+        }
+        d *= ga[j];
+        o[j] = rs * (d - dstats[(b * G + g) * 2 + 0] - xh * dstats[(b * G + g) * 2 + 1]);
+      }
+    }
+    *reinterpret_cast<uint4*>(out + off) = pack8(o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm: one wavefront per token row, row kept in registers (C <= 64*8*MAXC).
+// ---------------------------------------------------------------------------------------------------
+constexpr int LN_MAXC = 3;  // up to 1536 channels
+
+template <int MODE>
+__global__ __launch_bounds__(256) void ln_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                 const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
+                                                 float* __restrict__ stats, long M, int C, float eps,
+                                                 bf16_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int cols = C >> 3;
+  float xv[LN_MAXC][8];
+  float dv[LN_MAXC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < LN_MAXC; ++t) {
+    const int c = lane + t * 64;
+    if (c < cols) {
+      unpack8(*reinterpret_cast<const uint4*>(x + row * C + c * 8), xv[t]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += xv[t][j];
+    }
+  }
+  float mean, rstd;
+  if (MODE == 0) {
+    mean = wave_sum(s) / C;
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < LN_MAXC; ++t) {
+      const int c = lane + t * 64;
+      if (c < cols) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = xv[t][j] - mean;
+          v += d * d;
+        }
+      }
+    }
+    rstd = rsqrtf(wave_sum(v) / C + eps);
+    if (lane == 0) {
+      stats[row * 2 + 0] = mean;
+      stats[row * 2 + 1] = rstd;
+    }
+  } else {
+    mean = stats[row * 2 + 0];
+    rstd = stats[row * 2 + 1];
+  }
+  if (MODE == 0) {
+#pragma unroll
+    for (int t = 0; t < LN_MAXC; ++t) {
+      const int c = lane + t * 64;
+      if (c < cols) {
+        float ga[8], be[8], o[8];
+        unpack8(*reinterpret_cast<const uint4*>(gamma + c * 8), ga);
+        unpack8(*reinterpret_cast<const uint4*>(beta + c * 8), be);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (xv[t][j] - mean) * rstd * ga[j] + be[j];
+        *reinterpret_cast<uint4*>(out + row * C + c * 8) = pack8(o);
+      }
+    }
+  } else {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < LN_MAXC; ++t) {
+      const int c = lane + t * 64;
+      if (c < cols) {
+        float ga[8];
+        unpack8(*reinterpret_cast<const uint4*>(gamma + c * 8), ga);
+        unpack8(*reinterpret_cast<const uint4*>(dy + row * C + c * 8), dv[t]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          dv[t][j] *= ga[j];
+          xv[t][j] = (xv[t][j] - mean) * rstd;
+          s1 += dv[t][j];
+          s2 += dv[t][j] * xv[t][j];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
+#pragma unroll
+    for (int t = 0; t < LN_MAXC; ++t) {
+      const int c = lane + t * 64;
+      if (c < cols) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rstd * (dv[t][j] - s1 - xv[t][j] * s2);
+        *reinterpret_cast<uint4*>(out + row * C + c * 8) = pack8(o);
+      }
+    }
+  }
+}
+
+inline int gn_geometry(int HW, int C, int* threads, int* rows_per_slab) {
+  const int cols = C / 8;
+  int rp = 512 / cols;
+  if (rp < 1) rp = 1;
+  if (rp > HW) rp = HW;
+  *threads = cols * rp;
+  int nslab = (HW + 63) / 64;  // ~64 pixel rows per slab
+  if (nslab > 64) nslab = 64;
+  if (nslab < 1) nslab = 1;
+  *rows_per_slab = (HW + nslab - 1) / nslab;
+  return (HW + *rows_per_slab - 1) / *rows_per_slab;
+}
+
+}  // namespace
+
+// scratch: caller-owned fp32 workspace of at least aql_groupnorm_scratch_floats(B, HW) elements
+extern "C" long aql_groupnorm_scratch_floats(int B, int HW) {
+  (void)HW;
+  return (long)B * 64 * G * 2 + (long)B * G * 2;
+}
+
+extern "C" int aql_groupnorm_silu_fwd(const bf16_t* x, int B, int HW, int C, const bf16_t* gamma, const bf16_t* beta,
+                                      float eps, int silu, bf16_t* y, float* stats, float* scratch,
+                                      hipStream_t stream) {
+  AQL_CHECK_ARG(x && gamma && beta && y && stats && scratch, "aql_groupnorm_silu_fwd: null operand");
+  AQL_CHECK_ARG(C % (8 * 1) == 0 && C % G == 0 && C / 8 <= 1024, "aql_groupnorm_silu_fwd: bad C=%d", C);
+  int threads, rps;
+  const int nslab = gn_geometry(HW, C, &threads, &rps);
+  hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(nslab, B), dim3(threads), 0, stream, x, nullptr, gamma, beta, nullptr,
+                     HW, C, rps, silu, scratch);
+  hipLaunchKernelGGL(gn_finalize_kernel<0>, dim3(B), dim3(64), 0, stream, scratch, nslab,
+                     1.f / ((float)HW * (C / G)), eps, stats);
+  const long nchunk = (long)HW * (C / 8);
+  int blocks = (int)((nchunk + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(gn_apply_kernel<0>, dim3(blocks, B), dim3(256), 0, stream, x, nullptr, gamma, beta, stats, nullptr,
+                     HW, C, silu, y);
+  AQL_CHECK_LAUNCH("aql_groupnorm_silu_fwd");
+  return AQL_OK;
+}
+
+extern "C" int aql_groupnorm_silu_bwd(const bf16_t* x, const bf16_t* dy, int B, int HW, int C, const bf16_t* gamma,
+                                      const bf16_t* beta, int silu, const float* stats, bf16_t* dx, float* scratch,
+                                      hipStream_t stream) {
+  AQL_CHECK_ARG(x && dy && gamma && beta && dx && stats && scratch, "aql_groupnorm_silu_bwd: null operand");
+  AQL_CHECK_ARG(C % 8 == 0 && C % G == 0 && C / 8 <= 1024, "aql_groupnorm_silu_bwd: bad C=%d", C);
+  int threads, rps;
+  const int nslab = gn_geometry(HW, C, &threads, &rps);
+  float* dstats = scratch + (long)B * 64 * G * 2;
+  hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(nslab, B), dim3(threads), 0, stream, x, dy, gamma, beta, stats, HW, C,
+                     rps, silu, scratch);
+  hipLaunchKernelGGL(gn_finalize_kernel<1>, dim3(B), dim3(64), 0, stream, scratch, nslab,
+                     1.f / ((float)HW * (C / G)), 0.f, dstats);
+  const long nchunk = (long)HW * (C / 8);
+  int blocks = (int)((nchunk + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(blocks, B), dim3(256), 0, stream, x, dy, gamma, beta, stats, dstats, HW, C,
+                     silu, dx);
+  AQL_CHECK_LAUNCH("aql_groupnorm_silu_bwd");
+  return AQL_OK;
+}
+
+extern "C" int aql_layernorm_fwd(const bf16_t* x, long M, int C, const bf16_t* gamma, const bf16_t* beta, float eps,
+                                 bf16_t* y, float* stats, hipStream_t stream) {
+  AQL_CHECK_ARG(x && gamma && beta && y && stats, "aql_layernorm_fwd: null operand");
+  AQL_CHECK_ARG(C % 8 == 0 && C <= 64 * 8 * LN_MAXC, "aql_layernorm_fwd: unsupported C=%d", C);
+  hipLaunchKernelGGL(ln_kernel<0>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, x, nullptr, gamma, beta, stats,
+                     M, C, eps, y);
+  AQL_CHECK_LAUNCH("aql_layernorm_fwd");
+  return AQL_OK;
+}
+
+extern "C" int aql_layernorm_bwd(const bf16_t* x, const bf16_t* dy, long M, int C, const bf16_t* gamma,
+                                 const float* stats, bf16_t* dx, hipStream_t stream) {
+  AQL_CHECK_ARG(x && dy && gamma && dx && stats, "aql_layernorm_bwd: null operand");
+  AQL_CHECK_ARG(C % 8 == 0 && C <= 64 * 8 * LN_MAXC, "aql_layernorm_bwd: unsupported C=%d", C);
+  hipLaunchKernelGGL(ln_kernel<1>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, x, dy, gamma, nullptr,
+                     const_cast<float*>(stats), M, C, 0.f, dx);
+  AQL_CHECK_LAUNCH("aql_layernorm_bwd");
+  return AQL_OK;
+}
