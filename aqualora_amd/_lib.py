@@ -26,6 +26,25 @@ SIGNATURES = {
     "aql_conv3x3_fwd": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_sz, c_p],
     "aql_conv3x3_bwd_data": [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_sz, c_p],
     "aql_gemm_tn_f32": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_f, c_p, c_l, c_p],
+    "aql_groupnorm_silu_fwd": [c_p, c_i, c_i, c_i, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p],
+    "aql_groupnorm_silu_bwd": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p],
+    "aql_layernorm_fwd": [c_p, c_l, c_i, c_p, c_p, c_f, c_p, c_p, c_p],
+    "aql_layernorm_bwd": [c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p],
+    "aql_geglu_fwd": [c_p, c_l, c_i, c_p, c_p],
+    "aql_geglu_bwd": [c_p, c_p, c_l, c_i, c_p, c_p],
+    "aql_upsample2x_bwd": [c_p, c_i, c_i, c_i, c_i, c_p, c_p],
+    "aql_add_noise": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p],
+    "aql_mse_fwd_bwd": [c_p, c_p, c_l, c_p, c_p, c_p],
+    "aql_mapper_fwd": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
+    "aql_mapper_bwd": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
+    "aql_secret_encoder_fwd": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p],
+    "aql_cast_transpose": [c_p, c_i, c_i, c_p, c_p, c_p],
+    "aql_lora_ds": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
+    "aql_sumsq_f32": [c_p, c_l, c_p, c_p],
+    "aql_clipnorm_adamw": [c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_p, c_f, c_f, c_f, c_f, c_p, c_p],
+    "aql_sdpa_fwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p, c_p],
+    "aql_sdpa_bwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p,
+                     c_p, c_p],
 }
 
 _lib = None

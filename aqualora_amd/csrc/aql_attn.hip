@@ -1,0 +1,464 @@
+// Flash-style scaled-dot-product attention (forward + backward) for the SD-1.5 U-Net head sizes d = 40/80/160,
+// written for gfx950 wave64 + v_mfma_f32_16x16x32_bf16.  Replaces F.scaled_dot_product_attention as reached from
+// diffusers' AttnProcessor2_0 / the in-tree twin scripts/lib/original_unet.py:688-704 (no mask, no dropout).
+//
+// Layout: q/k/v/o are the un-permuted linear outputs [B, N, H*d]; head h owns columns [h*d, (h+1)*d).
+//
+// All three kernels share one shape.  The workgroup's 4 wavefronts each OWN 32 rows (kept in registers as MFMA
+// B-operands) and STREAM 64-row tiles of the other side through LDS:
+//   "S-product"  acc[streamed 16-row frag][owner frag] += tile_rowmajor(A) x owner(B)    (contraction over d)
+//   "T-product"  acc[d frag][owner frag]               += tile_transposed(A) x P(B)      (contraction over streamed rows)
+// Products are computed transposed (streamed rows x owner rows) so that every softmax statistic of an owner row is
+// lane-local up to a 4-lane-group exchange, and the probabilities feed the second MFMA straight from the
+// accumulator registers: the MFMA k-slot order is permuted identically on both operands instead of shuffling.
+//   forward : owner = Q,        stream K (row-major) and V (transposed)
+//   dQ      : owner = Q, dO     stream K (row-major + transposed) and V (row-major)
+//   dK/dV   : owner = K, V      stream Q, dO (row-major + transposed), LSE and delta
+#include "aql_common.h"
+
+namespace {
+
+constexpr int TILE = 64;                    // streamed rows per tile
+constexpr int OWN = 32;                     // owner rows per wavefront
+constexpr int PITCH_T = TILE * 2 + 8;       // bytes per row of a transposed tile [d][64 rows]
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <int DH>
+struct RowPitch {
+  static constexpr int value = DH * 2 + 16;  // odd number of 16-byte slots -> conflict-free ds_read_b128
+};
+
+__device__ __forceinline__ uint4 zero4() { return make_uint4(0u, 0u, 0u, 0u); }
+
+// global [rows][ld] (head slice already applied to ptr) -> LDS row-major [64][DH] (zero padded)
+template <int DH>
+__device__ __forceinline__ void stage_rows(char* lds, const bf16_t* g, long ld, int row0, int nrows, int d, int tid) {
+  constexpr int CPR = DH / 8;
+  for (int id = tid; id < TILE * CPR; id += 256) {
+    const int row = id / CPR, c = id - row * CPR;
+    uint4 v = zero4();
+    if (row0 + row < nrows && c * 8 < d) v = *reinterpret_cast<const uint4*>(g + (long)(row0 + row) * ld + c * 8);
+    *reinterpret_cast<uint4*>(lds + row * RowPitch<DH>::value + c * 16) = v;
+  }
+}
+
+// global [rows][ld] -> LDS transposed [DV][64 rows]
+template <int DV>
+__device__ __forceinline__ void stage_trans(char* lds, const bf16_t* g, long ld, int row0, int nrows, int d, int tid) {
+  constexpr int TASKS = (TILE / 4) * (DV / 8);
+  for (int id = tid; id < TASKS; id += 256) {
+    const int kq = id & 15, cg = id >> 4;
+    uint4 in[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = row0 + kq * 4 + i;
+      in[i] = (row < nrows && cg * 8 < d) ? *reinterpret_cast<const uint4*>(g + (long)row * ld + cg * 8) : zero4();
+    }
+    const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&in[0]);
+    const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&in[1]);
+    const uint32_t* w2 = reinterpret_cast<const uint32_t*>(&in[2]);
+    const uint32_t* w3 = reinterpret_cast<const uint32_t*>(&in[3]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int w = j >> 1;
+      uint32_t lo, hi;
+      if (j & 1) {
+        lo = (w0[w] >> 16) | (w1[w] & 0xffff0000u);
+        hi = (w2[w] >> 16) | (w3[w] & 0xffff0000u);
+      } else {
+        lo = (w0[w] & 0xffffu) | (w1[w] << 16);
+        hi = (w2[w] & 0xffffu) | (w3[w] << 16);
+      }
+      *reinterpret_cast<uint2*>(lds + (cg * 8 + j) * PITCH_T + kq * 8) = make_uint2(lo, hi);
+    }
+  }
+}
+
+// owner rows -> B-operand fragments  f[frag][kstep]
+template <int DH>
+__device__ __forceinline__ void load_owner(bf16x8_t (&f)[2][DH / 32], const bf16_t* g, long ld, int row0, int nrows,
+                                           int d, int lane) {
+#pragma unroll
+  for (int fr = 0; fr < 2; ++fr) {
+    const int row = row0 + fr * 16 + (lane & 15);
+#pragma unroll
+    for (int s = 0; s < DH / 32; ++s) {
+      const int col = s * 32 + (lane >> 4) * 8;
+      uint4 v = zero4();
+      if (row < nrows && col < d) v = *reinterpret_cast<const uint4*>(g + (long)row * ld + col);
+      f[fr][s] = *reinterpret_cast<bf16x8_t*>(&v);
+    }
+  }
+}
+
+// acc[sf][of] += rowmajor tile frag sf (A)  x  owner frag of (B)
+template <int DH>
+__device__ __forceinline__ void s_product(f32x4_t (&acc)[4][2], const char* tile, const bf16x8_t (&own)[2][DH / 32],
+                                          int lane) {
+#pragma unroll
+  for (int s = 0; s < DH / 32; ++s) {
+    bf16x8_t a[4];
+#pragma unroll
+    for (int sf = 0; sf < 4; ++sf)
+      a[sf] = *reinterpret_cast<const bf16x8_t*>(tile + (sf * 16 + (lane & 15)) * RowPitch<DH>::value + s * 64 +
+                                                 (lane >> 4) * 16);
+#pragma unroll
+    for (int sf = 0; sf < 4; ++sf)
+#pragma unroll
+      for (int of = 0; of < 2; ++of)
+        acc[sf][of] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[sf], own[of][s], acc[sf][of], 0, 0, 0);
+  }
+}
+
+// p[sf][of] (fp32, rows = streamed index sf*16 + g*4 + reg) -> B fragments over streamed rows:
+// k-slot (g,e) of step s2  <->  streamed row 32*s2 + 16*(e>>2) + 4*g + (e&3)
+__device__ __forceinline__ void pack_p(bf16x8_t (&pb)[2][2], const f32x4_t (&p)[4][2]) {
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int of = 0; of < 2; ++of) {
+      uint4 v;
+      v.x = pack_bf16x2(p[2 * s2][of][0], p[2 * s2][of][1]);
+      v.y = pack_bf16x2(p[2 * s2][of][2], p[2 * s2][of][3]);
+      v.z = pack_bf16x2(p[2 * s2 + 1][of][0], p[2 * s2 + 1][of][1]);
+      v.w = pack_bf16x2(p[2 * s2 + 1][of][2], p[2 * s2 + 1][of][3]);
+      pb[s2][of] = *reinterpret_cast<bf16x8_t*>(&v);
+    }
+}
+
+// acc[df][of] += transposed tile frag df (A)  x  pb (B)
+template <int DV>
+__device__ __forceinline__ void t_product(f32x4_t (&acc)[DV / 16][2], const char* ttile, const bf16x8_t (&pb)[2][2],
+                                          int lane) {
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+    for (int df = 0; df < DV / 16; ++df) {
+      const char* p = ttile + (df * 16 + (lane & 15)) * PITCH_T + (s2 * 32 + (lane >> 4) * 4) * 2;
+      const uint2 lo = *reinterpret_cast<const uint2*>(p);
+      const uint2 hi = *reinterpret_cast<const uint2*>(p + 32);
+      uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      const bf16x8_t a = *reinterpret_cast<bf16x8_t*>(&v);
+#pragma unroll
+      for (int of = 0; of < 2; ++of)
+        acc[df][of] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb[s2][of], acc[df][of], 0, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ float group4_max(float v) {  // across the 4 lanes sharing lane&15
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group4_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+template <int N>
+__device__ __forceinline__ void zero_acc(f32x4_t (&a)[N][2]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[i][j][e] = 0.f;
+}
+
+// store acc^T (d x owner rows) as out[row][d] bf16, 4 consecutive d per lane
+template <int DV>
+__device__ __forceinline__ void store_t(const f32x4_t (&acc)[DV / 16][2], bf16_t* g, long ld, int row0, int nrows, int d,
+                                        float mul0, float mul1, int lane) {
+#pragma unroll
+  for (int of = 0; of < 2; ++of) {
+    const int row = row0 + of * 16 + (lane & 15);
+    const float mul = of ? mul1 : mul0;
+    if (row >= nrows) continue;
+#pragma unroll
+    for (int df = 0; df < DV / 16; ++df) {
+      const int col = df * 16 + (lane >> 4) * 4;
+      if (col >= d) continue;
+      *reinterpret_cast<uint2*>(g + (long)row * ld + col) =
+          make_uint2(pack_bf16x2(acc[df][of][0] * mul, acc[df][of][1] * mul),
+                     pack_bf16x2(acc[df][of][2] * mul, acc[df][of][3] * mul));
+    }
+  }
+}
+
+struct AttnArgs {
+  const bf16_t *q, *k, *v, *o, *dout;
+  bf16_t *out, *dq, *dk, *dv;
+  float* lse;
+  float* delta;
+  long ldq, ldk, ldv, ldo;
+  int B, H, Nq, Nk, d;
+  float scale;
+};
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int DH, int DV>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char sK[TILE * RowPitch<DH>::value];
+  __shared__ __attribute__((aligned(16))) char sVt[DV * PITCH_T];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * (4 * OWN) + wave * OWN;
+  const bf16_t* qp = a.q + (long)b * a.Nq * a.ldq + h * a.d;
+  const bf16_t* kp = a.k + (long)b * a.Nk * a.ldk + h * a.d;
+  const bf16_t* vp = a.v + (long)b * a.Nk * a.ldv + h * a.d;
+  bf16x8_t qf[2][DH / 32];
+  load_owner<DH>(qf, qp, a.ldq, q0, a.Nq, a.d, lane);
+  f32x4_t o[DV / 16][2];
+  zero_acc(o);
+  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+  const float c = a.scale * LOG2E;
+  for (int kt = 0; kt < a.Nk; kt += TILE) {
+    __syncthreads();
+    stage_rows<DH>(sK, kp, a.ldk, kt, a.Nk, a.d, tid);
+    stage_trans<DV>(sVt, vp, a.ldv, kt, a.Nk, a.d, tid);
+    __syncthreads();
+    f32x4_t s[4][2];
+    zero_acc(s);
+    s_product<DH>(s, sK, qf, lane);
+    if (kt + TILE > a.Nk) {
+#pragma unroll
+      for (int sf = 0; sf < 4; ++sf)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (kt + sf * 16 + (lane >> 4) * 4 + e >= a.Nk) s[sf][0][e] = s[sf][1][e] = -INFINITY;
+    }
+#pragma unroll
+    for (int of = 0; of < 2; ++of) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int sf = 0; sf < 4; ++sf)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[sf][of][e]);
+      mx = group4_max(mx);
+      const float mn = fmaxf(m[of], mx);
+      const float alpha = exp2f((m[of] - mn) * c);
+      m[of] = mn;
+      float rs = 0.f;
+#pragma unroll
+      for (int sf = 0; sf < 4; ++sf)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p = exp2f((s[sf][of][e] - mn) * c);
+          s[sf][of][e] = p;
+          rs += p;
+        }
+      l[of] = l[of] * alpha + group4_sum(rs);
+#pragma unroll
+      for (int df = 0; df < DV / 16; ++df)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[df][of][e] *= alpha;
+    }
+    bf16x8_t pb[2][2];
+    pack_p(pb, s);
+    t_product<DV>(o, sVt, pb, lane);
+  }
+  store_t<DV>(o, a.out + (long)b * a.Nq * a.ldo + h * a.d, a.ldo, q0, a.Nq, a.d, 1.f / l[0], 1.f / l[1], lane);
+  if ((lane >> 4) == 0) {
+#pragma unroll
+    for (int of = 0; of < 2; ++of) {
+      const int row = q0 + of * 16 + (lane & 15);
+      if (row < a.Nq) a.lse[((long)b * a.H + h) * a.Nq + row] = m[of] * a.scale + logf(l[of]);
+    }
+  }
+}
+
+// delta[b,h,q] = sum_d dO[q,d] * O[q,d]
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
+  const long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, q, h) one wavefront each
+  const int lane = threadIdx.x & 63;
+  const long total = (long)a.B * a.Nq * a.H;
+  if (idx >= total) return;
+  const int h = (int)(idx % a.H);
+  const long bq = idx / a.H;
+  const bf16_t* op = a.o + bq * a.ldo + h * a.d;
+  const bf16_t* dp = a.dout + bq * a.ldo + h * a.d;
+  float acc = 0.f;
+  for (int e = lane; e < a.d; e += 64) acc += bf16_to_f32(op[e]) * bf16_to_f32(dp[e]);
+  acc = wave_sum(acc);
+  const int b = (int)(bq / a.Nq), q = (int)(bq % a.Nq);
+  if (lane == 0) a.delta[((long)b * a.H + h) * a.Nq + q] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------ dQ
+template <int DH, int DV>
+__global__ __launch_bounds__(256) void attn_dq_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char sK[TILE * RowPitch<DH>::value];
+  __shared__ __attribute__((aligned(16))) char sV[TILE * RowPitch<DH>::value];
+  __shared__ __attribute__((aligned(16))) char sKt[DV * PITCH_T];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * (4 * OWN) + wave * OWN;
+  const bf16_t* qp = a.q + (long)b * a.Nq * a.ldq + h * a.d;
+  const bf16_t* dop = a.dout + (long)b * a.Nq * a.ldo + h * a.d;
+  const bf16_t* kp = a.k + (long)b * a.Nk * a.ldk + h * a.d;
+  const bf16_t* vp = a.v + (long)b * a.Nk * a.ldv + h * a.d;
+  bf16x8_t qf[2][DH / 32], dof[2][DH / 32];
+  load_owner<DH>(qf, qp, a.ldq, q0, a.Nq, a.d, lane);
+  load_owner<DH>(dof, dop, a.ldo, q0, a.Nq, a.d, lane);
+  float lse2[2], dl[2];
+#pragma unroll
+  for (int of = 0; of < 2; ++of) {
+    const int row = q0 + of * 16 + (lane & 15);
+    const bool ok = row < a.Nq;
+    lse2[of] = ok ? a.lse[((long)b * a.H + h) * a.Nq + row] * LOG2E : INFINITY;
+    dl[of] = ok ? a.delta[((long)b * a.H + h) * a.Nq + row] : 0.f;
+  }
+  f32x4_t dq[DV / 16][2];
+  zero_acc(dq);
+  const float c = a.scale * LOG2E;
+  for (int kt = 0; kt < a.Nk; kt += TILE) {
+    __syncthreads();
+    stage_rows<DH>(sK, kp, a.ldk, kt, a.Nk, a.d, tid);
+    stage_rows<DH>(sV, vp, a.ldv, kt, a.Nk, a.d, tid);
+    stage_trans<DV>(sKt, kp, a.ldk, kt, a.Nk, a.d, tid);
+    __syncthreads();
+    f32x4_t s[4][2], dp[4][2];
+    zero_acc(s);
+    zero_acc(dp);
+    s_product<DH>(s, sK, qf, lane);
+    s_product<DH>(dp, sV, dof, lane);
+#pragma unroll
+    for (int sf = 0; sf < 4; ++sf)
+#pragma unroll
+      for (int of = 0; of < 2; ++of)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool valid = (kt + sf * 16 + (lane >> 4) * 4 + e) < a.Nk;
+          const float p = valid ? exp2f(s[sf][of][e] * c - lse2[of]) : 0.f;
+          s[sf][of][e] = p * (dp[sf][of][e] - dl[of]);
+        }
+    bf16x8_t pb[2][2];
+    pack_p(pb, s);
+    t_product<DV>(dq, sKt, pb, lane);
+  }
+  store_t<DV>(dq, a.dq + (long)b * a.Nq * a.ldq + h * a.d, a.ldq, q0, a.Nq, a.d, a.scale, a.scale, lane);
+}
+
+// ------------------------------------------------------------------------------------------------ dK, dV
+template <int DH, int DV>
+__global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char sQ[TILE * RowPitch<DH>::value];
+  __shared__ __attribute__((aligned(16))) char sdO[TILE * RowPitch<DH>::value];
+  __shared__ __attribute__((aligned(16))) char sQt[DV * PITCH_T];
+  __shared__ __attribute__((aligned(16))) char sdOt[DV * PITCH_T];
+  __shared__ __attribute__((aligned(16))) float sLse[TILE];
+  __shared__ __attribute__((aligned(16))) float sDelta[TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int k0 = blockIdx.x * (4 * OWN) + wave * OWN;
+  const bf16_t* qp = a.q + (long)b * a.Nq * a.ldq + h * a.d;
+  const bf16_t* dop = a.dout + (long)b * a.Nq * a.ldo + h * a.d;
+  const bf16_t* kp = a.k + (long)b * a.Nk * a.ldk + h * a.d;
+  const bf16_t* vp = a.v + (long)b * a.Nk * a.ldv + h * a.d;
+  bf16x8_t kf[2][DH / 32], vf[2][DH / 32];
+  load_owner<DH>(kf, kp, a.ldk, k0, a.Nk, a.d, lane);
+  load_owner<DH>(vf, vp, a.ldv, k0, a.Nk, a.d, lane);
+  f32x4_t dk[DV / 16][2], dv[DV / 16][2];
+  zero_acc(dk);
+  zero_acc(dv);
+  const float c = a.scale * LOG2E;
+  for (int qt = 0; qt < a.Nq; qt += TILE) {
+    __syncthreads();
+    stage_rows<DH>(sQ, qp, a.ldq, qt, a.Nq, a.d, tid);
+    stage_rows<DH>(sdO, dop, a.ldo, qt, a.Nq, a.d, tid);
+    stage_trans<DV>(sQt, qp, a.ldq, qt, a.Nq, a.d, tid);
+    stage_trans<DV>(sdOt, dop, a.ldo, qt, a.Nq, a.d, tid);
+    if (tid < TILE) {
+      const bool ok = (qt + tid) < a.Nq;
+      sLse[tid] = ok ? a.lse[((long)b * a.H + h) * a.Nq + qt + tid] * LOG2E : INFINITY;
+      sDelta[tid] = ok ? a.delta[((long)b * a.H + h) * a.Nq + qt + tid] : 0.f;
+    }
+    __syncthreads();
+    f32x4_t s[4][2], dp[4][2];
+    zero_acc(s);
+    zero_acc(dp);
+    s_product<DH>(s, sQ, kf, lane);
+    s_product<DH>(dp, sdO, vf, lane);
+    f32x4_t ds[4][2];
+#pragma unroll
+    for (int sf = 0; sf < 4; ++sf) {
+      const float4 ls = *reinterpret_cast<const float4*>(&sLse[sf * 16 + (lane >> 4) * 4]);
+      const float4 de = *reinterpret_cast<const float4*>(&sDelta[sf * 16 + (lane >> 4) * 4]);
+      const float lsv[4] = {ls.x, ls.y, ls.z, ls.w};
+      const float dev[4] = {de.x, de.y, de.z, de.w};
+#pragma unroll
+      for (int of = 0; of < 2; ++of)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p = exp2f(s[sf][of][e] * c - lsv[e]);
+          s[sf][of][e] = p;
+          ds[sf][of][e] = p * (dp[sf][of][e] - dev[e]);
+        }
+    }
+    bf16x8_t pb[2][2];
+    pack_p(pb, s);
+    t_product<DV>(dv, sdOt, pb, lane);
+    pack_p(pb, ds);
+    t_product<DV>(dk, sQt, pb, lane);
+  }
+  const long ldo_kv = (long)a.H * a.d;
+  store_t<DV>(dk, a.dk + (long)b * a.Nk * ldo_kv + h * a.d, ldo_kv, k0, a.Nk, a.d, a.scale, a.scale, lane);
+  store_t<DV>(dv, a.dv + (long)b * a.Nk * ldo_kv + h * a.d, ldo_kv, k0, a.Nk, a.d, 1.f, 1.f, lane);
+}
+
+template <int DH, int DV>
+int launch_fwd(const AttnArgs& a, hipStream_t st) {
+  dim3 grid(aql_cdiv(a.Nq, 4 * OWN), a.H, a.B);
+  hipLaunchKernelGGL((attn_fwd_kernel<DH, DV>), grid, dim3(256), 0, st, a);
+  return 0;
+}
+template <int DH, int DV>
+int launch_bwd(const AttnArgs& a, hipStream_t st) {
+  const long waves = (long)a.B * a.Nq * a.H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((attn_dq_kernel<DH, DV>), dim3(aql_cdiv(a.Nq, 4 * OWN), a.H, a.B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((attn_dkv_kernel<DH, DV>), dim3(aql_cdiv(a.Nk, 4 * OWN), a.H, a.B), dim3(256), 0, st, a);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int aql_sdpa_fwd(const bf16_t* q, long ldq, const bf16_t* k, long ldk, const bf16_t* v, long ldv, int B,
+                            int H, int Nq, int Nk, int d, float scale, bf16_t* o, long ldo, float* lse,
+                            hipStream_t stream) {
+  AQL_CHECK_ARG(q && k && v && o && lse, "aql_sdpa_fwd: null operand");
+  AQL_CHECK_ARG(d % 8 == 0 && d <= 160 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && Nk > 0,
+                "aql_sdpa_fwd: unsupported head dim %d or strides", d);
+  AttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+  a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d; a.scale = scale;
+  if (d <= 48) launch_fwd<64, 48>(a, stream);
+  else if (d <= 64) launch_fwd<64, 64>(a, stream);
+  else if (d <= 96) launch_fwd<96, 96>(a, stream);
+  else if (d <= 128) launch_fwd<128, 128>(a, stream);
+  else launch_fwd<160, 160>(a, stream);
+  AQL_CHECK_LAUNCH("aql_sdpa_fwd");
+  return AQL_OK;
+}
+
+extern "C" int aql_sdpa_bwd(const bf16_t* q, long ldq, const bf16_t* k, long ldk, const bf16_t* v, long ldv,
+                            const bf16_t* o, const bf16_t* dout, long ldo, const float* lse, float* delta, int B, int H,
+                            int Nq, int Nk, int d, float scale, bf16_t* dq, bf16_t* dk, bf16_t* dv,
+                            hipStream_t stream) {
+  AQL_CHECK_ARG(q && k && v && o && dout && lse && delta && dq && dk && dv, "aql_sdpa_bwd: null operand");
+  AQL_CHECK_ARG(d % 8 == 0 && d <= 160 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && Nk > 0,
+                "aql_sdpa_bwd: unsupported head dim %d or strides", d);
+  AttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.o = o; a.dout = dout; a.lse = const_cast<float*>(lse); a.delta = delta;
+  a.dq = dq; a.dk = dk; a.dv = dv;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+  a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d; a.scale = scale;
+  if (d <= 48) launch_bwd<64, 48>(a, stream);
+  else if (d <= 64) launch_bwd<64, 64>(a, stream);
+  else if (d <= 96) launch_bwd<96, 96>(a, stream);
+  else if (d <= 128) launch_bwd<128, 128>(a, stream);
+  else launch_bwd<160, 160>(a, stream);
+  AQL_CHECK_LAUNCH("aql_sdpa_bwd");
+  return AQL_OK;
+}

@@ -1,0 +1,384 @@
+// HBM-bound elementwise / reduction kernels of the PPFT step: GEGLU, nearest-x2 upsample backward,
+// forward-diffusion noising, MSE loss, MapperNet, SecretEncoder, LoRA weight casts, gradient-norm clip + AdamW.
+#include "aql_common.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  f[0] = bf16lo(v.x); f[1] = bf16hi(v.x); f[2] = bf16lo(v.y); f[3] = bf16hi(v.y);
+  f[4] = bf16lo(v.z); f[5] = bf16hi(v.z); f[6] = bf16lo(v.w); f[7] = bf16hi(v.w);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += sm[i];
+  __syncthreads();
+  return t;
+}
+
+// ---- GEGLU (scripts/lib/original_unet.py:727-729): out = h * gelu(g), exact erf gelu ----------------
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const bf16_t* __restrict__ in, long M, int F,
+                                                        bf16_t* __restrict__ out) {
+  const int cols = F >> 3;
+  const long n = M * cols;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x) {
+    const long m = id / cols;
+    const int c = (int)(id - m * cols) * 8;
+    float h[8], g[8], o[8];
+    unpack8(*reinterpret_cast<const uint4*>(in + m * 2 * F + c), h);
+    unpack8(*reinterpret_cast<const uint4*>(in + m * 2 * F + F + c), g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = h[j] * (0.5f * g[j] * (1.f + erff(g[j] * 0.70710678118654752f)));
+    *reinterpret_cast<uint4*>(out + m * F + c) = pack8(o);
+  }
+}
+
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ dy,
+                                                        long M, int F, bf16_t* __restrict__ din) {
+  const int cols = F >> 3;
+  const long n = M * cols;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x) {
+    const long m = id / cols;
+    const int c = (int)(id - m * cols) * 8;
+    float h[8], g[8], d[8], dh[8], dg[8];
+    unpack8(*reinterpret_cast<const uint4*>(in + m * 2 * F + c), h);
+    unpack8(*reinterpret_cast<const uint4*>(in + m * 2 * F + F + c), g);
+    unpack8(*reinterpret_cast<const uint4*>(dy + m * F + c), d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float cdf = 0.5f * (1.f + erff(g[j] * 0.70710678118654752f));
+      const float pdf = 0.3989422804014327f * __expf(-0.5f * g[j] * g[j]);
+      dh[j] = d[j] * g[j] * cdf;
+      dg[j] = d[j] * h[j] * (cdf + g[j] * pdf);
+    }
+    *reinterpret_cast<uint4*>(din + m * 2 * F + c) = pack8(dh);
+    *reinterpret_cast<uint4*>(din + m * 2 * F + F + c) = pack8(dg);
+  }
+}
+
+// ---- backward of the nearest x2 upsample folded into conv3x3: dX[b,h,w,:] = sum of the 2x2 block ------
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const bf16_t* __restrict__ du, int B, int H, int W, int C,
+                                                             bf16_t* __restrict__ dx) {
+  const int cols = C >> 3;
+  const long n = (long)B * H * W * cols;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(id % cols) * 8;
+    long p = id / cols;
+    const int w = (int)(p % W);
+    p /= W;
+    const int h = (int)(p % H);
+    const int b = (int)(p / H);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float v[8];
+        unpack8(*reinterpret_cast<const uint4*>(du + (((long)b * 2 * H + 2 * h + i) * 2 * W + 2 * w + j) * C + c), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+      }
+    *reinterpret_cast<uint4*>(dx + (((long)b * H + h) * W + w) * C + c) = pack8(acc);
+  }
+}
+
+// ---- add_noise (diffusers DDPMScheduler.add_noise via utils/cschedulers.py:15; ppft_train.py:1010-1011) -----
+// out = sqrt(acp[t]) * x + sqrt(1-acp[t]) * eps, computed in fp32, stored bf16.  Two inputs share eps and t.
+__global__ __launch_bounds__(256) void add_noise_kernel(const float* __restrict__ x0, const float* __restrict__ wm,
+                                                        const float* __restrict__ eps, const long* __restrict__ t,
+                                                        const float* __restrict__ acp, int per_sample,
+                                                        bf16_t* __restrict__ noisy, bf16_t* __restrict__ noisy_wm,
+                                                        long n) {
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(id / per_sample);
+    const float a = acp[t[b]];
+    const float sa = sqrtf(a), sb = sqrtf(1.f - a);
+    const float e = eps[id];
+    noisy[id] = f32_to_bf16(sa * x0[id] + sb * e);
+    if (noisy_wm != nullptr) noisy_wm[id] = f32_to_bf16(sa * (x0[id] + wm[id]) + sb * e);
+  }
+}
+
+// ---- MSE loss (ppft_train.py:1051): loss = mean((p-t)^2) in fp32; dpred = 2 (p-t)/n ------------------
+__global__ __launch_bounds__(256) void mse_kernel(const bf16_t* __restrict__ p, const bf16_t* __restrict__ t, long n,
+                                                  float* __restrict__ loss, bf16_t* __restrict__ dpred) {
+  __shared__ float sm[4];
+  float acc = 0.f;
+  const float k = 2.f / (float)n;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x) {
+    const float d = bf16_to_f32(p[id]) - bf16_to_f32(t[id]);
+    acc += d * d;
+    if (dpred != nullptr) dpred[id] = f32_to_bf16(k * d);
+  }
+  const float s = block_sum(acc, sm);
+  if (threadIdx.x == 0) atomicAdd(loss, s / (float)n);
+}
+
+// ---- MapperNet (utils/models.py:110-115): S = sum_i m_i E[i,:] / sqrt(bits) + 1 ---------------------
+__global__ void mapper_fwd_kernel(const float* __restrict__ msg, const float* __restrict__ E, int bits, int r,
+                                  float* __restrict__ S32, bf16_t* __restrict__ S16) {
+  const int b = blockIdx.x;
+  const float inv = rsqrtf((float)bits);
+  for (int j = threadIdx.x; j < r; j += blockDim.x) {
+    float acc = 0.f;
+    for (int i = 0; i < bits; ++i) acc += E[i * r + j] * msg[b * bits + i];
+    const float v = acc * inv + 1.f;
+    if (S32 != nullptr) S32[b * r + j] = v;
+    if (S16 != nullptr) S16[b * r + j] = f32_to_bf16(v);
+  }
+}
+// dE[i,j] += sum_b dS[b,j] * m[b,i] / sqrt(bits)
+__global__ void mapper_bwd_kernel(const float* __restrict__ msg, const float* __restrict__ dS, int nb, int bits, int r,
+                                  float* __restrict__ dE) {
+  const int i = blockIdx.x;
+  const float inv = rsqrtf((float)bits);
+  for (int j = threadIdx.x; j < r; j += blockDim.x) {
+    float acc = 0.f;
+    for (int b = 0; b < nb; ++b) acc += dS[b * r + j] * msg[b * bits + i];
+    dE[i * r + j] += acc * inv;
+  }
+}
+
+// ---- SecretEncoder (utils/models.py:57-64,74-81): Linear(bits->R*R) -> SiLU -> [1,R,R] repeated to 4 ch
+//      -> nearest x(res/R) -> conv3x3(4->4, pad 1).  (The bilinear resize to the latent size is the identity
+//      when the latent is res x res.)  Output NCHW fp32 [B,4,res,res] times `out_scale`.
+__global__ void secret_hidden_kernel(const float* __restrict__ msg, const float* __restrict__ W,
+                                     const float* __restrict__ bvec, int bits, int RR, float* __restrict__ hid) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= RR) return;
+  float acc = bvec[j];
+  for (int i = 0; i < bits; ++i) acc += W[j * bits + i] * msg[b * bits + i];
+  hid[b * RR + j] = acc / (1.f + __expf(-acc));
+}
+__global__ void secret_conv_kernel(const float* __restrict__ hid, const float* __restrict__ cw,
+                                   const float* __restrict__ cb, int R, int res, float out_scale,
+                                   float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int up = res / R;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 4 * res * res) return;
+  const int co = idx / (res * res);
+  const int y = (idx / res) % res, x = idx % res;
+  float acc = cb[co];
+  for (int kh = 0; kh < 3; ++kh)
+    for (int kw = 0; kw < 3; ++kw) {
+      const int yy = y + kh - 1, xx = x + kw - 1;
+      if (yy < 0 || xx < 0 || yy >= res || xx >= res) continue;
+      const float v = hid[b * R * R + (yy / up) * R + (xx / up)];  // same value in all 4 input channels
+      float wsum = 0.f;
+      for (int ci = 0; ci < 4; ++ci) wsum += cw[((co * 4 + ci) * 3 + kh) * 3 + kw];
+      acc += v * wsum;
+    }
+  out[(long)b * 4 * res * res + idx] = acc * out_scale;
+}
+
+// ---- LoRA master weights (fp32, [rows, cols]) -> bf16 copy and bf16 transposed copy ------------------
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ w, int rows, int cols,
+                                                             bf16_t* __restrict__ out, bf16_t* __restrict__ outT) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int r = by + i, c = bx + tx;
+    float v = 0.f;
+    if (r < rows && c < cols) {
+      v = w[(long)r * cols + c];
+      out[(long)r * cols + c] = f32_to_bf16(v);
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  if (outT != nullptr) {
+    for (int i = ty; i < 32; i += 8) {
+      const int c = bx + i, r = by + tx;
+      if (r < rows && c < cols) outT[(long)c * rows + r] = f32_to_bf16(tile[tx][i]);
+    }
+  }
+}
+
+// ---- dS[b, j] = sum_{m in sample b} dTs[m, j] * T[m, j]  (gradient of the per-message diagonal) --------
+__global__ __launch_bounds__(256) void lora_ds_kernel(const bf16_t* __restrict__ dTs, const bf16_t* __restrict__ T,
+                                                      int rows_per_sample, int r, float* __restrict__ dS) {
+  // grid: (slabs, nb); block 256 threads = (r/8 chunk columns) x row lanes; atomics into dS
+  __shared__ float acc[1024];
+  const int b = blockIdx.y;
+  const int cols = r >> 3;
+  const int rp = blockDim.x / cols;
+  const int col = threadIdx.x % cols, rr = threadIdx.x / cols;
+  const int slab_rows = (rows_per_sample + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * slab_rows, r1 = min(rows_per_sample, r0 + slab_rows);
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rr < rp) {
+    for (int m = r0 + rr; m < r1; m += rp) {
+      const long off = ((long)b * rows_per_sample + m) * r + col * 8;
+      float x[8], y[8];
+      unpack8(*reinterpret_cast<const uint4*>(dTs + off), x);
+      unpack8(*reinterpret_cast<const uint4*>(T + off), y);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += x[j] * y[j];
+    }
+  }
+  for (int i = threadIdx.x; i < r; i += blockDim.x) acc[i] = 0.f;
+  __syncthreads();
+  if (rr < rp) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(&acc[col * 8 + j], a[j]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < r; i += blockDim.x) atomicAdd(&dS[b * r + i], acc[i]);
+}
+
+// ---- global grad-norm clip + AdamW on flat fp32 buffers (ppft_train.py:1059-1068, 779-787) -----------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+  __shared__ float sm[4];
+  float acc = 0.f;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x)
+    acc += g[id] * g[id];
+  const float s = block_sum(acc, sm);
+  if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+// torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (norm + 1e-6)); torch.optim.AdamW (decoupled decay).
+// `sumsq` may be null (no clipping, e.g. the MapperNet group).  step is the 1-based step count.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, long n,
+                                                    const float* __restrict__ sumsq, float max_norm,
+                                                    const float* __restrict__ lr_ptr, float beta1, float beta2,
+                                                    float eps, float wd, const int* __restrict__ step_ptr) {
+  float coef = 1.f;
+  if (sumsq != nullptr) {
+    const float norm = sqrtf(*sumsq);
+    coef = fminf(1.f, max_norm / (norm + 1e-6f));
+  }
+  const float lr = *lr_ptr;
+  const float step = (float)(*step_ptr);
+  const float bc1 = 1.f - powf(beta1, step), bc2 = 1.f - powf(beta2, step);
+  const float step_size = lr / bc1;
+  const float rbc2 = rsqrtf(bc2);
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x) {
+    const float gr = g[id] * coef;
+    float w = p[id];
+    w *= (1.f - lr * wd);
+    const float mm = beta1 * m[id] + (1.f - beta1) * gr;
+    const float vv = beta2 * v[id] + (1.f - beta2) * gr * gr;
+    m[id] = mm;
+    v[id] = vv;
+    const float denom = sqrtf(vv) * rbc2 + eps;
+    p[id] = w - step_size * (mm / denom);
+  }
+}
+
+inline int grid_for(long n, int per = 256, int cap = 2048) {
+  long b = (n + per - 1) / per;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int aql_geglu_fwd(const bf16_t* in, long M, int F, bf16_t* out, hipStream_t stream) {
+  AQL_CHECK_ARG(in && out && F % 8 == 0, "aql_geglu_fwd: bad args");
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(grid_for(M * (F / 8))), dim3(256), 0, stream, in, M, F, out);
+  AQL_CHECK_LAUNCH("aql_geglu_fwd");
+  return AQL_OK;
+}
+extern "C" int aql_geglu_bwd(const bf16_t* in, const bf16_t* dy, long M, int F, bf16_t* din, hipStream_t stream) {
+  AQL_CHECK_ARG(in && dy && din && F % 8 == 0, "aql_geglu_bwd: bad args");
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid_for(M * (F / 8))), dim3(256), 0, stream, in, dy, M, F, din);
+  AQL_CHECK_LAUNCH("aql_geglu_bwd");
+  return AQL_OK;
+}
+extern "C" int aql_upsample2x_bwd(const bf16_t* du, int B, int H, int W, int C, bf16_t* dx, hipStream_t stream) {
+  AQL_CHECK_ARG(du && dx && C % 8 == 0, "aql_upsample2x_bwd: bad args");
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for((long)B * H * W * (C / 8))), dim3(256), 0, stream, du, B, H,
+                     W, C, dx);
+  AQL_CHECK_LAUNCH("aql_upsample2x_bwd");
+  return AQL_OK;
+}
+extern "C" int aql_add_noise(const float* x0, const float* wm, const float* eps, const long* t, const float* acp,
+                             int B, int per_sample, bf16_t* noisy, bf16_t* noisy_wm, hipStream_t stream) {
+  AQL_CHECK_ARG(x0 && eps && t && acp && noisy && (wm != nullptr || noisy_wm == nullptr), "aql_add_noise: bad args");
+  const long n = (long)B * per_sample;
+  hipLaunchKernelGGL(add_noise_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x0, wm, eps, t, acp, per_sample, noisy,
+                     noisy_wm, n);
+  AQL_CHECK_LAUNCH("aql_add_noise");
+  return AQL_OK;
+}
+extern "C" int aql_mse_fwd_bwd(const bf16_t* pred, const bf16_t* target, long n, float* loss, bf16_t* dpred,
+                               hipStream_t stream) {
+  AQL_CHECK_ARG(pred && target && loss, "aql_mse_fwd_bwd: bad args");
+  hipMemsetAsync(loss, 0, sizeof(float), stream);
+  hipLaunchKernelGGL(mse_kernel, dim3(grid_for(n, 256, 256)), dim3(256), 0, stream, pred, target, n, loss, dpred);
+  AQL_CHECK_LAUNCH("aql_mse_fwd_bwd");
+  return AQL_OK;
+}
+extern "C" int aql_mapper_fwd(const float* msg, const float* E, int nb, int bits, int r, float* S32, bf16_t* S16,
+                              hipStream_t stream) {
+  AQL_CHECK_ARG(msg && E && (S32 || S16), "aql_mapper_fwd: bad args");
+  hipLaunchKernelGGL(mapper_fwd_kernel, dim3(nb), dim3(256), 0, stream, msg, E, bits, r, S32, S16);
+  AQL_CHECK_LAUNCH("aql_mapper_fwd");
+  return AQL_OK;
+}
+extern "C" int aql_mapper_bwd(const float* msg, const float* dS, int nb, int bits, int r, float* dE,
+                              hipStream_t stream) {
+  AQL_CHECK_ARG(msg && dS && dE, "aql_mapper_bwd: bad args");
+  hipLaunchKernelGGL(mapper_bwd_kernel, dim3(bits), dim3(256), 0, stream, msg, dS, nb, bits, r, dE);
+  AQL_CHECK_LAUNCH("aql_mapper_bwd");
+  return AQL_OK;
+}
+extern "C" int aql_secret_encoder_fwd(const float* msg, const float* lin_w, const float* lin_b, const float* conv_w,
+                                      const float* conv_b, int nb, int bits, int base_res, int res, float out_scale,
+                                      float* hidden_scratch, float* out, hipStream_t stream) {
+  AQL_CHECK_ARG(msg && lin_w && lin_b && conv_w && conv_b && hidden_scratch && out, "aql_secret_encoder_fwd: null");
+  AQL_CHECK_ARG(res % base_res == 0, "aql_secret_encoder_fwd: res must be a multiple of base_res");
+  const int RR = base_res * base_res;
+  hipLaunchKernelGGL(secret_hidden_kernel, dim3((RR + 255) / 256, nb), dim3(256), 0, stream, msg, lin_w, lin_b, bits, RR,
+                     hidden_scratch);
+  hipLaunchKernelGGL(secret_conv_kernel, dim3((4 * res * res + 255) / 256, nb), dim3(256), 0, stream, hidden_scratch,
+                     conv_w, conv_b, base_res, res, out_scale, out);
+  AQL_CHECK_LAUNCH("aql_secret_encoder_fwd");
+  return AQL_OK;
+}
+extern "C" int aql_cast_transpose(const float* w, int rows, int cols, bf16_t* out, bf16_t* outT, hipStream_t stream) {
+  AQL_CHECK_ARG(w && out, "aql_cast_transpose: bad args");
+  hipLaunchKernelGGL(cast_transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, stream, w, rows,
+                     cols, out, outT);
+  AQL_CHECK_LAUNCH("aql_cast_transpose");
+  return AQL_OK;
+}
+extern "C" int aql_lora_ds(const bf16_t* dTs, const bf16_t* T, int nb, int rows_per_sample, int r, float* dS,
+                           hipStream_t stream) {
+  AQL_CHECK_ARG(dTs && T && dS && r % 8 == 0 && r <= 1024, "aql_lora_ds: bad args (r=%d)", r);
+  const int cols = r / 8;
+  const int threads = cols * (256 / cols > 0 ? 256 / cols : 1);
+  int slabs = (rows_per_sample + 255) / 256;
+  if (slabs > 32) slabs = 32;
+  hipLaunchKernelGGL(lora_ds_kernel, dim3(slabs, nb), dim3(threads), 0, stream, dTs, T, rows_per_sample, r, dS);
+  AQL_CHECK_LAUNCH("aql_lora_ds");
+  return AQL_OK;
+}
+extern "C" int aql_sumsq_f32(const float* g, long n, float* out, hipStream_t stream) {
+  AQL_CHECK_ARG(g && out, "aql_sumsq_f32: bad args");
+  hipMemsetAsync(out, 0, sizeof(float), stream);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 1024, 1024)), dim3(256), 0, stream, g, n, out);
+  AQL_CHECK_LAUNCH("aql_sumsq_f32");
+  return AQL_OK;
+}
+extern "C" int aql_clipnorm_adamw(float* p, const float* g, float* m, float* v, long n, const float* sumsq,
+                                  float max_norm, const float* lr, float beta1, float beta2, float eps, float wd,
+                                  const int* step, hipStream_t stream) {
+  AQL_CHECK_ARG(p && g && m && v && lr && step, "aql_clipnorm_adamw: bad args");
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 1024, 2048)), dim3(256), 0, stream, p, g, m, v, n, sumsq, max_norm,
+                     lr, beta1, beta2, eps, wd, step);
+  AQL_CHECK_LAUNCH("aql_clipnorm_adamw");
+  return AQL_OK;
+}

@@ -1,0 +1,352 @@
+"""torch.autograd.Function wrappers over the gfx950 C-ABI kernels.
+
+Conventions
+  * activations are bf16; 4-D tensors are logical NCHW with ``channels_last`` strides (physically NHWC), so a
+    feature map [B,C,H,W] and its token view [B,H*W,C] share memory and no permute kernel ever runs;
+  * frozen base weights are pre-packed once per host module (``pack_linear`` / ``pack_conv3x3``);
+  * LoRA weight gradients are accumulated straight into the flat fp32 gradient buffer owned by
+    ``aqualora_amd.lora.LoraBank`` (the Function returns ``None`` for them), the gradient of the per-message
+    diagonal ``S`` is returned through autograd so that it reaches MapperNet.
+Every function here requires a CUDA(HIP) tensor and the built shared library: there is no fallback.
+"""
+import torch
+
+from . import _lib as L
+
+CL = torch.channels_last
+_WS = {}
+_GN = {}
+
+
+def workspace(device, nfloats=64 << 20):
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nfloats:
+        ws = torch.empty(nfloats, dtype=torch.float32, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def _gn_scratch(device, B):
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    t = _GN.get(key)
+    need = B * 64 * 32 * 2 + B * 32 * 2
+    if t is None or t.numel() < need:
+        t = torch.empty(max(need, 1 << 16), dtype=torch.float32, device=device)
+        _GN[key] = t
+    return t
+
+
+def _req(t, name):
+    if not t.is_cuda:
+        raise L.AqlError(f"{name}: the HIP path needs a GPU tensor (got {t.device}); there is no CPU fallback")
+    return t
+
+
+def as_cl(x):
+    """Logical NCHW -> channels_last storage (no-op when already so)."""
+    return x.contiguous(memory_format=CL)
+
+
+def nhwc_view(x):
+    return x.permute(0, 2, 3, 1)
+
+
+# --------------------------------------------------------------------------------------------- packing
+class PackedLinear:
+    """bf16 kernel-layout copies of a frozen nn.Linear / 1x1 conv: W [N,K], W^T [K,N], bias [N]."""
+
+    def __init__(self, weight, bias):
+        w = weight.detach().reshape(weight.shape[0], -1)
+        self.N, self.K = w.shape
+        self.w = w.to(torch.bfloat16).contiguous()
+        self.wt = self.w.t().contiguous()
+        self.bias = None if bias is None else bias.detach().to(torch.bfloat16).contiguous()
+
+
+class PackedConv3x3:
+    """Wk [Cout, 9*Cin] (tap-major, channel-minor) for forward, Wt [Cin, 9*Cout] for backward-data."""
+
+    def __init__(self, weight, bias, stride):
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        self.Cin_real = Cin
+        w = weight.detach().to(torch.bfloat16)
+        if Cin % 8 != 0:  # conv_in: pad input channels with zeros
+            pad = 8 - Cin % 8
+            w = torch.cat([w, w.new_zeros(Cout, pad, 3, 3)], dim=1)
+            Cin += pad
+        self.Cout_real = Cout
+        if Cout % 8 != 0:  # conv_out: pad output channels with zeros
+            pad = 8 - Cout % 8
+            w = torch.cat([w, w.new_zeros(pad, Cin, 3, 3)], dim=0)
+            bias = None if bias is None else torch.cat([bias.detach(), bias.new_zeros(pad)])
+            Cout += pad
+        self.Cin, self.Cout, self.stride = Cin, Cout, int(stride)
+        self.wk = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+        self.wt = w.permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous()
+        self.bias = None if bias is None else bias.detach().to(torch.bfloat16).contiguous()
+
+
+# ------------------------------------------------------------------------------------- low-level calls
+def gemm_bf16(A, B, bias=None, A2=None, B2=None, rowbias=None, rps=1, residual=None, out=None):
+    """C[M,N] = A[M,K].B[N,K]^T (+A2.B2^T) + bias + rowbias[m//rps] + residual, bf16 with fp32 accumulation."""
+    M, K = A.shape
+    N = B.shape[0]
+    C = out if out is not None else torch.empty(M, N, dtype=torch.bfloat16, device=A.device)
+    ws = workspace(A.device)
+    L.call("aql_gemm_bf16", L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), M, N, K,
+           L.ptr(A2), 0 if A2 is None else A2.stride(0), L.ptr(B2), 0 if B2 is None else B2.stride(0),
+           0 if A2 is None else A2.shape[1], L.ptr(bias), L.ptr(rowbias), rps,
+           L.ptr(residual), 0 if residual is None else residual.stride(0), L.ptr(C), C.stride(0),
+           L.ptr(ws), ws.numel() * 4, L.stream_ptr())
+    return C
+
+
+def gemm_tn_acc(U, V, C, alpha=1.0):
+    """C[P,Q] (fp32) += alpha * U[M,P]^T V[M,Q]."""
+    M, P = U.shape
+    Q = V.shape[1]
+    L.call("aql_gemm_tn_f32", L.ptr(U), U.stride(0), L.ptr(V), V.stride(0), M, P, Q, float(alpha), L.ptr(C),
+           C.stride(0), L.stream_ptr())
+
+
+# ------------------------------------------------------------------------------------ fused LoRA linear
+class LoraLinearFn(torch.autograd.Function):
+    """Y = X.W^T + b [+ ((X.A^T) * S[sample]).Bup^T] [+ residual]   on token-major X [M,K].
+
+    Replaces CustomLoRACompatibleLinearforward + CustomLoRALinearLayerforward (reference
+    utils/lora_modules.py:56-62, 9-26) and, for 1x1 convolutions on channels-last maps, the conv pair
+    (:46-54, 28-44).  ``site`` is a lora.LoraSite (bf16 A, A^T, Bup, Bup^T and fp32 grad views) or None.
+    """
+
+    @staticmethod
+    def forward(ctx, x2d, packed, site, S16, rps, residual):
+        _req(x2d, "lora_linear")
+        M = x2d.shape[0]
+        ctx.packed, ctx.site, ctx.rps = packed, site, rps
+        ctx.has_res = residual is not None
+        use_lora = site is not None and S16 is not None
+        ctx.use_lora = use_lora
+        T = Ts = None
+        if use_lora:
+            r = site.rank
+            T = torch.empty(M, r, dtype=torch.bfloat16, device=x2d.device)
+            Ts = torch.empty_like(T)
+            L.call("aql_lora_down", L.ptr(x2d), x2d.stride(0), M, packed.K, L.ptr(site.a16), r, L.ptr(S16), rps,
+                   L.ptr(T), L.ptr(Ts), L.stream_ptr())
+            y = gemm_bf16(x2d, packed.w, packed.bias, Ts, site.b16, residual=residual)
+            ctx.save_for_backward(x2d, T, Ts, S16)
+        else:
+            y = gemm_bf16(x2d, packed.w, packed.bias, residual=residual)
+            ctx.save_for_backward(x2d)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        packed, site = ctx.packed, ctx.site
+        M = dy.shape[0]
+        dS = None
+        if ctx.use_lora:
+            x2d, T, Ts, S16 = ctx.saved_tensors
+            r = site.rank
+            # dTs = dY.Bup  (and dT = dTs * S) -- same two-output epilogue as the forward "down" GEMM
+            dTs = torch.empty(M, r, dtype=torch.bfloat16, device=dy.device)
+            dT = torch.empty_like(dTs)
+            L.call("aql_lora_down", L.ptr(dy), dy.stride(0), M, packed.N, L.ptr(site.bt16), r, L.ptr(S16), ctx.rps,
+                   L.ptr(dTs), L.ptr(dT), L.stream_ptr())
+            dx = gemm_bf16(dy, packed.wt, None, dT, site.at16) if ctx.needs_input_grad[0] else None
+            gemm_tn_acc(dy, Ts, site.gb)   # dBup[N,r] += dY^T Ts
+            gemm_tn_acc(dT, x2d, site.ga)  # dA[r,K]  += dT^T X
+            nb = S16.shape[0]
+            dS = torch.zeros(nb, r, dtype=torch.float32, device=dy.device)
+            L.call("aql_lora_ds", L.ptr(dTs), L.ptr(T), nb, ctx.rps, r, L.ptr(dS), L.stream_ptr())
+            if not ctx.needs_input_grad[3]:
+                dS = None
+        else:
+            dx = gemm_bf16(dy, packed.wt) if ctx.needs_input_grad[0] else None
+        return dx, None, None, dS, None, (dy if ctx.has_res else None)
+
+
+def lora_linear(x2d, packed, site=None, S16=None, rps=1, residual=None):
+    return LoraLinearFn.apply(x2d, packed, site, S16, rps, residual)
+
+
+# --------------------------------------------------------------------------------------------- conv 3x3
+class Conv3x3Fn(torch.autograd.Function):
+    """3x3 conv, pad 1, stride 1|2, optional nearest x2 upsample folded into the gather; channels-last bf16.
+    Optional per-sample row bias (the ResNet time-embedding add) and residual fused into the epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, packed, upsample, rowbias, residual):
+        _req(x, "conv3x3")
+        x = as_cl(x)
+        B, C, H, W = x.shape
+        if C != packed.Cin:  # conv_in: zero-pad channels to the packed width
+            xp = x.new_zeros((B, packed.Cin, H, W)).contiguous(memory_format=CL)
+            xp[:, :C] = x
+            x = xp
+        Hl, Wl = (H * 2, W * 2) if upsample else (H, W)
+        Ho = (Hl + 2 - 3) // packed.stride + 1
+        Wo = (Wl + 2 - 3) // packed.stride + 1
+        y = torch.empty((B, packed.Cout, Ho, Wo), dtype=torch.bfloat16, device=x.device, memory_format=CL)
+        ws = workspace(x.device)
+        res = None if residual is None else as_cl(residual)
+        L.call("aql_conv3x3_fwd", L.ptr(x), B, H, W, packed.Cin, L.ptr(packed.wk), L.ptr(packed.bias), packed.Cout,
+               packed.stride, int(upsample), L.ptr(rowbias), L.ptr(res), L.ptr(y), L.ptr(ws), ws.numel() * 4,
+               L.stream_ptr())
+        ctx.packed, ctx.upsample, ctx.in_shape, ctx.c_in = packed, upsample, (B, H, W), C
+        ctx.has_rb, ctx.has_res = rowbias is not None, residual is not None
+        if packed.Cout_real != packed.Cout:
+            y = y[:, :packed.Cout_real]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        packed = ctx.packed
+        B, H, W = ctx.in_shape
+        if packed.Cout_real != packed.Cout:
+            dyp = dy.new_zeros((B, packed.Cout, dy.shape[2], dy.shape[3])).contiguous(memory_format=CL)
+            dyp[:, :packed.Cout_real] = dy
+            dy = dyp
+        dy = as_cl(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            Hl, Wl = (H * 2, W * 2) if ctx.upsample else (H, W)
+            ws = workspace(dy.device)
+            du = torch.empty((B, packed.Cin, Hl, Wl), dtype=torch.bfloat16, device=dy.device, memory_format=CL)
+            L.call("aql_conv3x3_bwd_data", L.ptr(dy), B, Hl, Wl, packed.Cin, L.ptr(packed.wt), packed.Cout,
+                   packed.stride, L.ptr(du), L.ptr(ws), ws.numel() * 4, L.stream_ptr())
+            if ctx.upsample:
+                dx = torch.empty((B, packed.Cin, H, W), dtype=torch.bfloat16, device=dy.device, memory_format=CL)
+                L.call("aql_upsample2x_bwd", L.ptr(du), B, H, W, packed.Cin, L.ptr(dx), L.stream_ptr())
+            else:
+                dx = du
+            if ctx.c_in != packed.Cin:
+                dx = dx[:, :ctx.c_in]
+        drb = None
+        if ctx.has_rb and ctx.needs_input_grad[3]:
+            drb = dy.float().sum(dim=(2, 3)).to(torch.bfloat16)
+        return dx, None, None, drb, (dy if ctx.has_res else None)
+
+
+def conv3x3(x, packed, upsample=False, rowbias=None, residual=None):
+    return Conv3x3Fn.apply(x, packed, upsample, rowbias, residual)
+
+
+# ------------------------------------------------------------------------------------------- norms
+class GroupNormSiluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, silu):
+        _req(x, "groupnorm")
+        x = as_cl(x)
+        B, C, H, W = x.shape
+        y = torch.empty_like(x, memory_format=CL)
+        stats = torch.empty(B, 32, 2, dtype=torch.float32, device=x.device)
+        L.call("aql_groupnorm_silu_fwd", L.ptr(x), B, H * W, C, L.ptr(gamma), L.ptr(beta), float(eps), int(silu),
+               L.ptr(y), L.ptr(stats), L.ptr(_gn_scratch(x.device, B)), L.stream_ptr())
+        ctx.save_for_backward(x, gamma, beta, stats)
+        ctx.silu = silu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats = ctx.saved_tensors
+        dy = as_cl(dy)
+        B, C, H, W = x.shape
+        dx = torch.empty_like(x, memory_format=CL)
+        L.call("aql_groupnorm_silu_bwd", L.ptr(x), L.ptr(dy), B, H * W, C, L.ptr(gamma), L.ptr(beta), int(ctx.silu),
+               L.ptr(stats), L.ptr(dx), L.ptr(_gn_scratch(x.device, B)), L.stream_ptr())
+        return dx, None, None, None, None
+
+
+def groupnorm_silu(x, gamma, beta, eps, silu):
+    return GroupNormSiluFn.apply(x, gamma, beta, eps, silu)
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x2d, gamma, beta, eps):
+        _req(x2d, "layernorm")
+        M, C = x2d.shape
+        y = torch.empty_like(x2d)
+        stats = torch.empty(M, 2, dtype=torch.float32, device=x2d.device)
+        L.call("aql_layernorm_fwd", L.ptr(x2d), M, C, L.ptr(gamma), L.ptr(beta), float(eps), L.ptr(y), L.ptr(stats),
+               L.stream_ptr())
+        ctx.save_for_backward(x2d, gamma, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, gamma, stats = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, C = x2d.shape
+        dx = torch.empty_like(x2d)
+        L.call("aql_layernorm_bwd", L.ptr(x2d), L.ptr(dy), M, C, L.ptr(gamma), L.ptr(stats), L.ptr(dx), L.stream_ptr())
+        return dx, None, None, None
+
+
+def layernorm(x2d, gamma, beta, eps=1e-5):
+    return LayerNormFn.apply(x2d, gamma, beta, eps)
+
+
+class GegluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h2d):
+        _req(h2d, "geglu")
+        M, F2 = h2d.shape
+        out = torch.empty(M, F2 // 2, dtype=torch.bfloat16, device=h2d.device)
+        L.call("aql_geglu_fwd", L.ptr(h2d), M, F2 // 2, L.ptr(out), L.stream_ptr())
+        ctx.save_for_backward(h2d)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (h2d,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, F2 = h2d.shape
+        din = torch.empty_like(h2d)
+        L.call("aql_geglu_bwd", L.ptr(h2d), L.ptr(dy), M, F2 // 2, L.ptr(din), L.stream_ptr())
+        return din
+
+
+def geglu(h2d):
+    return GegluFn.apply(h2d)
+
+
+# --------------------------------------------------------------------------------------- attention
+class AttentionFn(torch.autograd.Function):
+    """softmax(Q K^T / sqrt(d)) V over heads packed along the channel axis: q [B,Nq,H*d], k/v [B,Nk,H*d]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads):
+        _req(q, "attention")
+        B, Nq, C = q.shape
+        Nk = k.shape[1]
+        d = C // heads
+        o = torch.empty_like(q)
+        lse = torch.empty(B, heads, Nq, dtype=torch.float32, device=q.device)
+        L.call("aql_sdpa_fwd", L.ptr(q), q.stride(1), L.ptr(k), k.stride(1), L.ptr(v), v.stride(1), B, heads, Nq, Nk,
+               d, float(d ** -0.5), L.ptr(o), o.stride(1), L.ptr(lse), L.stream_ptr())
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.heads = heads
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        do = do.contiguous()
+        B, Nq, C = q.shape
+        Nk = k.shape[1]
+        heads = ctx.heads
+        d = C // heads
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        delta = torch.empty(B, heads, Nq, dtype=torch.float32, device=q.device)
+        L.call("aql_sdpa_bwd", L.ptr(q), q.stride(1), L.ptr(k), k.stride(1), L.ptr(v), v.stride(1), L.ptr(o),
+               L.ptr(do), o.stride(1), L.ptr(lse), L.ptr(delta), B, heads, Nq, Nk, d, float(d ** -0.5),
+               L.ptr(dq), L.ptr(dk), L.ptr(dv), L.stream_ptr())
+        return dq, dk, dv, None
+
+
+def attention(q, k, v, heads):
+    return AttentionFn.apply(q, k, v, heads)
