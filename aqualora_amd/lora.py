@@ -1,0 +1,348 @@
+"""The watermark-LoRA plug-in surface, MI355X-native.
+
+Mirrors, name for name, what the reference monkey-patches onto diffusers 0.24 modules:
+
+  reference (utils/lora_modules.py)              here (HIP-backed, same signature and semantics)
+  CustomLoRALinearLayerforward        :9-26      CustomLoRALinearLayerforward
+  CustomLoRAConv2dLayerforward        :28-44     CustomLoRAConv2dLayerforward
+  CustomLoRACompatibleConvforward     :46-54     CustomLoRACompatibleConvforward
+  CustomLoRACompatibleLinearforward   :56-62     CustomLoRACompatibleLinearforward
+
+plus light-weight twins of the diffusers host / LoRA layer classes (``LoRACompatibleLinear``,
+``LoRACompatibleConv``, ``LoRALinearLayer``, ``LoRAConv2dLayer``; diffusers is not installed on the target
+image) and the injection / patch loops of train/ppft_train.py:620-689 (``inject_lora``, ``patch_lora_forwards``).
+
+``scale`` follows the reference: a float multiplies the LoRA branch, a ``[B, r]`` tensor is the per-message
+diagonal S (``B.diag(S).A``).  ``scale=None`` is an extension: skip the LoRA branch (bit-identical to the
+reference's all-zero scale of the "clean" pass, ppft_train.py:1026-1029, without spending the FLOPs).
+The fused host forwards also accept ``residual=`` (added in the GEMM epilogue).
+"""
+import types
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+# ----------------------------------------------------------------------------- diffusers-compatible classes
+class LoRALinearLayer(nn.Module):
+    """down: Linear(in, rank, bias=False) ~ N(0, 1/rank); up: Linear(rank, out, bias=False) = 0 (diffusers 0.24)."""
+
+    def __init__(self, in_features, out_features, rank=4, network_alpha=None, device=None, dtype=None):
+        super().__init__()
+        self.down = nn.Linear(in_features, rank, bias=False, device=device, dtype=dtype)
+        self.up = nn.Linear(rank, out_features, bias=False, device=device, dtype=dtype)
+        self.network_alpha = network_alpha
+        self.rank = rank
+        self.in_features = in_features
+        self.out_features = out_features
+        nn.init.normal_(self.down.weight, std=1 / rank)
+        nn.init.zeros_(self.up.weight)
+
+    def forward(self, hidden_states, scale=1.0):
+        return CustomLoRALinearLayerforward(self, hidden_states, scale)
+
+
+class LoRAConv2dLayer(nn.Module):
+    def __init__(self, in_features, out_features, rank=4, kernel_size=(1, 1), stride=(1, 1), padding=0,
+                 network_alpha=None):
+        super().__init__()
+        self.down = nn.Conv2d(in_features, rank, kernel_size=kernel_size, stride=stride, padding=padding, bias=False)
+        self.up = nn.Conv2d(rank, out_features, kernel_size=(1, 1), stride=(1, 1), bias=False)
+        self.network_alpha = network_alpha
+        self.rank = rank
+        nn.init.normal_(self.down.weight, std=1 / rank)
+        nn.init.zeros_(self.up.weight)
+
+    def forward(self, hidden_states, scale=1.0):
+        return CustomLoRAConv2dLayerforward(self, hidden_states, scale)
+
+
+class LoRACompatibleLinear(nn.Linear):
+    def __init__(self, *args, lora_layer=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.lora_layer = lora_layer
+
+    def set_lora_layer(self, lora_layer):
+        self.lora_layer = lora_layer
+
+    def forward(self, hidden_states, scale=1.0, residual=None):
+        return CustomLoRACompatibleLinearforward(self, hidden_states, scale, residual=residual)
+
+
+class LoRACompatibleConv(nn.Conv2d):
+    def __init__(self, *args, lora_layer=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.lora_layer = lora_layer
+
+    def set_lora_layer(self, lora_layer):
+        self.lora_layer = lora_layer
+
+    def forward(self, hidden_states, scale=1.0, residual=None):
+        return CustomLoRACompatibleConvforward(self, hidden_states, scale, residual=residual)
+
+
+# --------------------------------------------------------------------------------------------- LoRA sites
+class LoraSite:
+    """Compute-side state of one LoRA layer: bf16 A [r,K], A^T, Bup [N,r], Bup^T and fp32 gradient views."""
+
+    def __init__(self, layer):
+        self.layer = layer
+        self.rank = layer.rank
+        self.managed = False  # True when a LoraBank owns storage and refreshes the bf16 copies itself
+        self._ver = (-1, -1)
+        self.a16 = self.at16 = self.b16 = self.bt16 = None
+
+    def _pd(self):
+        return self.layer.down.weight, self.layer.up.weight
+
+    def refresh(self, force=False):
+        down, up = self._pd()
+        if not down.is_cuda:
+            raise ops.L.AqlError("watermark LoRA weights must live on the GPU: the HIP path has no CPU fallback")
+        ver = (down._version, up._version)
+        if not force and (self.managed or ver == self._ver) and self.a16 is not None:
+            return
+        r = self.rank
+        K = down.numel() // r
+        N = up.numel() // r
+        if self.a16 is None:
+            dev = down.device
+            self.a16 = torch.empty(r, K, dtype=torch.bfloat16, device=dev)
+            self.at16 = torch.empty(K, r, dtype=torch.bfloat16, device=dev)
+            self.b16 = torch.empty(N, r, dtype=torch.bfloat16, device=dev)
+            self.bt16 = torch.empty(r, N, dtype=torch.bfloat16, device=dev)
+        d32 = down.detach().float().reshape(r, K).contiguous()
+        u32 = up.detach().float().reshape(N, r).contiguous()
+        L = ops.L
+        L.call("aql_cast_transpose", L.ptr(d32), r, K, L.ptr(self.a16), L.ptr(self.at16), L.stream_ptr())
+        L.call("aql_cast_transpose", L.ptr(u32), N, r, L.ptr(self.b16), L.ptr(self.bt16), L.stream_ptr())
+        self._ver = ver
+
+    @property
+    def ga(self):
+        down = self.layer.down.weight
+        if down.grad is None:
+            down.grad = torch.zeros_like(down, dtype=torch.float32)
+        return down.grad.view(self.rank, -1)
+
+    @property
+    def gb(self):
+        up = self.layer.up.weight
+        if up.grad is None:
+            up.grad = torch.zeros_like(up, dtype=torch.float32)
+        return up.grad.view(-1, self.rank)
+
+
+def _site_of(layer):
+    site = getattr(layer, "_aql_site", None)
+    if site is None:
+        site = LoraSite(layer)
+        object.__setattr__(layer, "_aql_site", site)
+    site.refresh()
+    return site
+
+
+def _packed_linear(mod):
+    pk = getattr(mod, "_aql_packed", None)
+    if pk is None:
+        pk = ops.PackedLinear(mod.weight, mod.bias)
+        object.__setattr__(mod, "_aql_packed", pk)
+    return pk
+
+
+def _packed_conv3(mod):
+    pk = getattr(mod, "_aql_packed", None)
+    if pk is None:
+        pk = ops.PackedConv3x3(mod.weight, mod.bias, mod.stride[0])
+        object.__setattr__(mod, "_aql_packed", pk)
+    return pk
+
+
+def _scale16(scale, nb, r, device):
+    """-> (bf16 [nb, r] tensor or None, fp32 tensor that carries grad or None)."""
+    if scale is None:
+        return None
+    if isinstance(scale, torch.Tensor):
+        if scale.dim() != 2 or scale.shape[1] != r:
+            raise ValueError(f"scale must be [batch, rank={r}], got {tuple(scale.shape)}")
+        if scale.shape[0] != nb:
+            scale = scale.expand(nb, r)
+        return scale
+    return torch.full((nb, r), float(scale), dtype=torch.bfloat16, device=device)
+
+
+def _run_linear(x2d, packed, lora_layer, scale, nb, rps, residual):
+    site = S = S16 = None
+    if lora_layer is not None and scale is not None:
+        if getattr(lora_layer, "network_alpha", None) is not None:
+            raise NotImplementedError("network_alpha is always None on the PPFT path (ppft_train.py:662-666)")
+        site = _site_of(lora_layer)
+        S = _scale16(scale, nb, site.rank, x2d.device)
+        S16 = getattr(S, "_aql_s16", None)  # bf16 copy made once per scale tensor, shared by all 192 sites
+        if S16 is None:
+            S16 = S.detach().to(torch.bfloat16).contiguous()
+            S._aql_s16 = S16
+    return ops.lora_linear(x2d, packed, site, S, S16, rps, residual)
+
+
+# ------------------------------------------------------------------------------------ the four forwards
+def CustomLoRACompatibleLinearforward(self, hidden_states, scale=1.0, residual=None):
+    """nn.Linear.forward(x) [+ lora_layer(x, scale)]  -- one fused MFMA GEMM (reference lora_modules.py:56-62)."""
+    shp = hidden_states.shape
+    x2d = hidden_states.reshape(-1, shp[-1])
+    if x2d.dtype != torch.bfloat16:
+        x2d = x2d.to(torch.bfloat16)
+    x2d = x2d.contiguous()
+    nb = shp[0] if hidden_states.dim() >= 2 else 1
+    rps = x2d.shape[0] // nb
+    res2d = None if residual is None else residual.reshape(-1, self.out_features).contiguous()
+    y = _run_linear(x2d, _packed_linear(self), self.lora_layer, scale, nb, rps, res2d)
+    return y.reshape(*shp[:-1], self.out_features)
+
+
+def CustomLoRACompatibleConvforward(self, hidden_states, scale=1.0, residual=None):
+    """Conv2d [+ lora_layer(x, scale)] (reference lora_modules.py:46-54).  1x1 convs run as the fused LoRA GEMM on
+    the channels-last token view; 3x3/pad-1 convs (never LoRA'd in unet_keys.json) run the implicit-GEMM kernel."""
+    k = self.kernel_size
+    if k == (1, 1) and self.stride == (1, 1) and self.padding in ((0, 0), 0):
+        x = ops.as_cl(hidden_states if hidden_states.dtype == torch.bfloat16 else hidden_states.to(torch.bfloat16))
+        B, C, H, W = x.shape
+        x2d = ops.nhwc_view(x).reshape(B * H * W, C)
+        res2d = None if residual is None else ops.nhwc_view(ops.as_cl(residual)).reshape(B * H * W, self.out_channels)
+        y = _run_linear(x2d, _packed_linear(self), self.lora_layer, scale, B, H * W, res2d)
+        return y.view(B, H, W, self.out_channels).permute(0, 3, 1, 2)
+    if k == (3, 3) and self.padding in ((1, 1), 1) and self.stride in ((1, 1), (2, 2)) and self.lora_layer is None:
+        x = hidden_states if hidden_states.dtype == torch.bfloat16 else hidden_states.to(torch.bfloat16)
+        return ops.conv3x3(x, _packed_conv3(self), False, None, residual)
+    raise NotImplementedError(f"conv geometry k={k} stride={self.stride} pad={self.padding} "
+                              f"lora={self.lora_layer is not None} is not on the PPFT path")
+
+
+def CustomLoRALinearLayerforward(self, hidden_states, scale=1.0):
+    """up(down(x) @ diag_embed(scale)) -- the LoRA branch alone (reference lora_modules.py:9-26)."""
+    shp = hidden_states.shape
+    orig = hidden_states.dtype
+    x2d = hidden_states.reshape(-1, shp[-1]).to(torch.bfloat16).contiguous()
+    nb = shp[0]
+    pk = getattr(self, "_aql_zero_base", None)
+    if pk is None:
+        N, K = self.up.weight.shape[0], self.down.weight.numel() // self.rank
+        pk = ops.PackedLinear(torch.zeros(N, K, device=x2d.device), None)
+        object.__setattr__(self, "_aql_zero_base", pk)
+    y = _run_linear(x2d, pk, self, scale, nb, x2d.shape[0] // nb, None)
+    return y.reshape(*shp[:-1], y.shape[-1]).to(orig)
+
+
+def CustomLoRAConv2dLayerforward(self, hidden_states, scale=1.0):
+    """up(down(x) * scale[:, :, None, None]) for 1x1 convs (reference lora_modules.py:28-44)."""
+    orig = hidden_states.dtype
+    x = ops.as_cl(hidden_states.to(torch.bfloat16))
+    B, C, H, W = x.shape
+    y = CustomLoRALinearLayerforward(self, ops.nhwc_view(x).reshape(B, H * W, C), scale)
+    return y.view(B, H, W, -1).permute(0, 3, 1, 2).to(orig)
+
+
+# --------------------------------------------------------------------------- injection / patching loops
+def load_unet_keys(unet):
+    """The reference reads utils/unet_keys.json (192 sorted module paths); here the same list is derived from the
+    module tree (tests/test_golden.py checks it equals the reference file)."""
+    from .unet import lora_keys
+    return lora_keys(unet)
+
+
+def _walk(root, key):
+    m = root
+    for sub in key.split("."):
+        m = getattr(m, sub)
+    return m
+
+
+def inject_lora(unet, rank, keys=None, lora_state=None):
+    """ppft_train.py:620-678: build a LoRA layer for each key, optionally load weights, set_lora_layer.
+    Returns the list of trainable parameters (2 per site, in key order)."""
+    keys = keys if keys is not None else load_unet_keys(unet)
+    params = []
+    dev = next(unet.parameters()).device
+    for key in keys:
+        host = _walk(unet, key)
+        if isinstance(host, LoRACompatibleConv):
+            lora = LoRAConv2dLayer(host.in_channels, host.out_channels, rank=rank, kernel_size=host.kernel_size,
+                                   stride=host.stride, padding=host.padding)
+        elif isinstance(host, LoRACompatibleLinear):
+            lora = LoRALinearLayer(host.in_features, host.out_features, rank)
+        else:
+            raise ValueError(f"Module {key} is not a LoRACompatibleConv or LoRACompatibleLinear module.")
+        if lora_state is not None:
+            lora.load_state_dict({"down.weight": lora_state[key + ".down.weight"],
+                                  "up.weight": lora_state[key + ".up.weight"]})
+        lora.to(device=dev, dtype=torch.float32)
+        host.set_lora_layer(lora)
+        params.extend(lora.parameters())
+    return params
+
+
+def patch_lora_forwards(unet):
+    """ppft_train.py:681-689: bind the custom forwards onto every LoRA-compatible module of the U-Net."""
+    for _, module in unet.named_modules():
+        if isinstance(module, LoRACompatibleConv):
+            module.forward = types.MethodType(CustomLoRACompatibleConvforward, module)
+            if module.lora_layer is not None:
+                module.lora_layer.forward = types.MethodType(CustomLoRAConv2dLayerforward, module.lora_layer)
+        elif isinstance(module, LoRACompatibleLinear):
+            module.forward = types.MethodType(CustomLoRACompatibleLinearforward, module)
+            if module.lora_layer is not None:
+                module.lora_layer.forward = types.MethodType(CustomLoRALinearLayerforward, module.lora_layer)
+
+
+# ------------------------------------------------------------------------------------------ flat bank
+class LoraBank:
+    """Re-homes every LoRA parameter of a U-Net into ONE flat fp32 buffer (+ flat grad / exp_avg / exp_avg_sq),
+    so that clip-norm, AdamW and the data-parallel gradient exchange are single kernels / collectives over
+    contiguous HBM instead of 384 small tensors.  Sites are laid out in REVERSE key order so that the gradients
+    that finish first in backward (up_blocks.3 ...) sit at the front of the buffer: bucket i of the exchange is
+    complete as soon as backward has passed its last site."""
+
+    def __init__(self, unet, keys=None, extra_params=()):
+        keys = keys if keys is not None else load_unet_keys(unet)
+        self.layers = [_walk(unet, k).lora_layer for k in keys]
+        order = list(reversed(range(len(keys))))
+        plist = []
+        for i in order:
+            plist += [self.layers[i].down.weight, self.layers[i].up.weight]
+        self.n_lora = sum(p.numel() for p in plist)
+        plist += list(extra_params)
+        self.params = plist
+        n = sum(p.numel() for p in plist)
+        dev = plist[0].device
+        pad = (-n) % 64
+        self.flat = torch.zeros(n + pad, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros_like(self.flat)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.numel = n
+        off = 0
+        self.offsets = []
+        for p in plist:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.detach().float().reshape(-1))
+            p.data = self.flat[off:off + k].view(p.shape)
+            p.grad = self.grad[off:off + k].view(p.shape)
+            self.offsets.append(off)
+            off += k
+        self.sites = []
+        for layer in self.layers:
+            site = LoraSite(layer)
+            site.managed = True
+            object.__setattr__(layer, "_aql_site", site)
+            site.refresh(force=True)
+            self.sites.append(site)
+
+    def refresh(self):
+        """Re-cast the fp32 masters to the bf16 compute copies (call after every optimizer step)."""
+        for s in self.sites:
+            s.refresh(force=True)
+
+    def zero_grad(self):
+        self.grad.zero_()

@@ -120,13 +120,14 @@ class LoraLinearFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x2d, packed, site, S16, rps, residual):
+    def forward(ctx, x2d, packed, site, S, S16, rps, residual):
         _req(x2d, "lora_linear")
         M = x2d.shape[0]
         ctx.packed, ctx.site, ctx.rps = packed, site, rps
         ctx.has_res = residual is not None
         use_lora = site is not None and S16 is not None
         ctx.use_lora = use_lora
+        ctx.s_dtype = S.dtype if S is not None else None
         T = Ts = None
         if use_lora:
             r = site.rank
@@ -163,13 +164,17 @@ class LoraLinearFn(torch.autograd.Function):
             L.call("aql_lora_ds", L.ptr(dTs), L.ptr(T), nb, ctx.rps, r, L.ptr(dS), L.stream_ptr())
             if not ctx.needs_input_grad[3]:
                 dS = None
+            else:
+                dS = dS.to(ctx.s_dtype)
         else:
             dx = gemm_bf16(dy, packed.wt) if ctx.needs_input_grad[0] else None
-        return dx, None, None, dS, None, (dy if ctx.has_res else None)
+        return dx, None, None, dS, None, None, (dy if ctx.has_res else None)
 
 
-def lora_linear(x2d, packed, site=None, S16=None, rps=1, residual=None):
-    return LoraLinearFn.apply(x2d, packed, site, S16, rps, residual)
+def lora_linear(x2d, packed, site=None, S=None, S16=None, rps=1, residual=None):
+    """S: the [nb, r] scale as seen by autograd (its gradient dS is returned in S.dtype, accumulated in fp32);
+    S16: its bf16 copy read by the kernels."""
+    return LoraLinearFn.apply(x2d, packed, site, S, S16, rps, residual)
 
 
 # --------------------------------------------------------------------------------------------- conv 3x3

@@ -1,0 +1,351 @@
+"""SD-1.5 ``UNet2DConditionModel`` host for the HIP kernels.
+
+Same module tree / state-dict keys (686 tensors) and call surface as diffusers 0.24 (reference call sites
+train/ppft_train.py:546-548, 1026-1035; architecture pinned through the in-tree twin
+scripts/lib/original_unet.py:1311-1606), so a diffusers SD-1.5 checkpoint loads by key and
+``unet(sample, t, ctx, cross_attention_kwargs={"scale": S}).sample`` behaves like the reference's patched U-Net.
+
+MI355X-first choices:
+  * activations stay bf16 channels-last from conv_in to conv_out; a feature map and its token view share memory;
+  * nearest-x2 upsample is folded into the following conv's gather; the ResNet time-embedding add and every
+    residual add are fused into GEMM/conv epilogues; GroupNorm+SiLU is one op;
+  * every linear / 1x1 conv site goes through the fused LoRA GEMM, every 3x3 conv through the implicit-GEMM kernel.
+``scale`` is threaded positionally to every LoRA-compatible host exactly like diffusers does.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import ops, synth
+from .lora import (LoRACompatibleConv, LoRACompatibleLinear, _packed_conv3)
+
+SD15 = dict(in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+            cross_attention_dim=768, attention_heads=8, norm_groups=32,
+            down_attn=(True, True, True, False), up_attn=(False, True, True, True))
+
+
+class GroupNorm(nn.Module):
+    def __init__(self, channels, eps, device=None, dtype=None):
+        super().__init__()
+        self.num_groups, self.num_channels, self.eps = 32, channels, eps
+        self.weight = nn.Parameter(torch.ones(channels, device=device, dtype=dtype))
+        self.bias = nn.Parameter(torch.zeros(channels, device=device, dtype=dtype))
+
+    def forward(self, x, silu=False):
+        return ops.groupnorm_silu(x, self.weight, self.bias, self.eps, silu)
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, channels, eps=1e-5, device=None, dtype=None):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(channels, device=device, dtype=dtype))
+        self.bias = nn.Parameter(torch.zeros(channels, device=device, dtype=dtype))
+
+    def forward(self, x):
+        shp = x.shape
+        return ops.layernorm(x.reshape(-1, shp[-1]), self.weight, self.bias, self.eps).view(shp)
+
+
+def get_timestep_embedding(timesteps, dim, flip_sin_to_cos=True, downscale_freq_shift=0, max_period=10000):
+    """Sinusoidal embedding (original_unet.py:323-361), fp32."""
+    half = dim // 2
+    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32, device=timesteps.device)
+    exponent = exponent / (half - downscale_freq_shift)
+    emb = timesteps[:, None].float() * torch.exp(exponent)[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+    return emb
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_ch, dim, **kw):
+        super().__init__()
+        self.linear_1 = LoRACompatibleLinear(in_ch, dim, **kw)
+        self.linear_2 = LoRACompatibleLinear(dim, dim, **kw)
+
+    def forward(self, t_emb, scale=1.0):
+        return self.linear_2(torch.nn.functional.silu(self.linear_1(t_emb, scale)), scale)
+
+
+class ResnetBlock2D(nn.Module):
+    def __init__(self, cin, cout, temb_dim, eps, **kw):
+        super().__init__()
+        self.norm1 = GroupNorm(cin, eps, **kw)
+        self.conv1 = LoRACompatibleConv(cin, cout, 3, padding=1, **kw)
+        self.time_emb_proj = LoRACompatibleLinear(temb_dim, cout, **kw)
+        self.norm2 = GroupNorm(cout, eps, **kw)
+        self.conv2 = LoRACompatibleConv(cout, cout, 3, padding=1, **kw)
+        self.conv_shortcut = LoRACompatibleConv(cin, cout, 1, **kw) if cin != cout else None
+
+    def forward(self, x, temb_act, scale=1.0):
+        h = self.norm1(x, silu=True)
+        tproj = self.time_emb_proj(temb_act, scale)  # [B, cout]
+        h = ops.conv3x3(h, _packed_conv3(self.conv1), False, tproj.contiguous(), None)
+        h = self.norm2(h, silu=True)
+        shortcut = x if self.conv_shortcut is None else self.conv_shortcut(x, scale)
+        return ops.conv3x3(h, _packed_conv3(self.conv2), False, None, shortcut)
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, ch, **kw):
+        super().__init__()
+        self.conv = LoRACompatibleConv(ch, ch, 3, stride=2, padding=1, **kw)
+
+    def forward(self, x, scale=1.0):
+        return self.conv(x, scale)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, ch, **kw):
+        super().__init__()
+        self.conv = LoRACompatibleConv(ch, ch, 3, padding=1, **kw)
+
+    def forward(self, x, scale=1.0):
+        return ops.conv3x3(x, _packed_conv3(self.conv), True, None, None)
+
+
+class Attention(nn.Module):
+    def __init__(self, query_dim, cross_dim, heads, **kw):
+        super().__init__()
+        self.heads = heads
+        cross_dim = cross_dim if cross_dim is not None else query_dim
+        self.to_q = LoRACompatibleLinear(query_dim, query_dim, bias=False, **kw)
+        self.to_k = LoRACompatibleLinear(cross_dim, query_dim, bias=False, **kw)
+        self.to_v = LoRACompatibleLinear(cross_dim, query_dim, bias=False, **kw)
+        self.to_out = nn.ModuleList([LoRACompatibleLinear(query_dim, query_dim, **kw), nn.Dropout(0.0)])
+
+    def forward(self, hidden_states, encoder_hidden_states=None, scale=1.0, residual=None):
+        ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
+        q = self.to_q(hidden_states, scale)
+        k = self.to_k(ctx, scale)
+        v = self.to_v(ctx, scale)
+        o = ops.attention(q, k, v, self.heads)
+        return self.to_out[0](o, scale, residual=residual)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out, **kw):
+        super().__init__()
+        self.proj = LoRACompatibleLinear(dim_in, dim_out * 2, **kw)
+
+    def forward(self, x, scale=1.0):
+        h = self.proj(x, scale)
+        return ops.geglu(h.reshape(-1, h.shape[-1])).view(*h.shape[:-1], h.shape[-1] // 2)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, **kw):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * 4, **kw), nn.Dropout(0.0), LoRACompatibleLinear(dim * 4, dim, **kw)])
+
+    def forward(self, x, scale=1.0, residual=None):
+        return self.net[2](self.net[0](x, scale), scale, residual=residual)
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, heads, cross_dim, **kw):
+        super().__init__()
+        self.norm1 = LayerNorm(dim, **kw)
+        self.attn1 = Attention(dim, None, heads, **kw)
+        self.norm2 = LayerNorm(dim, **kw)
+        self.attn2 = Attention(dim, cross_dim, heads, **kw)
+        self.norm3 = LayerNorm(dim, **kw)
+        self.ff = FeedForward(dim, **kw)
+
+    def forward(self, h, ctx, scale=1.0):
+        h = self.attn1(self.norm1(h), None, scale, residual=h)
+        h = self.attn2(self.norm2(h), ctx, scale, residual=h)
+        return self.ff(self.norm3(h), scale, residual=h)
+
+
+class Transformer2DModel(nn.Module):
+    def __init__(self, ch, heads, cross_dim, **kw):
+        super().__init__()
+        self.norm = GroupNorm(ch, 1e-6, **kw)
+        self.proj_in = LoRACompatibleConv(ch, ch, 1, **kw)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(ch, heads, cross_dim, **kw)])
+        self.proj_out = LoRACompatibleConv(ch, ch, 1, **kw)
+
+    def forward(self, x, ctx, scale=1.0):
+        B, C, H, W = x.shape
+        h = self.proj_in(self.norm(x), scale)
+        tokens = ops.nhwc_view(h).reshape(B, H * W, C)
+        for blk in self.transformer_blocks:
+            tokens = blk(tokens, ctx, scale)
+        h = tokens.view(B, H, W, C).permute(0, 3, 1, 2)
+        return self.proj_out(h, scale, residual=x)
+
+
+class DownBlock(nn.Module):
+    def __init__(self, cin, cout, temb_dim, n_layers, attn, heads, cross_dim, add_down, eps, **kw):
+        super().__init__()
+        self.has_cross_attention = attn
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb_dim, eps, **kw)
+                                      for i in range(n_layers)])
+        if attn:
+            self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cross_dim, **kw) for _ in range(n_layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(cout, **kw)]) if add_down else None
+
+    def forward(self, h, temb_act, ctx, scale):
+        outs = ()
+        for i, res in enumerate(self.resnets):
+            h = res(h, temb_act, scale)
+            if self.has_cross_attention:
+                h = self.attentions[i](h, ctx, scale)
+            outs += (h,)
+        if self.downsamplers is not None:
+            h = self.downsamplers[0](h, scale)
+            outs += (h,)
+        return h, outs
+
+
+class MidBlock(nn.Module):
+    def __init__(self, ch, temb_dim, heads, cross_dim, eps, **kw):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(ch, ch, temb_dim, eps, **kw) for _ in range(2)])
+        self.attentions = nn.ModuleList([Transformer2DModel(ch, heads, cross_dim, **kw)])
+
+    def forward(self, h, temb_act, ctx, scale):
+        h = self.resnets[0](h, temb_act, scale)
+        h = self.attentions[0](h, ctx, scale)
+        return self.resnets[1](h, temb_act, scale)
+
+
+class UpBlock(nn.Module):
+    def __init__(self, cin, cout, prev, temb_dim, n_layers, attn, heads, cross_dim, add_up, eps, **kw):
+        super().__init__()
+        self.has_cross_attention = attn
+        resnets = []
+        for i in range(n_layers):
+            skip = cin if i == n_layers - 1 else cout
+            rin = prev if i == 0 else cout
+            resnets.append(ResnetBlock2D(rin + skip, cout, temb_dim, eps, **kw))
+        self.resnets = nn.ModuleList(resnets)
+        if attn:
+            self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cross_dim, **kw) for _ in range(n_layers)])
+        self.upsamplers = nn.ModuleList([Upsample2D(cout, **kw)]) if add_up else None
+
+    def forward(self, h, skips, temb_act, ctx, scale):
+        for i, res in enumerate(self.resnets):
+            h = torch.cat([h, skips[-1 - i]], dim=1)
+            if not h.is_contiguous(memory_format=torch.channels_last):
+                h = h.contiguous(memory_format=torch.channels_last)
+            h = res(h, temb_act, scale)
+            if self.has_cross_attention:
+                h = self.attentions[i](h, ctx, scale)
+        if self.upsamplers is not None:
+            h = self.upsamplers[0](h, scale)
+        return h
+
+
+class UNet2DConditionModel(nn.Module):
+    def __init__(self, config=None, device=None, dtype=torch.bfloat16):
+        super().__init__()
+        cfg = dict(SD15)
+        cfg.update(config or {})
+        self.config = SimpleNamespace(**cfg)
+        kw = dict(device=device, dtype=dtype)
+        boc = cfg["block_out_channels"]
+        L = cfg["layers_per_block"]
+        heads, cross = cfg["attention_heads"], cfg["cross_attention_dim"]
+        temb_dim = boc[0] * 4
+        eps = 1e-5
+        self.conv_in = LoRACompatibleConv(cfg["in_channels"], boc[0], 3, padding=1, **kw)
+        self.time_embedding = TimestepEmbedding(boc[0], temb_dim, **kw)
+        downs = []
+        out_ch = boc[0]
+        for i, ch in enumerate(boc):
+            in_ch, out_ch = out_ch, ch
+            downs.append(DownBlock(in_ch, out_ch, temb_dim, L, cfg["down_attn"][i], heads, cross, i != len(boc) - 1,
+                                   eps, **kw))
+        self.down_blocks = nn.ModuleList(downs)
+        self.mid_block = MidBlock(boc[-1], temb_dim, heads, cross, eps, **kw)
+        ups = []
+        rev = list(reversed(boc))
+        out_ch = rev[0]
+        for i in range(len(boc)):
+            prev = out_ch
+            out_ch = rev[i]
+            in_ch = rev[min(i + 1, len(boc) - 1)]
+            ups.append(UpBlock(in_ch, out_ch, prev, temb_dim, L + 1, cfg["up_attn"][i], heads, cross,
+                               i != len(boc) - 1, eps, **kw))
+        self.up_blocks = nn.ModuleList(ups)
+        self.conv_norm_out = GroupNorm(boc[0], eps, **kw)
+        self.conv_out = LoRACompatibleConv(boc[0], cfg["out_channels"], 3, padding=1, **kw)
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    @property
+    def dtype(self):
+        return self.conv_in.weight.dtype
+
+    @property
+    def device(self):
+        return self.conv_in.weight.device
+
+    def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, cross_attention_kwargs=None,
+                return_dict=True):
+        scale = 1.0
+        if cross_attention_kwargs is not None and "scale" in cross_attention_kwargs:
+            scale = cross_attention_kwargs["scale"]
+        if not torch.is_tensor(timestep):
+            timestep = torch.tensor([timestep], device=sample.device)
+        timestep = timestep.reshape(-1).expand(sample.shape[0])
+        t_emb = get_timestep_embedding(timestep, self.config.block_out_channels[0]).to(self.dtype)
+        emb = self.time_embedding(t_emb, scale)
+        temb_act = torch.nn.functional.silu(emb)  # every ResNet applies SiLU to temb first (original_unet.py:449)
+        ctx = encoder_hidden_states.to(self.dtype).contiguous()
+        h = self.conv_in(ops.as_cl(sample.to(self.dtype)), scale)
+        skips = (h,)
+        for blk in self.down_blocks:
+            h, outs = blk(h, temb_act, ctx, scale)
+            skips += outs
+        h = self.mid_block(h, temb_act, ctx, scale)
+        for blk in self.up_blocks:
+            n = len(blk.resnets)
+            h = blk(h, skips[-n:], temb_act, ctx, scale)
+            skips = skips[:-n]
+        h = self.conv_norm_out(h, silu=True)
+        h = self.conv_out(h, scale)
+        if not return_dict:
+            return (h,)
+        return SimpleNamespace(sample=h)
+
+
+def lora_keys(unet):
+    """The 192 injection points of utils/unet_keys.json, derived from the module tree: every proj_in / proj_out /
+    attn{1,2}.to_{q,k,v,out.0} / ff.net.0.proj / ff.net.2 of every transformer block, in sorted order."""
+    keys = []
+    for name, m in unet.named_modules():
+        if isinstance(m, Transformer2DModel):
+            keys += [f"{name}.proj_in", f"{name}.proj_out"]
+            for j in range(len(m.transformer_blocks)):
+                tb = f"{name}.transformer_blocks.{j}"
+                for a in ("attn1", "attn2"):
+                    keys += [f"{tb}.{a}.to_k", f"{tb}.{a}.to_out.0", f"{tb}.{a}.to_q", f"{tb}.{a}.to_v"]
+                keys += [f"{tb}.ff.net.0.proj", f"{tb}.ff.net.2"]
+    return sorted(keys)
+
+
+@torch.no_grad()
+def init_synthetic(unet, seed=2048):
+    """Counter-based synthetic weights: std 1/sqrt(fan_in), norm gamma 1 / beta 0, bias std 0.02."""
+    for name, p in unet.named_parameters():
+        if "lora_layer" in name:
+            continue
+        if name.endswith("weight") and p.dim() >= 2:
+            fan_in = p[0].numel()
+            p.copy_(synth.normal(name, p.shape, fan_in ** -0.5, seed, p.device).to(p.dtype))
+        elif name.endswith("weight"):
+            p.fill_(1.0)
+        elif "norm" in name:
+            p.zero_()
+        else:
+            p.copy_(synth.normal(name, p.shape, 0.02, seed, p.device).to(p.dtype))
+        mod = unet.get_submodule(name.rsplit(".", 1)[0])
+        if hasattr(mod, "_aql_packed"):
+            object.__delattr__(mod, "_aql_packed")

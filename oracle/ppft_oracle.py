@@ -1,0 +1,244 @@
+"""ORACLE -- test infrastructure only.  CPU restatement (plain PyTorch fp32) of the reference's PPFT hot path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's ``cpu_baseline`` leg may import this file; the product
+(aqualora_amd/) never does.  Parity status: PINNED -- tests/test_oracle_golden.py checks every function below
+against tests/golden/*.npz, which were produced by running the reference's own code (tests/golden/make_golden.py).
+
+Each function cites the reference lines it restates (paths relative to /root/reference):
+  lora_linear / lora_conv1x1      utils/lora_modules.py:9-26, 28-44, 46-54, 56-62
+  mapper                          utils/models.py:110-115
+  secret_encoder                  utils/models.py:57-64, 74-81
+  add_noise, alphas_cumprod       diffusers DDPMScheduler.add_noise as called at train/ppft_train.py:1010-1011
+                                  (SD-1.5 scaled_linear schedule), utils/cschedulers.py:56-72
+  lr_lambda                       utils/misc.py:23-33
+  unet_forward                    scripts/lib/original_unet.py:323-361, 413-462, 543-640, 708-890, 893-1249, 1464-1585
+  ppft_loss / ppft_step           train/ppft_train.py:987-1068 (+ optimizer 779-787)
+  lora_state_dict_keys            train/ppft_train.py:443-471, 1217-1221
+
+``rb`` (round-to-bf16 and back) is applied after every operator when ``bf16=True`` so the oracle mirrors the
+product's bf16 activation storage while keeping fp32 arithmetic inside each op -- this is what the GPU parity
+tests compare against.  With ``bf16=False`` it is the plain fp32 maths that is pinned to the golden vectors.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _rb(t, on):
+    return t.to(torch.bfloat16).float() if on else t
+
+
+# ------------------------------------------------------------------------------------------- LoRA forwards
+def lora_branch(x, down_w, up_w, scale):
+    """up(down(x) @ diag_embed(scale)); float scale multiplies the output (lora_modules.py:9-26)."""
+    t = x @ down_w.reshape(down_w.shape[0], -1).T
+    if isinstance(scale, torch.Tensor):
+        t = t * scale[:, None, :] if t.dim() == 3 else t * scale
+        return t @ up_w.reshape(up_w.shape[0], -1).T
+    return scale * (t @ up_w.reshape(up_w.shape[0], -1).T)
+
+
+def lora_linear(x, w, b, down_w=None, up_w=None, scale=1.0):
+    """nn.Linear(x) [+ lora(x, scale)] (lora_modules.py:56-62)."""
+    y = F.linear(x, w, b)
+    if down_w is not None and scale is not None:
+        y = y + lora_branch(x, down_w, up_w, scale)
+    return y
+
+
+def lora_conv1x1(x, w, b, down_w=None, up_w=None, scale=1.0):
+    """Conv2d 1x1 [+ up(down(x) * scale[:, :, None, None])] on NCHW (lora_modules.py:46-54, 28-44)."""
+    y = F.conv2d(x, w.reshape(w.shape[0], -1, 1, 1), b)
+    if down_w is not None and scale is not None:
+        t = F.conv2d(x, down_w.reshape(down_w.shape[0], -1, 1, 1))
+        if isinstance(scale, torch.Tensor):
+            t = t * scale[:, :, None, None]
+            y = y + F.conv2d(t, up_w.reshape(up_w.shape[0], -1, 1, 1))
+        else:
+            y = y + scale * F.conv2d(t, up_w.reshape(up_w.shape[0], -1, 1, 1))
+    return y
+
+
+# ---------------------------------------------------------------------------------- watermark modules
+def mapper(msg, E):
+    """(E * x[:, :, None]).sum(1) / sqrt(bits) + 1 (models.py:110-115)."""
+    return (E[None] * msg[:, :, None]).sum(dim=1) / math.sqrt(E.shape[0]) + 1.0
+
+
+def secret_encoder(msg, lin_w, lin_b, conv_w, conv_b, base_res=32, res=64):
+    """Linear -> SiLU -> view [B,1,R,R] -> repeat 4 ch -> nearest upsample -> conv3x3 (models.py:57-64)."""
+    h = F.silu(F.linear(msg, lin_w, lin_b)).view(-1, 1, base_res, base_res).repeat(1, 4, 1, 1)
+    h = F.interpolate(h, scale_factor=float(res // base_res), mode="nearest")
+    return F.conv2d(h, conv_w, conv_b, padding=1)
+
+
+def alphas_cumprod(n=1000, beta_start=0.00085, beta_end=0.012):
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, n, dtype=torch.float32) ** 2
+    return torch.cumprod(1.0 - betas, dim=0)
+
+
+def add_noise(x0, noise, t, acp=None):
+    acp = alphas_cumprod() if acp is None else acp
+    sa = (acp[t] ** 0.5).view(-1, 1, 1, 1)
+    sb = ((1 - acp[t]) ** 0.5).view(-1, 1, 1, 1)
+    return sa * x0 + sb * noise
+
+
+def lr_lambda(step, warm, total, lr_end, cycles=0.5):
+    if step < warm:
+        return float(step) / float(max(1, warm))
+    progress = float(step - warm) / float(max(1, total - warm))
+    return max(lr_end, 0.5 * (1.0 + math.cos(math.pi * float(cycles) * 2.0 * progress)))
+
+
+# -------------------------------------------------------------------------------------------- U-Net
+def timestep_embedding(t, dim):
+    half = dim // 2
+    exponent = -math.log(10000) * torch.arange(half, dtype=torch.float32) / half
+    emb = t[:, None].float() * torch.exp(exponent)[None, :]
+    return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)  # flip_sin_to_cos=True, shift 0
+
+
+class UNetOracle:
+    """Functional SD-1.5-style U-Net over a diffusers-keyed state dict ``sd`` and an optional LoRA dict
+    ``lora[key] = (down_w, up_w)``; ``scale`` as in the reference (tensor [B,r] | float | None)."""
+
+    def __init__(self, sd, cfg, lora=None, bf16=False):
+        self.sd = {k: v.float() for k, v in sd.items()}
+        self.cfg = cfg
+        self.lora = lora or {}
+        self.bf16 = bf16
+        if bf16:
+            self.sd = {k: _rb(v, True) for k, v in self.sd.items()}
+
+    def r(self, t):
+        return _rb(t, self.bf16)
+
+    def _lw(self, key):
+        if key in self.lora:
+            d, u = self.lora[key]
+            return (self.r(d.float()), self.r(u.float())) if self.bf16 else (d, u)
+        return None, None
+
+    def lin(self, key, x, scale, bias=True):
+        d, u = self._lw(key)
+        s = self.r(scale) if isinstance(scale, torch.Tensor) else scale
+        return lora_linear(x, self.sd[key + ".weight"], self.sd.get(key + ".bias") if bias else None, d, u, s)
+
+    def conv1(self, key, x, scale):
+        d, u = self._lw(key)
+        s = self.r(scale) if isinstance(scale, torch.Tensor) else scale
+        return lora_conv1x1(x, self.sd[key + ".weight"], self.sd[key + ".bias"], d, u, s)
+
+    def conv3(self, key, x, stride=1):
+        return F.conv2d(x, self.sd[key + ".weight"], self.sd[key + ".bias"], stride=stride, padding=1)
+
+    def gn(self, key, x, eps, silu):
+        y = F.group_norm(x, 32, self.sd[key + ".weight"], self.sd[key + ".bias"], eps)
+        return self.r(F.silu(y) if silu else y)
+
+    def ln(self, key, x):
+        return self.r(F.layer_norm(x, (x.shape[-1],), self.sd[key + ".weight"], self.sd[key + ".bias"], 1e-5))
+
+    def resnet(self, p, x, temb_act, scale):
+        h = self.gn(p + ".norm1", x, 1e-5, True)
+        tp = self.r(self.lin(p + ".time_emb_proj", temb_act, scale))
+        h = self.r(self.r(self.conv3(p + ".conv1", h)) + tp[:, :, None, None])
+        h = self.gn(p + ".norm2", h, 1e-5, True)
+        sc = x
+        if (p + ".conv_shortcut.weight") in self.sd:
+            sc = self.r(self.conv1(p + ".conv_shortcut", x, scale))
+        return self.r(self.r(self.conv3(p + ".conv2", h)) + sc)
+
+    def attn(self, p, x, ctx, scale, heads, residual):
+        c = x if ctx is None else ctx
+        q = self.r(self.lin(p + ".to_q", x, scale, bias=False))
+        k = self.r(self.lin(p + ".to_k", c, scale, bias=False))
+        v = self.r(self.lin(p + ".to_v", c, scale, bias=False))
+        B, N, C = q.shape
+        d = C // heads
+        qh, kh, vh = [t.view(B, -1, heads, d).transpose(1, 2) for t in (q, k, v)]
+        a = torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, dim=-1)
+        o = self.r((a @ vh).transpose(1, 2).reshape(B, N, C))
+        return self.r(self.r(self.lin(p + ".to_out.0", o, scale)) + residual)
+
+    def transformer(self, p, x, ctx, scale):
+        heads = self.cfg["attention_heads"]
+        B, C, H, W = x.shape
+        h = self.gn(p + ".norm", x, 1e-6, False)
+        h = self.r(self.conv1(p + ".proj_in", h, scale))
+        t = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
+        tb = p + ".transformer_blocks.0"
+        t = self.attn(tb + ".attn1", self.ln(tb + ".norm1", t), None, scale, heads, t)
+        t = self.attn(tb + ".attn2", self.ln(tb + ".norm2", t), ctx, scale, heads, t)
+        f = self.r(self.lin(tb + ".ff.net.0.proj", self.ln(tb + ".norm3", t), scale))
+        hh, g = f.chunk(2, dim=-1)
+        f = self.r(hh * F.gelu(g))
+        t = self.r(self.r(self.lin(tb + ".ff.net.2", f, scale)) + t)
+        h = t.reshape(B, H, W, C).permute(0, 3, 1, 2)
+        return self.r(self.r(self.conv1(p + ".proj_out", h, scale)) + x)
+
+    def forward(self, sample, t, ctx, scale=1.0):
+        cfg = self.cfg
+        boc = cfg["block_out_channels"]
+        L = cfg["layers_per_block"]
+        down_attn = cfg.get("down_attn", (True, True, True, False))
+        up_attn = cfg.get("up_attn", (False, True, True, True))
+        sample, ctx = self.r(sample.float()), self.r(ctx.float())
+        temb = self.r(timestep_embedding(t, boc[0]))
+        e = self.r(self.lin("time_embedding.linear_1", temb, scale))
+        emb = self.r(self.lin("time_embedding.linear_2", self.r(F.silu(e)), scale))
+        ta = self.r(F.silu(emb))
+        h = self.r(self.conv3("conv_in", sample))
+        skips = [h]
+        for i in range(len(boc)):
+            for j in range(L):
+                h = self.resnet(f"down_blocks.{i}.resnets.{j}", h, ta, scale)
+                if down_attn[i]:
+                    h = self.transformer(f"down_blocks.{i}.attentions.{j}", h, ctx, scale)
+                skips.append(h)
+            if i != len(boc) - 1:
+                h = self.r(self.conv3(f"down_blocks.{i}.downsamplers.0.conv", h, stride=2))
+                skips.append(h)
+        h = self.resnet("mid_block.resnets.0", h, ta, scale)
+        h = self.transformer("mid_block.attentions.0", h, ctx, scale)
+        h = self.resnet("mid_block.resnets.1", h, ta, scale)
+        for i in range(len(boc)):
+            for j in range(L + 1):
+                h = torch.cat([h, skips.pop()], dim=1)
+                h = self.resnet(f"up_blocks.{i}.resnets.{j}", h, ta, scale)
+                if up_attn[i]:
+                    h = self.transformer(f"up_blocks.{i}.attentions.{j}", h, ctx, scale)
+            if i != len(boc) - 1:
+                h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+                h = self.r(self.conv3(f"up_blocks.{i}.upsamplers.0.conv", h))
+        h = self.gn("conv_norm_out", h, 1e-5, True)
+        return self.r(self.conv3("conv_out", h))
+
+
+def ppft_loss(sd, cfg, lora, E, msg, z, wm, eps, t, ctx, bf16=False):
+    """ppft_train.py:989-1051 with injected inputs: returns (loss, pred, clean, S)."""
+    acp = alphas_cumprod()
+    S = mapper(msg, E)
+    x_t = add_noise(z, eps, t, acp)
+    x_t_wm = add_noise(z + wm, eps, t, acp)
+    net = UNetOracle(sd, cfg, lora, bf16)
+    with torch.no_grad():
+        clean = net.forward(x_t, t, ctx, scale=None)  # == the reference's all-zero scale (LoRA term is exactly 0)
+    pred = net.forward(x_t_wm, t, ctx, scale=S)
+    loss = F.mse_loss(pred.float(), clean.float(), reduction="mean")
+    return loss, pred, clean, S
+
+
+def lora_state_dict_keys(unet_keys):
+    """Checkpoint key mapping of ppft_train.py:443-471 (+ the "unet." prefix added by save_lora_weights)."""
+    out = []
+    for key in unet_keys:
+        k = key.replace(".proj_in", ".proj_in.lora").replace(".proj_out", ".proj_out.lora")
+        k = k.replace(".to_q", ".processor.to_q_lora").replace(".to_k", ".processor.to_k_lora")
+        k = k.replace(".to_v", ".processor.to_v_lora").replace(".to_out.0", ".processor.to_out_lora")
+        if "ff" in k:
+            k = k + ".lora"
+        out += [f"unet.{k}.down.weight", f"unet.{k}.up.weight"]
+    return out

@@ -1,0 +1,166 @@
+"""CPU: pins oracle/ppft_oracle.py (and the host-side helpers) to the golden vectors produced by the reference's
+own code (tests/golden/make_golden.py).  fp32 tolerance: 2e-5 relative to the tensor's max unless stated."""
+import numpy as np
+import torch
+
+from aqualora_amd import synth
+from aqualora_amd.unet import lora_keys
+from aqualora_amd.watermark import get_cosine_schedule_with_warmup_lr_end, sd15_alphas_cumprod
+from oracle import ppft_oracle as O
+from tests.common import LORA_CASES, SEED, T, TINY, TINY_RANK, ppft_inputs, tiny_lora, tiny_unet
+
+
+def close(a, b, tol=2e-5):
+    a = torch.as_tensor(np.asarray(a)).double()
+    b = torch.as_tensor(np.asarray(b)).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs().max().item() / (b.abs().max().item() + 1e-12)
+    assert err < tol, err
+
+
+def test_synth_torch_equals_numpy():
+    a = synth.normal("x.y", (257, 33), 0.37, seed=5)
+    assert np.array_equal(a.numpy(), synth.normal_np("x.y", (257, 33), 0.37, seed=5))
+
+
+def test_lora_forwards_match_reference(golden):
+    g = golden("lora_forwards.npz")
+    for tag, cin, cout, n, r in LORA_CASES:
+        w, b = T(f"{tag}.w", (cout, cin), cin ** -0.5), T(f"{tag}.b", (cout,), 0.02)
+        down = T(f"{tag}.down", (r, cin), 1.0 / r).requires_grad_(True)
+        up = T(f"{tag}.up", (cout, r), 0.05).requires_grad_(True)
+        x = T(f"{tag}.x", (2, n, cin)).requires_grad_(True)
+        S = (T(f"{tag}.S", (2, r), 0.3) + 1.0).requires_grad_(True)
+        y = O.lora_linear(x, w, b, down, up, S)
+        y.backward(T(f"{tag}.dy", (2, n, cout)))
+        close(y.detach(), g[f"{tag}.y"])
+        close(x.grad, g[f"{tag}.dx"])
+        close(S.grad, g[f"{tag}.dS"])
+        close(down.grad, g[f"{tag}.ddown"])
+        close(up.grad, g[f"{tag}.dup"])
+        close(O.lora_linear(x.detach(), w, b, down.detach(), up.detach(), 0.5), g[f"{tag}.y_float_scale"])
+        close(O.lora_branch(x.detach(), down.detach(), up.detach(), S.detach()), g[f"{tag}.lora_only"])
+        if f"{tag}.conv_y" in g:
+            xc = x.detach().permute(0, 2, 1).reshape(2, cin, 4, n // 4)
+            close(O.lora_conv1x1(xc, w, b, down.detach(), up.detach(), S.detach()), g[f"{tag}.conv_y"])
+
+
+def test_watermark_modules_match_reference(golden):
+    g = golden("watermark.npz")
+    E = T("mapper.E", (48, 32)).requires_grad_(True)
+    msg = synth.bits("msg", (4, 48), SEED)
+    S = O.mapper(msg, E)
+    S.backward(T("mapper.dS", (4, 32)))
+    close(S.detach(), g["S"])
+    close(E.grad, g["dE"])
+    c = O.secret_encoder(msg, T("enc.lin.w", (1024, 48), 48 ** -0.5), T("enc.lin.b", (1024,), 0.1),
+                         T("enc.conv.w", (4, 4, 3, 3), 0.05), T("enc.conv.b", (4,), 0.01))
+    close(c, g["c"])
+    assert float(g["zero_init_absmax"]) == 0.0  # reference invariant: zero-init conv => c == 0
+    assert list(g["enc_keys"]) == ["secret_scaler.0.bias", "secret_scaler.0.weight", "secret_scaler.5.bias",
+                                   "secret_scaler.5.weight"]
+    assert list(g["mapper_keys"]) == ["bit_embeddings.weight"]
+    assert np.allclose(g["fresh_row_std"], 1.0, atol=1e-5)
+
+
+def test_host_modules_state_dict_layout(golden):
+    g = golden("watermark.npz")
+    from aqualora_amd.watermark import MapperNet, SecretEncoder
+    assert sorted(SecretEncoder(48).state_dict().keys()) == list(g["enc_keys"])
+    m = MapperNet(48, 32)
+    assert sorted(m.state_dict().keys()) == list(g["mapper_keys"])
+    assert np.allclose(m.bit_embeddings.weight.detach().std(dim=1).numpy(), 1.0, atol=1e-5)
+
+
+def test_lr_schedule_matches_reference(golden):
+    g = golden("lr_schedule.npz")
+    for k in g.files:
+        row = g[k]
+        warm, total, lr_end = int(row[0]), int(row[1]), float(row[2])
+        vals = row[3:]
+        lam = get_cosine_schedule_with_warmup_lr_end(warm, total, lr_end=lr_end)
+        for s, v in enumerate(vals):
+            assert abs(O.lr_lambda(s, warm, total, lr_end) - v) < 1e-12
+            assert abs(lam(s) - v) < 1e-12
+
+
+def test_alphas_cumprod_known_values():
+    acp = O.alphas_cumprod()
+    assert abs(acp[0].item() - 0.99915) < 1e-5 and abs(acp[999].item() - 0.0046601) < 1e-5
+    assert torch.equal(acp, sd15_alphas_cumprod())
+    x, n = T("an.x", (2, 4, 8, 8)), T("an.n", (2, 4, 8, 8))
+    t = torch.tensor([0, 999])
+    y = O.add_noise(x, n, t)
+    close(y[1], (acp[999] ** 0.5) * x[1] + ((1 - acp[999]) ** 0.5) * n[1])
+
+
+def test_full_width_transformer_block_matches_reference(golden):
+    g = golden("full_block.npz")
+    from aqualora_amd.unet import Transformer2DModel
+    blk = Transformer2DModel(320, 8, 768, dtype=torch.float32)
+    sd = {}
+    for name, p in blk.named_parameters():
+        full = "blk." + name
+        if name.endswith("weight") and p.dim() >= 2:
+            sd["b." + name] = synth.normal(full, p.shape, p[0].numel() ** -0.5, SEED)
+        elif name.endswith("weight"):
+            sd["b." + name] = torch.ones_like(p)
+        elif "norm" in name:
+            sd["b." + name] = torch.zeros_like(p)
+        else:
+            sd["b." + name] = synth.normal(full, p.shape, 0.02, SEED)
+    net = O.UNetOracle(sd, dict(attention_heads=8))
+    y = net.transformer("b", T("blk.x", (1, 320, 16, 16)), T("blk.ctx", (1, 77, 768)), None)
+    close(y, g["y"], 5e-5)
+
+
+def test_unet_keys_and_checkpoint_layout(golden):
+    g = golden("tiny_ppft.npz")
+    unet = tiny_unet()
+    keys = lora_keys(unet)
+    assert keys == list(g["keys"]) and len(keys) == 192
+    ck = golden("checkpoint_layout.npz")
+    assert sorted(O.lora_state_dict_keys(keys)) == list(ck["names"])
+    from aqualora_amd.checkpoint import lora_state_dict
+    from aqualora_amd.lora import inject_lora
+    inject_lora(unet, TINY_RANK)
+    sd = lora_state_dict(unet)
+    assert sorted(sd.keys()) == list(ck["names"])
+    for n, shp in zip(ck["names"], ck["shapes"]):
+        assert list(sd[str(n)].shape) == [int(s) for s in shp if s > 0]
+        assert sd[str(n)].dtype == torch.float32
+
+
+def test_tiny_ppft_step_matches_reference(golden):
+    g = golden("tiny_ppft.npz")
+    unet = tiny_unet()
+    keys = lora_keys(unet)
+    sd = {k: v for k, v in unet.state_dict().items()}
+    lora = {k: (d.requires_grad_(True), u.requires_grad_(True)) for k, (d, u) in tiny_lora(keys, unet).items()}
+    inp = ppft_inputs()
+    E = inp["E"].requires_grad_(True)
+    loss, pred, clean, S = O.ppft_loss(sd, TINY, lora, E, inp["msg"], inp["z"], inp["wm"], inp["eps"], inp["t"],
+                                       inp["ctx"])
+    loss.backward()
+    close(clean, g["clean"], 5e-5)
+    close(pred.detach(), g["pred"], 5e-5)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * float(g["loss"])
+    close(S.detach(), g["S"])
+    params = []
+    for k in keys:
+        params += [lora[k][0], lora[k][1]]
+    gn = np.array([p.grad.norm().item() for p in params])
+    assert np.allclose(gn, g["grad_norms"], rtol=2e-3, atol=1e-9)
+    close(E.grad, g["mapper_grad"], 1e-3)
+    for name in g.files:
+        if name.startswith("g."):
+            key, which = name[2:].rsplit(".", 1)
+            close(lora[key][0 if which == "down" else 1].grad, g[name], 1e-3)
+    torch.nn.utils.clip_grad_norm_(params, 1.0)
+    opt = torch.optim.AdamW([{"params": params}, {"params": [E]}], lr=1e-4, betas=(0.9, 0.999), weight_decay=1e-2,
+                            eps=1e-8)
+    opt.step()
+    k0 = keys[0]
+    close(lora[k0][0].detach(), g["p." + k0 + ".down"], 1e-5)
+    close(lora[k0][1].detach(), g["p." + k0 + ".up"], 1e-5)
+    close(E.detach(), g["p.mapper"], 1e-5)

@@ -69,7 +69,7 @@ for (B, N, K, Nout, r) in [(2, 256, 320, 320, 32), (2, 77, 768, 640, 8), (2, 64,
     st = Site(); st.rank = r; st.a16 = A.to(torch.bfloat16); st.at16 = st.a16.t().contiguous(); st.b16 = Bu.to(torch.bfloat16); st.bt16 = st.b16.t().contiguous()
     st.ga = torch.zeros(r, K, device=dev); st.gb = torch.zeros(Nout, r, device=dev)
     S16 = S.to(torch.bfloat16)
-    y = ops.lora_linear(x, pk, st, S16, N, res)
+    y = ops.lora_linear(x, pk, st, S, S16, N, res)
     xr = x.detach().float().requires_grad_(True); Ar = st.a16.float().requires_grad_(True); Br = st.b16.float().requires_grad_(True); Sr = S16.detach().float().requires_grad_(True)
     T = xr @ Ar.T; yr = xr @ W.float().T + bias.float() + (T * Sr.repeat_interleave(N, 0)) @ Br.T + res.float()
     report(f"lora_linear fwd M{M} K{K} N{Nout} r{r}", relerr(y, yr), 1.5e-2)
