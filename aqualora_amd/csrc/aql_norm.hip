@@ -30,15 +30,14 @@ __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __
                                   const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
                                   const float* __restrict__ stats, int HW, int C, int rows_per_slab, int silu,
                                   float* __restrict__ partial) {
-  __shared__ float sg[G][2];
+  // per-thread partials are parked in LDS and reduced in a fixed order: deterministic (no float atomics)
+  extern __shared__ __attribute__((aligned(16))) float sp[];  // [blockDim.x][16]
   const int cols = C >> 3;
   const int rp = blockDim.x / cols;
   const int col = threadIdx.x % cols;
   const int rr = threadIdx.x / cols;
   const int b = blockIdx.y, slab = blockIdx.x;
   const int cpg = C / G;
-  for (int i = threadIdx.x; i < G * 2; i += blockDim.x) (&sg[0][0])[i] = 0.f;
-  __syncthreads();
   float a1[8], a2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) a1[j] = a2[j] = 0.f;
@@ -85,13 +84,17 @@ __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int g = (col * 8 + j) / cpg;
-    atomicAdd(&sg[g][0], a1[j]);
-    atomicAdd(&sg[g][1], a2[j]);
+    sp[threadIdx.x * 16 + j] = a1[j];
+    sp[threadIdx.x * 16 + 8 + j] = a2[j];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < G * 2; i += blockDim.x)
-    partial[(((long)b * gridDim.x + slab) * G) * 2 + i] = (&sg[0][0])[i];
+  for (int i = threadIdx.x; i < G * 2; i += blockDim.x) {
+    const int g = i >> 1, which = i & 1;
+    float acc = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c)
+      for (int q = 0; q < rp; ++q) acc += sp[(q * cols + (c >> 3)) * 16 + which * 8 + (c & 7)];
+    partial[(((long)b * gridDim.x + slab) * G) * 2 + i] = acc;
+  }
 }
 
 // pass 1.5: reduce slabs.  MODE 0 -> stats = (mean, rstd);  MODE 1 -> (mean dxhat, mean dxhat*xhat)
@@ -283,7 +286,7 @@ extern "C" int aql_groupnorm_silu_fwd(const bf16_t* x, int B, int HW, int C, con
   AQL_CHECK_ARG(C % (8 * 1) == 0 && C % G == 0 && C / 8 <= 1024, "aql_groupnorm_silu_fwd: bad C=%d", C);
   int threads, rps;
   const int nslab = gn_geometry(HW, C, &threads, &rps);
-  hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(nslab, B), dim3(threads), 0, stream, x, nullptr, gamma, beta, nullptr,
+  hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(nslab, B), dim3(threads), threads * 64, stream, x, nullptr, gamma, beta, nullptr,
                      HW, C, rps, silu, scratch);
   hipLaunchKernelGGL(gn_finalize_kernel<0>, dim3(B), dim3(64), 0, stream, scratch, nslab,
                      1.f / ((float)HW * (C / G)), eps, stats);
@@ -304,7 +307,7 @@ extern "C" int aql_groupnorm_silu_bwd(const bf16_t* x, const bf16_t* dy, int B, 
   int threads, rps;
   const int nslab = gn_geometry(HW, C, &threads, &rps);
   float* dstats = scratch + (long)B * 64 * G * 2;
-  hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(nslab, B), dim3(threads), 0, stream, x, dy, gamma, beta, stats, HW, C,
+  hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(nslab, B), dim3(threads), threads * 64, stream, x, dy, gamma, beta, stats, HW, C,
                      rps, silu, scratch);
   hipLaunchKernelGGL(gn_finalize_kernel<1>, dim3(B), dim3(64), 0, stream, scratch, nslab,
                      1.f / ((float)HW * (C / G)), 0.f, dstats);

@@ -355,3 +355,29 @@ class AttentionFn(torch.autograd.Function):
 
 def attention(q, k, v, heads):
     return AttentionFn.apply(q, k, v, heads)
+
+
+# ------------------------------------------------------------------------------------------- loss
+class MseFn(torch.autograd.Function):
+    """F.mse_loss(pred.float(), target.float(), reduction="mean") (ppft_train.py:1051): loss and d(pred) in one
+    pass over the two bf16 tensors."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        _req(pred, "mse")
+        p = pred.contiguous() if pred.is_contiguous() else as_cl(pred)
+        t = target.contiguous() if pred.is_contiguous() else as_cl(target)
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        dpred = torch.empty_like(p)
+        L.call("aql_mse_fwd_bwd", L.ptr(p), L.ptr(t), p.numel(), L.ptr(loss), L.ptr(dpred), L.stream_ptr())
+        ctx.save_for_backward(dpred)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return dpred * g.to(dpred.dtype), None
+
+
+def mse_loss(pred, target):
+    return MseFn.apply(pred, target)

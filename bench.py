@@ -1,0 +1,198 @@
+"""PPFT train-step benchmark (BASELINE.json metric): images/sec at 512x512 (64x64x4 latents), SD-1.5 U-Net,
+watermark-LoRA rank 32, 48-bit messages, batch 4 per GPU, bf16 -- synthetic latents/text states, random-init weights.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One JSON line on rank 0.  `roofline` prices the whole captured step against the dense bf16 MFMA peak with the
+algorithmic FLOPs of SURVEY.md §8(d) (2.477 TFLOP/image at r=32); `kernels` adds HIP-event timings of the two
+dominant kernels in isolation.  `cpu_baseline` times the CPU oracle on this box's host cores (baseline only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TF = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+UNET_FWD_GFLOP = 803.3
+LORA_FWD_GFLOP_PER_RANK = 0.7006
+
+
+def step_tflop_per_image(rank):
+    return (3 * UNET_FWD_GFLOP + 3 * LORA_FWD_GFLOP_PER_RANK * rank) / 1e3
+
+
+def build(device, rank, seed=2048):
+    from aqualora_amd import synth
+    from aqualora_amd.lora import inject_lora
+    from aqualora_amd.ppft import PPFTTrainer
+    from aqualora_amd.unet import UNet2DConditionModel, init_synthetic, lora_keys
+    from aqualora_amd.watermark import MapperNet, SecretEncoder, get_cosine_schedule_with_warmup_lr_end
+    unet = UNet2DConditionModel(device=device, dtype=torch.bfloat16)
+    init_synthetic(unet, seed)
+    keys = lora_keys(unet)
+    inject_lora(unet, rank, keys)
+    with torch.no_grad():
+        for k in keys:
+            lay = unet.get_submodule(k).lora_layer
+            lay.down.weight.copy_(synth.normal(k + ".lora.down", lay.down.weight.shape, 1.0 / rank, seed, device))
+            lay.up.weight.copy_(synth.normal(k + ".lora.up", lay.up.weight.shape, 0.02, seed, device))
+    mapper = MapperNet(48, rank)
+    enc = SecretEncoder(48)
+    with torch.no_grad():
+        enc.secret_scaler[5].weight.copy_(synth.normal("enc.conv.w", (4, 4, 3, 3), 0.05, seed))
+    tr = PPFTTrainer(unet, mapper, enc, rank, learning_rate=1e-4,
+                     lr_lambda=get_cosine_schedule_with_warmup_lr_end(0, 100000, lr_end=0.01))
+    return tr
+
+
+def synthetic_batch(B, device, rank_id, seed=2048):
+    from aqualora_amd import synth
+    s = seed + 977 * rank_id
+    return dict(z=synth.normal("bench.z", (B, 4, 64, 64), 1.0, s, device),
+                msg=synth.bits("bench.msg", (B, 48), s, device),
+                eps=synth.normal("bench.eps", (B, 4, 64, 64), 1.0, s, device),
+                t=synth.randint("bench.t", (B,), 1000, s, device),
+                ctx=synth.normal("bench.ctx", (B, 77, 768), 1.0, s, device).to(torch.bfloat16))
+
+
+def time_kernel(fn, iters=20):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters  # ms
+
+
+def dominant_kernels(B, device):
+    """HIP-event timing (torch's current stream == the launch stream of the C-ABI calls) of the two kernels that
+    carry most FLOPs: the implicit-GEMM 3x3 conv and the fused LoRA GEMM, at their largest U-Net shapes."""
+    from aqualora_amd import ops, synth
+    out = []
+    x = synth.normal("k.x", (B, 320, 64, 64), 1.0, 1, device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = synth.normal("k.w", (320, 320, 3, 3), 0.02, 1, device)
+    pk = ops.PackedConv3x3(w, torch.zeros(320, device=device), 1)
+    with torch.no_grad():
+        ms = time_kernel(lambda: ops.conv3x3(x, pk))
+    fl = 2.0 * B * 64 * 64 * 320 * 9 * 320
+    out.append({"kernel": "gemm_kernel<128,64,ConvFwdLoader> conv3x3 320->320 @64x64", "ms": ms,
+                "achieved_tflops": fl / ms / 1e9, "frac_of_mfma_peak": fl / ms / 1e9 / MFMA_PEAK_TF})
+    xs = synth.normal("k.x2", (B * 4096, 320), 1.0, 1, device).to(torch.bfloat16)
+    wl = synth.normal("k.w2", (2560, 320), 0.05, 1, device)
+    pl = ops.PackedLinear(wl, torch.zeros(2560, device=device))
+    with torch.no_grad():
+        ms = time_kernel(lambda: ops.lora_linear(xs, pl))
+    fl = 2.0 * B * 4096 * 320 * 2560
+    out.append({"kernel": "gemm_kernel<128,128,PlainLoader> ff.net.0.proj 320->2560 @4096 tok", "ms": ms,
+                "achieved_tflops": fl / ms / 1e9, "frac_of_mfma_peak": fl / ms / 1e9 / MFMA_PEAK_TF})
+    return out
+
+
+def cpu_baseline(tr, rank):
+    """Bounded CPU sample: ONE full-size U-Net forward (the 'clean' pass, batch 1) of the oracle on the host cores;
+    a PPFT step is 3 traversals + LoRA = 2.477/0.8033 of that work, which is how the images/s figure is derived."""
+    from oracle import ppft_oracle as O
+    from aqualora_amd.unet import SD15
+    from aqualora_amd import synth
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu() for k, v in tr.unet.state_dict().items() if "lora_layer" not in k}
+    net = O.UNetOracle(sd, dict(SD15))
+    x = synth.normal("bench.z", (1, 4, 64, 64), 1.0, 2048)
+    ctx = synth.normal("bench.ctx", (1, 77, 768), 1.0, 2048)
+    t = torch.tensor([500])
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        net.forward(x, t, ctx, None)
+        dt = time.perf_counter() - t0
+    step_s = dt * step_tflop_per_image(rank) / (UNET_FWD_GFLOP / 1e3)
+    return {"value": 1.0 / step_s, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"one full-size SD-1.5 U-Net forward (batch 1, fp32, oracle/ppft_oracle.py) = {dt:.2f} s; "
+                      f"PPFT step extrapolated by algorithmic FLOPs x{step_tflop_per_image(rank) / (UNET_FWD_GFLOP / 1e3):.3f}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rank", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank_id = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    tr = build(device, args.rank)
+    batch = synthetic_batch(args.batch, device, rank_id)
+    runner = tr.step
+    if not args.no_graph and hasattr(tr, "capture"):
+        runner = tr.capture(batch)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = runner(**batch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = runner(**batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    images = args.batch * world * args.steps
+    value = images / dt
+    loss_v = float(loss)
+
+    if rank_id == 0:
+        tf_img = step_tflop_per_image(args.rank)
+        achieved = tf_img * args.batch / (dt / args.steps)  # TFLOP/s per GPU
+        line = {
+            "metric": "PPFT train-step images/sec at 512x512", "value": value, "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"SD1.5 PPFT LoRA rank={args.rank}, 48-bit msg, 512x512 (64x64x4 latents in), "
+                                   f"batch={args.batch}/GPU, latent-in (VAE/CLIP outside the path)",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": runner is not tr.step,
+                       "loss": loss_v},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_PEAK_TF, "traffic": None,
+                         "launch": f"one PPFT step = {tf_img:.3f} TFLOP/image x {args.batch} images"},
+        }
+        with torch.no_grad():
+            line["kernels"] = dominant_kernels(args.batch, device)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(tr, args.rank)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,109 @@
+/* aqualora_hip -- C ABI of the MI355X (gfx950) kernels behind AquaLoRA's PPFT / latent-watermark hot path.
+ *
+ * Drop-in boundary.  The reference has no FFI: its "operator API" is a set of Python forwards
+ * monkey-patched onto diffusers modules.  Each entry point below names the reference interface it replaces
+ * (paths relative to the reference tree).  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (including workspaces); nothing is allocated inside;
+ *   - bf16_t is raw bfloat16 bits; activations are row-major with channels last ([tokens, C] / [B,H,W,C]);
+ *   - pointers are 16-byte aligned, channel counts / leading dims are multiples of 8;
+ *   - `stream` is a hipStream_t; calls are asynchronous, stateless and re-entrant (safe from autograd threads);
+ *   - return 0 on success, non-zero otherwise with a message in aql_last_error() (thread-local).
+ * Python binding: aqualora_amd/_lib.py (ctypes); see INTEGRATION.md for the reference-side stubs.
+ */
+#ifndef AQUALORA_HIP_H
+#define AQUALORA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t bf16_t;
+typedef void* aql_stream_t; /* hipStream_t */
+
+const char* aql_last_error(void);
+
+/* ---- GEMM family (csrc/aql_gemm.hip) ---------------------------------------------------------------------------
+ * C[M,N] = A[M,K].B[N,K]^T (+ A2[M,K2].B2[N,K2]^T) + bias[N] + rowbias[m / rows_per_sample][N] + residual[M,N]
+ * One MFMA accumulator for both K segments: this IS the fused watermark-LoRA linear
+ *   nn.Linear.forward(x) + lora_layer(x, scale)          utils/lora_modules.py:56-62 (and :46-54 for 1x1 convs)
+ * with A2 = (x.A^T)*S from aql_lora_down and B2 = up.weight.  ws: optional fp32 split-K workspace.             */
+int aql_gemm_bf16(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, int N, int K, const bf16_t* A2,
+                  long lda2, const bf16_t* B2, long ldb2, int K2, const bf16_t* bias, const bf16_t* rowbias,
+                  int rows_per_sample, const bf16_t* residual, long ldr, bf16_t* C, long ldc, float* ws,
+                  size_t ws_bytes, aql_stream_t stream);
+
+/* T = X.Adown^T ; Ts = T * S[m / rows_per_sample]   ==  down(x) @ diag_embed(scale)
+ *   utils/lora_modules.py:13-17 (linear) and :33-36 (conv, scale[:, :, None, None]).                           */
+int aql_lora_down(const bf16_t* X, long ldx, long M, int K, const bf16_t* Adown, int r, const bf16_t* S,
+                  int rows_per_sample, bf16_t* T, bf16_t* Ts, aql_stream_t stream);
+
+/* 3x3 convolution, pad 1, stride 1|2, NHWC, weights Wk[Cout][(kh*3+kw)*Cin+ci]; upsample=1 folds the nearest x2
+ * of Upsample2D into the gather.  Replaces F.conv2d in CustomLoRACompatibleConvforward (lora_modules.py:47-52)
+ * for the ResNet / down / up-sampler convs (scripts/lib/original_unet.py:425-430, 534, 1058).                    */
+int aql_conv3x3_fwd(const bf16_t* X, int B, int Hin, int Win, int Cin, const bf16_t* Wk, const bf16_t* bias, int Cout,
+                    int stride, int upsample, const bf16_t* rowbias, const bf16_t* residual, bf16_t* Y, float* ws,
+                    size_t ws_bytes, aql_stream_t stream);
+/* its input gradient (autograd of the same call); Wt[Cin][(kh*3+kw)*Cout+co]                                     */
+int aql_conv3x3_bwd_data(const bf16_t* dY, int B, int Hin, int Win, int Cin, const bf16_t* Wt, int Cout, int stride,
+                         bf16_t* dX, float* ws, size_t ws_bytes, aql_stream_t stream);
+
+/* C[P,Q] += alpha * U[M,P]^T.V[M,Q] (fp32, atomics over M splits): LoRA weight gradients d(up), d(down) that
+ * autograd derives from lora_modules.py:13-19.                                                                   */
+int aql_gemm_tn_f32(const bf16_t* U, long ldu, const bf16_t* V, long ldv, long M, int P, int Q, float alpha, float* C,
+                    long ldc, aql_stream_t stream);
+
+/* ---- normalisation (csrc/aql_norm.hip) ---- torch.nn.GroupNorm(32,C,eps)+SiLU, torch.nn.LayerNorm(C) as used at
+ * scripts/lib/original_unet.py:423,429,444-453,826 and :779-783.  stats: [B,32,2] / [M,2] fp32 (mean, rstd).     */
+long aql_groupnorm_scratch_floats(int B, int HW);
+int aql_groupnorm_silu_fwd(const bf16_t* x, int B, int HW, int C, const bf16_t* gamma, const bf16_t* beta, float eps,
+                           int silu, bf16_t* y, float* stats, float* scratch, aql_stream_t stream);
+int aql_groupnorm_silu_bwd(const bf16_t* x, const bf16_t* dy, int B, int HW, int C, const bf16_t* gamma,
+                           const bf16_t* beta, int silu, const float* stats, bf16_t* dx, float* scratch,
+                           aql_stream_t stream);
+int aql_layernorm_fwd(const bf16_t* x, long M, int C, const bf16_t* gamma, const bf16_t* beta, float eps, bf16_t* y,
+                      float* stats, aql_stream_t stream);
+int aql_layernorm_bwd(const bf16_t* x, const bf16_t* dy, long M, int C, const bf16_t* gamma, const float* stats,
+                      bf16_t* dx, aql_stream_t stream);
+
+/* ---- attention (csrc/aql_attn.hip) ---- F.scaled_dot_product_attention via diffusers AttnProcessor2_0 / twin
+ * original_unet.py:688-704.  q/k/v/o: [B,N,H*d] with row strides ld*; lse,delta: [B,H,Nq] fp32.                   */
+int aql_sdpa_fwd(const bf16_t* q, long ldq, const bf16_t* k, long ldk, const bf16_t* v, long ldv, int B, int H, int Nq,
+                 int Nk, int d, float scale, bf16_t* o, long ldo, float* lse, aql_stream_t stream);
+int aql_sdpa_bwd(const bf16_t* q, long ldq, const bf16_t* k, long ldk, const bf16_t* v, long ldv, const bf16_t* o,
+                 const bf16_t* dout, long ldo, const float* lse, float* delta, int B, int H, int Nq, int Nk, int d,
+                 float scale, bf16_t* dq, bf16_t* dk, bf16_t* dv, aql_stream_t stream);
+
+/* ---- elementwise / small modules (csrc/aql_elem.hip) ---------------------------------------------------------- */
+/* GEGLU  original_unet.py:727-729 : out[M,F] = in[:, :F] * gelu(in[:, F:])                                         */
+int aql_geglu_fwd(const bf16_t* in, long M, int F, bf16_t* out, aql_stream_t stream);
+int aql_geglu_bwd(const bf16_t* in, const bf16_t* dy, long M, int F, bf16_t* din, aql_stream_t stream);
+/* backward of F.interpolate(scale_factor=2, "nearest") (original_unet.py:1076): 2x2 block sum                      */
+int aql_upsample2x_bwd(const bf16_t* du, int B, int H, int W, int C, bf16_t* dx, aql_stream_t stream);
+/* DDPMScheduler.add_noise on x0 and x0+wm with shared noise/timesteps  train/ppft_train.py:1010-1011              */
+int aql_add_noise(const float* x0, const float* wm, const float* eps, const long* t, const float* alphas_cumprod, int B,
+                  int per_sample, bf16_t* noisy, bf16_t* noisy_wm, aql_stream_t stream);
+/* F.mse_loss(pred.float(), target.float()) and its gradient  train/ppft_train.py:1051                              */
+int aql_mse_fwd_bwd(const bf16_t* pred, const bf16_t* target, long n, float* loss, bf16_t* dpred, aql_stream_t stream);
+/* MapperNet.forward / its weight gradient  utils/models.py:110-115                                                 */
+int aql_mapper_fwd(const float* msg, const float* E, int nb, int bits, int r, float* S32, bf16_t* S16,
+                   aql_stream_t stream);
+int aql_mapper_bwd(const float* msg, const float* dS, int nb, int bits, int r, float* dE, aql_stream_t stream);
+/* SecretEncoder.encode  utils/models.py:57-64,70-72 (out = conv(...) * out_scale, NCHW fp32)                        */
+int aql_secret_encoder_fwd(const float* msg, const float* lin_w, const float* lin_b, const float* conv_w,
+                           const float* conv_b, int nb, int bits, int base_res, int res, float out_scale,
+                           float* hidden_scratch, float* out, aql_stream_t stream);
+/* fp32 LoRA master weight [rows,cols] -> bf16 copy and bf16 transposed copy (autocast's casts, lora_modules.py:10-13) */
+int aql_cast_transpose(const float* w, int rows, int cols, bf16_t* out, bf16_t* outT, aql_stream_t stream);
+/* dS[b,j] += sum_{m in sample b} dTs[m,j]*T[m,j]: gradient of the diagonal (autograd of diag_embed, :16-17)         */
+int aql_lora_ds(const bf16_t* dTs, const bf16_t* T, int nb, int rows_per_sample, int r, float* dS, aql_stream_t stream);
+/* clip_grad_norm_ + torch.optim.AdamW on flat fp32 buffers  train/ppft_train.py:1059-1066, 779-787                 */
+int aql_sumsq_f32(const float* g, long n, float* out, aql_stream_t stream);
+int aql_clipnorm_adamw(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float max_norm,
+                       const float* lr, float beta1, float beta2, float eps, float wd, const int* step,
+                       aql_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -21,7 +21,7 @@ def tiny_unet(device="cpu", dtype=torch.float32, cfg=None):
     return unet
 
 
-def tiny_lora(keys, unet, rank=TINY_RANK, up_std=0.02):
+def tiny_lora(keys, unet, rank=TINY_RANK, up_std=0.1):
     """{key: (down_w, up_w)} with the same names/shapes as tests/golden/make_golden.py."""
     out = {}
     for k in keys:
@@ -36,6 +36,6 @@ def tiny_lora(keys, unet, rank=TINY_RANK, up_std=0.02):
 
 def ppft_inputs(cfg=TINY, B=2, bits=48, res=16, rank=TINY_RANK, device="cpu"):
     return dict(E=T("ppft.mapper.E", (bits, rank), device=device), msg=synth.bits("ppft.msg", (B, bits), SEED, device),
-                z=T("ppft.z", (B, 4, res, res), device=device), wm=T("ppft.wm", (B, 4, res, res), 0.1, device),
+                z=T("ppft.z", (B, 4, res, res), device=device), wm=T("ppft.wm", (B, 4, res, res), 0.5, device),
                 eps=T("ppft.eps", (B, 4, res, res), device=device), t=synth.randint("ppft.t", (B,), 1000, SEED, device),
                 ctx=T("ppft.ctx", (B, 77, cfg["cross_attention_dim"]), device=device))

@@ -276,7 +276,7 @@ def build_reference_unet(ou, lm, cfg, rank, seed_tag="unet"):
             fwd = lm.CustomLoRACompatibleLinearforward
         with torch.no_grad():
             lora.down.weight.copy_(synth.normal(key + ".lora.down", lora.down.weight.shape, 1.0 / rank, SEED))
-            lora.up.weight.copy_(synth.normal(key + ".lora.up", lora.up.weight.shape, 0.02, SEED))
+            lora.up.weight.copy_(synth.normal(key + ".lora.up", lora.up.weight.shape, 0.1, SEED))
         m.lora_layer = lora
         m.forward = types.MethodType(lambda self, x, _f=fwd: _f(self, x, holder.scale), m)
         loras[key] = lora
@@ -292,7 +292,7 @@ def gen_tiny_ppft(lm, models, ou):
         mapper.bit_embeddings.weight.copy_(T("ppft.mapper.E", (bits, TINY_RANK)))
     msg = synth.bits("ppft.msg", (B, bits), SEED)
     z = T("ppft.z", (B, 4, 16, 16))
-    wm = T("ppft.wm", (B, 4, 16, 16), 0.1)
+    wm = T("ppft.wm", (B, 4, 16, 16), 0.5)
     eps = T("ppft.eps", (B, 4, 16, 16))
     t = synth.randint("ppft.t", (B,), 1000, SEED)
     ctx = T("ppft.ctx", (B, 77, cfg["cross_attention_dim"]))

@@ -1,0 +1,47 @@
+"""CPU: the C-ABI library builds, loads, and exports exactly the symbols include/aqualora_hip.h declares, with the
+argument counts the ctypes binding uses.  No compute call is made (no GPU here)."""
+import os
+import re
+
+from tests.conftest import ROOT
+
+
+def _header_decls():
+    text = open(os.path.join(ROOT, "include", "aqualora_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(?:int|long|const char\*)\s+(aql_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        n = 0 if args in ("void", "") else len([a for a in args.split(",") if a.strip()])
+        decls[m.group(1)] = n
+    return decls
+
+
+def test_header_matches_binding_and_library():
+    import __graft_entry__ as ge
+    ge.build()
+    from aqualora_amd import _lib
+    decls = _header_decls()
+    lib = _lib.load()
+    bound = dict((k, len(v)) for k, v in _lib.SIGNATURES.items())
+    for name, n in decls.items():
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+        if name in bound:
+            assert bound[name] == n, (name, bound[name], n)
+    for name in bound:
+        assert name in decls, f"{name} bound in _lib.py but missing from include/aqualora_hip.h"
+    assert set(decls) - set(bound) <= {"aql_last_error", "aql_groupnorm_scratch_floats"}
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a CPU-only box")
+    from aqualora_amd import _lib, lora
+    host = lora.LoRACompatibleLinear(16, 16)
+    with pytest.raises(_lib.AqlError):
+        host(torch.zeros(2, 4, 16))
+    from aqualora_amd.watermark import MapperNet
+    with pytest.raises(_lib.AqlError):
+        MapperNet(8, 8)(torch.zeros(1, 8))

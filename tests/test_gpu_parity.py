@@ -1,0 +1,218 @@
+"""GPU parity tests (MI355X): HIP path through the C-ABI vs the CPU oracle and the reference-generated golden vectors.
+
+Tolerances (bf16 storage, fp32 accumulation; the oracle mirrors the bf16 rounding points):
+  single op vs fp32 golden ............ 1.5e-2 of the tensor's max (bf16 has 8 mantissa bits)
+  tiny U-Net output vs bf16 oracle ..... 3e-2 ; vs fp32 golden 5e-2
+  LoRA gradient norms .................. 5e-2 relative
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.common import LORA_CASES, SEED, T, TINY, TINY_RANK, ppft_inputs, tiny_lora, tiny_unet
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def relerr(a, b):
+    a = torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a).detach().double().cpu()
+    b = torch.as_tensor(np.asarray(b) if not torch.is_tensor(b) else b).detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def test_library_is_loaded_and_complete():
+    from aqualora_amd import _lib
+    lib = _lib.load()
+    for name in _lib.SIGNATURES:
+        assert hasattr(lib, name)
+
+
+def test_lora_forwards_vs_reference_golden(golden):
+    from aqualora_amd import lora as AL
+    g = golden("lora_forwards.npz")
+    for tag, cin, cout, n, r in LORA_CASES:
+        host = AL.LoRACompatibleLinear(cin, cout, device=DEV, dtype=torch.bfloat16)
+        ll = AL.LoRALinearLayer(cin, cout, r, device=DEV, dtype=torch.float32)
+        with torch.no_grad():
+            host.weight.copy_(T(f"{tag}.w", (cout, cin), cin ** -0.5))
+            host.bias.copy_(T(f"{tag}.b", (cout,), 0.02))
+            ll.down.weight.copy_(T(f"{tag}.down", (r, cin), 1.0 / r))
+            ll.up.weight.copy_(T(f"{tag}.up", (cout, r), 0.05))
+        host.set_lora_layer(ll)
+        x = T(f"{tag}.x", (2, n, cin), device=DEV).to(torch.bfloat16).requires_grad_(True)
+        S = (T(f"{tag}.S", (2, r), 0.3, DEV) + 1.0).requires_grad_(True)
+        y = AL.CustomLoRACompatibleLinearforward(host, x, S)
+        y.backward(T(f"{tag}.dy", (2, n, cout), device=DEV).to(torch.bfloat16))
+        assert relerr(y, g[f"{tag}.y"]) < 1.5e-2
+        assert relerr(x.grad, g[f"{tag}.dx"]) < 1.5e-2
+        assert relerr(S.grad, g[f"{tag}.dS"]) < 2e-2
+        assert relerr(ll.down.weight.grad, g[f"{tag}.ddown"]) < 2e-2
+        assert relerr(ll.up.weight.grad, g[f"{tag}.dup"]) < 2e-2
+        assert relerr(AL.CustomLoRACompatibleLinearforward(host, x.detach(), 0.5), g[f"{tag}.y_float_scale"]) < 1.5e-2
+        assert relerr(AL.CustomLoRALinearLayerforward(ll, x.detach(), S.detach()), g[f"{tag}.lora_only"]) < 2e-2
+        if f"{tag}.conv_y" in g:
+            hc = AL.LoRACompatibleConv(cin, cout, 1, device=DEV, dtype=torch.bfloat16)
+            lc = AL.LoRAConv2dLayer(cin, cout, r).to(DEV)
+            with torch.no_grad():
+                hc.weight.copy_(host.weight.view(cout, cin, 1, 1)); hc.bias.copy_(host.bias)
+                lc.down.weight.copy_(ll.down.weight.view(r, cin, 1, 1)); lc.up.weight.copy_(ll.up.weight.view(cout, r, 1, 1))
+            hc.set_lora_layer(lc)
+            xc = x.detach().permute(0, 2, 1).reshape(2, cin, 4, n // 4)
+            assert relerr(AL.CustomLoRACompatibleConvforward(hc, xc, S.detach()), g[f"{tag}.conv_y"]) < 1.5e-2
+            assert relerr(AL.CustomLoRAConv2dLayerforward(lc, xc, S.detach()),
+                          g[f"{tag}.conv_y"] - torch.nn.functional.conv2d(
+                              xc.float().cpu(), hc.weight.detach().float().cpu(),
+                              hc.bias.detach().float().cpu()).numpy()) < 5e-2
+
+
+def test_watermark_modules_vs_reference_golden(golden):
+    from aqualora_amd import synth
+    from aqualora_amd.watermark import MapperNet, SecretEncoder, customDDPMScheduler
+    from oracle import ppft_oracle as O
+    g = golden("watermark.npz")
+    mp = MapperNet(48, 32).to(DEV)
+    with torch.no_grad():
+        mp.bit_embeddings.weight.copy_(T("mapper.E", (48, 32)))
+    msg = synth.bits("msg", (4, 48), SEED, DEV)
+    S = mp(msg)
+    S.backward(T("mapper.dS", (4, 32), device=DEV))
+    assert relerr(S, g["S"]) < 1e-5 and relerr(mp.bit_embeddings.weight.grad, g["dE"]) < 1e-5
+    enc = SecretEncoder(48).to(DEV)
+    assert enc.encode(msg).abs().max().item() == 0.0  # zero-init invariant (models.py:63)
+    with torch.no_grad():
+        enc.secret_scaler[0].weight.copy_(T("enc.lin.w", (1024, 48), 48 ** -0.5))
+        enc.secret_scaler[0].bias.copy_(T("enc.lin.b", (1024,), 0.1))
+        enc.secret_scaler[5].weight.copy_(T("enc.conv.w", (4, 4, 3, 3), 0.05))
+        enc.secret_scaler[5].bias.copy_(T("enc.conv.b", (4,), 0.01))
+    x = T("enc.x", (4, 4, 64, 64), device=DEV)
+    xc, c = enc(x, msg)
+    assert relerr(c, g["c"]) < 1e-5
+    assert abs(xc.double().sum().item() - float(g["x_plus_c_checksum"])) < 1e-2
+    sch = customDDPMScheduler(device=DEV)
+    z, e = T("an.x", (4, 4, 64, 64), device=DEV), T("an.n", (4, 4, 64, 64), device=DEV)
+    t = torch.tensor([0, 1, 500, 999], device=DEV)
+    a, b = sch.add_noise_pair(z, c, e, t)
+    assert relerr(a, O.add_noise(z.cpu(), e.cpu(), t.cpu())) < 5e-3
+    assert relerr(b, O.add_noise((z + c).cpu(), e.cpu(), t.cpu())) < 5e-3
+
+
+def _gpu_tiny(rank=TINY_RANK, up_std=0.1):
+    from aqualora_amd.lora import inject_lora, patch_lora_forwards
+    from aqualora_amd.unet import lora_keys
+    unet = tiny_unet(DEV, torch.bfloat16)
+    keys = lora_keys(unet)
+    lw = tiny_lora(keys, unet, rank, up_std)
+    state = {}
+    for k, (d, u) in lw.items():
+        state[k + ".down.weight"], state[k + ".up.weight"] = d, u
+    inject_lora(unet, rank, keys, state)
+    patch_lora_forwards(unet)
+    return unet, keys, lw
+
+
+def test_tiny_unet_forward_vs_oracle_and_golden(golden):
+    from oracle import ppft_oracle as O
+    g = golden("tiny_ppft.npz")
+    unet, keys, lw = _gpu_tiny()
+    inp = ppft_inputs()
+    acp = O.alphas_cumprod()
+    x_t = O.add_noise(inp["z"], inp["eps"], inp["t"], acp)
+    x_wm = O.add_noise(inp["z"] + inp["wm"], inp["eps"], inp["t"], acp)
+    S = O.mapper(inp["msg"], inp["E"])
+    ref = O.UNetOracle(tiny_unet().state_dict(), TINY, lw, bf16=True)
+    with torch.no_grad():
+        clean_o = ref.forward(x_t, inp["t"], inp["ctx"], None)
+        pred_o = ref.forward(x_wm, inp["t"], inp["ctx"], S)
+        clean = unet(x_t.to(DEV), inp["t"].to(DEV), inp["ctx"].to(DEV), cross_attention_kwargs={"scale": None}).sample
+        clean0 = unet(x_t.to(DEV), inp["t"].to(DEV), inp["ctx"].to(DEV),
+                      cross_attention_kwargs={"scale": torch.zeros_like(S).to(DEV)}).sample
+        pred = unet(x_wm.to(DEV), inp["t"].to(DEV), inp["ctx"].to(DEV), cross_attention_kwargs={"scale": S.to(DEV)}).sample
+    assert torch.equal(clean, clean0)  # skipping the LoRA branch == the reference's zero scale, bit for bit
+    assert relerr(clean, clean_o) < 3e-2 and relerr(pred, pred_o) < 3e-2
+    assert relerr(clean, g["clean"]) < 5e-2 and relerr(pred, g["pred"]) < 5e-2
+
+
+def test_tiny_ppft_step_vs_golden(golden):
+    from aqualora_amd.ppft import PPFTTrainer
+    from aqualora_amd.watermark import MapperNet, SecretEncoder
+    g = golden("tiny_ppft.npz")
+    unet, keys, lw = _gpu_tiny()
+    inp = ppft_inputs(device=DEV)
+    mapper = MapperNet(48, TINY_RANK)
+    with torch.no_grad():
+        mapper.bit_embeddings.weight.copy_(inp["E"])
+    enc = SecretEncoder(48, base_res=8, resolution=16)
+    tr = PPFTTrainer(unet, mapper, enc, TINY_RANK, learning_rate=1e-4)
+    # inject the golden watermark residual (the fixture's wm is synthetic, not an encoder output)
+    tr.sec_encoder.encode = lambda m, out_scale=1.0: inp["wm"]
+    loss, pred, clean = tr.forward_backward(inp["z"], inp["msg"], inp["eps"], inp["t"], inp["ctx"])
+    assert relerr(clean, g["clean"]) < 5e-2 and relerr(pred, g["pred"]) < 5e-2
+    assert abs(loss.item() - float(g["loss"])) < 0.15 * float(g["loss"])
+    # Gradients.  bf16 activation storage perturbs per-tensor LoRA gradients of this tiny config by 10-20 % against
+    # the fp32 golden (the bf16-mirroring oracle shows the same, see DESIGN.md "tolerances"), so the tight check is
+    # HIP vs the bf16-mirroring oracle and the golden check is a looser sanity bound.
+    from oracle import ppft_oracle as O
+    cpu = ppft_inputs()
+    lo = {k: (d.clone().requires_grad_(True), u.clone().requires_grad_(True)) for k, (d, u) in lw.items()}
+    Eo = cpu["E"].clone().requires_grad_(True)
+    lo_loss, _, _, _ = O.ppft_loss(tiny_unet().state_dict(), TINY, lo, Eo, cpu["msg"], cpu["z"], cpu["wm"], cpu["eps"],
+                                   cpu["t"], cpu["ctx"], bf16=True)
+    lo_loss.backward()
+    assert abs(loss.item() - lo_loss.item()) < 0.05 * lo_loss.item()
+
+    def l2rel(a, b):
+        a, b = a.detach().double().cpu().flatten(), torch.as_tensor(np.asarray(b)).double().flatten()
+        return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+    worst_o = worst_g = 0.0
+    all_o = []
+    gsq = 0.0
+    for k in keys:
+        lay = unet.get_submodule(k).lora_layer
+        for got, want in ((lay.down.weight.grad, lo[k][0].grad), (lay.up.weight.grad, lo[k][1].grad)):
+            gsq += got.double().pow(2).sum().item()
+            if want.norm() > 0.05 * max(p.grad.norm() for pr in lo.values() for p in pr):
+                all_o.append(l2rel(got, want.reshape(got.shape)))
+                worst_o = max(worst_o, all_o[-1])
+    for name in g.files:
+        if name.startswith("g."):
+            key, which = name[2:].rsplit(".", 1)
+            lay = unet.get_submodule(key).lora_layer
+            worst_g = max(worst_g, l2rel((lay.down if which == "down" else lay.up).weight.grad, g[name]))
+    # measured on MI355X: median 0.05, worst 0.11 (uniform over site types: bf16 rounding of the backward signal)
+    assert worst_o < 0.15 and float(np.median(all_o)) < 0.08, (worst_o, float(np.median(all_o)))
+    assert worst_g < 0.15, worst_g
+    assert l2rel(mapper.bit_embeddings.weight.grad, Eo.grad) < 0.10
+    assert abs(gsq ** 0.5 - float(g["total_norm"])) < 0.1 * float(g["total_norm"])
+    tr.exchange_gradients()
+    tr.optimizer_step()
+    k0 = keys[0]
+    lay = unet.get_submodule(k0).lora_layer
+    assert relerr(lay.down.weight, g["p." + k0 + ".down"]) < 1e-3
+    assert relerr(lay.up.weight, g["p." + k0 + ".up"]) < 5e-2
+    assert relerr(mapper.bit_embeddings.weight, g["p.mapper"]) < 1e-3
+    total = float(g["total_norm"])
+    assert abs(tr.grad_norm() - total) < 0.1 * total
+
+
+def test_checkpoint_roundtrip_and_consumer_contract(tmp_path, golden):
+    from aqualora_amd.checkpoint import load_lora_state, save_lora_weights
+    from aqualora_amd.lora import inject_lora
+    from aqualora_amd.watermark import MapperNet
+    from safetensors.torch import load_file
+    unet, keys, lw = _gpu_tiny()
+    mp = MapperNet(48, TINY_RANK)
+    save_lora_weights(str(tmp_path), unet, mp)
+    sd = load_file(str(tmp_path / "pytorch_lora_weights.safetensors"))
+    assert sorted(sd.keys()) == list(golden("checkpoint_layout.npz")["names"])
+    # create_wm_lora.py:24-41 branches on these substrings
+    for k in sd:
+        assert "unet" in k and (("attn" in k or "ff" in k) or ("proj_in" in k or "proj_out" in k))
+        assert ("up.weight" in k) or ("down.weight" in k)
+        assert ".alpha" not in k
+    back = load_lora_state(str(tmp_path))
+    for k in keys:
+        assert torch.equal(back[k + ".down.weight"], lw[k][0]) and torch.equal(back[k + ".up.weight"], lw[k][1])
+    assert list(torch.load(str(tmp_path / "mapper.pt")).keys()) == ["bit_embeddings.weight"]
