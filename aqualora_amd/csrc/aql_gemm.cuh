@@ -183,7 +183,7 @@ struct EpiParams {
   const bf16_t* rowscale;  // [nsamples][N]
   const bf16_t* rowbias;   // [nsamples][N] added (bf16 add) after bias, before the residual; or null
   int rows_per_sample;
-  int act;                 // 0 none, 1 GEGLU pairs (col j: value, col j+BN/2 inside tile: gate)  [reserved]
+  int trans_out;           // EPI_ATOMIC only: write C^T, i.e. element (m,n) goes to Cf[n*ldcf + m]
   // EPI_SLAB / EPI_ATOMIC: fp32 output
   float* Cf;               // slab base [splits][M][ldcf] or atomic target [M][ldcf]
   long ldcf;
@@ -449,6 +449,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs<LA, LB> g
           const int n = n0 + wn0 + j * 32 + q * 8 + (lane >> 5) * 4;
           if (m >= g.M || n >= g.N) continue;
           float* p = out + (long)m * ep.ldcf + n;
+          if constexpr (EPI == EPI_ATOMIC) {
+            if (ep.trans_out) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) atomicAdd(out + (long)(n + e) * ep.ldcf + m, ep.alpha * acc[i][j][q * 4 + e]);
+              continue;
+            }
+          }
           if constexpr (EPI == EPI_SLAB) {
             *reinterpret_cast<float4*>(p) =
                 make_float4(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);

@@ -73,39 +73,68 @@ struct OutSpec {
 };
 
 inline int pick_splits(int tiles, int kt_total, long M, int N, size_t ws_bytes) {
-  if (tiles >= 192 || kt_total < 8) return 1;
-  int s = (384 + tiles - 1) / tiles;
-  if (s > kt_total / 4) s = kt_total / 4;
-  if (s > 32) s = 32;
+  // split-K pays only when K is deep (the fp32 slabs cost 8 B per output element per split) and the grid is small
+  if (tiles >= 128 || kt_total < 32) return 1;
+  int s = (256 + tiles - 1) / tiles;
+  if (s > kt_total / 8) s = kt_total / 8;
+  if (s > 16) s = 16;
   while (s > 1 && (size_t)s * (size_t)M * (size_t)N * 4u > ws_bytes) --s;
   return s < 1 ? 1 : s;
 }
 
-// Dispatch one bf16-output GEMM over the tile configurations; falls back to split-K slabs + finalize when the
-// tile count cannot fill 256 CUs and the caller supplied a workspace.
+template <class LA, class LB, int EPI>
+void launch_cfg(int cfg, const GemmArgs<LA, LB>& g, hipStream_t stream) {
+  switch (cfg) {
+    case 0: launch_gemm<128, 32, 32, 32, LA, LB, EPI>(g, stream); break;
+    case 1: launch_gemm<128, 128, 64, 64, LA, LB, EPI>(g, stream); break;
+    case 2: launch_gemm<128, 64, 64, 32, LA, LB, EPI>(g, stream); break;
+    default: launch_gemm<64, 64, 32, 32, LA, LB, EPI>(g, stream); break;
+  }
+}
+
+// tile choice: the largest tile that still yields >= ~1 workgroup per CU; cfg ids as in launch_cfg
+inline int pick_cfg(long M, int N, int kt_total, bool can_split, int* tiles) {
+  if (N <= 32) {
+    *tiles = aql_cdiv(M, 128);
+    return 0;
+  }
+  const int t128 = aql_cdiv(M, 128) * aql_cdiv(N, 128);
+  const int t64 = aql_cdiv(M, 128) * aql_cdiv(N, 64);
+  const int t6464 = aql_cdiv(M, 64) * aql_cdiv(N, 64);
+  const bool waste128 = (N % 128 != 0) && (N % 128 <= 64);
+  if (t128 >= 240 && !waste128) {
+    *tiles = t128;
+    return 1;
+  }
+  if (t64 >= 240 || (waste128 && t128 >= 240)) {
+    *tiles = t64;
+    return 2;
+  }
+  if (can_split && kt_total >= 32) {  // deep K (3x3 convs at 8x8 .. 32x32): big tile + split-K beats small tiles
+    *tiles = waste128 ? t64 : t128;
+    return waste128 ? 2 : 1;
+  }
+  *tiles = t6464;
+  return 3;
+}
+
+// Dispatch one bf16-output GEMM over the tile configurations; split-K slabs + finalize when the grid cannot fill
+// 256 CUs, K is deep and the caller supplied a workspace.
 template <class LA, class LB>
 int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_bytes, hipStream_t stream,
                   const char* name) {
   g.epi = EpiParams{};
   g.epi.rows_per_sample = o.rows_per_sample > 0 ? o.rows_per_sample : 1;
   const int kt_total = g.ktiles0 + g.ktiles1;
-  const bool narrow = (g.N <= 32);
-  const bool n64 = !narrow && (g.N % 128 != 0) && (g.N % 128 <= 64);
-  const int BNsel = narrow ? 32 : (n64 ? 64 : 128);
-  const int tiles = aql_cdiv(g.M, 128) * aql_cdiv(g.N, BNsel);
+  int tiles = 0;
+  const int cfg = pick_cfg(g.M, g.N, kt_total, ws != nullptr && o.C2 == nullptr, &tiles);
   int splits = 1;
   if (ws != nullptr && o.C2 == nullptr) splits = pick_splits(tiles, kt_total, g.M, g.N, ws_bytes);
-  const bool slab = (splits > 1);
   g.splits = splits;
-  if (slab) {
+  if (splits > 1) {
     g.epi.Cf = ws;
     g.epi.ldcf = g.N;
-    if (narrow)
-      launch_gemm<128, 32, 32, 32, LA, LB, EPI_SLAB>(g, stream);
-    else if (n64)
-      launch_gemm<128, 64, 64, 32, LA, LB, EPI_SLAB>(g, stream);
-    else
-      launch_gemm<128, 128, 64, 64, LA, LB, EPI_SLAB>(g, stream);
+    launch_cfg<LA, LB, EPI_SLAB>(cfg, g, stream);
     AQL_CHECK_LAUNCH(name);
     const long nchunk = (long)g.M * (g.N / 4);
     int blocks = (int)((nchunk + 255) / 256);
@@ -124,12 +153,7 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
   g.epi.ldc2 = o.ldc2;
   g.epi.rowscale = o.rowscale;
   g.epi.rowbias = o.rowbias;
-  if (narrow)
-    launch_gemm<128, 32, 32, 32, LA, LB, EPI_BF16>(g, stream);
-  else if (n64)
-    launch_gemm<128, 64, 64, 32, LA, LB, EPI_BF16>(g, stream);
-  else
-    launch_gemm<128, 128, 64, 64, LA, LB, EPI_BF16>(g, stream);
+  launch_cfg<LA, LB, EPI_BF16>(cfg, g, stream);
   AQL_CHECK_LAUNCH(name);
   return AQL_OK;
 }
@@ -176,12 +200,85 @@ extern "C" int aql_gemm_bf16(const bf16_t* A, long lda, const bf16_t* B, long ld
   return run_bf16_gemm(g, o, ws, ws_bytes, stream, "aql_gemm_bf16");
 }
 
+// Skinny rank-r "down" GEMM for r <= 64: HBM-bound (reads X once), so no LDS staging of operands.  A workgroup owns
+// 16 rows; its 4 wavefronts split K in interleaved 32-wide steps (together they read 256 contiguous bytes per row),
+// stream X straight into MFMA B-operands, and the four partial r x 16 accumulators are summed through LDS.
+template <int RF>
+__global__ __launch_bounds__(256) void lora_down_skinny_kernel(const bf16_t* __restrict__ X, long ldx, long M, int K,
+                                                               const bf16_t* __restrict__ A,
+                                                               const bf16_t* __restrict__ S, int rps,
+                                                               bf16_t* __restrict__ T, bf16_t* __restrict__ Ts) {
+  __shared__ f32x4_t part[4][RF][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 16 + (lane & 15);
+  const int g = lane >> 4;
+  const bool ok = row < M;
+  const bf16_t* xp = X + (ok ? row : 0) * ldx + g * 8;
+  const bf16_t* ap = A + (long)(lane & 15) * K + g * 8;
+  f32x4_t acc[RF];
+#pragma unroll
+  for (int f = 0; f < RF; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  constexpr int D = 4;  // steps in flight per wavefront
+  const int nsteps = K / 32;
+  for (int s0 = wave; s0 < nsteps; s0 += 4 * D) {
+    uint4 xv[D], av[D][RF];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int s = s0 + 4 * d;
+      const bool in = ok && s < nsteps;
+      xv[d] = in ? *reinterpret_cast<const uint4*>(xp + s * 32) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+      for (int f = 0; f < RF; ++f)
+        av[d][f] = (s < nsteps) ? *reinterpret_cast<const uint4*>(ap + (long)f * 16 * K + s * 32)
+                                : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+      for (int f = 0; f < RF; ++f)
+        acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&av[d][f]),
+                                                         *reinterpret_cast<const bf16x8_t*>(&xv[d]), acc[f], 0, 0, 0);
+  }
+#pragma unroll
+  for (int f = 0; f < RF; ++f) part[wave][f][lane] = acc[f];
+  __syncthreads();
+  // wave w finalises fragment(s) f = w, w+4, ...: rows j = lane&15, r index f*16 + g*4 + e
+  const int r = RF * 16;
+  for (int f = wave; f < RF; f += 4) {
+    f32x4_t v = part[0][f][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const f32x4_t u = part[w][f][lane];
+      v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+    }
+    if (!ok) continue;
+    const int c = f * 16 + g * 4;
+    const uint2 t = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    *reinterpret_cast<uint2*>(T + row * r + c) = t;
+    const uint2 sv = *reinterpret_cast<const uint2*>(S + (row / rps) * r + c);
+    *reinterpret_cast<uint2*>(Ts + row * r + c) =
+        make_uint2(pack_bf16x2(bf16lo(t.x) * bf16lo(sv.x), bf16hi(t.x) * bf16hi(sv.x)),
+                   pack_bf16x2(bf16lo(t.y) * bf16lo(sv.y), bf16hi(t.y) * bf16hi(sv.y)));
+  }
+}
+
 // T = X.Adown^T (bf16) and Ts = T * S[sample]  -- the rank-r "down" half of the watermark LoRA.
 extern "C" int aql_lora_down(const bf16_t* X, long ldx, long M, int K, const bf16_t* Adown, int r, const bf16_t* S,
                              int rows_per_sample, bf16_t* T, bf16_t* Ts, hipStream_t stream) {
   AQL_CHECK_ARG(X && Adown && S && T && Ts, "aql_lora_down: null operand");
   AQL_CHECK_ARG(M > 0 && r > 0 && r % 8 == 0 && K % 8 == 0 && ldx % 8 == 0 && rows_per_sample > 0,
                 "aql_lora_down: bad shape M=%ld r=%d K=%d", M, r, K);
+  if (r % 16 == 0 && r <= 64 && K % 32 == 0) {
+    const unsigned blocks = (unsigned)((M + 15) / 16);
+    switch (r / 16) {
+      case 1: hipLaunchKernelGGL(lora_down_skinny_kernel<1>, dim3(blocks), dim3(256), 0, stream, X, ldx, M, K, Adown, S, rows_per_sample, T, Ts); break;
+      case 2: hipLaunchKernelGGL(lora_down_skinny_kernel<2>, dim3(blocks), dim3(256), 0, stream, X, ldx, M, K, Adown, S, rows_per_sample, T, Ts); break;
+      case 3: hipLaunchKernelGGL(lora_down_skinny_kernel<3>, dim3(blocks), dim3(256), 0, stream, X, ldx, M, K, Adown, S, rows_per_sample, T, Ts); break;
+      default: hipLaunchKernelGGL(lora_down_skinny_kernel<4>, dim3(blocks), dim3(256), 0, stream, X, ldx, M, K, Adown, S, rows_per_sample, T, Ts); break;
+    }
+    AQL_CHECK_LAUNCH("aql_lora_down");
+    return AQL_OK;
+  }
   GemmArgs<PlainLoader, PlainLoader> g;
   g.a0 = plain(X, ldx, M, K);
   g.b0 = plain(Adown, K, r, K);
@@ -265,38 +362,36 @@ extern "C" int aql_gemm_tn_f32(const bf16_t* U, long ldu, const bf16_t* V, long 
   AQL_CHECK_ARG(U && V && C, "aql_gemm_tn_f32: null operand");
   AQL_CHECK_ARG(M > 0 && P % 8 == 0 && Q % 8 == 0 && ldu % 8 == 0 && ldv % 8 == 0 && M < (1L << 31),
                 "aql_gemm_tn_f32: bad shape M=%ld P=%d Q=%d", M, P, Q);
+  // the narrow side (the LoRA rank) always goes on the weight-side (BN) operand; swap + transposed write if needed
+  const bool swap = (P <= 32 && Q > 32);
   GemmArgs<TransLoader, TransLoader> g;
-  g.a0.base = U;
-  g.a0.ld = ldu;
-  g.a0.rows = P;
+  g.a0.base = swap ? V : U;
+  g.a0.ld = swap ? ldv : ldu;
+  g.a0.rows = swap ? Q : P;
   g.a0.K = (int)M;
-  g.b0.base = V;
-  g.b0.ld = ldv;
-  g.b0.rows = Q;
+  g.b0.base = swap ? U : V;
+  g.b0.ld = swap ? ldu : ldv;
+  g.b0.rows = swap ? P : Q;
   g.b0.K = (int)M;
   g.a1 = g.a0;
   g.b1 = g.b0;
   g.ktiles0 = aql_cdiv(M, BK);
   g.ktiles1 = 0;
-  g.M = P;
-  g.N = Q;
+  g.M = g.a0.rows;
+  g.N = g.b0.rows;
   g.epi = EpiParams{};
   g.epi.Cf = C;
   g.epi.ldcf = ldc;
   g.epi.alpha = alpha;
-  const bool narrow = (Q <= 32);
-  const bool n64 = !narrow && (Q % 128 != 0) && (Q % 128 <= 64);
-  const int tiles = aql_cdiv(P, 128) * aql_cdiv(Q, narrow ? 32 : (n64 ? 64 : 128));
-  int splits = (512 + tiles - 1) / tiles;
-  if (splits > g.ktiles0) splits = g.ktiles0;
+  g.epi.trans_out = swap ? 1 : 0;
+  int tiles = 0;
+  int cfg = pick_cfg(g.M, g.N, g.ktiles0, false, &tiles);
+  if (cfg == 3) cfg = 2, tiles = aql_cdiv(g.M, 128) * aql_cdiv(g.N, 64);
+  int splits = (256 + tiles - 1) / tiles;
+  if (splits > g.ktiles0 / 4) splits = g.ktiles0 / 4;
   if (splits < 1) splits = 1;
   g.splits = splits;
-  if (narrow)
-    launch_gemm<128, 32, 32, 32, TransLoader, TransLoader, EPI_ATOMIC>(g, stream);
-  else if (n64)
-    launch_gemm<128, 64, 64, 32, TransLoader, TransLoader, EPI_ATOMIC>(g, stream);
-  else
-    launch_gemm<128, 128, 64, 64, TransLoader, TransLoader, EPI_ATOMIC>(g, stream);
+  launch_cfg<TransLoader, TransLoader, EPI_ATOMIC>(cfg, g, stream);
   AQL_CHECK_LAUNCH("aql_gemm_tn_f32");
   return AQL_OK;
 }

@@ -99,5 +99,42 @@ class PPFTTrainer:
         self.lr_t.fill_(self.base_lr * self.lr_lambda(self.global_step))
         return loss
 
+    # ---------------------------------------------------------------------------------------------
+    def capture(self, batch, warmup=2):
+        """Capture the step into HIP graphs (torch.cuda.CUDAGraph == hipGraph on ROCm): one graph for
+        forward+backward, one for clip+AdamW+weight re-cast; the gradient all-reduce runs between them on the same
+        stream.  ~3.7k kernel launches per step become two graph launches, which removes the host from the critical
+        path.  Returns ``run(z, msg, eps, t, ctx) -> loss`` that copies the inputs into static buffers and replays."""
+        static = {k: v.clone() for k, v in batch.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.forward_backward(**static)
+                self.exchange_gradients()
+                self.optimizer_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_fb):
+            loss, _, _ = self.forward_backward(**static)
+        with torch.cuda.graph(g_opt, pool=g_fb.pool()):
+            self.optimizer_step()
+        self._graphs = (g_fb, g_opt, static, loss)
+
+        def run(z, msg, eps, t, ctx):
+            for k, v in (("z", z), ("msg", msg), ("eps", eps), ("t", t), ("ctx", ctx)):
+                if v is not static[k]:
+                    static[k].copy_(v)
+            g_fb.replay()
+            self.exchange_gradients()
+            g_opt.replay()
+            self.global_step += 1
+            self.lr_t.fill_(self.base_lr * self.lr_lambda(self.global_step))
+            return loss
+
+        run.is_graph = True
+        return run
+
     def grad_norm(self):
         return float(torch.sqrt(self.sumsq)[0])

@@ -179,7 +179,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"SD1.5 PPFT LoRA rank={args.rank}, 48-bit msg, 512x512 (64x64x4 latents in), "
                                    f"batch={args.batch}/GPU, latent-in (VAE/CLIP outside the path)",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": runner is not tr.step,
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(getattr(runner, "is_graph", False)),
                        "loss": loss_v},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TF, "traffic": None,
