@@ -22,7 +22,7 @@ c_sz = ctypes.c_size_t
 SIGNATURES = {
     "aql_gemm_bf16": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_i, c_p, c_l, c_p, c_l,
                       c_p, c_sz, c_p],
-    "aql_lora_down": [c_p, c_l, c_l, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p],
+    "aql_lora_down": [c_p, c_l, c_l, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p],
     "aql_conv3x3_fwd": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_sz, c_p],
     "aql_conv3x3_bwd_data": [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_sz, c_p],
     "aql_gemm_tn_f32": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_f, c_p, c_l, c_p],
@@ -39,6 +39,7 @@ SIGNATURES = {
     "aql_mapper_bwd": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     "aql_secret_encoder_fwd": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p],
     "aql_cast_transpose": [c_p, c_i, c_i, c_p, c_p, c_p],
+    "aql_cast_transpose_batched": [c_p, c_i, c_i, c_p],
     "aql_lora_ds": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     "aql_sumsq_f32": [c_p, c_l, c_p, c_p],
     "aql_clipnorm_adamw": [c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_p, c_f, c_f, c_f, c_f, c_p, c_p],

@@ -29,16 +29,33 @@ struct RowPitch {
 };
 
 __device__ __forceinline__ uint4 zero4() { return make_uint4(0u, 0u, 0u, 0u); }
+// AND-mask instead of a select: keeps the load unconditional (a select lets LLVM sink the load under a branch, and
+// hipcc then waits vmcnt(0) after every such load)
+__device__ __forceinline__ uint4 mask4(const uint4& v, bool ok) {
+  const uint32_t m = 0u - (uint32_t)ok;
+  return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
+}
 
 // global [rows][ld] (head slice already applied to ptr) -> LDS row-major [64][DH] (zero padded)
 template <int DH>
 __device__ __forceinline__ void stage_rows(char* lds, const bf16_t* g, long ld, int row0, int nrows, int d, int tid) {
   constexpr int CPR = DH / 8;
-  for (int id = tid; id < TILE * CPR; id += 256) {
+  constexpr int NIT = (TILE * CPR + 255) / 256;
+  uint4 v[NIT];
+  // all loads first (unconditional, clamped address, masked after): branches would serialise them on vmcnt(0)
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int id = tid + it * 256;
     const int row = id / CPR, c = id - row * CPR;
-    uint4 v = zero4();
-    if (row0 + row < nrows && c * 8 < d) v = *reinterpret_cast<const uint4*>(g + (long)(row0 + row) * ld + c * 8);
-    *reinterpret_cast<uint4*>(lds + row * RowPitch<DH>::value + c * 16) = v;
+    const bool ok = (id < TILE * CPR) & (row0 + row < nrows) & (c * 8 < d);
+    const uint4 x = *reinterpret_cast<const uint4*>(g + (ok ? (long)(row0 + row) * ld + c * 8 : 0));
+    v[it] = mask4(x, ok);
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int id = tid + it * 256;
+    const int row = id / CPR, c = id - row * CPR;
+    if (id < TILE * CPR) *reinterpret_cast<uint4*>(lds + row * RowPitch<DH>::value + c * 16) = v[it];
   }
 }
 
@@ -46,14 +63,26 @@ __device__ __forceinline__ void stage_rows(char* lds, const bf16_t* g, long ld, 
 template <int DV>
 __device__ __forceinline__ void stage_trans(char* lds, const bf16_t* g, long ld, int row0, int nrows, int d, int tid) {
   constexpr int TASKS = (TILE / 4) * (DV / 8);
-  for (int id = tid; id < TASKS; id += 256) {
+  constexpr int NIT = (TASKS + 255) / 256;
+  uint4 all[NIT][4];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int id = tid + it * 256;
     const int kq = id & 15, cg = id >> 4;
-    uint4 in[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = row0 + kq * 4 + i;
-      in[i] = (row < nrows && cg * 8 < d) ? *reinterpret_cast<const uint4*>(g + (long)row * ld + cg * 8) : zero4();
+      const bool ok = (id < TASKS) & (row < nrows) & (cg * 8 < d);
+      const uint4 x = *reinterpret_cast<const uint4*>(g + (ok ? (long)row * ld + cg * 8 : 0));
+      all[it][i] = mask4(x, ok);
     }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int id = tid + it * 256;
+    if (id >= TASKS) continue;
+    const int kq = id & 15, cg = id >> 4;
+    const uint4* in = all[it];
     const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&in[0]);
     const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&in[1]);
     const uint32_t* w2 = reinterpret_cast<const uint32_t*>(&in[2]);
@@ -84,8 +113,9 @@ __device__ __forceinline__ void load_owner(bf16x8_t (&f)[2][DH / 32], const bf16
 #pragma unroll
     for (int s = 0; s < DH / 32; ++s) {
       const int col = s * 32 + (lane >> 4) * 8;
-      uint4 v = zero4();
-      if (row < nrows && col < d) v = *reinterpret_cast<const uint4*>(g + (long)row * ld + col);
+      const bool ok = (row < nrows) & (col < d);
+      const uint4 x = *reinterpret_cast<const uint4*>(g + (ok ? (long)row * ld + col : 0));
+      uint4 v = mask4(x, ok);
       f[fr][s] = *reinterpret_cast<bf16x8_t*>(&v);
     }
   }

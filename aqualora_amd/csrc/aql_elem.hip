@@ -204,6 +204,42 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
   }
 }
 
+// batched form: one launch for every LoRA tensor.  desc[i] = {src, out, outT, rows, cols, first_tile}; 32x32 tiles.
+struct CastDesc {
+  const float* w;
+  bf16_t* out;
+  bf16_t* outT;
+  int rows, cols;
+  int first_tile, pad;
+};
+__global__ __launch_bounds__(256) void cast_transpose_batched_kernel(const CastDesc* __restrict__ desc, int n) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {  // last descriptor with first_tile <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid].first_tile <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const CastDesc d = desc[lo];
+  const int t = blockIdx.x - d.first_tile;
+  const int tx_tiles = (d.cols + 31) / 32;
+  const int bx = (t % tx_tiles) * 32, by = (t / tx_tiles) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = by + i, c = bx + tx;
+    float v = 0.f;
+    if (r < d.rows && c < d.cols) {
+      v = d.w[(long)r * d.cols + c];
+      d.out[(long)r * d.cols + c] = f32_to_bf16(v);
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = bx + i, r = by + tx;
+    if (r < d.rows && c < d.cols) d.outT[(long)c * d.rows + r] = f32_to_bf16(tile[tx][i]);
+  }
+}
+
 // ---- dS[b, j] = sum_{m in sample b} dTs[m, j] * T[m, j]  (gradient of the per-message diagonal) --------
 __global__ __launch_bounds__(256) void lora_ds_kernel(const bf16_t* __restrict__ dTs, const bf16_t* __restrict__ T,
                                                       int rows_per_sample, int r, float* __restrict__ dS) {
@@ -353,6 +389,13 @@ extern "C" int aql_cast_transpose(const float* w, int rows, int cols, bf16_t* ou
   hipLaunchKernelGGL(cast_transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, stream, w, rows,
                      cols, out, outT);
   AQL_CHECK_LAUNCH("aql_cast_transpose");
+  return AQL_OK;
+}
+extern "C" int aql_cast_transpose_batched(const void* desc, int n, int total_tiles, hipStream_t stream) {
+  AQL_CHECK_ARG(desc && n > 0 && total_tiles > 0, "aql_cast_transpose_batched: bad args");
+  hipLaunchKernelGGL(cast_transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, stream,
+                     static_cast<const CastDesc*>(desc), n);
+  AQL_CHECK_LAUNCH("aql_cast_transpose_batched");
   return AQL_OK;
 }
 extern "C" int aql_lora_ds(const bf16_t* dTs, const bf16_t* T, int nb, int rows_per_sample, int r, float* dS,

@@ -436,9 +436,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs<LA, LB> g
         *reinterpret_cast<uint4*>(ep.C2 + (long)m * ep.ldc2 + n) = o;
       }
     }
-  } else {
-    float* out = ep.Cf;
-    if constexpr (EPI == EPI_SLAB) out += (long)blockIdx.z * g.M * ep.ldcf;
+  } else if constexpr (EPI == EPI_SLAB) {
+    float* out = ep.Cf + (long)blockIdx.z * g.M * ep.ldcf;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int m = m0 + wm0 + i * 32 + (lane & 31);
@@ -448,23 +447,47 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs<LA, LB> g
         for (int q = 0; q < 4; ++q) {
           const int n = n0 + wn0 + j * 32 + q * 8 + (lane >> 5) * 4;
           if (m >= g.M || n >= g.N) continue;
-          float* p = out + (long)m * ep.ldcf + n;
-          if constexpr (EPI == EPI_ATOMIC) {
-            if (ep.trans_out) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) atomicAdd(out + (long)(n + e) * ep.ldcf + m, ep.alpha * acc[i][j][q * 4 + e]);
-              continue;
-            }
-          }
-          if constexpr (EPI == EPI_SLAB) {
-            *reinterpret_cast<float4*>(p) =
-                make_float4(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(p + e, ep.alpha * acc[i][j][q * 4 + e]);
-          }
+          *reinterpret_cast<float4*>(out + (long)m * ep.ldcf + n) =
+              make_float4(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
         }
       }
+    }
+  } else {
+    // EPI_ATOMIC: stage the fp32 tile in LDS so that consecutive lanes hit consecutive addresses of the target
+    // (coalesced global_atomic_add_f32); trans_out writes C^T.
+    static_assert(BM * BN * 4 <= LDS_BYTES, "fp32 tile must fit in the staging LDS");
+    float* ct = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int row = wm0 + i * 32 + (lane & 31);
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = wn0 + j * 32 + q * 8 + (lane >> 5) * 4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // [row][col] for the plain layout, [col][row] for the transposed one: the fast index is the output's
+            if (ep.trans_out) ct[(col + e) * BM + row] = acc[i][j][q * 4 + e];
+            else ct[row * BN + col + e] = acc[i][j][q * 4 + e];
+          }
+        }
+    }
+    __syncthreads();
+    for (int id = tid; id < BM * BN; id += NTHREADS) {
+      int row, col;
+      if (ep.trans_out) {
+        col = id / BM;
+        row = id - col * BM;
+      } else {
+        row = id / BN;
+        col = id - row * BN;
+      }
+      const int m = m0 + row, n = n0 + col;
+      if (m >= g.M || n >= g.N) continue;
+      const float v = ep.alpha * ct[id];
+      if (ep.trans_out) atomicAdd(ep.Cf + (long)n * ep.ldcf + m, v);
+      else atomicAdd(ep.Cf + (long)m * ep.ldcf + n, v);
     }
   }
 }

@@ -2,6 +2,7 @@
 // contract of every symbol and the reference interface (file:line) it replaces.
 #include "aql_gemm.cuh"
 #include <stdarg.h>
+#include <stdlib.h>
 
 using namespace aqlgemm;
 
@@ -102,6 +103,10 @@ inline int pick_cfg(long M, int N, int kt_total, bool can_split, int* tiles) {
   const int t64 = aql_cdiv(M, 128) * aql_cdiv(N, 64);
   const int t6464 = aql_cdiv(M, 64) * aql_cdiv(N, 64);
   const bool waste128 = (N % 128 != 0) && (N % 128 <= 64);
+  if (can_split && kt_total >= 32) {  // deep K (3x3 convs): big tile + split-K beats small tiles (measured)
+    *tiles = waste128 ? t64 : t128;
+    return waste128 ? 2 : 1;
+  }
   if (t128 >= 240 && !waste128) {
     *tiles = t128;
     return 1;
@@ -109,10 +114,6 @@ inline int pick_cfg(long M, int N, int kt_total, bool can_split, int* tiles) {
   if (t64 >= 240 || (waste128 && t128 >= 240)) {
     *tiles = t64;
     return 2;
-  }
-  if (can_split && kt_total >= 32) {  // deep K (3x3 convs at 8x8 .. 32x32): big tile + split-K beats small tiles
-    *tiles = waste128 ? t64 : t128;
-    return waste128 ? 2 : 1;
   }
   *tiles = t6464;
   return 3;
@@ -207,7 +208,9 @@ template <int RF>
 __global__ __launch_bounds__(256) void lora_down_skinny_kernel(const bf16_t* __restrict__ X, long ldx, long M, int K,
                                                                const bf16_t* __restrict__ A,
                                                                const bf16_t* __restrict__ S, int rps,
-                                                               bf16_t* __restrict__ T, bf16_t* __restrict__ Ts) {
+                                                               bf16_t* __restrict__ T, bf16_t* __restrict__ Ts,
+                                                               const bf16_t* __restrict__ Tref,
+                                                               float* __restrict__ dS) {
   __shared__ f32x4_t part[4][RF][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long row = (long)blockIdx.x * 16 + (lane & 15);
@@ -251,9 +254,36 @@ __global__ __launch_bounds__(256) void lora_down_skinny_kernel(const bf16_t* __r
       const f32x4_t u = part[w][f][lane];
       v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
     }
-    if (!ok) continue;
     const int c = f * 16 + g * 4;
     const uint2 t = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    if (Tref != nullptr) {
+      // backward use: this GEMM produced dTs; dS[sample, c+e] += sum_rows dTs * T  (gradient of the diagonal)
+      float pr[4] = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        const uint2 tr = *reinterpret_cast<const uint2*>(Tref + row * r + c);
+        pr[0] = bf16lo(t.x) * bf16lo(tr.x);
+        pr[1] = bf16hi(t.x) * bf16hi(tr.x);
+        pr[2] = bf16lo(t.y) * bf16lo(tr.y);
+        pr[3] = bf16hi(t.y) * bf16hi(tr.y);
+      }
+      if (rps % 16 == 0) {  // the 16 rows of this workgroup belong to one sample: reduce across them first
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) pr[e] += __shfl_xor(pr[e], o, 64);
+        }
+        if ((lane & 15) == 0 && (long)blockIdx.x * 16 < M) {
+          float* dp = dS + ((long)blockIdx.x * 16 / rps) * r + c;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) atomicAdd(dp + e, pr[e]);
+        }
+      } else if (ok) {
+        float* dp = dS + (row / rps) * r + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(dp + e, pr[e]);
+      }
+    }
+    if (!ok) continue;
     *reinterpret_cast<uint2*>(T + row * r + c) = t;
     const uint2 sv = *reinterpret_cast<const uint2*>(S + (row / rps) * r + c);
     *reinterpret_cast<uint2*>(Ts + row * r + c) =
@@ -263,21 +293,26 @@ __global__ __launch_bounds__(256) void lora_down_skinny_kernel(const bf16_t* __r
 }
 
 // T = X.Adown^T (bf16) and Ts = T * S[sample]  -- the rank-r "down" half of the watermark LoRA.
+extern "C" int aql_lora_ds(const bf16_t* dTs, const bf16_t* T, int nb, int rows_per_sample, int r, float* dS,
+                           hipStream_t stream);
+
 extern "C" int aql_lora_down(const bf16_t* X, long ldx, long M, int K, const bf16_t* Adown, int r, const bf16_t* S,
-                             int rows_per_sample, bf16_t* T, bf16_t* Ts, hipStream_t stream) {
-  AQL_CHECK_ARG(X && Adown && S && T && Ts, "aql_lora_down: null operand");
+                             int rows_per_sample, bf16_t* T, bf16_t* Ts, const bf16_t* Tref, float* dS,
+                             hipStream_t stream) {
+  AQL_CHECK_ARG(X && Adown && S && T && Ts && (Tref == nullptr || dS != nullptr), "aql_lora_down: null operand");
   AQL_CHECK_ARG(M > 0 && r > 0 && r % 8 == 0 && K % 8 == 0 && ldx % 8 == 0 && rows_per_sample > 0,
                 "aql_lora_down: bad shape M=%ld r=%d K=%d", M, r, K);
   if (r % 16 == 0 && r <= 64 && K % 32 == 0) {
     const unsigned blocks = (unsigned)((M + 15) / 16);
     switch (r / 16) {
-      case 1: hipLaunchKernelGGL(lora_down_skinny_kernel<1>, dim3(blocks), dim3(256), 0, stream, X, ldx, M, K, Adown, S, rows_per_sample, T, Ts); break;
-      case 2: hipLaunchKernelGGL(lora_down_skinny_kernel<2>, dim3(blocks), dim3(256), 0, stream, X, ldx, M, K, Adown, S, rows_per_sample, T, Ts); break;
-      case 3: hipLaunchKernelGGL(lora_down_skinny_kernel<3>, dim3(blocks), dim3(256), 0, stream, X, ldx, M, K, Adown, S, rows_per_sample, T, Ts); break;
-      default: hipLaunchKernelGGL(lora_down_skinny_kernel<4>, dim3(blocks), dim3(256), 0, stream, X, ldx, M, K, Adown, S, rows_per_sample, T, Ts); break;
+      case 1: hipLaunchKernelGGL(lora_down_skinny_kernel<1>, dim3(blocks), dim3(256), 0, stream, X, ldx, M, K, Adown, S, rows_per_sample, T, Ts, nullptr, nullptr); break;
+      case 2: hipLaunchKernelGGL(lora_down_skinny_kernel<2>, dim3(blocks), dim3(256), 0, stream, X, ldx, M, K, Adown, S, rows_per_sample, T, Ts, nullptr, nullptr); break;
+      case 3: hipLaunchKernelGGL(lora_down_skinny_kernel<3>, dim3(blocks), dim3(256), 0, stream, X, ldx, M, K, Adown, S, rows_per_sample, T, Ts, nullptr, nullptr); break;
+      default: hipLaunchKernelGGL(lora_down_skinny_kernel<4>, dim3(blocks), dim3(256), 0, stream, X, ldx, M, K, Adown, S, rows_per_sample, T, Ts, nullptr, nullptr); break;
     }
     AQL_CHECK_LAUNCH("aql_lora_down");
-    return AQL_OK;
+    if (Tref == nullptr) return AQL_OK;
+    return aql_lora_ds(T, Tref, (int)(M / rows_per_sample), rows_per_sample, r, dS, stream);
   }
   GemmArgs<PlainLoader, PlainLoader> g;
   g.a0 = plain(X, ldx, M, K);
@@ -289,7 +324,9 @@ extern "C" int aql_lora_down(const bf16_t* X, long ldx, long M, int K, const bf1
   g.M = (int)M;
   g.N = r;
   OutSpec o{nullptr, nullptr, rows_per_sample, nullptr, 0, T, r, Ts, r, S};
-  return run_bf16_gemm(g, o, nullptr, 0, stream, "aql_lora_down");
+  const int rc = run_bf16_gemm(g, o, nullptr, 0, stream, "aql_lora_down");
+  if (rc != AQL_OK || Tref == nullptr) return rc;
+  return aql_lora_ds(T, Tref, (int)(M / rows_per_sample), rows_per_sample, r, dS, stream);
 }
 
 extern "C" int aql_conv3x3_fwd(const bf16_t* X, int B, int Hin, int Win, int Cin, const bf16_t* Wk, const bf16_t* bias,
@@ -387,9 +424,11 @@ extern "C" int aql_gemm_tn_f32(const bf16_t* U, long ldu, const bf16_t* V, long 
   int tiles = 0;
   int cfg = pick_cfg(g.M, g.N, g.ktiles0, false, &tiles);
   if (cfg == 3) cfg = 2, tiles = aql_cdiv(g.M, 128) * aql_cdiv(g.N, 64);
-  int splits = (256 + tiles - 1) / tiles;
+  int splits = (384 + tiles - 1) / tiles;  // measured on MI355X (tools/probe_tn.py): 300-400 workgroups
   if (splits > g.ktiles0 / 4) splits = g.ktiles0 / 4;
+  if (splits > 48) splits = 48;
   if (splits < 1) splits = 1;
+  if (const char* e = getenv("AQL_TN_SPLITS")) splits = atoi(e) < g.ktiles0 ? atoi(e) : g.ktiles0;  // tuning hook
   g.splits = splits;
   launch_cfg<TransLoader, TransLoader, EPI_ATOMIC>(cfg, g, stream);
   AQL_CHECK_LAUNCH("aql_gemm_tn_f32");

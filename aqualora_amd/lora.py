@@ -331,18 +331,46 @@ class LoraBank:
             p.grad = self.grad[off:off + k].view(p.shape)
             self.offsets.append(off)
             off += k
+        # bf16 compute copies (A, A^T, Bup, Bup^T per site) in one flat buffer, refreshed by ONE batched launch
+        import numpy as np
+        total16 = sum(2 * (l.down.weight.numel() + l.up.weight.numel()) for l in self.layers)
+        self.c16 = torch.empty(total16 + 64, dtype=torch.bfloat16, device=dev)
+        desc = np.zeros(2 * len(self.layers), dtype=np.dtype(
+            [("w", "<u8"), ("out", "<u8"), ("outT", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("first", "<i4"),
+             ("pad", "<i4")]))
         self.sites = []
+        off16, tile, di = 0, 0, 0
+
+        def take(n):
+            nonlocal off16
+            v = self.c16[off16:off16 + n]
+            off16 += (n + 7) // 8 * 8  # keep every view 16-byte aligned
+            return v
+
         for layer in self.layers:
             site = LoraSite(layer)
             site.managed = True
+            r = layer.rank
+            K = layer.down.weight.numel() // r
+            N = layer.up.weight.numel() // r
+            site.a16, site.at16 = take(r * K).view(r, K), take(r * K).view(K, r)
+            site.b16, site.bt16 = take(N * r).view(N, r), take(N * r).view(r, N)
+            for w, rows, cols, o, ot in ((layer.down.weight, r, K, site.a16, site.at16),
+                                         (layer.up.weight, N, r, site.b16, site.bt16)):
+                desc[di] = (w.data_ptr(), o.data_ptr(), ot.data_ptr(), rows, cols, tile, 0)
+                tile += ((rows + 31) // 32) * ((cols + 31) // 32)
+                di += 1
             object.__setattr__(layer, "_aql_site", site)
-            site.refresh(force=True)
             self.sites.append(site)
+        assert off16 <= self.c16.numel()
+        self._desc = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
+        self._ndesc, self._ntiles = di, tile
+        self.refresh()
 
     def refresh(self):
-        """Re-cast the fp32 masters to the bf16 compute copies (call after every optimizer step)."""
-        for s in self.sites:
-            s.refresh(force=True)
+        """Re-cast the fp32 masters to the bf16 compute copies (call after every optimizer step): one launch."""
+        L = ops.L
+        L.call("aql_cast_transpose_batched", L.ptr(self._desc), self._ndesc, self._ntiles, L.stream_ptr())
 
     def zero_grad(self):
         self.grad.zero_()

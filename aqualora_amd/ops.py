@@ -134,7 +134,9 @@ class LoraLinearFn(torch.autograd.Function):
             T = torch.empty(M, r, dtype=torch.bfloat16, device=x2d.device)
             Ts = torch.empty_like(T)
             L.call("aql_lora_down", L.ptr(x2d), x2d.stride(0), M, packed.K, L.ptr(site.a16), r, L.ptr(S16), rps,
-                   L.ptr(T), L.ptr(Ts), L.stream_ptr())
+                   L.ptr(T), L.ptr(Ts), None, None, L.stream_ptr())
+            # trainers can hand in one persistent fp32 accumulator for dS (shared by all 192 sites)
+            ctx.ds_accum = getattr(S, "_aql_ds_accum", None)
             y = gemm_bf16(x2d, packed.w, packed.bias, Ts, site.b16, residual=residual)
             ctx.save_for_backward(x2d, T, Ts, S16)
         else:
@@ -154,18 +156,19 @@ class LoraLinearFn(torch.autograd.Function):
             # dTs = dY.Bup  (and dT = dTs * S) -- same two-output epilogue as the forward "down" GEMM
             dTs = torch.empty(M, r, dtype=torch.bfloat16, device=dy.device)
             dT = torch.empty_like(dTs)
+            nb = S16.shape[0]
+            acc = ctx.ds_accum
+            want_ds = ctx.needs_input_grad[3] or acc is not None
+            if want_ds and acc is None:
+                dS = torch.zeros(nb, r, dtype=torch.float32, device=dy.device)
             L.call("aql_lora_down", L.ptr(dy), dy.stride(0), M, packed.N, L.ptr(site.bt16), r, L.ptr(S16), ctx.rps,
-                   L.ptr(dTs), L.ptr(dT), L.stream_ptr())
+                   L.ptr(dTs), L.ptr(dT), L.ptr(T) if want_ds else None,
+                   L.ptr(acc if acc is not None else dS) if want_ds else None, L.stream_ptr())
             dx = gemm_bf16(dy, packed.wt, None, dT, site.at16) if ctx.needs_input_grad[0] else None
             gemm_tn_acc(dy, Ts, site.gb)   # dBup[N,r] += dY^T Ts
             gemm_tn_acc(dT, x2d, site.ga)  # dA[r,K]  += dT^T X
-            nb = S16.shape[0]
-            dS = torch.zeros(nb, r, dtype=torch.float32, device=dy.device)
-            L.call("aql_lora_ds", L.ptr(dTs), L.ptr(T), nb, ctx.rps, r, L.ptr(dS), L.stream_ptr())
-            if not ctx.needs_input_grad[3]:
-                dS = None
-            else:
-                dS = dS.to(ctx.s_dtype)
+            if dS is not None:
+                dS = dS.to(ctx.s_dtype) if ctx.needs_input_grad[3] else None
         else:
             dx = gemm_bf16(dy, packed.wt) if ctx.needs_input_grad[0] else None
         return dx, None, None, dS, None, None, (dy if ctx.has_res else None)

@@ -48,6 +48,7 @@ class PPFTTrainer:
         self.lr_t = torch.full((1,), learning_rate * self.lr_lambda(0), dtype=torch.float32, device=dev)
         self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.ds_accum = None
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
 
@@ -55,13 +56,19 @@ class PPFTTrainer:
     def forward_backward(self, z, msg, eps, t, ctx):
         """Everything up to (and including) backward; returns (loss, pred, clean)."""
         S = self.mapper(msg)
+        if self.ds_accum is None or self.ds_accum.shape != S.shape:
+            self.ds_accum = torch.zeros_like(S, dtype=torch.float32)
+        self.ds_accum.zero_()
+        S_in = S.detach().requires_grad_(True)  # the U-Net sees a leaf; all 192 sites accumulate dS into ONE fp32 buffer that is
+        S_in._aql_ds_accum = self.ds_accum  # pushed through the mapper once, after the U-Net backward
         wm = self.sec_encoder.encode(msg, out_scale=VAE_SCALING)
         x_t, x_t_wm = self.scheduler.add_noise_pair(z, wm, eps, t)
         with torch.no_grad():
             clean = self.unet(x_t, t, ctx, cross_attention_kwargs={"scale": None}).sample
-        pred = self.unet(x_t_wm, t, ctx, cross_attention_kwargs={"scale": S}).sample
+        pred = self.unet(x_t_wm, t, ctx, cross_attention_kwargs={"scale": S_in}).sample
         loss = ops.mse_loss(pred, clean)
         loss.backward()
+        S.backward(self.ds_accum)
         return loss.detach(), pred.detach(), clean
 
     def exchange_gradients(self):

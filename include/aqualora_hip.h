@@ -35,8 +35,10 @@ int aql_gemm_bf16(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, 
 
 /* T = X.Adown^T ; Ts = T * S[m / rows_per_sample]   ==  down(x) @ diag_embed(scale)
  *   utils/lora_modules.py:13-17 (linear) and :33-36 (conv, scale[:, :, None, None]).                           */
+/* Backward reuse: with X = dY, Adown = up.weight^T it yields dTs and dT = dTs*S; passing Tref (the forward T) and dS
+ * additionally accumulates dS[sample,:] += sum_rows dTs*Tref, the gradient of the diagonal.                       */
 int aql_lora_down(const bf16_t* X, long ldx, long M, int K, const bf16_t* Adown, int r, const bf16_t* S,
-                  int rows_per_sample, bf16_t* T, bf16_t* Ts, aql_stream_t stream);
+                  int rows_per_sample, bf16_t* T, bf16_t* Ts, const bf16_t* Tref, float* dS, aql_stream_t stream);
 
 /* 3x3 convolution, pad 1, stride 1|2, NHWC, weights Wk[Cout][(kh*3+kw)*Cin+ci]; upsample=1 folds the nearest x2
  * of Upsample2D into the gather.  Replaces F.conv2d in CustomLoRACompatibleConvforward (lora_modules.py:47-52)
@@ -95,6 +97,9 @@ int aql_secret_encoder_fwd(const float* msg, const float* lin_w, const float* li
                            float* hidden_scratch, float* out, aql_stream_t stream);
 /* fp32 LoRA master weight [rows,cols] -> bf16 copy and bf16 transposed copy (autocast's casts, lora_modules.py:10-13) */
 int aql_cast_transpose(const float* w, int rows, int cols, bf16_t* out, bf16_t* outT, aql_stream_t stream);
+/* all LoRA tensors in one launch: desc = device array of {const float* w; bf16_t* out; bf16_t* outT; int rows, cols,
+ * first_tile, pad} (32 bytes each, 32x32 tiles numbered consecutively)                                              */
+int aql_cast_transpose_batched(const void* desc, int n, int total_tiles, aql_stream_t stream);
 /* dS[b,j] += sum_{m in sample b} dTs[m,j]*T[m,j]: gradient of the diagonal (autograd of diag_embed, :16-17)         */
 int aql_lora_ds(const bf16_t* dTs, const bf16_t* T, int nb, int rows_per_sample, int r, float* dS, aql_stream_t stream);
 /* clip_grad_norm_ + torch.optim.AdamW on flat fp32 buffers  train/ppft_train.py:1059-1066, 779-787                 */

@@ -60,7 +60,7 @@ report("gemm dualK+rowbias", relerr(gemm(A, B, A2, B2, rowbias=rb, rps=512), ref
 for (M, K, r, rps) in [(4096, 320, 32, 1024), (308, 768, 8, 77), (2048, 1280, 320, 256)]:
     X = rnd(M, K); Ad = rnd(r, K, scale=K ** -0.5); S = rnd(M // rps, r)
     T = torch.empty(M, r, dtype=torch.bfloat16, device=dev); Ts = torch.empty_like(T)
-    L.call("aql_lora_down", L.ptr(X), K, M, K, L.ptr(Ad), r, L.ptr(S), rps, L.ptr(T), L.ptr(Ts), L.stream_ptr())
+    L.call("aql_lora_down", L.ptr(X), K, M, K, L.ptr(Ad), r, L.ptr(S), rps, L.ptr(T), L.ptr(Ts), None, None, L.stream_ptr())
     Tr = (X.float() @ Ad.float().T)
     report(f"lora_down T M{M} K{K} r{r}", relerr(T, Tr), 1.5e-2)
     report(f"lora_down Ts", relerr(Ts, T.float() * S.float().repeat_interleave(rps, 0)), 1e-2)
