@@ -266,14 +266,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[sf][of][e]);
       mx = group4_max(mx);
       const float mn = fmaxf(m[of], mx);
-      const float alpha = exp2f((m[of] - mn) * c);
+      const float alpha = __builtin_amdgcn_exp2f((m[of] - mn) * c);
+      const float mnc = mn * c;
       m[of] = mn;
       float rs = 0.f;
 #pragma unroll
       for (int sf = 0; sf < 4; ++sf)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float p = exp2f((s[sf][of][e] - mn) * c);
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sf][of][e], c, -mnc));  // one FMA + one v_exp_f32
           s[sf][of][e] = p;
           rs += p;
         }
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(const AttnArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const bool valid = (kt + sf * 16 + (lane >> 4) * 4 + e) < a.Nk;
-          const float p = valid ? exp2f(s[sf][of][e] * c - lse2[of]) : 0.f;
+          const float p = valid ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[sf][of][e], c, -lse2[of])) : 0.f;
           s[sf][of][e] = p * (dp[sf][of][e] - dl[of]);
         }
     bf16x8_t pb[2][2];
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnArgs a) {
       for (int of = 0; of < 2; ++of)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float p = exp2f(s[sf][of][e] * c - lsv[e]);
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sf][of][e], c, -lsv[e]));
           s[sf][of][e] = p;
           ds[sf][of][e] = p * (dp[sf][of][e] - dev[e]);
         }

@@ -39,17 +39,18 @@ void aql_set_error(const char* fmt, ...);
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even, NaN preserved as quiet NaN
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16, round-to-nearest-even: gfx950's v_cvt_pk_bf16_f32 (one VALU op per PAIR; the compiler selects it
+// for __bf16 vector conversions, a hand-rolled bit trick costs ~5 ops per element)
+typedef __bf16 aql_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float aql_f32x2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  const aql_f32x2_t v = {lo, hi};
+  const aql_bf16x2_t r = __builtin_convertvector(v, aql_bf16x2_t);
+  return *reinterpret_cast<const uint32_t*>(&r);
 }
+
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }

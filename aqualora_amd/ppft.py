@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib as L
-from . import ops
+from . import dp, ops
 from .lora import LoraBank, inject_lora, patch_lora_forwards
 from .watermark import customDDPMScheduler
 
@@ -74,13 +74,7 @@ class PPFTTrainer:
     def exchange_gradients(self):
         """DDP's gradient all-reduce(mean) (accelerator.backward, ppft_train.py:1058) as ONE collective over the flat
         fp32 gradient buffer (54 MB at r=32, 543 MB at r=320)."""
-        if self.world > 1:
-            g = self.bank.grad
-            if dist.get_backend(self.pg) == "nccl":
-                dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.pg)
-            else:
-                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
-                g.div_(self.world)
+        dp.allreduce_mean_(self.bank.grad[:self.bank.numel], self.pg)
 
     def optimizer_step(self):
         b = self.bank

@@ -106,7 +106,7 @@ def cpu_baseline(tr, rank):
     from oracle import ppft_oracle as O
     from aqualora_amd.unet import SD15
     from aqualora_amd import synth
-    cores = len(os.sched_getaffinity(0))
+    cores = min(32, len(os.sched_getaffinity(0)))  # more threads than this slows torch's CPU convs down on big hosts
     torch.set_num_threads(cores)
     sd = {k: v.detach().float().cpu() for k, v in tr.unet.state_dict().items() if "lora_layer" not in k}
     net = O.UNetOracle(sd, dict(SD15))
