@@ -11,16 +11,17 @@
 // Products are computed transposed (streamed rows x owner rows) so that every softmax statistic of an owner row is
 // lane-local up to a 4-lane-group exchange, and the probabilities feed the second MFMA straight from the
 // accumulator registers: the MFMA k-slot order is permuted identically on both operands instead of shuffling.
-//   forward : owner = Q,        stream K (row-major) and V (transposed)
-//   dQ      : owner = Q, dO     stream K (row-major + transposed) and V (row-major)
-//   dK/dV   : owner = K, V      stream Q, dO (row-major + transposed), LSE and delta
+//   forward : owner = Q,        stream K and V
+//   dQ      : owner = Q, dO     stream K and V
+//   dK/dV   : owner = K, V      stream Q, dO, LSE and delta
+// Streamed tiles are staged ONCE, row-major; the T-product gathers its transposed fragments with the LDS
+// transpose-read ds_read_b64_tr_b16, so there is no transposing staging pass and no second LDS image.
 #include "aql_common.h"
 
 namespace {
 
 constexpr int TILE = 64;                    // streamed rows per tile
 constexpr int OWN = 32;                     // owner rows per wavefront
-constexpr int PITCH_T = TILE * 2 + 8;       // bytes per row of a transposed tile [d][64 rows]
 constexpr float LOG2E = 1.4426950408889634f;
 
 template <int DH>
@@ -56,50 +57,6 @@ __device__ __forceinline__ void stage_rows(char* lds, const bf16_t* g, long ld, 
     const int id = tid + it * 256;
     const int row = id / CPR, c = id - row * CPR;
     if (id < TILE * CPR) *reinterpret_cast<uint4*>(lds + row * RowPitch<DH>::value + c * 16) = v[it];
-  }
-}
-
-// global [rows][ld] -> LDS transposed [DV][64 rows]
-template <int DV>
-__device__ __forceinline__ void stage_trans(char* lds, const bf16_t* g, long ld, int row0, int nrows, int d, int tid) {
-  constexpr int TASKS = (TILE / 4) * (DV / 8);
-  constexpr int NIT = (TASKS + 255) / 256;
-  uint4 all[NIT][4];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int id = tid + it * 256;
-    const int kq = id & 15, cg = id >> 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = row0 + kq * 4 + i;
-      const bool ok = (id < TASKS) & (row < nrows) & (cg * 8 < d);
-      const uint4 x = *reinterpret_cast<const uint4*>(g + (ok ? (long)row * ld + cg * 8 : 0));
-      all[it][i] = mask4(x, ok);
-    }
-  }
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int id = tid + it * 256;
-    if (id >= TASKS) continue;
-    const int kq = id & 15, cg = id >> 4;
-    const uint4* in = all[it];
-    const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&in[0]);
-    const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&in[1]);
-    const uint32_t* w2 = reinterpret_cast<const uint32_t*>(&in[2]);
-    const uint32_t* w3 = reinterpret_cast<const uint32_t*>(&in[3]);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int w = j >> 1;
-      uint32_t lo, hi;
-      if (j & 1) {
-        lo = (w0[w] >> 16) | (w1[w] & 0xffff0000u);
-        hi = (w2[w] >> 16) | (w3[w] & 0xffff0000u);
-      } else {
-        lo = (w0[w] & 0xffffu) | (w1[w] << 16);
-        hi = (w2[w] & 0xffffu) | (w3[w] << 16);
-      }
-      *reinterpret_cast<uint2*>(lds + (cg * 8 + j) * PITCH_T + kq * 8) = make_uint2(lo, hi);
-    }
   }
 }
 
@@ -156,19 +113,25 @@ __device__ __forceinline__ void pack_p(bf16x8_t (&pb)[2][2], const f32x4_t (&p)[
     }
 }
 
-// acc[df][of] += transposed tile frag df (A)  x  pb (B)
-template <int DV>
-__device__ __forceinline__ void t_product(f32x4_t (&acc)[DV / 16][2], const char* ttile, const bf16x8_t (&pb)[2][2],
+// acc[df][of] += (row-major tile)^T frag df (A)  x  pb (B).  The A fragment (i = column df*16 + lane&15 of the tile,
+// k = 8 streamed rows) is gathered by the LDS transpose-read ds_read_b64_tr_b16: within a 16-lane group lane p supplies
+// the address of row p>>2, columns 4*(p&3).. and receives column p of that 4x16 block (verified on hardware with
+// tools/micro/tr_probe.hip).  k-slot (g,e) of step s2 <-> streamed row 32*s2 + 16*(e>>2) + 4*g + (e&3), as in pack_p.
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+template <int DH, int DV>
+__device__ __forceinline__ void t_product(f32x4_t (&acc)[DV / 16][2], const char* tile, const bf16x8_t (&pb)[2][2],
                                           int lane) {
+  const int p = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2) {
+    const char* base = tile + (s2 * 32 + g * 4 + (p >> 2)) * RowPitch<DH>::value + (p & 3) * 8;
 #pragma unroll
     for (int df = 0; df < DV / 16; ++df) {
-      const char* p = ttile + (df * 16 + (lane & 15)) * PITCH_T + (s2 * 32 + (lane >> 4) * 4) * 2;
-      const uint2 lo = *reinterpret_cast<const uint2*>(p);
-      const uint2 hi = *reinterpret_cast<const uint2*>(p + 32);
-      uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
-      const bf16x8_t a = *reinterpret_cast<bf16x8_t*>(&v);
+      const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (v4s_t __attribute__((address_space(3)))*)(base + df * 32));
+      const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (v4s_t __attribute__((address_space(3)))*)(base + df * 32 + 16 * RowPitch<DH>::value));
+      const bf16x8_t a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
       for (int of = 0; of < 2; ++of)
         acc[df][of] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb[s2][of], acc[df][of], 0, 0, 0);
@@ -229,7 +192,7 @@ struct AttnArgs {
 template <int DH, int DV>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char sK[TILE * RowPitch<DH>::value];
-  __shared__ __attribute__((aligned(16))) char sVt[DV * PITCH_T];
+  __shared__ __attribute__((aligned(16))) char sV[TILE * RowPitch<DH>::value];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.y, b = blockIdx.z;
   const int q0 = blockIdx.x * (4 * OWN) + wave * OWN;
@@ -245,7 +208,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   for (int kt = 0; kt < a.Nk; kt += TILE) {
     __syncthreads();
     stage_rows<DH>(sK, kp, a.ldk, kt, a.Nk, a.d, tid);
-    stage_trans<DV>(sVt, vp, a.ldv, kt, a.Nk, a.d, tid);
+    stage_rows<DH>(sV, vp, a.ldv, kt, a.Nk, a.d, tid);
     __syncthreads();
     f32x4_t s[4][2];
     zero_acc(s);
@@ -286,7 +249,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     }
     bf16x8_t pb[2][2];
     pack_p(pb, s);
-    t_product<DV>(o, sVt, pb, lane);
+    t_product<DH, DV>(o, sV, pb, lane);
   }
   store_t<DV>(o, a.out + (long)b * a.Nq * a.ldo + h * a.d, a.ldo, q0, a.Nq, a.d, 1.f / l[0], 1.f / l[1], lane);
   if ((lane >> 4) == 0) {
@@ -320,7 +283,6 @@ template <int DH, int DV>
 __global__ __launch_bounds__(256) void attn_dq_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char sK[TILE * RowPitch<DH>::value];
   __shared__ __attribute__((aligned(16))) char sV[TILE * RowPitch<DH>::value];
-  __shared__ __attribute__((aligned(16))) char sKt[DV * PITCH_T];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.y, b = blockIdx.z;
   const int q0 = blockIdx.x * (4 * OWN) + wave * OWN;
@@ -346,7 +308,6 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(const AttnArgs a) {
     __syncthreads();
     stage_rows<DH>(sK, kp, a.ldk, kt, a.Nk, a.d, tid);
     stage_rows<DH>(sV, vp, a.ldv, kt, a.Nk, a.d, tid);
-    stage_trans<DV>(sKt, kp, a.ldk, kt, a.Nk, a.d, tid);
     __syncthreads();
     f32x4_t s[4][2], dp[4][2];
     zero_acc(s);
@@ -365,7 +326,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(const AttnArgs a) {
         }
     bf16x8_t pb[2][2];
     pack_p(pb, s);
-    t_product<DV>(dq, sKt, pb, lane);
+    t_product<DH, DV>(dq, sK, pb, lane);
   }
   store_t<DV>(dq, a.dq + (long)b * a.Nq * a.ldq + h * a.d, a.ldq, q0, a.Nq, a.d, a.scale, a.scale, lane);
 }
@@ -375,8 +336,6 @@ template <int DH, int DV>
 __global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char sQ[TILE * RowPitch<DH>::value];
   __shared__ __attribute__((aligned(16))) char sdO[TILE * RowPitch<DH>::value];
-  __shared__ __attribute__((aligned(16))) char sQt[DV * PITCH_T];
-  __shared__ __attribute__((aligned(16))) char sdOt[DV * PITCH_T];
   __shared__ __attribute__((aligned(16))) float sLse[TILE];
   __shared__ __attribute__((aligned(16))) float sDelta[TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -397,8 +356,6 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnArgs a) {
     __syncthreads();
     stage_rows<DH>(sQ, qp, a.ldq, qt, a.Nq, a.d, tid);
     stage_rows<DH>(sdO, dop, a.ldo, qt, a.Nq, a.d, tid);
-    stage_trans<DV>(sQt, qp, a.ldq, qt, a.Nq, a.d, tid);
-    stage_trans<DV>(sdOt, dop, a.ldo, qt, a.Nq, a.d, tid);
     if (tid < TILE) {
       const bool ok = (qt + tid) < a.Nq;
       sLse[tid] = ok ? a.lse[((long)b * a.H + h) * a.Nq + qt + tid] * LOG2E : INFINITY;
@@ -428,9 +385,9 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnArgs a) {
     }
     bf16x8_t pb[2][2];
     pack_p(pb, s);
-    t_product<DV>(dv, sdOt, pb, lane);
+    t_product<DH, DV>(dv, sdO, pb, lane);
     pack_p(pb, ds);
-    t_product<DV>(dk, sQt, pb, lane);
+    t_product<DH, DV>(dk, sQ, pb, lane);
   }
   const long ldo_kv = (long)a.H * a.d;
   store_t<DV>(dk, a.dk + (long)b * a.Nk * ldo_kv + h * a.d, ldo_kv, k0, a.Nk, a.d, a.scale, a.scale, lane);
