@@ -40,6 +40,10 @@ SIGNATURES = {
     "aql_secret_encoder_fwd": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p],
     "aql_cast_transpose": [c_p, c_i, c_i, c_p, c_p, c_p],
     "aql_cast_transpose_batched": [c_p, c_i, c_i, c_p],
+    "aql_tn_desc_fill": [c_p, c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_f, c_p, c_l, c_i],
+    "aql_gemm_tn_grouped": [c_p, c_i, c_i, c_p],
+    "aql_ds_desc_fill": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i],
+    "aql_lora_ds_grouped": [c_p, c_i, c_i, c_p],
     "aql_lora_ds": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     "aql_sumsq_f32": [c_p, c_l, c_p, c_p],
     "aql_clipnorm_adamw": [c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_p, c_f, c_f, c_f, c_f, c_p, c_p],
@@ -93,3 +97,8 @@ def stream_ptr():
 def call(name, *args):
     lib = load()
     check(getattr(lib, name)(*args), name)
+
+
+def call_raw(name, *args):
+    """For the *_desc_fill helpers, whose return value is a workgroup count rather than a status."""
+    return getattr(load(), name)(*args)

@@ -272,6 +272,50 @@ __global__ __launch_bounds__(256) void lora_ds_kernel(const bf16_t* __restrict__
   for (int i = threadIdx.x; i < r; i += blockDim.x) atomicAdd(&dS[b * r + i], acc[i]);
 }
 
+// grouped form: all LoRA sites of a backward pass in one launch
+struct DsGroupDesc {
+  const bf16_t* dTs;
+  const bf16_t* T;
+  float* dS;
+  int nb, rps, r, slabs;
+  int first_block, pad;
+};
+__global__ __launch_bounds__(256) void lora_ds_grouped_kernel(const DsGroupDesc* __restrict__ descs, int n) {
+  __shared__ float acc[1024];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const DsGroupDesc d = descs[lo];
+  const int local = blockIdx.x - d.first_block;
+  const int slab = local % d.slabs, b = local / d.slabs;
+  const int r = d.r, cols = r >> 3;
+  const int rp = 256 / cols;
+  const int col = threadIdx.x % cols, rr = threadIdx.x / cols;
+  const int slab_rows = (d.rps + d.slabs - 1) / d.slabs;
+  const int r0 = slab * slab_rows, r1 = min(d.rps, r0 + slab_rows);
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rr < rp) {
+    for (int m = r0 + rr; m < r1; m += rp) {
+      const long off = ((long)b * d.rps + m) * r + col * 8;
+      float x[8], y[8];
+      unpack8(*reinterpret_cast<const uint4*>(d.dTs + off), x);
+      unpack8(*reinterpret_cast<const uint4*>(d.T + off), y);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += x[j] * y[j];
+    }
+  }
+  for (int i = threadIdx.x; i < r; i += blockDim.x) acc[i] = 0.f;
+  __syncthreads();
+  if (rr < rp) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(&acc[col * 8 + j], a[j]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < r; i += blockDim.x) atomicAdd(&d.dS[b * r + i], acc[i]);
+}
+
 // ---- global grad-norm clip + AdamW on flat fp32 buffers (ppft_train.py:1059-1068, 779-787) -----------
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
   __shared__ float sm[4];
@@ -407,6 +451,32 @@ extern "C" int aql_lora_ds(const bf16_t* dTs, const bf16_t* T, int nb, int rows_
   if (slabs > 32) slabs = 32;
   hipLaunchKernelGGL(lora_ds_kernel, dim3(slabs, nb), dim3(threads), 0, stream, dTs, T, rows_per_sample, r, dS);
   AQL_CHECK_LAUNCH("aql_lora_ds");
+  return AQL_OK;
+}
+extern "C" int aql_ds_desc_fill(void* host_desc, const bf16_t* dTs, const bf16_t* T, int nb, int rows_per_sample,
+                                int r, float* dS, int first_block) {
+  if (!host_desc || !dTs || !T || !dS || r % 8 || r > 1024 || r / 8 > 256) return 0;
+  DsGroupDesc d;
+  d.dTs = dTs;
+  d.T = T;
+  d.dS = dS;
+  d.nb = nb;
+  d.rps = rows_per_sample;
+  d.r = r;
+  int slabs = (rows_per_sample + 255) / 256;
+  if (slabs > 32) slabs = 32;
+  d.slabs = slabs;
+  d.first_block = first_block;
+  d.pad = 0;
+  memcpy(host_desc, &d, sizeof(d));
+  return slabs * nb;
+}
+extern "C" int aql_lora_ds_grouped(const void* dev_descs, int n, int total_blocks, hipStream_t stream) {
+  AQL_CHECK_ARG(dev_descs && n > 0 && total_blocks > 0, "aql_lora_ds_grouped: bad args");
+  static_assert(sizeof(DsGroupDesc) == 48, "descriptor layout is part of the ABI");
+  hipLaunchKernelGGL(lora_ds_grouped_kernel, dim3(total_blocks), dim3(256), 0, stream,
+                     static_cast<const DsGroupDesc*>(dev_descs), n);
+  AQL_CHECK_LAUNCH("aql_lora_ds_grouped");
   return AQL_OK;
 }
 extern "C" int aql_sumsq_f32(const float* g, long n, float* out, hipStream_t stream) {

@@ -285,7 +285,7 @@ struct Stager<R, TransLoader> {
 // the kernel
 // --------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs<LA, LB> g) {
+__device__ __forceinline__ void gemm_body(const GemmArgs<LA, LB>& g, const int block_x, const int block_z) {
   constexpr int FM = WM / 32, FN = WN / 32;
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * (BN / WN) == 4, "4 wavefronts per workgroup");
@@ -302,14 +302,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs<LA, LB> g
   const int wn0 = (wave % WAVES_N) * WN;
 
   const int tiles_n = (g.N + BN - 1) / BN;
-  const int tile_m = blockIdx.x / tiles_n;
-  const int tile_n = blockIdx.x - tile_m * tiles_n;
+  const int tile_m = block_x / tiles_n;
+  const int tile_n = block_x - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // K range of this split
   const int kt_total = g.ktiles0 + g.ktiles1;
-  const int kt_begin = (int)(((long)kt_total * blockIdx.z) / g.splits);
-  const int kt_end = (int)(((long)kt_total * (blockIdx.z + 1)) / g.splits);
+  const int kt_begin = (int)(((long)kt_total * block_z) / g.splits);
+  const int kt_end = (int)(((long)kt_total * (block_z + 1)) / g.splits);
 
   Stager<BM, LA> sa;
   Stager<BN, LB> sb;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs<LA, LB> g
       }
     }
   } else if constexpr (EPI == EPI_SLAB) {
-    float* out = ep.Cf + (long)blockIdx.z * g.M * ep.ldcf;
+    float* out = ep.Cf + (long)block_z * g.M * ep.ldcf;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int m = m0 + wm0 + i * 32 + (lane & 31);
@@ -490,6 +490,45 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs<LA, LB> g
       else atomicAdd(ep.Cf + (long)m * ep.ldcf + n, v);
     }
   }
+}
+
+template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs<LA, LB> g) {
+  gemm_body<BM, BN, WM, WN, LA, LB, EPI>(g, blockIdx.x, blockIdx.z);
+}
+
+// Grouped token-reduction GEMMs: ONE launch for all LoRA weight gradients of a backward pass.  Every problem has a
+// narrow (rank <= 32) side, so all of them share the 128x32 tile; blockIdx.x is mapped to (problem, tile, K split)
+// through the descriptor table (first_block is a running prefix).
+struct TnGroupDesc {
+  const bf16_t* a;   // [M][lda], rows of the output tile come from its columns (the wide side)
+  const bf16_t* b;   // [M][ldb], the narrow side
+  float* C;
+  long lda, ldb, ldc;
+  int M, a_rows, b_rows, splits;
+  int first_block, trans_out;
+  float alpha;
+  int pad;
+};
+
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_grouped_kernel(const TnGroupDesc* __restrict__ descs, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const TnGroupDesc d = descs[lo];
+  const int local = blockIdx.x - d.first_block;
+  const int tiles = (d.a_rows + 127) / 128;  // b_rows <= 32: one tile along N
+  GemmArgs<TransLoader, TransLoader> g;
+  g.a0.base = d.a; g.a0.ld = d.lda; g.a0.rows = d.a_rows; g.a0.K = d.M;
+  g.b0.base = d.b; g.b0.ld = d.ldb; g.b0.rows = d.b_rows; g.b0.K = d.M;
+  g.a1 = g.a0; g.b1 = g.b0;
+  g.ktiles0 = (d.M + BK - 1) / BK; g.ktiles1 = 0;
+  g.M = d.a_rows; g.N = d.b_rows; g.splits = d.splits;
+  g.epi = EpiParams{};
+  g.epi.Cf = d.C; g.epi.ldcf = d.ldc; g.epi.alpha = d.alpha; g.epi.trans_out = d.trans_out;
+  gemm_body<128, 32, 32, 32, TransLoader, TransLoader, EPI_ATOMIC>(g, local % tiles, local / tiles);
 }
 
 template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI>

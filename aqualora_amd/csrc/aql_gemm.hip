@@ -434,3 +434,48 @@ extern "C" int aql_gemm_tn_f32(const bf16_t* U, long ldu, const bf16_t* V, long 
   AQL_CHECK_LAUNCH("aql_gemm_tn_f32");
   return AQL_OK;
 }
+
+// ---- grouped weight-gradient GEMMs ---------------------------------------------------------------------------
+// aql_tn_desc_fill writes one host-side descriptor (64 bytes) for  C[P,Q] += alpha * U[M,P]^T V[M,Q]  with
+// min(P,Q) <= 32 and returns the number of workgroups it needs (0 if the shape is not groupable);
+// aql_gemm_tn_grouped launches all of them at once from a DEVICE copy of the table.
+extern "C" int aql_tn_desc_fill(void* host_desc, const bf16_t* U, long ldu, const bf16_t* V, long ldv, long M, int P,
+                                int Q, float alpha, float* C, long ldc, int first_block) {
+  if (host_desc == nullptr || U == nullptr || V == nullptr || C == nullptr) return 0;
+  if (P % 8 || Q % 8 || ldu % 8 || ldv % 8 || M <= 0 || M >= (1L << 31)) return 0;
+  const bool swap = (P <= 32 && Q > 32);
+  const int a_rows = swap ? Q : P, b_rows = swap ? P : Q;
+  if (b_rows > 32) return 0;
+  TnGroupDesc d;
+  d.a = swap ? V : U;
+  d.b = swap ? U : V;
+  d.lda = swap ? ldv : ldu;
+  d.ldb = swap ? ldu : ldv;
+  d.C = C;
+  d.ldc = ldc;
+  d.M = (int)M;
+  d.a_rows = a_rows;
+  d.b_rows = b_rows;
+  const int tiles = aql_cdiv(a_rows, 128);
+  const int ktiles = aql_cdiv(M, BK);
+  int splits = (384 + tiles - 1) / tiles;
+  if (splits > ktiles / 4) splits = ktiles / 4;
+  if (splits > 48) splits = 48;
+  if (splits < 1) splits = 1;
+  d.splits = splits;
+  d.first_block = first_block;
+  d.trans_out = swap ? 1 : 0;
+  d.alpha = alpha;
+  d.pad = 0;
+  memcpy(host_desc, &d, sizeof(d));
+  return tiles * splits;
+}
+
+extern "C" int aql_gemm_tn_grouped(const void* dev_descs, int n, int total_blocks, hipStream_t stream) {
+  AQL_CHECK_ARG(dev_descs && n > 0 && total_blocks > 0, "aql_gemm_tn_grouped: bad args");
+  static_assert(sizeof(TnGroupDesc) == 80, "descriptor layout is part of the ABI");
+  hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total_blocks), dim3(NTHREADS), 0, stream,
+                     static_cast<const TnGroupDesc*>(dev_descs), n);
+  AQL_CHECK_LAUNCH("aql_gemm_tn_grouped");
+  return AQL_OK;
+}

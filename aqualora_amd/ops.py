@@ -110,6 +110,65 @@ def gemm_tn_acc(U, V, C, alpha=1.0):
            C.stride(0), L.stream_ptr())
 
 
+# ------------------------------------------------------------------------ deferred (grouped) weight gradients
+class DeferredDW:
+    """Collects the LoRA weight-gradient GEMMs (dA, dBup) and the dS reductions of a whole backward pass and runs
+    them as ONE grouped launch each (`flush`).  They are off the backward critical path -- nothing consumes dA/dB/dS
+    before the optimizer -- and as 384+192 separate small launches they were the largest single item of the step.
+    Descriptors are written into pinned host tables and copied with one async H2D each (graph-capturable: the device
+    addresses they hold are the capture pool's, identical on every replay)."""
+
+    TN_BYTES, DS_BYTES = 80, 48
+
+    def __init__(self, device, max_sites=1024):
+        self.device = device
+        self.tn_host = torch.zeros(2 * max_sites * self.TN_BYTES, dtype=torch.uint8).pin_memory()
+        self.ds_host = torch.zeros(max_sites * self.DS_BYTES, dtype=torch.uint8).pin_memory()
+        self.tn_dev = torch.zeros_like(self.tn_host, device=device)
+        self.ds_dev = torch.zeros_like(self.ds_host, device=device)
+        self.reset()
+
+    def reset(self):
+        self.n_tn = self.n_ds = self.blk_tn = self.blk_ds = 0
+        self.keep = []
+
+    def add_tn(self, U, V, C, alpha=1.0):
+        """C[P,Q] += alpha * U^T V;  returns False if the shape cannot be grouped (caller launches it directly)."""
+        slot = self.tn_host.data_ptr() + self.n_tn * self.TN_BYTES
+        nblk = L.call_raw("aql_tn_desc_fill", L.c_p(slot), L.ptr(U), U.stride(0), L.ptr(V), V.stride(0), U.shape[0],
+                          U.shape[1], V.shape[1], float(alpha), L.ptr(C), C.stride(0), self.blk_tn)
+        if nblk <= 0:
+            return False
+        self.n_tn += 1
+        self.blk_tn += nblk
+        self.keep += [U, V]
+        return True
+
+    def add_ds(self, dTs, T, dS, nb, rps, r):
+        slot = self.ds_host.data_ptr() + self.n_ds * self.DS_BYTES
+        nblk = L.call_raw("aql_ds_desc_fill", L.c_p(slot), L.ptr(dTs), L.ptr(T), nb, rps, r, L.ptr(dS), self.blk_ds)
+        if nblk <= 0:
+            return False
+        self.n_ds += 1
+        self.blk_ds += nblk
+        self.keep += [dTs, T]
+        return True
+
+    def flush(self):
+        if self.n_tn:
+            nbytes = self.n_tn * self.TN_BYTES
+            self.tn_dev[:nbytes].copy_(self.tn_host[:nbytes], non_blocking=True)
+            L.call("aql_gemm_tn_grouped", L.ptr(self.tn_dev), self.n_tn, self.blk_tn, L.stream_ptr())
+        if self.n_ds:
+            nbytes = self.n_ds * self.DS_BYTES
+            self.ds_dev[:nbytes].copy_(self.ds_host[:nbytes], non_blocking=True)
+            L.call("aql_lora_ds_grouped", L.ptr(self.ds_dev), self.n_ds, self.blk_ds, L.stream_ptr())
+        self.reset()
+
+
+DEFERRED = None  # set by a trainer around backward (ppft.PPFTTrainer); None => every site launches its own kernels
+
+
 # ------------------------------------------------------------------------------------ fused LoRA linear
 class LoraLinearFn(torch.autograd.Function):
     """Y = X.W^T + b [+ ((X.A^T) * S[sample]).Bup^T] [+ residual]   on token-major X [M,K].
@@ -161,12 +220,20 @@ class LoraLinearFn(torch.autograd.Function):
             want_ds = ctx.needs_input_grad[3] or acc is not None
             if want_ds and acc is None:
                 dS = torch.zeros(nb, r, dtype=torch.float32, device=dy.device)
+            dfr = DEFERRED
+            ds_target = acc if acc is not None else dS
+            ds_deferred = want_ds and dfr is not None and acc is not None
             L.call("aql_lora_down", L.ptr(dy), dy.stride(0), M, packed.N, L.ptr(site.bt16), r, L.ptr(S16), ctx.rps,
-                   L.ptr(dTs), L.ptr(dT), L.ptr(T) if want_ds else None,
-                   L.ptr(acc if acc is not None else dS) if want_ds else None, L.stream_ptr())
+                   L.ptr(dTs), L.ptr(dT), L.ptr(T) if (want_ds and not ds_deferred) else None,
+                   L.ptr(ds_target) if (want_ds and not ds_deferred) else None, L.stream_ptr())
+            if ds_deferred and not dfr.add_ds(dTs, T, ds_target, nb, ctx.rps, r):
+                L.call("aql_lora_ds", L.ptr(dTs), L.ptr(T), nb, ctx.rps, r, L.ptr(ds_target), L.stream_ptr())
             dx = gemm_bf16(dy, packed.wt, None, dT, site.at16) if ctx.needs_input_grad[0] else None
-            gemm_tn_acc(dy, Ts, site.gb)   # dBup[N,r] += dY^T Ts
-            gemm_tn_acc(dT, x2d, site.ga)  # dA[r,K]  += dT^T X
+            # dBup[N,r] += dY^T Ts ; dA[r,K] += dT^T X   (grouped at the end of backward when a trainer defers them)
+            if dfr is None or not dfr.add_tn(dy, Ts, site.gb):
+                gemm_tn_acc(dy, Ts, site.gb)
+            if dfr is None or not dfr.add_tn(dT, x2d, site.ga):
+                gemm_tn_acc(dT, x2d, site.ga)
             if dS is not None:
                 dS = dS.to(ctx.s_dtype) if ctx.needs_input_grad[3] else None
         else:

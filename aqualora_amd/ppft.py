@@ -49,6 +49,7 @@ class PPFTTrainer:
         self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.ds_accum = None
+        self.deferred = ops.DeferredDW(dev)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
 
@@ -67,7 +68,12 @@ class PPFTTrainer:
             clean = self.unet(x_t, t, ctx, cross_attention_kwargs={"scale": None}).sample
         pred = self.unet(x_t_wm, t, ctx, cross_attention_kwargs={"scale": S_in}).sample
         loss = ops.mse_loss(pred, clean)
-        loss.backward()
+        ops.DEFERRED = self.deferred  # weight-gradient GEMMs + dS reductions are collected ...
+        try:
+            loss.backward()
+        finally:
+            ops.DEFERRED = None
+        self.deferred.flush()         # ... and run as two grouped launches here
         S.backward(self.ds_accum)
         return loss.detach(), pred.detach(), clean
 

@@ -55,6 +55,13 @@ int aql_conv3x3_bwd_data(const bf16_t* dY, int B, int Hin, int Win, int Cin, con
 int aql_gemm_tn_f32(const bf16_t* U, long ldu, const bf16_t* V, long ldv, long M, int P, int Q, float alpha, float* C,
                     long ldc, aql_stream_t stream);
 
+/* Grouped form: ONE launch for every LoRA weight gradient of a backward pass (all problems have a rank <= 32 side).
+ * aql_tn_desc_fill writes an 80-byte descriptor into HOST memory and returns the workgroups it needs (0 = shape not
+ * groupable); the caller copies the table to the device and passes the running block prefix as first_block.       */
+int aql_tn_desc_fill(void* host_desc, const bf16_t* U, long ldu, const bf16_t* V, long ldv, long M, int P, int Q,
+                     float alpha, float* C, long ldc, int first_block);
+int aql_gemm_tn_grouped(const void* dev_descs, int n, int total_blocks, aql_stream_t stream);
+
 /* ---- normalisation (csrc/aql_norm.hip) ---- torch.nn.GroupNorm(32,C,eps)+SiLU, torch.nn.LayerNorm(C) as used at
  * scripts/lib/original_unet.py:423,429,444-453,826 and :779-783.  stats: [B,32,2] / [M,2] fp32 (mean, rstd).     */
 long aql_groupnorm_scratch_floats(int B, int HW);
@@ -102,6 +109,10 @@ int aql_cast_transpose(const float* w, int rows, int cols, bf16_t* out, bf16_t* 
 int aql_cast_transpose_batched(const void* desc, int n, int total_tiles, aql_stream_t stream);
 /* dS[b,j] += sum_{m in sample b} dTs[m,j]*T[m,j]: gradient of the diagonal (autograd of diag_embed, :16-17)         */
 int aql_lora_ds(const bf16_t* dTs, const bf16_t* T, int nb, int rows_per_sample, int r, float* dS, aql_stream_t stream);
+/* grouped form (48-byte host descriptors, same protocol as aql_tn_desc_fill)                                         */
+int aql_ds_desc_fill(void* host_desc, const bf16_t* dTs, const bf16_t* T, int nb, int rows_per_sample, int r, float* dS,
+                     int first_block);
+int aql_lora_ds_grouped(const void* dev_descs, int n, int total_blocks, aql_stream_t stream);
 /* clip_grad_norm_ + torch.optim.AdamW on flat fp32 buffers  train/ppft_train.py:1059-1066, 779-787                 */
 int aql_sumsq_f32(const float* g, long n, float* out, aql_stream_t stream);
 int aql_clipnorm_adamw(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float max_norm,
