@@ -17,7 +17,11 @@ namespace aqlgemm {
 constexpr int BK = 64;
 constexpr int NTHREADS = 256;
 
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+// ds_read_b128 is serviced in four NON-contiguous 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) over a
+// 256-B bank window (two 128-B rows).  XOR-ing the chunk with (row>>1)&7 gives every group 8 distinct slots per row
+// parity, i.e. conflict-free fragment reads; the (row&7) swizzle measured 33 % SQ_LDS_BANK_CONFLICT (rows r and r+8
+// of one group collide).
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 __device__ __forceinline__ uint4 zero4() { return make_uint4(0u, 0u, 0u, 0u); }
 
