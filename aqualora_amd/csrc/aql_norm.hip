@@ -99,15 +99,19 @@ __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __
 
 // pass 1.5: reduce slabs.  MODE 0 -> stats = (mean, rstd);  MODE 1 -> (mean dxhat, mean dxhat*xhat)
 template <int MODE>
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nslab, float inv_count, float eps,
-                                   float* __restrict__ out) {
-  const int b = blockIdx.x, g = threadIdx.x;
-  if (g >= G) return;
-  float s1 = 0.f, s2 = 0.f;
-  for (int s = 0; s < nslab; ++s) {
-    s1 += partial[(((long)b * nslab + s) * G + g) * 2 + 0];
-    s2 += partial[(((long)b * nslab + s) * G + g) * 2 + 1];
-  }
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nslab, float inv_count,
+                                                          float eps, float* __restrict__ out) {
+  // 256 threads: (group,which) = t & 63, slab quarter = t >> 6; fixed-order tree -> deterministic
+  __shared__ float red[4][64];
+  const int b = blockIdx.x, gw = threadIdx.x & 63, part = threadIdx.x >> 6;
+  float acc = 0.f;
+  for (int s = part; s < nslab; s += 4) acc += partial[((long)b * nslab + s) * (G * 2) + gw];
+  red[part][gw] = acc;
+  __syncthreads();
+  if (threadIdx.x >= G) return;
+  const int g = threadIdx.x;
+  const float s1 = (red[0][2 * g] + red[1][2 * g]) + (red[2][2 * g] + red[3][2 * g]);
+  const float s2 = (red[0][2 * g + 1] + red[1][2 * g + 1]) + (red[2][2 * g + 1] + red[3][2 * g + 1]);
   if (MODE == 0) {
     const float mean = s1 * inv_count;
     const float var = fmaxf(s2 * inv_count - mean * mean, 0.f);
@@ -264,8 +268,8 @@ inline int gn_geometry(int HW, int C, int* threads, int* rows_per_slab) {
   if (rp < 1) rp = 1;
   if (rp > HW) rp = HW;
   *threads = cols * rp;
-  int nslab = (HW + 63) / 64;  // ~64 pixel rows per slab
-  if (nslab > 64) nslab = 64;
+  int nslab = (HW + 31) / 32;  // ~32 pixel rows per slab
+  if (nslab > 128) nslab = 128;
   if (nslab < 1) nslab = 1;
   *rows_per_slab = (HW + nslab - 1) / nslab;
   return (HW + *rows_per_slab - 1) / *rows_per_slab;
@@ -276,7 +280,7 @@ inline int gn_geometry(int HW, int C, int* threads, int* rows_per_slab) {
 // scratch: caller-owned fp32 workspace of at least aql_groupnorm_scratch_floats(B, HW) elements
 extern "C" long aql_groupnorm_scratch_floats(int B, int HW) {
   (void)HW;
-  return (long)B * 64 * G * 2 + (long)B * G * 2;
+  return (long)B * 128 * G * 2 + (long)B * G * 2;
 }
 
 extern "C" int aql_groupnorm_silu_fwd(const bf16_t* x, int B, int HW, int C, const bf16_t* gamma, const bf16_t* beta,
@@ -288,7 +292,7 @@ extern "C" int aql_groupnorm_silu_fwd(const bf16_t* x, int B, int HW, int C, con
   const int nslab = gn_geometry(HW, C, &threads, &rps);
   hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(nslab, B), dim3(threads), threads * 64, stream, x, nullptr, gamma, beta, nullptr,
                      HW, C, rps, silu, scratch);
-  hipLaunchKernelGGL(gn_finalize_kernel<0>, dim3(B), dim3(64), 0, stream, scratch, nslab,
+  hipLaunchKernelGGL(gn_finalize_kernel<0>, dim3(B), dim3(256), 0, stream, scratch, nslab,
                      1.f / ((float)HW * (C / G)), eps, stats);
   const long nchunk = (long)HW * (C / 8);
   int blocks = (int)((nchunk + 255) / 256);
@@ -306,10 +310,10 @@ extern "C" int aql_groupnorm_silu_bwd(const bf16_t* x, const bf16_t* dy, int B, 
   AQL_CHECK_ARG(C % 8 == 0 && C % G == 0 && C / 8 <= 1024, "aql_groupnorm_silu_bwd: bad C=%d", C);
   int threads, rps;
   const int nslab = gn_geometry(HW, C, &threads, &rps);
-  float* dstats = scratch + (long)B * 64 * G * 2;
+  float* dstats = scratch + (long)B * 128 * G * 2;
   hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(nslab, B), dim3(threads), threads * 64, stream, x, dy, gamma, beta, stats, HW, C,
                      rps, silu, scratch);
-  hipLaunchKernelGGL(gn_finalize_kernel<1>, dim3(B), dim3(64), 0, stream, scratch, nslab,
+  hipLaunchKernelGGL(gn_finalize_kernel<1>, dim3(B), dim3(256), 0, stream, scratch, nslab,
                      1.f / ((float)HW * (C / G)), 0.f, dstats);
   const long nchunk = (long)HW * (C / 8);
   int blocks = (int)((nchunk + 255) / 256);

@@ -5,6 +5,8 @@ One process per GPU; the LoRA + mapper gradients already live in ONE flat fp32 b
 order (lora.LoraBank), so the exchange is one collective (or a few large buckets) over RCCL/xGMI instead of DDP's
 many 25 MB buckets.  Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -17,8 +19,8 @@ def allreduce_mean_(flat, group=None, bucket_elems=None):
     """In-place mean over ranks of a flat tensor, optionally in buckets of ``bucket_elems`` (front buckets first:
     with the bank's reverse-traversal layout they are complete first in backward)."""
     w = world_size(group)
-    if w == 1:
-        return flat
+    if w == 1 and not (dist.is_available() and dist.is_initialized() and os.environ.get("AQL_FORCE_ALLREDUCE")):
+        return flat  # (AQL_FORCE_ALLREDUCE=1 exercises the collective on a single GPU)
     backend = dist.get_backend(group)
     n = flat.numel()
     step = n if not bucket_elems else int(bucket_elems)

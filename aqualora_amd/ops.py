@@ -30,9 +30,9 @@ def workspace(device, nfloats=64 << 20):
 def _gn_scratch(device, B):
     key = (device.index if device.index is not None else torch.cuda.current_device())
     t = _GN.get(key)
-    need = B * 64 * 32 * 2 + B * 32 * 2
+    need = B * 128 * 32 * 2 + B * 32 * 2
     if t is None or t.numel() < need:
-        t = torch.empty(max(need, 1 << 16), dtype=torch.float32, device=device)
+        t = torch.empty(max(need, 1 << 17), dtype=torch.float32, device=device)
         _GN[key] = t
     return t
 

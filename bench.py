@@ -139,7 +139,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    launched = "RANK" in os.environ  # under torch.distributed.run (also for N=1, so the RCCL path is the one measured)
+    if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
 
@@ -150,7 +151,7 @@ def main():
         runner = tr.capture(batch)
 
     def barrier():
-        if world > 1:
+        if launched:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -162,7 +163,7 @@ def main():
         loss = runner(**batch)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if launched:
         tt = torch.tensor([dt], device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
@@ -190,7 +191,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tr, args.rank)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if launched:
         dist.destroy_process_group()
 
 
