@@ -1,0 +1,32 @@
+"""GPU: per-kernel parity sweeps (GEMM family, conv fwd/bwd, norms, GEGLU, attention fwd/bwd incl. ragged / cross /
+spiked-softmax cases, fused LoRA linear at ranks 8..320) against fp32 torch references of the same op.  The sweeps live
+in tools/probe_gemm.py and tools/probe_ops.py (they also print timings); each prints PASS/FAIL per case with its
+tolerance and a final verdict."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(script):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script)], capture_output=True, text=True,
+                         timeout=900)
+    text = out.stdout + out.stderr
+    fails = [l for l in text.splitlines() if l.startswith("FAIL")]
+    assert out.returncode == 0 and "ALL PASS" in text and not fails, "\n".join(fails[:20]) or text[-2000:]
+    return text
+
+
+def test_gemm_family_parity():
+    text = _run("probe_gemm.py")
+    assert text.count("PASS") >= 30
+
+
+def test_ops_parity():
+    text = _run("probe_ops.py")
+    assert text.count("PASS") >= 60

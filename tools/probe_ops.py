@@ -61,7 +61,8 @@ k[0, 200, :40] = q[0, 5, :40] * 20
 report("attn fwd spike", relerr(ops.attention(q, k, v, 8), attn_ref(q.float(), k.float(), v.float(), 8)), 1.5e-2)
 # fused LoRA linear fwd/bwd
 class Site: pass
-for (B, N, K, Nout, r) in [(2, 256, 320, 320, 32), (2, 77, 768, 640, 8), (2, 64, 1280, 10240, 32), (1, 1024, 320, 320, 320)]:
+for (B, N, K, Nout, r) in [(2, 256, 320, 320, 32), (2, 77, 768, 640, 8), (2, 64, 1280, 10240, 32), (1, 1024, 320, 320, 320),
+                           (2, 256, 640, 640, 16), (2, 64, 1280, 1280, 64), (2, 77, 768, 320, 320)]:
     M = B * N
     x = rnd(M, K).requires_grad_(True); W = rnd(Nout, K, scale=K ** -0.5); bias = rnd(Nout); A = torch.randn(r, K, device=dev) / r; Bu = torch.randn(Nout, r, device=dev) * 0.05
     S = (torch.randn(B, r, device=dev) * 0.3 + 1).requires_grad_(True); res = rnd(M, Nout)
