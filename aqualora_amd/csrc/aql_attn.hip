@@ -24,10 +24,18 @@ constexpr int TILE = 64;                    // streamed rows per tile
 constexpr int OWN = 32;                     // owner rows per wavefront
 constexpr float LOG2E = 1.4426950408889634f;
 
+// LDS image of a streamed tile: [64 rows][pitch], pitch a multiple of the 256-B bank window, 16-B chunk index XORed with
+// (row & 7) << 1.  With the hardware's real lane groups this is conflict-free for BOTH consumers: the ds_read_b128
+// A-fragments of the S-product (group = rows {0-3,12-15} at chunk c + rows 4-11 at chunk c+1) and the 8-row x 32-B
+// ds_read_b64_tr_b16 gathers of the T-product (bit 0 of the chunk is left alone so a 32-B pair stays a pair).
 template <int DH>
 struct RowPitch {
-  static constexpr int value = DH * 2 + 16;  // odd number of 16-byte slots -> conflict-free ds_read_b128
+  static constexpr int value = (DH <= 128) ? 256 : 512;
 };
+template <int DH>
+__device__ __forceinline__ int tile_off(int row, int chunk) {
+  return row * RowPitch<DH>::value + ((chunk ^ ((row & 7) << 1)) << 4);
+}
 
 __device__ __forceinline__ uint4 zero4() { return make_uint4(0u, 0u, 0u, 0u); }
 // AND-mask instead of a select: keeps the load unconditional (a select lets LLVM sink the load under a branch, and
@@ -56,7 +64,7 @@ __device__ __forceinline__ void stage_rows(char* lds, const bf16_t* g, long ld, 
   for (int it = 0; it < NIT; ++it) {
     const int id = tid + it * 256;
     const int row = id / CPR, c = id - row * CPR;
-    if (id < TILE * CPR) *reinterpret_cast<uint4*>(lds + row * RowPitch<DH>::value + c * 16) = v[it];
+    if (id < TILE * CPR) *reinterpret_cast<uint4*>(lds + tile_off<DH>(row, c)) = v[it];
   }
 }
 
@@ -87,8 +95,7 @@ __device__ __forceinline__ void s_product(f32x4_t (&acc)[4][2], const char* tile
     bf16x8_t a[4];
 #pragma unroll
     for (int sf = 0; sf < 4; ++sf)
-      a[sf] = *reinterpret_cast<const bf16x8_t*>(tile + (sf * 16 + (lane & 15)) * RowPitch<DH>::value + s * 64 +
-                                                 (lane >> 4) * 16);
+      a[sf] = *reinterpret_cast<const bf16x8_t*>(tile + tile_off<DH>(sf * 16 + (lane & 15), s * 4 + (lane >> 4)));
 #pragma unroll
     for (int sf = 0; sf < 4; ++sf)
 #pragma unroll
@@ -124,13 +131,13 @@ __device__ __forceinline__ void t_product(f32x4_t (&acc)[DV / 16][2], const char
   const int p = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2) {
-    const char* base = tile + (s2 * 32 + g * 4 + (p >> 2)) * RowPitch<DH>::value + (p & 3) * 8;
+    const int row = s2 * 32 + g * 4 + (p >> 2);  // rows row and row+16 share (row & 7): same swizzle
 #pragma unroll
     for (int df = 0; df < DV / 16; ++df) {
-      const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (v4s_t __attribute__((address_space(3)))*)(base + df * 32));
+      const char* base = tile + tile_off<DH>(row, df * 2 + ((p & 3) >> 1)) + (p & 1) * 8;
+      const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3)))*)(base));
       const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (v4s_t __attribute__((address_space(3)))*)(base + df * 32 + 16 * RowPitch<DH>::value));
+          (v4s_t __attribute__((address_space(3)))*)(base + 16 * RowPitch<DH>::value));
       const bf16x8_t a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
       for (int of = 0; of < 2; ++of)
