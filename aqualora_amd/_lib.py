@@ -47,6 +47,7 @@ SIGNATURES = {
     "aql_lora_ds": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     "aql_sumsq_f32": [c_p, c_l, c_p, c_p],
     "aql_clipnorm_adamw": [c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_p, c_f, c_f, c_f, c_f, c_p, c_p],
+    "aql_jpeg_mask": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "aql_sdpa_fwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p, c_p],
     "aql_sdpa_bwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p,
                      c_p, c_p],

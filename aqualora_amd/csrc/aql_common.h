@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <math.h>
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits; no torch / hip_bf16 types cross the ABI
 

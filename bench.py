@@ -113,13 +113,16 @@ def cpu_baseline(tr, rank):
     x = synth.normal("bench.z", (1, 4, 64, 64), 1.0, 2048)
     ctx = synth.normal("bench.ctx", (1, 77, 768), 1.0, 2048)
     t = torch.tensor([500])
+    times = []
     with torch.no_grad():
-        t0 = time.perf_counter()
-        net.forward(x, t, ctx, None)
-        dt = time.perf_counter() - t0
+        for _ in range(4):  # 1 warm-up + 3 timed full-size forwards (about 10 s of CPU work on 32 threads)
+            t0 = time.perf_counter()
+            net.forward(x, t, ctx, None)
+            times.append(time.perf_counter() - t0)
+    dt = sorted(times[1:])[1]
     step_s = dt * step_tflop_per_image(rank) / (UNET_FWD_GFLOP / 1e3)
     return {"value": 1.0 / step_s, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"one full-size SD-1.5 U-Net forward (batch 1, fp32, oracle/ppft_oracle.py) = {dt:.2f} s; "
+            "sample": f"median of 3 full-size SD-1.5 U-Net forwards (batch 1, fp32, oracle/ppft_oracle.py) = {dt:.2f} s; "
                       f"PPFT step extrapolated by algorithmic FLOPs x{step_tflop_per_image(rank) / (UNET_FWD_GFLOP / 1e3):.3f}"}
 
 

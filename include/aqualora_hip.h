@@ -119,6 +119,11 @@ int aql_clipnorm_adamw(float* p, const float* g, float* m, float* v, long n, con
                        const float* lr, float beta1, float beta2, float eps, float wd, const int* step,
                        aql_stream_t stream);
 
+/* ---- distortion layers (csrc/aql_jpeg.hip) ---- JpegCompression.forward  utils/noise_layers/jpeg_compression.py:127-162
+ * (RGB->YUV, 8x8 DCT, zig-zag keep-mask 25/9/9, IDCT, YUV->RGB; NCHW fp32).  backward=1 applies the transposed map.   */
+int aql_jpeg_mask(const float* x, float* y, int B, int H, int W, int keep_y, int keep_u, int keep_v, int backward,
+                  aql_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -242,3 +242,49 @@ def lora_state_dict_keys(unet_keys):
             k = k + ".lora"
         out += [f"unet.{k}.down.weight", f"unet.{k}.up.weight"]
     return out
+
+
+# ------------------------------------------------------------------------------------ distortions + metrics
+def jpeg_zigzag_mask(keep):
+    """8x8 keep-mask: first `keep` positions of sorted((i,j), key=(i+j, -j if (i+j) odd else j)) (jpeg_compression.py:31-41)."""
+    order = sorted(((i, j) for i in range(8) for j in range(8)), key=lambda p: (p[0] + p[1], -p[1] if (p[0] + p[1]) % 2 else p[1]))
+    m = torch.zeros(8, 8)
+    for i, j in order[:keep]:
+        m[i, j] = 1.0
+    return m
+
+
+def jpeg_compression(x, keep=(25, 9, 9)):
+    """utils/noise_layers/jpeg_compression.py:127-162 on NCHW fp32: zero-pad to multiples of 8, rgb2yuv (:53-57),
+    blockwise DCT with dct_coeff (:44-45), zig-zag keep-mask, IDCT with idct_coeff (:48-50), yuv2rgb (:60-64), crop."""
+    B, C, H, W = x.shape
+    ph, pw = (8 - H % 8) % 8, (8 - W % 8) % 8
+    xp = F.pad(x, (0, pw, 0, ph))
+    rgb2yuv = torch.tensor([[0.299, 0.587, 0.114], [-0.14713, -0.28886, 0.436], [0.615, -0.51499, -0.10001]])
+    yuv2rgb = torch.tensor([[1.0, 0.0, 1.13983], [1.0, -0.39465, -0.58060], [1.0, 2.03211, 0.0]])
+    n = torch.arange(8, dtype=torch.float64)
+    Tm = torch.cos(math.pi / 8 * (n[None, :] + 0.5) * n[:, None]).float()                       # T[k][n]
+    Um = (((n[None, :] == 0).double() * -0.5 + torch.cos(math.pi / 8 * (n[:, None] + 0.5) * n[None, :])) *
+          math.sqrt(1 / 16)).float()                                                            # U[k][n] = idct(n,k)
+    yuv = torch.einsum("ij,bjhw->bihw", rgb2yuv, xp)
+    Hp, Wp = yuv.shape[2:]
+    blocks = yuv.reshape(B, 3, Hp // 8, 8, Wp // 8, 8).permute(0, 1, 2, 4, 3, 5)                # [B,3,bh,bw,8,8]
+    coef = Tm @ blocks @ Tm.T
+    mask = torch.stack([jpeg_zigzag_mask(k) for k in keep])[None, :, None, None]
+    rec = Um @ (coef * mask) @ Um.T
+    rec = rec.permute(0, 1, 2, 4, 3, 5).reshape(B, 3, Hp, Wp)
+    out = torch.einsum("ij,bjhw->bihw", yuv2rgb, rec)
+    return out[:, :, :H, :W]
+
+
+def calculate_fpr(tau, k):
+    """evaluation/utils_eval.py:131-134."""
+    return sum(math.comb(k, i) for i in range(tau + 1, k + 1)) / (2 ** k)
+
+
+def get_threshold(k, fpr):
+    """evaluation/utils_eval.py:136-140."""
+    tau = 0
+    while calculate_fpr(tau, k) > fpr:
+        tau += 1
+    return tau

@@ -106,7 +106,8 @@ def install_stubs():
               "diffusers.schedulers", "diffusers.schedulers.scheduling_ddpm", "diffusers.schedulers.scheduling_ddim",
               "diffusers.schedulers.scheduling_euler_discrete", "diffusers.configuration_utils",
               "diffusers.training_utils", "torchvision", "torchvision.models", "torchvision.models.efficientnet",
-              "torchvision.transforms", "torchvision.utils", "lpips", "timm", "kornia", "kornia.augmentation",
+              "torchvision.transforms", "torchvision.utils", "torchvision.io", "torchvision.transforms.functional",
+              "diffusers.pipelines", "diffusers.pipelines.stable_diffusion", "lpips", "timm", "kornia", "kornia.augmentation",
               "xformers", "wandb", "bitsandbytes"]:
         if n not in sys.modules:
             _stub(n)
@@ -374,6 +375,38 @@ def gen_full_block(lm, ou):
     save("full_block.npz", y=y.detach().numpy())
 
 
+def gen_jpeg_and_metrics():
+    import utils.noise_layers.jpeg_compression as jc
+    layer = jc.JpegCompression("cpu")
+    out = {}
+    for tag, shape in (("a", (2, 3, 64, 64)), ("b", (1, 3, 50, 44))):
+        x = T(f"jpeg.{tag}.x", shape, 0.5).requires_grad_(True)
+        y = layer([x, None])[0]
+        dy = T(f"jpeg.{tag}.dy", shape)
+        y.backward(dy)
+        out[f"{tag}.y"] = y.detach().numpy()
+        out[f"{tag}.dx"] = x.grad.numpy()
+    mask = layer.get_mask((3, 8, 8)).numpy()
+    out["mask8"] = mask
+    out["mask_counts"] = mask.reshape(3, -1).sum(1)
+    save("jpeg.npz", **out)
+    # metrics: evaluation/utils_eval.py get_threshold / calculate_fpr (file imports heavy third-party modules; stubs)
+    for n in ["PIL", "diffusers.pipelines", "tqdm"]:
+        pass
+    sys.path.insert(0, os.path.join(REF, "evaluation"))
+    import importlib
+    try:
+        ue = importlib.import_module("utils_eval")
+        ks = [16, 32, 48, 64]
+        fprs = [1e-2, 1e-3, 1e-6, 1e-9]
+        thr = np.array([[ue.get_threshold(k, f) for f in fprs] for k in ks])
+        fpr_tab = np.array([ue.calculate_fpr(t, 48) for t in range(0, 48, 4)])
+        save("metrics.npz", ks=np.array(ks), fprs=np.array(fprs), thresholds=thr, fpr48=fpr_tab)
+    except Exception as e:  # noqa: BLE001
+        print("utils_eval import failed:", repr(e))
+        raise
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     lm, models, misc, ou = import_reference()
@@ -381,6 +414,7 @@ if __name__ == "__main__":
     gen_watermark(models)
     gen_misc(misc)
     gen_full_block(lm, ou)
+    gen_jpeg_and_metrics()
     unet, keys, loras = gen_tiny_ppft(lm, models, ou)
     try:
         gen_checkpoint_layout(unet, keys, loras)

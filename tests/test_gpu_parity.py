@@ -216,3 +216,20 @@ def test_checkpoint_roundtrip_and_consumer_contract(tmp_path, golden):
     for k in keys:
         assert torch.equal(back[k + ".down.weight"], lw[k][0]) and torch.equal(back[k + ".up.weight"], lw[k][1])
     assert list(torch.load(str(tmp_path / "mapper.pt")).keys()) == ["bit_embeddings.weight"]
+
+
+def test_jpeg_layer_vs_reference_golden(golden):
+    from aqualora_amd.noise import JpegCompression
+    g = golden("jpeg.npz")
+    layer = JpegCompression()
+    for tag, shape in (("a", (2, 3, 64, 64)), ("b", (1, 3, 50, 44))):
+        x = T(f"jpeg.{tag}.x", shape, 0.5, DEV).requires_grad_(True)
+        y = layer([x, None])[0]
+        y.backward(T(f"jpeg.{tag}.dy", shape, device=DEV))
+        assert relerr(y, g[f"{tag}.y"]) < 1e-5 and relerr(x.grad, g[f"{tag}.dx"]) < 1e-5
+    # full-size property checks (512x512): idempotence of the projection and linearity
+    x = T("jpeg.big", (2, 3, 512, 512), 0.5, DEV)
+    y = layer([x.clone(), None])[0]
+    yy = layer([y.clone(), None])[0]
+    assert relerr(layer([2.0 * x, None])[0], 2.0 * y) < 1e-5
+    assert y.shape == x.shape and torch.isfinite(yy).all()

@@ -164,3 +164,31 @@ def test_tiny_ppft_step_matches_reference(golden):
     close(lora[k0][0].detach(), g["p." + k0 + ".down"], 1e-5)
     close(lora[k0][1].detach(), g["p." + k0 + ".up"], 1e-5)
     close(E.detach(), g["p.mapper"], 1e-5)
+
+
+def test_jpeg_layer_matches_reference(golden):
+    g = golden("jpeg.npz")
+    assert list(g["mask_counts"]) == [25, 9, 9]
+    assert np.array_equal(torch.stack([O.jpeg_zigzag_mask(k) for k in (25, 9, 9)]).numpy(), g["mask8"])
+    for tag, shape in (("a", (2, 3, 64, 64)), ("b", (1, 3, 50, 44))):
+        x = T(f"jpeg.{tag}.x", shape, 0.5).requires_grad_(True)
+        y = O.jpeg_compression(x)
+        y.backward(T(f"jpeg.{tag}.dy", shape))
+        close(y.detach(), g[f"{tag}.y"], 1e-5)
+        close(x.grad, g[f"{tag}.dx"], 1e-5)
+
+
+def test_metrics_match_reference(golden):
+    from aqualora_amd import metrics as M
+    g = golden("metrics.npz")
+    for i, k in enumerate(g["ks"]):
+        for j, f in enumerate(g["fprs"]):
+            assert O.get_threshold(int(k), float(f)) == int(g["thresholds"][i, j]) == M.get_threshold(int(k), float(f))
+    assert M.get_threshold(48, 1e-6) == 40 and M.get_threshold(48, 1e-3) == 35
+    for t, v in zip(range(0, 48, 4), g["fpr48"]):
+        assert abs(M.calculate_fpr(t, 48) - float(v)) < 1e-15 and abs(O.calculate_fpr(t, 48) - float(v)) < 1e-15
+    bits = torch.tensor([[1, 0, 1, 1], [0, 0, 1, 1]])
+    gt = torch.tensor([[1, 0, 1, 0], [0, 0, 1, 1]])
+    assert M.bit_accuracy(bits, gt).tolist() == [0.75, 1.0]
+    logits = torch.tensor([[[0.1, 0.9], [2.0, -1.0]]])
+    assert M.extract_bits(logits).tolist() == [[1, 0]]
