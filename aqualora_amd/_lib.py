@@ -48,6 +48,12 @@ SIGNATURES = {
     "aql_sumsq_f32": [c_p, c_l, c_p, c_p],
     "aql_clipnorm_adamw": [c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_p, c_f, c_f, c_f, c_f, c_p, c_p],
     "aql_jpeg_mask": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "aql_resize_bilinear_nhwc": [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
+    "aql_stem_conv3x3s2_silu": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
+    "aql_dwconv_silu": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
+    "aql_avgpool_nhwc": [c_p, c_i, c_i, c_i, c_p, c_p],
+    "aql_se_gate": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p],
+    "aql_pwconv_f32": [c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_i, c_i, c_p, c_p],
     "aql_sdpa_fwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p, c_p],
     "aql_sdpa_bwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p,
                      c_p, c_p],

@@ -89,6 +89,7 @@ void launch_cfg(int cfg, const GemmArgs<LA, LB>& g, hipStream_t stream) {
     case 0: launch_gemm<128, 32, 32, 32, LA, LB, EPI>(g, stream); break;
     case 1: launch_gemm<128, 128, 64, 64, LA, LB, EPI>(g, stream); break;
     case 2: launch_gemm<128, 64, 64, 32, LA, LB, EPI>(g, stream); break;
+    case 4: launch_gemm<256, 64, 64, 64, LA, LB, EPI>(g, stream); break;
     default: launch_gemm<64, 64, 32, 32, LA, LB, EPI>(g, stream); break;
   }
 }
@@ -128,7 +129,13 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
   g.epi.rows_per_sample = o.rows_per_sample > 0 ? o.rows_per_sample : 1;
   const int kt_total = g.ktiles0 + g.ktiles1;
   int tiles = 0;
-  const int cfg = pick_cfg(g.M, g.N, kt_total, ws != nullptr && o.C2 == nullptr, &tiles);
+  int cfg = pick_cfg(g.M, g.N, kt_total, ws != nullptr && o.C2 == nullptr, &tiles);
+  if (const char* e = getenv("AQL_CFG2_AS")) {  // tuning hook: remap the 128x64 config
+    if (cfg == 2 && g.M >= 1024) {
+      cfg = atoi(e);
+      tiles = aql_cdiv(g.M, cfg == 4 ? 256 : 128) * aql_cdiv(g.N, 64);
+    }
+  }
   int splits = 1;
   if (ws != nullptr && o.C2 == nullptr) splits = pick_splits(tiles, kt_total, g.M, g.N, ws_bytes);
   g.splits = splits;

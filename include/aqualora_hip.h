@@ -124,6 +124,20 @@ int aql_clipnorm_adamw(float* p, const float* g, float* m, float* v, long n, con
 int aql_jpeg_mask(const float* x, float* y, int B, int H, int W, int keep_y, int keep_u, int keep_v, int backward,
                   aql_stream_t stream);
 
+/* ---- SecretDecoder inference (csrc/aql_decoder.hip) ---- utils/models.py:91-96 (torchvision efficientnet_b1, eval mode,
+ * BatchNorm folded by the host), fp32 NHWC.                                                                           */
+int aql_resize_bilinear_nhwc(const float* x_nchw, int B, int C, int H, int W, int Ho, int Wo, float* y_nhwc,
+                             aql_stream_t stream);
+int aql_stem_conv3x3s2_silu(const float* x, const float* w, const float* bias, int B, int H, int W, int Cout, float* y,
+                            aql_stream_t stream);
+int aql_dwconv_silu(const float* x, const float* w, const float* bias, int B, int H, int W, int C, int k, int stride,
+                    float* y, aql_stream_t stream);
+int aql_avgpool_nhwc(const float* x, int B, int HW, int C, float* out, aql_stream_t stream);
+int aql_se_gate(const float* pool, const float* w1, const float* b1, const float* w2, const float* b2, int B, int C,
+                int Cs, float* gate, aql_stream_t stream);
+int aql_pwconv_f32(const float* x, const float* w, const float* bias, const float* gate, int rows_per_sample,
+                   const float* residual, long M, int N, int K, int act, float* y, aql_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -233,3 +233,50 @@ def test_jpeg_layer_vs_reference_golden(golden):
     yy = layer([y.clone(), None])[0]
     assert relerr(layer([2.0 * x, None])[0], 2.0 * y) < 1e-5
     assert y.shape == x.shape and torch.isfinite(yy).all()
+
+
+def _synthetic_decoder(bits=48):
+    from aqualora_amd import synth
+    from aqualora_amd.decoder import SecretDecoder
+    dec = SecretDecoder(bits)
+    with torch.no_grad():
+        for name, t in dec.state_dict().items():
+            if name.endswith("num_batches_tracked"):
+                continue
+            if name.endswith("running_var"):
+                t.copy_(synth.normal(name, t.shape, 0.2, SEED).abs() + 0.5)
+            elif name.endswith("running_mean"):
+                t.copy_(synth.normal(name, t.shape, 0.1, SEED))
+            elif t.dim() >= 2:
+                t.copy_(synth.normal(name, t.shape, (1.0 / t[0].numel()) ** 0.5, SEED))
+            elif name.endswith(".1.weight"):  # BN gamma; the residual-branch (project) BN is damped so that the
+                last = (".block.3.1." in name) or (".block.2.1." in name and "features.1." in name)  # net stays O(1)
+                t.copy_((1.0 + synth.normal(name, t.shape, 0.1, SEED)) * (0.3 if last else 1.0))
+            else:
+                t.copy_(synth.normal(name, t.shape, 0.05, SEED))
+    return dec
+
+
+def test_secret_decoder_vs_oracle_bits_exact():
+    """fp32 logits within 1e-3 of the CPU oracle and the extracted bits identical (north star: bits bit-exact)."""
+    from aqualora_amd import metrics
+    from oracle.decoder_oracle import secret_decoder
+    dec = _synthetic_decoder(48)
+    sd = {k: v.clone() for k, v in dec.state_dict().items()}
+    dec = dec.to(DEV).eval()
+    for shape in ((2, 3, 512, 512), (1, 3, 576, 640), (3, 3, 96, 80)):
+        x = T("dec.x" + str(shape), shape, 0.5).clamp(-1, 1)
+        with torch.no_grad():
+            want = secret_decoder(sd, x, 48)
+        got = dec(x.to(DEV))
+        assert got.shape == want.shape == (shape[0], 48, 2)
+        assert relerr(got, want) < 1e-3, relerr(got, want)
+        margin = (want[..., 0] - want[..., 1]).abs()
+        sure = margin > 1e-3 * want.abs().max()
+        assert torch.equal(metrics.extract_bits(got).cpu()[sure], metrics.extract_bits(want)[sure])
+        assert sure.float().mean() > 0.95
+    msg = metrics.extract_bits(want)
+    acc, tpr = metrics.tpr_at_fpr(metrics.extract_bits(got).cpu(), msg, 1e-6)
+    assert acc == 1.0 and tpr == 1.0
+    with pytest.raises(NotImplementedError):
+        dec.train()
