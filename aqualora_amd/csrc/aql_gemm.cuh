@@ -207,6 +207,7 @@ struct GemmArgs {
   int ktiles0, ktiles1;
   int M, N;
   int splits;  // grid.z; k tiles of the concatenated K range are divided evenly
+  int m_fast;  // tile order: 0 = N tiles of one M tile adjacent (activation reuse), 1 = M tiles adjacent (weight reuse)
   EpiParams epi;
 };
 
@@ -306,8 +307,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<LA, LB>& g, const int b
   const int wn0 = (wave % WAVES_N) * WN;
 
   const int tiles_n = (g.N + BN - 1) / BN;
-  const int tile_m = block_x / tiles_n;
-  const int tile_n = block_x - tile_m * tiles_n;
+  const int tiles_m = (g.M + BM - 1) / BM;
+  int tile_m, tile_n;
+  if (g.m_fast) {
+    tile_n = block_x / tiles_m;
+    tile_m = block_x - tile_n * tiles_m;
+  } else {
+    tile_m = block_x / tiles_n;
+    tile_n = block_x - tile_m * tiles_n;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // K range of this split
@@ -498,7 +506,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<LA, LB>& g, const int b
 
 template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs<LA, LB> g) {
-  gemm_body<BM, BN, WM, WN, LA, LB, EPI>(g, blockIdx.x, blockIdx.z);
+  // XCD-aware remap (guide T1): hardware block b runs on XCD b % 8, each XCD has a private L2.  Give every XCD a
+  // CONTIGUOUS run of logical tiles so that tiles sharing an operand panel hit the same L2 (bijective for any grid).
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  gemm_body<BM, BN, WM, WN, LA, LB, EPI>(g, logical, blockIdx.z);
 }
 
 // Grouped token-reduction GEMMs: ONE launch for all LoRA weight gradients of a backward pass.  Every problem has a
@@ -529,7 +542,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_grouped_kernel(const TnGroup
   g.b0.base = d.b; g.b0.ld = d.ldb; g.b0.rows = d.b_rows; g.b0.K = d.M;
   g.a1 = g.a0; g.b1 = g.b0;
   g.ktiles0 = (d.M + BK - 1) / BK; g.ktiles1 = 0;
-  g.M = d.a_rows; g.N = d.b_rows; g.splits = d.splits;
+  g.M = d.a_rows; g.N = d.b_rows; g.splits = d.splits; g.m_fast = 0;
   g.epi = EpiParams{};
   g.epi.Cf = d.C; g.epi.ldcf = d.ldc; g.epi.alpha = d.alpha; g.epi.trans_out = d.trans_out;
   gemm_body<128, 32, 32, 32, TransLoader, TransLoader, EPI_ATOMIC>(g, local % tiles, local / tiles);

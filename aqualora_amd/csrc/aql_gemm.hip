@@ -75,8 +75,8 @@ struct OutSpec {
 
 inline int pick_splits(int tiles, int kt_total, long M, int N, size_t ws_bytes) {
   // split-K pays only when K is deep (the fp32 slabs cost 8 B per output element per split) and the grid is small
-  if (tiles >= 128 || kt_total < 32) return 1;
-  int s = (256 + tiles - 1) / tiles;
+  if (tiles >= 224 || kt_total < 32) return 1;
+  int s = (320 + tiles - 1) / tiles;
   if (s > kt_total / 8) s = kt_total / 8;
   if (s > 16) s = 16;
   while (s > 1 && (size_t)s * (size_t)M * (size_t)N * 4u > ws_bytes) --s;
@@ -128,6 +128,10 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
   g.epi = EpiParams{};
   g.epi.rows_per_sample = o.rows_per_sample > 0 ? o.rows_per_sample : 1;
   const int kt_total = g.ktiles0 + g.ktiles1;
+  // adjacent tiles share the LARGER operand: the weight panel when it outweighs the activations (deep 3x3 convs at
+  // 8x8 / 16x16 / 32x32), else the activation rows
+  g.m_fast = ((long)g.N * kt_total > (long)g.M * (kt_total < 9 ? kt_total : kt_total / 9 + 1)) ? 1 : 0;
+  if (const char* e = getenv("AQL_MFAST")) g.m_fast = atoi(e);
   int tiles = 0;
   int cfg = pick_cfg(g.M, g.N, kt_total, ws != nullptr && o.C2 == nullptr, &tiles);
   if (const char* e = getenv("AQL_CFG2_AS")) {  // tuning hook: remap the 128x64 config
@@ -428,6 +432,7 @@ extern "C" int aql_gemm_tn_f32(const bf16_t* U, long ldu, const bf16_t* V, long 
   g.epi.ldcf = ldc;
   g.epi.alpha = alpha;
   g.epi.trans_out = swap ? 1 : 0;
+  g.m_fast = 0;
   int tiles = 0;
   int cfg = pick_cfg(g.M, g.N, g.ktiles0, false, &tiles);
   if (cfg == 3) cfg = 2, tiles = aql_cdiv(g.M, 128) * aql_cdiv(g.N, 64);
