@@ -87,16 +87,17 @@ def dominant_kernels(B, device):
     with torch.no_grad():
         ms = time_kernel(lambda: ops.conv3x3(x, pk))
     fl = 2.0 * B * 64 * 64 * 320 * 9 * 320
-    out.append({"kernel": "gemm_kernel<128,64,ConvFwdLoader> conv3x3 320->320 @64x64", "ms": ms,
-                "achieved_tflops": fl / ms / 1e9, "frac_of_mfma_peak": fl / ms / 1e9 / MFMA_PEAK_TF})
+    out.append({"kernel": "gemm_kernel<128,64,64,32,ConvFwdLoader,PlainLoader,0> conv3x3 320->320 @64x64", "ms": ms,
+                "flops": fl, "achieved_tflops": fl / ms / 1e9, "frac_of_mfma_peak": fl / ms / 1e9 / MFMA_PEAK_TF})
     xs = synth.normal("k.x2", (B * 4096, 320), 1.0, 1, device).to(torch.bfloat16)
     wl = synth.normal("k.w2", (2560, 320), 0.05, 1, device)
     pl = ops.PackedLinear(wl, torch.zeros(2560, device=device))
     with torch.no_grad():
         ms = time_kernel(lambda: ops.lora_linear(xs, pl))
     fl = 2.0 * B * 4096 * 320 * 2560
-    out.append({"kernel": "gemm_kernel<128,128,PlainLoader> ff.net.0.proj 320->2560 @4096 tok", "ms": ms,
-                "achieved_tflops": fl / ms / 1e9, "frac_of_mfma_peak": fl / ms / 1e9 / MFMA_PEAK_TF})
+    out.append({"kernel": "gemm_kernel<128,128,64,64,PlainLoader,PlainLoader,0> ff.net.0.proj 320->2560 @4096 tok",
+                "ms": ms, "flops": fl, "achieved_tflops": fl / ms / 1e9,
+                "frac_of_mfma_peak": fl / ms / 1e9 / MFMA_PEAK_TF})
     return out
 
 
@@ -185,12 +186,21 @@ def main():
                                    f"batch={args.batch}/GPU, latent-in (VAE/CLIP outside the path)",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(getattr(runner, "is_graph", False)),
                        "loss": loss_v},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_PEAK_TF, "traffic": None,
-                         "launch": f"one PPFT step = {tf_img:.3f} TFLOP/image x {args.batch} images"},
         }
         with torch.no_grad():
-            line["kernels"] = dominant_kernels(args.batch, device)
+            ks = dominant_kernels(args.batch, device)
+        dom = ks[0]
+        # dominant kernel = the implicit-GEMM 3x3 convolution family (48 % of the step's algorithmic FLOPs); timed live
+        # with HIP events on the launch stream.  `traffic` is the PMC figure of profiles/r01_pmc_gemm_conv.txt
+        # ((2*FETCH_SIZE + WRITE_SIZE)*1024 per launch) and only applies to the default batch of 4.
+        line["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_tflops"],
+                            "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": dom["frac_of_mfma_peak"],
+                            "traffic": 477.0e6 if args.batch == 4 else None,
+                            "flops_per_launch": dom["flops"], "ms_per_launch": dom["ms"]}
+        line["step_roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                 "frac": achieved / MFMA_PEAK_TF,
+                                 "launch": f"one PPFT step = {tf_img:.3f} TFLOP/image x {args.batch} images"}
+        line["kernels"] = ks
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tr, args.rank)
         print(json.dumps(line), flush=True)
