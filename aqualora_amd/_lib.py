@@ -54,6 +54,9 @@ SIGNATURES = {
     "aql_avgpool_nhwc": [c_p, c_i, c_i, c_i, c_p, c_p],
     "aql_se_gate": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     "aql_pwconv_f32": [c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_i, c_i, c_p, c_p],
+    "aql_crop_resize_bilinear": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "aql_gauss_blur": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p],
+    "aql_add_gauss_noise": [c_p, c_p, c_f, c_i, c_l, c_p, c_p],
     "aql_sdpa_fwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p, c_p],
     "aql_sdpa_bwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p,
                      c_p, c_p],

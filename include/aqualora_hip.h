@@ -124,6 +124,15 @@ int aql_clipnorm_adamw(float* p, const float* g, float* m, float* v, long n, con
 int aql_jpeg_mask(const float* x, float* y, int B, int H, int W, int keep_y, int keep_u, int keep_v, int backward,
                   aql_stream_t stream);
 
+/* csrc/aql_distort.hip: deterministic image maps of noises.py:34-85 / noiser.py:46-71 (random parameters are drawn by the
+ * host like the reference does); NCHW fp32, BC = batch*channels; backward=1 applies the adjoint.                        */
+int aql_crop_resize_bilinear(const float* src, float* dst, int BC, int H, int W, int top, int left, int ch, int cw,
+                             int oh, int ow, int backward, aql_stream_t stream);
+int aql_gauss_blur(const float* src, float* dst, float* tmp, int BC, int H, int W, int k, const float* taps, int backward,
+                   aql_stream_t stream);
+int aql_add_gauss_noise(const float* x, const float* noise, float std, int clamp01, long n, float* y,
+                        aql_stream_t stream);
+
 /* ---- SecretDecoder inference (csrc/aql_decoder.hip) ---- utils/models.py:91-96 (torchvision efficientnet_b1, eval mode,
  * BatchNorm folded by the host), fp32 NHWC.                                                                           */
 int aql_resize_bilinear_nhwc(const float* x_nchw, int B, int C, int H, int W, int Ho, int Wo, float* y_nhwc,

@@ -280,3 +280,31 @@ def test_secret_decoder_vs_oracle_bits_exact():
     assert acc == 1.0 and tpr == 1.0
     with pytest.raises(NotImplementedError):
         dec.train()
+
+
+def test_distortion_maps_vs_torch():
+    """crop+bilinear resize, Gaussian blur (reflect), additive noise: forward and adjoint vs plain torch ops."""
+    import torch.nn.functional as F
+    from aqualora_amd import noise as NZ
+    x = T("dist.x", (2, 3, 96, 80), 0.5, DEV).requires_grad_(True)
+    y = NZ.crop_resize(x, 7, 5, 61, 50, 128, 96)
+    xr = x.detach().clone().requires_grad_(True)
+    yr = F.interpolate(xr[:, :, 7:68, 5:55], size=(128, 96), mode="bilinear", align_corners=False)
+    dy = T("dist.dy", (2, 3, 128, 96), device=DEV)
+    y.backward(dy); yr.backward(dy)
+    assert relerr(y, yr) < 1e-5 and relerr(x.grad, xr.grad) < 1e-5
+    for k, sigma in ((3, 0.7), (5, 4.0), (9, 2.0)):
+        x2 = T("dist.x2", (2, 3, 64, 48), 0.5, DEV).requires_grad_(True)
+        y2 = NZ.gaussian_blur(x2, k, sigma)
+        taps = NZ.gaussian_taps(k, sigma, DEV)
+        w2 = (taps[:, None] * taps[None, :])[None, None].repeat(3, 1, 1, 1)
+        xr2 = x2.detach().clone().requires_grad_(True)
+        yr2 = F.conv2d(F.pad(xr2, (k // 2,) * 4, mode="reflect"), w2, groups=3)
+        dy2 = T("dist.dy2", (2, 3, 64, 48), device=DEV)
+        y2.backward(dy2); yr2.backward(dy2)
+        assert relerr(y2, yr2) < 1e-5 and relerr(x2.grad, xr2.grad) < 1e-5
+    n = T("dist.n", (2, 3, 64, 48), device=DEV)
+    z = NZ.add_gaussian_noise(x2.detach(), 0.1, clamp01=True, noise=n)
+    assert torch.allclose(z, (x2.detach() + 0.1 * n).clamp(0, 1), atol=1e-6)  # kernel contracts to one fma
+    out = NZ.distorsion_unit(T("dist.img", (1, 3, 512, 512), 0.2, DEV) + 0.5, "crop")
+    assert out.shape == (1, 3, 512, 512)
