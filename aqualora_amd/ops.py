@@ -18,8 +18,14 @@ _WS = {}
 _GN = {}
 
 
+def _skey(device):
+    # one workspace per (device, stream): kernels of concurrent streams must not share split-K slabs / GN scratch
+    return (device.index if device.index is not None else torch.cuda.current_device(),
+            torch.cuda.current_stream(device).cuda_stream)
+
+
 def workspace(device, nfloats=64 << 20):
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    key = _skey(device)
     ws = _WS.get(key)
     if ws is None or ws.numel() < nfloats:
         ws = torch.empty(nfloats, dtype=torch.float32, device=device)
@@ -28,7 +34,7 @@ def workspace(device, nfloats=64 << 20):
 
 
 def _gn_scratch(device, B):
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    key = _skey(device)
     t = _GN.get(key)
     need = B * 128 * 32 * 2 + B * 32 * 2
     if t is None or t.numel() < need:

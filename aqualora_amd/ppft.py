@@ -49,6 +49,8 @@ class PPFTTrainer:
         self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.ds_accum = None
+        self.overlap_clean = True
+        self.side = torch.cuda.Stream(device=dev)
         self.deferred = ops.DeferredDW(dev)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -64,9 +66,20 @@ class PPFTTrainer:
         S_in._aql_ds_accum = self.ds_accum  # pushed through the mapper once, after the U-Net backward
         wm = self.sec_encoder.encode(msg, out_scale=VAE_SCALING)
         x_t, x_t_wm = self.scheduler.add_noise_pair(z, wm, eps, t)
-        with torch.no_grad():
-            clean = self.unet(x_t, t, ctx, cross_attention_kwargs={"scale": None}).sample
+        # The frozen "clean" pass is independent of the watermarked pass until the loss: run it on a second HIP stream
+        # so that its (small-grid) kernels fill the CUs the main stream leaves idle.
+        main = torch.cuda.current_stream()
+        if self.overlap_clean:
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side), torch.no_grad():
+                clean = self.unet(x_t, t, ctx, cross_attention_kwargs={"scale": None}).sample
+        else:
+            with torch.no_grad():
+                clean = self.unet(x_t, t, ctx, cross_attention_kwargs={"scale": None}).sample
         pred = self.unet(x_t_wm, t, ctx, cross_attention_kwargs={"scale": S_in}).sample
+        if self.overlap_clean:
+            main.wait_stream(self.side)
+            clean.record_stream(main)
         loss = ops.mse_loss(pred, clean)
         ops.DEFERRED = self.deferred  # weight-gradient GEMMs + dS reductions are collected ...
         try:
