@@ -27,7 +27,7 @@ VAE_SCALING = 0.18215
 class PPFTTrainer:
     def __init__(self, unet, mapper, sec_encoder, rank, learning_rate=1e-4, adam_beta1=0.9, adam_beta2=0.999,
                  adam_weight_decay=1e-2, adam_epsilon=1e-8, max_grad_norm=1.0, lr_lambda=None, lora_state=None,
-                 process_group=None):
+                 process_group=None, micro_batches=1):
         dev = unet.device
         if dev.type != "cuda":
             raise L.AqlError("PPFTTrainer needs the U-Net on an MI355X (cuda device); there is no CPU path")
@@ -49,46 +49,62 @@ class PPFTTrainer:
         self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.ds_accum = None
-        self.overlap_clean = True
-        self.side = torch.cuda.Stream(device=dev)
+        self.micro = micro_batches
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(2 * max(1, micro_batches))]
         self.deferred = ops.DeferredDW(dev)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
 
     # ---------------------------------------------------------------------------------------------
     def forward_backward(self, z, msg, eps, t, ctx):
-        """Everything up to (and including) backward; returns (loss, pred, clean)."""
+        """Everything up to (and including) backward; returns (loss, pred, clean).
+
+        Concurrency: samples are independent (no batch statistics anywhere in the U-Net), so the batch is cut into
+        ``micro`` slices that run the whole clean / watermarked / backward chain on their own pair of HIP streams.
+        Inside a captured graph these become independent branches that the GPU co-schedules, which fills the CUs
+        that a single stream of small-grid kernels leaves idle.  LoRA gradients of all slices accumulate into the
+        same flat buffer (fp32 atomics), dS into disjoint rows of one accumulator."""
+        B = z.shape[0]
+        micro = self.micro if (B % max(self.micro, 1) == 0) else 1
         S = self.mapper(msg)
         if self.ds_accum is None or self.ds_accum.shape != S.shape:
             self.ds_accum = torch.zeros_like(S, dtype=torch.float32)
         self.ds_accum.zero_()
-        S_in = S.detach().requires_grad_(True)  # the U-Net sees a leaf; all 192 sites accumulate dS into ONE fp32 buffer that is
-        S_in._aql_ds_accum = self.ds_accum  # pushed through the mapper once, after the U-Net backward
         wm = self.sec_encoder.encode(msg, out_scale=VAE_SCALING)
         x_t, x_t_wm = self.scheduler.add_noise_pair(z, wm, eps, t)
-        # The frozen "clean" pass is independent of the watermarked pass until the loss: run it on a second HIP stream
-        # so that its (small-grid) kernels fill the CUs the main stream leaves idle.
         main = torch.cuda.current_stream()
-        if self.overlap_clean:
-            self.side.wait_stream(main)
-            with torch.cuda.stream(self.side), torch.no_grad():
-                clean = self.unet(x_t, t, ctx, cross_attention_kwargs={"scale": None}).sample
-        else:
-            with torch.no_grad():
-                clean = self.unet(x_t, t, ctx, cross_attention_kwargs={"scale": None}).sample
-        pred = self.unet(x_t_wm, t, ctx, cross_attention_kwargs={"scale": S_in}).sample
-        if self.overlap_clean:
-            main.wait_stream(self.side)
-            clean.record_stream(main)
-        loss = ops.mse_loss(pred, clean)
-        ops.DEFERRED = self.deferred  # weight-gradient GEMMs + dS reductions are collected ...
+        n = B // micro
+        preds, cleans, losses = [], [], []
+        ops.DEFERRED = self.deferred  # weight-gradient GEMMs + dS reductions of every slice are collected ...
         try:
-            loss.backward()
+            for i in range(micro):
+                sl = slice(i * n, (i + 1) * n)
+                wm_stream, clean_stream = self.streams[2 * i], self.streams[2 * i + 1]
+                wm_stream.wait_stream(main)
+                clean_stream.wait_stream(main)
+                # the frozen "clean" pass is independent of the watermarked pass until the loss
+                with torch.cuda.stream(clean_stream), torch.no_grad():
+                    clean = self.unet(x_t[sl], t[sl], ctx[sl], cross_attention_kwargs={"scale": None}).sample
+                with torch.cuda.stream(wm_stream):
+                    S_in = S[sl].detach().requires_grad_(True)  # the U-Net sees a leaf; all 192 sites accumulate dS
+                    S_in._aql_ds_accum = self.ds_accum[sl]       # into one fp32 buffer, pushed through the mapper once
+                    pred = self.unet(x_t_wm[sl], t[sl], ctx[sl], cross_attention_kwargs={"scale": S_in}).sample
+                    wm_stream.wait_stream(clean_stream)
+                    loss = ops.mse_loss(pred, clean)
+                    (loss / micro).backward()
+                preds.append(pred.detach())
+                cleans.append(clean)
+                losses.append(loss.detach())
+            for st in self.streams[:2 * micro]:
+                main.wait_stream(st)
         finally:
             ops.DEFERRED = None
+        for tns in preds + cleans + losses:
+            tns.record_stream(main)
         self.deferred.flush()         # ... and run as two grouped launches here
         S.backward(self.ds_accum)
-        return loss.detach(), pred.detach(), clean
+        loss = torch.stack(losses).mean()
+        return loss, torch.cat(preds), torch.cat(cleans)
 
     def exchange_gradients(self):
         """DDP's gradient all-reduce(mean) (accelerator.backward, ppft_train.py:1058) as ONE collective over the flat

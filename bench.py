@@ -30,7 +30,7 @@ def step_tflop_per_image(rank):
     return (3 * UNET_FWD_GFLOP + 3 * LORA_FWD_GFLOP_PER_RANK * rank) / 1e3
 
 
-def build(device, rank, seed=2048):
+def build(device, rank, seed=2048, micro=1):
     from aqualora_amd import synth
     from aqualora_amd.lora import inject_lora
     from aqualora_amd.ppft import PPFTTrainer
@@ -50,7 +50,7 @@ def build(device, rank, seed=2048):
     with torch.no_grad():
         enc.secret_scaler[5].weight.copy_(synth.normal("enc.conv.w", (4, 4, 3, 3), 0.05, seed))
     tr = PPFTTrainer(unet, mapper, enc, rank, learning_rate=1e-4,
-                     lr_lambda=get_cosine_schedule_with_warmup_lr_end(0, 100000, lr_end=0.01))
+                     lr_lambda=get_cosine_schedule_with_warmup_lr_end(0, 100000, lr_end=0.01), micro_batches=micro)
     return tr
 
 
@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--micro", type=int, default=1, help="concurrent micro-batch slices per step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,7 +149,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
 
-    tr = build(device, args.rank)
+    tr = build(device, args.rank, micro=args.micro)
     batch = synthetic_batch(args.batch, device, rank_id)
     runner = tr.step
     if not args.no_graph and hasattr(tr, "capture"):
