@@ -43,6 +43,52 @@ def _gn_scratch(device, B):
     return t
 
 
+# ---------------------------------------------------------------------------------- branch-level concurrency
+BRANCH_STREAMS = 0   # >0: independent sibling ops (attention q/k/v projections) are issued on this many side streams.
+# EXPERIMENTAL, eager only: nested stream forks inside a hipGraph capture crash hipStreamEndCapture on this ROCm
+# (measured round 1), so the captured trainer keeps it at 0.
+_BR = {}
+
+
+def parallel(fns):
+    """Run independent thunks; with BRANCH_STREAMS > 0 all but the first go to side HIP streams that fork from and
+    join back into the current stream (autograd replays each branch's backward on its own stream too)."""
+    if BRANCH_STREAMS <= 0 or len(fns) < 2:
+        return [f() for f in fns]
+    main = torch.cuda.current_stream()
+    key = (main.device.index, main.cuda_stream)
+    pool = _BR.get(key)
+    if pool is None or len(pool) < BRANCH_STREAMS:
+        pool = [torch.cuda.Stream(device=main.device) for _ in range(BRANCH_STREAMS)]
+        _BR[key] = pool
+    outs = [None] * len(fns)
+    used = []
+    for i, f in enumerate(fns[1:], start=1):
+        st = pool[(i - 1) % len(pool)]
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            outs[i] = f()
+        used.append(st)
+    outs[0] = fns[0]()
+    for st in used:
+        main.wait_stream(st)
+    if not torch.cuda.is_current_stream_capturing():
+        for o in outs[1:]:
+            if torch.is_tensor(o):
+                o.record_stream(main)
+    return outs
+
+
+def join_branches():
+    """Make the current stream wait for every branch stream forked from it (and from any other stream): needed
+    before work that consumes branch results outside autograd's own synchronisation (deferred dW/dS) and before a
+    graph capture ends."""
+    cur = torch.cuda.current_stream()
+    for pool in _BR.values():
+        for st in pool:
+            cur.wait_stream(st)
+
+
 def _req(t, name):
     if not t.is_cuda:
         raise L.AqlError(f"{name}: the HIP path needs a GPU tensor (got {t.device}); there is no CPU fallback")

@@ -85,6 +85,7 @@ class PPFTTrainer:
                 # the frozen "clean" pass is independent of the watermarked pass until the loss
                 with torch.cuda.stream(clean_stream), torch.no_grad():
                     clean = self.unet(x_t[sl], t[sl], ctx[sl], cross_attention_kwargs={"scale": None}).sample
+                    ops.join_branches()
                 with torch.cuda.stream(wm_stream):
                     S_in = S[sl].detach().requires_grad_(True)  # the U-Net sees a leaf; all 192 sites accumulate dS
                     S_in._aql_ds_accum = self.ds_accum[sl]       # into one fp32 buffer, pushed through the mapper once
@@ -92,6 +93,7 @@ class PPFTTrainer:
                     wm_stream.wait_stream(clean_stream)
                     loss = ops.mse_loss(pred, clean)
                     (loss / micro).backward()
+                    ops.join_branches()
                 preds.append(pred.detach())
                 cleans.append(clean)
                 losses.append(loss.detach())

@@ -120,9 +120,8 @@ class Attention(nn.Module):
 
     def forward(self, hidden_states, encoder_hidden_states=None, scale=1.0, residual=None):
         ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
-        q = self.to_q(hidden_states, scale)
-        k = self.to_k(ctx, scale)
-        v = self.to_v(ctx, scale)
+        q, k, v = ops.parallel([lambda: self.to_q(hidden_states, scale), lambda: self.to_k(ctx, scale),
+                                lambda: self.to_v(ctx, scale)])
         o = ops.attention(q, k, v, self.heads)
         return self.to_out[0](o, scale, residual=residual)
 
