@@ -308,3 +308,32 @@ def test_distortion_maps_vs_torch():
     assert torch.allclose(z, (x2.detach() + 0.1 * n).clamp(0, 1), atol=1e-6)  # kernel contracts to one fma
     out = NZ.distorsion_unit(T("dist.img", (1, 3, 512, 512), 0.2, DEV) + 0.5, "crop")
     assert out.shape == (1, 3, 512, 512)
+
+
+def test_captured_step_equals_eager_step():
+    """HIP-graph replay (two graphs + exchange) must train exactly like the eager step: same loss trajectory and the
+    same parameters after 3 steps (up to fp32 atomic-order noise in the weight gradients)."""
+    from aqualora_amd.ppft import PPFTTrainer
+    from aqualora_amd.watermark import MapperNet, SecretEncoder
+    inp = ppft_inputs(device=DEV)
+    batch = dict(z=inp["z"], msg=inp["msg"], eps=inp["eps"], t=inp["t"], ctx=inp["ctx"].to(torch.bfloat16))
+    results = []
+    for mode in ("eager", "graph"):
+        unet, keys, lw = _gpu_tiny()
+        mapper = MapperNet(48, TINY_RANK)
+        with torch.no_grad():
+            mapper.bit_embeddings.weight.copy_(inp["E"])
+        enc = SecretEncoder(48, base_res=8, resolution=16)
+        with torch.no_grad():
+            enc.secret_scaler[0].weight.copy_(T("cap.lin.w", (64, 48), 48 ** -0.5))
+            enc.secret_scaler[0].bias.copy_(T("cap.lin.b", (64,), 0.1))
+            enc.secret_scaler[5].weight.copy_(T("enc.conv.w", (4, 4, 3, 3), 0.05))
+        tr = PPFTTrainer(unet, mapper, enc, TINY_RANK, learning_rate=1e-3)
+        run = tr.step if mode == "eager" else tr.capture(batch, warmup=0)
+        losses = [float(run(**batch)) for _ in range(3)]
+        torch.cuda.synchronize()
+        results.append((losses, tr.bank.flat.clone()))
+    (le, pe), (lg, pg) = results
+    assert all(abs(a - b) < 2e-3 * abs(a) for a, b in zip(le, lg)), (le, lg)
+    assert relerr(pg, pe) < 2e-3
+    assert le[-1] < le[0]  # and it actually trains
