@@ -185,7 +185,8 @@ struct EpiParams {
   bf16_t* C2;              // second output (row-scaled) or null
   long ldc2;
   const bf16_t* rowscale;  // [nsamples][N]
-  const bf16_t* rowbias;   // [nsamples][N] added (bf16 add) after bias, before the residual; or null
+  const bf16_t* rowbias;   // [nsamples][rowbias_ld] added (bf16 add) after bias, before the residual; or null
+  long rowbias_ld;
   int rows_per_sample;
   int trans_out;           // EPI_ATOMIC only: write C^T, i.e. element (m,n) goes to Cf[n*ldcf + m]
   // EPI_SLAB / EPI_ATOMIC: fp32 output
@@ -423,7 +424,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<LA, LB>& g, const int b
       if (m >= g.M || n >= g.N) continue;
       uint4 v = *reinterpret_cast<const uint4*>(lds + row * C_PITCH + cc * 16);
       if (ep.rowbias != nullptr) {
-        const uint4 r = *reinterpret_cast<const uint4*>(ep.rowbias + (long)(m / ep.rows_per_sample) * g.N + n);
+        const uint4 r = *reinterpret_cast<const uint4*>(ep.rowbias + (long)(m / ep.rows_per_sample) * ep.rowbias_ld + n);
         v.x = pack_bf16x2(bf16lo(v.x) + bf16lo(r.x), bf16hi(v.x) + bf16hi(r.x));
         v.y = pack_bf16x2(bf16lo(v.y) + bf16lo(r.y), bf16hi(v.y) + bf16hi(r.y));
         v.z = pack_bf16x2(bf16lo(v.z) + bf16lo(r.z), bf16hi(v.z) + bf16hi(r.z));

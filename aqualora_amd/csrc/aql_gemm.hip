@@ -23,7 +23,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __restrict__ slabs, int splits, long M,
                                                               int N, const bf16_t* __restrict__ bias,
                                                               const bf16_t* __restrict__ rowbias,
-                                                              int rows_per_sample,
+                                                              long rowbias_ld, int rows_per_sample,
                                                               const bf16_t* __restrict__ residual, long ldr,
                                                               bf16_t* __restrict__ C, long ldc) {
   const long nchunk = M * (N / 4);
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
     }
     uint2 v = make_uint2(pack_bf16x2(s.x, s.y), pack_bf16x2(s.z, s.w));
     if (rowbias != nullptr) {
-      const uint2 r = *reinterpret_cast<const uint2*>(rowbias + (m / rows_per_sample) * N + n);
+      const uint2 r = *reinterpret_cast<const uint2*>(rowbias + (m / rows_per_sample) * rowbias_ld + n);
       v.x = pack_bf16x2(bf16lo(v.x) + bf16lo(r.x), bf16hi(v.x) + bf16hi(r.x));
       v.y = pack_bf16x2(bf16lo(v.y) + bf16lo(r.y), bf16hi(v.y) + bf16hi(r.y));
     }
@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
 struct OutSpec {
   const bf16_t* bias;
   const bf16_t* rowbias;
+  long rowbias_ld;
   int rows_per_sample;
   const bf16_t* residual;
   long ldr;
@@ -152,7 +153,8 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
     int blocks = (int)((nchunk + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, stream, ws, splits, (long)g.M, g.N,
-                       o.bias, o.rowbias, g.epi.rows_per_sample, o.residual, o.ldr, o.C, o.ldc);
+                       o.bias, o.rowbias, o.rowbias_ld > 0 ? o.rowbias_ld : (long)g.N, g.epi.rows_per_sample, o.residual, o.ldr, o.C,
+                       o.ldc);
     AQL_CHECK_LAUNCH(name);
     return AQL_OK;
   }
@@ -165,6 +167,7 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
   g.epi.ldc2 = o.ldc2;
   g.epi.rowscale = o.rowscale;
   g.epi.rowbias = o.rowbias;
+  g.epi.rowbias_ld = o.rowbias_ld > 0 ? o.rowbias_ld : (long)g.N;
   launch_cfg<LA, LB, EPI_BF16>(cfg, g, stream);
   AQL_CHECK_LAUNCH(name);
   return AQL_OK;
@@ -208,7 +211,7 @@ extern "C" int aql_gemm_bf16(const bf16_t* A, long lda, const bf16_t* B, long ld
   }
   g.M = (int)M;
   g.N = N;
-  OutSpec o{bias, rowbias, rows_per_sample, residual, ldr, C, ldc, nullptr, 0, nullptr};
+  OutSpec o{bias, rowbias, 0, rows_per_sample, residual, ldr, C, ldc, nullptr, 0, nullptr};
   return run_bf16_gemm(g, o, ws, ws_bytes, stream, "aql_gemm_bf16");
 }
 
@@ -334,15 +337,15 @@ extern "C" int aql_lora_down(const bf16_t* X, long ldx, long M, int K, const bf1
   g.ktiles1 = 0;
   g.M = (int)M;
   g.N = r;
-  OutSpec o{nullptr, nullptr, rows_per_sample, nullptr, 0, T, r, Ts, r, S};
+  OutSpec o{nullptr, nullptr, 0, rows_per_sample, nullptr, 0, T, r, Ts, r, S};
   const int rc = run_bf16_gemm(g, o, nullptr, 0, stream, "aql_lora_down");
   if (rc != AQL_OK || Tref == nullptr) return rc;
   return aql_lora_ds(T, Tref, (int)(M / rows_per_sample), rows_per_sample, r, dS, stream);
 }
 
 extern "C" int aql_conv3x3_fwd(const bf16_t* X, int B, int Hin, int Win, int Cin, const bf16_t* Wk, const bf16_t* bias,
-                               int Cout, int stride, int upsample, const bf16_t* rowbias, const bf16_t* residual,
-                               bf16_t* Y, float* ws, size_t ws_bytes, hipStream_t stream) {
+                               int Cout, int stride, int upsample, const bf16_t* rowbias, long rowbias_ld,
+                               const bf16_t* residual, bf16_t* Y, float* ws, size_t ws_bytes, hipStream_t stream) {
   AQL_CHECK_ARG(X && Wk && Y, "aql_conv3x3_fwd: null operand");
   AQL_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0, "aql_conv3x3_fwd: Cin/Cout must be multiples of 8 (%d,%d)", Cin, Cout);
   AQL_CHECK_ARG((stride == 1 || stride == 2) && (upsample == 0 || upsample == 1) && !(upsample && stride == 2),
@@ -369,7 +372,7 @@ extern "C" int aql_conv3x3_fwd(const bf16_t* X, int B, int Hin, int Win, int Cin
   g.ktiles1 = 0;
   g.M = l.rows;
   g.N = Cout;
-  OutSpec o{bias, rowbias, l.Hout * l.Wout, residual, Cout, Y, Cout, nullptr, 0, nullptr};
+  OutSpec o{bias, rowbias, rowbias_ld, l.Hout * l.Wout, residual, Cout, Y, Cout, nullptr, 0, nullptr};
   return run_bf16_gemm(g, o, ws, ws_bytes, stream, "aql_conv3x3_fwd");
 }
 
@@ -398,7 +401,7 @@ extern "C" int aql_conv3x3_bwd_data(const bf16_t* dY, int B, int Hin, int Win, i
   g.ktiles1 = 0;
   g.M = l.rows;
   g.N = Cin;
-  OutSpec o{nullptr, nullptr, 1, nullptr, 0, dX, Cin, nullptr, 0, nullptr};
+  OutSpec o{nullptr, nullptr, 0, 1, nullptr, 0, dX, Cin, nullptr, 0, nullptr};
   return run_bf16_gemm(g, o, ws, ws_bytes, stream, "aql_conv3x3_bwd_data");
 }
 

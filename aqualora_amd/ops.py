@@ -320,8 +320,8 @@ class Conv3x3Fn(torch.autograd.Function):
         ws = workspace(x.device)
         res = None if residual is None else as_cl(residual)
         L.call("aql_conv3x3_fwd", L.ptr(x), B, H, W, packed.Cin, L.ptr(packed.wk), L.ptr(packed.bias), packed.Cout,
-               packed.stride, int(upsample), L.ptr(rowbias), L.ptr(res), L.ptr(y), L.ptr(ws), ws.numel() * 4,
-               L.stream_ptr())
+               packed.stride, int(upsample), L.ptr(rowbias), 0 if rowbias is None else rowbias.stride(0), L.ptr(res),
+               L.ptr(y), L.ptr(ws), ws.numel() * 4, L.stream_ptr())
         ctx.packed, ctx.upsample, ctx.in_shape, ctx.c_in = packed, upsample, (B, H, W), C
         ctx.has_rb, ctx.has_res = rowbias is not None, residual is not None
         if packed.Cout_real != packed.Cout:

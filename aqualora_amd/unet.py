@@ -83,8 +83,11 @@ class ResnetBlock2D(nn.Module):
 
     def forward(self, x, temb_act, scale=1.0):
         h = self.norm1(x, silu=True)
-        tproj = self.time_emb_proj(temb_act, scale)  # [B, cout]
-        h = ops.conv3x3(h, _packed_conv3(self.conv1), False, tproj.contiguous(), None)
+        if isinstance(temb_act, dict):  # projections of all ResNets were batched into one GEMM (UNet forward)
+            tproj = temb_act[id(self)]   # [B, cout] view with row stride = sum of all couts
+        else:
+            tproj = self.time_emb_proj(temb_act, scale).contiguous()
+        h = ops.conv3x3(h, _packed_conv3(self.conv1), False, tproj, None)
         h = self.norm2(h, silu=True)
         shortcut = x if self.conv_shortcut is None else self.conv_shortcut(x, scale)
         return ops.conv3x3(h, _packed_conv3(self.conv2), False, None, shortcut)
@@ -278,6 +281,24 @@ class UNet2DConditionModel(nn.Module):
         for p in self.parameters():
             p.requires_grad_(False)
 
+    def _all_time_projections(self, temb_act):
+        """time_emb_proj(SiLU(temb)) of all 22 ResNets (original_unet.py:449) as ONE GEMM: they depend only on the
+        timestep, so 22 tiny launches per pass collapse into one; each ResNet reads its [B, cout] column slice."""
+        cat = getattr(self, "_aql_temb_cat", None)
+        if cat is None:
+            blocks = [m for m in self.modules() if isinstance(m, ResnetBlock2D)]
+            w = torch.cat([m.time_emb_proj.weight.detach() for m in blocks], dim=0)
+            b = torch.cat([m.time_emb_proj.bias.detach() for m in blocks], dim=0)
+            offs, o = [], 0
+            for m in blocks:
+                offs.append((id(m), o, m.time_emb_proj.out_features))
+                o += m.time_emb_proj.out_features
+            cat = (ops.PackedLinear(w, b), offs)
+            object.__setattr__(self, "_aql_temb_cat", cat)
+        packed, offs = cat
+        allp = ops.lora_linear(temb_act.contiguous(), packed)
+        return {key: allp[:, o:o + n] for key, o, n in offs}
+
     @property
     def dtype(self):
         return self.conv_in.weight.dtype
@@ -297,6 +318,7 @@ class UNet2DConditionModel(nn.Module):
         t_emb = get_timestep_embedding(timestep, self.config.block_out_channels[0]).to(self.dtype)
         emb = self.time_embedding(t_emb, scale)
         temb_act = torch.nn.functional.silu(emb)  # every ResNet applies SiLU to temb first (original_unet.py:449)
+        temb_act = self._all_time_projections(temb_act)
         ctx = encoder_hidden_states.to(self.dtype).contiguous()
         h = self.conv_in(ops.as_cl(sample.to(self.dtype)), scale)
         skips = (h,)
@@ -348,3 +370,5 @@ def init_synthetic(unet, seed=2048):
         mod = unet.get_submodule(name.rsplit(".", 1)[0])
         if hasattr(mod, "_aql_packed"):
             object.__delattr__(mod, "_aql_packed")
+    if hasattr(unet, "_aql_temb_cat"):
+        object.__delattr__(unet, "_aql_temb_cat")

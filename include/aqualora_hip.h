@@ -44,8 +44,8 @@ int aql_lora_down(const bf16_t* X, long ldx, long M, int K, const bf16_t* Adown,
  * of Upsample2D into the gather.  Replaces F.conv2d in CustomLoRACompatibleConvforward (lora_modules.py:47-52)
  * for the ResNet / down / up-sampler convs (scripts/lib/original_unet.py:425-430, 534, 1058).                    */
 int aql_conv3x3_fwd(const bf16_t* X, int B, int Hin, int Win, int Cin, const bf16_t* Wk, const bf16_t* bias, int Cout,
-                    int stride, int upsample, const bf16_t* rowbias, const bf16_t* residual, bf16_t* Y, float* ws,
-                    size_t ws_bytes, aql_stream_t stream);
+                    int stride, int upsample, const bf16_t* rowbias, long rowbias_ld, const bf16_t* residual, bf16_t* Y,
+                    float* ws, size_t ws_bytes, aql_stream_t stream);
 /* its input gradient (autograd of the same call); Wt[Cin][(kh*3+kw)*Cout+co]                                     */
 int aql_conv3x3_bwd_data(const bf16_t* dY, int B, int Hin, int Win, int Cin, const bf16_t* Wt, int Cout, int stride,
                          bf16_t* dX, float* ws, size_t ws_bytes, aql_stream_t stream);

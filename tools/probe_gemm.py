@@ -73,7 +73,7 @@ def conv_case(Bn, H, W, Cin, Cout, stride, ups):
     xh = x.permute(0, 2, 3, 1).contiguous(); wk = w.permute(0, 2, 3, 1).contiguous().view(Cout, 9 * Cin)
     Ho, Wo = ref.shape[2], ref.shape[3]
     y = torch.empty(Bn, Ho, Wo, Cout, dtype=torch.bfloat16, device=dev)
-    L.call("aql_conv3x3_fwd", L.ptr(xh), Bn, H, W, Cin, L.ptr(wk), L.ptr(b), Cout, stride, ups, None, None, L.ptr(y),
+    L.call("aql_conv3x3_fwd", L.ptr(xh), Bn, H, W, Cin, L.ptr(wk), L.ptr(b), Cout, stride, ups, None, 0, None, L.ptr(y),
            L.ptr(ws), ws.numel() * 4, L.stream_ptr())
     report(f"conv3x3 fwd B{Bn} {H}x{W} {Cin}->{Cout} s{stride} u{ups}", relerr(y.permute(0, 3, 1, 2), ref), 1.5e-2)
     if not ups:
@@ -108,7 +108,7 @@ for (M, N, K) in [(16384, 320, 320), (16384, 2560, 320), (16384, 320, 1280), (40
 for (Bn, H, Cin, Cout) in [(4, 64, 320, 320), (4, 32, 640, 640), (4, 16, 1280, 1280), (4, 8, 1280, 1280), (4, 16, 2560, 1280), (4, 64, 960, 320)]:
     xh = rnd(Bn, H, H, Cin); wk = rnd(Cout, 9 * Cin); b = rnd(Cout)
     y = torch.empty(Bn, H, H, Cout, dtype=torch.bfloat16, device=dev)
-    fn = lambda: L.call("aql_conv3x3_fwd", L.ptr(xh), Bn, H, H, Cin, L.ptr(wk), L.ptr(b), Cout, 1, 0, None, None, L.ptr(y), L.ptr(ws), ws.numel() * 4, L.stream_ptr())
+    fn = lambda: L.call("aql_conv3x3_fwd", L.ptr(xh), Bn, H, H, Cin, L.ptr(wk), L.ptr(b), Cout, 1, 0, None, 0, None, L.ptr(y), L.ptr(ws), ws.numel() * 4, L.stream_ptr())
     ms = timeit(fn)
     xn = xh.permute(0, 3, 1, 2); wn = wk.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
     ms_t = timeit(lambda: F.conv2d(xn, wn, b, padding=1))
