@@ -495,3 +495,27 @@ extern "C" int aql_clipnorm_adamw(float* p, const float* g, float* m, float* v, 
   AQL_CHECK_LAUNCH("aql_clipnorm_adamw");
   return AQL_OK;
 }
+
+// ---- DDIM step with classifier-free guidance (diffusers DDIMScheduler.step, eta = 0, epsilon prediction):
+//   eps = eps_u + g (eps_c - eps_u);  x0 = (x - sqrt(1-a_t) eps) / sqrt(a_t);  x <- sqrt(a_prev) x0 + sqrt(1-a_prev) eps
+// coef (device) = {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)}; eps_u/eps_c are the two halves of the U-Net output.
+namespace {
+__global__ __launch_bounds__(256) void ddim_step_kernel(float* __restrict__ x, const bf16_t* __restrict__ eps_u,
+                                                        const bf16_t* __restrict__ eps_c, float g,
+                                                        const float* __restrict__ coef, long n) {
+  const float sa = coef[0], sb = coef[1], pa = coef[2], pb = coef[3];
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x) {
+    const float eu = bf16_to_f32(eps_u[id]), ec = bf16_to_f32(eps_c[id]);
+    const float e = eu + g * (ec - eu);
+    const float x0 = (x[id] - sb * e) / sa;
+    x[id] = pa * x0 + pb * e;
+  }
+}
+}  // namespace
+extern "C" int aql_ddim_step(float* x, const bf16_t* eps_u, const bf16_t* eps_c, float guidance, const float* coef, long n,
+                             hipStream_t stream) {
+  AQL_CHECK_ARG(x && eps_u && eps_c && coef, "aql_ddim_step: bad args");
+  hipLaunchKernelGGL(ddim_step_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, eps_u, eps_c, guidance, coef, n);
+  AQL_CHECK_LAUNCH("aql_ddim_step");
+  return AQL_OK;
+}

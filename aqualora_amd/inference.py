@@ -1,0 +1,117 @@
+"""Inference side of the watermark: bake a message into the LoRA, fuse it into the U-Net,
+sample latents with DDIM + classifier-free guidance.
+
+  create_watermark_lora  scripts/create_wm_lora.py:9-51   down' = diag(S(m)) . down . scale   (conv: down * S[:,None,None,None])
+  fuse_lora              pipe.fuse_lora(lora_scale) as used at evaluation/utils_eval.py:81-82: W += lora_scale . up @ down
+  ddim_sample            StableDiffusionPipeline + DDIMScheduler (utils_eval.py:83-126): 50 steps, leading spacing,
+                         steps_offset 1, eta 0, guidance 7.5 (recalled semantics; unpinned)
+The VAE decode that turns latents into pixels is outside this path.
+"""
+import torch
+
+from . import _lib as L
+from . import ops
+from .checkpoint import site_to_ckpt_key
+from .lora import _walk, load_unet_keys
+from .watermark import sd15_alphas_cumprod
+
+
+@torch.no_grad()
+def create_watermark_lora(lora_state_dict, mapper, hidinfo, scale=1.03):
+    """Bake message bits into an ordinary LoRA (same keys, same shapes).  ``hidinfo``: str of 0/1 or [1, bits] tensor."""
+    if isinstance(hidinfo, str):
+        hidinfo = torch.tensor([int(c) for c in hidinfo]).unsqueeze(0)
+    dev = mapper.bit_embeddings.weight.device
+    S = mapper(hidinfo.float().to(dev))[0]  # [r]
+    out = {}
+    for key, v in lora_state_dict.items():
+        if "unet" not in key:
+            if "text_encoder" in key:
+                continue
+            raise ValueError(f"key {key} not found")
+        v = v.to(dev).float()
+        if "up.weight" in key:
+            out[key] = v
+        elif "down.weight" in key:
+            out[key] = (S.view(-1, *([1] * (v.dim() - 1))) * v) * scale
+    return "".join(str(int(b)) for b in hidinfo[0].tolist()), out
+
+
+@torch.no_grad()
+def fuse_lora(unet, lora_state_dict, lora_scale=1.0, keys=None):
+    """W <- W + lora_scale * up @ down for every site (one MFMA GEMM each: C = up . down^T^T + W as the residual)."""
+    keys = keys if keys is not None else load_unet_keys(unet)
+    for key in keys:
+        host = _walk(unet, key)
+        ck = site_to_ckpt_key(key)
+        down = lora_state_dict[ck + ".down.weight"].to(host.weight.device).float()
+        up = lora_state_dict[ck + ".up.weight"].to(host.weight.device).float()
+        r = down.shape[0]
+        down2 = down.reshape(r, -1)
+        up2 = (up.reshape(-1, r) * lora_scale)
+        rp = (r + 7) // 8 * 8  # GEMM wants K % 8 == 0
+        a = torch.zeros(up2.shape[0], rp, dtype=torch.bfloat16, device=up2.device)
+        a[:, :r] = up2
+        b = torch.zeros(down2.shape[1], rp, dtype=torch.bfloat16, device=up2.device)
+        b[:, :r] = down2.t()
+        w2 = host.weight.detach().reshape(host.weight.shape[0], -1).to(torch.bfloat16).contiguous()
+        fused = ops.gemm_bf16(a, b, residual=w2)
+        host.weight.data.copy_(fused.view_as(host.weight))
+        if hasattr(host, "_aql_packed"):
+            object.__delattr__(host, "_aql_packed")
+        host.set_lora_layer(None)
+
+
+def ddim_timesteps(num_inference_steps, num_train_timesteps=1000, steps_offset=1):
+    ratio = num_train_timesteps // num_inference_steps
+    return [(i * ratio) + steps_offset for i in range(num_inference_steps)][::-1]
+
+
+@torch.no_grad()
+def ddim_sample(unet, ctx_cond, ctx_uncond, latents, num_inference_steps=50, guidance_scale=7.5, graph=True):
+    """latents: [B,4,h,w] fp32 ~ N(0,1) (init_noise_sigma = 1 for DDIM).  Returns the final fp32 latents.
+    One HIP graph holds a full guided step (U-Net on batch 2B + the DDIM update); it is replayed once per timestep with
+    the timestep and the four schedule coefficients in device scalars."""
+    dev = latents.device
+    acp = sd15_alphas_cumprod(device="cpu").double()
+    ts = ddim_timesteps(num_inference_steps)
+    ratio = 1000 // num_inference_steps
+    x = latents.float().contiguous().clone()
+    B = x.shape[0]
+    ctx = torch.cat([ctx_uncond, ctx_cond]).to(torch.bfloat16).contiguous()
+    t_dev = torch.zeros(2 * B, dtype=torch.long, device=dev)
+    coef = torch.zeros(4, dtype=torch.float32, device=dev)
+    n = x.numel()
+
+    def one_step():
+        eps = unet(torch.cat([x, x]), t_dev, ctx, cross_attention_kwargs={"scale": None}).sample
+        eps = eps.contiguous()  # NCHW-contiguous so that it lines up with x element for element
+        L.call("aql_ddim_step", L.ptr(x), L.ptr(eps[:B]), L.ptr(eps[B:]), float(guidance_scale), L.ptr(coef), n,
+               L.stream_ptr())
+
+    def set_step(t):
+        a_t = acp[t]
+        a_prev = acp[t - ratio] if t - ratio >= 0 else acp[0]
+        t_dev.fill_(t)
+        coef.copy_(torch.tensor([a_t.sqrt(), (1 - a_t).sqrt(), a_prev.sqrt(), (1 - a_prev).sqrt()], dtype=torch.float32))
+
+    g = None
+    if graph:
+        set_step(ts[0])
+        x_keep = x.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            one_step()
+        torch.cuda.current_stream().wait_stream(side)
+        x.copy_(x_keep)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            one_step()
+    for t in ts:
+        set_step(t)
+        if g is not None:
+            g.replay()
+        else:
+            one_step()
+    return x

@@ -127,6 +127,34 @@ def cpu_baseline(tr, rank):
                       f"PPFT step extrapolated by algorithmic FLOPs x{step_tflop_per_image(rank) / (UNET_FWD_GFLOP / 1e3):.3f}"}
 
 
+def infer_bench(args, device):
+    """BASELINE config 4 without the VAE (outside the path): 50-step DDIM, CFG 7.5, 64x64x4 latents, fused-LoRA U-Net
+    (the LoRA is folded into W, utils_eval.py:81-82, so this is the plain SD-1.5 U-Net on batch 2 per image)."""
+    from aqualora_amd import synth
+    from aqualora_amd.inference import ddim_sample
+    from aqualora_amd.unet import UNet2DConditionModel, init_synthetic
+    unet = UNet2DConditionModel(device=device, dtype=torch.bfloat16)
+    init_synthetic(unet, 2048)
+    B = 1
+    ctx = synth.normal("inf.ctx", (B, 77, 768), 1.0, 1, device)
+    lat = synth.normal("inf.lat", (B, 4, 64, 64), 1.0, 1, device)
+    ddim_sample(unet, ctx, torch.zeros_like(ctx), lat, 50, 7.5)  # warm-up (captures its own graph)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = max(1, args.steps // 5)
+    for _ in range(n):
+        out = ddim_sample(unet, ctx, torch.zeros_like(ctx), lat, 50, 7.5)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    tf = 50 * 2 * UNET_FWD_GFLOP / 1e3
+    print(json.dumps({"metric": "50-step DDIM txt2img latent sampling images/sec at 512x512 (no VAE)", "value": B / dt,
+                      "unit": "images/sec", "n_gpus": 1, "steps": n, "ms_per_image": 1e3 * dt, "dtype": "bf16",
+                      "higher_is_better": True, "data": "synthetic",
+                      "roofline": {"bound": "mfma", "achieved": tf / dt, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                   "frac": tf / dt / MFMA_PEAK_TF},
+                      "finite": bool(torch.isfinite(out).all())}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,6 +164,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--mode", choices=["train", "infer"], default="train",
+                    help="train: the PPFT step (BASELINE metric); infer: 50-step DDIM + CFG latent sampling (config 4)")
     ap.add_argument("--micro", type=int, default=1, help="concurrent micro-batch slices per step")
     args = ap.parse_args()
 
@@ -149,6 +179,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
 
+    if args.mode == "infer":
+        return infer_bench(args, device)
     tr = build(device, args.rank, micro=args.micro)
     batch = synthetic_batch(args.batch, device, rank_id)
     runner = tr.step

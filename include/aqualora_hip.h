@@ -124,6 +124,12 @@ int aql_clipnorm_adamw(float* p, const float* g, float* m, float* v, long n, con
 int aql_jpeg_mask(const float* x, float* y, int B, int H, int W, int keep_y, int keep_u, int keep_v, int backward,
                   aql_stream_t stream);
 
+/* DDIM step (eta 0, epsilon prediction) with classifier-free guidance, in place on the fp32 latents: the sampler maths of
+ * evaluation/utils_eval.py:83-126 (`--sampler ddim`) / diffusers DDIMScheduler.step.  coef = {sqrt(a_t), sqrt(1-a_t),
+ * sqrt(a_prev), sqrt(1-a_prev)} on the device.                                                                          */
+int aql_ddim_step(float* x, const bf16_t* eps_uncond, const bf16_t* eps_cond, float guidance, const float* coef, long n,
+                  aql_stream_t stream);
+
 /* csrc/aql_distort.hip: deterministic image maps of noises.py:34-85 / noiser.py:46-71 (random parameters are drawn by the
  * host like the reference does); NCHW fp32, BC = batch*channels; backward=1 applies the adjoint.                        */
 int aql_crop_resize_bilinear(const float* src, float* dst, int BC, int H, int W, int top, int left, int ch, int cw,

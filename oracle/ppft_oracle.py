@@ -288,3 +288,14 @@ def get_threshold(k, fpr):
     while calculate_fpr(tau, k) > fpr:
         tau += 1
     return tau
+
+
+def ddim_step(x, eps_u, eps_c, t, t_prev, guidance, acp=None):
+    """DDIM (eta 0, epsilon prediction, no clipping) + classifier-free guidance; recalled diffusers semantics
+    (SURVEY.md App. C): alpha_prev = alphas_cumprod[t_prev] if t_prev >= 0 else alphas_cumprod[0]."""
+    acp = alphas_cumprod().double() if acp is None else acp
+    a_t = acp[t]
+    a_p = acp[t_prev] if t_prev >= 0 else acp[0]
+    eps = eps_u.double() + guidance * (eps_c.double() - eps_u.double())
+    x0 = (x.double() - (1 - a_t).sqrt() * eps) / a_t.sqrt()
+    return (a_p.sqrt() * x0 + (1 - a_p).sqrt() * eps).float()

@@ -407,6 +407,31 @@ def gen_jpeg_and_metrics():
         raise
 
 
+def gen_create_wm_lora(models):
+    """scripts/create_wm_lora.py:create_watermark_lora on a small synthetic checkpoint (rank 320 is hard-coded there)."""
+    import tempfile
+    from safetensors.torch import save_file
+    sys.path.insert(0, os.path.join(REF, "scripts"))
+    import create_wm_lora as cw
+    r = 320
+    sd = {}
+    for k, dshape, ushape in (("unet.down_blocks.0.attentions.0.proj_in.lora", (r, 32, 1, 1), (32, r, 1, 1)),
+                              ("unet.down_blocks.0.attentions.0.transformer_blocks.0.attn1.processor.to_q_lora", (r, 32), (32, r)),
+                              ("unet.down_blocks.0.attentions.0.transformer_blocks.0.ff.net.2.lora", (r, 128), (32, r))):
+        sd[k + ".down.weight"] = T(k + ".down", dshape, 1.0 / r)
+        sd[k + ".up.weight"] = T(k + ".up", ushape, 0.05)
+    mp = models.MapperNet(input_size=48, output_size=r)
+    with torch.no_grad():
+        mp.bit_embeddings.weight.copy_(T("cwl.E", (48, r)))
+    msg = "".join(str(int(b)) for b in synth.bits("cwl.msg", (48,), SEED).tolist())
+    with tempfile.TemporaryDirectory() as d:
+        save_file(sd, os.path.join(d, "pytorch_lora_weights.safetensors"))
+        torch.save(mp.state_dict(), os.path.join(d, "mapper.pt"))
+        hid, out = cw.create_watermark_lora(d, 1.03, 48, msg, save=False)
+    assert hid == msg
+    save("create_wm_lora.npz", msg=np.array(msg), **{k: v.detach().numpy() for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     lm, models, misc, ou = import_reference()
@@ -415,6 +440,7 @@ if __name__ == "__main__":
     gen_misc(misc)
     gen_full_block(lm, ou)
     gen_jpeg_and_metrics()
+    gen_create_wm_lora(models)
     unet, keys, loras = gen_tiny_ppft(lm, models, ou)
     try:
         gen_checkpoint_layout(unet, keys, loras)

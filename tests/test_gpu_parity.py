@@ -337,3 +337,56 @@ def test_captured_step_equals_eager_step():
     assert all(abs(a - b) < 2e-3 * abs(a) for a, b in zip(le, lg)), (le, lg)
     assert relerr(pg, pe) < 2e-3
     assert le[-1] < le[0]  # and it actually trains
+
+
+def test_create_watermark_lora_vs_reference_golden(golden):
+    from aqualora_amd.inference import create_watermark_lora
+    from aqualora_amd.watermark import MapperNet
+    g = golden("create_wm_lora.npz")
+    r = 320
+    sd = {}
+    for k in g.files:
+        if k == "msg":
+            continue
+        base, which = k.rsplit(".", 2)[0], k.rsplit(".", 2)[1]
+        shape = g[k].shape
+        sd[k] = T(base + "." + which, shape, 1.0 / r if which == "down" else 0.05)
+    mp = MapperNet(48, r).to(DEV)
+    with torch.no_grad():
+        mp.bit_embeddings.weight.copy_(T("cwl.E", (48, r)))
+    hid, out = create_watermark_lora(sd, mp, str(g["msg"]), 1.03)
+    assert hid == str(g["msg"]) and sorted(out) == sorted(k for k in g.files if k != "msg")
+    for k in out:
+        assert relerr(out[k], g[k]) < 1e-6, k
+
+
+def test_fuse_lora_and_ddim_sampler():
+    from aqualora_amd.checkpoint import lora_state_dict
+    from aqualora_amd.inference import ddim_sample, ddim_timesteps, fuse_lora
+    from oracle import ppft_oracle as O
+    assert ddim_timesteps(50)[:3] == [981, 961, 941] and ddim_timesteps(50)[-1] == 1
+    unet, keys, lw = _gpu_tiny()
+    inp = ppft_inputs(device=DEV)
+    x = inp["z"]
+    with torch.no_grad():
+        y_lora = unet(x, inp["t"], inp["ctx"], cross_attention_kwargs={"scale": 1.0}).sample.float()
+    sd = lora_state_dict(unet, keys)
+    fuse_lora(unet, sd, 1.0, keys)
+    assert all(unet.get_submodule(k).lora_layer is None for k in keys)
+    with torch.no_grad():
+        y_fused = unet(x, inp["t"], inp["ctx"]).sample.float()
+    assert relerr(y_fused, y_lora) < 3e-2
+    # sampler: graph replay == eager loop == oracle update rule driven by the same U-Net
+    ctx_u = torch.zeros_like(inp["ctx"])
+    lat = T("ddim.lat", (2, 4, 16, 16), device=DEV)
+    a = ddim_sample(unet, inp["ctx"], ctx_u, lat, num_inference_steps=5, guidance_scale=7.5, graph=True)
+    b = ddim_sample(unet, inp["ctx"], ctx_u, lat, num_inference_steps=5, guidance_scale=7.5, graph=False)
+    assert torch.equal(a, b)
+    xr = lat.clone()
+    ts = ddim_timesteps(5)
+    ctx2 = torch.cat([ctx_u, inp["ctx"]])
+    for t in ts:
+        with torch.no_grad():
+            e = unet(torch.cat([xr, xr]), torch.full((4,), t, device=DEV), ctx2).sample.float().contiguous()
+        xr = O.ddim_step(xr.cpu(), e[:2].cpu(), e[2:].cpu(), t, t - 200, 7.5).to(DEV)
+    assert relerr(a, xr) < 1e-4
