@@ -27,9 +27,9 @@ SIGNATURES = {
     "aql_conv3x3_bwd_data": [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_sz, c_p],
     "aql_gemm_tn_f32": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_f, c_p, c_l, c_p],
     "aql_groupnorm_silu_fwd": [c_p, c_i, c_i, c_i, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p],
-    "aql_groupnorm_silu_bwd": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p],
+    "aql_groupnorm_silu_bwd": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p],
     "aql_layernorm_fwd": [c_p, c_l, c_i, c_p, c_p, c_f, c_p, c_p, c_p],
-    "aql_layernorm_bwd": [c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p],
+    "aql_layernorm_bwd": [c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p],
     "aql_geglu_fwd": [c_p, c_l, c_i, c_p, c_p],
     "aql_geglu_bwd": [c_p, c_p, c_l, c_i, c_p, c_p],
     "aql_upsample2x_bwd": [c_p, c_i, c_i, c_i, c_i, c_p, c_p],

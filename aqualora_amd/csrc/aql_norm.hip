@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
                                                        const bf16_t* __restrict__ beta,
                                                        const float* __restrict__ stats,
                                                        const float* __restrict__ dstats, int HW, int C, int silu,
-                                                       bf16_t* __restrict__ out) {
+                                                       const bf16_t* __restrict__ dres, bf16_t* __restrict__ out) {
   const int b = blockIdx.y;
   const int cols = C >> 3;
   const int cpg = C / G;
@@ -161,6 +161,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
         d *= ga[j];
         o[j] = rs * (d - dstats[(b * G + g) * 2 + 0] - xh * dstats[(b * G + g) * 2 + 1]);
       }
+    }
+    if (MODE == 1 && dres != nullptr) {  // gradient of the residual / shortcut branch that shares this input
+      float rsd[8];
+      unpack8(*reinterpret_cast<const uint4*>(dres + off), rsd);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += rsd[j];
     }
     *reinterpret_cast<uint4*>(out + off) = pack8(o);
   }
@@ -256,6 +262,12 @@ __global__ __launch_bounds__(256) void ln_kernel(const bf16_t* __restrict__ x, c
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = rstd * (dv[t][j] - s1 - xv[t][j] * s2);
+        if (beta != nullptr) {  // backward: `beta` carries the gradient of the residual branch (same shape as x)
+          float rsd[8];
+          unpack8(*reinterpret_cast<const uint4*>(beta + row * C + c * 8), rsd);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += rsd[j];
+        }
         *reinterpret_cast<uint4*>(out + row * C + c * 8) = pack8(o);
       }
     }
@@ -298,14 +310,14 @@ extern "C" int aql_groupnorm_silu_fwd(const bf16_t* x, int B, int HW, int C, con
   int blocks = (int)((nchunk + 255) / 256);
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(gn_apply_kernel<0>, dim3(blocks, B), dim3(256), 0, stream, x, nullptr, gamma, beta, stats, nullptr,
-                     HW, C, silu, y);
+                     HW, C, silu, nullptr, y);
   AQL_CHECK_LAUNCH("aql_groupnorm_silu_fwd");
   return AQL_OK;
 }
 
 extern "C" int aql_groupnorm_silu_bwd(const bf16_t* x, const bf16_t* dy, int B, int HW, int C, const bf16_t* gamma,
-                                      const bf16_t* beta, int silu, const float* stats, bf16_t* dx, float* scratch,
-                                      hipStream_t stream) {
+                                      const bf16_t* beta, int silu, const float* stats, const bf16_t* dres, bf16_t* dx,
+                                      float* scratch, hipStream_t stream) {
   AQL_CHECK_ARG(x && dy && gamma && beta && dx && stats && scratch, "aql_groupnorm_silu_bwd: null operand");
   AQL_CHECK_ARG(C % 8 == 0 && C % G == 0 && C / 8 <= 1024, "aql_groupnorm_silu_bwd: bad C=%d", C);
   int threads, rps;
@@ -319,7 +331,7 @@ extern "C" int aql_groupnorm_silu_bwd(const bf16_t* x, const bf16_t* dy, int B, 
   int blocks = (int)((nchunk + 255) / 256);
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(blocks, B), dim3(256), 0, stream, x, dy, gamma, beta, stats, dstats, HW, C,
-                     silu, dx);
+                     silu, dres, dx);
   AQL_CHECK_LAUNCH("aql_groupnorm_silu_bwd");
   return AQL_OK;
 }
@@ -335,10 +347,10 @@ extern "C" int aql_layernorm_fwd(const bf16_t* x, long M, int C, const bf16_t* g
 }
 
 extern "C" int aql_layernorm_bwd(const bf16_t* x, const bf16_t* dy, long M, int C, const bf16_t* gamma,
-                                 const float* stats, bf16_t* dx, hipStream_t stream) {
+                                 const float* stats, const bf16_t* dres, bf16_t* dx, hipStream_t stream) {
   AQL_CHECK_ARG(x && dy && gamma && dx && stats, "aql_layernorm_bwd: null operand");
   AQL_CHECK_ARG(C % 8 == 0 && C <= 64 * 8 * LN_MAXC, "aql_layernorm_bwd: unsupported C=%d", C);
-  hipLaunchKernelGGL(ln_kernel<1>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, x, dy, gamma, nullptr,
+  hipLaunchKernelGGL(ln_kernel<1>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, x, dy, gamma, dres,
                      const_cast<float*>(stats), M, C, 0.f, dx);
   AQL_CHECK_LAUNCH("aql_layernorm_bwd");
   return AQL_OK;

@@ -363,8 +363,12 @@ def conv3x3(x, packed, upsample=False, rowbias=None, residual=None):
 
 # ------------------------------------------------------------------------------------------- norms
 class GroupNormSiluFn(torch.autograd.Function):
+    """GroupNorm(32)+SiLU.  With ``passthrough`` the input is ALSO returned (as a view) so that the residual / shortcut
+    branch hangs off this node: backward then receives both gradients at once and adds the residual one inside the
+    GroupNorm backward kernel instead of a separate elementwise-add launch."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, silu):
+    def forward(ctx, x, gamma, beta, eps, silu, passthrough=False):
         _req(x, "groupnorm")
         x = as_cl(x)
         B, C, H, W = x.shape
@@ -374,26 +378,36 @@ class GroupNormSiluFn(torch.autograd.Function):
                L.ptr(y), L.ptr(stats), L.ptr(_gn_scratch(x.device, B)), L.stream_ptr())
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.silu = silu
+        if passthrough:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, gamma, beta, stats = ctx.saved_tensors
-        dy = as_cl(dy)
         B, C, H, W = x.shape
+        if dy is None:  # only the pass-through branch carried a gradient
+            return (None if dres is None else as_cl(dres)), None, None, None, None, None
+        dy = as_cl(dy)
+        dres = None if dres is None else as_cl(dres)
         dx = torch.empty_like(x, memory_format=CL)
         L.call("aql_groupnorm_silu_bwd", L.ptr(x), L.ptr(dy), B, H * W, C, L.ptr(gamma), L.ptr(beta), int(ctx.silu),
-               L.ptr(stats), L.ptr(dx), L.ptr(_gn_scratch(x.device, B)), L.stream_ptr())
-        return dx, None, None, None, None
+               L.ptr(stats), L.ptr(dres), L.ptr(dx), L.ptr(_gn_scratch(x.device, B)), L.stream_ptr())
+        return dx, None, None, None, None, None
 
 
 def groupnorm_silu(x, gamma, beta, eps, silu):
     return GroupNormSiluFn.apply(x, gamma, beta, eps, silu)
 
 
+def groupnorm_silu_res(x, gamma, beta, eps, silu):
+    """-> (normalised, x) with the residual gradient folded into the GroupNorm backward kernel."""
+    return GroupNormSiluFn.apply(x, gamma, beta, eps, silu, True)
+
+
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x2d, gamma, beta, eps):
+    def forward(ctx, x2d, gamma, beta, eps, passthrough=False):
         _req(x2d, "layernorm")
         M, C = x2d.shape
         y = torch.empty_like(x2d)
@@ -401,20 +415,31 @@ class LayerNormFn(torch.autograd.Function):
         L.call("aql_layernorm_fwd", L.ptr(x2d), M, C, L.ptr(gamma), L.ptr(beta), float(eps), L.ptr(y), L.ptr(stats),
                L.stream_ptr())
         ctx.save_for_backward(x2d, gamma, stats)
+        if passthrough:
+            return y, x2d.view_as(x2d)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x2d, gamma, stats = ctx.saved_tensors
+        if dy is None:
+            return (None if dres is None else dres.contiguous()), None, None, None, None
         dy = dy.contiguous()
+        dres = None if dres is None else dres.contiguous()
         M, C = x2d.shape
         dx = torch.empty_like(x2d)
-        L.call("aql_layernorm_bwd", L.ptr(x2d), L.ptr(dy), M, C, L.ptr(gamma), L.ptr(stats), L.ptr(dx), L.stream_ptr())
-        return dx, None, None, None
+        L.call("aql_layernorm_bwd", L.ptr(x2d), L.ptr(dy), M, C, L.ptr(gamma), L.ptr(stats), L.ptr(dres), L.ptr(dx),
+               L.stream_ptr())
+        return dx, None, None, None, None
 
 
 def layernorm(x2d, gamma, beta, eps=1e-5):
     return LayerNormFn.apply(x2d, gamma, beta, eps)
+
+
+def layernorm_res(x2d, gamma, beta, eps=1e-5):
+    """-> (normalised, x2d) with the residual gradient folded into the LayerNorm backward kernel."""
+    return LayerNormFn.apply(x2d, gamma, beta, eps, True)
 
 
 class GegluFn(torch.autograd.Function):

@@ -36,6 +36,11 @@ class GroupNorm(nn.Module):
     def forward(self, x, silu=False):
         return ops.groupnorm_silu(x, self.weight, self.bias, self.eps, silu)
 
+    def forward_res(self, x, silu=False):
+        """-> (norm(x), x): use the second value for the residual / shortcut branch (its gradient is then added inside the
+        GroupNorm backward kernel)."""
+        return ops.groupnorm_silu_res(x, self.weight, self.bias, self.eps, silu)
+
 
 class LayerNorm(nn.Module):
     def __init__(self, channels, eps=1e-5, device=None, dtype=None):
@@ -47,6 +52,11 @@ class LayerNorm(nn.Module):
     def forward(self, x):
         shp = x.shape
         return ops.layernorm(x.reshape(-1, shp[-1]), self.weight, self.bias, self.eps).view(shp)
+
+    def forward_res(self, x):
+        shp = x.shape
+        y, xr = ops.layernorm_res(x.reshape(-1, shp[-1]), self.weight, self.bias, self.eps)
+        return y.view(shp), xr.view(shp)
 
 
 def get_timestep_embedding(timesteps, dim, flip_sin_to_cos=True, downscale_freq_shift=0, max_period=10000):
@@ -82,7 +92,7 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = LoRACompatibleConv(cin, cout, 1, **kw) if cin != cout else None
 
     def forward(self, x, temb_act, scale=1.0):
-        h = self.norm1(x, silu=True)
+        h, x = self.norm1.forward_res(x, silu=True)
         if isinstance(temb_act, dict):  # projections of all ResNets were batched into one GEMM (UNet forward)
             tproj = temb_act[id(self)]   # [B, cout] view with row stride = sum of all couts
         else:
@@ -159,9 +169,12 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim, **kw)
 
     def forward(self, h, ctx, scale=1.0):
-        h = self.attn1(self.norm1(h), None, scale, residual=h)
-        h = self.attn2(self.norm2(h), ctx, scale, residual=h)
-        return self.ff(self.norm3(h), scale, residual=h)
+        n, h = self.norm1.forward_res(h)
+        h = self.attn1(n, None, scale, residual=h)
+        n, h = self.norm2.forward_res(h)
+        h = self.attn2(n, ctx, scale, residual=h)
+        n, h = self.norm3.forward_res(h)
+        return self.ff(n, scale, residual=h)
 
 
 class Transformer2DModel(nn.Module):
@@ -174,7 +187,8 @@ class Transformer2DModel(nn.Module):
 
     def forward(self, x, ctx, scale=1.0):
         B, C, H, W = x.shape
-        h = self.proj_in(self.norm(x), scale)
+        n, x = self.norm.forward_res(x)
+        h = self.proj_in(n, scale)
         tokens = ops.nhwc_view(h).reshape(B, H * W, C)
         for blk in self.transformer_blocks:
             tokens = blk(tokens, ctx, scale)

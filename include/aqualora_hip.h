@@ -67,13 +67,14 @@ int aql_gemm_tn_grouped(const void* dev_descs, int n, int total_blocks, aql_stre
 long aql_groupnorm_scratch_floats(int B, int HW);
 int aql_groupnorm_silu_fwd(const bf16_t* x, int B, int HW, int C, const bf16_t* gamma, const bf16_t* beta, float eps,
                            int silu, bf16_t* y, float* stats, float* scratch, aql_stream_t stream);
+/* dres (optional): gradient of the residual / shortcut branch that consumed the same x; added into dx in the same pass */
 int aql_groupnorm_silu_bwd(const bf16_t* x, const bf16_t* dy, int B, int HW, int C, const bf16_t* gamma,
-                           const bf16_t* beta, int silu, const float* stats, bf16_t* dx, float* scratch,
-                           aql_stream_t stream);
+                           const bf16_t* beta, int silu, const float* stats, const bf16_t* dres, bf16_t* dx,
+                           float* scratch, aql_stream_t stream);
 int aql_layernorm_fwd(const bf16_t* x, long M, int C, const bf16_t* gamma, const bf16_t* beta, float eps, bf16_t* y,
                       float* stats, aql_stream_t stream);
 int aql_layernorm_bwd(const bf16_t* x, const bf16_t* dy, long M, int C, const bf16_t* gamma, const float* stats,
-                      bf16_t* dx, aql_stream_t stream);
+                      const bf16_t* dres, bf16_t* dx, aql_stream_t stream);
 
 /* ---- attention (csrc/aql_attn.hip) ---- F.scaled_dot_product_attention via diffusers AttnProcessor2_0 / twin
  * original_unet.py:688-704.  q/k/v/o: [B,N,H*d] with row strides ld*; lse,delta: [B,H,Nq] fp32.                   */
