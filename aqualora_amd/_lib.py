@@ -75,6 +75,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and not os.environ.get("AQL_NO_AUTOBUILD"):
+        # a source-only checkout: compile the HIP library in-tree (this is a build, not a fallback -- if hipcc is
+        # missing or the build fails we still stop below)
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j8"], check=False, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL)
     if not os.path.exists(LIB_PATH):
         raise AqlError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

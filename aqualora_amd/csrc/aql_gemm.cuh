@@ -290,7 +290,7 @@ struct Stager<R, TransLoader> {
 // --------------------------------------------------------------------------------------------
 // the kernel
 // --------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI>
+template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG = 2>
 __device__ __forceinline__ void gemm_body(const GemmArgs<LA, LB>& g, const int block_x, const int block_z) {
   constexpr int FM = WM / 32, FN = WN / 32;
   constexpr int WAVES_N = BN / WN;
@@ -298,7 +298,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<LA, LB>& g, const int b
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int C_PITCH = (BN + 8) * 2;  // bytes per row of the bf16 C tile staged in LDS
-  constexpr int LDS_BYTES = (2 * STAGE > BM * C_PITCH) ? 2 * STAGE : BM * C_PITCH;
+  // NSTG = 2: double-buffered stages (one barrier per K tile).  NSTG = 1: a single stage and two barriers per K tile,
+  // half the LDS -> twice the resident workgroups per CU, which is what the short-K, latency-bound shapes want.
+  constexpr int LDS_BYTES = (NSTG * STAGE > BM * C_PITCH) ? NSTG * STAGE : BM * C_PITCH;
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
 
   const int tid = threadIdx.x;
@@ -359,7 +361,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<LA, LB>& g, const int b
   __syncthreads();
 
   for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int cur = (kt - kt_begin) & 1;
+    const int cur = (NSTG == 2) ? ((kt - kt_begin) & 1) : 0;
     char* sA = lds + cur * STAGE;
     char* sB = sA + A_BYTES;
     const bool more = (kt + 1 < kt_end);
@@ -382,8 +384,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<LA, LB>& g, const int b
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
 
+    if (NSTG == 1) __syncthreads();  // everybody is done reading the only stage
     if (more) {
-      char* nA = lds + (cur ^ 1) * STAGE;
+      char* nA = lds + ((NSTG == 2) ? (cur ^ 1) : 0) * STAGE;
       sa.commit(nA, tid);
       sb.commit(nA + A_BYTES, tid);
     }
@@ -505,14 +508,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<LA, LB>& g, const int b
   }
 }
 
-template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI>
+template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG = 2>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs<LA, LB> g) {
   // XCD-aware remap (guide T1): hardware block b runs on XCD b % 8, each XCD has a private L2.  Give every XCD a
   // CONTIGUOUS run of logical tiles so that tiles sharing an operand panel hit the same L2 (bijective for any grid).
   const int nblk = gridDim.x, bid = blockIdx.x;
   const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
   const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  gemm_body<BM, BN, WM, WN, LA, LB, EPI>(g, logical, blockIdx.z);
+  gemm_body<BM, BN, WM, WN, LA, LB, EPI, NSTG>(g, logical, blockIdx.z);
 }
 
 // Grouped token-reduction GEMMs: ONE launch for all LoRA weight gradients of a backward pass.  Every problem has a
@@ -549,10 +552,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_grouped_kernel(const TnGroup
   gemm_body<128, 32, 32, 32, TransLoader, TransLoader, EPI_ATOMIC>(g, local % tiles, local / tiles);
 }
 
-template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI>
+template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG = 2>
 inline void launch_gemm(const GemmArgs<LA, LB>& g, hipStream_t stream) {
   dim3 grid(aql_cdiv(g.M, BM) * aql_cdiv(g.N, BN), 1, g.splits);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LA, LB, EPI>), grid, dim3(NTHREADS), 0, stream, g);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LA, LB, EPI, NSTG>), grid, dim3(NTHREADS), 0, stream, g);
 }
 
 }  // namespace aqlgemm

@@ -86,6 +86,15 @@ inline int pick_splits(int tiles, int kt_total, long M, int N, size_t ws_bytes) 
 
 template <class LA, class LB, int EPI>
 void launch_cfg(int cfg, const GemmArgs<LA, LB>& g, hipStream_t stream) {
+  static int single = -1;  // tuning hook: AQL_SINGLE_STAGE=1 -> single-stage LDS for the 128x64 / 64x64 tiles
+  if (single < 0) {
+    const char* e = getenv("AQL_SINGLE_STAGE");
+    single = e ? atoi(e) : 1;  // measured: equal or slightly faster on the K <= 1536 shapes, half the LDS
+  }
+  if constexpr (!LA::kTrans) {
+    if (single && cfg == 2 && g.ktiles0 + g.ktiles1 <= 24) return launch_gemm<128, 64, 64, 32, LA, LB, EPI, 1>(g, stream);
+    if (single && cfg == 3 && g.ktiles0 + g.ktiles1 <= 24) return launch_gemm<64, 64, 32, 32, LA, LB, EPI, 1>(g, stream);
+  }
   switch (cfg) {
     case 0: launch_gemm<128, 32, 32, 32, LA, LB, EPI>(g, stream); break;
     case 1: launch_gemm<128, 128, 64, 64, LA, LB, EPI>(g, stream); break;
