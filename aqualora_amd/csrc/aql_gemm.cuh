@@ -509,6 +509,196 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<LA, LB>& g, const int b
 }
 
 template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG = 2>
+__device__ __forceinline__ void gemm_body16(const GemmArgs<LA, LB>& g, const int block_x, const int block_z) {
+  // 16x16x32 MFMA variant: fragment granularity 16, so BN = 160 (every channel count of this U-Net is a multiple of
+  // 160) tiles with a 64x80 / 32x80 wave tile: 0.45-0.7 LDS fragment reads per MFMA instead of 1.0-1.5.
+  static_assert(EPI != EPI_ATOMIC && !LA::kTrans, "bf16 / slab epilogues only");
+  constexpr int FM = WM / 16, FN = WN / 16;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * (BN / WN) == 4, "4 wavefronts per workgroup");
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int C_PITCH = (BN + 8) * 2;  // bytes per row of the bf16 C tile staged in LDS
+  // NSTG = 2: double-buffered stages (one barrier per K tile).  NSTG = 1: a single stage and two barriers per K tile,
+  // half the LDS -> twice the resident workgroups per CU, which is what the short-K, latency-bound shapes want.
+  constexpr int LDS_BYTES = (NSTG * STAGE > BM * C_PITCH) ? NSTG * STAGE : BM * C_PITCH;
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm0 = (wave / WAVES_N) * WM;
+  const int wn0 = (wave % WAVES_N) * WN;
+
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int tiles_m = (g.M + BM - 1) / BM;
+  int tile_m, tile_n;
+  if (g.m_fast) {
+    tile_n = block_x / tiles_m;
+    tile_m = block_x - tile_n * tiles_m;
+  } else {
+    tile_m = block_x / tiles_n;
+    tile_n = block_x - tile_m * tiles_n;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // K range of this split
+  const int kt_total = g.ktiles0 + g.ktiles1;
+  const int kt_begin = (int)(((long)kt_total * block_z) / g.splits);
+  const int kt_end = (int)(((long)kt_total * (block_z + 1)) / g.splits);
+
+  Stager<BM, LA> sa;
+  Stager<BN, LB> sb;
+  sa.init(g.a0, m0, tid);
+  sb.init(g.b0, n0, tid);
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+  auto fetch = [&](int kt) {
+    if (kt < g.ktiles0) {
+      sa.fetch(g.a0, kt * BK, tid);
+      sb.fetch(g.b0, kt * BK, tid);
+    } else {
+      if (kt == g.ktiles0 || kt == kt_begin) {  // switch row descriptors to segment 1
+        sa.init(g.a1, m0, tid);
+        sb.init(g.b1, n0, tid);
+      }
+      sa.fetch(g.a1, (kt - g.ktiles0) * BK, tid);
+      sb.fetch(g.b1, (kt - g.ktiles0) * BK, tid);
+    }
+  };
+
+  if (kt_begin < kt_end) {
+    fetch(kt_begin);
+    sa.commit(lds, tid);
+    sb.commit(lds + A_BYTES, tid);
+  }
+  __syncthreads();
+
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (NSTG == 2) ? ((kt - kt_begin) & 1) : 0;
+    char* sA = lds + cur * STAGE;
+    char* sB = sA + A_BYTES;
+    const bool more = (kt + 1 < kt_end);
+    if (more) fetch(kt + 1);
+
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8_t fa[FM], fb[FN];
+      const int chunk = ks * 4 + (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+        fa[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(wm0 + i * 16 + (lane & 15), chunk));
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        fb[j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(wn0 + j * 16 + (lane & 15), chunk));
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+
+    if (NSTG == 1) __syncthreads();  // everybody is done reading the only stage
+    if (more) {
+      char* nA = lds + ((NSTG == 2) ? (cur ^ 1) : 0) * STAGE;
+      sa.commit(nA, tid);
+      sb.commit(nA + A_BYTES, tid);
+    }
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  // acc[i][j][e]: output row m = m0+wm0+i*16+(lane&15); col n = n0+wn0+j*16 + 4*(lane>>4) + e
+  const EpiParams& ep = g.epi;
+  if constexpr (EPI == EPI_BF16) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int row = wm0 + i * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int col = wn0 + j * 16 + (lane >> 4) * 4;
+        float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+        if (ep.bias != nullptr && (n0 + col) < g.N) {
+          const uint2 bb = *reinterpret_cast<const uint2*>(ep.bias + n0 + col);
+          v0 += bf16lo(bb.x);
+          v1 += bf16hi(bb.x);
+          v2 += bf16lo(bb.y);
+          v3 += bf16hi(bb.y);
+        }
+        *reinterpret_cast<uint2*>(lds + row * C_PITCH + col * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+      }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;  // 16-byte chunks per row
+    for (int id = tid; id < BM * CPR; id += NTHREADS) {
+      const int row = id / CPR, cc = id - row * CPR;
+      const int m = m0 + row, n = n0 + cc * 8;
+      if (m >= g.M || n >= g.N) continue;
+      uint4 v = *reinterpret_cast<const uint4*>(lds + row * C_PITCH + cc * 16);
+      if (ep.rowbias != nullptr) {
+        const uint4 r = *reinterpret_cast<const uint4*>(ep.rowbias + (long)(m / ep.rows_per_sample) * ep.rowbias_ld + n);
+        v.x = pack_bf16x2(bf16lo(v.x) + bf16lo(r.x), bf16hi(v.x) + bf16hi(r.x));
+        v.y = pack_bf16x2(bf16lo(v.y) + bf16lo(r.y), bf16hi(v.y) + bf16hi(r.y));
+        v.z = pack_bf16x2(bf16lo(v.z) + bf16lo(r.z), bf16hi(v.z) + bf16hi(r.z));
+        v.w = pack_bf16x2(bf16lo(v.w) + bf16lo(r.w), bf16hi(v.w) + bf16hi(r.w));
+      }
+      if (ep.residual != nullptr) {
+        const uint4 r = *reinterpret_cast<const uint4*>(ep.residual + (long)m * ep.ldr + n);
+        v.x = pack_bf16x2(bf16lo(v.x) + bf16lo(r.x), bf16hi(v.x) + bf16hi(r.x));
+        v.y = pack_bf16x2(bf16lo(v.y) + bf16lo(r.y), bf16hi(v.y) + bf16hi(r.y));
+        v.z = pack_bf16x2(bf16lo(v.z) + bf16lo(r.z), bf16hi(v.z) + bf16hi(r.z));
+        v.w = pack_bf16x2(bf16lo(v.w) + bf16lo(r.w), bf16hi(v.w) + bf16hi(r.w));
+      }
+      if (ep.C != nullptr) *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + n) = v;
+      if (ep.C2 != nullptr) {
+        const uint4 s =
+            *reinterpret_cast<const uint4*>(ep.rowscale + (long)(m / ep.rows_per_sample) * g.N + n);
+        uint4 o;
+        o.x = pack_bf16x2(bf16lo(v.x) * bf16lo(s.x), bf16hi(v.x) * bf16hi(s.x));
+        o.y = pack_bf16x2(bf16lo(v.y) * bf16lo(s.y), bf16hi(v.y) * bf16hi(s.y));
+        o.z = pack_bf16x2(bf16lo(v.z) * bf16lo(s.z), bf16hi(v.z) * bf16hi(s.z));
+        o.w = pack_bf16x2(bf16lo(v.w) * bf16lo(s.w), bf16hi(v.w) * bf16hi(s.w));
+        *reinterpret_cast<uint4*>(ep.C2 + (long)m * ep.ldc2 + n) = o;
+      }
+    }
+  } else {
+    float* out = ep.Cf + (long)block_z * g.M * ep.ldcf;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int m = m0 + wm0 + i * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn0 + j * 16 + (lane >> 4) * 4;
+        if (m >= g.M || n >= g.N) continue;
+        *reinterpret_cast<float4*>(out + (long)m * ep.ldcf + n) =
+            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG = 2>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel16(const GemmArgs<LA, LB> g) {
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  gemm_body16<BM, BN, WM, WN, LA, LB, EPI, NSTG>(g, logical, blockIdx.z);
+}
+
+template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG = 2>
+inline void launch_gemm16(const GemmArgs<LA, LB>& g, hipStream_t stream) {
+  dim3 grid(aql_cdiv(g.M, BM) * aql_cdiv(g.N, BN), 1, g.splits);
+  hipLaunchKernelGGL((gemm_kernel16<BM, BN, WM, WN, LA, LB, EPI, NSTG>), grid, dim3(NTHREADS), 0, stream, g);
+}
+
+template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG = 2>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs<LA, LB> g) {
   // XCD-aware remap (guide T1): hardware block b runs on XCD b % 8, each XCD has a private L2.  Give every XCD a
   // CONTIGUOUS run of logical tiles so that tiles sharing an operand panel hit the same L2 (bijective for any grid).

@@ -91,6 +91,10 @@ void launch_cfg(int cfg, const GemmArgs<LA, LB>& g, hipStream_t stream) {
     const char* e = getenv("AQL_SINGLE_STAGE");
     single = e ? atoi(e) : 1;  // measured: equal or slightly faster on the K <= 1536 shapes, half the LDS
   }
+  if constexpr (!LA::kTrans && EPI != EPI_ATOMIC) {
+    if (cfg == 5) return launch_gemm16<128, 160, 64, 80, LA, LB, EPI>(g, stream);
+    if (cfg == 6) return launch_gemm16<64, 160, 32, 80, LA, LB, EPI>(g, stream);
+  }
   if constexpr (!LA::kTrans) {
     if (single && cfg == 2 && g.ktiles0 + g.ktiles1 <= 24) return launch_gemm<128, 64, 64, 32, LA, LB, EPI, 1>(g, stream);
     if (single && cfg == 3 && g.ktiles0 + g.ktiles1 <= 24) return launch_gemm<64, 64, 32, 32, LA, LB, EPI, 1>(g, stream);
@@ -144,6 +148,19 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
   if (const char* e = getenv("AQL_MFAST")) g.m_fast = atoi(e);
   int tiles = 0;
   int cfg = pick_cfg(g.M, g.N, kt_total, ws != nullptr && o.C2 == nullptr, &tiles);
+  // 160-wide tiles on the 16x16x32 MFMA (every channel count here is a multiple of 160): taken when they fill the chip
+  // with >= ~2 workgroups per CU, or when K is deep enough to split (measured per shape, tools/probe_gemm.py)
+  static int n160 = -1;
+  if (n160 < 0) {
+    const char* e = getenv("AQL_N160");
+    n160 = e ? atoi(e) : 1;
+  }
+  if (n160 && g.N % 160 == 0 && o.C2 == nullptr) {
+    const int t5 = aql_cdiv(g.M, 128) * (g.N / 160), t6 = aql_cdiv(g.M, 64) * (g.N / 160);
+    const bool deep = ws != nullptr && kt_total >= 32;
+    if (n160 == 2 || (n160 == 1 && (t5 >= 448 || (deep && t6 < 448)))) cfg = 5, tiles = t5;
+    else if (n160 == 3 || (n160 == 1 && t6 >= 448)) cfg = 6, tiles = t6;
+  }
   if (const char* e = getenv("AQL_CFG2_AS")) {  // tuning hook: remap the 128x64 config
     if (cfg == 2 && g.M >= 1024) {
       cfg = atoi(e);
