@@ -84,31 +84,39 @@ inline int pick_splits(int tiles, int kt_total, long M, int N, size_t ws_bytes) 
   return s < 1 ? 1 : s;
 }
 
+// Tile configurations.  ids 0-4: the transposing (token-reduction) kernels on the 32x32x16 MFMA; ids 5-10: the
+// pipelined buffer-load kernels on the 16x16x32 MFMA used by every bf16-output GEMM / conv.
+enum { P_128x160 = 5, P_64x160 = 6, P_32x160 = 7, P_64x64 = 8, P_128x32 = 9, P_128x128 = 10 };
+
 template <class LA, class LB, int EPI>
-void launch_cfg(int cfg, const GemmArgs<LA, LB>& g, hipStream_t stream) {
-  static int single = -1;  // tuning hook: AQL_SINGLE_STAGE=1 -> single-stage LDS for the 128x64 / 64x64 tiles
-  if (single < 0) {
-    const char* e = getenv("AQL_SINGLE_STAGE");
-    single = e ? atoi(e) : 1;  // measured: equal or slightly faster on the K <= 1536 shapes, half the LDS
-  }
-  if constexpr (!LA::kTrans && EPI != EPI_ATOMIC) {
-    if (cfg == 5) return launch_gemm16<128, 160, 64, 80, LA, LB, EPI>(g, stream);
-    if (cfg == 6) return launch_gemm16<64, 160, 32, 80, LA, LB, EPI>(g, stream);
-  }
-  if constexpr (!LA::kTrans) {
-    if (single && cfg == 2 && g.ktiles0 + g.ktiles1 <= 24) return launch_gemm<128, 64, 64, 32, LA, LB, EPI, 1>(g, stream);
-    if (single && cfg == 3 && g.ktiles0 + g.ktiles1 <= 24) return launch_gemm<64, 64, 32, 32, LA, LB, EPI, 1>(g, stream);
-  }
-  switch (cfg) {
-    case 0: launch_gemm<128, 32, 32, 32, LA, LB, EPI>(g, stream); break;
-    case 1: launch_gemm<128, 128, 64, 64, LA, LB, EPI>(g, stream); break;
-    case 2: launch_gemm<128, 64, 64, 32, LA, LB, EPI>(g, stream); break;
-    case 4: launch_gemm<256, 64, 64, 64, LA, LB, EPI>(g, stream); break;
-    default: launch_gemm<64, 64, 32, 32, LA, LB, EPI>(g, stream); break;
+void launch_cfg(int cfg, int pd, const GemmArgs<LA, LB>& g, hipStream_t stream) {
+  if constexpr (LA::kTrans) {
+    switch (cfg) {
+      case 0: launch_gemm<128, 32, 32, 32, LA, LB, EPI>(g, stream); break;
+      case 1: launch_gemm<128, 128, 64, 64, LA, LB, EPI>(g, stream); break;
+      case 2: launch_gemm<128, 64, 64, 32, LA, LB, EPI>(g, stream); break;
+      default: launch_gemm<64, 64, 32, 32, LA, LB, EPI>(g, stream); break;
+    }
+  } else {
+#define AQL_P(BM, BN, WM, WN, PDHI)                                                              \
+  if (pd == 12) return launch_gemm_d<BM, BN, WM, WN, LA, LB, EPI, 2>(g, stream);                 \
+  if (pd == 13) return launch_gemm_d<BM, BN, WM, WN, LA, LB, EPI, 3>(g, stream);                 \
+  if (pd <= 1) return launch_gemm_p<BM, BN, WM, WN, LA, LB, EPI, 1>(g, stream);                  \
+  if (pd == 2) return launch_gemm_p<BM, BN, WM, WN, LA, LB, EPI, 2>(g, stream);                  \
+  return launch_gemm_p<BM, BN, WM, WN, LA, LB, EPI, PDHI>(g, stream);
+    switch (cfg) {
+      case P_128x160: { AQL_P(128, 160, 64, 80, 3) }
+      case P_64x160: { AQL_P(64, 160, 32, 80, 4) }
+      case P_32x160: { AQL_P(32, 160, 16, 80, 4) }
+      case P_128x32: { AQL_P(128, 32, 32, 32, 4) }
+      case P_128x128: { AQL_P(128, 128, 64, 64, 3) }
+      default: { AQL_P(64, 64, 32, 32, 4) }
+    }
+#undef AQL_P
   }
 }
 
-// tile choice: the largest tile that still yields >= ~1 workgroup per CU; cfg ids as in launch_cfg
+// tile choice for the token-reduction kernels: the largest tile that still yields >= ~1 workgroup per CU
 inline int pick_cfg(long M, int N, int kt_total, bool can_split, int* tiles) {
   if (N <= 32) {
     *tiles = aql_cdiv(M, 128);
@@ -118,10 +126,6 @@ inline int pick_cfg(long M, int N, int kt_total, bool can_split, int* tiles) {
   const int t64 = aql_cdiv(M, 128) * aql_cdiv(N, 64);
   const int t6464 = aql_cdiv(M, 64) * aql_cdiv(N, 64);
   const bool waste128 = (N % 128 != 0) && (N % 128 <= 64);
-  if (can_split && kt_total >= 32) {  // deep K (3x3 convs): big tile + split-K beats small tiles (measured)
-    *tiles = waste128 ? t64 : t128;
-    return waste128 ? 2 : 1;
-  }
   if (t128 >= 240 && !waste128) {
     *tiles = t128;
     return 1;
@@ -132,6 +136,40 @@ inline int pick_cfg(long M, int N, int kt_total, bool can_split, int* tiles) {
   }
   *tiles = t6464;
   return 3;
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+// Tile + prefetch depth for a bf16-output GEMM.  Every channel count of the U-Net is a multiple of 160, so the 160-wide
+// tiles cover the model; the 64x64 / 128x128 / 128x32 tiles take the odd shapes (LoRA rank, tests).  Measured per shape
+// with tools/probe_gemm.py on MI355X.
+inline void pick_tile(long M, int N, int kt_total, bool can_split, int* cfg, int* tiles, int* pd) {
+  static const int force = env_int("AQL_TILE", 0), force_pd = env_int("AQL_PD", 0);  // tuning hooks
+  const bool deep = can_split && kt_total >= 32;
+  if (N % 160 == 0) {
+    const int nt = N / 160;
+    const int t128 = aql_cdiv(M, 128) * nt, t64 = aql_cdiv(M, 64) * nt, t32 = aql_cdiv(M, 32) * nt;
+    if (t128 >= 448 || (deep && t64 < 448)) *cfg = P_128x160, *tiles = t128;
+    else if (t64 >= 200) *cfg = P_64x160, *tiles = t64;
+    else if (t32 >= 128) *cfg = P_32x160, *tiles = t32;
+    else *cfg = P_64x64, *tiles = aql_cdiv(M, 64) * aql_cdiv(N, 64);
+    if (force >= P_128x160 && force <= P_32x160) {
+      *cfg = force;
+      *tiles = aql_cdiv(M, force == P_128x160 ? 128 : force == P_64x160 ? 64 : 32) * nt;
+    }
+  } else if (N <= 32) {
+    *cfg = P_128x32, *tiles = aql_cdiv(M, 128);
+  } else {
+    const int t128 = aql_cdiv(M, 128) * aql_cdiv(N, 128);
+    if (t128 >= 240 || deep) *cfg = P_128x128, *tiles = t128;
+    else *cfg = P_64x64, *tiles = aql_cdiv(M, 64) * aql_cdiv(N, 64);
+  }
+  if (force == P_64x64) *cfg = P_64x64, *tiles = aql_cdiv(M, 64) * aql_cdiv(N, 64);
+  *pd = 12;  // LDS-DMA, two stages: measured fastest on every shape (hot and cold operands)
+  if (force_pd) *pd = force_pd;
 }
 
 // Dispatch one bf16-output GEMM over the tile configurations; split-K slabs + finalize when the grid cannot fill
@@ -146,34 +184,15 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
   // 8x8 / 16x16 / 32x32), else the activation rows
   g.m_fast = ((long)g.N * kt_total > (long)g.M * (kt_total < 9 ? kt_total : kt_total / 9 + 1)) ? 1 : 0;
   if (const char* e = getenv("AQL_MFAST")) g.m_fast = atoi(e);
-  int tiles = 0;
-  int cfg = pick_cfg(g.M, g.N, kt_total, ws != nullptr && o.C2 == nullptr, &tiles);
-  // 160-wide tiles on the 16x16x32 MFMA (every channel count here is a multiple of 160): taken when they fill the chip
-  // with >= ~2 workgroups per CU, or when K is deep enough to split (measured per shape, tools/probe_gemm.py)
-  static int n160 = -1;
-  if (n160 < 0) {
-    const char* e = getenv("AQL_N160");
-    n160 = e ? atoi(e) : 1;
-  }
-  if (n160 && g.N % 160 == 0 && o.C2 == nullptr) {
-    const int t5 = aql_cdiv(g.M, 128) * (g.N / 160), t6 = aql_cdiv(g.M, 64) * (g.N / 160);
-    const bool deep = ws != nullptr && kt_total >= 32;
-    if (n160 == 2 || (n160 == 1 && (t5 >= 448 || (deep && t6 < 448)))) cfg = 5, tiles = t5;
-    else if (n160 == 3 || (n160 == 1 && t6 >= 448)) cfg = 6, tiles = t6;
-  }
-  if (const char* e = getenv("AQL_CFG2_AS")) {  // tuning hook: remap the 128x64 config
-    if (cfg == 2 && g.M >= 1024) {
-      cfg = atoi(e);
-      tiles = aql_cdiv(g.M, cfg == 4 ? 256 : 128) * aql_cdiv(g.N, 64);
-    }
-  }
+  int tiles = 0, cfg = 0, pd = 1;
+  pick_tile(g.M, g.N, kt_total, ws != nullptr && o.C2 == nullptr, &cfg, &tiles, &pd);
   int splits = 1;
   if (ws != nullptr && o.C2 == nullptr) splits = pick_splits(tiles, kt_total, g.M, g.N, ws_bytes);
   g.splits = splits;
   if (splits > 1) {
     g.epi.Cf = ws;
     g.epi.ldcf = g.N;
-    launch_cfg<LA, LB, EPI_SLAB>(cfg, g, stream);
+    launch_cfg<LA, LB, EPI_SLAB>(cfg, pd, g, stream);
     AQL_CHECK_LAUNCH(name);
     const long nchunk = (long)g.M * (g.N / 4);
     int blocks = (int)((nchunk + 255) / 256);
@@ -194,7 +213,7 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
   g.epi.rowscale = o.rowscale;
   g.epi.rowbias = o.rowbias;
   g.epi.rowbias_ld = o.rowbias_ld > 0 ? o.rowbias_ld : (long)g.N;
-  launch_cfg<LA, LB, EPI_BF16>(cfg, g, stream);
+  launch_cfg<LA, LB, EPI_BF16>(cfg, pd, g, stream);
   AQL_CHECK_LAUNCH(name);
   return AQL_OK;
 }
@@ -471,7 +490,7 @@ extern "C" int aql_gemm_tn_f32(const bf16_t* U, long ldu, const bf16_t* V, long 
   if (splits < 1) splits = 1;
   if (const char* e = getenv("AQL_TN_SPLITS")) splits = atoi(e) < g.ktiles0 ? atoi(e) : g.ktiles0;  // tuning hook
   g.splits = splits;
-  launch_cfg<TransLoader, TransLoader, EPI_ATOMIC>(cfg, g, stream);
+  launch_cfg<TransLoader, TransLoader, EPI_ATOMIC>(cfg, 1, g, stream);
   AQL_CHECK_LAUNCH("aql_gemm_tn_f32");
   return AQL_OK;
 }
