@@ -84,6 +84,222 @@ __global__ __launch_bounds__(256) void add_noise_clamp_kernel(const float* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Colour jiggle (kornia 0.6.12 ColorJiggle as called at noises.py:97-103, noiser.py:52-57, utils_eval.py:271-276):
+// brightness (additive shift, clamp), contrast (multiplicative, clamp), saturation and hue (through HSV), applied in a
+// caller-supplied order.  One thread per pixel.  The backward pass evaluates the same code on dual numbers
+// (value + gradient w.r.t. the pixel's r,g,b), so forward and backward cannot drift apart.
+// ---------------------------------------------------------------------------------------------------------------
+struct D3 {  // value + d/d(r_in, g_in, b_in)
+  float v, d[3];
+};
+__device__ __forceinline__ D3 operator+(D3 a, D3 b) { return {a.v + b.v, {a.d[0] + b.d[0], a.d[1] + b.d[1], a.d[2] + b.d[2]}}; }
+__device__ __forceinline__ D3 operator-(D3 a, D3 b) { return {a.v - b.v, {a.d[0] - b.d[0], a.d[1] - b.d[1], a.d[2] - b.d[2]}}; }
+__device__ __forceinline__ D3 operator*(D3 a, D3 b) {
+  return {a.v * b.v, {a.d[0] * b.v + a.v * b.d[0], a.d[1] * b.v + a.v * b.d[1], a.d[2] * b.v + a.v * b.d[2]}};
+}
+__device__ __forceinline__ D3 operator/(D3 a, D3 b) {
+  const float q = a.v / b.v, ib = 1.f / b.v;
+  return {q, {(a.d[0] - q * b.d[0]) * ib, (a.d[1] - q * b.d[1]) * ib, (a.d[2] - q * b.d[2]) * ib}};
+}
+__device__ __forceinline__ D3 operator+(D3 a, float b) { return {a.v + b, {a.d[0], a.d[1], a.d[2]}}; }
+__device__ __forceinline__ D3 operator-(D3 a, float b) { return {a.v - b, {a.d[0], a.d[1], a.d[2]}}; }
+__device__ __forceinline__ D3 operator*(D3 a, float b) { return {a.v * b, {a.d[0] * b, a.d[1] * b, a.d[2] * b}}; }
+__device__ __forceinline__ D3 operator-(float a, D3 b) { return {a - b.v, {-b.d[0], -b.d[1], -b.d[2]}}; }
+__device__ __forceinline__ float val(float a) { return a; }
+__device__ __forceinline__ float val(D3 a) { return a.v; }
+__device__ __forceinline__ float cst(float, float c) { return c; }      // a constant of the same scalar type
+__device__ __forceinline__ D3 cst(D3, float c) { return {c, {0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ float with_val(float, float v) { return v; }  // same derivative, new value (mod / wrap)
+__device__ __forceinline__ D3 with_val(D3 a, float v) { return {v, {a.d[0], a.d[1], a.d[2]}}; }
+
+template <class T>
+__device__ __forceinline__ T clamp01(T a) {
+  const float v = val(a);
+  return v < 0.f ? cst(a, 0.f) : (v > 1.f ? cst(a, 1.f) : a);
+}
+
+constexpr float TWO_PI = 6.283185307179586f;
+
+template <class T>
+__device__ __forceinline__ void rgb_to_hsv(T r, T g, T b, T& h, T& s, T& v) {
+  // first maximum wins (torch.max index), like the gather on argmax in kornia.color.rgb_to_hsv
+  int am = 0;
+  T mx = r;
+  if (val(g) > val(mx)) mx = g, am = 1;
+  if (val(b) > val(mx)) mx = b, am = 2;
+  T mn = r;
+  if (val(g) < val(mn)) mn = g;
+  if (val(b) < val(mn)) mn = b;
+  T delta = mx - mn;
+  v = mx;
+  s = delta / (mx + 1e-8f);
+  if (val(delta) == 0.f) delta = cst(delta, 1.f);
+  const T rc = mx - r, gc = mx - g, bc = mx - b;
+  T hh = am == 0 ? (bc - gc) : (am == 1 ? (rc - bc) + delta * 2.f : (gc - rc) + delta * 4.f);
+  hh = hh / delta;
+  hh = hh * (1.f / 6.f);
+  const float w = val(hh) - floorf(val(hh));  // python-style % 1.0
+  h = with_val(hh, w) * TWO_PI;
+}
+
+template <class T>
+__device__ __forceinline__ void hsv_to_rgb(T h, T s, T v, T& r, T& g, T& b) {
+  const T h6 = h * (6.f / TWO_PI);
+  const float fl = floorf(val(h6));
+  int hi = (int)fl % 6;
+  if (hi < 0) hi += 6;
+  const T f = with_val(h6, val(h6) - fl);  // (h*6) % 6 - hi  ==  frac(h*6)
+  const T one = cst(v, 1.f);
+  const T p = v * (one - s), q = v * (one - f * s), t = v * (one - (one - f) * s);
+  switch (hi) {
+    case 0: r = v, g = t, b = p; break;
+    case 1: r = q, g = v, b = p; break;
+    case 2: r = p, g = v, b = t; break;
+    case 3: r = p, g = q, b = v; break;
+    case 4: r = t, g = p, b = v; break;
+    default: r = v, g = p, b = q; break;
+  }
+}
+
+// fac = {brightness shift (factor - 1), contrast, saturation, hue shift in radians}; order[i] in 0..3 names the i-th op
+template <class T>
+__device__ __forceinline__ void jiggle(T& r, T& g, T& b, const float* fac, const int* order) {
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i) {
+    const int op = order[i];
+    if (op == 0) {
+      r = clamp01(r + fac[0]), g = clamp01(g + fac[0]), b = clamp01(b + fac[0]);
+    } else if (op == 1) {
+      r = clamp01(r * fac[1]), g = clamp01(g * fac[1]), b = clamp01(b * fac[1]);
+    } else {
+      T h, s, v;
+      rgb_to_hsv(r, g, b, h, s, v);
+      if (op == 2) {
+        s = clamp01(s * fac[2]);
+      } else {
+        const T hs = h + fac[3];
+        h = with_val(hs, fmodf(val(hs), TWO_PI));  // torch.fmod: sign of the dividend
+      }
+      hsv_to_rgb(h, s, v, r, g, b);
+    }
+  }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void color_jiggle_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ out, int B, long HW,
+                                                           const float* __restrict__ factors,
+                                                           const int* __restrict__ order) {
+  int ord[4] = {order[0], order[1], order[2], order[3]};
+  const long n = (long)B * HW;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x) {
+    const long bi = id / HW, p = id - bi * HW;
+    const long base = bi * 3 * HW + p;
+    const float fac[4] = {factors[bi * 4 + 0], factors[bi * 4 + 1], factors[bi * 4 + 2], factors[bi * 4 + 3]};
+    if (!BWD) {
+      float r = x[base], g = x[base + HW], b = x[base + 2 * HW];
+      jiggle(r, g, b, fac, ord);
+      out[base] = r, out[base + HW] = g, out[base + 2 * HW] = b;
+    } else {
+      D3 r = {x[base], {1.f, 0.f, 0.f}}, g = {x[base + HW], {0.f, 1.f, 0.f}}, b = {x[base + 2 * HW], {0.f, 0.f, 1.f}};
+      jiggle(r, g, b, fac, ord);
+      const float gr = dy[base], gg = dy[base + HW], gb = dy[base + 2 * HW];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) out[base + c * HW] = gr * r.d[c] + gg * g.d[c] + gb * b.d[c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Rotation about the image centre (kornia RandomRotation -> rotate -> warp_affine, bilinear, zeros padding,
+// align_corners=True; noises.py:20-31, utils_eval.py:292).  Positive angle = anti-clockwise (OpenCV convention of
+// get_rotation_matrix2d).  Output pixel (x,y) samples the source at R(x - c) + c.  BWD scatters the adjoint.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ __launch_bounds__(256) void rotate_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C,
+                                                     int H, int W, const float* __restrict__ angle_deg) {
+  const long n = (long)B * C * H * W;
+  const float cx = 0.5f * (W - 1), cy = 0.5f * (H - 1);
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(id % W), y = (int)((id / W) % H);
+    const long bc = id / ((long)W * H);
+    const float th = angle_deg[bc / C] * 0.017453292519943295f;
+    const float cs = cosf(th), sn = sinf(th);
+    const float sx = cs * (x - cx) - sn * (y - cy) + cx, sy = sn * (x - cx) + cs * (y - cy) + cy;
+    const float fx = floorf(sx), fy = floorf(sy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx = sx - fx, wy = sy - fy;
+    const long base = bc * H * W;
+    float acc = 0.f;
+    const float g = BWD ? src[id] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int xx = x0 + i, yy = y0 + j;
+        if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+        const float w = (i ? wx : 1.f - wx) * (j ? wy : 1.f - wy);
+        if (!BWD) acc += w * src[base + (long)yy * W + xx];
+        else atomicAdd(dst + base + (long)yy * W + xx, g * w);
+      }
+    if (!BWD) dst[id] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Sharpness (kornia RandomSharpness -> sharpness(); noises.py:106-119, utils_eval.py:294): blend of the image with a
+// 3x3 smoothed copy ([[1,1,1],[1,5,1],[1,1,1]]/13, valid region only, clamped to [0,1]; the 1-pixel border keeps the
+// input):  out = blur + f * (x - blur), clamped to [0,1] unless 0 < f < 1.
+//   fwd:  dst = out.     bwd pass 0: tmp = (1-f) * g_eff * [interior] * [0 < blur < 1],  dst = f_eff * g_eff
+//                        bwd pass 1: dst += sum_taps w * tmp(neighbours)         (g_eff = dy masked by the final clamp)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float smooth3(const float* p, int W) {
+  return (p[-W - 1] + p[-W] + p[-W + 1] + p[-1] + 5.f * p[0] + p[1] + p[W - 1] + p[W] + p[W + 1]) * (1.f / 13.f);
+}
+
+template <int MODE>  // 0 = forward, 1 = backward pass 0, 2 = backward pass 1
+__global__ __launch_bounds__(256) void sharpness_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        float* __restrict__ dst, float* __restrict__ tmp, int B, int C,
+                                                        int H, int W, const float* __restrict__ factor) {
+  const long n = (long)B * C * H * W;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x) {
+    const int px = (int)(id % W), py = (int)((id / W) % H);
+    const long bc = id / ((long)W * H);
+    const float f = factor[bc / C];
+    const bool interior = px > 0 && px < W - 1 && py > 0 && py < H - 1;
+    if (MODE == 2) {
+      float acc = 0.f;
+      const float* t = tmp + id;
+#pragma unroll
+      for (int j = -1; j <= 1; ++j)
+#pragma unroll
+        for (int i = -1; i <= 1; ++i) {
+          const int xx = px + i, yy = py + j;
+          if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+          acc += ((i == 0 && j == 0) ? 5.f : 1.f) * t[(long)j * W + i];
+        }
+      dst[id] += acc * (1.f / 13.f);
+      continue;
+    }
+    const float xv = x[id];
+    const float raw = interior ? smooth3(x + id, W) : xv;
+    const float blur = interior ? fminf(fmaxf(raw, 0.f), 1.f) : xv;
+    const float res = blur + (xv - blur) * f;
+    const bool clampit = !(f > 0.f && f < 1.f) && f != 0.f && f != 1.f;
+    if (MODE == 0) {
+      dst[id] = f == 0.f ? blur : (f == 1.f ? xv : (clampit ? fminf(fmaxf(res, 0.f), 1.f) : res));
+    } else {
+      float g = dy[id];
+      if (clampit && (res < 0.f || res > 1.f)) g = 0.f;
+      const float fe = f == 0.f ? 0.f : (f == 1.f ? 1.f : f);
+      // border pixels: blur == x, so d(out)/dx = 1
+      dst[id] = interior ? fe * g : g;
+      tmp[id] = (interior && raw > 0.f && raw < 1.f) ? (1.f - fe) * g : 0.f;
+    }
+  }
+}
+
 inline int grid_for(long n) {
   long b = (n + 255) / 256;
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -132,5 +348,49 @@ extern "C" int aql_add_gauss_noise(const float* x, const float* noise, float std
   AQL_CHECK_ARG(x && noise && y, "aql_add_gauss_noise: bad args");
   hipLaunchKernelGGL(add_noise_clamp_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, noise, std, clamp01, n, y);
   AQL_CHECK_LAUNCH("aql_add_gauss_noise");
+  return AQL_OK;
+}
+
+// x, y: [B,3,H,W] fp32 in [0,1]; factors: device [B][4] = {brightness shift, contrast, saturation, hue shift (rad)};
+// order: device int[4], a permutation of {0:brightness, 1:contrast, 2:saturation, 3:hue}.  dy == null: y = jiggle(x);
+// else y receives dx = J(x)^T dy.
+extern "C" int aql_color_jiggle(const float* x, const float* dy, float* y, int B, int H, int W, const float* factors,
+                                const int* order, hipStream_t stream) {
+  AQL_CHECK_ARG(x && y && factors && order && B > 0 && H > 0 && W > 0, "aql_color_jiggle: bad args");
+  const long n = (long)B * H * W;
+  if (dy) hipLaunchKernelGGL(color_jiggle_kernel<true>, dim3(grid_for(n)), dim3(256), 0, stream, x, dy, y, B, (long)H * W, factors, order);
+  else hipLaunchKernelGGL(color_jiggle_kernel<false>, dim3(grid_for(n)), dim3(256), 0, stream, x, dy, y, B, (long)H * W, factors, order);
+  AQL_CHECK_LAUNCH("aql_color_jiggle");
+  return AQL_OK;
+}
+
+// src/dst: [B,C,H,W] fp32; angle_deg: device [B] (anti-clockwise).  backward = 1: src is dy, dst receives dx.
+extern "C" int aql_rotate_bilinear(const float* src, float* dst, int B, int C, int H, int W, const float* angle_deg,
+                                   int backward, hipStream_t stream) {
+  AQL_CHECK_ARG(src && dst && angle_deg && B > 0 && C > 0 && H > 1 && W > 1, "aql_rotate_bilinear: bad args");
+  const long n = (long)B * C * H * W;
+  if (backward) {
+    (void)hipMemsetAsync(dst, 0, n * sizeof(float), stream);
+    hipLaunchKernelGGL(rotate_kernel<true>, dim3(grid_for(n)), dim3(256), 0, stream, src, dst, B, C, H, W, angle_deg);
+  } else {
+    hipLaunchKernelGGL(rotate_kernel<false>, dim3(grid_for(n)), dim3(256), 0, stream, src, dst, B, C, H, W, angle_deg);
+  }
+  AQL_CHECK_LAUNCH("aql_rotate_bilinear");
+  return AQL_OK;
+}
+
+// x: [B,C,H,W] fp32 in [0,1]; factor: device [B].  dy == null: dst = sharpness(x).  Else dst = dx (tmp: B*C*H*W floats).
+extern "C" int aql_sharpness(const float* x, const float* dy, float* dst, float* tmp, int B, int C, int H, int W,
+                             const float* factor, hipStream_t stream) {
+  AQL_CHECK_ARG(x && dst && factor && B > 0 && C > 0 && H > 2 && W > 2 && (dy == nullptr || tmp != nullptr),
+                "aql_sharpness: bad args");
+  const long n = (long)B * C * H * W;
+  if (!dy) {
+    hipLaunchKernelGGL(sharpness_kernel<0>, dim3(grid_for(n)), dim3(256), 0, stream, x, dy, dst, tmp, B, C, H, W, factor);
+  } else {
+    hipLaunchKernelGGL(sharpness_kernel<1>, dim3(grid_for(n)), dim3(256), 0, stream, x, dy, dst, tmp, B, C, H, W, factor);
+    hipLaunchKernelGGL(sharpness_kernel<2>, dim3(grid_for(n)), dim3(256), 0, stream, x, dy, dst, tmp, B, C, H, W, factor);
+  }
+  AQL_CHECK_LAUNCH("aql_sharpness");
   return AQL_OK;
 }

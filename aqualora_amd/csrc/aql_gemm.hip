@@ -98,19 +98,21 @@ void launch_cfg(int cfg, int pd, const GemmArgs<LA, LB>& g, hipStream_t stream) 
       default: launch_gemm<64, 64, 32, 32, LA, LB, EPI>(g, stream); break;
     }
   } else {
-#define AQL_P(BM, BN, WM, WN, PDHI)                                                              \
+// pd: 1/2/4 = register-staged loads, that many K tiles in flight; 12 = LDS-DMA with two stages; 13 = LDS-DMA with as many
+// stages as fit the 160 KB LDS (DEEP), for grids of at most one workgroup per CU
+#define AQL_P(BM, BN, WM, WN, PDHI, DEEP)                                                        \
   if (pd == 12) return launch_gemm_d<BM, BN, WM, WN, LA, LB, EPI, 2>(g, stream);                 \
-  if (pd == 13) return launch_gemm_d<BM, BN, WM, WN, LA, LB, EPI, 3>(g, stream);                 \
+  if (pd == 13) return launch_gemm_d<BM, BN, WM, WN, LA, LB, EPI, DEEP>(g, stream);              \
   if (pd <= 1) return launch_gemm_p<BM, BN, WM, WN, LA, LB, EPI, 1>(g, stream);                  \
   if (pd == 2) return launch_gemm_p<BM, BN, WM, WN, LA, LB, EPI, 2>(g, stream);                  \
   return launch_gemm_p<BM, BN, WM, WN, LA, LB, EPI, PDHI>(g, stream);
     switch (cfg) {
-      case P_128x160: { AQL_P(128, 160, 64, 80, 3) }
-      case P_64x160: { AQL_P(64, 160, 32, 80, 4) }
-      case P_32x160: { AQL_P(32, 160, 16, 80, 4) }
-      case P_128x32: { AQL_P(128, 32, 32, 32, 4) }
-      case P_128x128: { AQL_P(128, 128, 64, 64, 3) }
-      default: { AQL_P(64, 64, 32, 32, 4) }
+      case P_128x160: { AQL_P(128, 160, 64, 80, 3, 4) }
+      case P_64x160: { AQL_P(64, 160, 32, 80, 4, 5) }
+      case P_32x160: { AQL_P(32, 160, 16, 80, 4, 6) }
+      case P_128x32: { AQL_P(128, 32, 32, 32, 4, 6) }
+      case P_128x128: { AQL_P(128, 128, 64, 64, 3, 4) }
+      default: { AQL_P(64, 64, 32, 32, 4, 8) }
     }
 #undef AQL_P
   }
@@ -168,8 +170,7 @@ inline void pick_tile(long M, int N, int kt_total, bool can_split, int* cfg, int
     else *cfg = P_64x64, *tiles = aql_cdiv(M, 64) * aql_cdiv(N, 64);
   }
   if (force == P_64x64) *cfg = P_64x64, *tiles = aql_cdiv(M, 64) * aql_cdiv(N, 64);
-  *pd = 12;  // LDS-DMA, two stages: measured fastest on every shape (hot and cold operands)
-  if (force_pd) *pd = force_pd;
+  *pd = force_pd ? force_pd : 0;  // 0: chosen from the grid size once the split count is known
 }
 
 // Dispatch one bf16-output GEMM over the tile configurations; split-K slabs + finalize when the grid cannot fill
@@ -189,6 +190,9 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
   int splits = 1;
   if (ws != nullptr && o.C2 == nullptr) splits = pick_splits(tiles, kt_total, g.M, g.N, ws_bytes);
   g.splits = splits;
+  // LDS-DMA staging everywhere (measured fastest on every shape, hot or cold operands); a grid of <= 1 workgroup per CU
+  // cannot hide latency with occupancy, so it gets the deep stage ring instead
+  if (pd == 0) pd = (tiles * splits <= 288) ? 13 : 12;
   if (splits > 1) {
     g.epi.Cf = ws;
     g.epi.ldcf = g.N;

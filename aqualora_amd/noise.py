@@ -1,10 +1,13 @@
 """Distortion layers of the watermark pipeline (reference utils/noise_layers/*), HIP-backed.
 
-Built so far: ``Identity`` (identity.py:3-11) and ``JpegCompression`` (jpeg_compression.py:67-162) -- the layer whose
-arithmetic lives in the reference tree itself (DCT-mask JPEG simulation, differentiable, forward AND backward through
-one kernel because the layer is a fixed linear map per 8x8x3 block).  The kornia / torchvision based layers
-(crop-resize, blur, noise, colour jitter) are not built yet (their arithmetic is third-party and
-unpinned here).  Calling convention follows the reference: ``layer([image, cover]) -> [image', cover]`` with NCHW fp32.
+``Identity`` (identity.py:3-11) and ``JpegCompression`` (jpeg_compression.py:67-162) have their arithmetic in the
+reference tree itself and are pinned by golden vectors (DCT-mask JPEG simulation, differentiable, forward AND backward
+through one kernel because the layer is a fixed linear map per 8x8x3 block).  The kornia / torchvision based layers
+(noises.py: CropandResize, GaussianBlur, GaussianNoise, ColorJitter, Rotation, Sharpness; noiser.py:46-71 and
+utils_eval.py:269-301 ``distorsion_unit``) follow the published kornia 0.6.12 / torchvision 0.15.2 behaviour -- those
+packages are not in this image, so their parity is UNPINNED (checked against oracle/distort_oracle.py only).
+Calling convention follows the reference: ``layer([image, cover]) -> [image', cover]`` with NCHW fp32.  Random parameters
+are drawn on the host where the reference draws them; every deterministic image map and its adjoint is a HIP kernel.
 """
 import torch
 import torch.nn as nn
@@ -170,9 +173,203 @@ class GaussianNoise(nn.Module):
         return noised_and_cover
 
 
+def _need_gpu(x, what):
+    if not x.is_cuda:
+        raise L.AqlError(f"{what}: the HIP path needs a GPU tensor; there is no CPU fallback")
+
+
+class _ColorJiggleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, factors, order):
+        x = x.float().contiguous()
+        B, C, H, W = x.shape
+        assert C == 3, "colour jiggle works on RGB images"
+        y = torch.empty_like(x)
+        L.call("aql_color_jiggle", L.ptr(x), None, L.ptr(y), B, H, W, L.ptr(factors), L.ptr(order), L.stream_ptr())
+        ctx.save_for_backward(x, factors, order)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, factors, order = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        B, C, H, W = x.shape
+        dx = torch.empty_like(x)
+        L.call("aql_color_jiggle", L.ptr(x), L.ptr(dy), L.ptr(dx), B, H, W, L.ptr(factors), L.ptr(order), L.stream_ptr())
+        return dx, None, None
+
+
+def color_jiggle(x, brightness, contrast, saturation, hue, order=(0, 1, 2, 3)):
+    """kornia ColorJiggle with explicit parameters: x [B,3,H,W] in [0,1]; brightness/contrast/saturation/hue are [B]
+    factors as kornia samples them (brightness & co. around 1, hue in [-0.5, 0.5] turns); ``order`` is the permutation
+    of (0 brightness, 1 contrast, 2 saturation, 3 hue) kornia draws with randperm."""
+    _need_gpu(x, "color_jiggle")
+    f = torch.stack([torch.as_tensor(brightness, dtype=torch.float32) - 1.0, torch.as_tensor(contrast, dtype=torch.float32),
+                     torch.as_tensor(saturation, dtype=torch.float32),
+                     torch.as_tensor(hue, dtype=torch.float32) * (2.0 * np.pi)], dim=-1).reshape(-1, 4)
+    f = f.expand(x.shape[0], 4).contiguous().to(x.device)
+    o = torch.as_tensor(list(order), dtype=torch.int32, device=x.device)
+    assert sorted(o.tolist()) == [0, 1, 2, 3]
+    return _ColorJiggleFn.apply(x, f, o)
+
+
+def random_color_jiggle(x, brightness, contrast, saturation, hue):
+    """ColorJiggle(brightness=(lo,hi), ..., p=1): per-sample uniform factors, one random op order per call."""
+    B = x.shape[0]
+    u = lambda r: torch.empty(B).uniform_(r[0], r[1])
+    return color_jiggle(x, u(brightness), u(contrast), u(saturation), u(hue), torch.randperm(4).tolist())
+
+
+class _RotateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, angles):
+        x = x.float().contiguous()
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        L.call("aql_rotate_bilinear", L.ptr(x), L.ptr(y), B, C, H, W, L.ptr(angles), 0, L.stream_ptr())
+        ctx.save_for_backward(angles)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (angles,) = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        B, C, H, W = dy.shape
+        dx = torch.empty_like(dy)
+        L.call("aql_rotate_bilinear", L.ptr(dy), L.ptr(dx), B, C, H, W, L.ptr(angles), 1, L.stream_ptr())
+        return dx, None
+
+
+def rotate(x, angle_deg):
+    """kornia rotate(): anti-clockwise by angle_deg ([B] or scalar) about the centre, bilinear, zero padding."""
+    _need_gpu(x, "rotate")
+    a = torch.as_tensor(angle_deg, dtype=torch.float32).reshape(-1).expand(x.shape[0]).contiguous().to(x.device)
+    return _RotateFn.apply(x, a)
+
+
+class _SharpnessFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, factor):
+        x = x.float().contiguous()
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        L.call("aql_sharpness", L.ptr(x), None, L.ptr(y), None, B, C, H, W, L.ptr(factor), L.stream_ptr())
+        ctx.save_for_backward(x, factor)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, factor = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        B, C, H, W = x.shape
+        dx, tmp = torch.empty_like(x), torch.empty_like(x)
+        L.call("aql_sharpness", L.ptr(x), L.ptr(dy), L.ptr(dx), L.ptr(tmp), B, C, H, W, L.ptr(factor), L.stream_ptr())
+        return dx, None
+
+
+def sharpness(x, factor):
+    """kornia sharpness(): x [B,C,H,W] in [0,1], factor [B] or scalar."""
+    _need_gpu(x, "sharpness")
+    f = torch.as_tensor(factor, dtype=torch.float32).reshape(-1).expand(x.shape[0]).contiguous().to(x.device)
+    return _SharpnessFn.apply(x, f)
+
+
+class ColorJitter(nn.Module):
+    """noises.py:88-104: images in [-1,1] -> [0,1] -> ColorJiggle(b .7-1.3, c .8-1.25, s .8-1.25, h +-.2) -> [-1,1]."""
+
+    def forward(self, noised_and_cover):
+        y = random_color_jiggle(noised_and_cover[0] / 2 + 0.5, (0.7, 1.3), (0.8, 1.25), (0.8, 1.25), (-0.2, 0.2))
+        noised_and_cover[0] = y * 2 - 1
+        return noised_and_cover
+
+
+class Rotation(nn.Module):
+    """noises.py:20-31: RandomRotation(degrees) -> angle ~ U(-degrees, degrees) per sample."""
+
+    def __init__(self, degrees=180):
+        super().__init__()
+        self.degrees = degrees
+
+    def forward(self, noised_and_cover):
+        x = noised_and_cover[0]
+        noised_and_cover[0] = rotate(x, torch.empty(x.shape[0]).uniform_(-self.degrees, self.degrees))
+        return noised_and_cover
+
+
+class Sharpness(nn.Module):
+    """noises.py:106-119: strength ~ U(0, max) on the host, then RandomSharpness(strength) -> factor ~ U(0, strength)."""
+
+    def __init__(self, strength=1.0):
+        super().__init__()
+        self.strength_max = strength
+
+    def forward(self, noised_and_cover):
+        x = noised_and_cover[0]
+        strength = np.random.rand() * self.strength_max
+        y = sharpness(x / 2 + 0.5, torch.empty(x.shape[0]).uniform_(0, max(strength, 1e-12)))
+        noised_and_cover[0] = y * 2 - 1
+        return noised_and_cover
+
+
+class Noiser(nn.Module):
+    """noiser.py:12-44: one layer per call, chosen with the given probabilities; layer names as in the reference."""
+
+    def __init__(self, noise_layers, posibilities, device=None):
+        super().__init__()
+        self.noise_layers = [Identity()]
+        for layer in noise_layers:
+            if isinstance(layer, str):
+                if layer == "Identity":
+                    continue
+                elif layer == "Jpeg":
+                    self.noise_layers.append(JpegCompression(device))
+                elif layer == "CropandResize":
+                    self.noise_layers.append(CropandResize((256, 512), (256, 512)))
+                elif layer == "GaussianBlur":
+                    self.noise_layers.append(GaussianBlur(10.0))
+                elif layer == "GaussianNoise":
+                    self.noise_layers.append(GaussianNoise(0.2))
+                elif layer == "ColorJitter":
+                    self.noise_layers.append(ColorJitter())
+                else:
+                    raise ValueError("Wrong layer placeholder string in Noiser.__init__().")
+            else:
+                self.noise_layers.append(layer)
+        self.posibilities = posibilities
+
+    def forward(self, encoded_and_cover, possibilites=None):
+        p = self.posibilities if possibilites is None else possibilites
+        idx = int(np.random.choice(len(self.noise_layers), 1, p=p)[0])
+        return self.noise_layers[idx](encoded_and_cover)
+
+
+def eval_distorsion_unit(encoded_image, type):
+    """evaluation/utils_eval.py:269-301, the tensor-space attacks: 'color_jitter' (.9-1.1, hue +-.1), 'crop' (460x460
+    window -> back to the input size), 'blur' (k=3, sigma 4), 'noise' (std .1, clamp), 'rotation' (15 deg), 'sharpness'
+    (factor ~ U(0,10)).  'jpeg_compress' (PIL codec) and 'SDEdit' (a diffusion pipeline) are outside this library."""
+    x = encoded_image if encoded_image.dim() == 4 else encoded_image[None]
+    if type == "color_jitter":
+        y = random_color_jiggle(x, (0.9, 1.1), (0.9, 1.1), (0.9, 1.1), (-0.1, 0.1))
+    elif type == "crop":
+        H, W = x.shape[2:]
+        top, left = np.random.randint(0, H - 460 + 1), np.random.randint(0, W - 460 + 1)
+        y = crop_resize(x, top, left, 460, 460, H, W)
+    elif type == "blur":
+        y = gaussian_blur(x, 3, 4.0)
+    elif type == "noise":
+        y = add_gaussian_noise(x, 0.1, clamp01=True)
+    elif type == "rotation":
+        y = rotate(x, 15.0)
+    elif type == "sharpness":
+        y = sharpness(x, torch.empty(x.shape[0]).uniform_(0, 10.0))
+    else:
+        raise ValueError("Wrong distorsion type in add_distorsion().")
+    return y if encoded_image.dim() == 4 else y[0]
+
+
 def distorsion_unit(encoded_image, type):
-    """noiser.py:46-71 (rob-finetune): 'crop' (432..512 window -> 512x512), 'blur' (k in 3..5, sigma 4), 'noise'
-    (std 0.1, clamp to [0,1]).  'color_jitter' (kornia ColorJiggle) is not built yet."""
+    """noiser.py:46-71 (rob-finetune): 'color_jitter' (.8-1.2, hue +-.1), 'crop' (432..512 window -> 512x512), 'blur'
+    (k in 3..5, sigma 4), 'noise' (std 0.1, clamp to [0,1])."""
     if type == "crop":
         ch, cw = np.random.randint(432, 512), np.random.randint(432, 512)
         H, W = encoded_image.shape[2:]
@@ -183,5 +380,5 @@ def distorsion_unit(encoded_image, type):
     if type == "noise":
         return add_gaussian_noise(encoded_image, 0.1, clamp01=True)
     if type == "color_jitter":
-        raise NotImplementedError("kornia ColorJiggle is not built yet")
+        return random_color_jiggle(encoded_image, (0.8, 1.2), (0.8, 1.2), (0.8, 1.2), (-0.1, 0.1))
     raise ValueError("Wrong distorsion type.")

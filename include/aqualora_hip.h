@@ -139,6 +139,19 @@ int aql_gauss_blur(const float* src, float* dst, float* tmp, int BC, int H, int 
                    aql_stream_t stream);
 int aql_add_gauss_noise(const float* x, const float* noise, float std, int clamp01, long n, float* y,
                         aql_stream_t stream);
+/* kornia ColorJiggle as called at noises.py:97-103, noiser.py:52-57, utils_eval.py:271-276 (kornia 0.6.12, recalled):
+ * x,y [B,3,H,W] in [0,1]; factors device [B][4] = {brightness-1, contrast, saturation, hue*2pi}; order device int[4]
+ * (permutation of 0 brightness, 1 contrast, 2 saturation, 3 hue).  dy == NULL: y = f(x); else y = J(x)^T dy.          */
+int aql_color_jiggle(const float* x, const float* dy, float* y, int B, int H, int W, const float* factors,
+                     const int* order, aql_stream_t stream);
+/* kornia RandomRotation -> rotate (noises.py:20-31, utils_eval.py:292): bilinear, zeros padding, align_corners=True,
+ * about the image centre; angle_deg device [B], anti-clockwise.  backward=1: src = dy, dst = dx.                       */
+int aql_rotate_bilinear(const float* src, float* dst, int B, int C, int H, int W, const float* angle_deg, int backward,
+                        aql_stream_t stream);
+/* kornia RandomSharpness -> sharpness (noises.py:106-119, utils_eval.py:294): factor device [B].  dy == NULL:
+ * dst = sharpness(x); else dst = dx and tmp is B*C*H*W floats of scratch.                                              */
+int aql_sharpness(const float* x, const float* dy, float* dst, float* tmp, int B, int C, int H, int W,
+                  const float* factor, aql_stream_t stream);
 
 /* ---- SecretDecoder inference (csrc/aql_decoder.hip) ---- utils/models.py:91-96 (torchvision efficientnet_b1, eval mode,
  * BatchNorm folded by the host), fp32 NHWC.                                                                           */

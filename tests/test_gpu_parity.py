@@ -310,6 +310,54 @@ def test_distortion_maps_vs_torch():
     assert out.shape == (1, 3, 512, 512)
 
 
+def test_kornia_style_distortions_vs_oracle():
+    """Colour jiggle (all 4 ops, two orders), centre rotation and sharpness: forward and adjoint vs the torch CPU
+    restatement of kornia 0.6.12 (oracle/distort_oracle.py, parity unpinned: kornia is absent from the image)."""
+    from aqualora_amd import noise as NZ
+    from oracle import distort_oracle as DO
+
+    def frac_bad(a, b, tol):
+        a, b = a.float().cpu(), b.float().cpu()
+        return ((a - b).abs() > tol * (1.0 + b.abs())).float().mean().item()
+
+    x0 = (T("kd.x", (2, 3, 40, 56), 0.35, "cpu") + 0.5).clamp(0, 1)
+    dy = T("kd.dy", (2, 3, 40, 56), device="cpu")
+    for order in ((0, 1, 2, 3), (3, 1, 0, 2)):
+        br, ct, sa, hu = [1.2, 0.75], [0.8, 1.25], [1.25, 0.8], [0.2, -0.15]
+        xr = x0.clone().requires_grad_(True)
+        yr = DO.color_jiggle(xr, br, ct, sa, hu, order)
+        yr.backward(dy)
+        xg = x0.to(DEV).requires_grad_(True)
+        yg = NZ.color_jiggle(xg, br, ct, sa, hu, order)
+        yg.backward(dy.to(DEV))
+        assert frac_bad(yg, yr, 2e-5) == 0.0
+        assert frac_bad(xg.grad, xr.grad, 1e-3) < 2e-3   # kinks (clamps, hue sectors, max/min ties) are measure-zero
+    for ang in ([15.0, -160.0], [90.0, 0.0]):
+        xr = x0.clone().requires_grad_(True)
+        yr = DO.rotate(xr, ang)
+        yr.backward(dy)
+        xg = x0.to(DEV).requires_grad_(True)
+        yg = NZ.rotate(xg, ang)
+        yg.backward(dy.to(DEV))
+        assert frac_bad(yg, yr, 1e-4) < 1e-3 and frac_bad(xg.grad, xr.grad, 1e-4) < 1e-3  # floor() ties at exact angles
+    for fac in ([0.5, 10.0], [0.0, 1.0], [3.0, 0.25]):
+        xr = x0.clone().requires_grad_(True)
+        yr = DO.sharpness(xr, fac)
+        yr.backward(dy)
+        xg = x0.to(DEV).requires_grad_(True)
+        yg = NZ.sharpness(xg, fac)
+        yg.backward(dy.to(DEV))
+        assert frac_bad(yg, yr, 1e-5) == 0.0 and frac_bad(xg.grad, xr.grad, 1e-4) < 1e-3
+    img = (T("kd.img", (1, 3, 512, 512), 0.2, DEV) + 0.5).clamp(0, 1)
+    for kind in ("color_jitter", "crop", "blur", "noise", "rotation", "sharpness"):
+        out = NZ.eval_distorsion_unit(img, kind)
+        assert out.shape == img.shape and torch.isfinite(out).all()
+    assert NZ.distorsion_unit(img, "color_jitter").shape == img.shape
+    nz = NZ.Noiser(["Identity", "Jpeg", "CropandResize", "GaussianBlur", "GaussianNoise", "ColorJitter"], [0, 0, 0, 0, 0, 1.0])
+    out = nz([img * 2 - 1, None])
+    assert out[0].shape == img.shape and out[1] is None
+
+
 def test_captured_step_equals_eager_step():
     """HIP-graph replay (two graphs + exchange) must train exactly like the eager step: same loss trajectory and the
     same parameters after 3 steps (up to fp32 atomic-order noise in the weight gradients)."""
