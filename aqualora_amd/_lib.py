@@ -60,6 +60,17 @@ SIGNATURES = {
     "aql_color_jiggle": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
     "aql_rotate_bilinear": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p],
     "aql_sharpness": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
+    "aql_gemm_f32": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_p, c_l, c_l, c_i, c_l, c_p],
+    "aql_bn_train_fwd": [c_p, c_p, c_p, c_l, c_i, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "aql_bn_train_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
+    "aql_dwconv_train": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
+    "aql_stem_train": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
+    "aql_chan_scale": [c_p, c_p, c_i, c_l, c_i, c_p, c_p],
+    "aql_chan_reduce": [c_p, c_p, c_i, c_l, c_i, c_f, c_p, c_p],
+    "aql_chan_bcast": [c_p, c_i, c_l, c_i, c_f, c_i, c_p, c_p],
+    "aql_act_f32": [c_p, c_p, c_i, c_l, c_p, c_p],
+    "aql_resize_bilinear_nhwc_bwd": [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
+    "aql_bce_logits": [c_p, c_p, c_l, c_p, c_p, c_p],
     "aql_ddim_step": [c_p, c_p, c_p, c_f, c_p, c_l, c_p],
     "aql_sdpa_fwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p, c_p],
     "aql_sdpa_bwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p,

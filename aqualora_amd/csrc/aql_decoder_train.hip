@@ -1,0 +1,647 @@
+// SecretDecoder TRAINING kernels (stage 1: train/latent_wm_pretrain.py:159-225; robustness fine-tune:
+// train/rob_enhance_finetune.py, decoder fwd+bwd at B=16): torchvision efficientnet_b1 in train mode, i.e. BatchNorm
+// with batch statistics, plus the backward of every layer.  fp32 like the reference (the decoder is never cast),
+// channels-last activations [B,H,W,C] == [M,C].  Layers are kept separate (conv | BN+SiLU | SE | ...) because training
+// needs each pre-normalisation tensor for the backward; BN backward recomputes the normalised value instead of storing it.
+#include "aql_common.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoid_(float z) { return 1.f / (1.f + __expf(-z)); }
+__device__ __forceinline__ float silu_(float z) { return z * sigmoid_(z); }
+__device__ __forceinline__ float dsilu_(float z) {
+  const float s = sigmoid_(z);
+  return s * (1.f + z * (1.f - s));
+}
+
+inline int grid_for(long n, int cap = 8192) {
+  long b = (n + 255) / 256;
+  if (b > cap) b = cap;
+  return (int)(b < 1 ? 1 : b);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Generic fp32 GEMM on the exact-fp32 MFMA:  C[m,n] (+)= sum_k A(m,k) * B(n,k) (+ bias[n]),
+//   A(m,k) = A[m*sam + k*sak],  B(n,k) = B[n*sbn + k*sbk]   (either stride may be 1; the loader walks the unit stride)
+// 64x64 tile, K tile 32, 4 wavefronts of 32x32; grid.z splits K and combines with fp32 atomics (C pre-zeroed).
+// Covers the three passes of a 1x1 convolution / linear layer:
+//   forward   Y[M,Co]  = X[M,Ci] . W[Co,Ci]^T     A=X (Ci,1)   B=W (Ci,1)
+//   data      dX[M,Ci] = dY[M,Co] . W[Co,Ci]      A=dY (Co,1)  B=W (1,Ci)
+//   weight    dW[Co,Ci] = dY^T . X   (K = M)      A=dY (1,Co)  B=X (1,Ci)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long sam, long sak,
+                                                       const float* __restrict__ B, long sbn, long sbk,
+                                                       const float* __restrict__ bias, float* __restrict__ C, long ldc,
+                                                       long M, int N, long K, int splits) {
+  __shared__ float sA[64][33], sB[64][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long m0 = (long)blockIdx.x * 64;
+  const int n0 = blockIdx.y * 64;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const long kt = (K + 31) / 32;
+  const long k_begin = (kt * blockIdx.z / splits) * 32, k_end = min(K, (kt * (blockIdx.z + 1) / splits) * 32);
+  f32x16_t acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (long k0 = k_begin; k0 < k_end; k0 += 32) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int id = tid + it * 256;
+      int r, c;
+      if (sak == 1) r = id >> 5, c = id & 31; else c = id >> 6, r = id & 63;
+      const long m = m0 + r, k = k0 + c;
+      sA[r][c] = (m < M && k < k_end) ? A[m * sam + k * sak] : 0.f;
+      if (sbk == 1) r = id >> 5, c = id & 31; else c = id >> 6, r = id & 63;
+      const long kb = k0 + c;
+      sB[r][c] = (n0 + r < N && kb < k_end) ? B[(long)(n0 + r) * sbn + kb * sbk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 2) {
+      const float a = sB[wn + (lane & 31)][kk + (lane >> 5)];   // MFMA operand A rows = output columns n
+      const float bq = sA[wm + (lane & 31)][kk + (lane >> 5)];  // MFMA operand B cols = output rows m
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const long m = m0 + wm + (lane & 31);
+  if (m >= M) return;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int n = n0 + wn + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+    if (n >= N) continue;
+    float v = acc[e];
+    if (bias != nullptr && blockIdx.z == 0) v += bias[n];
+    if (splits > 1) atomicAdd(C + m * ldc + n, v);
+    else C[m * ldc + n] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// BatchNorm2d, training mode, on [M,C] with optional fused SiLU.
+//   stats:    per-(row-chunk, channel) partial sums  ->  finalize (double): mean, invstd, running stats
+//   apply:    y = act(gamma * (x - mean) * invstd + beta)
+//   backward: z recomputed; dz = dy * act'(z);  dgamma = sum dz*xhat, dbeta = sum dz,
+//             dx = gamma*invstd * (dz - dbeta/M - xhat*dgamma/M)
+// A workgroup covers 64 channels x 4 row lanes; deterministic (no atomics).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int BN_ROWS = 2048;  // rows per partial chunk
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         int act, long M, int C, float* __restrict__ p0,
+                                                         float* __restrict__ p1) {
+  __shared__ float r0[4][64], r1[4][64];
+  const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  const long m_begin = (long)blockIdx.x * BN_ROWS, m_end = min(M, m_begin + BN_ROWS);
+  float a0 = 0.f, a1 = 0.f;
+  if (c < C) {
+    float mu = 0.f, is = 0.f, g = 0.f, bt = 0.f;
+    if (BWD) mu = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
+    for (long m = m_begin + part; m < m_end; m += 4) {
+      const float xv = x[m * C + c];
+      if (!BWD) {
+        a0 += xv;
+        a1 += xv * xv;
+      } else {
+        const float xh = (xv - mu) * is;
+        float dz = dy[m * C + c];
+        if (act) dz *= dsilu_(g * xh + bt);
+        a0 += dz;
+        a1 += dz * xh;
+      }
+    }
+  }
+  r0[part][cl] = a0;
+  r1[part][cl] = a1;
+  __syncthreads();
+  if (part == 0 && c < C) {
+    p0[(long)blockIdx.x * C + c] = (r0[0][cl] + r0[1][cl]) + (r0[2][cl] + r0[3][cl]);
+    p1[(long)blockIdx.x * C + c] = (r1[0][cl] + r1[1][cl]) + (r1[2][cl] + r1[3][cl]);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
+                                                              int nchunk, long M, int C, float eps, float momentum,
+                                                              float* __restrict__ mean, float* __restrict__ invstd,
+                                                              float* __restrict__ run_mean, float* __restrict__ run_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int i = 0; i < nchunk; ++i) s += p0[(long)i * C + c], q += p1[(long)i * C + c];
+  const double mu = s / (double)M;
+  double var = q / (double)M - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (run_mean != nullptr) {
+    const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mu;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
+                                                              int nchunk, int C, float* __restrict__ dbeta,
+                                                              float* __restrict__ dgamma) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int i = 0; i < nchunk; ++i) s += p0[(long)i * C + c], q += p1[(long)i * C + c];
+  dbeta[c] = (float)s;
+  dgamma[c] = (float)q;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ dbeta, const float* __restrict__ dgamma,
+                                                       int act, long M, int C, float* __restrict__ out) {
+  const long n = M * (C / 4);
+  const float invM = 1.f / (float)M;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(id % (C / 4)) * 4;
+    const long off = (id / (C / 4)) * C + c;
+    const float4 xv = *reinterpret_cast<const float4*>(x + off);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c), bt = *reinterpret_cast<const float4*>(beta + c);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, mus[4] = {mu.x, mu.y, mu.z, mu.w}, iss[4] = {is.x, is.y, is.z, is.w};
+    const float gs[4] = {g.x, g.y, g.z, g.w}, bs[4] = {bt.x, bt.y, bt.z, bt.w};
+    float o[4];
+    if (!BWD) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float z = gs[i] * (xs[i] - mus[i]) * iss[i] + bs[i];
+        o[i] = act ? silu_(z) : z;
+      }
+    } else {
+      const float4 dv = *reinterpret_cast<const float4*>(dy + off);
+      const float4 db = *reinterpret_cast<const float4*>(dbeta + c), dg = *reinterpret_cast<const float4*>(dgamma + c);
+      const float ds[4] = {dv.x, dv.y, dv.z, dv.w}, dbs[4] = {db.x, db.y, db.z, db.w}, dgs[4] = {dg.x, dg.y, dg.z, dg.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float xh = (xs[i] - mus[i]) * iss[i];
+        float dz = ds[i];
+        if (act) dz *= dsilu_(gs[i] * xh + bs[i]);
+        o[i] = gs[i] * iss[i] * (dz - dbs[i] * invM - xh * dgs[i] * invM);
+      }
+    }
+    *reinterpret_cast<float4*>(out + off) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// depthwise k x k conv (k = 3|5, stride 1|2, pad k/2), NHWC, w packed [k*k][C].  MODE 0: y = conv(x);  MODE 1: dx =
+// adjoint(dy) (gather form: for every input pixel, the outputs that read it).
+// ------------------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ src, const float* __restrict__ w, int B, int H,
+                                                 int W, int C, int k, int stride, float* __restrict__ dst) {
+  const int pad = k / 2;
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const int c4n = C / 4;
+  const int Hd = MODE == 0 ? Ho : H, Wd = MODE == 0 ? Wo : W;  // extent of dst
+  const long n = (long)B * Hd * Wd * c4n;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(id % c4n) * 4;
+    long p = id / c4n;
+    const int xd = (int)(p % Wd);
+    p /= Wd;
+    const int yd = (int)(p % Hd);
+    const int b = (int)(p / Hd);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kh = 0; kh < k; ++kh) {
+      int ys;
+      if (MODE == 0) {
+        ys = yd * stride + kh - pad;
+        if (ys < 0 || ys >= H) continue;
+      } else {  // yd = yo*stride + kh - pad  ->  yo = (yd + pad - kh) / stride
+        const int t = yd + pad - kh;
+        if (t < 0 || t % stride != 0) continue;
+        ys = t / stride;
+        if (ys >= Ho) continue;
+      }
+      for (int kw = 0; kw < k; ++kw) {
+        int xs;
+        if (MODE == 0) {
+          xs = xd * stride + kw - pad;
+          if (xs < 0 || xs >= W) continue;
+        } else {
+          const int t = xd + pad - kw;
+          if (t < 0 || t % stride != 0) continue;
+          xs = t / stride;
+          if (xs >= Wo) continue;
+        }
+        const int Hs = MODE == 0 ? H : Ho, Ws = MODE == 0 ? W : Wo;
+        const float4 v = *reinterpret_cast<const float4*>(src + (((long)b * Hs + ys) * Ws + xs) * C + c);
+        const float4 ww = *reinterpret_cast<const float4*>(w + (long)(kh * k + kw) * C + c);
+        acc.x += v.x * ww.x;
+        acc.y += v.y * ww.y;
+        acc.z += v.z * ww.z;
+        acc.w += v.w * ww.w;
+      }
+    }
+    *reinterpret_cast<float4*>(dst + (((long)b * Hd + yd) * Wd + xd) * C + c) = acc;
+  }
+}
+
+// dw[tap][c] += sum_{b,yo,xo} dy[b,yo,xo,c] * x[b, yo*s+kh-pad, xo*s+kw-pad, c]; a workgroup = 64 channels x 4 lanes over a
+// chunk of output pixels, all k*k taps; one atomicAdd per (workgroup, tap, channel)
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B,
+                                                       int H, int W, int C, int k, int stride, int chunk,
+                                                       float* __restrict__ dw) {
+  __shared__ float red[4][64];
+  const int pad = k / 2;
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  const long P = (long)B * Ho * Wo;
+  const long p_begin = (long)blockIdx.x * chunk, p_end = min(P, p_begin + chunk);
+  for (int tap = 0; tap < k * k; ++tap) {
+    const int kh = tap / k, kw = tap - kh * k;
+    float acc = 0.f;
+    if (c < C)
+      for (long p = p_begin + part; p < p_end; p += 4) {
+        const int xo = (int)(p % Wo), yo = (int)((p / Wo) % Ho);
+        const long b = p / ((long)Wo * Ho);
+        const int yi = yo * stride + kh - pad, xi = xo * stride + kw - pad;
+        if (yi < 0 || yi >= H || xi < 0 || xi >= W) continue;
+        acc += dy[p * C + c] * x[((b * H + yi) * W + xi) * C + c];
+      }
+    red[part][cl] = acc;
+    __syncthreads();
+    if (part == 0 && c < C) atomicAdd(dw + (long)tap * C + c, (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// stem 3x3 stride-2 pad-1 conv 3 -> Cout, NHWC, w packed [27][Cout] (tap-major (kh,kw,ci)).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, int B,
+                                                       int H, int W, int Cout, float* __restrict__ y) {
+  __shared__ float sw[27 * 64];
+  for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) sw[i] = w[i];
+  __syncthreads();
+  const int Ho = H / 2, Wo = W / 2;
+  const long n = (long)B * Ho * Wo * (Cout / 4);
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(id % (Cout / 4)) * 4;
+    long p = id / (Cout / 4);
+    const int xo = (int)(p % Wo);
+    p /= Wo;
+    const int yo = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int kh = 0; kh < 3; ++kh) {
+      const int yi = yo * 2 + kh - 1;
+      if (yi < 0 || yi >= H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int xi = xo * 2 + kw - 1;
+        if (xi < 0 || xi >= W) continue;
+        const float* px = x + (((long)b * H + yi) * W + xi) * 3;
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+          const float v = px[ci];
+          const float* ww = sw + ((kh * 3 + kw) * 3 + ci) * Cout + c4;
+          a0 += v * ww[0], a1 += v * ww[1], a2 += v * ww[2], a3 += v * ww[3];
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(y + (((long)b * Ho + yo) * Wo + xo) * Cout + c4) = make_float4(a0, a1, a2, a3);
+  }
+}
+
+// dx[b,yi,xi,ci] = sum over outputs (yo,xo) reading it, over co: dy[b,yo,xo,co] * w[(kh,kw,ci)][co]
+__global__ __launch_bounds__(256) void stem_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                            int B, int H, int W, int Cout, float* __restrict__ dx) {
+  __shared__ float sw[27 * 64];
+  for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) sw[i] = w[i];
+  __syncthreads();
+  const int Ho = H / 2, Wo = W / 2;
+  const long n = (long)B * H * W;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x) {
+    const int xi = (int)(id % W), yi = (int)((id / W) % H);
+    const long b = id / ((long)W * H);
+    float a[3] = {0.f, 0.f, 0.f};
+    for (int kh = 0; kh < 3; ++kh) {
+      const int t = yi + 1 - kh;
+      if (t < 0 || (t & 1)) continue;
+      const int yo = t >> 1;
+      if (yo >= Ho) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int u = xi + 1 - kw;
+        if (u < 0 || (u & 1)) continue;
+        const int xo = u >> 1;
+        if (xo >= Wo) continue;
+        const float* g = dy + ((b * Ho + yo) * Wo + xo) * Cout;
+        const float* ww = sw + (kh * 3 + kw) * 3 * Cout;
+        for (int co = 0; co < Cout; ++co) {
+          const float gv = g[co];
+          a[0] += gv * ww[co], a[1] += gv * ww[Cout + co], a[2] += gv * ww[2 * Cout + co];
+        }
+      }
+    }
+    dx[id * 3 + 0] = a[0], dx[id * 3 + 1] = a[1], dx[id * 3 + 2] = a[2];
+  }
+}
+
+// dw[(kh,kw,ci)][co] += sum_p dy[p,co] * x[..]; workgroup = Cout (<=64) channels x 4 lanes over a chunk of output pixels
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B,
+                                                         int H, int W, int Cout, int chunk, float* __restrict__ dw) {
+  __shared__ float red[4][64];
+  const int Ho = H / 2, Wo = W / 2;
+  const int co = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const long P = (long)B * Ho * Wo;
+  const long p_begin = (long)blockIdx.x * chunk, p_end = min(P, p_begin + chunk);
+  for (int tap = 0; tap < 27; ++tap) {
+    const int ci = tap % 3, kw = (tap / 3) % 3, kh = tap / 9;
+    float acc = 0.f;
+    if (co < Cout)
+      for (long p = p_begin + part; p < p_end; p += 4) {
+        const int xo = (int)(p % Wo), yo = (int)((p / Wo) % Ho);
+        const long b = p / ((long)Wo * Ho);
+        const int yi = yo * 2 + kh - 1, xi = xo * 2 + kw - 1;
+        if (yi < 0 || yi >= H || xi < 0 || xi >= W) continue;
+        acc += dy[p * Cout + co] * x[((b * H + yi) * W + xi) * 3 + ci];
+      }
+    red[part][co] = acc;
+    __syncthreads();
+    if (part == 0 && co < Cout) atomicAdd(dw + (long)tap * Cout + co, (red[0][co] + red[1][co]) + (red[2][co] + red[3][co]));
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// squeeze-excite plumbing and small elementwise pieces
+// ------------------------------------------------------------------------------------------------------------------
+// y[b,p,c] = x[b,p,c] * g[b,c]   (also the backward dx = dy * g)
+__global__ __launch_bounds__(256) void chan_scale_kernel(const float* __restrict__ x, const float* __restrict__ g, long HW,
+                                                         int C, long n4, float* __restrict__ y) {
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n4; id += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(id % (C / 4)) * 4;
+    const long row = id / (C / 4);
+    const long b = row / HW;
+    const float4 v = *reinterpret_cast<const float4*>(x + row * C + c);
+    const float4 s = *reinterpret_cast<const float4*>(g + b * C + c);
+    *reinterpret_cast<float4*>(y + row * C + c) = make_float4(v.x * s.x, v.y * s.y, v.z * s.z, v.w * s.w);
+  }
+}
+
+// out[b,c] = scale * sum_p a[b,p,c] * (bmul ? bmul[b,p,c] : 1)   (avgpool forward: scale = 1/HW; gate gradient: a=dy, bmul=x)
+__global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restrict__ a, const float* __restrict__ bmul,
+                                                          long HW, int C, float scale, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < C)
+    for (long p = part; p < HW; p += 4) {
+      const long o = ((long)b * HW + p) * C + c;
+      acc += bmul ? a[o] * bmul[o] : a[o];
+    }
+  red[part][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (part == 0 && c < C) {
+    const int l = threadIdx.x;
+    out[(long)b * C + c] = ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) * scale;
+  }
+}
+
+// dx[b,p,c] (+)= g[b,c] * scale   (avgpool backward: scale = 1/HW); accumulate adds onto an existing dx
+__global__ __launch_bounds__(256) void chan_bcast_kernel(const float* __restrict__ g, long HW, int C, float scale,
+                                                         int accumulate, long n4, float* __restrict__ dx) {
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n4; id += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(id % (C / 4)) * 4;
+    const long row = id / (C / 4);
+    const long b = row / HW;
+    const float4 s = *reinterpret_cast<const float4*>(g + b * C + c);
+    float4 v = make_float4(s.x * scale, s.y * scale, s.z * scale, s.w * scale);
+    if (accumulate) {
+      const float4 o = *reinterpret_cast<const float4*>(dx + row * C + c);
+      v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
+    }
+    *reinterpret_cast<float4*>(dx + row * C + c) = v;
+  }
+}
+
+// small-tensor activation: kind 1 = SiLU, 2 = sigmoid.  fwd: y = act(x).  bwd: y = dy * act'(x)
+__global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ x, const float* __restrict__ dy, int kind,
+                                                  long n, float* __restrict__ y) {
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x) {
+    const float z = x[id];
+    if (dy == nullptr) y[id] = kind == 1 ? silu_(z) : sigmoid_(z);
+    else {
+      const float s = sigmoid_(z);
+      y[id] = dy[id] * (kind == 1 ? s * (1.f + z * (1.f - s)) : s * (1.f - s));
+    }
+  }
+}
+
+// adjoint of resize_bilinear NCHW -> NHWC: dx[b,c,y,x] += w * dy[b,yo,xo,c]   (dx pre-zeroed)
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict__ dy, int B, int C, int H, int W, int Ho,
+                                                         int Wo, float* __restrict__ dx) {
+  const long n = (long)B * Ho * Wo;
+  const float sh = (float)H / Ho, sw = (float)W / Wo;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x) {
+    const int xo = (int)(id % Wo), yo = (int)((id / Wo) % Ho);
+    const int b = (int)(id / ((long)Wo * Ho));
+    const float fy = fmaxf((yo + 0.5f) * sh - 0.5f, 0.f), fx = fmaxf((xo + 0.5f) * sw - 0.5f, 0.f);
+    const int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float wy = fy - y0, wx = fx - x0;
+    for (int c = 0; c < C; ++c) {
+      const float g = dy[id * C + c];
+      float* p = dx + ((long)b * C + c) * H * W;
+      atomicAdd(p + (long)y0 * W + x0, g * (1.f - wy) * (1.f - wx));
+      atomicAdd(p + (long)y0 * W + x1, g * (1.f - wy) * wx);
+      atomicAdd(p + (long)y1 * W + x0, g * wy * (1.f - wx));
+      atomicAdd(p + (long)y1 * W + x1, g * wy * wx);
+    }
+  }
+}
+
+// F.binary_cross_entropy_with_logits(logits, target) (mean) and its gradient (latent_wm_pretrain.py:196)
+__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ z, const float* __restrict__ t, long n,
+                                                  float* __restrict__ loss, float* __restrict__ dz) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x) {
+    const float x = z[id], y = t[id];
+    acc += fmaxf(x, 0.f) - x * y + log1pf(__expf(-fabsf(x)));
+    if (dz != nullptr) dz[id] = (sigmoid_(x) - y) / (float)n;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, ((red[0] + red[1]) + (red[2] + red[3])) / (float)n);
+}
+
+}  // namespace
+
+extern "C" int aql_gemm_f32(const float* A, long sam, long sak, const float* B, long sbn, long sbk, const float* bias,
+                            float* C, long ldc, long M, int N, long K, hipStream_t stream) {
+  AQL_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && (sam == 1 || sak == 1) && (sbn == 1 || sbk == 1),
+                "aql_gemm_f32: bad args (one stride of each operand must be 1)");
+  const long tiles = ((M + 63) / 64) * ((N + 63) / 64);
+  int splits = 1;
+  if (tiles < 256 && K >= 2048) {
+    splits = (int)((512 + tiles - 1) / tiles);
+    const long kt = (K + 31) / 32;
+    if (splits > kt / 8) splits = (int)(kt / 8);
+    if (splits > 256) splits = 256;
+    if (splits < 1) splits = 1;
+  }
+  if (splits > 1) {
+    if (ldc == N) (void)hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), stream);
+    else (void)hipMemset2DAsync(C, ldc * sizeof(float), 0, N * sizeof(float), M, stream);
+  }
+  hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)((M + 63) / 64), (N + 63) / 64, splits), dim3(256), 0, stream, A, sam,
+                     sak, B, sbn, sbk, bias, C, ldc, M, N, K, splits);
+  AQL_CHECK_LAUNCH("aql_gemm_f32");
+  return AQL_OK;
+}
+
+extern "C" long aql_bn_scratch_floats(long M, int C) { return 2 * ((M + BN_ROWS - 1) / BN_ROWS) * (long)C; }
+
+// y = act(BN_train(x)); writes mean/invstd [C] for the backward and updates the running statistics (may be null)
+extern "C" int aql_bn_train_fwd(const float* x, const float* gamma, const float* beta, long M, int C, float eps,
+                                float momentum, int act, float* y, float* mean, float* invstd, float* run_mean,
+                                float* run_var, float* scratch, hipStream_t stream) {
+  AQL_CHECK_ARG(x && gamma && beta && y && mean && invstd && scratch && M > 0 && C % 4 == 0, "aql_bn_train_fwd: bad args");
+  const int nchunk = (int)((M + BN_ROWS - 1) / BN_ROWS);
+  float* p0 = scratch;
+  float* p1 = scratch + (long)nchunk * C;
+  hipLaunchKernelGGL(bn_partial_kernel<false>, dim3(nchunk, (C + 63) / 64), dim3(256), 0, stream, x, nullptr, nullptr,
+                     nullptr, nullptr, nullptr, 0, M, C, p0, p1);
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, p0, p1, nchunk, M, C, eps,
+                     momentum, mean, invstd, run_mean, run_var);
+  hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(grid_for(M * (C / 4))), dim3(256), 0, stream, x, nullptr, mean, invstd,
+                     gamma, beta, nullptr, nullptr, act, M, C, y);
+  AQL_CHECK_LAUNCH("aql_bn_train_fwd");
+  return AQL_OK;
+}
+
+extern "C" int aql_bn_train_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean,
+                                const float* invstd, long M, int C, int act, float* dx, float* dgamma, float* dbeta,
+                                float* scratch, hipStream_t stream) {
+  AQL_CHECK_ARG(x && dy && gamma && beta && mean && invstd && dx && dgamma && dbeta && scratch && C % 4 == 0,
+                "aql_bn_train_bwd: bad args");
+  const int nchunk = (int)((M + BN_ROWS - 1) / BN_ROWS);
+  float* p0 = scratch;
+  float* p1 = scratch + (long)nchunk * C;
+  hipLaunchKernelGGL(bn_partial_kernel<true>, dim3(nchunk, (C + 63) / 64), dim3(256), 0, stream, x, dy, mean, invstd,
+                     gamma, beta, act, M, C, p0, p1);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, p0, p1, nchunk, C, dbeta,
+                     dgamma);
+  hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(grid_for(M * (C / 4))), dim3(256), 0, stream, x, dy, mean, invstd, gamma,
+                     beta, dbeta, dgamma, act, M, C, dx);
+  AQL_CHECK_LAUNCH("aql_bn_train_bwd");
+  return AQL_OK;
+}
+
+// mode 0: y = dwconv(x) [B,Ho,Wo,C];  mode 1: src = dy [B,Ho,Wo,C] -> dst = dx [B,H,W,C];  mode 2: dst = dw [k*k][C]
+// (+= : zeroed here) from src = x and src2 = dy
+extern "C" int aql_dwconv_train(const float* src, const float* src2, const float* w, int B, int H, int W, int C, int k,
+                                int stride, int mode, float* dst, hipStream_t stream) {
+  AQL_CHECK_ARG(src && dst && C % 4 == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2) && mode >= 0 && mode <= 2 &&
+                    (mode == 2 ? src2 != nullptr : w != nullptr),
+                "aql_dwconv_train: bad args");
+  const int Ho = (H + 2 * (k / 2) - k) / stride + 1, Wo = (W + 2 * (k / 2) - k) / stride + 1;
+  if (mode == 0) {
+    hipLaunchKernelGGL(dw_kernel<0>, dim3(grid_for((long)B * Ho * Wo * (C / 4))), dim3(256), 0, stream, src, w, B, H, W, C,
+                       k, stride, dst);
+  } else if (mode == 1) {
+    hipLaunchKernelGGL(dw_kernel<1>, dim3(grid_for((long)B * H * W * (C / 4))), dim3(256), 0, stream, src, w, B, H, W, C, k,
+                       stride, dst);
+  } else {
+    (void)hipMemsetAsync(dst, 0, (size_t)k * k * C * sizeof(float), stream);
+    const long P = (long)B * Ho * Wo;
+    const int chunk = 1024;
+    hipLaunchKernelGGL(dw_wgrad_kernel, dim3((unsigned)((P + chunk - 1) / chunk), (C + 63) / 64), dim3(256), 0, stream,
+                       src, src2, B, H, W, C, k, stride, chunk, dst);
+  }
+  AQL_CHECK_LAUNCH("aql_dwconv_train");
+  return AQL_OK;
+}
+
+// mode 0: y = stem(x) ([B,H,W,3] -> [B,H/2,W/2,Cout]);  mode 1: src = dy -> dst = dx [B,H,W,3];  mode 2: dst = dw [27][Cout]
+extern "C" int aql_stem_train(const float* src, const float* src2, const float* w, int B, int H, int W, int Cout, int mode,
+                              float* dst, hipStream_t stream) {
+  AQL_CHECK_ARG(src && dst && Cout % 4 == 0 && Cout <= 64 && H % 2 == 0 && W % 2 == 0 && mode >= 0 && mode <= 2 &&
+                    (mode == 2 ? src2 != nullptr : w != nullptr),
+                "aql_stem_train: bad args");
+  const long P = (long)B * (H / 2) * (W / 2);
+  if (mode == 0) {
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3(grid_for(P * (Cout / 4))), dim3(256), 0, stream, src, w, B, H, W, Cout, dst);
+  } else if (mode == 1) {
+    hipLaunchKernelGGL(stem_bwd_data_kernel, dim3(grid_for((long)B * H * W)), dim3(256), 0, stream, src, w, B, H, W, Cout,
+                       dst);
+  } else {
+    (void)hipMemsetAsync(dst, 0, (size_t)27 * Cout * sizeof(float), stream);
+    const int chunk = 2048;
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)((P + chunk - 1) / chunk)), dim3(256), 0, stream, src, src2, B, H,
+                       W, Cout, chunk, dst);
+  }
+  AQL_CHECK_LAUNCH("aql_stem_train");
+  return AQL_OK;
+}
+
+// y[b,p,c] = x[b,p,c] * g[b,c]
+extern "C" int aql_chan_scale(const float* x, const float* g, int B, long HW, int C, float* y, hipStream_t stream) {
+  AQL_CHECK_ARG(x && g && y && C % 4 == 0, "aql_chan_scale: bad args");
+  const long n4 = (long)B * HW * (C / 4);
+  hipLaunchKernelGGL(chan_scale_kernel, dim3(grid_for(n4)), dim3(256), 0, stream, x, g, HW, C, n4, y);
+  AQL_CHECK_LAUNCH("aql_chan_scale");
+  return AQL_OK;
+}
+
+// out[b,c] = scale * sum_p a[b,p,c] * (bmul ? bmul[b,p,c] : 1)
+extern "C" int aql_chan_reduce(const float* a, const float* bmul, int B, long HW, int C, float scale, float* out,
+                               hipStream_t stream) {
+  AQL_CHECK_ARG(a && out, "aql_chan_reduce: bad args");
+  hipLaunchKernelGGL(chan_reduce_kernel, dim3((C + 63) / 64, B), dim3(256), 0, stream, a, bmul, HW, C, scale, out);
+  AQL_CHECK_LAUNCH("aql_chan_reduce");
+  return AQL_OK;
+}
+
+// dx[b,p,c] (+)= g[b,c] * scale
+extern "C" int aql_chan_bcast(const float* g, int B, long HW, int C, float scale, int accumulate, float* dx,
+                              hipStream_t stream) {
+  AQL_CHECK_ARG(g && dx && C % 4 == 0, "aql_chan_bcast: bad args");
+  const long n4 = (long)B * HW * (C / 4);
+  hipLaunchKernelGGL(chan_bcast_kernel, dim3(grid_for(n4)), dim3(256), 0, stream, g, HW, C, scale, accumulate, n4, dx);
+  AQL_CHECK_LAUNCH("aql_chan_bcast");
+  return AQL_OK;
+}
+
+// kind 1 = SiLU, 2 = sigmoid; dy == null: y = act(x); else y = dy * act'(x)
+extern "C" int aql_act_f32(const float* x, const float* dy, int kind, long n, float* y, hipStream_t stream) {
+  AQL_CHECK_ARG(x && y && (kind == 1 || kind == 2), "aql_act_f32: bad args");
+  hipLaunchKernelGGL(act_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, dy, kind, n, y);
+  AQL_CHECK_LAUNCH("aql_act_f32");
+  return AQL_OK;
+}
+
+// dx [B,C,H,W] = adjoint of the bilinear resize to [B,Ho,Wo,C] applied to dy
+extern "C" int aql_resize_bilinear_nhwc_bwd(const float* dy, int B, int C, int H, int W, int Ho, int Wo, float* dx,
+                                            hipStream_t stream) {
+  AQL_CHECK_ARG(dy && dx && B > 0 && C > 0, "aql_resize_bilinear_nhwc_bwd: bad args");
+  (void)hipMemsetAsync(dx, 0, (size_t)B * C * H * W * sizeof(float), stream);
+  hipLaunchKernelGGL(resize_bwd_kernel, dim3(grid_for((long)B * Ho * Wo)), dim3(256), 0, stream, dy, B, C, H, W, Ho, Wo, dx);
+  AQL_CHECK_LAUNCH("aql_resize_bilinear_nhwc_bwd");
+  return AQL_OK;
+}
+
+// loss (device scalar, overwritten) = mean BCE-with-logits; dlogits (may be null) = d loss / d logits
+extern "C" int aql_bce_logits(const float* logits, const float* target, long n, float* loss, float* dlogits,
+                              hipStream_t stream) {
+  AQL_CHECK_ARG(logits && target && loss && n > 0, "aql_bce_logits: bad args");
+  (void)hipMemsetAsync(loss, 0, sizeof(float), stream);
+  hipLaunchKernelGGL(bce_kernel, dim3(grid_for(n, 64)), dim3(256), 0, stream, logits, target, n, loss, dlogits);
+  AQL_CHECK_LAUNCH("aql_bce_logits");
+  return AQL_OK;
+}

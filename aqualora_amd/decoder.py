@@ -9,8 +9,11 @@ state-dict key names as ``msgdecoder.pt`` (``model.features.*``, ``model.classif
 torchvision itself: HIP is checked against oracle/decoder_oracle.py, a CPU restatement of the same
 public architecture.
 
-Inference (eval mode: BN running stats, no dropout / stochastic depth) runs in the fp32 HIP kernels of
-csrc/aql_decoder.hip.  Training mode (stage 1 / rob-finetune) is not built yet and raises.
+Inference (eval mode: BN running stats, no dropout / stochastic depth) runs in the fused fp32 HIP kernels of
+csrc/aql_decoder.hip with BatchNorm folded into the convolutions.  Training mode (``.train()``: stage 1,
+latent_wm_pretrain.py:159-225, and the robustness fine-tune) runs layer by layer through csrc/aql_decoder_train.hip --
+BatchNorm with batch statistics and running-stat updates, stochastic depth (torchvision "row" mode, p = 0.2*i/23),
+dropout 0.2 -- with every backward in HIP; torch only adds the residual branches and owns the parameters.
 """
 import torch
 import torch.nn as nn
@@ -114,16 +117,73 @@ class SecretDecoder(nn.Module):
         return P
 
     def train(self, mode=True):
-        if mode:
-            raise NotImplementedError("SecretDecoder training (BN batch statistics, backward) is not built yet; "
-                                      "inference only (call .eval())")
-        return super().train(False)
+        self._packed = None  # folded inference weights go stale as soon as the parameters may move
+        return super().train(mode)
 
     # ---------------------------------------------------------------------------------------- forward
-    @torch.no_grad()
-    def forward(self, x):
+    def forward(self, x, sd_noise=None, drop_mask=None):
         if not x.is_cuda:
             raise L.AqlError("SecretDecoder: the HIP path needs GPU tensors; there is no CPU fallback")
+        if self.training:
+            return self.forward_train(x, sd_noise, drop_mask)
+        with torch.no_grad():
+            return self._forward_eval(x)
+
+    def forward_train(self, x, sd_noise=None, drop_mask=None):
+        """train()-mode forward with autograd.  ``sd_noise`` ([n_blocks][B] survival factors, already divided by the
+        survival probability) and ``drop_mask`` ([B,1280], already divided by 0.8) override the random draws (tests)."""
+        m = self.model
+        B = x.shape[0]
+        h = _ResizeFn.apply(x.float().contiguous(), 512, 512)            # [B,512,512,3] NHWC
+        h = _StemFn.apply(h, m.features[0][0].weight)                     # [B,256,256,32]
+        h = _bn_act(h, m.features[0][1], True)
+        nblk = sum(len(stage) for stage in list(m.features)[1:-1])
+        bi = 0
+        for stage in list(m.features)[1:-1]:
+            for blk in stage:
+                t, k, s, cin, cout = blk.cfg
+                lay = list(blk.block)
+                inp = h
+                i = 0
+                if t != 1:
+                    h = _conv1x1(h, lay[0][0].weight, None)
+                    h = _bn_act(h, lay[0][1], True)
+                    i = 1
+                h = _DwConvFn.apply(h, lay[i][0].weight, k, s)
+                h = _bn_act(h, lay[i][1], True)
+                se = lay[i + 1]
+                Bq, Hc, Wc, C = h.shape
+                pooled = _ChanReduceFn.apply(h.view(Bq, Hc * Wc, C))      # [B,C] mean
+                g = _conv1x1(pooled, se.fc1.weight, se.fc1.bias)
+                g = _ActFn.apply(g, 1)
+                g = _conv1x1(g, se.fc2.weight, se.fc2.bias)
+                g = _ActFn.apply(g, 2)
+                h = _ChanScaleFn.apply(h.view(Bq, Hc * Wc, C), g).view(Bq, Hc, Wc, C)
+                h = _conv1x1(h, lay[i + 2][0].weight, None)
+                h = _bn_act(h, lay[i + 2][1], False)
+                if blk.use_res:
+                    p = 0.2 * bi / nblk                                   # torchvision: sd_prob * block_id / total
+                    if sd_noise is not None:
+                        noise = sd_noise[bi].to(h.device, torch.float32)
+                    else:
+                        noise = torch.empty(B, device=h.device).bernoulli_(1.0 - p)
+                        if p < 1.0:
+                            noise = noise / (1.0 - p)
+                    Bq, Hc, Wc, C = h.shape
+                    h = _ChanScaleFn.apply(h.view(Bq, Hc * Wc, C), noise.view(B, 1).expand(B, C).contiguous())
+                    h = h.view(Bq, Hc, Wc, C) + inp
+                bi += 1
+        h = _conv1x1(h, m.features[-1][0].weight, None)
+        h = _bn_act(h, m.features[-1][1], True)
+        Bq, Hc, Wc, C = h.shape
+        pooled = _ChanReduceFn.apply(h.view(Bq, Hc * Wc, C))
+        if drop_mask is None:
+            drop_mask = torch.empty(B, C, device=h.device).bernoulli_(0.8) / 0.8
+        pooled = _ChanScaleFn.apply(pooled.view(B, 1, C), drop_mask.to(h.device, torch.float32).contiguous()).view(B, C)
+        logits = _conv1x1(pooled, m.classifier[1].weight, m.classifier[1].bias)
+        return logits.view(-1, self.output_size, 2)
+
+    def _forward_eval(self, x):
         P = self._packed or self._pack()
         st = L.stream_ptr()
         B, C, H, W = x.shape
@@ -167,3 +227,257 @@ class SecretDecoder(nn.Module):
         L.call("aql_pwconv_f32", L.ptr(pool), L.ptr(P["fc"][0]), L.ptr(P["fc"][1]), None, 0, None, B,
                self.output_size * 2, 1280, 0, L.ptr(logits), st)
         return logits.view(-1, self.output_size, 2)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# train()-mode building blocks: one autograd.Function per HIP layer (csrc/aql_decoder_train.hip)
+# ------------------------------------------------------------------------------------------------------------
+def _gemm(A, sam, sak, Bm, sbn, sbk, bias, M, N, K, out):
+    L.call("aql_gemm_f32", L.ptr(A), sam, sak, L.ptr(Bm), sbn, sbk, L.ptr(bias), L.ptr(out), N, M, N, K, L.stream_ptr())
+    return out
+
+
+class _Conv1x1Fn(torch.autograd.Function):
+    """y[..., Co] = x[..., Ci] . W[Co,Ci]^T (+ bias): 1x1 convolution on channels-last activations / nn.Linear."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x = x.contiguous()
+        w2 = w.detach().reshape(w.shape[0], -1).float().contiguous()
+        Ci, Co = w2.shape[1], w2.shape[0]
+        M = x.numel() // Ci
+        y = torch.empty(*x.shape[:-1], Co, device=x.device, dtype=torch.float32)
+        _gemm(x, Ci, 1, w2, Ci, 1, None if bias is None else bias.detach().float().contiguous(), M, Co, Ci, y)
+        ctx.save_for_backward(x, w2)
+        ctx.has_bias = bias is not None
+        ctx.wshape = w.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w2 = ctx.saved_tensors
+        dy = dy.contiguous()
+        Co, Ci = w2.shape
+        M = x.numel() // Ci
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _gemm(dy, Co, 1, w2, 1, Ci, None, M, Ci, Co, torch.empty_like(x))
+        if ctx.needs_input_grad[1]:
+            dw = _gemm(dy, 1, Co, x, 1, Ci, None, Co, Ci, M, torch.empty(Co, Ci, device=x.device)).view(ctx.wshape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(Co, device=x.device)
+            L.call("aql_chan_reduce", L.ptr(dy), None, 1, M, Co, 1.0, L.ptr(db), L.stream_ptr())
+        return dx, dw, db
+
+
+def _conv1x1(x, w, bias):
+    return _Conv1x1Fn.apply(x, w, bias)
+
+
+def _bn_scratch(M, C, dev):
+    return torch.empty(2 * ((M + 2047) // 2048) * C, device=dev, dtype=torch.float32)
+
+
+class _BNActFn(torch.autograd.Function):
+    """nn.BatchNorm2d in training mode (batch statistics, running-stat update) + optional SiLU, on [.., C]."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, eps, momentum, act):
+        x = x.contiguous()
+        C = x.shape[-1]
+        M = x.numel() // C
+        y = torch.empty_like(x)
+        mean = torch.empty(C, device=x.device)
+        invstd = torch.empty(C, device=x.device)
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        L.call("aql_bn_train_fwd", L.ptr(x), L.ptr(g), L.ptr(b), M, C, float(eps), float(momentum), int(act), L.ptr(y),
+               L.ptr(mean), L.ptr(invstd), L.ptr(run_mean), L.ptr(run_var), L.ptr(_bn_scratch(M, C, x.device)),
+               L.stream_ptr())
+        ctx.save_for_backward(x, g, b, mean, invstd)
+        ctx.act = int(act)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, b, mean, invstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        C = x.shape[-1]
+        M = x.numel() // C
+        dx = torch.empty_like(x)
+        dg = torch.empty(C, device=x.device)
+        db = torch.empty(C, device=x.device)
+        L.call("aql_bn_train_bwd", L.ptr(x), L.ptr(dy), L.ptr(g), L.ptr(b), L.ptr(mean), L.ptr(invstd), M, C, ctx.act,
+               L.ptr(dx), L.ptr(dg), L.ptr(db), L.ptr(_bn_scratch(M, C, x.device)), L.stream_ptr())
+        return dx, dg, db, None, None, None, None, None
+
+
+def _bn_act(x, bn, act):
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return _BNActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                          0.1 if bn.momentum is None else bn.momentum, act)
+
+
+class _DwConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, k, stride):
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        wp = w.detach().float().reshape(C, k * k).t().contiguous()       # [k*k][C]
+        Ho = (H + 2 * (k // 2) - k) // stride + 1
+        y = torch.empty(B, Ho, Ho, C, device=x.device)
+        L.call("aql_dwconv_train", L.ptr(x), None, L.ptr(wp), B, H, W, C, k, stride, 0, L.ptr(y), L.stream_ptr())
+        ctx.save_for_backward(x, wp)
+        ctx.cfg = (k, stride, w.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wp = ctx.saved_tensors
+        k, stride, wshape = ctx.cfg
+        dy = dy.contiguous()
+        B, H, W, C = x.shape
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            L.call("aql_dwconv_train", L.ptr(dy), None, L.ptr(wp), B, H, W, C, k, stride, 1, L.ptr(dx), L.stream_ptr())
+        if ctx.needs_input_grad[1]:
+            dwp = torch.empty(k * k, C, device=x.device)
+            L.call("aql_dwconv_train", L.ptr(x), L.ptr(dy), None, B, H, W, C, k, stride, 2, L.ptr(dwp), L.stream_ptr())
+            dw = dwp.t().reshape(wshape)
+        return dx, dw, None, None
+
+
+class _StemFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        B, H, W, _ = x.shape
+        Co = w.shape[0]
+        wp = w.detach().float().permute(2, 3, 1, 0).reshape(27, Co).contiguous()
+        y = torch.empty(B, H // 2, W // 2, Co, device=x.device)
+        L.call("aql_stem_train", L.ptr(x), None, L.ptr(wp), B, H, W, Co, 0, L.ptr(y), L.stream_ptr())
+        ctx.save_for_backward(x, wp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wp = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, H, W, _ = x.shape
+        Co = wp.shape[1]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            L.call("aql_stem_train", L.ptr(dy), None, L.ptr(wp), B, H, W, Co, 1, L.ptr(dx), L.stream_ptr())
+        if ctx.needs_input_grad[1]:
+            dwp = torch.empty(27, Co, device=x.device)
+            L.call("aql_stem_train", L.ptr(x), L.ptr(dy), None, B, H, W, Co, 2, L.ptr(dwp), L.stream_ptr())
+            dw = dwp.view(3, 3, 3, Co).permute(3, 2, 0, 1).contiguous()
+        return dx, dw
+
+
+class _ChanScaleFn(torch.autograd.Function):
+    """y[b,p,c] = x[b,p,c] * g[b,c]  (squeeze-excite gate, stochastic depth, dropout)."""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        x, g = x.contiguous(), g.contiguous()
+        B, HW, C = x.shape
+        y = torch.empty_like(x)
+        L.call("aql_chan_scale", L.ptr(x), L.ptr(g), B, HW, C, L.ptr(y), L.stream_ptr())
+        ctx.save_for_backward(x, g)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, HW, C = x.shape
+        dx = dg = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            L.call("aql_chan_scale", L.ptr(dy), L.ptr(g), B, HW, C, L.ptr(dx), L.stream_ptr())
+        if ctx.needs_input_grad[1]:
+            dg = torch.empty_like(g)
+            L.call("aql_chan_reduce", L.ptr(dy), L.ptr(x), B, HW, C, 1.0, L.ptr(dg), L.stream_ptr())
+        return dx, dg
+
+
+class _ChanReduceFn(torch.autograd.Function):
+    """global average pool [B,HW,C] -> [B,C]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, HW, C = x.shape
+        out = torch.empty(B, C, device=x.device)
+        L.call("aql_chan_reduce", L.ptr(x), None, B, HW, C, 1.0 / HW, L.ptr(out), L.stream_ptr())
+        ctx.shape = (B, HW, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, HW, C = ctx.shape
+        dx = torch.empty(B, HW, C, device=dy.device)
+        L.call("aql_chan_bcast", L.ptr(dy.contiguous()), B, HW, C, 1.0 / HW, 0, L.ptr(dx), L.stream_ptr())
+        return dx
+
+
+class _ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kind):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        L.call("aql_act_f32", L.ptr(x), None, kind, x.numel(), L.ptr(y), L.stream_ptr())
+        ctx.save_for_backward(x)
+        ctx.kind = kind
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        L.call("aql_act_f32", L.ptr(x), L.ptr(dy.contiguous()), ctx.kind, x.numel(), L.ptr(dx), L.stream_ptr())
+        return dx, None
+
+
+class _ResizeFn(torch.autograd.Function):
+    """F.interpolate(x, (Ho,Wo), mode="bilinear") with NCHW in, NHWC out (models.py:92-94)."""
+
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        B, C, H, W = x.shape
+        y = torch.empty(B, Ho, Wo, C, device=x.device)
+        L.call("aql_resize_bilinear_nhwc", L.ptr(x), B, C, H, W, Ho, Wo, L.ptr(y), L.stream_ptr())
+        ctx.cfg = (B, C, H, W, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W, Ho, Wo = ctx.cfg
+        dx = torch.empty(B, C, H, W, device=dy.device)
+        L.call("aql_resize_bilinear_nhwc_bwd", L.ptr(dy.contiguous()), B, C, H, W, Ho, Wo, L.ptr(dx), L.stream_ptr())
+        return dx, None, None
+
+
+class _BceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        z, t = logits.float().contiguous(), target.float().contiguous()
+        loss = torch.empty((), device=z.device)
+        dz = torch.empty_like(z)
+        L.call("aql_bce_logits", L.ptr(z), L.ptr(t), z.numel(), L.ptr(loss), L.ptr(dz), L.stream_ptr())
+        ctx.save_for_backward(dz)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dz,) = ctx.saved_tensors
+        return dz * g, None
+
+
+def bce_with_logits(logits, target):
+    """F.binary_cross_entropy_with_logits(logits, target) (mean reduction), latent_wm_pretrain.py:196."""
+    if not logits.is_cuda:
+        raise L.AqlError("bce_with_logits: the HIP path needs GPU tensors; there is no CPU fallback")
+    return _BceFn.apply(logits, target)

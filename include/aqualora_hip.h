@@ -167,6 +167,40 @@ int aql_se_gate(const float* pool, const float* w1, const float* b1, const float
 int aql_pwconv_f32(const float* x, const float* w, const float* bias, const float* gate, int rows_per_sample,
                    const float* residual, long M, int N, int K, int act, float* y, aql_stream_t stream);
 
+/* ---- SecretDecoder training (csrc/aql_decoder_train.hip) ---- torchvision efficientnet_b1 in train() mode as run by
+ * train/latent_wm_pretrain.py:159-225 (sec_decoder.train(), :160) and train/rob_enhance_finetune.py (msgdecoder fwd+bwd at
+ * B=16): BatchNorm with batch statistics and every layer's backward.  fp32, channels-last [B,H,W,C] == [M,C].            */
+/* C[m,n] = sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk] (+ bias[n]); one stride of each operand must be 1 (1x1 conv fwd /
+ * bwd-data / bwd-weight are the three stride patterns)                                                                   */
+int aql_gemm_f32(const float* A, long sam, long sak, const float* B, long sbn, long sbk, const float* bias, float* C,
+                 long ldc, long M, int N, long K, aql_stream_t stream);
+long aql_bn_scratch_floats(long M, int C);
+/* nn.BatchNorm2d(eps, momentum) training forward (+ fused SiLU when act=1); mean/invstd [C] are saved for the backward   */
+int aql_bn_train_fwd(const float* x, const float* gamma, const float* beta, long M, int C, float eps, float momentum,
+                     int act, float* y, float* mean, float* invstd, float* run_mean, float* run_var, float* scratch,
+                     aql_stream_t stream);
+int aql_bn_train_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean,
+                     const float* invstd, long M, int C, int act, float* dx, float* dgamma, float* dbeta, float* scratch,
+                     aql_stream_t stream);
+/* depthwise k x k conv, w packed [k*k][C]: mode 0 forward, 1 backward-data (src = dy), 2 backward-weight (src = x,
+ * src2 = dy, dst = dw)                                                                                                   */
+int aql_dwconv_train(const float* src, const float* src2, const float* w, int B, int H, int W, int C, int k, int stride,
+                     int mode, float* dst, aql_stream_t stream);
+/* stem 3x3 stride-2 conv 3 -> Cout, w packed [27][Cout]; modes as above                                                  */
+int aql_stem_train(const float* src, const float* src2, const float* w, int B, int H, int W, int Cout, int mode,
+                   float* dst, aql_stream_t stream);
+/* squeeze-excite / pooling plumbing on [B,HW,C] with per-(sample, channel) vectors [B,C]                                 */
+int aql_chan_scale(const float* x, const float* g, int B, long HW, int C, float* y, aql_stream_t stream);
+int aql_chan_reduce(const float* a, const float* bmul, int B, long HW, int C, float scale, float* out,
+                    aql_stream_t stream);
+int aql_chan_bcast(const float* g, int B, long HW, int C, float scale, int accumulate, float* dx, aql_stream_t stream);
+/* kind 1 SiLU, 2 sigmoid; dy == NULL: y = act(x), else y = dy * act'(x)                                                  */
+int aql_act_f32(const float* x, const float* dy, int kind, long n, float* y, aql_stream_t stream);
+int aql_resize_bilinear_nhwc_bwd(const float* dy, int B, int C, int H, int W, int Ho, int Wo, float* dx,
+                                 aql_stream_t stream);
+/* F.binary_cross_entropy_with_logits (mean), latent_wm_pretrain.py:196; dlogits may be NULL                              */
+int aql_bce_logits(const float* logits, const float* target, long n, float* loss, float* dlogits, aql_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

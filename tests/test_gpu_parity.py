@@ -22,6 +22,11 @@ def relerr(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
 
 
+def l2rel(a, b):
+    a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
 def test_library_is_loaded_and_complete():
     from aqualora_amd import _lib
     lib = _lib.load()
@@ -278,8 +283,54 @@ def test_secret_decoder_vs_oracle_bits_exact():
     msg = metrics.extract_bits(want)
     acc, tpr = metrics.tpr_at_fpr(metrics.extract_bits(got).cpu(), msg, 1e-6)
     assert acc == 1.0 and tpr == 1.0
-    with pytest.raises(NotImplementedError):
-        dec.train()
+
+
+def test_secret_decoder_training_step_vs_oracle():
+    """train()-mode EfficientNet-B1 (BatchNorm batch statistics, stochastic depth, dropout) forward, BCE loss and the
+    full backward (all 301 parameter tensors + the input image) against torch autograd on the CPU restatement, with the
+    random masks pinned; running statistics must move identically."""
+    from aqualora_amd import decoder as D
+    from oracle.decoder_oracle import secret_decoder_train
+    torch.manual_seed(0)
+    B, bits = 2, 48
+    dec = _synthetic_decoder(bits)
+    sd = {k[len("model."):]: v.clone().float() for k, v in dec.state_dict().items()}
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if "running" not in k and "num_batches" not in k}
+    nblk = 23
+    sd_noise = [torch.bernoulli(torch.full((B,), 1.0 - 0.2 * i / nblk)) / (1.0 - 0.2 * i / nblk) for i in range(nblk)]
+    drop = torch.bernoulli(torch.full((B, 1280), 0.8)) / 0.8
+    x = T("dect.x", (B, 3, 96, 80), 0.5).clamp(-1, 1)
+    msg = (T("dect.m", (B, bits), 1.0) > 0).long()
+    target = torch.nn.functional.one_hot(msg, 2).float()
+
+    xr = x.clone().requires_grad_(True)
+    want = secret_decoder_train({**sd, **params}, xr, bits, sd_noise, drop)
+    loss_r = torch.nn.functional.binary_cross_entropy_with_logits(want, target)
+    loss_r.backward()
+
+    dec = dec.to(DEV).train()
+    xg = x.to(DEV).requires_grad_(True)
+    got = dec(xg, sd_noise=sd_noise, drop_mask=drop)
+    loss_g = D.bce_with_logits(got, target.to(DEV))
+    loss_g.backward()
+
+    assert relerr(got, want) < 2e-3, relerr(got, want)
+    assert abs(loss_g.item() - loss_r.item()) < 1e-4 * max(1.0, abs(loss_r.item()))
+    assert l2rel(xg.grad, xr.grad) < 2e-2, l2rel(xg.grad, xr.grad)
+    worst, n = 0.0, 0
+    for name, p in dec.model.named_parameters():
+        ref = params[name].grad
+        assert p.grad is not None and p.grad.shape == ref.shape, name
+        if ref.norm() > 1e-6 * (1 + params[name].detach().norm()):
+            e = l2rel(p.grad, ref)
+            worst = max(worst, e)
+            n += 1
+    assert n > 250 and worst < 5e-2, (n, worst)
+    for name, b in dec.model.named_buffers():
+        if "running" in name:
+            assert relerr(b, sd[name]) < 1e-3, name
+    dec.eval()                       # folded inference weights are rebuilt from the moved running statistics
+    assert dec(x.to(DEV)).shape == (B, bits, 2)
 
 
 def test_distortion_maps_vs_torch():
