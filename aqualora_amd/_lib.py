@@ -71,6 +71,9 @@ SIGNATURES = {
     "aql_act_f32": [c_p, c_p, c_i, c_l, c_p, c_p],
     "aql_resize_bilinear_nhwc_bwd": [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "aql_bce_logits": [c_p, c_p, c_l, c_p, c_p, c_p],
+    "aql_secret_encoder_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
+    "aql_prvl_loss_fwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
+    "aql_prvl_loss_bwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "aql_ddim_step": [c_p, c_p, c_p, c_f, c_p, c_l, c_p],
     "aql_sdpa_fwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p, c_p],
     "aql_sdpa_bwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p,

@@ -343,6 +343,20 @@ class Noiser(nn.Module):
         return self.noise_layers[idx](encoded_and_cover)
 
 
+class RobNoiser:
+    """rob_enhance_finetune.py:121-132: Identity / color_jitter / crop / blur / noise on [0,1] images."""
+
+    distorsion_types = ["Identity", "color_jitter", "crop", "blur", "noise"]
+
+    def __init__(self, posibilities):
+        self.posibilities = posibilities
+
+    def __call__(self, encoded_image, possibilites=None):
+        p = self.posibilities if possibilites is None else possibilites
+        kind = self.distorsion_types[int(np.random.choice(len(self.distorsion_types), 1, p=p)[0])]
+        return encoded_image if kind == "Identity" else distorsion_unit(encoded_image, kind)
+
+
 def eval_distorsion_unit(encoded_image, type):
     """evaluation/utils_eval.py:269-301, the tensor-space attacks: 'color_jitter' (.9-1.1, hue +-.1), 'crop' (460x460
     window -> back to the input size), 'blur' (k=3, sigma 4), 'noise' (std .1, clamp), 'rotation' (15 deg), 'sharpness'

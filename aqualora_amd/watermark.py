@@ -58,8 +58,9 @@ class _View(nn.Module):  # placeholders so that state-dict indices match nn.Sequ
 
 class SecretEncoder(nn.Module):
     """Linear(bits -> R*R) -> SiLU -> [1,R,R] -> repeat 4 ch -> nearest x(res/R) -> zero-init conv3x3(4->4)
-    (utils/models.py:51-81).  ``forward(x, c)`` returns ``(x + c_map, c_map)`` like the reference.  Inference only on
-    the PPFT path (ppft_train.py:994-996 runs it under no_grad)."""
+    (utils/models.py:51-81).  ``forward(x, c)`` returns ``(x + c_map, c_map)`` like the reference.  The PPFT path runs
+    it under no_grad (ppft_train.py:994-996); stage 1 trains it, so with grad enabled the forward is differentiable
+    (HIP backward, csrc/aql_stage1.hip)."""
 
     def __init__(self, secret_len, base_res=32, resolution=64):
         super().__init__()
@@ -84,11 +85,48 @@ class SecretEncoder(nn.Module):
                L.ptr(hid), L.ptr(out), L.stream_ptr())
         return out
 
+    def encode_train(self, c):
+        """encode() with autograd (stage 1 trains the encoder, latent_wm_pretrain.py:172,221)."""
+        if not c.is_cuda:
+            raise L.AqlError("SecretEncoder: the HIP path needs GPU tensors; there is no CPU fallback")
+        lin, conv = self.secret_scaler[0], self.secret_scaler[5]
+        return _SecretEncoderFn.apply(c.float().contiguous(), lin.weight, lin.bias, conv.weight, conv.bias,
+                                      self.secret_len, self.base_res, self.resolution)
+
     def forward(self, x, c):
-        cm = self.encode(c)
+        grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        cm = self.encode_train(c) if grad else self.encode(c)
         if tuple(x.shape[2:]) != (self.resolution, self.resolution):
-            cm = torch.nn.functional.interpolate(cm, size=(x.shape[2], x.shape[3]), mode="bilinear")
+            from .noise import crop_resize  # bilinear resize kernel (forward + adjoint)
+            cm = crop_resize(cm, 0, 0, self.resolution, self.resolution, x.shape[2], x.shape[3])
         return x + cm, cm
+
+
+class _SecretEncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, msg, lin_w, lin_b, conv_w, conv_b, bits, base_res, res):
+        nb = msg.shape[0]
+        hid = torch.empty(nb, base_res * base_res, dtype=torch.float32, device=msg.device)
+        out = torch.empty(nb, 4, res, res, dtype=torch.float32, device=msg.device)
+        ws = [t.detach().float().contiguous() for t in (lin_w, lin_b, conv_w, conv_b)]
+        L.call("aql_secret_encoder_fwd", L.ptr(msg), L.ptr(ws[0]), L.ptr(ws[1]), L.ptr(ws[2]), L.ptr(ws[3]), nb, bits,
+               base_res, res, 1.0, L.ptr(hid), L.ptr(out), L.stream_ptr())
+        ctx.save_for_backward(msg, hid, *ws)
+        ctx.cfg = (bits, base_res, res)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        msg, hid, lw, lb, cw, cb = ctx.saved_tensors
+        bits, base_res, res = ctx.cfg
+        nb = msg.shape[0]
+        dev = msg.device
+        dpre = torch.empty(nb, base_res * base_res, device=dev)
+        dlw, dlb, dcw, dcb = torch.empty_like(lw), torch.empty_like(lb), torch.empty_like(cw), torch.empty_like(cb)
+        L.call("aql_secret_encoder_bwd", L.ptr(dout.float().contiguous()), L.ptr(msg), L.ptr(lw), L.ptr(lb), L.ptr(cw),
+               L.ptr(hid), nb, bits, base_res, res, L.ptr(dpre), L.ptr(dlw), L.ptr(dlb), L.ptr(dcw), L.ptr(dcb),
+               L.stream_ptr())
+        return None, dlw, dlb, dcw, dcb, None, None, None
 
 
 def sd15_alphas_cumprod(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, device="cpu"):

@@ -201,6 +201,20 @@ int aql_resize_bilinear_nhwc_bwd(const float* dy, int B, int C, int H, int W, in
 /* F.binary_cross_entropy_with_logits (mean), latent_wm_pretrain.py:196; dlogits may be NULL                              */
 int aql_bce_logits(const float* logits, const float* target, long n, float* loss, float* dlogits, aql_stream_t stream);
 
+/* ---- stage 1, latent watermark pre-training (csrc/aql_stage1.hip) ---- train/latent_wm_pretrain.py:159-225             */
+/* gradients of SecretEncoder.encode() (utils/models.py:70-73): dout [nb,4,res,res]; hidden = forward's SiLU output       */
+int aql_secret_encoder_bwd(const float* dout, const float* msg, const float* lin_w, const float* lin_b,
+                           const float* conv_w, const float* hidden, int nb, int bits, int base_res, int res,
+                           float* dpre_scratch, float* dlin_w, float* dlin_b, float* dconv_w, float* dconv_b,
+                           aql_stream_t stream);
+/* PRVL_loss (latent_wm_pretrain.py:42-50): max over (sample, window) of the win x win box mean (padding win/2) of the
+ * channel-mean |img1 - img2|; loss is a device scalar, arg the winning window (device long) for the backward              */
+long aql_prvl_scratch_floats(int B, int H, int W, int win);
+int aql_prvl_loss_fwd(const float* img1, const float* img2, int B, int C, int H, int W, int win, float* scratch,
+                      float* loss, long* arg, aql_stream_t stream);
+int aql_prvl_loss_bwd(const float* img1, const float* img2, const long* arg, const float* gout, int B, int C, int H, int W,
+                      int win, float* d1, float* d2, aql_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

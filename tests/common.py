@@ -39,3 +39,11 @@ def ppft_inputs(cfg=TINY, B=2, bits=48, res=16, rank=TINY_RANK, device="cpu"):
                 z=T("ppft.z", (B, 4, res, res), device=device), wm=T("ppft.wm", (B, 4, res, res), 0.5, device),
                 eps=T("ppft.eps", (B, 4, res, res), device=device), t=synth.randint("ppft.t", (B,), 1000, SEED, device),
                 ctx=T("ppft.ctx", (B, 77, cfg["cross_attention_dim"]), device=device))
+
+
+def prvl_case(i, B, H, W, amp):
+    """inputs of the PRVL golden cases (same construction as tests/golden/make_golden.py:prvl_case)."""
+    a = T(f"prvl.a{i}", (B, 3, H, W), 0.5)
+    d = T(f"prvl.d{i}", (B, 3, H, W), amp)
+    d[:, :, H // 3: H // 3 + 20, W // 4: W // 4 + 25] *= 4.0
+    return a, (a + d)

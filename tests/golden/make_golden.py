@@ -432,9 +432,45 @@ def gen_create_wm_lora(models):
     save("create_wm_lora.npz", msg=np.array(msg), **{k: v.detach().numpy() for k, v in out.items()})
 
 
+def prvl_case(i, B, H, W, amp):
+    a = T(f"prvl.a{i}", (B, 3, H, W), 0.5)
+    d = T(f"prvl.d{i}", (B, 3, H, W), amp)
+    d[:, :, H // 3: H // 3 + 20, W // 4: W // 4 + 25] *= 4.0   # a localised artefact, the thing PRVL looks for
+    return a, (a + d)
+
+
+def gen_stage1():
+    """PRVL_loss of the reference's stage-1 script (train/latent_wm_pretrain.py:42-50), imported with the third-party
+    modules stubbed (tensorboard, torchsummary and the kornia/torchvision based noiser are absent here)."""
+    for n in ["torch.utils.tensorboard", "torchsummary", "kornia.augmentation", "torchvision.transforms"]:
+        if n not in sys.modules:
+            _stub(n)
+    sys.path.insert(0, os.path.join(REF, "train"))
+    import importlib
+    st = importlib.import_module("latent_wm_pretrain")
+    out = {}
+    for i, (B, H, W, amp) in enumerate([(1, 512, 512, 0.05), (2, 96, 80, 0.3), (3, 40, 33, 1.0)]):
+        a, b = prvl_case(i, B, H, W, amp)
+        b.requires_grad_(True)
+        loss = st.PRVL_loss(a, b)
+        loss.backward()
+        out[f"loss{i}"] = loss.detach().numpy()
+        if i == 0:   # full-size case: inputs are regenerated by the test (counter-based generator), gradient summarised
+            g = b.grad
+            nz = g.nonzero()
+            out["grad_nnz0"], out["grad_abs_sum0"] = np.array(len(nz)), g.abs().sum().numpy()
+            out["grad_bbox0"] = np.array([nz[:, 2].min(), nz[:, 2].max(), nz[:, 3].min(), nz[:, 3].max()])
+        else:
+            out[f"a{i}"], out[f"b{i}"], out[f"grad_b{i}"] = a.numpy(), b.detach().numpy(), b.grad.numpy()
+    save("stage1_prvl.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     lm, models, misc, ou = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "stage1":
+        gen_stage1()
+        sys.exit(0)
     gen_lora(lm)
     gen_watermark(models)
     gen_misc(misc)

@@ -30,7 +30,7 @@ def test_header_matches_binding_and_library():
             assert bound[name] == n, (name, bound[name], n)
     for name in bound:
         assert name in decls, f"{name} bound in _lib.py but missing from include/aqualora_hip.h"
-    assert set(decls) - set(bound) <= {"aql_last_error", "aql_groupnorm_scratch_floats", "aql_bn_scratch_floats"}
+    assert set(decls) - set(bound) <= {"aql_last_error", "aql_groupnorm_scratch_floats", "aql_bn_scratch_floats", "aql_prvl_scratch_floats"}
 
 
 def test_product_path_fails_loudly_without_gpu():

@@ -409,6 +409,122 @@ def test_kornia_style_distortions_vs_oracle():
     assert out[0].shape == img.shape and out[1] is None
 
 
+def test_stage1_pieces_vs_reference_golden_and_oracle(golden):
+    """PRVL_loss (forward + gradient) against the reference's own outputs; SecretEncoder backward, gen_combined_latents
+    and one full stage-1 step (encoder -> stand-in VAE decoder -> distortion -> train-mode decoder -> BCE + PRVL) against
+    torch autograd on the CPU restatements."""
+    import torch.nn.functional as F
+    from aqualora_amd import decoder as D, noise as NZ, stage1 as S1
+    from aqualora_amd.watermark import SecretEncoder
+    from oracle import ppft_oracle as O, stage1_oracle as SO
+    from oracle.decoder_oracle import secret_decoder_train
+    from tests.common import prvl_case
+    g = golden("stage1_prvl.npz")
+    for i in (1, 2):
+        a = torch.tensor(g[f"a{i}"]).to(DEV)
+        b = torch.tensor(g[f"b{i}"]).to(DEV).requires_grad_(True)
+        loss = S1.PRVL_loss(a, b)
+        loss.backward()
+        assert abs(loss.item() - float(g[f"loss{i}"])) < 2e-6 * max(1.0, float(g[f"loss{i}"]))
+        assert np.allclose(b.grad.cpu().numpy(), g[f"grad_b{i}"], atol=1e-7)
+    a, b = prvl_case(0, 1, 512, 512, 0.05)
+    b = b.to(DEV).requires_grad_(True)
+    loss = S1.PRVL_loss(a.to(DEV), b)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss0"])) < 2e-6
+    nz = b.grad.nonzero()
+    assert len(nz) == int(g["grad_nnz0"]) and abs(b.grad.abs().sum().item() - float(g["grad_abs_sum0"])) < 1e-5
+    assert [int(nz[:, 2].min()), int(nz[:, 2].max()), int(nz[:, 3].min()), int(nz[:, 3].max())] == g["grad_bbox0"].tolist()
+
+    # SecretEncoder: trainable forward + backward
+    B, bits = 3, 48
+    enc = SecretEncoder(bits)
+    with torch.no_grad():
+        enc.secret_scaler[0].weight.copy_(T("s1.lw", (1024, bits), 0.2))
+        enc.secret_scaler[0].bias.copy_(T("s1.lb", (1024,), 0.2))
+        enc.secret_scaler[5].weight.copy_(T("s1.cw", (4, 4, 3, 3), 0.1))
+        enc.secret_scaler[5].bias.copy_(T("s1.cb", (4,), 0.1))
+    ref = [p.detach().clone().requires_grad_(True) for p in (enc.secret_scaler[0].weight, enc.secret_scaler[0].bias,
+                                                              enc.secret_scaler[5].weight, enc.secret_scaler[5].bias)]
+    msg = (T("s1.m", (B, bits)) > 0).float()
+    lat = T("s1.lat", (B, 4, 64, 64))
+    dy = T("s1.dy", (B, 4, 64, 64))
+    cm_r = O.secret_encoder(msg, *ref)
+    ((lat + cm_r) * dy).sum().backward()
+    enc = enc.to(DEV)
+    xo, cm = enc(lat.to(DEV), msg.to(DEV))
+    (xo * dy.to(DEV)).sum().backward()
+    assert relerr(cm, cm_r) < 1e-5
+    for p, r in zip((enc.secret_scaler[0].weight, enc.secret_scaler[0].bias, enc.secret_scaler[5].weight,
+                     enc.secret_scaler[5].bias), ref):
+        assert l2rel(p.grad, r.grad) < 1e-4, l2rel(p.grad, r.grad)
+
+    # gen_combined_latents, both branches
+    wm = T("s1.wm", (B, 4, 64, 64), 0.1)
+    for corner, sc in ((False, (1.0, 1.0)), (True, (1.37, 1.81))):
+        wr = wm.clone().requires_grad_(True)
+        out_r = SO.gen_combined_latents(lat, wr, 0.03, corner, sc)
+        (out_r * dy).sum().backward()
+        wg = wm.to(DEV).requires_grad_(True)
+        out_g = S1.gen_combined_latents(lat.to(DEV), wg, 0.03, corner, sc)
+        (out_g * dy.to(DEV)).sum().backward()
+        assert relerr(out_g, out_r) < 1e-5 and l2rel(wg.grad, wr.grad) < 1e-5
+
+    # one full step (post-warm-up schedule, identity distortion) with a stand-in linear "VAE decoder"
+    B = 2
+    dec = _synthetic_decoder(bits)
+    sd = {k[len("model."):]: v.clone().float() for k, v in dec.state_dict().items()}
+    dparams = {k: v.requires_grad_(True) for k, v in sd.items() if "running" not in k and "num_batches" not in k}
+    Wd = T("s1.vae", (3, 4), 0.5)
+
+    def vae_decode(w):
+        def f(z):  # nearest x4 upsample + 1x1 mix, tanh-free so it is exactly linear: [B,4,64,64] -> [B,3,256,256]
+            return torch.einsum("oc,bchw->bohw", w.to(z.device), F.interpolate(z, scale_factor=4.0, mode="nearest"))
+        return f
+
+    sd_noise = [torch.ones(B) for _ in range(23)]
+    drop = torch.ones(B, 1280)
+    msg = (T("s1.m2", (B, bits)) > 0).long()
+    lat = T("s1.lat2", (B, 4, 64, 64))
+    cm_r = O.secret_encoder(msg.float(), *ref)
+    for r in ref:
+        r.grad = None
+    wml_r = SO.gen_combined_latents(lat, cm_r, 1.0, False)
+    clean_r, wimg_r = vae_decode(Wd)(lat).detach(), vae_decode(Wd)(wml_r)
+    prvl_r = SO.prvl_loss(clean_r, wimg_r)
+    logits_r = secret_decoder_train({**sd, **dparams}, wimg_r, bits, sd_noise, drop)
+    msgloss_r = F.binary_cross_entropy_with_logits(logits_r, F.one_hot(msg, 2).float())
+    loss_r = SO.stage1_loss(msgloss_r, torch.zeros(()), prvl_r, False, 11, False)
+    loss_r.backward()
+
+    dec = dec.to(DEV).train()
+    orig_forward = dec.forward
+    dec.forward = lambda x: orig_forward(x, sd_noise=sd_noise, drop_mask=drop)
+    for p in enc.parameters():
+        p.grad = None
+    step = S1.Stage1Step(enc, dec, vae_decode(Wd), NZ.Noiser(["Identity", "Jpeg"], [1.0, 0.0]))
+    step.warmup = False
+    out = step.losses(lat.to(DEV), msg.to(DEV), epochs_done=11, noiser_choice=[1.0, 0.0])
+    out["loss"].backward()
+    assert abs(out["prvl_loss"].item() - prvl_r.item()) < 1e-5 * max(1.0, prvl_r.item())
+    assert abs(out["msgloss"].item() - msgloss_r.item()) < 2e-4 * max(1.0, msgloss_r.item())
+    assert abs(out["loss"].item() - loss_r.item()) < 2e-4 * max(1.0, loss_r.item())
+    for p, r in zip((enc.secret_scaler[0].weight, enc.secret_scaler[0].bias, enc.secret_scaler[5].weight,
+                     enc.secret_scaler[5].bias), ref):
+        assert l2rel(p.grad, r.grad) < 3e-2, l2rel(p.grad, r.grad)
+    worst = max(l2rel(p.grad, dparams[n].grad) for n, p in dec.model.named_parameters()
+                if dparams[n].grad.norm() > 1e-6 * (1 + dparams[n].detach().norm()))
+    assert worst < 5e-2, worst
+
+    # rob-finetune step: decoder-only update on distorted [0,1] images
+    opt = torch.optim.AdamW(dec.parameters(), lr=1e-4)
+    before = dec.model.classifier[1].weight.detach().clone()
+    imgs = (T("s1.img", (B, 3, 128, 160), 0.2, DEV) + 0.5).clamp(0, 1)
+    loss, acc = S1.rob_finetune_step(dec, opt, imgs, msg.to(DEV), distort=NZ.RobNoiser([0.0, 1.0, 0.0, 0.0, 0.0]))
+    assert torch.isfinite(loss) and 0.0 <= acc.item() <= 1.0
+    assert not torch.equal(before, dec.model.classifier[1].weight.detach())
+
+
 def test_captured_step_equals_eager_step():
     """HIP-graph replay (two graphs + exchange) must train exactly like the eager step: same loss trajectory and the
     same parameters after 3 steps (up to fp32 atomic-order noise in the weight gradients)."""

@@ -192,3 +192,18 @@ def test_metrics_match_reference(golden):
     assert M.bit_accuracy(bits, gt).tolist() == [0.75, 1.0]
     logits = torch.tensor([[[0.1, 0.9], [2.0, -1.0]]])
     assert M.extract_bits(logits).tolist() == [[1, 0]]
+
+
+def test_prvl_loss_matches_reference(golden):
+    """oracle PRVL_loss vs the reference's own function (outputs + gradients captured in stage1_prvl.npz)."""
+    from oracle import stage1_oracle as S
+    from tests.common import prvl_case
+    g = golden("stage1_prvl.npz")
+    for i in (1, 2):
+        a, b = torch.tensor(g[f"a{i}"]), torch.tensor(g[f"b{i}"]).requires_grad_(True)
+        loss = S.prvl_loss(a, b)
+        loss.backward()
+        assert abs(loss.item() - float(g[f"loss{i}"])) < 1e-6
+        assert np.allclose(b.grad.numpy(), g[f"grad_b{i}"], atol=1e-7)
+    a, b = prvl_case(0, 1, 512, 512, 0.05)
+    assert abs(S.prvl_loss(a, b).item() - float(g["loss0"])) < 1e-6
