@@ -87,7 +87,7 @@ def dominant_kernels(B, device):
     with torch.no_grad():
         ms = time_kernel(lambda: ops.conv3x3(x, pk))
     fl = 2.0 * B * 64 * 64 * 320 * 9 * 320
-    out.append({"kernel": "gemm_kernel<128,64,64,32,ConvFwdLoader,PlainLoader,0> conv3x3 320->320 @64x64", "ms": ms,
+    out.append({"kernel": "gemm_kernel_d<64,160,32,80,ConvFwdLoader,PlainLoader,EPI_BF16,2> conv3x3 320->320 @64x64", "ms": ms,
                 "flops": fl, "achieved_tflops": fl / ms / 1e9, "frac_of_mfma_peak": fl / ms / 1e9 / MFMA_PEAK_TF})
     xs = synth.normal("k.x2", (B * 4096, 320), 1.0, 1, device).to(torch.bfloat16)
     wl = synth.normal("k.w2", (2560, 320), 0.05, 1, device)
@@ -95,7 +95,7 @@ def dominant_kernels(B, device):
     with torch.no_grad():
         ms = time_kernel(lambda: ops.lora_linear(xs, pl))
     fl = 2.0 * B * 4096 * 320 * 2560
-    out.append({"kernel": "gemm_kernel<128,128,64,64,PlainLoader,PlainLoader,0> ff.net.0.proj 320->2560 @4096 tok",
+    out.append({"kernel": "gemm_kernel_d<128,160,64,80,PlainLoader,PlainLoader,EPI_BF16,2> ff.net.0.proj 320->2560 @4096 tok",
                 "ms": ms, "flops": fl, "achieved_tflops": fl / ms / 1e9,
                 "frac_of_mfma_peak": fl / ms / 1e9 / MFMA_PEAK_TF})
     return out
@@ -224,11 +224,12 @@ def main():
             ks = dominant_kernels(args.batch, device)
         dom = ks[0]
         # dominant kernel = the implicit-GEMM 3x3 convolution family (48 % of the step's algorithmic FLOPs); timed live
-        # with HIP events on the launch stream.  `traffic` is the PMC figure of profiles/r01_pmc_gemm_conv.txt
-        # ((2*FETCH_SIZE + WRITE_SIZE)*1024 per launch) and only applies to the default batch of 4.
+        # with HIP events on the launch stream.  `traffic` is null: the FETCH_SIZE / WRITE_SIZE pass of rocprofv3 times out
+        # on this image for the current kernel (profiles/r01_pmc_gemm_conv.txt holds the figure of the PREVIOUS conv
+        # kernel, 477 MB per launch before the XCD-aware remap; algorithmic bytes are 22.8 MB).
         line["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_tflops"],
                             "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": dom["frac_of_mfma_peak"],
-                            "traffic": 477.0e6 if args.batch == 4 else None,
+                            "traffic": None,
                             "flops_per_launch": dom["flops"], "ms_per_launch": dom["ms"]}
         line["step_roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
                                  "frac": achieved / MFMA_PEAK_TF,

@@ -19,3 +19,15 @@ print(f"steps analysed: {nsteps}; GPU span per step {wall:.2f} ms; kernel-busy p
 print(f"{'%':>6} {'ms/step':>8} {'calls/step':>10} {'avg us':>8}  kernel")
 for n, (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(sys.argv[3]) if len(sys.argv) > 3 else 30]:
     print(f"{100 * us / tot:6.2f} {us / 1e3 / nsteps:8.3f} {cnt / nsteps:10.1f} {us / cnt:8.1f}  {n}")
+
+# launches AFTER the last step: bench.py's isolated timing of the dominant kernels (roofline.achieved comes from these)
+tail = rows[marks[-1] + 1:]
+tagg = {}
+for n, s_, e in tail:
+    n = re.sub(r"\(anonymous namespace\)::|aqlgemm::|void ", "", n)
+    n = re.sub(r"\(.*", "", n)[:90]
+    a = tagg.setdefault(n, [0, 0.0]); a[0] += 1; a[1] += (e - s_) / 1e3
+if tagg:
+    print("\nisolated launches after the last step (bench.py dominant_kernels):")
+    for n, (cnt, us) in sorted(tagg.items(), key=lambda kv: -kv[1][1])[:6]:
+        print(f"   {cnt:5d} launches  avg {us / cnt:8.1f} us  {n}")
