@@ -509,378 +509,216 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<LA, LB>& g, const int b
 }
 
 // ------------------------------------------------------------------------------------------------
-// Pipelined main loop (non-transposed loaders).  The plain double-buffered loop above keeps ONE K tile of global
-// loads in flight per workgroup, and with <= 2 workgroups per CU a K tile's MFMA work (a few hundred cycles) cannot
-// cover an HBM / L2 round trip (1-2 k cycles): measured, every GEMM of the train step sat at 10-20 % MFMA use.  Here
-// PD K tiles are in flight in REGISTERS (the 512 KB register file is the roomy resource, not the 160 KB LDS):
-//   * operands are read with raw BUFFER loads: out-of-range rows / K tails / conv padding become an out-of-range
-//     offset that the hardware answers with zeros - no branch around the load, so the compiler can count
-//     (s_waitcnt vmcnt(n)) instead of draining the queue;
-//   * 16x16x32 MFMA fragments, so BN = 160 tiles exist (every channel count of this U-Net is a multiple of 160).
+// LDS-DMA main loop (non-transposed loaders).  Measured on MI355X (tools/tune_gemm.py, tools/trace_gemm.py):
+//   * operands are read with raw BUFFER loads straight into LDS (buffer_load_dwordx4 ... lds): out-of-range rows / K
+//     tails / conv padding become an out-of-range voffset that the hardware answers with zeros -- no branch, no staging
+//     registers, no ds_write;
+//   * 16x16x32 MFMA fragments, so BN = 160 tiles exist (every channel count of this U-Net is a multiple of 160);
+//   * address generation is INCREMENTAL: an in-kernel trace showed the per-tile div/mod address math of the first
+//     version costing 860 of 1950 cycles per K tile (a wave64 VALU op is 4 cycles, an integer division ~40 ops).  Tiles
+//     are always requested in increasing order, so each stager keeps scalar (wave-uniform) tap / channel / byte-offset
+//     state and spends <= 1 VALU op per weight row and ~6 per gathered activation row; the K offset of plain operands
+//     rides in the instruction's scalar offset (not part of the hardware range check).
 // ------------------------------------------------------------------------------------------------
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-constexpr uint32_t OOB_ROW = 0x80000000u;  // any offset >= BUF_BYTES reads as zero
-constexpr uint32_t OOB_K = 0x40000000u;
+constexpr uint32_t OOB_ROW = 0x80000000u;    // any voffset >= BUF_BYTES reads as zero
 constexpr uint32_t BUF_BYTES = 0x40000000u;  // operands must be < 1 GiB (host-checked)
+constexpr int FAR = 1 << 20;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, p ? BUF_BYTES : 0u, 0x00020000);
 }
-__device__ __forceinline__ u32x4_t buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t off) {
-  return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, uint32_t voff, uint32_t soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
 }
 
-// PStager<R, L, PD>: thread owns 16-byte chunk c = tid&7 of rows (tid>>3) + 32*i of an R-row operand tile and keeps PD
-// K tiles of them in registers.
-template <int R, class L, int PD>
-struct PStager;
+// DmaStager<R, L>: the wave's 64 lanes fill 8 consecutive 128-B LDS rows per instruction; lane (row = 32i + tid>>3,
+// slot = tid&7) fetches source chunk slot ^ ((row >> 1) & 7) (the XOR swizzle is applied on the SOURCE side), i.e.
+// k element kc = ((tid&7) ^ ((tid>>4)&7)) * 8 of the tile.  begin() positions the stager on tile t_first of the
+// concatenated K range; every dma() stages the next tile and advances.  Tiles at or past t_end are zero-filled.
+template <int R, class L>
+struct DmaStager;
 
-template <int R, int PD>
-struct PStager<R, PlainLoader, PD> {
+template <int R>
+struct DmaStager<R, PlainLoader> {
   static constexpr int NL = R / 32;
-  uint32_t rowoff0[NL], rowoff1[NL];
-  __amdgpu_buffer_rsrc_t rs0, rs1;
-  int klim0, klim1;
-  u32x4_t regs[PD][NL];
-  __device__ __forceinline__ void init(const PlainLoader& l0, const PlainLoader& l1, bool dual, int row0, int tid,
-                                       int kend0, int kend1) {
-    rs0 = make_rsrc(l0.base);
+  uint32_t voff[NL], voff1[NL];  // row byte offset + lane chunk offset (current segment / segment 1), or OOB_ROW
+  __amdgpu_buffer_rsrc_t rs, rs1;
+  uint32_t soff;                 // byte offset of the next tile inside the current segment
+  int krem, krem1;               // valid k elements from the next tile's first k on (<= 0: nothing valid)
+  int to_switch;                 // tiles until segment 1 starts
+  int kc;
+  __device__ __forceinline__ void begin(const PlainLoader& l0, const PlainLoader& l1, bool dual, int row0, int tid,
+                                        int t_first, int t_end, int ktiles0) {
+    kc = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
+    const bool in1 = dual && t_first >= ktiles0;
     rs1 = make_rsrc(dual ? l1.base : nullptr);
-    klim0 = l0.K < kend0 ? l0.K : kend0;
-    klim1 = dual ? (l1.K < kend1 ? l1.K : kend1) : 0;
+    rs = in1 ? rs1 : make_rsrc(l0.base);
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const int r = row0 + (tid >> 3) + 32 * i;
-      rowoff0[i] = r < l0.rows ? (uint32_t)r * (uint32_t)(l0.ld * 2) : OOB_ROW;
-      rowoff1[i] = (dual && r < l1.rows) ? (uint32_t)r * (uint32_t)(l1.ld * 2) : OOB_ROW;
+      const uint32_t v0 = r < l0.rows ? (uint32_t)r * (uint32_t)(l0.ld * 2) + kc * 2 : OOB_ROW;
+      voff1[i] = (dual && r < l1.rows) ? (uint32_t)r * (uint32_t)(l1.ld * 2) + kc * 2 : OOB_ROW;
+      voff[i] = in1 ? voff1[i] : v0;
     }
+    const int kend0 = min(l0.K, min(t_end, ktiles0) * BK);
+    const int kend1 = dual ? min(l1.K, (t_end - ktiles0) * BK) : 0;
+    const int tl = in1 ? t_first - ktiles0 : t_first;  // tile index inside the current segment
+    soff = (uint32_t)tl * (BK * 2);
+    krem = (in1 ? kend1 : kend0) - tl * BK;
+    krem1 = kend1;
+    to_switch = (dual && !in1) ? ktiles0 - t_first : 0x7fffffff;
   }
-  __device__ __forceinline__ void fetch(int slot, bool seg, int k) {
-    const __amdgpu_buffer_rsrc_t rs = seg ? rs1 : rs0;
-    const uint32_t koff = (k < (seg ? klim1 : klim0)) ? (uint32_t)k * 2u : OOB_K;
+  __device__ __forceinline__ void dma(char* stage, int wave) {
+    const bool bad = kc >= krem;  // K tail of the segment / past the end of this split
 #pragma unroll
-    for (int i = 0; i < NL; ++i) regs[slot][i] = buf_load16(rs, (seg ? rowoff1[i] : rowoff0[i]) + koff);
-  }
-  // LDS-DMA variant: the wave's 64 lanes fill 8 consecutive 128-B LDS rows; the XOR swizzle is applied on the SOURCE
-  // side (lane (row, slot) fetches chunk slot ^ ((row >> 1) & 7)), kc = that chunk's first k
-  __device__ __forceinline__ void dma(char* stage, int wave, bool seg, int k) const {
-    const __amdgpu_buffer_rsrc_t rs = seg ? rs1 : rs0;
-    const uint32_t koff = (k < (seg ? klim1 : klim0)) ? (uint32_t)k * 2u : OOB_K;
+    for (int i = 0; i < NL; ++i) dma16(rs, stage + (32 * i + 8 * wave) * 128, bad ? OOB_ROW : voff[i], soff);
+    soff += BK * 2;
+    krem -= BK;
+    if (--to_switch == 0) {  // uniform: enter segment 1 (the LoRA rank segment)
+      rs = rs1;
+      soff = 0;
+      krem = krem1;
 #pragma unroll
-    for (int i = 0; i < NL; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(stage + (32 * i + 8 * wave) * 128), 16,
-                                               (seg ? rowoff1[i] : rowoff0[i]) + koff, 0, 0, 0);
-  }
-  __device__ __forceinline__ void commit(int slot, char* lds, int tid) const {
-#pragma unroll
-    for (int i = 0; i < NL; ++i)
-      *reinterpret_cast<u32x4_t*>(lds + lds_off((tid >> 3) + 32 * i, tid & 7)) = regs[slot][i];
+      for (int i = 0; i < NL; ++i) voff[i] = voff1[i];
+    }
   }
 };
 
-template <int R, int PD>
-struct PStager<R, ConvFwdLoader, PD> {
+// 3x3 gather loaders.  Fast path (channels % 64 == 0, no folded upsample / stride-2 adjoint): a K tile lies inside one
+// tap, so (kh, kw, c0) are scalars advanced per tile and a row's offset is rowbase + tapoff.  Anything else takes the
+// general per-lane path (conv_in with 8 channels, the 3 upsample convs, the 3 stride-2 backward convs).
+template <int R>
+struct DmaStager<R, ConvFwdLoader> {
   static constexpr int NL = R / 32;
-  int rb[NL], rh[NL], rw[NL];  // b*Hin, h0, w0 of the row's output pixel (h0 = -2^20 for rows past M)
+  int rb[NL], rh[NL], rw[NL];  // b*Hin, h0, w0 of the row's output pixel (h0 = -FAR for rows past M)
+  uint32_t rowbase[NL];        // fast path: (((b*Hin + h0)*Win + w0)*Cin + kc)*2   (wraps for border rows; only used when valid)
   __amdgpu_buffer_rsrc_t rs;
-  int klim, Cin, Win, Hl, Wl, ups;
-  u32x4_t regs[PD][NL];
-  __device__ __forceinline__ void init(const ConvFwdLoader& l, const ConvFwdLoader&, bool, int row0, int tid, int kend0,
-                                       int) {
+  int Cin, Win, Hl, Wl, ups, kc;
+  int kh, kw, c0, left, t;     // scalar state of the next tile
+  bool fast;
+  __device__ __forceinline__ void begin(const ConvFwdLoader& l, const ConvFwdLoader&, bool, int row0, int tid,
+                                        int t_first, int t_end, int ktiles0) {
+    kc = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
     rs = make_rsrc(l.base);
-    klim = l.K < kend0 ? l.K : kend0;
-    Cin = l.Cin;
-    Win = l.Win;
-    ups = l.ups;
-    Hl = l.Hin << l.ups;
-    Wl = l.Win << l.ups;
+    Cin = l.Cin, Win = l.Win, ups = l.ups, Hl = l.Hin << l.ups, Wl = l.Win << l.ups;
+    fast = (l.Cin % BK == 0) && l.ups == 0;
     const int hw = l.Hout * l.Wout;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const int r = row0 + (tid >> 3) + 32 * i;
       const int b = r / hw, rem = r - b * hw, ho = rem / l.Wout;
       rb[i] = b * l.Hin;
-      rh[i] = r < l.rows ? ho * l.stride - 1 : -(1 << 20);
+      rh[i] = r < l.rows ? ho * l.stride - 1 : -FAR;
       rw[i] = (rem - ho * l.Wout) * l.stride - 1;
+      rowbase[i] = (uint32_t)(((rb[i] + rh[i]) * Win + rw[i]) * Cin + kc) * 2u;
     }
+    t = t_first;
+    left = min(t_end, ktiles0) - t_first;  // tiles still inside the K range
+    const int k0 = t_first * BK, tap = k0 / Cin;
+    c0 = k0 - tap * Cin;
+    kh = tap / 3;
+    kw = tap - kh * 3;
   }
-  __device__ __forceinline__ void fetch(int slot, bool seg, int k) {
-    const bool kok = !seg && k < klim;
-    const int tap = k / Cin, ci = k - tap * Cin;
-    const int kh = kok ? tap / 3 : -(1 << 20), kw = tap - (tap / 3) * 3;
+  __device__ __forceinline__ void dma(char* stage, int wave) {
+    if (fast) {
+      const int khe = left > 0 ? kh : -FAR;
+      const uint32_t tapoff = (uint32_t)((khe * Win + kw) * Cin + c0) * 2u;
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int hi = rh[i] + kh, wi = rw[i] + kw;
-      const bool ok = (unsigned)hi < (unsigned)Hl && (unsigned)wi < (unsigned)Wl;
-      const uint32_t off = (uint32_t)(((rb[i] + (hi >> ups)) * Win + (wi >> ups)) * Cin + ci) * 2u;
-      regs[slot][i] = buf_load16(rs, ok ? off : OOB_ROW);
+      for (int i = 0; i < NL; ++i) {
+        const bool ok = (unsigned)(rh[i] + khe) < (unsigned)Hl && (unsigned)(rw[i] + kw) < (unsigned)Wl;
+        dma16(rs, stage + (32 * i + 8 * wave) * 128, ok ? rowbase[i] + tapoff : OOB_ROW, 0);
+      }
+      c0 += BK;
+      if (c0 >= Cin) {
+        c0 = 0;
+        if (++kw == 3) kw = 0, ++kh;
+      }
+    } else {
+      const int k = t * BK + kc;
+      const bool kok = left > 0 && k < 9 * Cin;
+      const int tap = k / Cin, ci = k - tap * Cin;
+      const int khl = kok ? tap / 3 : -FAR, kwl = tap - (tap / 3) * 3;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int hi = rh[i] + khl, wi = rw[i] + kwl;
+        const bool ok = (unsigned)hi < (unsigned)Hl && (unsigned)wi < (unsigned)Wl;
+        const uint32_t off = (uint32_t)(((rb[i] + (hi >> ups)) * Win + (wi >> ups)) * Cin + ci) * 2u;
+        dma16(rs, stage + (32 * i + 8 * wave) * 128, ok ? off : OOB_ROW, 0);
+      }
     }
-  }
-  __device__ __forceinline__ void dma(char* stage, int wave, bool seg, int k) const {
-    const bool kok = !seg && k < klim;
-    const int tap = k / Cin, ci = k - tap * Cin;
-    const int kh = kok ? tap / 3 : -(1 << 20), kw = tap - (tap / 3) * 3;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int hi = rh[i] + kh, wi = rw[i] + kw;
-      const bool ok = (unsigned)hi < (unsigned)Hl && (unsigned)wi < (unsigned)Wl;
-      const uint32_t off = (uint32_t)(((rb[i] + (hi >> ups)) * Win + (wi >> ups)) * Cin + ci) * 2u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(stage + (32 * i + 8 * wave) * 128), 16,
-                                               ok ? off : OOB_ROW, 0, 0, 0);
-    }
-  }
-  __device__ __forceinline__ void commit(int slot, char* lds, int tid) const {
-#pragma unroll
-    for (int i = 0; i < NL; ++i)
-      *reinterpret_cast<u32x4_t*>(lds + lds_off((tid >> 3) + 32 * i, tid & 7)) = regs[slot][i];
+    ++t;
+    --left;
   }
 };
 
-template <int R, int PD>
-struct PStager<R, ConvBwdLoader, PD> {
+template <int R>
+struct DmaStager<R, ConvBwdLoader> {
   static constexpr int NL = R / 32;
-  int rb[NL], rh[NL], rw[NL];  // b*Hout, hi+1, wi+1 of the row's input pixel
+  int rb[NL], rh[NL], rw[NL];  // b*Hout, hi+1, wi+1 of the row's input pixel (hi+1 = -FAR for rows past M)
+  uint32_t rowbase[NL];        // fast path: (((b*Hout + hi+1)*Wout + wi+1)*Cout + kc)*2
   __amdgpu_buffer_rsrc_t rs;
-  int klim, Cout, Hout, Wout, s2;
-  u32x4_t regs[PD][NL];
-  __device__ __forceinline__ void init(const ConvBwdLoader& l, const ConvBwdLoader&, bool, int row0, int tid, int kend0,
-                                       int) {
+  int Cout, Hout, Wout, s2, kc;
+  int kh, kw, c0, left, t;
+  bool fast;
+  __device__ __forceinline__ void begin(const ConvBwdLoader& l, const ConvBwdLoader&, bool, int row0, int tid,
+                                        int t_first, int t_end, int ktiles0) {
+    kc = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
     rs = make_rsrc(l.base);
-    klim = l.K < kend0 ? l.K : kend0;
-    Cout = l.Cout;
-    Hout = l.Hout;
-    Wout = l.Wout;
-    s2 = l.stride == 2 ? 1 : 0;
+    Cout = l.Cout, Hout = l.Hout, Wout = l.Wout, s2 = l.stride == 2 ? 1 : 0;
+    fast = (l.Cout % BK == 0) && l.stride == 1;
     const int hw = l.Hin * l.Win;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const int r = row0 + (tid >> 3) + 32 * i;
       const int b = r / hw, rem = r - b * hw, hi = rem / l.Win;
       rb[i] = b * l.Hout;
-      rh[i] = r < l.rows ? hi + 1 : -(1 << 20);
+      rh[i] = r < l.rows ? hi + 1 : -FAR;
       rw[i] = (rem - hi * l.Win) + 1;
+      rowbase[i] = (uint32_t)(((rb[i] + rh[i]) * Wout + rw[i]) * Cout + kc) * 2u;
     }
+    t = t_first;
+    left = min(t_end, ktiles0) - t_first;
+    const int k0 = t_first * BK, tap = k0 / Cout;
+    c0 = k0 - tap * Cout;
+    kh = tap / 3;
+    kw = tap - kh * 3;
   }
-  __device__ __forceinline__ void fetch(int slot, bool seg, int k) {
-    const bool kok = !seg && k < klim;
-    const int tap = k / Cout, co = k - tap * Cout;
-    const int kh = kok ? tap / 3 : (1 << 21), kw = tap - (tap / 3) * 3;
+  __device__ __forceinline__ void dma(char* stage, int wave) {
+    if (fast) {
+      const int khe = left > 0 ? kh : 2 * FAR;
+      const uint32_t tapoff = (uint32_t)(c0 - (khe * Wout + kw) * Cout) * 2u;
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int th = rh[i] - kh, tw = rw[i] - kw;
-      const bool par = ((th | tw) & s2) == 0;  // stride 2: only even offsets hit an output pixel
-      const int ho = th >> s2, wo = tw >> s2;
-      const bool ok = par && th >= 0 && tw >= 0 && ho < Hout && wo < Wout;
-      const uint32_t off = (uint32_t)(((rb[i] + ho) * Wout + wo) * Cout + co) * 2u;
-      regs[slot][i] = buf_load16(rs, ok ? off : OOB_ROW);
+      for (int i = 0; i < NL; ++i) {
+        const bool ok = (unsigned)(rh[i] - khe) < (unsigned)Hout && (unsigned)(rw[i] - kw) < (unsigned)Wout;
+        dma16(rs, stage + (32 * i + 8 * wave) * 128, ok ? rowbase[i] + tapoff : OOB_ROW, 0);
+      }
+      c0 += BK;
+      if (c0 >= Cout) {
+        c0 = 0;
+        if (++kw == 3) kw = 0, ++kh;
+      }
+    } else {
+      const int k = t * BK + kc;
+      const bool kok = left > 0 && k < 9 * Cout;
+      const int tap = k / Cout, co = k - tap * Cout;
+      const int khl = kok ? tap / 3 : 2 * FAR, kwl = tap - (tap / 3) * 3;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int th = rh[i] - khl, tw = rw[i] - kwl;
+        const bool par = ((th | tw) & s2) == 0;  // stride 2: only even offsets hit an output pixel
+        const int ho = th >> s2, wo = tw >> s2;
+        const bool ok = par && th >= 0 && tw >= 0 && ho < Hout && wo < Wout;
+        const uint32_t off = (uint32_t)(((rb[i] + ho) * Wout + wo) * Cout + co) * 2u;
+        dma16(rs, stage + (32 * i + 8 * wave) * 128, ok ? off : OOB_ROW, 0);
+      }
     }
-  }
-  __device__ __forceinline__ void dma(char* stage, int wave, bool seg, int k) const {
-    const bool kok = !seg && k < klim;
-    const int tap = k / Cout, co = k - tap * Cout;
-    const int kh = kok ? tap / 3 : (1 << 21), kw = tap - (tap / 3) * 3;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int th = rh[i] - kh, tw = rw[i] - kw;
-      const bool par = ((th | tw) & s2) == 0;
-      const int ho = th >> s2, wo = tw >> s2;
-      const bool ok = par && th >= 0 && tw >= 0 && ho < Hout && wo < Wout;
-      const uint32_t off = (uint32_t)(((rb[i] + ho) * Wout + wo) * Cout + co) * 2u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(stage + (32 * i + 8 * wave) * 128), 16,
-                                               ok ? off : OOB_ROW, 0, 0, 0);
-    }
-  }
-  __device__ __forceinline__ void commit(int slot, char* lds, int tid) const {
-#pragma unroll
-    for (int i = 0; i < NL; ++i)
-      *reinterpret_cast<u32x4_t*>(lds + lds_off((tid >> 3) + 32 * i, tid & 7)) = regs[slot][i];
+    ++t;
+    --left;
   }
 };
 
-template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int PD>
-__device__ __forceinline__ void gemm_body_p(const GemmArgs<LA, LB>& g, const int block_x, const int block_z) {
-  static_assert(EPI != EPI_ATOMIC && !LA::kTrans, "bf16 / slab epilogues only");
-  constexpr int FM = WM / 16, FN = WN / 16;
-  constexpr int WAVES_N = BN / WN;
-  static_assert((BM / WM) * (BN / WN) == 4, "4 wavefronts per workgroup");
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-  constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int C_PITCH = (BN + 8) * 2;  // bytes per row of the bf16 C tile staged in LDS
-  constexpr int LDS_BYTES = (2 * STAGE > BM * C_PITCH) ? 2 * STAGE : BM * C_PITCH;
-  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm0 = (wave / WAVES_N) * WM;
-  const int wn0 = (wave % WAVES_N) * WN;
-
-  const int tiles_n = (g.N + BN - 1) / BN;
-  const int tiles_m = (g.M + BM - 1) / BM;
-  int tile_m, tile_n;
-  if (g.m_fast) {
-    tile_n = block_x / tiles_m;
-    tile_m = block_x - tile_n * tiles_m;
-  } else {
-    tile_m = block_x / tiles_n;
-    tile_n = block_x - tile_m * tiles_n;
-  }
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  // K range of this split; tiles past kt_end read as zeros (K limit folded into the loaders)
-  const int kt_total = g.ktiles0 + g.ktiles1;
-  const int kt_begin = (int)(((long)kt_total * block_z) / g.splits);
-  const int kt_end = (int)(((long)kt_total * (block_z + 1)) / g.splits);
-  const bool dual = g.ktiles1 > 0;
-
-  PStager<BM, LA, PD> sa;
-  PStager<BN, LB, PD> sb;
-  sa.init(g.a0, g.a1, dual, m0, tid, kt_end * BK, (kt_end - g.ktiles0) * BK);
-  sb.init(g.b0, g.b1, dual, n0, tid, kt_end * BK, (kt_end - g.ktiles0) * BK);
-
-  f32x4_t acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
-
-  auto issue = [&](int slot, int t) {
-    const bool seg = t >= g.ktiles0;  // uniform
-    const int k = (seg ? t - g.ktiles0 : t) * BK + (tid & 7) * 8;
-    sa.fetch(slot, seg, k);
-    sb.fetch(slot, seg, k);
-  };
-
-#pragma unroll
-  for (int u = 0; u < PD; ++u) issue(u, kt_begin + u);
-  sa.commit(0, lds, tid);
-  sb.commit(0, lds + A_BYTES, tid);
-  __syncthreads();
-
-  int cur = 0;
-  for (int kt = kt_begin; kt < kt_end; kt += PD) {
-#pragma unroll
-    for (int u = 0; u < PD; ++u) {
-      const int t = kt + u;
-      // LDS[cur] holds tile t (it came from slot u); refill the slot with tile t + PD.  Every step issues the same
-      // loads whether or not t is past the end (then they are out of range and free), so the in-flight count is static.
-      issue(u, t + PD);
-      if (t < kt_end) {
-        const char* sA = lds + cur * STAGE;
-        const char* sB = sA + A_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < BK / 32; ++ks) {
-          bf16x8_t fa[FM], fb[FN];
-          const int chunk = ks * 4 + (lane >> 4);
-#pragma unroll
-          for (int i = 0; i < FM; ++i)
-            fa[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(wm0 + i * 16 + (lane & 15), chunk));
-#pragma unroll
-          for (int j = 0; j < FN; ++j)
-            fb[j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(wn0 + j * 16 + (lane & 15), chunk));
-#pragma unroll
-          for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-        }
-      }
-      // tile t + 1 (slot u+1) -> the other LDS stage; PD - 1 younger tiles stay in flight
-      char* nA = lds + (cur ^ 1) * STAGE;
-      sa.commit((u + 1) % PD, nA, tid);
-      sb.commit((u + 1) % PD, nA + A_BYTES, tid);
-      __syncthreads();
-      cur ^= 1;
-    }
-  }
-
-  // ---------------------------------------------------------------- epilogue
-  // acc[i][j][e]: output row m = m0+wm0+i*16+(lane&15); col n = n0+wn0+j*16 + 4*(lane>>4) + e
-  const EpiParams& ep = g.epi;
-  if constexpr (EPI == EPI_BF16) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int row = wm0 + i * 16 + (lane & 15);
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int col = wn0 + j * 16 + (lane >> 4) * 4;
-        float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-        if (ep.bias != nullptr && (n0 + col) < g.N) {
-          const uint2 bb = *reinterpret_cast<const uint2*>(ep.bias + n0 + col);
-          v0 += bf16lo(bb.x);
-          v1 += bf16hi(bb.x);
-          v2 += bf16lo(bb.y);
-          v3 += bf16hi(bb.y);
-        }
-        *reinterpret_cast<uint2*>(lds + row * C_PITCH + col * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-      }
-    }
-    __syncthreads();
-    constexpr int CPR = BN / 8;  // 16-byte chunks per row
-    for (int id = tid; id < BM * CPR; id += NTHREADS) {
-      const int row = id / CPR, cc = id - row * CPR;
-      const int m = m0 + row, n = n0 + cc * 8;
-      if (m >= g.M || n >= g.N) continue;
-      uint4 v = *reinterpret_cast<const uint4*>(lds + row * C_PITCH + cc * 16);
-      if (ep.rowbias != nullptr) {
-        const uint4 r = *reinterpret_cast<const uint4*>(ep.rowbias + (long)(m / ep.rows_per_sample) * ep.rowbias_ld + n);
-        v.x = pack_bf16x2(bf16lo(v.x) + bf16lo(r.x), bf16hi(v.x) + bf16hi(r.x));
-        v.y = pack_bf16x2(bf16lo(v.y) + bf16lo(r.y), bf16hi(v.y) + bf16hi(r.y));
-        v.z = pack_bf16x2(bf16lo(v.z) + bf16lo(r.z), bf16hi(v.z) + bf16hi(r.z));
-        v.w = pack_bf16x2(bf16lo(v.w) + bf16lo(r.w), bf16hi(v.w) + bf16hi(r.w));
-      }
-      if (ep.residual != nullptr) {
-        const uint4 r = *reinterpret_cast<const uint4*>(ep.residual + (long)m * ep.ldr + n);
-        v.x = pack_bf16x2(bf16lo(v.x) + bf16lo(r.x), bf16hi(v.x) + bf16hi(r.x));
-        v.y = pack_bf16x2(bf16lo(v.y) + bf16lo(r.y), bf16hi(v.y) + bf16hi(r.y));
-        v.z = pack_bf16x2(bf16lo(v.z) + bf16lo(r.z), bf16hi(v.z) + bf16hi(r.z));
-        v.w = pack_bf16x2(bf16lo(v.w) + bf16lo(r.w), bf16hi(v.w) + bf16hi(r.w));
-      }
-      if (ep.C != nullptr) *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + n) = v;
-      if (ep.C2 != nullptr) {
-        const uint4 s =
-            *reinterpret_cast<const uint4*>(ep.rowscale + (long)(m / ep.rows_per_sample) * g.N + n);
-        uint4 o;
-        o.x = pack_bf16x2(bf16lo(v.x) * bf16lo(s.x), bf16hi(v.x) * bf16hi(s.x));
-        o.y = pack_bf16x2(bf16lo(v.y) * bf16lo(s.y), bf16hi(v.y) * bf16hi(s.y));
-        o.z = pack_bf16x2(bf16lo(v.z) * bf16lo(s.z), bf16hi(v.z) * bf16hi(s.z));
-        o.w = pack_bf16x2(bf16lo(v.w) * bf16lo(s.w), bf16hi(v.w) * bf16hi(s.w));
-        *reinterpret_cast<uint4*>(ep.C2 + (long)m * ep.ldc2 + n) = o;
-      }
-    }
-  } else {
-    float* out = ep.Cf + (long)block_z * g.M * ep.ldcf;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int m = m0 + wm0 + i * 16 + (lane & 15);
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int n = n0 + wn0 + j * 16 + (lane >> 4) * 4;
-        if (m >= g.M || n >= g.N) continue;
-        *reinterpret_cast<float4*>(out + (long)m * ep.ldcf + n) =
-            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-      }
-    }
-  }
-}
-
-template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int PD>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel_p(const GemmArgs<LA, LB> g) {
-  const int nblk = gridDim.x, bid = blockIdx.x;
-  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  gemm_body_p<BM, BN, WM, WN, LA, LB, EPI, PD>(g, logical, blockIdx.z);
-}
-
-template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int PD>
-inline void launch_gemm_p(const GemmArgs<LA, LB>& g, hipStream_t stream) {
-  dim3 grid(aql_cdiv(g.M, BM) * aql_cdiv(g.N, BN), 1, g.splits);
-  hipLaunchKernelGGL((gemm_kernel_p<BM, BN, WM, WN, LA, LB, EPI, PD>), grid, dim3(NTHREADS), 0, stream, g);
-}
-
-template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG>
+template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG, int ABL = 0>
 __device__ __forceinline__ void gemm_body_d(const GemmArgs<LA, LB>& g, const int block_x, const int block_z) {
   static_assert(EPI != EPI_ATOMIC && !LA::kTrans, "bf16 / slab epilogues only");
   constexpr int FM = WM / 16, FN = WN / 16;
@@ -916,11 +754,11 @@ __device__ __forceinline__ void gemm_body_d(const GemmArgs<LA, LB>& g, const int
   const int kt_end = (int)(((long)kt_total * (block_z + 1)) / g.splits);
   const bool dual = g.ktiles1 > 0;
 
-  PStager<BM, LA, 1> sa;  // row descriptors only: tiles go global -> LDS directly (no staging registers, no ds_write)
-  PStager<BN, LB, 1> sb;
+  DmaStager<BM, LA> sa;  // row descriptors only: tiles go global -> LDS directly (no staging registers, no ds_write)
+  DmaStager<BN, LB> sb;
   constexpr int NLD = BM / 32 + BN / 32;  // LDS-DMA instructions per thread per K tile
-  sa.init(g.a0, g.a1, dual, m0, tid, kt_end * BK, (kt_end - g.ktiles0) * BK);
-  sb.init(g.b0, g.b1, dual, n0, tid, kt_end * BK, (kt_end - g.ktiles0) * BK);
+  sa.begin(g.a0, g.a1, dual, m0, tid, kt_begin, kt_end, g.ktiles0);
+  sb.begin(g.b0, g.b1, dual, n0, tid, kt_begin, kt_end, g.ktiles0);
 
   f32x4_t acc[FM][FN];
 #pragma unroll
@@ -930,14 +768,10 @@ __device__ __forceinline__ void gemm_body_d(const GemmArgs<LA, LB>& g, const int
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
-  // lane (row = 32i + tid>>3, slot = tid&7) fetches source chunk slot ^ ((row >> 1) & 7) = (tid&7) ^ ((tid>>4)&7)
-  const int kc = (((tid & 7) ^ ((tid >> 4) & 7))) * 8;
-  auto issue = [&](int stage, int t) {
-    const bool seg = t >= g.ktiles0;  // uniform
-    const int k = (seg ? t - g.ktiles0 : t) * BK + kc;
+  auto issue = [&](int stage, int) {  // stages the NEXT tile of the K range (tiles are requested in order)
     char* sA = lds + stage * STAGE;
-    sa.dma(sA, wave, seg, k);
-    sb.dma(sA + A_BYTES, wave, seg, k);
+    sa.dma(sA, wave);
+    sb.dma(sA + A_BYTES, wave);
   };
 
   // NSTG LDS stages, NSTG-1 K tiles in flight; ONE barrier per K tile:
@@ -950,14 +784,23 @@ __device__ __forceinline__ void gemm_body_d(const GemmArgs<LA, LB>& g, const int
 
   int rd = 0, wr = NSTG - 1;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
+    // ABL == 9: per-step timestamps of one wave (tools/trace_gemm.py); slots: loop top, data landed, barrier passed, DMA
+    // issued; the next loop top closes the compute phase
+    long* trace = nullptr;
+    if (ABL == 9 && (block_x == 0 || block_x == 300) && block_z == 0 && (tid & 63) == 0)
+      trace = reinterpret_cast<long*>(g.epi.Cf) + ((block_x ? 4 : 0) + wave) * 1024 + (kt - kt_begin) * 4;
+    if (ABL == 9 && trace) trace[0] = clock64();
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * NLD) : "memory");
+    if (ABL == 9 && trace) trace[1] = clock64();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    issue(wr, kt + NSTG - 1);
+    if (ABL == 9 && trace) trace[2] = clock64();
+    if (ABL != 3 && ABL != 4) issue(wr, kt + NSTG - 1);
+    if (ABL == 9 && trace) trace[3] = clock64();  // ABL: ablation probes (tools/tune_gemm.py), 0 in production
     const char* sA = lds + rd * STAGE;
     const char* sB = sA + A_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
+    for (int ks = 0; ks < ((ABL == 2 || ABL == 4) ? 0 : BK / 32); ++ks) {
       bf16x8_t fa[FM], fb[FN];
       const int chunk = ks * 4 + (lane >> 4);
 #pragma unroll
@@ -970,7 +813,11 @@ __device__ __forceinline__ void gemm_body_d(const GemmArgs<LA, LB>& g, const int
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+          if (ABL == 1) {  // keep the LDS reads alive without the MFMA
+            asm volatile("" ::"v"(fb[j]), "v"(fa[i]));
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+          }
     }
     rd = (rd + 1 == NSTG) ? 0 : rd + 1;
     wr = (wr + 1 == NSTG) ? 0 : wr + 1;
@@ -1049,18 +896,18 @@ __device__ __forceinline__ void gemm_body_d(const GemmArgs<LA, LB>& g, const int
   }
 }
 
-template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG>
+template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG, int ABL = 0>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel_d(const GemmArgs<LA, LB> g) {
   const int nblk = gridDim.x, bid = blockIdx.x;
   const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
   const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  gemm_body_d<BM, BN, WM, WN, LA, LB, EPI, NSTG>(g, logical, blockIdx.z);
+  gemm_body_d<BM, BN, WM, WN, LA, LB, EPI, NSTG, ABL>(g, logical, blockIdx.z);
 }
 
-template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG>
+template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG, int ABL = 0>
 inline void launch_gemm_d(const GemmArgs<LA, LB>& g, hipStream_t stream) {
   dim3 grid(aql_cdiv(g.M, BM) * aql_cdiv(g.N, BN), 1, g.splits);
-  hipLaunchKernelGGL((gemm_kernel_d<BM, BN, WM, WN, LA, LB, EPI, NSTG>), grid, dim3(NTHREADS), 0, stream, g);
+  hipLaunchKernelGGL((gemm_kernel_d<BM, BN, WM, WN, LA, LB, EPI, NSTG, ABL>), grid, dim3(NTHREADS), 0, stream, g);
 }
 
 template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG = 2>

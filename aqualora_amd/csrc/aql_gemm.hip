@@ -1,5 +1,6 @@
 // C-ABI entry points built on the MFMA GEMM core (aql_gemm.cuh).  See include/aqualora_hip.h for the
 // contract of every symbol and the reference interface (file:line) it replaces.
+#include <type_traits>
 #include "aql_gemm.cuh"
 #include <stdarg.h>
 #include <stdlib.h>
@@ -84,6 +85,11 @@ inline int pick_splits(int tiles, int kt_total, long M, int N, size_t ws_bytes) 
   return s < 1 ? 1 : s;
 }
 
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
 // Tile configurations.  ids 0-4: the transposing (token-reduction) kernels on the 32x32x16 MFMA; ids 5-10: the
 // pipelined buffer-load kernels on the 16x16x32 MFMA used by every bf16-output GEMM / conv.
 enum { P_128x160 = 5, P_64x160 = 6, P_32x160 = 7, P_64x64 = 8, P_128x32 = 9, P_128x128 = 10 };
@@ -98,14 +104,21 @@ void launch_cfg(int cfg, int pd, const GemmArgs<LA, LB>& g, hipStream_t stream) 
       default: launch_gemm<64, 64, 32, 32, LA, LB, EPI>(g, stream); break;
     }
   } else {
-// pd: 1/2/4 = register-staged loads, that many K tiles in flight; 12 = LDS-DMA with two stages; 13 = LDS-DMA with as many
-// stages as fit the 160 KB LDS (DEEP), for grids of at most one workgroup per CU
+// pd: 12 = LDS-DMA ring with two stages; 13 = as many stages as fit the 160 KB LDS (DEEP), for grids of at most one
+// workgroup per CU
 #define AQL_P(BM, BN, WM, WN, PDHI, DEEP)                                                        \
-  if (pd == 12) return launch_gemm_d<BM, BN, WM, WN, LA, LB, EPI, 2>(g, stream);                 \
   if (pd == 13) return launch_gemm_d<BM, BN, WM, WN, LA, LB, EPI, DEEP>(g, stream);              \
-  if (pd <= 1) return launch_gemm_p<BM, BN, WM, WN, LA, LB, EPI, 1>(g, stream);                  \
-  if (pd == 2) return launch_gemm_p<BM, BN, WM, WN, LA, LB, EPI, 2>(g, stream);                  \
-  return launch_gemm_p<BM, BN, WM, WN, LA, LB, EPI, PDHI>(g, stream);
+  return launch_gemm_d<BM, BN, WM, WN, LA, LB, EPI, 2>(g, stream);
+    if constexpr (std::is_same<LA, ConvFwdLoader>::value && EPI == EPI_BF16) {  // ablation probes, never in production
+      static const int abl = env_int("AQL_ABL", 0);
+      if (abl && cfg == P_64x160) {
+        if (abl == 1) return launch_gemm_d<64, 160, 32, 80, LA, LB, EPI, 2, 1>(g, stream);
+        if (abl == 2) return launch_gemm_d<64, 160, 32, 80, LA, LB, EPI, 2, 2>(g, stream);
+        if (abl == 3) return launch_gemm_d<64, 160, 32, 80, LA, LB, EPI, 2, 3>(g, stream);
+        if (abl == 9) return launch_gemm_d<64, 160, 32, 80, LA, LB, EPI, 2, 9>(g, stream);
+        return launch_gemm_d<64, 160, 32, 80, LA, LB, EPI, 2, 4>(g, stream);
+      }
+    }
     switch (cfg) {
       case P_128x160: { AQL_P(128, 160, 64, 80, 3, 4) }
       case P_64x160: { AQL_P(64, 160, 32, 80, 4, 5) }
@@ -138,11 +151,6 @@ inline int pick_cfg(long M, int N, int kt_total, bool can_split, int* tiles) {
   }
   *tiles = t6464;
   return 3;
-}
-
-static int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
 }
 
 // Tile + prefetch depth for a bf16-output GEMM.  Every channel count of the U-Net is a multiple of 160, so the 160-wide
@@ -207,6 +215,7 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
     AQL_CHECK_LAUNCH(name);
     return AQL_OK;
   }
+  g.epi.Cf = ws;  // only read by the ablation/trace probes
   g.epi.C = o.C;
   g.epi.ldc = o.ldc;
   g.epi.bias = o.bias;

@@ -504,7 +504,8 @@ def test_stage1_pieces_vs_reference_golden_and_oracle(golden):
         p.grad = None
     step = S1.Stage1Step(enc, dec, vae_decode(Wd), NZ.Noiser(["Identity", "Jpeg"], [1.0, 0.0]))
     step.warmup = False
-    out = step.losses(lat.to(DEV), msg.to(DEV), epochs_done=11, noiser_choice=[1.0, 0.0])
+    out = step.losses(lat.to(DEV), msg.to(DEV), epochs_done=11, combine={"cornerfy_aug": False},
+                      noiser_choice=[1.0, 0.0])
     out["loss"].backward()
     assert abs(out["prvl_loss"].item() - prvl_r.item()) < 1e-5 * max(1.0, prvl_r.item())
     assert abs(out["msgloss"].item() - msgloss_r.item()) < 2e-4 * max(1.0, msgloss_r.item())
