@@ -910,6 +910,204 @@ inline void launch_gemm_d(const GemmArgs<LA, LB>& g, hipStream_t stream) {
   hipLaunchKernelGGL((gemm_kernel_d<BM, BN, WM, WN, LA, LB, EPI, NSTG, ABL>), grid, dim3(NTHREADS), 0, stream, g);
 }
 
+template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG>
+__device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int block_x, const int block_z) {
+  static_assert(EPI != EPI_ATOMIC && !LA::kTrans, "bf16 / slab epilogues only");
+  constexpr int FM = WM / 16, FN = WN / 16;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * (BN / WN) == 4, "4 compute wavefronts (+ 4 loader wavefronts) per workgroup");
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int C_PITCH = (BN + 8) * 2;  // bytes per row of the bf16 C tile staged in LDS
+  constexpr int LDS_BYTES = (NSTG * STAGE > BM * C_PITCH) ? NSTG * STAGE : BM * C_PITCH;
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+
+  // Wave specialisation: wavefronts 0-3 only read LDS and issue MFMAs, wavefronts 4-7 only issue the LDS-DMA loads.  An
+  // in-kernel trace of the 4-wave kernel showed a wave stuck ~720 of 1800 cycles per K tile in the ISSUE of its loads
+  // (the texture-address unit accepts 64 B/clk, the instruction blocks until accepted) before it could start its MFMAs;
+  // with dedicated loader waves the matrix pipes never wait behind a load issue.
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the role branch below is a uniform branch
+  const bool loader = wave >= 4;
+  const int ltid = tid & 255;                                   // loader waves: the 256-thread staging layout
+  const int wm0 = ((wave & 3) / WAVES_N) * WM;
+  const int wn0 = ((wave & 3) % WAVES_N) * WN;
+
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int tiles_m = (g.M + BM - 1) / BM;
+  int tile_m, tile_n;
+  if (g.m_fast) {
+    tile_n = block_x / tiles_m;
+    tile_m = block_x - tile_n * tiles_m;
+  } else {
+    tile_m = block_x / tiles_n;
+    tile_n = block_x - tile_m * tiles_n;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // K range of this split; tiles past kt_end read as zeros (K limit folded into the loaders)
+  const int kt_total = g.ktiles0 + g.ktiles1;
+  const int kt_begin = (int)(((long)kt_total * block_z) / g.splits);
+  const int kt_end = (int)(((long)kt_total * (block_z + 1)) / g.splits);
+  const bool dual = g.ktiles1 > 0;
+
+  constexpr int NLD = BM / 32 + BN / 32;  // LDS-DMA instructions per loader thread per K tile
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+  // Ring of NSTG LDS stages, NSTG-1 K tiles in flight, ONE barrier per K tile.  Step t:
+  //   loaders : wait until their DMAs of tile t landed            | compute : (finished tile t-1)
+  //   ---------------------------------- s_barrier ----------------------------------
+  //   loaders : refill tile t-1's stage with tile t+NSTG-1         | compute : ds_read + MFMA on tile t
+  // Tiles past the end are out-of-range DMAs (zero fill, no traffic), so the counted wait is a compile-time constant.
+  // The two roles are separate loops (same barrier count) so that the stager state and the accumulators never share a
+  // live range: the compute loop then has the registers to fetch the fragments of BOTH k halves of a tile up front.
+  if (loader) {
+    DmaStager<BM, LA> sa;  // row descriptors only: tiles go global -> LDS directly (no staging registers, no ds_write)
+    DmaStager<BN, LB> sb;
+    sa.begin(g.a0, g.a1, dual, m0, ltid, kt_begin, kt_end, g.ktiles0);
+    sb.begin(g.b0, g.b1, dual, n0, ltid, kt_begin, kt_end, g.ktiles0);
+    auto issue = [&](int stage) {  // stages the NEXT tile of the K range (tiles are requested in order)
+      char* sA = lds + stage * STAGE;
+      sa.dma(sA, wave - 4);
+      sb.dma(sA + A_BYTES, wave - 4);
+    };
+#pragma unroll
+    for (int u = 0; u < NSTG - 1; ++u) issue(u);
+    int wr = NSTG - 1;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * NLD) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue(wr);
+      wr = (wr + 1 == NSTG) ? 0 : wr + 1;
+    }
+  } else {
+    int rd = 0;
+    const int arow = (wm0 + (lane & 15)), brow = (wn0 + (lane & 15));
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char* sA = lds + rd * STAGE;
+      const char* sB = sA + A_BYTES;
+      bf16x8_t fa[2][FM], fb[2][FN];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int chunk = ks * 4 + (lane >> 4);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(brow + j * 16, chunk));
+#pragma unroll
+        for (int i = 0; i < FM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(arow + i * 16, chunk));
+      }
+      // all 2*(FM+FN) fragment reads are in flight before the first MFMA; the compiler then only needs counted
+      // lgkmcnt(n) waits (LDS returns in order), so the reads of the second k half land under the MFMAs of the first
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+      rd = (rd + 1 == NSTG) ? 0 : rd + 1;
+    }
+  }
+  // the trailing (zero-fill) DMAs still write LDS: retire them before the C tile reuses it
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---------------------------------------------------------------- epilogue
+  // acc[i][j][e]: output row m = m0+wm0+i*16+(lane&15); col n = n0+wn0+j*16 + 4*(lane>>4) + e
+  const EpiParams& ep = g.epi;
+  if constexpr (EPI == EPI_BF16) {
+    if (!loader) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int row = wm0 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int col = wn0 + j * 16 + (lane >> 4) * 4;
+          float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+          if (ep.bias != nullptr && (n0 + col) < g.N) {
+            const uint2 bb = *reinterpret_cast<const uint2*>(ep.bias + n0 + col);
+            v0 += bf16lo(bb.x);
+            v1 += bf16hi(bb.x);
+            v2 += bf16lo(bb.y);
+            v3 += bf16hi(bb.y);
+          }
+          *reinterpret_cast<uint2*>(lds + row * C_PITCH + col * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+        }
+      }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;  // 16-byte chunks per row
+    for (int id = tid; id < BM * CPR; id += 2 * NTHREADS) {
+      const int row = id / CPR, cc = id - row * CPR;
+      const int m = m0 + row, n = n0 + cc * 8;
+      if (m >= g.M || n >= g.N) continue;
+      uint4 v = *reinterpret_cast<const uint4*>(lds + row * C_PITCH + cc * 16);
+      if (ep.rowbias != nullptr) {
+        const uint4 r = *reinterpret_cast<const uint4*>(ep.rowbias + (long)(m / ep.rows_per_sample) * ep.rowbias_ld + n);
+        v.x = pack_bf16x2(bf16lo(v.x) + bf16lo(r.x), bf16hi(v.x) + bf16hi(r.x));
+        v.y = pack_bf16x2(bf16lo(v.y) + bf16lo(r.y), bf16hi(v.y) + bf16hi(r.y));
+        v.z = pack_bf16x2(bf16lo(v.z) + bf16lo(r.z), bf16hi(v.z) + bf16hi(r.z));
+        v.w = pack_bf16x2(bf16lo(v.w) + bf16lo(r.w), bf16hi(v.w) + bf16hi(r.w));
+      }
+      if (ep.residual != nullptr) {
+        const uint4 r = *reinterpret_cast<const uint4*>(ep.residual + (long)m * ep.ldr + n);
+        v.x = pack_bf16x2(bf16lo(v.x) + bf16lo(r.x), bf16hi(v.x) + bf16hi(r.x));
+        v.y = pack_bf16x2(bf16lo(v.y) + bf16lo(r.y), bf16hi(v.y) + bf16hi(r.y));
+        v.z = pack_bf16x2(bf16lo(v.z) + bf16lo(r.z), bf16hi(v.z) + bf16hi(r.z));
+        v.w = pack_bf16x2(bf16lo(v.w) + bf16lo(r.w), bf16hi(v.w) + bf16hi(r.w));
+      }
+      if (ep.C != nullptr) *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + n) = v;
+      if (ep.C2 != nullptr) {
+        const uint4 s =
+            *reinterpret_cast<const uint4*>(ep.rowscale + (long)(m / ep.rows_per_sample) * g.N + n);
+        uint4 o;
+        o.x = pack_bf16x2(bf16lo(v.x) * bf16lo(s.x), bf16hi(v.x) * bf16hi(s.x));
+        o.y = pack_bf16x2(bf16lo(v.y) * bf16lo(s.y), bf16hi(v.y) * bf16hi(s.y));
+        o.z = pack_bf16x2(bf16lo(v.z) * bf16lo(s.z), bf16hi(v.z) * bf16hi(s.z));
+        o.w = pack_bf16x2(bf16lo(v.w) * bf16lo(s.w), bf16hi(v.w) * bf16hi(s.w));
+        *reinterpret_cast<uint4*>(ep.C2 + (long)m * ep.ldc2 + n) = o;
+      }
+    }
+  } else if (!loader) {
+    float* out = ep.Cf + (long)block_z * g.M * ep.ldcf;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int m = m0 + wm0 + i * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn0 + j * 16 + (lane >> 4) * 4;
+        if (m >= g.M || n >= g.N) continue;
+        *reinterpret_cast<float4*>(out + (long)m * ep.ldcf + n) =
+            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG>
+__global__ __launch_bounds__(2 * NTHREADS) void gemm_kernel_w(const GemmArgs<LA, LB> g) {
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  gemm_body_w<BM, BN, WM, WN, LA, LB, EPI, NSTG>(g, logical, blockIdx.z);
+}
+
+template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG>
+inline void launch_gemm_w(const GemmArgs<LA, LB>& g, hipStream_t stream) {
+  dim3 grid(aql_cdiv(g.M, BM) * aql_cdiv(g.N, BN), 1, g.splits);
+  hipLaunchKernelGGL((gemm_kernel_w<BM, BN, WM, WN, LA, LB, EPI, NSTG>), grid, dim3(2 * NTHREADS), 0, stream, g);
+}
+
 template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG = 2>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs<LA, LB> g) {
   // XCD-aware remap (guide T1): hardware block b runs on XCD b % 8, each XCD has a private L2.  Give every XCD a

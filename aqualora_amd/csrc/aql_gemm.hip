@@ -92,7 +92,7 @@ static int env_int(const char* name, int dflt) {
 
 // Tile configurations.  ids 0-4: the transposing (token-reduction) kernels on the 32x32x16 MFMA; ids 5-10: the
 // pipelined buffer-load kernels on the 16x16x32 MFMA used by every bf16-output GEMM / conv.
-enum { P_128x160 = 5, P_64x160 = 6, P_32x160 = 7, P_64x64 = 8, P_128x32 = 9, P_128x128 = 10 };
+enum { P_128x160 = 5, P_64x160 = 6, P_32x160 = 7, P_64x64 = 8, P_128x32 = 9, P_128x128 = 10, P_W128x160 = 11, P_W64x160 = 12 };
 
 template <class LA, class LB, int EPI>
 void launch_cfg(int cfg, int pd, const GemmArgs<LA, LB>& g, hipStream_t stream) {
@@ -119,6 +119,8 @@ void launch_cfg(int cfg, int pd, const GemmArgs<LA, LB>& g, hipStream_t stream) 
         return launch_gemm_d<64, 160, 32, 80, LA, LB, EPI, 2, 4>(g, stream);
       }
     }
+    if (cfg == P_W128x160) return launch_gemm_w<128, 160, 64, 80, LA, LB, EPI, 4>(g, stream);
+    if (cfg == P_W64x160) return launch_gemm_w<64, 160, 32, 80, LA, LB, EPI, 5>(g, stream);
     switch (cfg) {
       case P_128x160: { AQL_P(128, 160, 64, 80, 3, 4) }
       case P_64x160: { AQL_P(64, 160, 32, 80, 4, 5) }
@@ -166,10 +168,20 @@ inline void pick_tile(long M, int N, int kt_total, bool can_split, int* cfg, int
     else if (t64 >= 200) *cfg = P_64x160, *tiles = t64;
     else if (t32 >= 128) *cfg = P_32x160, *tiles = t32;
     else *cfg = P_64x64, *tiles = aql_cdiv(M, 64) * aql_cdiv(N, 64);
+    // wave-specialised kernels (one 8-wave workgroup per CU): they win when the grid is a whole number of chip-wide
+    // rounds and K is long enough to amortise the un-overlapped prologue / epilogue (measured, tools/tune_gemm.py)
+    static const int use_w = env_int("AQL_W", 1);
+    if (use_w && kt_total >= 8) {
+      if (t128 >= 240 && t128 <= 768) *cfg = P_W128x160, *tiles = t128;
+      else if (deep && t128 < 240 && use_w != 3) *cfg = P_W128x160, *tiles = t128;  // split K up to one chip-wide round
+      else if (t128 < 240 && t64 >= 240 && t64 <= 512) *cfg = P_W64x160, *tiles = t64;
+    }
     if (force >= P_128x160 && force <= P_32x160) {
       *cfg = force;
       *tiles = aql_cdiv(M, force == P_128x160 ? 128 : force == P_64x160 ? 64 : 32) * nt;
     }
+    if (force == P_W128x160) *cfg = force, *tiles = t128;
+    if (force == P_W64x160) *cfg = force, *tiles = t64;
   } else if (N <= 32) {
     *cfg = P_128x32, *tiles = aql_cdiv(M, 128);
   } else {
@@ -197,6 +209,13 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
   pick_tile(g.M, g.N, kt_total, ws != nullptr && o.C2 == nullptr, &cfg, &tiles, &pd);
   int splits = 1;
   if (ws != nullptr && o.C2 == nullptr) splits = pick_splits(tiles, kt_total, g.M, g.N, ws_bytes);
+  if ((cfg == P_W128x160 || cfg == P_W64x160) && splits > 1) {
+    // one workgroup per CU: aim at exactly one (or two) chip-wide rounds
+    int s2 = 256 / tiles;
+    if (s2 < 1) s2 = 1;
+    while (s2 > 1 && (kt_total / s2 < 8 || (size_t)s2 * (size_t)g.M * (size_t)g.N * 4u > ws_bytes)) --s2;
+    splits = s2;
+  }
   g.splits = splits;
   // LDS-DMA staging everywhere (measured fastest on every shape, hot or cold operands); a grid of <= 1 workgroup per CU
   // cannot hide latency with occupancy, so it gets the deep stage ring instead
