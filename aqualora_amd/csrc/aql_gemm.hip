@@ -307,31 +307,38 @@ __global__ __launch_bounds__(256) void lora_down_skinny_kernel(const bf16_t* __r
   const long row = (long)blockIdx.x * 16 + (lane & 15);
   const int g = lane >> 4;
   const bool ok = row < M;
-  const bf16_t* xp = X + (ok ? row : 0) * ldx + g * 8;
-  const bf16_t* ap = A + (long)(lane & 15) * K + g * 8;
+  // raw buffer loads: rows past M and K steps past the end are out-of-range offsets (hardware zero fill), so there is
+  // no branch around any load and all D*(1+RF) loads of an iteration are in flight together
+  const __amdgpu_buffer_rsrc_t rx = aqlgemm::make_rsrc(X), ra = aqlgemm::make_rsrc(A);
+  const uint32_t xoff = ok ? (uint32_t)(row * ldx + g * 8) * 2u : aqlgemm::OOB_ROW;
+  const uint32_t aoff = (uint32_t)((lane & 15) * K + g * 8) * 2u;
   f32x4_t acc[RF];
 #pragma unroll
   for (int f = 0; f < RF; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  constexpr int D = 4;  // steps in flight per wavefront
+  constexpr int D = 8;  // steps in flight per wavefront
   const int nsteps = K / 32;
   for (int s0 = wave; s0 < nsteps; s0 += 4 * D) {
-    uint4 xv[D], av[D][RF];
+    aqlgemm::u32x4_t xv[D], av[D][RF];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const int s = s0 + 4 * d;
-      const bool in = ok && s < nsteps;
-      xv[d] = in ? *reinterpret_cast<const uint4*>(xp + s * 32) : make_uint4(0u, 0u, 0u, 0u);
+      if (s < nsteps) {  // wave-uniform: a skipped step issues nothing (an out-of-range load still costs an issue slot)
+        const uint32_t so = (uint32_t)s * 64u;
+        xv[d] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff + so, 0, 0);
 #pragma unroll
-      for (int f = 0; f < RF; ++f)
-        av[d][f] = (s < nsteps) ? *reinterpret_cast<const uint4*>(ap + (long)f * 16 * K + s * 32)
-                                : make_uint4(0u, 0u, 0u, 0u);
+        for (int f = 0; f < RF; ++f)
+          av[d][f] = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff + (uint32_t)(f * 16 * K) * 2u + so, 0, 0);
+      }
     }
 #pragma unroll
-    for (int d = 0; d < D; ++d)
+    for (int d = 0; d < D; ++d) {
+      if (s0 + 4 * d < nsteps) {
 #pragma unroll
-      for (int f = 0; f < RF; ++f)
-        acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&av[d][f]),
-                                                         *reinterpret_cast<const bf16x8_t*>(&xv[d]), acc[f], 0, 0, 0);
+        for (int f = 0; f < RF; ++f)
+          acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&av[d][f]),
+                                                           *reinterpret_cast<const bf16x8_t*>(&xv[d]), acc[f], 0, 0, 0);
+      }
+    }
   }
 #pragma unroll
   for (int f = 0; f < RF; ++f) part[wave][f][lane] = acc[f];

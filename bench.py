@@ -87,7 +87,7 @@ def dominant_kernels(B, device):
     with torch.no_grad():
         ms = time_kernel(lambda: ops.conv3x3(x, pk))
     fl = 2.0 * B * 64 * 64 * 320 * 9 * 320
-    out.append({"kernel": "gemm_kernel_d<64,160,32,80,ConvFwdLoader,PlainLoader,EPI_BF16,2> conv3x3 320->320 @64x64", "ms": ms,
+    out.append({"kernel": "gemm_kernel_w<128,160,64,80,ConvFwdLoader,PlainLoader,EPI_BF16,4> conv3x3 320->320 @64x64", "ms": ms,
                 "flops": fl, "achieved_tflops": fl / ms / 1e9, "frac_of_mfma_peak": fl / ms / 1e9 / MFMA_PEAK_TF})
     xs = synth.normal("k.x2", (B * 4096, 320), 1.0, 1, device).to(torch.bfloat16)
     wl = synth.normal("k.w2", (2560, 320), 0.05, 1, device)
