@@ -961,13 +961,16 @@ __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
-  // Ring of NSTG LDS stages, NSTG-1 K tiles in flight, ONE barrier per K tile.  Step t:
-  //   loaders : wait until their DMAs of tile t landed            | compute : (finished tile t-1)
-  //   ---------------------------------- s_barrier ----------------------------------
-  //   loaders : refill tile t-1's stage with tile t+NSTG-1         | compute : ds_read + MFMA on tile t
-  // Tiles past the end are out-of-range DMAs (zero fill, no traffic), so the counted wait is a compile-time constant.
+  // Ring of NSTG (>= 3) LDS stages, ONE barrier per K tile, software-pipelined across tiles.  barrier(t) certifies that
+  // tiles <= t+1 have landed and that nobody still reads tile t-1:
+  //   loaders : issue t0..t0+NSTG-2 | wait t0 | B(pre) | { wait tile t+1 | B(t) | refill stage of t-1 with tile t+NSTG-1 }
+  //   compute :                                B(pre) | read k-half 0 of t0 |
+  //             { B(t) | read k-half 1 of t | MFMA k-half 0 of t | read k-half 0 of t+1 | MFMA k-half 1 of t }
+  // so every fragment read is issued a full MFMA batch (20 x 16 cycles) before it is needed and nothing but the barrier
+  // skew is exposed.  Tiles past the end are out-of-range DMAs (zero fill, no traffic): the counted waits are constants.
   // The two roles are separate loops (same barrier count) so that the stager state and the accumulators never share a
-  // live range: the compute loop then has the registers to fetch the fragments of BOTH k halves of a tile up front.
+  // live range.
+  static_assert(NSTG >= 3, "the cross-tile prefetch needs tile t+1 resident while tile t-1's stage is refilled");
   if (loader) {
     DmaStager<BM, LA> sa;  // row descriptors only: tiles go global -> LDS directly (no staging registers, no ds_write)
     DmaStager<BN, LB> sb;
@@ -980,42 +983,81 @@ __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int
     };
 #pragma unroll
     for (int u = 0; u < NSTG - 1; ++u) issue(u);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * NLD) : "memory");  // first tile landed
+    __builtin_amdgcn_s_barrier();
     int wr = NSTG - 1;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * NLD) : "memory");
+#ifdef AQL_TRACE_W
+      long* trace = nullptr;
+      if ((block_x == 0 || block_x == 100) && block_z == 0 && lane == 0)
+        trace = reinterpret_cast<long*>(g.epi.Cf) + ((block_x ? 8 : 0) + wave) * 1024 + (kt - kt_begin) * 4;
+      if (trace) trace[0] = clock64();
+#endif
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 3) * NLD) : "memory");  // tile kt+1 landed
+#ifdef AQL_TRACE_W
+      if (trace) trace[1] = clock64();
+#endif
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+#ifdef AQL_TRACE_W
+      if (trace) trace[2] = clock64();
+#endif
       issue(wr);
+#ifdef AQL_TRACE_W
+      if (trace) trace[3] = clock64();
+#endif
       wr = (wr + 1 == NSTG) ? 0 : wr + 1;
     }
   } else {
-    int rd = 0;
     const int arow = (wm0 + (lane & 15)), brow = (wn0 + (lane & 15));
+    const int ch0 = lane >> 4, ch1 = 4 + (lane >> 4);
+    bf16x8_t fa0[FM], fb0[FN], fa1[FM], fb1[FN];
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < FN; ++j) fb0[j] = *reinterpret_cast<const bf16x8_t*>(lds + A_BYTES + lds_off(brow + j * 16, ch0));
+#pragma unroll
+    for (int i = 0; i < FM; ++i) fa0[i] = *reinterpret_cast<const bf16x8_t*>(lds + lds_off(arow + i * 16, ch0));
+    int rd = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
+#ifdef AQL_TRACE_W
+      long* trace = nullptr;
+      if ((block_x == 0 || block_x == 100) && block_z == 0 && lane == 0)
+        trace = reinterpret_cast<long*>(g.epi.Cf) + ((block_x ? 8 : 0) + wave) * 1024 + (kt - kt_begin) * 4;
+      if (trace) trace[0] = clock64();
+#endif
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+#ifdef AQL_TRACE_W
+      if (trace) trace[1] = trace[2] = clock64();
+#endif
       const char* sA = lds + rd * STAGE;
       const char* sB = sA + A_BYTES;
-      bf16x8_t fa[2][FM], fb[2][FN];
+      rd = (rd + 1 == NSTG) ? 0 : rd + 1;
+      const char* nA = lds + rd * STAGE;
+      const char* nB = nA + A_BYTES;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int chunk = ks * 4 + (lane >> 4);
+      for (int j = 0; j < FN; ++j) fb1[j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(brow + j * 16, ch1));
 #pragma unroll
-        for (int j = 0; j < FN; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(brow + j * 16, chunk));
-#pragma unroll
-        for (int i = 0; i < FM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(arow + i * 16, chunk));
-      }
-      // all 2*(FM+FN) fragment reads are in flight before the first MFMA; the compiler then only needs counted
-      // lgkmcnt(n) waits (LDS returns in order), so the reads of the second k half land under the MFMAs of the first
+      for (int i = 0; i < FM; ++i) fa1[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(arow + i * 16, ch1));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int j = 0; j < FN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
-      rd = (rd + 1 == NSTG) ? 0 : rd + 1;
+      for (int j = 0; j < FN; ++j) fb0[j] = *reinterpret_cast<const bf16x8_t*>(nB + lds_off(brow + j * 16, ch0));
+#pragma unroll
+      for (int i = 0; i < FM; ++i) fa0[i] = *reinterpret_cast<const bf16x8_t*>(nA + lds_off(arow + i * 16, ch0));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // the trailing (zero-fill) DMAs still write LDS: retire them before the C tile reuses it

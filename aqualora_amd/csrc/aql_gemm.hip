@@ -77,7 +77,8 @@ struct OutSpec {
 
 inline int pick_splits(int tiles, int kt_total, long M, int N, size_t ws_bytes) {
   // split-K pays only when K is deep (the fp32 slabs cost 8 B per output element per split) and the grid is small
-  if (tiles >= 224 || kt_total < 32) return 1;
+  static const int deep_kt = getenv("AQL_DEEPKT") ? atoi(getenv("AQL_DEEPKT")) : 32;  // tuning hook
+  if (tiles >= 224 || kt_total < deep_kt) return 1;
   int s = (320 + tiles - 1) / tiles;
   if (s > kt_total / 8) s = kt_total / 8;
   if (s > 16) s = 16;
@@ -92,7 +93,7 @@ static int env_int(const char* name, int dflt) {
 
 // Tile configurations.  ids 0-4: the transposing (token-reduction) kernels on the 32x32x16 MFMA; ids 5-10: the
 // pipelined buffer-load kernels on the 16x16x32 MFMA used by every bf16-output GEMM / conv.
-enum { P_128x160 = 5, P_64x160 = 6, P_32x160 = 7, P_64x64 = 8, P_128x32 = 9, P_128x128 = 10, P_W128x160 = 11, P_W64x160 = 12 };
+enum { P_128x160 = 5, P_64x160 = 6, P_32x160 = 7, P_64x64 = 8, P_128x32 = 9, P_128x128 = 10, P_W128x160 = 11, P_W64x160 = 12, P_W32x160 = 13 };
 
 template <class LA, class LB, int EPI>
 void launch_cfg(int cfg, int pd, const GemmArgs<LA, LB>& g, hipStream_t stream) {
@@ -121,6 +122,7 @@ void launch_cfg(int cfg, int pd, const GemmArgs<LA, LB>& g, hipStream_t stream) 
     }
     if (cfg == P_W128x160) return launch_gemm_w<128, 160, 64, 80, LA, LB, EPI, 4>(g, stream);
     if (cfg == P_W64x160) return launch_gemm_w<64, 160, 32, 80, LA, LB, EPI, 5>(g, stream);
+    if (cfg == P_W32x160) return launch_gemm_w<32, 160, 16, 80, LA, LB, EPI, 6>(g, stream);
     switch (cfg) {
       case P_128x160: { AQL_P(128, 160, 64, 80, 3, 4) }
       case P_64x160: { AQL_P(64, 160, 32, 80, 4, 5) }
@@ -160,7 +162,8 @@ inline int pick_cfg(long M, int N, int kt_total, bool can_split, int* tiles) {
 // with tools/probe_gemm.py on MI355X.
 inline void pick_tile(long M, int N, int kt_total, bool can_split, int* cfg, int* tiles, int* pd) {
   static const int force = env_int("AQL_TILE", 0), force_pd = env_int("AQL_PD", 0);  // tuning hooks
-  const bool deep = can_split && kt_total >= 32;
+  static const int deep_kt = env_int("AQL_DEEPKT", 32);  // tuning hook
+  const bool deep = can_split && kt_total >= deep_kt;
   if (N % 160 == 0) {
     const int nt = N / 160;
     const int t128 = aql_cdiv(M, 128) * nt, t64 = aql_cdiv(M, 64) * nt, t32 = aql_cdiv(M, 32) * nt;
@@ -175,6 +178,7 @@ inline void pick_tile(long M, int N, int kt_total, bool can_split, int* cfg, int
       if (t128 >= 240 && t128 <= 768) *cfg = P_W128x160, *tiles = t128;
       else if (deep && t128 < 240 && use_w != 3) *cfg = P_W128x160, *tiles = t128;  // split K up to one chip-wide round
       else if (t128 < 240 && t64 >= 240 && t64 <= 512) *cfg = P_W64x160, *tiles = t64;
+      else if (t64 < 240 && t32 >= 240 && t32 <= 512) *cfg = P_W32x160, *tiles = t32;
     }
     if (force >= P_128x160 && force <= P_32x160) {
       *cfg = force;
@@ -182,6 +186,7 @@ inline void pick_tile(long M, int N, int kt_total, bool can_split, int* cfg, int
     }
     if (force == P_W128x160) *cfg = force, *tiles = t128;
     if (force == P_W64x160) *cfg = force, *tiles = t64;
+    if (force == P_W32x160) *cfg = force, *tiles = t32;
   } else if (N <= 32) {
     *cfg = P_128x32, *tiles = aql_cdiv(M, 128);
   } else {
@@ -209,7 +214,7 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
   pick_tile(g.M, g.N, kt_total, ws != nullptr && o.C2 == nullptr, &cfg, &tiles, &pd);
   int splits = 1;
   if (ws != nullptr && o.C2 == nullptr) splits = pick_splits(tiles, kt_total, g.M, g.N, ws_bytes);
-  if ((cfg == P_W128x160 || cfg == P_W64x160) && splits > 1) {
+  if ((cfg == P_W128x160 || cfg == P_W64x160 || cfg == P_W32x160) && splits > 1) {
     // one workgroup per CU: aim at exactly one (or two) chip-wide rounds
     int s2 = 256 / tiles;
     if (s2 < 1) s2 = 1;
