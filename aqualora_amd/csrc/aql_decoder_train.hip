@@ -250,31 +250,45 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ src, 
 }
 
 // dw[tap][c] += sum_{b,yo,xo} dy[b,yo,xo,c] * x[b, yo*s+kh-pad, xo*s+kw-pad, c]; a workgroup = 64 channels x 4 lanes over a
-// chunk of output pixels, all k*k taps; one atomicAdd per (workgroup, tap, channel)
+// chunk of output pixels.  One pass over the pixels with all K*K tap sums in registers (dy read once per pixel), then one
+// atomicAdd per (workgroup, tap, channel).
+template <int K>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B,
-                                                       int H, int W, int C, int k, int stride, int chunk,
+                                                       int H, int W, int C, int stride, int chunk,
                                                        float* __restrict__ dw) {
   __shared__ float red[4][64];
-  const int pad = k / 2;
-  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  constexpr int pad = K / 2;
+  const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
   const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int c = blockIdx.y * 64 + cl;
   const long P = (long)B * Ho * Wo;
   const long p_begin = (long)blockIdx.x * chunk, p_end = min(P, p_begin + chunk);
-  for (int tap = 0; tap < k * k; ++tap) {
-    const int kh = tap / k, kw = tap - kh * k;
-    float acc = 0.f;
-    if (c < C)
-      for (long p = p_begin + part; p < p_end; p += 4) {
-        const int xo = (int)(p % Wo), yo = (int)((p / Wo) % Ho);
-        const long b = p / ((long)Wo * Ho);
-        const int yi = yo * stride + kh - pad, xi = xo * stride + kw - pad;
-        if (yi < 0 || yi >= H || xi < 0 || xi >= W) continue;
-        acc += dy[p * C + c] * x[((b * H + yi) * W + xi) * C + c];
+  float acc[K * K];
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) acc[t] = 0.f;
+  if (c < C)
+    for (long p = p_begin + part; p < p_end; p += 4) {
+      const int xo = (int)(p % Wo), yo = (int)((p / Wo) % Ho);
+      const long b = p / ((long)Wo * Ho);
+      const float g = dy[p * C + c];
+      const int y0 = yo * stride - pad, x0 = xo * stride - pad;
+#pragma unroll
+      for (int kh = 0; kh < K; ++kh) {
+        const int yi = y0 + kh;
+        if (yi < 0 || yi >= H) continue;
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+          const int xi = x0 + kw;
+          if (xi < 0 || xi >= W) continue;
+          acc[kh * K + kw] += g * x[((b * H + yi) * W + xi) * C + c];
+        }
       }
-    red[part][cl] = acc;
+    }
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) {
+    red[part][cl] = acc[t];
     __syncthreads();
-    if (part == 0 && c < C) atomicAdd(dw + (long)tap * C + c, (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
+    if (part == 0 && c < C) atomicAdd(dw + (long)t * C + c, (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
     __syncthreads();
   }
 }
@@ -350,7 +364,8 @@ __global__ __launch_bounds__(256) void stem_bwd_data_kernel(const float* __restr
   }
 }
 
-// dw[(kh,kw,ci)][co] += sum_p dy[p,co] * x[..]; workgroup = Cout (<=64) channels x 4 lanes over a chunk of output pixels
+// dw[(kh,kw,ci)][co] += sum_p dy[p,co] * x[..]; workgroup = Cout (<=64) channels x 4 lanes over a chunk of output pixels,
+// one pass with the 27 tap sums in registers
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B,
                                                          int H, int W, int Cout, int chunk, float* __restrict__ dw) {
   __shared__ float red[4][64];
@@ -358,20 +373,33 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
   const int co = threadIdx.x & 63, part = threadIdx.x >> 6;
   const long P = (long)B * Ho * Wo;
   const long p_begin = (long)blockIdx.x * chunk, p_end = min(P, p_begin + chunk);
-  for (int tap = 0; tap < 27; ++tap) {
-    const int ci = tap % 3, kw = (tap / 3) % 3, kh = tap / 9;
-    float acc = 0.f;
-    if (co < Cout)
-      for (long p = p_begin + part; p < p_end; p += 4) {
-        const int xo = (int)(p % Wo), yo = (int)((p / Wo) % Ho);
-        const long b = p / ((long)Wo * Ho);
-        const int yi = yo * 2 + kh - 1, xi = xo * 2 + kw - 1;
-        if (yi < 0 || yi >= H || xi < 0 || xi >= W) continue;
-        acc += dy[p * Cout + co] * x[((b * H + yi) * W + xi) * 3 + ci];
+  float acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = 0.f;
+  if (co < Cout)
+    for (long p = p_begin + part; p < p_end; p += 4) {
+      const int xo = (int)(p % Wo), yo = (int)((p / Wo) % Ho);
+      const long b = p / ((long)Wo * Ho);
+      const float g = dy[p * Cout + co];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int yi = yo * 2 + kh - 1;
+        if (yi < 0 || yi >= H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int xi = xo * 2 + kw - 1;
+          if (xi < 0 || xi >= W) continue;
+          const float* px = x + ((b * H + yi) * W + xi) * 3;
+#pragma unroll
+          for (int ci = 0; ci < 3; ++ci) acc[(kh * 3 + kw) * 3 + ci] += g * px[ci];
+        }
       }
-    red[part][co] = acc;
+    }
+#pragma unroll
+  for (int t = 0; t < 27; ++t) {
+    red[part][co] = acc[t];
     __syncthreads();
-    if (part == 0 && co < Cout) atomicAdd(dw + (long)tap * Cout + co, (red[0][co] + red[1][co]) + (red[2][co] + red[3][co]));
+    if (part == 0 && co < Cout) atomicAdd(dw + (long)t * Cout + co, (red[0][co] + red[1][co]) + (red[2][co] + red[3][co]));
     __syncthreads();
   }
 }
@@ -393,13 +421,17 @@ __global__ __launch_bounds__(256) void chan_scale_kernel(const float* __restrict
 }
 
 // out[b,c] = scale * sum_p a[b,p,c] * (bmul ? bmul[b,p,c] : 1)   (avgpool forward: scale = 1/HW; gate gradient: a=dy, bmul=x)
+// grid (C/64, B, nsplit): a workgroup reduces a slice of HW rows; nsplit > 1 combines with atomics (out pre-zeroed)
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restrict__ a, const float* __restrict__ bmul,
-                                                          long HW, int C, float scale, float* __restrict__ out) {
+                                                          long HW, int C, float scale, int nsplit,
+                                                          float* __restrict__ out) {
   __shared__ float red[4][64];
   const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  const long per = (HW + nsplit - 1) / nsplit;
+  const long p0 = (long)blockIdx.z * per, p1 = min(HW, p0 + per);
   float acc = 0.f;
   if (c < C)
-    for (long p = part; p < HW; p += 4) {
+    for (long p = p0 + part; p < p1; p += 4) {
       const long o = ((long)b * HW + p) * C + c;
       acc += bmul ? a[o] * bmul[o] : a[o];
     }
@@ -407,7 +439,9 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
   __syncthreads();
   if (part == 0 && c < C) {
     const int l = threadIdx.x;
-    out[(long)b * C + c] = ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) * scale;
+    const float v = ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) * scale;
+    if (nsplit > 1) atomicAdd(out + (long)b * C + c, v);
+    else out[(long)b * C + c] = v;
   }
 }
 
@@ -561,8 +595,9 @@ extern "C" int aql_dwconv_train(const float* src, const float* src2, const float
     (void)hipMemsetAsync(dst, 0, (size_t)k * k * C * sizeof(float), stream);
     const long P = (long)B * Ho * Wo;
     const int chunk = 1024;
-    hipLaunchKernelGGL(dw_wgrad_kernel, dim3((unsigned)((P + chunk - 1) / chunk), (C + 63) / 64), dim3(256), 0, stream,
-                       src, src2, B, H, W, C, k, stride, chunk, dst);
+    const dim3 grid((unsigned)((P + chunk - 1) / chunk), (C + 63) / 64);
+    if (k == 3) hipLaunchKernelGGL(dw_wgrad_kernel<3>, grid, dim3(256), 0, stream, src, src2, B, H, W, C, stride, chunk, dst);
+    else hipLaunchKernelGGL(dw_wgrad_kernel<5>, grid, dim3(256), 0, stream, src, src2, B, H, W, C, stride, chunk, dst);
   }
   AQL_CHECK_LAUNCH("aql_dwconv_train");
   return AQL_OK;
@@ -603,7 +638,15 @@ extern "C" int aql_chan_scale(const float* x, const float* g, int B, long HW, in
 extern "C" int aql_chan_reduce(const float* a, const float* bmul, int B, long HW, int C, float scale, float* out,
                                hipStream_t stream) {
   AQL_CHECK_ARG(a && out, "aql_chan_reduce: bad args");
-  hipLaunchKernelGGL(chan_reduce_kernel, dim3((C + 63) / 64, B), dim3(256), 0, stream, a, bmul, HW, C, scale, out);
+  int nsplit = 1;
+  const long blocks = (long)((C + 63) / 64) * B;
+  if (blocks < 1024 && HW >= 2048) {
+    nsplit = (int)min((long)(2048 / blocks > 0 ? 2048 / blocks : 1), HW / 512);
+    if (nsplit < 1) nsplit = 1;
+  }
+  if (nsplit > 1) (void)hipMemsetAsync(out, 0, (size_t)B * C * sizeof(float), stream);
+  hipLaunchKernelGGL(chan_reduce_kernel, dim3((C + 63) / 64, B, nsplit), dim3(256), 0, stream, a, bmul, HW, C, scale, nsplit,
+                     out);
   AQL_CHECK_LAUNCH("aql_chan_reduce");
   return AQL_OK;
 }

@@ -155,6 +155,48 @@ def infer_bench(args, device):
                       "finite": bool(torch.isfinite(out).all())}), flush=True)
 
 
+def robft_bench(args, device):
+    """BASELINE config 5, the part that trains: rob_enhance_finetune.py:1018-1036 -- generated images (synthetic here)
+    -> distortion -> SecretDecoder in train() mode (EfficientNet-B1, BatchNorm batch statistics) forward + backward ->
+    BCE -> AdamW, batch 16 at 512x512.  The 20-step sampling pipeline that produces the images runs under no_grad and is
+    `--mode infer`'s kernel path."""
+    from aqualora_amd import noise as NZ, stage1 as S1, synth
+    from aqualora_amd.decoder import SecretDecoder
+    B = 16
+    dec = SecretDecoder(48)
+    with torch.no_grad():
+        for name, t in list(dec.named_parameters()) + list(dec.named_buffers()):
+            if name.endswith("running_var"):
+                t.fill_(1.0)
+            elif name.endswith("running_mean") or name.endswith("num_batches_tracked"):
+                t.zero_()
+            elif name.endswith(".1.weight") and t.dim() == 1:
+                t.fill_(1.0)
+            elif t.dim() == 1:
+                t.zero_()
+            else:
+                fan = t[0].numel()
+                t.copy_(synth.normal("rob." + name, tuple(t.shape), (2.0 / fan) ** 0.5, 2048))
+    dec = dec.to(device).train()
+    opt = torch.optim.AdamW(dec.parameters(), lr=1e-4)
+    imgs = (synth.normal("rob.img", (B, 3, 512, 512), 0.25, 1, device) + 0.5).clamp(0, 1)
+    bits = synth.bits("rob.bits", (B, 48), 1).to(device)
+    distort = NZ.RobNoiser([0.6, 0.1, 0.15, 0.05, 0.1])
+    for _ in range(max(1, args.warmup)):
+        loss, acc = S1.rob_finetune_step(dec, opt, imgs, bits, distort)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, acc = S1.rob_finetune_step(dec, opt, imgs, bits, distort)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    gf = 3 * 6.4 * B  # fwd + bwd-data + bwd-weight of the 6.4 GFLOP/img network
+    print(json.dumps({"metric": "rob-finetune decoder step images/sec at 512x512 (EfficientNet-B1 train mode, fp32)",
+                      "value": B / dt, "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "ms_per_step": 1e3 * dt,
+                      "dtype": "f32", "higher_is_better": True, "data": "synthetic", "batch": B,
+                      "achieved_tflops_fp32": gf / dt / 1e3, "loss": float(loss), "bit_acc": float(acc)}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,7 +206,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--mode", choices=["train", "infer"], default="train",
+    ap.add_argument("--mode", choices=["train", "infer", "robft"], default="train",
                     help="train: the PPFT step (BASELINE metric); infer: 50-step DDIM + CFG latent sampling (config 4)")
     ap.add_argument("--micro", type=int, default=1, help="concurrent micro-batch slices per step")
     args = ap.parse_args()
@@ -181,6 +223,8 @@ def main():
 
     if args.mode == "infer":
         return infer_bench(args, device)
+    if args.mode == "robft":
+        return robft_bench(args, device)
     tr = build(device, args.rank, micro=args.micro)
     batch = synthetic_batch(args.batch, device, rank_id)
     runner = tr.step
