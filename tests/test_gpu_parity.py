@@ -139,6 +139,50 @@ def test_tiny_unet_forward_vs_oracle_and_golden(golden):
     assert relerr(clean, g["clean"]) < 5e-2 and relerr(pred, g["pred"]) < 5e-2
 
 
+def test_full_size_sd15_unet_forward_vs_oracle():
+    """BASELINE size: the full SD-1.5 U-Net (859.5 M synthetic parameters, 64x64x4 latents, 77x768 context) with the
+    rank-32 watermark LoRA on all 192 sites -- HIP forward (clean and watermarked) against the bf16-mirroring CPU oracle.
+    Also the size-independent properties: zero scale == skipped LoRA branch bit for bit, run-to-run determinism, and the
+    LoRA branch changing the prediction."""
+    from aqualora_amd import synth
+    from aqualora_amd.lora import inject_lora
+    from aqualora_amd.unet import SD15, UNet2DConditionModel, init_synthetic, lora_keys
+    from oracle import ppft_oracle as O
+    rank, seed = 32, 2048
+    unet = UNet2DConditionModel(device=DEV, dtype=torch.bfloat16)
+    init_synthetic(unet, seed)
+    keys = lora_keys(unet)
+    assert len(keys) == 192
+    sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
+    inject_lora(unet, rank, keys)
+    lw = {}
+    with torch.no_grad():
+        for k in keys:
+            lay = unet.get_submodule(k).lora_layer
+            lay.down.weight.copy_(synth.normal(k + ".lora.down", lay.down.weight.shape, 1.0 / rank, seed, DEV))
+            lay.up.weight.copy_(synth.normal(k + ".lora.up", lay.up.weight.shape, 0.02, seed, DEV))
+            lw[k] = (lay.down.weight.detach().float().cpu(), lay.up.weight.detach().float().cpu())
+    x = synth.normal("full.z", (1, 4, 64, 64), 1.0, seed)
+    ctx = synth.normal("full.ctx", (1, 77, 768), 1.0, seed)
+    t = torch.tensor([500])
+    S = 1.0 + 0.5 * synth.normal("full.S", (1, rank), 1.0, seed)
+    torch.set_num_threads(min(32, len(__import__("os").sched_getaffinity(0))))
+    ref = O.UNetOracle(sd, dict(SD15), lw, bf16=True)
+    with torch.no_grad():
+        clean_o = ref.forward(x, t, ctx, None)
+        pred_o = ref.forward(x, t, ctx, S)
+        xb, cb = x.to(DEV), ctx.to(DEV).to(torch.bfloat16)
+        clean = unet(xb, t.to(DEV), cb, cross_attention_kwargs={"scale": None}).sample
+        clean0 = unet(xb, t.to(DEV), cb, cross_attention_kwargs={"scale": torch.zeros_like(S).to(DEV)}).sample
+        pred = unet(xb, t.to(DEV), cb, cross_attention_kwargs={"scale": S.to(DEV)}).sample
+        pred2 = unet(xb, t.to(DEV), cb, cross_attention_kwargs={"scale": S.to(DEV)}).sample
+    assert torch.equal(clean, clean0) and torch.equal(pred, pred2)
+    assert relerr(clean, clean_o) < 4e-2, relerr(clean, clean_o)
+    assert relerr(pred, pred_o) < 4e-2, relerr(pred, pred_o)
+    lora_effect = relerr(pred_o, clean_o)
+    assert lora_effect > 1e-3 and relerr(pred.float() - clean.float(), pred_o - clean_o) < 0.35
+
+
 def test_tiny_ppft_step_vs_golden(golden):
     from aqualora_amd.ppft import PPFTTrainer
     from aqualora_amd.watermark import MapperNet, SecretEncoder
