@@ -60,6 +60,8 @@ SIGNATURES = {
     "aql_color_jiggle": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
     "aql_rotate_bilinear": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p],
     "aql_sharpness": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
+    "aql_transpose_bf16": [c_p, c_l, c_i, c_l, c_p, c_p],
+    "aql_gemm_nt_f32_accum": [c_p, c_l, c_p, c_l, c_l, c_i, c_l, c_f, c_p, c_l, c_p, ctypes.c_size_t, c_p],
     "aql_gemm_f32": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_p, c_l, c_l, c_i, c_l, c_p],
     "aql_bn_train_fwd": [c_p, c_p, c_p, c_l, c_i, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "aql_bn_train_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p],

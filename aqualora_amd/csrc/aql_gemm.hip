@@ -61,6 +61,55 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
   }
 }
 
+// C[m][n] (fp32) += alpha * sum_z slab[z][m][n]   (weight-gradient accumulation after a split-K NT GEMM)
+__global__ __launch_bounds__(256) void splitk_accum_kernel(const float* __restrict__ slabs, int splits, long M, int N,
+                                                           float alpha, float* __restrict__ C, long ldc) {
+  const long nchunk = M * (N / 4);
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < nchunk; id += (long)gridDim.x * blockDim.x) {
+    const long m = id / (N / 4);
+    const int n = (int)(id - m * (N / 4)) * 4;
+    float4 s = *reinterpret_cast<const float4*>(slabs + m * N + n);
+    for (int z = 1; z < splits; ++z) {
+      const float4 t = *reinterpret_cast<const float4*>(slabs + ((long)z * M + m) * N + n);
+      s.x += t.x, s.y += t.y, s.z += t.z, s.w += t.w;
+    }
+    float* c = C + m * ldc + n;
+    c[0] += alpha * s.x, c[1] += alpha * s.y, c[2] += alpha * s.z, c[3] += alpha * s.w;
+  }
+}
+
+// dst[c][r] = src[r][c]  (bf16, rows x cols with leading dimension ld -> cols x rows, dense); 64x64 tiles through LDS,
+// 16-byte global accesses on both sides
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, long rows, int cols, long ld,
+                                                             bf16_t* __restrict__ dst) {
+  __shared__ bf16_t tile[64][64 + 8];
+  const long r0 = (long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const int tr = threadIdx.x >> 3, tc = (threadIdx.x & 7) * 8;  // 32 rows x 8 chunks per pass
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const long r = r0 + tr + 32 * p;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (r < rows && c0 + tc < cols) v = *reinterpret_cast<const uint4*>(src + r * ld + c0 + tc);
+    *reinterpret_cast<uint4*>(&tile[tr + 32 * p][tc]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int c = tr + 32 * p;  // output row = source column
+    if (c0 + c >= cols) continue;
+    bf16_t o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = tile[tc + e][c];
+    const long r = r0 + tc;
+    if (r + 8 <= rows) {
+      *reinterpret_cast<uint4*>(dst + (long)(c0 + c) * rows + r) = *reinterpret_cast<const uint4*>(o);
+    } else {
+      for (int e = 0; e < 8 && r + e < rows; ++e) dst[(long)(c0 + c) * rows + r + e] = o[e];
+    }
+  }
+}
+
 struct OutSpec {
   const bf16_t* bias;
   const bf16_t* rowbias;
@@ -536,6 +585,56 @@ extern "C" int aql_gemm_tn_f32(const bf16_t* U, long ldu, const bf16_t* V, long 
   g.splits = splits;
   launch_cfg<TransLoader, TransLoader, EPI_ATOMIC>(cfg, 1, g, stream);
   AQL_CHECK_LAUNCH("aql_gemm_tn_f32");
+  return AQL_OK;
+}
+
+// dst [cols][rows] = src [rows][cols]^T (bf16); rows % 8 == 0 and cols % 8 == 0
+extern "C" int aql_transpose_bf16(const bf16_t* src, long rows, int cols, long ld, bf16_t* dst, hipStream_t stream) {
+  AQL_CHECK_ARG(src && dst && rows > 0 && cols > 0 && rows % 8 == 0 && cols % 8 == 0 && ld % 8 == 0,
+                "aql_transpose_bf16: bad shape rows=%ld cols=%d", rows, cols);
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)((rows + 63) / 64), (cols + 63) / 64), dim3(256), 0, stream, src,
+                     rows, cols, ld, dst);
+  AQL_CHECK_LAUNCH("aql_transpose_bf16");
+  return AQL_OK;
+}
+
+// C[M,N] (fp32) += alpha * A[M,K] . B[N,K]^T   (bf16 operands, K contiguous): the wide-rank (r > 32) LoRA weight
+// gradients dA = dT^T.X and dB = dY^T.Ts after both operands were transposed once -- the pipelined NT kernels run
+// 5-7x faster than the transposing-loader kernel on these shapes.  ws holds the split-K slabs (>= M*N*4 bytes).
+extern "C" int aql_gemm_nt_f32_accum(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, int N, long K,
+                                     float alpha, float* C, long ldc, float* ws, size_t ws_bytes, hipStream_t stream) {
+  AQL_CHECK_ARG(A && B && C && ws, "aql_gemm_nt_f32_accum: null operand");
+  AQL_CHECK_ARG(M > 0 && N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && K < (1L << 31) &&
+                    (size_t)M * N * 4u <= ws_bytes,
+                "aql_gemm_nt_f32_accum: bad shape M=%ld N=%d K=%ld", M, N, K);
+  GemmArgs<PlainLoader, PlainLoader> g;
+  g.a0 = plain(A, lda, M, (int)K);
+  g.b0 = plain(B, ldb, N, (int)K);
+  g.a1 = g.a0;
+  g.b1 = g.b0;
+  g.ktiles0 = aql_cdiv(K, BK);
+  g.ktiles1 = 0;
+  g.M = (int)M;
+  g.N = N;
+  g.epi = EpiParams{};
+  g.epi.rows_per_sample = 1;
+  g.m_fast = 0;
+  int tiles = 0, cfg = 0, pd = 1;
+  pick_tile(g.M, g.N, g.ktiles0, true, &cfg, &tiles, &pd);
+  int splits = 256 / (tiles > 0 ? tiles : 1);
+  if (splits < 1) splits = 1;
+  while (splits > 1 && (g.ktiles0 / splits < 8 || (size_t)splits * (size_t)M * (size_t)N * 4u > ws_bytes)) --splits;
+  g.splits = splits;
+  if (pd == 0) pd = (tiles * splits <= 288) ? 13 : 12;
+  g.epi.Cf = ws;
+  g.epi.ldcf = N;
+  launch_cfg<PlainLoader, PlainLoader, EPI_SLAB>(cfg, pd, g, stream);
+  AQL_CHECK_LAUNCH("aql_gemm_nt_f32_accum");
+  const long nchunk = M * (N / 4);
+  int blocks = (int)((nchunk + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_accum_kernel, dim3(blocks), dim3(256), 0, stream, ws, splits, M, N, alpha, C, ldc);
+  AQL_CHECK_LAUNCH("aql_gemm_nt_f32_accum");
   return AQL_OK;
 }
 

@@ -154,12 +154,38 @@ def gemm_bf16(A, B, bias=None, A2=None, B2=None, rowbias=None, rps=1, residual=N
     return C
 
 
+_TN_SCRATCH = {}
+
+
+def _tn_scratch(nelem, device):
+    """per-(device, stream) bf16 scratch for the transposed operands of the wide-rank weight-gradient GEMMs"""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _TN_SCRATCH.get(key)
+    if buf is None or buf.numel() < nelem:
+        buf = torch.empty(max(nelem, 1 << 24), dtype=torch.bfloat16, device=device)
+        _TN_SCRATCH[key] = buf
+    return buf
+
+
 def gemm_tn_acc(U, V, C, alpha=1.0):
-    """C[P,Q] (fp32) += alpha * U[M,P]^T V[M,Q]."""
+    """C[P,Q] (fp32) += alpha * U[M,P]^T V[M,Q].  Narrow problems (a LoRA rank <= 32 side) use the transposing-loader
+    kernel (normally through the grouped launch); wide-rank problems transpose both operands once and run the pipelined
+    NT kernels, which are 5-7x faster on these shapes (tools/probe_tn320.py)."""
     M, P = U.shape
     Q = V.shape[1]
-    L.call("aql_gemm_tn_f32", L.ptr(U), U.stride(0), L.ptr(V), V.stride(0), M, P, Q, float(alpha), L.ptr(C),
-           C.stride(0), L.stream_ptr())
+    wide = (min(P, Q) > 32 and M % 8 == 0 and M * P * Q >= 1.5e9 and U.stride(1) == 1 and V.stride(1) == 1)  # >= 3 GFLOP
+    if not wide:
+        L.call("aql_gemm_tn_f32", L.ptr(U), U.stride(0), L.ptr(V), V.stride(0), M, P, Q, float(alpha), L.ptr(C),
+               C.stride(0), L.stream_ptr())
+        return
+    st = L.stream_ptr()
+    buf = _tn_scratch(M * (P + Q), U.device)
+    Ut, Vt = buf[:M * P], buf[M * P:M * (P + Q)]
+    L.call("aql_transpose_bf16", L.ptr(U), M, P, U.stride(0), L.ptr(Ut), st)
+    L.call("aql_transpose_bf16", L.ptr(V), M, Q, V.stride(0), L.ptr(Vt), st)
+    ws = workspace(U.device)
+    L.call("aql_gemm_nt_f32_accum", L.ptr(Ut), M, L.ptr(Vt), M, P, Q, M, float(alpha), L.ptr(C), C.stride(0), L.ptr(ws),
+           ws.numel() * 4, st)
 
 
 # ------------------------------------------------------------------------ deferred (grouped) weight gradients

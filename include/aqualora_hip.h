@@ -167,6 +167,13 @@ int aql_se_gate(const float* pool, const float* w1, const float* b1, const float
 int aql_pwconv_f32(const float* x, const float* w, const float* bias, const float* gate, int rows_per_sample,
                    const float* residual, long M, int N, int K, int act, float* y, aql_stream_t stream);
 
+/* wide-rank (r > 32) LoRA weight gradients (ppft_train.py:1058 backward through lora_modules.py:13-19): both operands
+ * are transposed once (aql_transpose_bf16: dst[cols][rows] = src[rows][cols]^T) and C[M,N] += alpha * A[M,K].B[N,K]^T runs
+ * on the pipelined NT kernels with split-K slabs in ws                                                                    */
+int aql_transpose_bf16(const bf16_t* src, long rows, int cols, long ld, bf16_t* dst, aql_stream_t stream);
+int aql_gemm_nt_f32_accum(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, int N, long K, float alpha,
+                          float* C, long ldc, float* ws, size_t ws_bytes, aql_stream_t stream);
+
 /* ---- SecretDecoder training (csrc/aql_decoder_train.hip) ---- torchvision efficientnet_b1 in train() mode as run by
  * train/latent_wm_pretrain.py:159-225 (sec_decoder.train(), :160) and train/rob_enhance_finetune.py (msgdecoder fwd+bwd at
  * B=16): BatchNorm with batch statistics and every layer's backward.  fp32, channels-last [B,H,W,C] == [M,C].            */

@@ -97,6 +97,14 @@ for (M, P, Q) in [(4096, 320, 32), (1000, 32, 768), (2048, 640, 320), (308, 1280
     C = torch.zeros(P, Q, dtype=torch.float32, device=dev)
     L.call("aql_gemm_tn_f32", L.ptr(U), P, L.ptr(V), Q, M, P, Q, 1.0, L.ptr(C), Q, L.stream_ptr())
     report(f"gemm_tn M{M} P{P} Q{Q}", relerr(C, U.float().T @ V.float()), 2e-3)
+# 5b. wide-rank weight gradients (transpose + NT kernels), accumulating onto a non-zero C
+from aqualora_amd import ops as _ops
+for (M, P, Q) in [(8192, 640, 320), (16384, 320, 768), (16384, 320, 320), (4000, 320, 1280), (616, 320, 768)]:
+    U = rnd(M, P); V = rnd(M, Q)
+    C0 = torch.randn(P, Q, device=dev)
+    C = C0.clone()
+    _ops.gemm_tn_acc(U, V, C, 0.5)
+    report(f"gemm_tn wide M{M} P{P} Q{Q}", relerr(C, C0 + 0.5 * (U.float().T @ V.float())), 2e-3)
 
 # 6. timing
 print("--- timing (bf16, random data) ---")
