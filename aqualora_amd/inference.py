@@ -106,7 +106,7 @@ def ddim_sample(unet, ctx_cond, ctx_uncond, latents, num_inference_steps=50, gui
         torch.cuda.current_stream().wait_stream(side)
         x.copy_(x_keep)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):  # see ppft.capture: RCCL's watchdog thread
             one_step()
     for t in ts:
         set_step(t)

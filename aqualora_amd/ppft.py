@@ -154,9 +154,12 @@ class PPFTTrainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_fb):
+        # thread_local capture mode: with a process group alive, RCCL's watchdog thread polls hipEventQuery on the
+        # warm-up collectives; under the default global mode that call is illegal while ANY thread captures and aborts
+        # the process ("operation not permitted when stream is capturing") -- found with AQL_FORCE_ALLREDUCE=1.
+        with torch.cuda.graph(g_fb, capture_error_mode="thread_local"):
             loss, _, _ = self.forward_backward(**static)
-        with torch.cuda.graph(g_opt, pool=g_fb.pool()):
+        with torch.cuda.graph(g_opt, pool=g_fb.pool(), capture_error_mode="thread_local"):
             self.optimizer_step()
         self._graphs = (g_fb, g_opt, static, loss)
 

@@ -650,3 +650,21 @@ def test_fuse_lora_and_ddim_sampler():
             e = unet(torch.cat([xr, xr]), torch.full((4,), t, device=DEV), ctx2).sample.float().contiguous()
         xr = O.ddim_step(xr.cpu(), e[:2].cpu(), e[2:].cpu(), t, t - 200, 7.5).to(DEV)
     assert relerr(a, xr) < 1e-4
+
+
+def test_bench_under_torchrun_with_rccl_collective():
+    """The N>1 launch path on one GPU: bench.py under torch.distributed.run with the gradient all-reduce forced through
+    RCCL (AQL_FORCE_ALLREDUCE=1).  Regression test: RCCL's watchdog thread calls hipEventQuery while the step is being
+    captured into HIP graphs, which aborts the process unless the capture is thread-local."""
+    import json, os, subprocess, sys
+    from tests.conftest import ROOT
+    env = dict(os.environ, AQL_FORCE_ALLREDUCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["config"]["hip_graph"] is True
+    assert "roofline" in rec and rec["roofline"]["frac"] > 0
