@@ -1,14 +1,14 @@
-// bf16 MFMA GEMM core for gfx950 (CDNA4): one templated main loop shared by
-//   * the fused LoRA linear  Y = X.W^T + b + (T*S).Bup^T      (two K segments, one accumulator)
-//   * the 3x3 NHWC convolution as an implicit GEMM (gather loader, nearest-x2 upsample and stride folded in)
-//   * its backward-data form, and
-//   * the weight-gradient GEMMs dA/dB (reduction over tokens, transposing loader).
-//
-// Tile: BM x BN outputs per 256-thread workgroup (4 wavefronts of 64), K tile 64 bf16, double-buffered LDS,
-// v_mfma_f32_32x32x16_bf16 with the *weight-side* tile as MFMA operand A and the *activation-side* tile as
-// operand B, so a lane ends up with 4 consecutive output columns of one output row (8-byte packed stores).
-// LDS rows are 128 B (8 chunks of 16 B); chunk index is XOR-swizzled with (row & 7) so that both the 16-byte
-// staging writes and the ds_read_b128 fragment reads are bank-conflict free (guide T2).
+// bf16 MFMA GEMM core for gfx950 (CDNA4).  Operand descriptors ("loaders") are shared by three kernel bodies:
+//   * gemm_body_w  -- wave-specialised LDS-DMA kernel (4 loader + 4 MFMA wavefronts, 16x16x32 MFMA, 160-wide tiles):
+//                     the fused LoRA linear  Y = X.W^T + b + (T*S).Bup^T  (two K segments, one accumulator), the 3x3
+//                     NHWC convolution as an implicit GEMM (gather loader, nearest-x2 upsample and stride folded in) and
+//                     its backward-data form, whenever the grid is a whole number of one-workgroup-per-CU rounds;
+//   * gemm_body_d  -- the same LDS-DMA pipeline with 4 all-purpose wavefronts for short-K / odd-grid problems;
+//   * gemm_body    -- 32x32x16-MFMA kernel with a register-transposing loader for the token-reduction GEMMs dA / dB
+//                     (rank <= 32 LoRA weight gradients, grouped launch, fp32 atomics).
+// Common to all: the *weight-side* tile is MFMA operand A and the *activation-side* tile operand B, so a lane ends up
+// with 4 consecutive output columns of one output row; LDS rows are 128 B (8 chunks of 16 B) with the chunk index
+// XOR-swizzled by (row >> 1) & 7 so that staging and ds_read_b128 fragment reads are bank-conflict free.
 #pragma once
 #include "aql_common.h"
 
@@ -35,22 +35,6 @@ struct PlainLoader {
   long ld;
   int rows;
   int K;
-  struct Row {
-    const bf16_t* p;
-  };
-  struct KInfo {
-    int k;
-  };
-  __device__ __forceinline__ Row row(int r) const {
-    Row x;
-    x.p = (r < rows) ? base + (long)r * ld : nullptr;
-    return x;
-  }
-  __device__ __forceinline__ KInfo kinfo(int k) const { return KInfo{k < K ? k : -1}; }
-  __device__ __forceinline__ uint4 load(const Row& x, const KInfo& ki) const {
-    if (x.p != nullptr && ki.k >= 0) return *reinterpret_cast<const uint4*>(x.p + ki.k);
-    return zero4();
-  }
 };
 
 // Forward 3x3 conv, NHWC input [B,Hin,Win,Cin]; row r = (b,ho,wo); k = (kh*3+kw)*Cin + ci.
@@ -60,49 +44,6 @@ struct ConvFwdLoader {
   const bf16_t* base;
   int B, Hin, Win, Cin, Hout, Wout, stride, ups;
   int rows, K;
-  struct Row {
-    int b, h, w;
-  };
-  struct KInfo {
-    int kh, kw, ci;
-  };
-  __device__ __forceinline__ Row row(int r) const {
-    Row x;
-    if (r >= rows) {
-      x.b = -1;
-      x.h = x.w = 0;
-      return x;
-    }
-    int hw = Hout * Wout;
-    x.b = r / hw;
-    int rem = r - x.b * hw;
-    int ho = rem / Wout;
-    x.h = ho * stride - 1;
-    x.w = (rem - ho * Wout) * stride - 1;
-    return x;
-  }
-  __device__ __forceinline__ KInfo kinfo(int k) const {
-    KInfo ki;
-    if (k >= K) {
-      ki.kh = -100;
-      ki.kw = 0;
-      ki.ci = 0;
-      return ki;
-    }
-    int tap = k / Cin;
-    ki.ci = k - tap * Cin;
-    ki.kh = tap / 3;
-    ki.kw = tap - ki.kh * 3;
-    return ki;
-  }
-  __device__ __forceinline__ uint4 load(const Row& x, const KInfo& ki) const {
-    int hi = x.h + ki.kh, wi = x.w + ki.kw;
-    int Hl = Hin << ups, Wl = Win << ups;
-    if (x.b < 0 || hi < 0 || wi < 0 || hi >= Hl || wi >= Wl) return zero4();
-    hi >>= ups;
-    wi >>= ups;
-    return *reinterpret_cast<const uint4*>(base + (((long)x.b * Hin + hi) * Win + wi) * Cin + ki.ci);
-  }
 };
 
 // Backward-data 3x3 conv: rows are input pixels (b,hi,wi) of dX; source is dY [B,Hout,Wout,Cout];
@@ -112,52 +53,6 @@ struct ConvBwdLoader {
   const bf16_t* base;
   int B, Hin, Win, Cout, Hout, Wout, stride;
   int rows, K;
-  struct Row {
-    int b, h, w;
-  };
-  struct KInfo {
-    int kh, kw, co;
-  };
-  __device__ __forceinline__ Row row(int r) const {
-    Row x;
-    if (r >= rows) {
-      x.b = -1;
-      x.h = x.w = 0;
-      return x;
-    }
-    int hw = Hin * Win;
-    x.b = r / hw;
-    int rem = r - x.b * hw;
-    int hi = rem / Win;
-    x.h = hi + 1;
-    x.w = (rem - hi * Win) + 1;
-    return x;
-  }
-  __device__ __forceinline__ KInfo kinfo(int k) const {
-    KInfo ki;
-    if (k >= K) {
-      ki.kh = 100000;
-      ki.kw = 0;
-      ki.co = 0;
-      return ki;
-    }
-    int tap = k / Cout;
-    ki.co = k - tap * Cout;
-    ki.kh = tap / 3;
-    ki.kw = tap - ki.kh * 3;
-    return ki;
-  }
-  __device__ __forceinline__ uint4 load(const Row& x, const KInfo& ki) const {
-    int th = x.h - ki.kh, tw = x.w - ki.kw;
-    if (x.b < 0 || th < 0 || tw < 0) return zero4();
-    if (stride == 2) {
-      if ((th | tw) & 1) return zero4();
-      th >>= 1;
-      tw >>= 1;
-    }
-    if (th >= Hout || tw >= Wout) return zero4();
-    return *reinterpret_cast<const uint4*>(base + (((long)x.b * Hout + th) * Wout + tw) * Cout + ki.co);
-  }
 };
 
 // Transposed source: element (row, k) lives at base[k*ld + row]  (rows contiguous).  Used for the
@@ -216,26 +111,7 @@ struct GemmArgs {
 // staging helpers
 // --------------------------------------------------------------------------------------------
 template <int R, class L>
-struct Stager {
-  // non-transposed: thread owns chunk c = tid&7 of rows (tid>>3) + 32*i
-  static constexpr int NL = R / 32;
-  typename L::Row rows[NL];
-  uint4 regs[NL];
-  __device__ __forceinline__ void init(const L& l, int row0, int tid) {
-#pragma unroll
-    for (int i = 0; i < NL; ++i) rows[i] = l.row(row0 + (tid >> 3) + 32 * i);
-  }
-  __device__ __forceinline__ void fetch(const L& l, int k0, int tid) {
-    typename L::KInfo ki = l.kinfo(k0 + (tid & 7) * 8);
-#pragma unroll
-    for (int i = 0; i < NL; ++i) regs[i] = l.load(rows[i], ki);
-  }
-  __device__ __forceinline__ void commit(char* lds, int tid) const {
-#pragma unroll
-    for (int i = 0; i < NL; ++i)
-      *reinterpret_cast<uint4*>(lds + lds_off((tid >> 3) + 32 * i, tid & 7)) = regs[i];
-  }
-};
+struct Stager;  // only the transposing specialisation below is used (token-reduction GEMMs)
 
 template <int R>
 struct Stager<R, TransLoader> {
