@@ -42,6 +42,7 @@ SIGNATURES = {
     "aql_cast_transpose_batched": [c_p, c_i, c_i, c_p],
     "aql_tn_desc_fill": [c_p, c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_f, c_p, c_l, c_i],
     "aql_gemm_tn_grouped": [c_p, c_i, c_i, c_p],
+    "aql_gemm_tn_grouped_range": [c_p, c_i, c_i, c_i, c_i, c_p],
     "aql_ds_desc_fill": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i],
     "aql_lora_ds_grouped": [c_p, c_i, c_i, c_p],
     "aql_lora_ds": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],

@@ -1050,14 +1050,18 @@ struct TnGroupDesc {
   int pad;
 };
 
-__global__ __launch_bounds__(NTHREADS) void gemm_tn_grouped_kernel(const TnGroupDesc* __restrict__ descs, int n) {
+// `block_base` lets a launch cover a sub-range of the table (one gradient bucket of the data-parallel exchange): descs
+// then points at the bucket's first descriptor and block_base is that descriptor's first_block.
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_grouped_kernel(const TnGroupDesc* __restrict__ descs, int n,
+                                                                   int block_base) {
+  const int bid = (int)blockIdx.x + block_base;
   int lo = 0, hi = n - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (descs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    if (descs[mid].first_block <= bid) lo = mid; else hi = mid - 1;
   }
   const TnGroupDesc d = descs[lo];
-  const int local = blockIdx.x - d.first_block;
+  const int local = bid - d.first_block;
   const int tiles = (d.a_rows + 127) / 128;  // b_rows <= 32: one tile along N
   GemmArgs<TransLoader, TransLoader> g;
   g.a0.base = d.a; g.a0.ld = d.lda; g.a0.rows = d.a_rows; g.a0.K = d.M;

@@ -678,7 +678,19 @@ extern "C" int aql_gemm_tn_grouped(const void* dev_descs, int n, int total_block
   AQL_CHECK_ARG(dev_descs && n > 0 && total_blocks > 0, "aql_gemm_tn_grouped: bad args");
   static_assert(sizeof(TnGroupDesc) == 80, "descriptor layout is part of the ABI");
   hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total_blocks), dim3(NTHREADS), 0, stream,
-                     static_cast<const TnGroupDesc*>(dev_descs), n);
+                     static_cast<const TnGroupDesc*>(dev_descs), n, 0);
   AQL_CHECK_LAUNCH("aql_gemm_tn_grouped");
+  return AQL_OK;
+}
+
+// Sub-range form: descriptors [first, first + n) of the same table, i.e. one gradient bucket.  `block_base` is the
+// first_block of descriptor `first`, `n_blocks` the workgroups of the range.
+extern "C" int aql_gemm_tn_grouped_range(const void* dev_descs, int first, int n, int block_base, int n_blocks,
+                                         hipStream_t stream) {
+  AQL_CHECK_ARG(dev_descs && first >= 0 && n > 0 && block_base >= 0 && n_blocks > 0,
+                "aql_gemm_tn_grouped_range: bad args");
+  hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(n_blocks), dim3(NTHREADS), 0, stream,
+                     static_cast<const TnGroupDesc*>(dev_descs) + first, n, block_base);
+  AQL_CHECK_LAUNCH("aql_gemm_tn_grouped_range");
   return AQL_OK;
 }

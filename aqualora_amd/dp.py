@@ -32,3 +32,59 @@ def allreduce_mean_(flat, group=None, bucket_elems=None):
             dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=group)
             chunk.div_(w)
     return flat
+
+
+def exchange_active(group=None):
+    """True when a gradient collective has to run: more than one rank, or AQL_FORCE_ALLREDUCE=1 (exercises the RCCL
+    path on a single GPU)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return world_size(group) > 1 or bool(os.environ.get("AQL_FORCE_ALLREDUCE"))
+
+
+def bucket_count(nbytes):
+    """Buckets for the flat LoRA gradient buffer; 1 = no bucketing (one grouped weight-gradient launch inside the
+    backward graph, one collective after it).
+
+    Measured on MI355X (bench.py under torchrun, collectives forced on one rank): every extra graph boundary costs
+    ~0.35 ms of idle GPU, so at r=32 (54 MB, ~0.5 ms on the wire over 8 GPUs) splitting cannot win and the exchange
+    stays ONE collective; at r=320 (543 MB, ~5 ms on the wire) eight 68 MB buckets cost 1.9 ms of boundaries on a
+    73 ms step and hide all but the last bucket's transfer under the weight-gradient GEMMs.  xGMI is point-to-point
+    (a ring is bound by one ~153 GB/s link and pays its latency per collective), so buckets stay >= 64 MB.
+    AQL_BUCKETS overrides (tests)."""
+    if os.environ.get("AQL_BUCKETS"):
+        return max(1, int(os.environ["AQL_BUCKETS"]))
+    if nbytes < (128 << 20):
+        return 1
+    return int(min(8, nbytes // (64 << 20)))
+
+
+class BucketedAllreduce:
+    """Asynchronous mean-all-reduce of slices of one flat buffer, one collective per bucket.
+
+    ``launch(chunk)`` enqueues the collective behind everything already queued on the CURRENT stream (ProcessGroupNCCL
+    records an event there and runs the collective on its own stream), so kernels launched afterwards on the current
+    stream -- the next bucket's weight-gradient GEMMs -- overlap with it.  ``finish()`` makes the current stream wait
+    for all of them (and applies the 1/world factor on backends without ReduceOp.AVG)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.pending = []
+
+    def launch(self, chunk):
+        if not exchange_active(self.group) or chunk.numel() == 0:
+            return
+        if dist.get_backend(self.group) == "nccl":
+            w = dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            self.pending.append((w, None))
+        else:
+            w = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.pending.append((w, chunk))
+
+    def finish(self):
+        n = world_size(self.group)
+        for w, chunk in self.pending:
+            w.wait()
+            if chunk is not None:
+                chunk.div_(n)
+        self.pending = []

@@ -189,17 +189,61 @@ def gemm_tn_acc(U, V, C, alpha=1.0):
 
 
 # ------------------------------------------------------------------------ deferred (grouped) weight gradients
+def plan_buckets(offsets, sizes, nbuckets):
+    """Cut work items into <= nbuckets groups of CONTIGUOUS ranges of a flat buffer, balanced by size.
+
+    offsets/sizes: start and length (elements) of the output region of each item inside the flat gradient buffer.
+    Returns [(lo, hi, [item indices])...] ordered by lo; every item lies inside exactly one [lo, hi) and the ranges
+    tile [min offset, max end) without gaps, so one collective per range exchanges exactly that group's results
+    (plus any untouched elements between them, which are zeros on every rank).  Pure host logic (CPU-tested)."""
+    order = sorted(range(len(offsets)), key=lambda i: offsets[i])
+    if not order:
+        return []
+    total = sum(sizes)
+    target = total / max(1, nbuckets)
+    out, cur, acc, done = [], [], 0, 0
+    for i in order:
+        cur.append(i)
+        acc += sizes[i]
+        if acc >= target and len(out) < nbuckets - 1 and done + acc < total:
+            out.append(cur)
+            done += acc
+            cur, acc = [], 0
+    if cur:
+        out.append(cur)
+    res = []
+    lo = offsets[order[0]]
+    for k, items in enumerate(out):
+        hi = max(offsets[i] + sizes[i] for i in items)
+        if k + 1 < len(out):
+            nxt = min(offsets[i] for i in out[k + 1])
+            if nxt < hi:
+                raise ValueError("plan_buckets: output regions overlap")
+            hi = nxt
+        res.append((lo, hi, items))
+        lo = hi
+    return res
+
+
 class DeferredDW:
     """Collects the LoRA weight-gradient GEMMs (dA, dBup) and the dS reductions of a whole backward pass and runs
     them as ONE grouped launch each (`flush`).  They are off the backward critical path -- nothing consumes dA/dB/dS
     before the optimizer -- and as 384+192 separate small launches they were the largest single item of the step.
     Descriptors are written into pinned host tables and copied with one async H2D each (graph-capturable: the device
-    addresses they hold are the capture pool's, identical on every replay)."""
+    addresses they hold are the capture pool's, identical on every replay).
+
+    Data-parallel runs use the bucketed form instead (`plan` / `run_bucket`): the problems are sorted by where their
+    output lives in the flat gradient buffer and cut into a few contiguous buckets; the trainer launches bucket k and
+    immediately hands its range to RCCL on the collective stream, so the all-reduce of bucket k runs under the
+    weight-gradient GEMMs of bucket k+1 (the role DDP's grad-ready hooks play at ppft_train.py:1058).  With
+    ``defer_wide`` the rank > 32 problems (which are not groupable and would otherwise run inline in backward) are
+    held back too and executed inside their bucket."""
 
     TN_BYTES, DS_BYTES = 80, 48
 
-    def __init__(self, device, max_sites=1024):
+    def __init__(self, device, max_sites=1024, defer_wide=False):
         self.device = device
+        self.defer_wide = defer_wide
         self.tn_host = torch.zeros(2 * max_sites * self.TN_BYTES, dtype=torch.uint8).pin_memory()
         self.ds_host = torch.zeros(max_sites * self.DS_BYTES, dtype=torch.uint8).pin_memory()
         self.tn_dev = torch.zeros_like(self.tn_host, device=device)
@@ -209,14 +253,21 @@ class DeferredDW:
     def reset(self):
         self.n_tn = self.n_ds = self.blk_tn = self.blk_ds = 0
         self.keep = []
+        self.items = []    # (C, nblk or None, direct args or None) in arrival order
+        self.buckets = None
 
     def add_tn(self, U, V, C, alpha=1.0):
-        """C[P,Q] += alpha * U^T V;  returns False if the shape cannot be grouped (caller launches it directly)."""
+        """C[P,Q] += alpha * U^T V;  returns False if the problem was not taken (caller launches it directly)."""
         slot = self.tn_host.data_ptr() + self.n_tn * self.TN_BYTES
         nblk = L.call_raw("aql_tn_desc_fill", L.c_p(slot), L.ptr(U), U.stride(0), L.ptr(V), V.stride(0), U.shape[0],
                           U.shape[1], V.shape[1], float(alpha), L.ptr(C), C.stride(0), self.blk_tn)
         if nblk <= 0:
-            return False
+            if not self.defer_wide:
+                return False
+            self.items.append((C, None, (U, V, float(alpha))))
+            self.keep += [U, V]
+            return True
+        self.items.append((C, nblk, None))
         self.n_tn += 1
         self.blk_tn += nblk
         self.keep += [U, V]
@@ -232,16 +283,74 @@ class DeferredDW:
         self.keep += [dTs, T]
         return True
 
-    def flush(self):
-        if self.n_tn:
-            nbytes = self.n_tn * self.TN_BYTES
-            self.tn_dev[:nbytes].copy_(self.tn_host[:nbytes], non_blocking=True)
-            L.call("aql_gemm_tn_grouped", L.ptr(self.tn_dev), self.n_tn, self.blk_tn, L.stream_ptr())
+    def flush_ds(self):
         if self.n_ds:
             nbytes = self.n_ds * self.DS_BYTES
             self.ds_dev[:nbytes].copy_(self.ds_host[:nbytes], non_blocking=True)
             L.call("aql_lora_ds_grouped", L.ptr(self.ds_dev), self.n_ds, self.blk_ds, L.stream_ptr())
+        self.n_ds = self.blk_ds = 0
+
+    def flush_tn(self):
+        if self.n_tn:
+            nbytes = self.n_tn * self.TN_BYTES
+            self.tn_dev[:nbytes].copy_(self.tn_host[:nbytes], non_blocking=True)
+            L.call("aql_gemm_tn_grouped", L.ptr(self.tn_dev), self.n_tn, self.blk_tn, L.stream_ptr())
+        for C, nblk, direct in self.items:
+            if direct is not None:
+                gemm_tn_acc(direct[0], direct[1], C, direct[2])
+        self.n_tn = self.blk_tn = 0
+        self.items = []
+
+    def flush(self):
+        self.flush_tn()
+        self.flush_ds()
         self.reset()
+
+    # ---- bucketed form -------------------------------------------------------------------------------------
+    def plan(self, flat_grad, nbuckets):
+        """Sort the held-back problems by the offset of their output inside ``flat_grad`` and cut them into buckets.
+        Rewrites the host descriptor table in that order.  Returns [(lo, hi)] element ranges of flat_grad."""
+        import numpy as np
+        base, esz = flat_grad.data_ptr(), flat_grad.element_size()
+        offs, sizes = [], []
+        for C, _, _ in self.items:
+            o = (C.data_ptr() - base) // esz
+            if not (0 <= o and o + C.numel() <= flat_grad.numel() and C.is_contiguous()):
+                raise L.AqlError("DeferredDW.plan: a weight gradient does not live in the flat gradient buffer")
+            offs.append(o)
+            sizes.append(C.numel())
+        groups = plan_buckets(offs, sizes, nbuckets)
+        grouped_idx = [i for i, it in enumerate(self.items) if it[1] is not None]   # arrival order == table order
+        slot_of = {i: s for s, i in enumerate(grouped_idx)}
+        tbl = self.tn_host.numpy()[:self.n_tn * self.TN_BYTES].reshape(self.n_tn, self.TN_BYTES)
+        old = tbl.copy()
+        self.buckets = []
+        pos = blk = 0
+        for lo, hi, idxs in groups:
+            first, base_blk, direct = pos, blk, []
+            for i in idxs:
+                C, nblk, d = self.items[i]
+                if d is not None:
+                    direct.append((d[0], d[1], C, d[2]))
+                    continue
+                tbl[pos] = old[slot_of[i]]
+                tbl[pos, 64:68].view(np.int32)[0] = blk     # TnGroupDesc.first_block
+                pos += 1
+                blk += nblk
+            self.buckets.append(dict(lo=lo, hi=hi, first=first, n=pos - first, base=base_blk, nblk=blk - base_blk,
+                                     direct=direct))
+        assert pos == self.n_tn and blk == self.blk_tn
+        return [(b["lo"], b["hi"]) for b in self.buckets]
+
+    def run_bucket(self, k):
+        b = self.buckets[k]
+        if b["n"]:
+            lo, hi = b["first"] * self.TN_BYTES, (b["first"] + b["n"]) * self.TN_BYTES
+            self.tn_dev[lo:hi].copy_(self.tn_host[lo:hi], non_blocking=True)
+            L.call("aql_gemm_tn_grouped_range", L.ptr(self.tn_dev), b["first"], b["n"], b["base"], b["nblk"],
+                   L.stream_ptr())
+        for U, V, C, alpha in b["direct"]:
+            gemm_tn_acc(U, V, C, alpha)
 
 
 DEFERRED = None  # set by a trainer around backward (ppft.PPFTTrainer); None => every site launches its own kernels

@@ -51,13 +51,18 @@ class PPFTTrainer:
         self.ds_accum = None
         self.micro = micro_batches
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(2 * max(1, micro_batches))]
-        self.deferred = ops.DeferredDW(dev)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        # data parallel: weight-gradient GEMMs run in buckets, each followed by its slice of the all-reduce (see
+        # exchange_bucketed); single GPU: one grouped launch at the end of backward, no collective
+        self.bucketed = dp.exchange_active(process_group) and dp.bucket_count(4 * self.bank.n_lora) > 1
+        self.deferred = ops.DeferredDW(dev, defer_wide=self.bucketed)
+        self.reducer = dp.BucketedAllreduce(process_group)
 
     # ---------------------------------------------------------------------------------------------
-    def forward_backward(self, z, msg, eps, t, ctx):
-        """Everything up to (and including) backward; returns (loss, pred, clean).
+    def forward_backward(self, z, msg, eps, t, ctx, flush_dw=True):
+        """Everything up to (and including) backward; returns (loss, pred, clean).  With ``flush_dw=False`` the LoRA
+        weight-gradient GEMMs stay queued in ``self.deferred`` for `exchange_bucketed`.
 
         Concurrency: samples are independent (no batch statistics anywhere in the U-Net), so the batch is cut into
         ``micro`` slices that run the whole clean / watermarked / backward chain on their own pair of HIP streams.
@@ -103,15 +108,39 @@ class PPFTTrainer:
             ops.DEFERRED = None
         for tns in preds + cleans + losses:
             tns.record_stream(main)
-        self.deferred.flush()         # ... and run as two grouped launches here
+        if flush_dw:
+            self.deferred.flush()     # ... and run as two grouped launches here
+        else:
+            self.deferred.flush_ds()
         S.backward(self.ds_accum)
         loss = torch.stack(losses).mean()
         return loss, torch.cat(preds), torch.cat(cleans)
 
     def exchange_gradients(self):
         """DDP's gradient all-reduce(mean) (accelerator.backward, ppft_train.py:1058) as ONE collective over the flat
-        fp32 gradient buffer (54 MB at r=32, 543 MB at r=320)."""
+        fp32 gradient buffer (54 MB at r=32, 543 MB at r=320).  Used when the weight gradients were already flushed."""
         dp.allreduce_mean_(self.bank.grad[:self.bank.numel], self.pg)
+
+    def plan_exchange(self):
+        """Bucket plan for the queued weight-gradient GEMMs: [(lo, hi)] ranges tiling [0, n_lora) of the flat gradient
+        buffer.  The bank is laid out in gradient-ready order, so bucket 0 holds the sites backward reached first."""
+        b = self.bank
+        ranges = self.deferred.plan(b.grad, dp.bucket_count(4 * b.n_lora))
+        if ranges:
+            ranges[0] = (0, ranges[0][1])
+            ranges[-1] = (ranges[-1][0], b.n_lora)
+        return ranges
+
+    def exchange_bucketed(self, ranges, run_bucket):
+        """Overlapped exchange (DDP's grad-ready buckets, ppft_train.py:1058): the mapper gradient is complete after
+        backward and goes first; then for every bucket k: launch its weight-gradient GEMMs (``run_bucket(k)``) and hand
+        grad[lo_k:hi_k] to RCCL, which runs on the collective stream under bucket k+1's GEMMs."""
+        b = self.bank
+        self.reducer.launch(b.grad[b.n_lora:b.numel])
+        for k, (lo, hi) in enumerate(ranges):
+            run_bucket(k)
+            self.reducer.launch(b.grad[lo:hi])
+        self.reducer.finish()
 
     def optimizer_step(self):
         b = self.bank
@@ -129,10 +158,19 @@ class PPFTTrainer:
         b.refresh()
         b.zero_grad()
 
-    def step(self, z, msg, eps, t, ctx):
-        loss, _, _ = self.forward_backward(z, msg, eps, t, ctx)
-        self.exchange_gradients()
+    def _step_body(self, z, msg, eps, t, ctx):
+        if self.bucketed:
+            loss, _, _ = self.forward_backward(z, msg, eps, t, ctx, flush_dw=False)
+            self.exchange_bucketed(self.plan_exchange(), self.deferred.run_bucket)
+            self.deferred.reset()
+        else:
+            loss, _, _ = self.forward_backward(z, msg, eps, t, ctx)
+            self.exchange_gradients()
         self.optimizer_step()
+        return loss
+
+    def step(self, z, msg, eps, t, ctx):
+        loss = self._step_body(z, msg, eps, t, ctx)
         self.global_step += 1
         self.lr_t.fill_(self.base_lr * self.lr_lambda(self.global_step))
         return loss
@@ -148,12 +186,12 @@ class PPFTTrainer:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self.forward_backward(**static)
-                self.exchange_gradients()
-                self.optimizer_step()
+                self._step_body(**static)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        if self.bucketed:
+            return self._capture_bucketed(static, g_fb, g_opt)
         # thread_local capture mode: with a process group alive, RCCL's watchdog thread polls hipEventQuery on the
         # warm-up collectives; under the default global mode that call is illegal while ANY thread captures and aborts
         # the process ("operation not permitted when stream is capturing") -- found with AQL_FORCE_ALLREDUCE=1.
@@ -169,6 +207,47 @@ class PPFTTrainer:
                     static[k].copy_(v)
             g_fb.replay()
             self.exchange_gradients()
+            g_opt.replay()
+            self.global_step += 1
+            self.lr_t.fill_(self.base_lr * self.lr_lambda(self.global_step))
+            return loss
+
+        run.is_graph = True
+        return run
+
+    def _capture_bucketed(self, static, g_fb, g_opt):
+        """Data-parallel capture: graph 0 = forward + backward (+ dS, mapper backward); one small graph per gradient
+        bucket (its grouped / wide weight-gradient GEMMs); graph N+1 = clip + AdamW + re-cast.  The RCCL collectives
+        are issued eagerly between the bucket graphs (RCCL calls are kept out of the captures on purpose: a captured
+        collective cannot be validated on the 1-GPU boxes this is developed on)."""
+        eager_deferred = self.deferred
+        self.deferred = ops.DeferredDW(eager_deferred.device, defer_wide=True)  # its pinned table belongs to the graphs
+        with torch.cuda.graph(g_fb, capture_error_mode="thread_local"):
+            loss, _, _ = self.forward_backward(**static, flush_dw=False)
+        ranges = self.plan_exchange()
+        g_dw = []
+        for k in range(len(ranges)):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=g_fb.pool(), capture_error_mode="thread_local"):
+                self.deferred.run_bucket(k)
+            g_dw.append(g)
+        with torch.cuda.graph(g_opt, pool=g_fb.pool(), capture_error_mode="thread_local"):
+            self.optimizer_step()
+        captured = self.deferred      # keeps the operands of the bucket graphs (capture-pool memory) referenced
+        self.deferred = eager_deferred
+        self._graphs = (g_fb, g_dw, g_opt, static, loss, captured)
+        self.exchange_ranges = ranges
+
+        import os
+        run_bucket = (lambda k: g_dw[k].replay()) if os.environ.get("AQL_BUCKET_GRAPHS", "1") == "1" \
+            else captured.run_bucket
+
+        def run(z, msg, eps, t, ctx):
+            for k, v in (("z", z), ("msg", msg), ("eps", eps), ("t", t), ("ctx", ctx)):
+                if v is not static[k]:
+                    static[k].copy_(v)
+            g_fb.replay()
+            self.exchange_bucketed(ranges, run_bucket)
             g_opt.replay()
             self.global_step += 1
             self.lr_t.fill_(self.base_lr * self.lr_lambda(self.global_step))

@@ -61,6 +61,10 @@ int aql_gemm_tn_f32(const bf16_t* U, long ldu, const bf16_t* V, long ldv, long M
 int aql_tn_desc_fill(void* host_desc, const bf16_t* U, long ldu, const bf16_t* V, long ldv, long M, int P, int Q,
                      float alpha, float* C, long ldc, int first_block);
 int aql_gemm_tn_grouped(const void* dev_descs, int n, int total_blocks, aql_stream_t stream);
+/* Descriptors [first, first+n) of the same table = one gradient bucket of the data-parallel exchange (DDP's bucketed
+ * all-reduce under accelerator.backward, ppft_train.py:1058); block_base = first_block of descriptor `first`.    */
+int aql_gemm_tn_grouped_range(const void* dev_descs, int first, int n, int block_base, int n_blocks,
+                              aql_stream_t stream);
 
 /* ---- normalisation (csrc/aql_norm.hip) ---- torch.nn.GroupNorm(32,C,eps)+SiLU, torch.nn.LayerNorm(C) as used at
  * scripts/lib/original_unet.py:423,429,444-453,826 and :779-783.  stats: [B,32,2] / [M,2] fp32 (mean, rstd).     */

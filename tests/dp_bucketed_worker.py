@@ -1,0 +1,71 @@
+"""GPU worker (run as ``python -m tests.dp_bucketed_worker`` by test_gpu_parity): a single-rank RCCL process group with
+AQL_FORCE_ALLREDUCE=1 switches PPFTTrainer to its data-parallel form -- weight-gradient GEMMs in buckets, one
+asynchronous all-reduce per bucket, bucket graphs between the forward/backward graph and the optimizer graph -- and the
+result must equal the single-GPU form (one grouped launch, no collective) on the same inputs.  Prints one JSON line."""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+
+def build(rank, inp, lr=1e-3):
+    from aqualora_amd.ppft import PPFTTrainer
+    from aqualora_amd.watermark import MapperNet, SecretEncoder
+    from tests.common import T
+    from tests.test_gpu_parity import _gpu_tiny
+    unet, keys, lw = _gpu_tiny(rank=rank)
+    mapper = MapperNet(48, rank)
+    with torch.no_grad():
+        mapper.bit_embeddings.weight.copy_(inp["E"])
+    enc = SecretEncoder(48, base_res=8, resolution=16)
+    with torch.no_grad():
+        enc.secret_scaler[0].weight.copy_(T("cap.lin.w", (64, 48), 48 ** -0.5))
+        enc.secret_scaler[0].bias.copy_(T("cap.lin.b", (64,), 0.1))
+        enc.secret_scaler[5].weight.copy_(T("enc.conv.w", (4, 4, 3, 3), 0.05))
+    return PPFTTrainer(unet, mapper, enc, rank, learning_rate=lr)
+
+
+def main():
+    from tests.common import ppft_inputs
+    dev = "cuda"
+    out = {}
+    for rank in (8, 40):   # 40 > 32: the weight gradients are "wide" problems, held back as direct launches
+        inp = ppft_inputs(device=dev, rank=rank)
+        batch = dict(z=inp["z"], msg=inp["msg"], eps=inp["eps"], t=inp["t"], ctx=inp["ctx"].to(torch.bfloat16))
+        res = {}
+        for mode in ("plain", "bucketed_eager", "bucketed_graph"):
+            if mode == "plain":
+                os.environ.pop("AQL_FORCE_ALLREDUCE", None)
+            else:
+                os.environ["AQL_FORCE_ALLREDUCE"] = "1"
+                os.environ["AQL_BUCKETS"] = "3"     # the tiny bank is far below the size where bucketing switches on
+            tr = build(rank, inp)
+            assert tr.bucketed == (mode != "plain")
+            run = tr.capture(batch, warmup=0) if mode == "bucketed_graph" else tr.step
+            losses = [float(run(**batch)) for _ in range(3)]
+            torch.cuda.synchronize()
+            res[mode] = (losses, tr.bank.flat.clone())
+            if mode == "bucketed_graph":
+                out[f"r{rank}_ranges"] = [list(map(int, r)) for r in tr.exchange_ranges]
+                out[f"r{rank}_n_lora"] = int(tr.bank.n_lora)
+        lp, pp = res["plain"]
+        for mode in ("bucketed_eager", "bucketed_graph"):
+            l, p = res[mode]
+            out[f"r{rank}_{mode}_param_relerr"] = float((p - pp).abs().max() / pp.abs().max())
+            out[f"r{rank}_{mode}_losses"] = l
+        out[f"r{rank}_plain_losses"] = lp
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    torch.cuda.set_device(0)
+    try:
+        main()
+    finally:
+        dist.destroy_process_group()
+    sys.exit(0)

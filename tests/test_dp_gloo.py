@@ -28,7 +28,15 @@ def _worker(rank, world, port, q):
     z0 = synth.normal("bench.z", (2, 4, 8, 8), 1.0, 2048 + 977 * rank)
     gathered = [torch.zeros_like(z0) for _ in range(world)]
     dist.all_gather(gathered, z0)
-    q.put((rank, torch.allclose(a, want, atol=1e-6), torch.equal(a, b), not torch.equal(gathered[0], gathered[1])))
+    # bucketed asynchronous form used by the trainer: one collective per contiguous range, finished together
+    c = g.clone()
+    red = dp.BucketedAllreduce()
+    for lo, hi in ((0, 3000), (3000, 3001), (3001, n)):
+        red.launch(c[lo:hi])
+    red.finish()
+    ok_async = torch.allclose(c, want, atol=1e-6) and dp.exchange_active() and not red.pending
+    q.put((rank, torch.allclose(a, want, atol=1e-6), torch.equal(a, b) and ok_async,
+           not torch.equal(gathered[0], gathered[1])))
     dist.destroy_process_group()
 
 
@@ -43,3 +51,44 @@ def test_allreduce_mean_world2():
     for p in procs:
         p.join(timeout=60)
     assert all(ok1 and ok2 and ok3 for _, ok1, ok2, ok3 in res), res
+
+
+def test_plan_buckets_tiles_the_flat_buffer():
+    """Host logic of the bucketed exchange: problems arrive in backward order (roughly, not exactly, the buffer order),
+    buckets must be contiguous, disjoint, gap-free ranges that contain every problem's output exactly once."""
+    import random
+    from aqualora_amd.ops import plan_buckets
+    from aqualora_amd import dp
+    rng = random.Random(7)
+    sizes = [rng.choice([320 * 8, 8 * 320, 2560 * 8, 8 * 1280, 640 * 8]) for _ in range(384)]
+    offs, o = [], 0
+    for s in sizes:
+        offs.append(o)
+        o += s
+    perm = list(range(384))
+    for i in range(0, 380, 4):           # local shuffles: q/k/v backward order is autograd's choice
+        blk = perm[i:i + 4]
+        rng.shuffle(blk)
+        perm[i:i + 4] = blk
+    p_offs, p_sizes = [offs[i] for i in perm], [sizes[i] for i in perm]
+    for nb in (1, 2, 4, 8):
+        plan = plan_buckets(p_offs, p_sizes, nb)
+        assert 1 <= len(plan) <= nb
+        assert plan[0][0] == 0 and plan[-1][1] == o
+        seen = []
+        for (lo, hi, items), nxt in zip(plan, plan[1:] + [None]):
+            assert lo < hi and (nxt is None or nxt[0] == hi)
+            for i in items:
+                assert lo <= p_offs[i] and p_offs[i] + p_sizes[i] <= hi
+            seen += items
+        assert sorted(seen) == list(range(384))
+        if nb > 1:
+            tot = [sum(p_sizes[i] for i in items) for _, _, items in plan]
+            assert max(tot) < 2.0 * o / len(plan)      # balanced
+    assert plan_buckets([], [], 4) == []
+    try:
+        plan_buckets([0, 5], [10, 10], 2)
+        raise AssertionError("overlap not detected")
+    except ValueError:
+        pass
+    assert dp.bucket_count(54 << 20) == 1 and dp.bucket_count(543 << 20) == 8 and dp.bucket_count(200 << 20) == 3

@@ -668,3 +668,25 @@ def test_bench_under_torchrun_with_rccl_collective():
     rec = json.loads(line)
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["config"]["hip_graph"] is True
     assert "roofline" in rec and rec["roofline"]["frac"] > 0
+
+
+def test_bucketed_exchange_equals_single_flush():
+    """Data-parallel form of the step on one GPU (single-rank RCCL group, collectives forced): bucketed weight-gradient
+    launches + one async all-reduce per bucket, eager and as bucket graphs, at rank 8 (grouped problems) and rank 40
+    (wide problems held back as direct launches) -- parameters after 3 steps equal the single-GPU form's."""
+    import json, os, subprocess, sys
+    from tests.conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    env.pop("AQL_FORCE_ALLREDUCE", None)
+    out = subprocess.run([sys.executable, "-m", "tests.dp_bucketed_worker"], env=env, cwd=ROOT, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    for r in (8, 40):
+        ranges = rec[f"r{r}_ranges"]
+        assert len(ranges) >= 2 and ranges[0][0] == 0 and ranges[-1][1] == rec[f"r{r}_n_lora"]
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))      # the buckets tile the LoRA gradients
+        lp = rec[f"r{r}_plain_losses"]
+        for mode in ("bucketed_eager", "bucketed_graph"):
+            assert rec[f"r{r}_{mode}_param_relerr"] < 2e-3, rec
+            assert all(abs(a - b) < 2e-3 * abs(a) for a, b in zip(lp, rec[f"r{r}_{mode}_losses"])), rec
