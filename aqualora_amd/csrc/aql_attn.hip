@@ -68,6 +68,78 @@ __device__ __forceinline__ void stage_rows(char* lds, const bf16_t* g, long ld, 
   }
 }
 
+// Register-prefetching form of stage_rows for the streaming loops.  Per thread: NIT 16-byte slots of the 64-row tile.
+//   init    : pointers for the first tile (rows clamped to the last valid row), LDS offsets, and the d..DH padding
+//             chunks of the LDS image zeroed ONCE (they are never overwritten afterwards)
+//   fetch   : issue the global loads of the current tile into registers (no masks, no branches)
+//   commit  : registers -> LDS
+//   next    : move to the tile starting at `row0`: a pointer bump for full tiles, a re-clamp for the last partial one
+// Rows past the end of a partial tile are copies of the last valid row: finite values whose scores the callers mask
+// (forward / dQ) or whose probabilities are zero through lse = +inf (dK/dV), so they never reach a result.
+// The loop issues tile t+1's loads right after tile t is published in LDS, so their latency hides under the MFMAs and
+// softmax of tile t instead of sitting between two barriers (the old stage_rows also spent ~70 VALU ops per tile on
+// bounds masks and 64-bit address arithmetic in a loop whose VALU work already exceeds its MFMA work).
+// PF = false (head sizes above 64, which already run at one workgroup per CU with AGPR-resident accumulators: the extra
+// live registers cost more than the latency they hide, measured): same addressing, but the loads are issued inside
+// commit(), i.e. synchronously between the two barriers.
+template <int DH, bool PF = (DH <= 64)>
+struct Stager {
+  static constexpr int CPR = DH / 8;
+  static constexpr int NIT = (TILE * CPR + 255) / 256;
+  long p[NIT];   // element offset of the slot's 16 bytes from g (offsets, not pointers: pointer arrays end up in scratch)
+  uint4 v[NIT];
+  int off[NIT];  // LDS byte offset of the slot, -1: nothing to stage (outside the tile or padding chunk)
+  const bf16_t* g;
+  long ld;
+  int nrows;
+
+  __device__ __forceinline__ void point(int row0, int tid) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int id = tid + it * 256;
+      const int row = id / CPR, c = id - row * CPR;
+      const int r = min(row0 + row, nrows - 1);
+      p[it] = off[it] >= 0 ? (long)r * ld + c * 8 : 0;
+    }
+  }
+  __device__ __forceinline__ void init(char* lds, const bf16_t* g_, long ld_, int row0, int nrows_, int d, int tid) {
+    g = g_;
+    ld = ld_;
+    nrows = nrows_;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int id = tid + it * 256;
+      const int row = id / CPR, c = id - row * CPR;
+      const bool in_tile = id < TILE * CPR;
+      const bool live = in_tile & (c * 8 < d);
+      off[it] = live ? tile_off<DH>(row, c) : -1;
+      if (in_tile & !live) *reinterpret_cast<uint4*>(lds + tile_off<DH>(row, c)) = zero4();
+    }
+    point(row0, tid);
+  }
+  __device__ __forceinline__ void load() {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) v[it] = *reinterpret_cast<const uint4*>(g + p[it]);
+  }
+  __device__ __forceinline__ void fetch() {
+    if constexpr (PF) load();
+  }
+  __device__ __forceinline__ void commit(char* lds) {
+    if constexpr (!PF) load();
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+      if (off[it] >= 0) *reinterpret_cast<uint4*>(lds + off[it]) = v[it];
+  }
+  __device__ __forceinline__ void next(int row0, int tid) {
+    if (row0 + TILE <= nrows) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) p[it] += (long)TILE * ld;  // dead slots walk along row starts: still in bounds
+    } else {
+      point(row0, tid);
+    }
+  }
+};
+
 // owner rows -> B-operand fragments  f[frag][kstep]
 template <int DH>
 __device__ __forceinline__ void load_owner(bf16x8_t (&f)[2][DH / 32], const bf16_t* g, long ld, int row0, int nrows,
@@ -185,6 +257,24 @@ __device__ __forceinline__ void store_t(const f32x4_t (&acc)[DV / 16][2], bf16_t
   }
 }
 
+// same element mapping as store_t, fp32, no scaling (split-Q partials of dK/dV)
+template <int DV>
+__device__ __forceinline__ void store_t_f32(const f32x4_t (&acc)[DV / 16][2], float* g, long ld, int row0, int nrows, int d,
+                                            int lane) {
+#pragma unroll
+  for (int of = 0; of < 2; ++of) {
+    const int row = row0 + of * 16 + (lane & 15);
+    if (row >= nrows) continue;
+#pragma unroll
+    for (int df = 0; df < DV / 16; ++df) {
+      const int col = df * 16 + (lane >> 4) * 4;
+      if (col >= d) continue;
+      *reinterpret_cast<float4*>(g + (long)row * ld + col) =
+          make_float4(acc[df][of][0], acc[df][of][1], acc[df][of][2], acc[df][of][3]);
+    }
+  }
+}
+
 struct AttnArgs {
   const bf16_t *q, *k, *v, *o, *dout;
   bf16_t *out, *dq, *dk, *dv;
@@ -193,11 +283,18 @@ struct AttnArgs {
   long ldq, ldk, ldv, ldo;
   int B, H, Nq, Nk, d;
   float scale;
+  int qsplit;    // dK/dV only: the streamed Q range is cut into qsplit pieces (grid.z = B * qsplit) ...
+  float* part;   // ... whose fp32 partial results [2][qsplit][B][H][Nk][d] are summed by attn_dkv_reduce_kernel
 };
 
+// Occupancy hint (second __launch_bounds__ argument): with >= 2 workgroups per CU the register budget is 256 VGPRs and
+// LLVM selects the VGPR form of the MFMAs.  Without it the accumulators live in AGPRs and every softmax / rescale step
+// round-trips them through v_accvgpr_read/write: ~190 extra VALU moves per K/V tile in a loop whose VALU work
+// (exp2, max, sum, pack) already outweighs its 28 MFMAs.  Only the head sizes that fit 256 registers without spilling
+// get the hint.
 // ------------------------------------------------------------------------------------------------ forward
 template <int DH, int DV>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char sK[TILE * RowPitch<DH>::value];
   __shared__ __attribute__((aligned(16))) char sV[TILE * RowPitch<DH>::value];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -212,11 +309,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   zero_acc(o);
   float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
   const float c = a.scale * LOG2E;
+  Stager<DH> stK, stV;
+  stK.init(sK, kp, a.ldk, 0, a.Nk, a.d, tid);
+  stV.init(sV, vp, a.ldv, 0, a.Nk, a.d, tid);
+  stK.fetch();
+  stV.fetch();
   for (int kt = 0; kt < a.Nk; kt += TILE) {
     __syncthreads();
-    stage_rows<DH>(sK, kp, a.ldk, kt, a.Nk, a.d, tid);
-    stage_rows<DH>(sV, vp, a.ldv, kt, a.Nk, a.d, tid);
+    stK.commit(sK);
+    stV.commit(sV);
     __syncthreads();
+    if (kt + TILE < a.Nk) {  // next tile's loads fly under this tile's MFMAs and softmax
+      stK.next(kt + TILE, tid);
+      stV.next(kt + TILE, tid);
+      stK.fetch();
+      stV.fetch();
+    }
     f32x4_t s[4][2];
     zero_acc(s);
     s_product<DH>(s, sK, qf, lane);
@@ -287,7 +395,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------ dQ
 template <int DH, int DV>
-__global__ __launch_bounds__(256) void attn_dq_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dq_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char sK[TILE * RowPitch<DH>::value];
   __shared__ __attribute__((aligned(16))) char sV[TILE * RowPitch<DH>::value];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -311,11 +419,22 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(const AttnArgs a) {
   f32x4_t dq[DV / 16][2];
   zero_acc(dq);
   const float c = a.scale * LOG2E;
+  Stager<DH> stK, stV;
+  stK.init(sK, kp, a.ldk, 0, a.Nk, a.d, tid);
+  stV.init(sV, vp, a.ldv, 0, a.Nk, a.d, tid);
+  stK.fetch();
+  stV.fetch();
   for (int kt = 0; kt < a.Nk; kt += TILE) {
     __syncthreads();
-    stage_rows<DH>(sK, kp, a.ldk, kt, a.Nk, a.d, tid);
-    stage_rows<DH>(sV, vp, a.ldv, kt, a.Nk, a.d, tid);
+    stK.commit(sK);
+    stV.commit(sV);
     __syncthreads();
+    if (kt + TILE < a.Nk) {
+      stK.next(kt + TILE, tid);
+      stV.next(kt + TILE, tid);
+      stK.fetch();
+      stV.fetch();
+    }
     f32x4_t s[4][2], dp[4][2];
     zero_acc(s);
     zero_acc(dp);
@@ -327,10 +446,16 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(const AttnArgs a) {
       for (int of = 0; of < 2; ++of)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const bool valid = (kt + sf * 16 + (lane >> 4) * 4 + e) < a.Nk;
-          const float p = valid ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[sf][of][e], c, -lse2[of])) : 0.f;
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sf][of][e], c, -lse2[of]));
           s[sf][of][e] = p * (dp[sf][of][e] - dl[of]);
         }
+    if (kt + TILE > a.Nk) {  // last, partial tile: its padding rows repeat the last key row -> drop them
+#pragma unroll
+      for (int sf = 0; sf < 4; ++sf)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (kt + sf * 16 + (lane >> 4) * 4 + e >= a.Nk) s[sf][0][e] = s[sf][1][e] = 0.f;
+    }
     bf16x8_t pb[2][2];
     pack_p(pb, s);
     t_product<DH, DV>(dq, sK, pb, lane);
@@ -340,14 +465,19 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(const AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------ dK, dV
 template <int DH, int DV>
-__global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dkv_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char sQ[TILE * RowPitch<DH>::value];
   __shared__ __attribute__((aligned(16))) char sdO[TILE * RowPitch<DH>::value];
   __shared__ __attribute__((aligned(16))) float sLse[TILE];
   __shared__ __attribute__((aligned(16))) float sDelta[TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = blockIdx.y, b = blockIdx.z;
+  const int h = blockIdx.y, b = blockIdx.z / a.qsplit, split = blockIdx.z - b * a.qsplit;
   const int k0 = blockIdx.x * (4 * OWN) + wave * OWN;
+  // cross-attention has 77 key rows: one owner workgroup per (b, h) would stream all of Q on 32 CUs.  Split the Q range
+  // over qsplit workgroups instead; each writes an fp32 partial that a small kernel reduces (deterministic, no atomics)
+  const int tiles_per_split = ((a.Nq + TILE - 1) / TILE + a.qsplit - 1) / a.qsplit;
+  const int qt_lo = split * tiles_per_split * TILE;
+  const int qt_hi = min(a.Nq, qt_lo + tiles_per_split * TILE);
   const bf16_t* qp = a.q + (long)b * a.Nq * a.ldq + h * a.d;
   const bf16_t* dop = a.dout + (long)b * a.Nq * a.ldo + h * a.d;
   const bf16_t* kp = a.k + (long)b * a.Nk * a.ldk + h * a.d;
@@ -359,16 +489,42 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnArgs a) {
   zero_acc(dk);
   zero_acc(dv);
   const float c = a.scale * LOG2E;
-  for (int qt = 0; qt < a.Nq; qt += TILE) {
-    __syncthreads();
-    stage_rows<DH>(sQ, qp, a.ldq, qt, a.Nq, a.d, tid);
-    stage_rows<DH>(sdO, dop, a.ldo, qt, a.Nq, a.d, tid);
+  Stager<DH> stQ, stO;
+  stQ.init(sQ, qp, a.ldq, qt_lo, a.Nq, a.d, tid);
+  stO.init(sdO, dop, a.ldo, qt_lo, a.Nq, a.d, tid);
+  const float* lse_row = a.lse + ((long)b * a.H + h) * a.Nq;
+  const float* delta_row = a.delta + ((long)b * a.H + h) * a.Nq;
+  float lse_r = 0.f, delta_r = 0.f;   // threads 0..63: row statistics of the tile in flight
+  if (qt_lo < qt_hi) {
+    stQ.fetch();
+    stO.fetch();
     if (tid < TILE) {
-      const bool ok = (qt + tid) < a.Nq;
-      sLse[tid] = ok ? a.lse[((long)b * a.H + h) * a.Nq + qt + tid] * LOG2E : INFINITY;
-      sDelta[tid] = ok ? a.delta[((long)b * a.H + h) * a.Nq + qt + tid] : 0.f;
+      const int r = min(qt_lo + tid, a.Nq - 1);
+      lse_r = lse_row[r];
+      delta_r = delta_row[r];
+    }
+  }
+  for (int qt = qt_lo; qt < qt_hi; qt += TILE) {
+    __syncthreads();
+    stQ.commit(sQ);
+    stO.commit(sdO);
+    if (tid < TILE) {
+      const bool ok = (qt + tid) < a.Nq;   // rows past the end: p = exp2(s - inf) = 0
+      sLse[tid] = ok ? lse_r * LOG2E : INFINITY;
+      sDelta[tid] = ok ? delta_r : 0.f;
     }
     __syncthreads();
+    if (qt + TILE < qt_hi) {
+      stQ.next(qt + TILE, tid);
+      stO.next(qt + TILE, tid);
+      stQ.fetch();
+      stO.fetch();
+      if (tid < TILE) {
+        const int r = min(qt + TILE + tid, a.Nq - 1);
+        lse_r = lse_row[r];
+        delta_r = delta_row[r];
+      }
+    }
     f32x4_t s[4][2], dp[4][2];
     zero_acc(s);
     zero_acc(dp);
@@ -397,8 +553,41 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnArgs a) {
     t_product<DH, DV>(dk, sQ, pb, lane);
   }
   const long ldo_kv = (long)a.H * a.d;
+  if (a.qsplit > 1) {
+    const long slab = (long)a.qsplit * a.B * a.H * a.Nk * a.d;
+    float* pk = a.part + (((long)split * a.B + b) * a.H + h) * a.Nk * a.d;
+    store_t_f32<DV>(dk, pk, a.d, k0, a.Nk, a.d, lane);
+    store_t_f32<DV>(dv, pk + slab, a.d, k0, a.Nk, a.d, lane);
+    return;
+  }
   store_t<DV>(dk, a.dk + (long)b * a.Nk * ldo_kv + h * a.d, ldo_kv, k0, a.Nk, a.d, a.scale, a.scale, lane);
   store_t<DV>(dv, a.dv + (long)b * a.Nk * ldo_kv + h * a.d, ldo_kv, k0, a.Nk, a.d, 1.f, 1.f, lane);
+}
+
+// dk/dv[b][row][h*d + c] = bf16(mul * sum_split part[which][split][b][h][row][c]); 4 columns per thread
+__global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const AttnArgs a) {
+  const int d4 = a.d >> 2;
+  const long per = (long)a.B * a.H * a.Nk * d4, total = 2 * per;
+  const long slab = (long)a.qsplit * a.B * a.H * a.Nk * a.d;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+    const int which = id >= per;
+    long r = id - which * per;
+    const int c = (int)(r % d4) * 4;
+    r /= d4;
+    const int row = (int)(r % a.Nk);
+    r /= a.Nk;
+    const int h = (int)(r % a.H), b = (int)(r / a.H);
+    const float* p = a.part + which * slab + (((long)b * a.H + h) * a.Nk + row) * a.d + c;
+    const long sstride = (long)a.B * a.H * a.Nk * a.d;
+    float4 acc = *reinterpret_cast<const float4*>(p);
+    for (int sp = 1; sp < a.qsplit; ++sp) {
+      const float4 t = *reinterpret_cast<const float4*>(p + sp * sstride);
+      acc.x += t.x, acc.y += t.y, acc.z += t.z, acc.w += t.w;
+    }
+    const float mul = which ? 1.f : a.scale;
+    bf16_t* out = (which ? a.dv : a.dk) + ((long)b * a.Nk + row) * ((long)a.H * a.d) + h * a.d + c;
+    *reinterpret_cast<uint2*>(out) = make_uint2(pack_bf16x2(acc.x * mul, acc.y * mul), pack_bf16x2(acc.z * mul, acc.w * mul));
+  }
 }
 
 template <int DH, int DV>
@@ -412,7 +601,11 @@ int launch_bwd(const AttnArgs& a, hipStream_t st) {
   const long waves = (long)a.B * a.Nq * a.H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
   hipLaunchKernelGGL((attn_dq_kernel<DH, DV>), dim3(aql_cdiv(a.Nq, 4 * OWN), a.H, a.B), dim3(256), 0, st, a);
-  hipLaunchKernelGGL((attn_dkv_kernel<DH, DV>), dim3(aql_cdiv(a.Nk, 4 * OWN), a.H, a.B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((attn_dkv_kernel<DH, DV>), dim3(aql_cdiv(a.Nk, 4 * OWN), a.H, a.B * a.qsplit), dim3(256), 0, st, a);
+  if (a.qsplit > 1) {
+    const long n = 2L * a.B * a.H * a.Nk * (a.d / 4);
+    hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+  }
   return 0;
 }
 
@@ -439,8 +632,8 @@ extern "C" int aql_sdpa_fwd(const bf16_t* q, long ldq, const bf16_t* k, long ldk
 
 extern "C" int aql_sdpa_bwd(const bf16_t* q, long ldq, const bf16_t* k, long ldk, const bf16_t* v, long ldv,
                             const bf16_t* o, const bf16_t* dout, long ldo, const float* lse, float* delta, int B, int H,
-                            int Nq, int Nk, int d, float scale, bf16_t* dq, bf16_t* dk, bf16_t* dv,
-                            hipStream_t stream) {
+                            int Nq, int Nk, int d, float scale, bf16_t* dq, bf16_t* dk, bf16_t* dv, float* ws,
+                            size_t ws_bytes, hipStream_t stream) {
   AQL_CHECK_ARG(q && k && v && o && dout && lse && delta && dq && dk && dv, "aql_sdpa_bwd: null operand");
   AQL_CHECK_ARG(d % 8 == 0 && d <= 160 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && Nk > 0,
                 "aql_sdpa_bwd: unsupported head dim %d or strides", d);
@@ -449,6 +642,17 @@ extern "C" int aql_sdpa_bwd(const bf16_t* q, long ldq, const bf16_t* k, long ldk
   a.dq = dq; a.dk = dk; a.dv = dv;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d; a.scale = scale;
+  // split the streamed Q range when the key side alone cannot fill the chip (cross-attention: Nk = 77)
+  a.qsplit = 1;
+  a.part = ws;
+  const long owner_wgs = (long)aql_cdiv(Nk, 4 * OWN) * H * B;
+  if (ws != nullptr && owner_wgs < 256 && Nq >= 4 * TILE) {
+    int sp = (int)(512 / owner_wgs);
+    const int qtiles = aql_cdiv(Nq, TILE);
+    if (sp > qtiles / 2) sp = qtiles / 2;   // at least two Q tiles per workgroup
+    while (sp > 1 && (size_t)2 * sp * B * H * Nk * d * sizeof(float) > ws_bytes) --sp;
+    if (sp > 1) a.qsplit = sp;
+  }
   if (d <= 48) launch_bwd<64, 48>(a, stream);
   else if (d <= 64) launch_bwd<64, 64>(a, stream);
   else if (d <= 96) launch_bwd<96, 96>(a, stream);

@@ -629,9 +629,11 @@ class AttentionFn(torch.autograd.Function):
         d = C // heads
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         delta = torch.empty(B, heads, Nq, dtype=torch.float32, device=q.device)
+        ws = workspace(q.device)
+        ws = workspace(q.device)   # split-Q partials of dK/dV when Nk is short (cross-attention)
         L.call("aql_sdpa_bwd", L.ptr(q), q.stride(1), L.ptr(k), k.stride(1), L.ptr(v), v.stride(1), L.ptr(o),
                L.ptr(do), o.stride(1), L.ptr(lse), L.ptr(delta), B, heads, Nq, Nk, d, float(d ** -0.5),
-               L.ptr(dq), L.ptr(dk), L.ptr(dv), L.stream_ptr())
+               L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(ws), ws.numel() * 4, L.stream_ptr())
         return dq, dk, dv, None
 
 

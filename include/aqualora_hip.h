@@ -86,7 +86,9 @@ int aql_sdpa_fwd(const bf16_t* q, long ldq, const bf16_t* k, long ldk, const bf1
                  int Nk, int d, float scale, bf16_t* o, long ldo, float* lse, aql_stream_t stream);
 int aql_sdpa_bwd(const bf16_t* q, long ldq, const bf16_t* k, long ldk, const bf16_t* v, long ldv, const bf16_t* o,
                  const bf16_t* dout, long ldo, const float* lse, float* delta, int B, int H, int Nq, int Nk, int d,
-                 float scale, bf16_t* dq, bf16_t* dk, bf16_t* dv, aql_stream_t stream);
+                 float scale, bf16_t* dq, bf16_t* dk, bf16_t* dv, float* ws, size_t ws_bytes, aql_stream_t stream);
+/* ws (optional, caller-owned, per stream): fp32 scratch for split-Q partials of dK/dV when Nk is too short to fill the
+ * chip (cross-attention, Nk = 77); 2*splits*B*H*Nk*d floats are used, NULL disables the split.                    */
 
 /* ---- elementwise / small modules (csrc/aql_elem.hip) ---------------------------------------------------------- */
 /* GEGLU  original_unet.py:727-729 : out[M,F] = in[:, :F] * gelu(in[:, F:])                                         */
