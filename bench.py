@@ -268,12 +268,17 @@ def main():
             ks = dominant_kernels(args.batch, device)
         dom = ks[0]
         # dominant kernel = the implicit-GEMM 3x3 convolution family (48 % of the step's algorithmic FLOPs); timed live
-        # with HIP events on the launch stream.  `traffic` is null: the FETCH_SIZE / WRITE_SIZE pass of rocprofv3 times out
-        # on this image for the current kernel (profiles/r01_pmc_gemm_conv.txt holds the figure of the PREVIOUS conv
-        # kernel, 477 MB per launch before the XCD-aware remap; algorithmic bytes are 22.8 MB).
+        # with HIP events on the launch stream.  `traffic` = HBM bytes per launch of the same kernel and shape from the
+        # rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 2x FETCH correction), collected
+        # with tools/pmc_traffic.sh and committed as profiles/r01_pmc_traffic.json; null for other batch sizes.
+        traffic = None
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        if args.batch == 4 and os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                traffic = json.load(f)["conv3x3 320->320 @64x64 B=4"]["traffic_bytes"]
         line["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_tflops"],
                             "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": dom["frac_of_mfma_peak"],
-                            "traffic": None,
+                            "traffic": traffic, "traffic_unit": "bytes/launch (algorithmic: 22.8e6)",
                             "flops_per_launch": dom["flops"], "ms_per_launch": dom["ms"]}
         line["step_roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
                                  "frac": achieved / MFMA_PEAK_TF,
