@@ -102,29 +102,39 @@ def dominant_kernels(B, device):
 
 
 def cpu_baseline(tr, rank):
-    """Bounded CPU sample: ONE full-size U-Net forward (the 'clean' pass, batch 1) of the oracle on the host cores;
-    a PPFT step is 3 traversals + LoRA = 2.477/0.8033 of that work, which is how the images/s figure is derived."""
+    """Bounded CPU sample of the SAME workload: ONE real PPFT step of the oracle (oracle/ppft_oracle.py: clean forward,
+    watermarked forward with the LoRA branch, MSE, backward to all 384 LoRA tensors + the mapper) on the full-size
+    SD-1.5 U-Net at batch 1, fp32, on the host cores -- about 10-20 s after one warm-up forward."""
     from oracle import ppft_oracle as O
-    from aqualora_amd.unet import SD15
+    from aqualora_amd.unet import SD15, lora_keys
     from aqualora_amd import synth
     cores = min(32, len(os.sched_getaffinity(0)))  # more threads than this slows torch's CPU convs down on big hosts
     torch.set_num_threads(cores)
     sd = {k: v.detach().float().cpu() for k, v in tr.unet.state_dict().items() if "lora_layer" not in k}
-    net = O.UNetOracle(sd, dict(SD15))
-    x = synth.normal("bench.z", (1, 4, 64, 64), 1.0, 2048)
+    keys = lora_keys(tr.unet)
+    lora = {}
+    for k in keys:
+        layer = tr.unet.get_submodule(k).lora_layer
+        lora[k] = (layer.down.weight.detach().float().cpu().clone().requires_grad_(True),
+                   layer.up.weight.detach().float().cpu().clone().requires_grad_(True))
+    E = tr.mapper.bit_embeddings.weight.detach().float().cpu().clone().requires_grad_(True)
+    z = synth.normal("bench.z", (1, 4, 64, 64), 1.0, 2048)
+    wm = synth.normal("bench.wm", (1, 4, 64, 64), 0.05, 2048)
+    eps = synth.normal("bench.eps", (1, 4, 64, 64), 1.0, 2048)
+    msg = synth.bits("bench.msg", (1, 48), 2048)
     ctx = synth.normal("bench.ctx", (1, 77, 768), 1.0, 2048)
     t = torch.tensor([500])
-    times = []
-    with torch.no_grad():
-        for _ in range(4):  # 1 warm-up + 3 timed full-size forwards (about 10 s of CPU work on 32 threads)
-            t0 = time.perf_counter()
-            net.forward(x, t, ctx, None)
-            times.append(time.perf_counter() - t0)
-    dt = sorted(times[1:])[1]
-    step_s = dt * step_tflop_per_image(rank) / (UNET_FWD_GFLOP / 1e3)
+    with torch.no_grad():  # warm-up: pages the weights in, spins the thread pool up
+        t0 = time.perf_counter()
+        O.UNetOracle(sd, dict(SD15)).forward(z, t, ctx, None)
+        fwd_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    loss, _, _, _ = O.ppft_loss(sd, dict(SD15), lora, E, msg, z, wm, eps, t, ctx)
+    loss.backward()
+    step_s = time.perf_counter() - t0
     return {"value": 1.0 / step_s, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"median of 3 full-size SD-1.5 U-Net forwards (batch 1, fp32, oracle/ppft_oracle.py) = {dt:.2f} s; "
-                      f"PPFT step extrapolated by algorithmic FLOPs x{step_tflop_per_image(rank) / (UNET_FWD_GFLOP / 1e3):.3f}"}
+            "sample": f"one full PPFT step of oracle/ppft_oracle.py (clean fwd + LoRA fwd + backward to {2 * len(keys)} LoRA "
+                      f"tensors) on the full-size SD-1.5 U-Net, batch 1, fp32: {step_s:.2f} s (warm-up forward {fwd_s:.2f} s)"}
 
 
 def infer_bench(args, device):
