@@ -88,16 +88,19 @@ struct Stager {
   static constexpr int NIT = (TILE * CPR + 255) / 256;
   long p[NIT];   // element offset of the slot's 16 bytes from g (offsets, not pointers: pointer arrays end up in scratch)
   uint4 v[NIT];
-  int off[NIT];  // LDS byte offset of the slot, -1: nothing to stage (outside the tile or padding chunk)
+  int off[NIT];  // LDS byte offset of the slot, -1: no slot (the tile has only TILE * d/8 live chunks)
   const bf16_t* g;
   long ld;
-  int nrows;
+  int nrows, cl;  // cl = d / 8 live 16-byte chunks per row
 
+  // Slots are numbered over the LIVE chunks only (row = id / cl, chunk = id % cl): at d = 40 a tile is 320 chunks, so
+  // the second slot of wavefronts 1-3 is empty and skipped wave-uniformly instead of issuing a load + LDS write for
+  // padding (staging measured at 57 of the 213 us of the d=40 forward with one slot per padded chunk).
   __device__ __forceinline__ void point(int row0, int tid) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int id = tid + it * 256;
-      const int row = id / CPR, c = id - row * CPR;
+      const int row = id / cl, c = id - row * cl;
       const int r = min(row0 + row, nrows - 1);
       p[it] = off[it] >= 0 ? (long)r * ld + c * 8 : 0;
     }
@@ -106,20 +109,23 @@ struct Stager {
     g = g_;
     ld = ld_;
     nrows = nrows_;
+    cl = PF ? (d >> 3) : CPR;   // larger heads keep the compile-time mapping (their kernels are short: init cost matters)
+    const int dl = d >> 3;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int id = tid + it * 256;
-      const int row = id / CPR, c = id - row * CPR;
-      const bool in_tile = id < TILE * CPR;
-      const bool live = in_tile & (c * 8 < d);
-      off[it] = live ? tile_off<DH>(row, c) : -1;
-      if (in_tile & !live) *reinterpret_cast<uint4*>(lds + tile_off<DH>(row, c)) = zero4();
+      const int row = id / cl, c = id - row * cl;
+      off[it] = (id < TILE * cl && c < dl) ? tile_off<DH>(row, c) : -1;
+      // padding chunks d/8 .. DH/8 of the LDS image: zeroed once, never overwritten
+      const int prow = id / CPR, pc = id - prow * CPR;
+      if (id < TILE * CPR && pc >= dl) *reinterpret_cast<uint4*>(lds + tile_off<DH>(prow, pc)) = zero4();
     }
     point(row0, tid);
   }
   __device__ __forceinline__ void load() {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) v[it] = *reinterpret_cast<const uint4*>(g + p[it]);
+    for (int it = 0; it < NIT; ++it) v[it] = *reinterpret_cast<const uint4*>(g + p[it]);  // unconditional: a branch
+    // around a load makes hipcc wait vmcnt(0) right behind it; empty slots re-read g[0] (one cache line, all lanes)
   }
   __device__ __forceinline__ void fetch() {
     if constexpr (PF) load();
@@ -133,7 +139,7 @@ struct Stager {
   __device__ __forceinline__ void next(int row0, int tid) {
     if (row0 + TILE <= nrows) {
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) p[it] += (long)TILE * ld;  // dead slots walk along row starts: still in bounds
+      for (int it = 0; it < NIT; ++it) p[it] += (long)TILE * ld;
     } else {
       point(row0, tid);
     }
@@ -376,23 +382,6 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const
   }
 }
 
-// delta[b,h,q] = sum_d dO[q,d] * O[q,d]
-__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
-  const long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, q, h) one wavefront each
-  const int lane = threadIdx.x & 63;
-  const long total = (long)a.B * a.Nq * a.H;
-  if (idx >= total) return;
-  const int h = (int)(idx % a.H);
-  const long bq = idx / a.H;
-  const bf16_t* op = a.o + bq * a.ldo + h * a.d;
-  const bf16_t* dp = a.dout + bq * a.ldo + h * a.d;
-  float acc = 0.f;
-  for (int e = lane; e < a.d; e += 64) acc += bf16_to_f32(op[e]) * bf16_to_f32(dp[e]);
-  acc = wave_sum(acc);
-  const int b = (int)(bq / a.Nq), q = (int)(bq % a.Nq);
-  if (lane == 0) a.delta[((long)b * a.H + h) * a.Nq + q] = acc;
-}
-
 // ------------------------------------------------------------------------------------------------ dQ
 template <int DH, int DV>
 __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dq_kernel(const AttnArgs a) {
@@ -408,13 +397,31 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dq_kernel(const 
   bf16x8_t qf[2][DH / 32], dof[2][DH / 32];
   load_owner<DH>(qf, qp, a.ldq, q0, a.Nq, a.d, lane);
   load_owner<DH>(dof, dop, a.ldo, q0, a.Nq, a.d, lane);
+  // delta[row] = sum_d dO[row,d] * O[row,d], computed here from the owner fragments (each lane holds 8 columns per
+  // k-step of its row; the 4 lane groups of a row are summed) instead of a separate kernel; written out for dK/dV.
   float lse2[2], dl[2];
+  {
+    bf16x8_t ofr[2][DH / 32];
+    load_owner<DH>(ofr, a.o + (long)b * a.Nq * a.ldo + h * a.d, a.ldo, q0, a.Nq, a.d, lane);
+#pragma unroll
+    for (int of = 0; of < 2; ++of) {
+      float acc = 0.f;
+#pragma unroll
+      for (int s = 0; s < DH / 32; ++s) {
+        const uint4 x = *reinterpret_cast<const uint4*>(&dof[of][s]);
+        const uint4 y = *reinterpret_cast<const uint4*>(&ofr[of][s]);
+        acc += bf16lo(x.x) * bf16lo(y.x) + bf16hi(x.x) * bf16hi(y.x) + bf16lo(x.y) * bf16lo(y.y) + bf16hi(x.y) * bf16hi(y.y) +
+               bf16lo(x.z) * bf16lo(y.z) + bf16hi(x.z) * bf16hi(y.z) + bf16lo(x.w) * bf16lo(y.w) + bf16hi(x.w) * bf16hi(y.w);
+      }
+      dl[of] = group4_sum(acc);
+    }
+  }
 #pragma unroll
   for (int of = 0; of < 2; ++of) {
     const int row = q0 + of * 16 + (lane & 15);
     const bool ok = row < a.Nq;
     lse2[of] = ok ? a.lse[((long)b * a.H + h) * a.Nq + row] * LOG2E : INFINITY;
-    dl[of] = ok ? a.delta[((long)b * a.H + h) * a.Nq + row] : 0.f;
+    if (ok && (lane >> 4) == 0) a.delta[((long)b * a.H + h) * a.Nq + row] = dl[of];
   }
   f32x4_t dq[DV / 16][2];
   zero_acc(dq);
@@ -598,8 +605,6 @@ int launch_fwd(const AttnArgs& a, hipStream_t st) {
 }
 template <int DH, int DV>
 int launch_bwd(const AttnArgs& a, hipStream_t st) {
-  const long waves = (long)a.B * a.Nq * a.H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
   hipLaunchKernelGGL((attn_dq_kernel<DH, DV>), dim3(aql_cdiv(a.Nq, 4 * OWN), a.H, a.B), dim3(256), 0, st, a);
   hipLaunchKernelGGL((attn_dkv_kernel<DH, DV>), dim3(aql_cdiv(a.Nk, 4 * OWN), a.H, a.B * a.qsplit), dim3(256), 0, st, a);
   if (a.qsplit > 1) {

@@ -6,6 +6,8 @@ import torch
 
 sys.path.insert(0, ".")
 from aqualora_amd import _lib as L  # noqa: E402
+import os
+L.LIB_PATH = os.environ.get("AQL_LIB", L.LIB_PATH)   # ablation builds
 
 SHAPES = [(4, 8, 4096, 4096, 40), (4, 8, 1024, 1024, 80), (4, 8, 256, 256, 160), (4, 8, 4096, 77, 40),
           (4, 8, 1024, 77, 80), (4, 8, 256, 77, 160), (4, 8, 64, 64, 160)]
