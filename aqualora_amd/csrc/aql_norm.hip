@@ -173,6 +173,142 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Fused GroupNorm: ONE launch, one workgroup per (sample, group).  The workgroup streams its HW x (C/32) slice twice --
+// pass 1 statistics, pass 2 normalise (+SiLU) -- and the second read is served by the XCD's L2 (a slice is 82 KB at
+// 64x64x320, 245 KB at 64x64x960), so HBM sees one read and one write and nothing but a workgroup barrier separates the
+// passes (the 3-kernel form drains the chip twice per GroupNorm, 180 times a step).  Accesses are 4-byte (two
+// channels): group boundaries are only 4-byte aligned (10 / 20 / 30 / 60 channels per group in the SD-1.5 U-Net);
+// consecutive lanes walk the dwords of a pixel, then the next pixel.  Block mapping: hardware block b runs on XCD b % 8;
+// groups 4x .. 4x+3 of every sample go to XCD x so that the cache lines they share are fetched by one L2.
+// Requires an even number of channels per group (else the callers use the 3-kernel path).
+// MODE 0: y = act(xhat*gamma+beta), writes stats.  MODE 1: dx = rstd*(dxhat - mean(dxhat) - xhat*mean(dxhat*xhat)) (+dres)
+// ---------------------------------------------------------------------------------------------------
+constexpr int GNF_THREADS = 1024;
+constexpr int GNF_U = 8;  // pixels in flight per thread
+
+template <int MODE>
+__global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                               const bf16_t* __restrict__ gamma,
+                                                               const bf16_t* __restrict__ beta, float* __restrict__ stats,
+                                                               int HW, int C, float eps, int silu,
+                                                               const bf16_t* __restrict__ dres, bf16_t* __restrict__ out) {
+  __shared__ float red[2][GNF_THREADS / 64];
+  __shared__ float bc[2];
+  const int bid = blockIdx.x;
+  const int b = bid >> 5, gi = bid & 31;
+  const int g = ((gi & 7) << 2) | (gi >> 3);  // XCD (bid % 8) hosts groups 4x..4x+3
+  const int cpg = C / G, D = cpg >> 1;        // dwords per pixel of this group
+  const int active = (GNF_THREADS / D) * D;   // each thread keeps ONE channel pair
+  const int tid = threadIdx.x;
+  const bool live = tid < active;
+  const int dw = tid % D, p0 = tid / D, pstep = active / D;
+  const int ch = g * cpg + 2 * dw;
+  const long base = (long)b * HW * C + ch;
+  float ga0 = 0.f, ga1 = 0.f, be0 = 0.f, be1 = 0.f;
+  {
+    const uint32_t gw = *reinterpret_cast<const uint32_t*>(gamma + ch), bw = *reinterpret_cast<const uint32_t*>(beta + ch);
+    ga0 = bf16lo(gw); ga1 = bf16hi(gw); be0 = bf16lo(bw); be1 = bf16hi(bw);
+  }
+  float mu, rs;
+  if (MODE == 1) {
+    mu = stats[(b * G + g) * 2 + 0];
+    rs = stats[(b * G + g) * 2 + 1];
+  }
+  auto dxhat = [&](float xh, float d, float ga, float be) {
+    if (silu) {
+      const float z = xh * ga + be;
+      const float sg = sigmoidf_(z);
+      d *= sg * (1.f + z * (1.f - sg));
+    }
+    return d * ga;
+  };
+  // ---- pass 1.  GNF_U pixels per thread are loaded before any is used: a thread has only HW*D/1020 (~20) dwords to
+  // fetch per pass, so the pass is latency-bound unless they are all in flight
+  float s1 = 0.f, s2 = 0.f;
+  if (live) {
+    for (int p = p0; p < HW; p += pstep * GNF_U) {
+      uint32_t xw[GNF_U], dwv[GNF_U];
+#pragma unroll
+      for (int u = 0; u < GNF_U; ++u) {
+        const int pp = min(p + u * pstep, HW - 1);
+        xw[u] = *reinterpret_cast<const uint32_t*>(x + base + (long)pp * C);
+        if (MODE == 1) dwv[u] = *reinterpret_cast<const uint32_t*>(dy + base + (long)pp * C);
+      }
+#pragma unroll
+      for (int u = 0; u < GNF_U; ++u) {
+        if (p + u * pstep >= HW) continue;
+        const float x0 = bf16lo(xw[u]), x1 = bf16hi(xw[u]);
+        if (MODE == 0) {
+          s1 += x0 + x1;
+          s2 += x0 * x0 + x1 * x1;
+        } else {
+          const float h0 = (x0 - mu) * rs, h1 = (x1 - mu) * rs;
+          const float d0 = dxhat(h0, bf16lo(dwv[u]), ga0, be0), d1 = dxhat(h1, bf16hi(dwv[u]), ga1, be1);
+          s1 += d0 + d1;
+          s2 += d0 * h0 + d1 * h1;
+        }
+      }
+    }
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = s1;
+    red[1][tid >> 6] = s2;
+  }
+  __syncthreads();
+  if (tid < 2) {  // fixed-order sum over the 16 wavefronts: deterministic
+    float a = 0.f;
+    for (int w = 0; w < GNF_THREADS / 64; ++w) a += red[tid][w];
+    bc[tid] = a;
+  }
+  __syncthreads();
+  const float inv = 1.f / ((float)HW * cpg);
+  float m1, m2;
+  if (MODE == 0) {
+    mu = bc[0] * inv;
+    rs = rsqrtf(fmaxf(bc[1] * inv - mu * mu, 0.f) + eps);
+    if (tid == 0) {
+      stats[(b * G + g) * 2 + 0] = mu;
+      stats[(b * G + g) * 2 + 1] = rs;
+    }
+  } else {
+    m1 = bc[0] * inv;
+    m2 = bc[1] * inv;
+  }
+  // ---- pass 2 (re-read from L2)
+  if (!live) return;
+  for (int p = p0; p < HW; p += pstep * GNF_U) {
+    uint32_t xw[GNF_U], dwv[GNF_U], rw[GNF_U];
+#pragma unroll
+    for (int u = 0; u < GNF_U; ++u) {
+      const long o = base + (long)min(p + u * pstep, HW - 1) * C;
+      xw[u] = *reinterpret_cast<const uint32_t*>(x + o);
+      if (MODE == 1) {
+        dwv[u] = *reinterpret_cast<const uint32_t*>(dy + o);
+        rw[u] = dres != nullptr ? *reinterpret_cast<const uint32_t*>(dres + o) : 0u;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < GNF_U; ++u) {
+      if (p + u * pstep >= HW) continue;
+      const long o = base + (long)(p + u * pstep) * C;
+      const float h0 = (bf16lo(xw[u]) - mu) * rs, h1 = (bf16hi(xw[u]) - mu) * rs;
+      float r0, r1;
+      if (MODE == 0) {
+        const float z0 = h0 * ga0 + be0, z1 = h1 * ga1 + be1;
+        r0 = silu ? z0 * sigmoidf_(z0) : z0;
+        r1 = silu ? z1 * sigmoidf_(z1) : z1;
+      } else {
+        r0 = rs * (dxhat(h0, bf16lo(dwv[u]), ga0, be0) - m1 - h0 * m2) + bf16lo(rw[u]);
+        r1 = rs * (dxhat(h1, bf16hi(dwv[u]), ga1, be1) - m1 - h1 * m2) + bf16hi(rw[u]);
+      }
+      *reinterpret_cast<uint32_t*>(out + o) = pack_bf16x2(r0, r1);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // LayerNorm: one wavefront per token row, row kept in registers (C <= 64*8*MAXC).
 // ---------------------------------------------------------------------------------------------------
 constexpr int LN_MAXC = 3;  // up to 1536 channels
@@ -287,6 +423,17 @@ inline int gn_geometry(int HW, int C, int* threads, int* rows_per_slab) {
   return (HW + *rows_per_slab - 1) / *rows_per_slab;
 }
 
+// Fused single-launch form: needs an even channel count per group (4-byte accesses).  Measured per shape inside a HIP
+// graph (tools/tune_gn.py, B=4): 2-4x faster than the 3-kernel form up to 32x32 maps (8.1 vs 14.7 us at 320 ch, 13.6 vs
+// 23.4 at 1280 ch; backward 4.7 vs 22.3 us at 8x8x1280), slower at 64x64 (33.5 vs 26.5 us at 320 ch: a group's 20-byte
+// pixel segments touch 6x their bytes in cache lines and 128 workgroups cannot hide it), so large maps keep the slab
+// form.  AQL_GN_FUSED=0 forces the 3-kernel path, =2 forces the fused one (tuning).
+inline bool gn_use_fused(int C, int HW) {
+  static const int en = getenv("AQL_GN_FUSED") ? atoi(getenv("AQL_GN_FUSED")) : 1;
+  if (!en || (C / G) % 2 != 0 || (C / G) / 2 > GNF_THREADS) return false;
+  return en == 2 || HW <= 2048;
+}
+
 }  // namespace
 
 // scratch: caller-owned fp32 workspace of at least aql_groupnorm_scratch_floats(B, HW) elements
@@ -300,6 +447,12 @@ extern "C" int aql_groupnorm_silu_fwd(const bf16_t* x, int B, int HW, int C, con
                                       hipStream_t stream) {
   AQL_CHECK_ARG(x && gamma && beta && y && stats && scratch, "aql_groupnorm_silu_fwd: null operand");
   AQL_CHECK_ARG(C % (8 * 1) == 0 && C % G == 0 && C / 8 <= 1024, "aql_groupnorm_silu_fwd: bad C=%d", C);
+  if (gn_use_fused(C, HW)) {
+    hipLaunchKernelGGL(gn_fused_kernel<0>, dim3(B * G), dim3(GNF_THREADS), 0, stream, x, nullptr, gamma, beta, stats, HW, C,
+                       eps, silu, nullptr, y);
+    AQL_CHECK_LAUNCH("aql_groupnorm_silu_fwd");
+    return AQL_OK;
+  }
   int threads, rps;
   const int nslab = gn_geometry(HW, C, &threads, &rps);
   hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(nslab, B), dim3(threads), threads * 64, stream, x, nullptr, gamma, beta, nullptr,
@@ -320,6 +473,12 @@ extern "C" int aql_groupnorm_silu_bwd(const bf16_t* x, const bf16_t* dy, int B, 
                                       float* scratch, hipStream_t stream) {
   AQL_CHECK_ARG(x && dy && gamma && beta && dx && stats && scratch, "aql_groupnorm_silu_bwd: null operand");
   AQL_CHECK_ARG(C % 8 == 0 && C % G == 0 && C / 8 <= 1024, "aql_groupnorm_silu_bwd: bad C=%d", C);
+  if (gn_use_fused(C, HW)) {
+    hipLaunchKernelGGL(gn_fused_kernel<1>, dim3(B * G), dim3(GNF_THREADS), 0, stream, x, dy, gamma, beta,
+                       const_cast<float*>(stats), HW, C, 0.f, silu, dres, dx);
+    AQL_CHECK_LAUNCH("aql_groupnorm_silu_bwd");
+    return AQL_OK;
+  }
   int threads, rps;
   const int nslab = gn_geometry(HW, C, &threads, &rps);
   float* dstats = scratch + (long)B * 128 * G * 2;
