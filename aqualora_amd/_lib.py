@@ -26,6 +26,8 @@ SIGNATURES = {
     "aql_conv3x3_fwd": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_sz, c_p],
     "aql_conv3x3_bwd_data": [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_sz, c_p],
     "aql_gemm_tn_f32": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_f, c_p, c_l, c_p],
+    "aql_gemm_tn_tr_f32": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_f, c_p, c_l, c_p],
+    "aql_gemm_tn_tr_grouped": [c_p, c_i, c_i, c_i, c_i, c_p],
     "aql_groupnorm_silu_fwd": [c_p, c_i, c_i, c_i, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p],
     "aql_groupnorm_silu_bwd": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p],
     "aql_layernorm_fwd": [c_p, c_l, c_i, c_p, c_p, c_f, c_p, c_p, c_p],
@@ -41,6 +43,7 @@ SIGNATURES = {
     "aql_cast_transpose": [c_p, c_i, c_i, c_p, c_p, c_p],
     "aql_cast_transpose_batched": [c_p, c_i, c_i, c_p],
     "aql_tn_desc_fill": [c_p, c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_f, c_p, c_l, c_i],
+    "aql_tntr_desc_fill": [c_p, c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_f, c_p, c_l, c_i],
     "aql_gemm_tn_grouped": [c_p, c_i, c_i, c_p],
     "aql_gemm_tn_grouped_range": [c_p, c_i, c_i, c_i, c_i, c_p],
     "aql_ds_desc_fill": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i],

@@ -1,0 +1,259 @@
+// Token-reduction ("TN") GEMM for the wide-rank LoRA weight gradients:  C[P,Q] (fp32) += alpha * U[M,P]^T V[M,Q]
+// (dA = dT^T X and dB = dY^T Ts of utils/lora_modules.py:13-19 under autograd, at rank 320 real GEMMs of
+// 2*320*C*tokens FLOP each).  Both operands are stored token-major, i.e. the contraction index is the ROW index, which
+// is the wrong way round for an MFMA fragment (8 consecutive contraction elements per lane).  Instead of transposing
+// both operands in HBM first (the previous path: 2 transpose launches + NT GEMM + split-K accumulate per gradient,
+// 17 % of the rank-320 step), the 64-token tiles are staged row-major exactly as they lie in memory and the fragments
+// are gathered with the LDS transpose read ds_read_b64_tr_b16 -- the same gather as the P.V product of the attention
+// kernels (aql_attn.hip, t_product).  Both operands use the identical gather, so the k-slot permutation it implies
+// (slot (g,e) of step s <-> token 32 s + 16 (e>>2) + 4 g + (e&3)) cancels.
+//
+// Workgroup: 256 threads = 2x2 wavefronts, tile 128 (P) x 128 (Q), 64x64 per wavefront (16 accumulators of 16x16);
+// LDS 2 x 16 KB, next tile prefetched into registers under the MFMAs; the token range is split over grid.y and the
+// partial tiles are accumulated with fp32 atomics (the weight gradients are order-nondeterministic in the last bits
+// already).
+#include "aql_common.h"
+
+namespace {
+
+constexpr int TK = 64;      // tokens per stage
+constexpr int BT = 128;     // tile width, both sides
+constexpr int PITCH = 256;  // bytes per LDS row
+constexpr int SLOTS = TK * (BT / 8) / 256;  // 16-byte slots per thread per operand tile (= 4)
+
+// conflict-free for the 8-row x 32-byte transpose gathers (same image as aql_attn.hip's row tiles)
+__device__ __forceinline__ int tile_off(int row, int chunk) { return row * PITCH + ((chunk ^ ((row & 7) << 1)) << 4); }
+
+__device__ __forceinline__ uint4 mask4(const uint4& v, bool ok) {
+  const uint32_t m = 0u - (uint32_t)ok;
+  return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
+}
+
+struct TileStager {
+  long p[SLOTS];   // element offset from g of the slot in the CURRENT tile
+  uint4 v[SLOTS];
+  int off[SLOTS];  // LDS byte offset, -1: column past the operand's width (zeroed once)
+  const bf16_t* g;
+  long ld;
+
+  __device__ __forceinline__ void init(char* lds, const bf16_t* g_, long ld_, long m0, int col0, int width, int tid) {
+    g = g_;
+    ld = ld_;
+#pragma unroll
+    for (int it = 0; it < SLOTS; ++it) {
+      const int id = tid + it * 256;
+      const int row = id >> 4, c = id & 15;
+      const bool live = col0 + c * 8 < width;
+      off[it] = live ? tile_off(row, c) : -1;
+      p[it] = live ? (m0 + row) * ld + col0 + c * 8 : 0;
+      if (!live) *reinterpret_cast<uint4*>(lds + tile_off(row, c)) = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  // full tile: unconditional loads; tail tile (rows past M must read as ZERO: they enter the sum): clamped + masked
+  __device__ __forceinline__ void fetch(long m0, long M, int tid) {
+    if (m0 + TK <= M) {
+#pragma unroll
+      for (int it = 0; it < SLOTS; ++it) v[it] = *reinterpret_cast<const uint4*>(g + p[it]);
+    } else {
+#pragma unroll
+      for (int it = 0; it < SLOTS; ++it) {
+        const int row = (tid + it * 256) >> 4;
+        const bool ok = (m0 + row < M) & (off[it] >= 0);
+        const uint4 x = *reinterpret_cast<const uint4*>(g + (ok ? p[it] : 0));
+        v[it] = mask4(x, ok);
+      }
+    }
+  }
+  __device__ __forceinline__ void commit(char* lds) const {
+#pragma unroll
+    for (int it = 0; it < SLOTS; ++it)
+      if (off[it] >= 0) *reinterpret_cast<uint4*>(lds + off[it]) = v[it];
+  }
+  __device__ __forceinline__ void advance() {
+#pragma unroll
+    for (int it = 0; it < SLOTS; ++it) p[it] += (long)TK * ld;  // dead slots stay at offset 0 + k*TK*ld: unused
+  }
+};
+
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+
+// 16 columns [col0, col0+16) of the row-major tile, tokens 32*s2 .. 32*s2+31, as an MFMA operand (see header)
+__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int s2, int col0, int lane) {
+  const int p = lane & 15, g = lane >> 4;
+  const int row = s2 * 32 + g * 4 + (p >> 2);  // rows row and row+16 share (row & 7): same swizzle
+  const char* base = tile + tile_off(row, (col0 >> 3) + ((p & 3) >> 1)) + (p & 1) * 8;
+  const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3)))*)(base));
+  const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3)))*)(base + 16 * PITCH));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+struct TnArgs {
+  const bf16_t *U, *V;
+  long ldu, ldv, M;
+  int P, Q;
+  float alpha;
+  float* C;
+  long ldc;
+  int tiles_q, tiles_per_split;
+};
+
+__device__ __forceinline__ void tn_tr_body(const TnArgs& a, const int tile, const int split, char* sU, char* sV) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tp = tile / a.tiles_q, tq = tile - tp * a.tiles_q;
+  const int p0 = tp * BT, q0 = tq * BT;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const long m_lo = (long)split * a.tiles_per_split * TK;
+  long m_hi = m_lo + (long)a.tiles_per_split * TK;
+  if (m_hi > a.M) m_hi = a.M;
+  if (m_lo >= m_hi) return;
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  TileStager su, sv;
+  su.init(sU, a.U, a.ldu, m_lo, p0, a.P, tid);
+  sv.init(sV, a.V, a.ldv, m_lo, q0, a.Q, tid);
+  su.fetch(m_lo, a.M, tid);
+  sv.fetch(m_lo, a.M, tid);
+  for (long m = m_lo; m < m_hi; m += TK) {
+    __syncthreads();
+    su.commit(sU);
+    sv.commit(sV);
+    __syncthreads();
+    if (m + TK < m_hi) {  // next tile's loads fly under this tile's MFMAs
+      su.advance();
+      sv.advance();
+      su.fetch(m + TK, a.M, tid);
+      sv.fetch(m + TK, a.M, tid);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8_t fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = tr_frag(sU, s2, wm0 + i * 16, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = tr_frag(sV, s2, wn0 + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // acc[i][j][e]: row P = p0 + wm0 + 16 i + 4 (lane>>4) + e, column Q = q0 + wn0 + 16 j + (lane & 15)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int pr = p0 + wm0 + i * 16 + (lane >> 4) * 4 + e;
+      if (pr >= a.P) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int qc = q0 + wn0 + j * 16 + (lane & 15);
+        if (qc < a.Q) atomicAdd(a.C + (long)pr * a.ldc + qc, a.alpha * acc[i][j][e]);
+      }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const TnArgs a) {
+  __shared__ __attribute__((aligned(16))) char sU[TK * PITCH];
+  __shared__ __attribute__((aligned(16))) char sV[TK * PITCH];
+  tn_tr_body(a, blockIdx.x, blockIdx.y, sU, sV);
+}
+
+// Grouped form: ONE launch for all wide weight gradients of a backward pass (or of one exchange bucket).  The table is
+// an array of TnTrDesc in device memory; first_block is a running prefix, block_base offsets a sub-range launch.
+struct TnTrDesc {
+  TnArgs a;         // 80 bytes
+  int first_block;  // workgroups of all earlier descriptors
+  int n_tiles;      // tiles_p * tiles_q
+  int pad[2];
+};
+static_assert(sizeof(TnArgs) == 80 && sizeof(TnTrDesc) == 96, "descriptor layout is part of the ABI");
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_tr_grouped_kernel(const TnTrDesc* __restrict__ descs, int n, int block_base) {
+  __shared__ __attribute__((aligned(16))) char sU[TK * PITCH];
+  __shared__ __attribute__((aligned(16))) char sV[TK * PITCH];
+  const int bid = (int)blockIdx.x + block_base;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].first_block <= bid) lo = mid; else hi = mid - 1;
+  }
+  const TnTrDesc d = descs[lo];
+  const int local = bid - d.first_block;
+  // splits of one tile are adjacent block ids: they share the operand panels' columns in L2 while they run
+  tn_tr_body(d.a, local % d.n_tiles, local / d.n_tiles, sU, sV);
+}
+
+// token tiles per workgroup: enough to amortise the prologue and the 128x128 fp32 atomic epilogue
+inline int tn_tr_splits(int tiles, int ktiles, bool grouped) {
+  static const int force = getenv("AQL_TN_SPLITS") ? atoi(getenv("AQL_TN_SPLITS")) : 0;
+  int splits;
+  if (force > 0) splits = force;
+  else if (grouped) splits = ktiles / 32;            // the launch as a whole fills the chip
+  else splits = (320 + tiles - 1) / tiles;           // a lone problem: about one workgroup per CU (measured optimum)
+  if (splits > ktiles / 2) splits = ktiles / 2;
+  if (splits < 1) splits = 1;
+  return splits;
+}
+
+inline bool tn_tr_fill(TnArgs* a, const bf16_t* U, long ldu, const bf16_t* V, long ldv, long M, int P, int Q, float alpha,
+                       float* C, long ldc, bool grouped, int* n_tiles, int* n_blocks) {
+  if (!U || !V || !C || M <= 0 || P <= 0 || Q <= 0 || P % 8 || Q % 8 || ldu % 8 || ldv % 8) return false;
+  if ((((uintptr_t)U | (uintptr_t)V) & 15) != 0) return false;
+  a->U = U; a->V = V; a->ldu = ldu; a->ldv = ldv; a->M = M; a->P = P; a->Q = Q; a->alpha = alpha; a->C = C; a->ldc = ldc;
+  a->tiles_q = aql_cdiv(Q, BT);
+  const int tiles = aql_cdiv(P, BT) * a->tiles_q;
+  const int ktiles = aql_cdiv(M, TK);
+  int splits = tn_tr_splits(tiles, ktiles, grouped);
+  a->tiles_per_split = aql_cdiv(ktiles, splits);
+  splits = aql_cdiv(ktiles, a->tiles_per_split);
+  *n_tiles = tiles;
+  *n_blocks = tiles * splits;
+  return true;
+}
+
+}  // namespace
+
+// host-side descriptor (96 bytes) for the grouped launch; returns the workgroups it needs, 0 if the problem is not
+// eligible (caller launches it on its own)
+extern "C" int aql_tntr_desc_fill(void* host_desc, const bf16_t* U, long ldu, const bf16_t* V, long ldv, long M, int P, int Q,
+                                  float alpha, float* C, long ldc, int first_block) {
+  if (host_desc == nullptr) return 0;
+  TnTrDesc d;
+  memset(&d, 0, sizeof(d));
+  int n_tiles = 0, n_blocks = 0;
+  if (!tn_tr_fill(&d.a, U, ldu, V, ldv, M, P, Q, alpha, C, ldc, true, &n_tiles, &n_blocks)) return 0;
+  d.first_block = first_block;
+  d.n_tiles = n_tiles;
+  memcpy(host_desc, &d, sizeof(d));
+  return n_blocks;
+}
+
+// descriptors [first, first+n) of a device table; block_base = first_block of descriptor `first`
+extern "C" int aql_gemm_tn_tr_grouped(const void* dev_descs, int first, int n, int block_base, int n_blocks,
+                                      hipStream_t stream) {
+  AQL_CHECK_ARG(dev_descs && first >= 0 && n > 0 && block_base >= 0 && n_blocks > 0, "aql_gemm_tn_tr_grouped: bad args");
+  hipLaunchKernelGGL(gemm_tn_tr_grouped_kernel, dim3(n_blocks), dim3(256), 0, stream,
+                     static_cast<const TnTrDesc*>(dev_descs) + first, n, block_base);
+  AQL_CHECK_LAUNCH("aql_gemm_tn_tr_grouped");
+  return AQL_OK;
+}
+
+extern "C" int aql_gemm_tn_tr_f32(const bf16_t* U, long ldu, const bf16_t* V, long ldv, long M, int P, int Q, float alpha,
+                                  float* C, long ldc, hipStream_t stream) {
+  AQL_CHECK_ARG(U && V && C, "aql_gemm_tn_tr_f32: null operand");
+  AQL_CHECK_ARG(M > 0 && P > 0 && Q > 0 && P % 8 == 0 && Q % 8 == 0 && ldu % 8 == 0 && ldv % 8 == 0,
+                "aql_gemm_tn_tr_f32: P, Q and leading dimensions must be multiples of 8 (P=%d Q=%d)", P, Q);
+  AQL_CHECK_ARG((((uintptr_t)U | (uintptr_t)V) & 15) == 0, "aql_gemm_tn_tr_f32: operands must be 16-byte aligned");
+  TnArgs a;
+  int tiles = 0, n_blocks = 0;
+  AQL_CHECK_ARG(tn_tr_fill(&a, U, ldu, V, ldv, M, P, Q, alpha, C, ldc, false, &tiles, &n_blocks), "aql_gemm_tn_tr_f32: bad problem");
+  const int splits = n_blocks / tiles;
+  hipLaunchKernelGGL(gemm_tn_tr_kernel, dim3(tiles, splits), dim3(256), 0, stream, a);
+  AQL_CHECK_LAUNCH("aql_gemm_tn_tr_f32");
+  return AQL_OK;
+}

@@ -9,6 +9,8 @@ Conventions
     diagonal ``S`` is returned through autograd so that it reaches MapperNet.
 Every function here requires a CUDA(HIP) tensor and the built shared library: there is no fallback.
 """
+import os
+
 import torch
 
 from . import _lib as L
@@ -169,10 +171,15 @@ def _tn_scratch(nelem, device):
 
 def gemm_tn_acc(U, V, C, alpha=1.0):
     """C[P,Q] (fp32) += alpha * U[M,P]^T V[M,Q].  Narrow problems (a LoRA rank <= 32 side) use the transposing-loader
-    kernel (normally through the grouped launch); wide-rank problems transpose both operands once and run the pipelined
-    NT kernels, which are 5-7x faster on these shapes (tools/probe_tn320.py)."""
+    kernel (normally through the grouped launch); wide-rank problems run on aql_gemm_tn_tr_f32: 128x128 tiles whose
+    fragments are gathered from the row-major operands with LDS transpose reads (no transposed copies in HBM).
+    AQL_TN_OLD=1 selects the previous wide path (transpose both operands once + pipelined NT kernels) for comparison."""
     M, P = U.shape
     Q = V.shape[1]
+    if min(P, Q) > 32 and U.stride(1) == 1 and V.stride(1) == 1 and not os.environ.get("AQL_TN_OLD"):
+        L.call("aql_gemm_tn_tr_f32", L.ptr(U), U.stride(0), L.ptr(V), V.stride(0), M, P, Q, float(alpha), L.ptr(C),
+               C.stride(0), L.stream_ptr())
+        return
     wide = (min(P, Q) > 32 and M % 8 == 0 and M * P * Q >= 1.5e9 and U.stride(1) == 1 and V.stride(1) == 1)  # >= 3 GFLOP
     if not wide:
         L.call("aql_gemm_tn_f32", L.ptr(U), U.stride(0), L.ptr(V), V.stride(0), M, P, Q, float(alpha), L.ptr(C),
@@ -230,46 +237,59 @@ class DeferredDW:
     them as ONE grouped launch each (`flush`).  They are off the backward critical path -- nothing consumes dA/dB/dS
     before the optimizer -- and as 384+192 separate small launches they were the largest single item of the step.
     Descriptors are written into pinned host tables and copied with one async H2D each (graph-capturable: the device
-    addresses they hold are the capture pool's, identical on every replay).
+    addresses they hold are the capture pool's, identical on every replay).  Two tables: narrow problems (a LoRA rank
+    <= 32 side: 128x32 tiles, `aql_gemm_tn_grouped`) and wide ones (rank > 32: 128x128 transpose-read tiles,
+    `aql_gemm_tn_tr_grouped`); a problem neither kernel takes is launched on its own.
 
     Data-parallel runs use the bucketed form instead (`plan` / `run_bucket`): the problems are sorted by where their
     output lives in the flat gradient buffer and cut into a few contiguous buckets; the trainer launches bucket k and
     immediately hands its range to RCCL on the collective stream, so the all-reduce of bucket k runs under the
-    weight-gradient GEMMs of bucket k+1 (the role DDP's grad-ready hooks play at ppft_train.py:1058).  With
-    ``defer_wide`` the rank > 32 problems (which are not groupable and would otherwise run inline in backward) are
-    held back too and executed inside their bucket."""
+    weight-gradient GEMMs of bucket k+1 (the role DDP's grad-ready hooks play at ppft_train.py:1058)."""
 
-    TN_BYTES, DS_BYTES = 80, 48
+    # kind -> (descriptor bytes, byte offset of first_block inside the descriptor, fill entry, grouped launch entry)
+    KINDS = {"n": (80, 64, "aql_tn_desc_fill", "aql_gemm_tn_grouped_range"),
+             "w": (96, 80, "aql_tntr_desc_fill", "aql_gemm_tn_tr_grouped")}
+    DS_BYTES = 48
 
-    def __init__(self, device, max_sites=1024, defer_wide=False):
+    def __init__(self, device, max_sites=1024, defer_wide=True):
         self.device = device
-        self.defer_wide = defer_wide
-        self.tn_host = torch.zeros(2 * max_sites * self.TN_BYTES, dtype=torch.uint8).pin_memory()
+        self.defer_wide = defer_wide   # kept for callers; wide problems are always grouped now
+        self.host, self.dev = {}, {}
+        for k, (nbytes, _, _, _) in self.KINDS.items():
+            self.host[k] = torch.zeros(2 * max_sites * nbytes, dtype=torch.uint8).pin_memory()
+            self.dev[k] = torch.zeros_like(self.host[k], device=device)
         self.ds_host = torch.zeros(max_sites * self.DS_BYTES, dtype=torch.uint8).pin_memory()
-        self.tn_dev = torch.zeros_like(self.tn_host, device=device)
         self.ds_dev = torch.zeros_like(self.ds_host, device=device)
         self.reset()
 
     def reset(self):
-        self.n_tn = self.n_ds = self.blk_tn = self.blk_ds = 0
+        self.n = {"n": 0, "w": 0}      # descriptors per table
+        self.blk = {"n": 0, "w": 0}    # workgroups per table
+        self.n_ds = self.blk_ds = 0
         self.keep = []
-        self.items = []    # (C, nblk or None, direct args or None) in arrival order
+        self.items = []    # (C, kind, nblk, direct args or None) in arrival order; kind "d" = launched on its own
         self.buckets = None
 
+    @property
+    def n_tn(self):
+        return self.n["n"] + self.n["w"]
+
     def add_tn(self, U, V, C, alpha=1.0):
-        """C[P,Q] += alpha * U^T V;  returns False if the problem was not taken (caller launches it directly)."""
-        slot = self.tn_host.data_ptr() + self.n_tn * self.TN_BYTES
-        nblk = L.call_raw("aql_tn_desc_fill", L.c_p(slot), L.ptr(U), U.stride(0), L.ptr(V), V.stride(0), U.shape[0],
-                          U.shape[1], V.shape[1], float(alpha), L.ptr(C), C.stride(0), self.blk_tn)
-        if nblk <= 0:
-            if not self.defer_wide:
-                return False
-            self.items.append((C, None, (U, V, float(alpha))))
-            self.keep += [U, V]
-            return True
-        self.items.append((C, nblk, None))
-        self.n_tn += 1
-        self.blk_tn += nblk
+        """C[P,Q] += alpha * U^T V;  always taken (returns True): grouped when a table accepts it, else held back as a
+        direct launch that `flush` / `run_bucket` issues."""
+        kinds = ("n", "w") if min(U.shape[1], V.shape[1]) <= 32 else ("w", "n")
+        for k in kinds:
+            nbytes, _, fill, _ = self.KINDS[k]
+            slot = self.host[k].data_ptr() + self.n[k] * nbytes
+            nblk = L.call_raw(fill, L.c_p(slot), L.ptr(U), U.stride(0), L.ptr(V), V.stride(0), U.shape[0], U.shape[1],
+                              V.shape[1], float(alpha), L.ptr(C), C.stride(0), self.blk[k])
+            if nblk > 0:
+                self.items.append((C, k, nblk, None))
+                self.n[k] += 1
+                self.blk[k] += nblk
+                self.keep += [U, V]
+                return True
+        self.items.append((C, "d", 0, (U, V, float(alpha))))
         self.keep += [U, V]
         return True
 
@@ -290,15 +310,21 @@ class DeferredDW:
             L.call("aql_lora_ds_grouped", L.ptr(self.ds_dev), self.n_ds, self.blk_ds, L.stream_ptr())
         self.n_ds = self.blk_ds = 0
 
+    def _launch(self, k, first, n, base, nblk):
+        nbytes, _, _, entry = self.KINDS[k]
+        lo, hi = first * nbytes, (first + n) * nbytes
+        self.dev[k][lo:hi].copy_(self.host[k][lo:hi], non_blocking=True)
+        L.call(entry, L.ptr(self.dev[k]), first, n, base, nblk, L.stream_ptr())
+
     def flush_tn(self):
-        if self.n_tn:
-            nbytes = self.n_tn * self.TN_BYTES
-            self.tn_dev[:nbytes].copy_(self.tn_host[:nbytes], non_blocking=True)
-            L.call("aql_gemm_tn_grouped", L.ptr(self.tn_dev), self.n_tn, self.blk_tn, L.stream_ptr())
-        for C, nblk, direct in self.items:
-            if direct is not None:
+        for k in ("n", "w"):
+            if self.n[k]:
+                self._launch(k, 0, self.n[k], 0, self.blk[k])
+        for C, k, _, direct in self.items:
+            if k == "d":
                 gemm_tn_acc(direct[0], direct[1], C, direct[2])
-        self.n_tn = self.blk_tn = 0
+        self.n = {"n": 0, "w": 0}
+        self.blk = {"n": 0, "w": 0}
         self.items = []
 
     def flush(self):
@@ -309,46 +335,47 @@ class DeferredDW:
     # ---- bucketed form -------------------------------------------------------------------------------------
     def plan(self, flat_grad, nbuckets):
         """Sort the held-back problems by the offset of their output inside ``flat_grad`` and cut them into buckets.
-        Rewrites the host descriptor table in that order.  Returns [(lo, hi)] element ranges of flat_grad."""
+        Rewrites the host descriptor tables in that order.  Returns [(lo, hi)] element ranges of flat_grad."""
         import numpy as np
         base, esz = flat_grad.data_ptr(), flat_grad.element_size()
         offs, sizes = [], []
-        for C, _, _ in self.items:
+        for C, _, _, _ in self.items:
             o = (C.data_ptr() - base) // esz
             if not (0 <= o and o + C.numel() <= flat_grad.numel() and C.is_contiguous()):
                 raise L.AqlError("DeferredDW.plan: a weight gradient does not live in the flat gradient buffer")
             offs.append(o)
             sizes.append(C.numel())
         groups = plan_buckets(offs, sizes, nbuckets)
-        grouped_idx = [i for i, it in enumerate(self.items) if it[1] is not None]   # arrival order == table order
-        slot_of = {i: s for s, i in enumerate(grouped_idx)}
-        tbl = self.tn_host.numpy()[:self.n_tn * self.TN_BYTES].reshape(self.n_tn, self.TN_BYTES)
-        old = tbl.copy()
+        tbl, old, slot_of, pos, blk = {}, {}, {}, {"n": 0, "w": 0}, {"n": 0, "w": 0}
+        for k, (nbytes, _, _, _) in self.KINDS.items():
+            tbl[k] = self.host[k].numpy()[:self.n[k] * nbytes].reshape(self.n[k], nbytes)
+            old[k] = tbl[k].copy()
+            idx = [i for i, it in enumerate(self.items) if it[1] == k]   # arrival order == table order
+            slot_of[k] = {i: s for s, i in enumerate(idx)}
         self.buckets = []
-        pos = blk = 0
         for lo, hi, idxs in groups:
-            first, base_blk, direct = pos, blk, []
+            first, base_blk, direct = dict(pos), dict(blk), []
             for i in idxs:
-                C, nblk, d = self.items[i]
-                if d is not None:
+                C, k, nblk, d = self.items[i]
+                if k == "d":
                     direct.append((d[0], d[1], C, d[2]))
                     continue
-                tbl[pos] = old[slot_of[i]]
-                tbl[pos, 64:68].view(np.int32)[0] = blk     # TnGroupDesc.first_block
-                pos += 1
-                blk += nblk
-            self.buckets.append(dict(lo=lo, hi=hi, first=first, n=pos - first, base=base_blk, nblk=blk - base_blk,
-                                     direct=direct))
-        assert pos == self.n_tn and blk == self.blk_tn
+                fb = self.KINDS[k][1]
+                tbl[k][pos[k]] = old[k][slot_of[k][i]]
+                tbl[k][pos[k], fb:fb + 4].view(np.int32)[0] = blk[k]     # first_block
+                pos[k] += 1
+                blk[k] += nblk
+            self.buckets.append(dict(lo=lo, hi=hi, direct=direct,
+                                     ranges={k: (first[k], pos[k] - first[k], base_blk[k], blk[k] - base_blk[k])
+                                             for k in ("n", "w")}))
+        assert pos == self.n and blk == self.blk
         return [(b["lo"], b["hi"]) for b in self.buckets]
 
     def run_bucket(self, k):
         b = self.buckets[k]
-        if b["n"]:
-            lo, hi = b["first"] * self.TN_BYTES, (b["first"] + b["n"]) * self.TN_BYTES
-            self.tn_dev[lo:hi].copy_(self.tn_host[lo:hi], non_blocking=True)
-            L.call("aql_gemm_tn_grouped_range", L.ptr(self.tn_dev), b["first"], b["n"], b["base"], b["nblk"],
-                   L.stream_ptr())
+        for kind, (first, n, base, nblk) in b["ranges"].items():
+            if n:
+                self._launch(kind, first, n, base, nblk)
         for U, V, C, alpha in b["direct"]:
             gemm_tn_acc(U, V, C, alpha)
 

@@ -55,6 +55,16 @@ int aql_conv3x3_bwd_data(const bf16_t* dY, int B, int Hin, int Win, int Cin, con
 int aql_gemm_tn_f32(const bf16_t* U, long ldu, const bf16_t* V, long ldv, long M, int P, int Q, float alpha, float* C,
                     long ldc, aql_stream_t stream);
 
+/* Same contract for wide problems (LoRA rank > 32): 128x128 tiles, both token-major operands staged as they lie in
+ * memory and gathered with LDS transpose reads -- no transposed copies in HBM (csrc/aql_gemm_tntr.hip).            */
+int aql_gemm_tn_tr_f32(const bf16_t* U, long ldu, const bf16_t* V, long ldv, long M, int P, int Q, float alpha,
+                       float* C, long ldc, aql_stream_t stream);
+/* Grouped form of the above (96-byte host descriptors, same protocol as aql_tn_desc_fill / aql_gemm_tn_grouped_range):
+ * one launch for all wide weight gradients of a backward pass or of one exchange bucket.                          */
+int aql_tntr_desc_fill(void* host_desc, const bf16_t* U, long ldu, const bf16_t* V, long ldv, long M, int P, int Q,
+                       float alpha, float* C, long ldc, int first_block);
+int aql_gemm_tn_tr_grouped(const void* dev_descs, int first, int n, int block_base, int n_blocks, aql_stream_t stream);
+
 /* Grouped form: ONE launch for every LoRA weight gradient of a backward pass (all problems have a rank <= 32 side).
  * aql_tn_desc_fill writes an 80-byte descriptor into HOST memory and returns the workgroups it needs (0 = shape not
  * groupable); the caller copies the table to the device and passes the running block prefix as first_block.       */
