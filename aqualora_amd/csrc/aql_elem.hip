@@ -519,3 +519,37 @@ extern "C" int aql_ddim_step(float* x, const bf16_t* eps_u, const bf16_t* eps_c,
   AQL_CHECK_LAUNCH("aql_ddim_step");
   return AQL_OK;
 }
+
+// ---- row softmax for the VAE's single-head, 512-wide attention (diffusers AutoencoderKL mid-block Attention; the flash
+// kernels of aql_attn.hip stop at d = 160): P[m, :] = softmax(scale * S[m, :]) with S fp32 (from aql_gemm_nt_f32_accum)
+// and P bf16.  One workgroup per row; the row is read three times (max, sum, write) and stays in L2.
+namespace {
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, long lds_, int N, float scale,
+                                                           bf16_t* __restrict__ P, long ldp) {
+  __shared__ float red[4];
+  const float* s = S + (long)blockIdx.x * lds_;
+  bf16_t* p = P + (long)blockIdx.x * ldp;
+  const int tid = threadIdx.x;
+  float mx = -INFINITY;
+  for (int i = tid; i < N; i += 256) mx = fmaxf(mx, s[i]);
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int i = tid; i < N; i += 256) sum += __expf((s[i] - mx) * scale);
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) red[tid >> 6] = sum;
+  __syncthreads();
+  const float inv = 1.f / ((red[0] + red[1]) + (red[2] + red[3]));
+  for (int i = tid; i < N; i += 256) p[i] = f32_to_bf16(__expf((s[i] - mx) * scale) * inv);
+}
+}  // namespace
+extern "C" int aql_softmax_rows(const float* S, long lds_, long M, int N, float scale, bf16_t* P, long ldp,
+                                hipStream_t stream) {
+  AQL_CHECK_ARG(S && P && M > 0 && N > 0 && scale > 0.f, "aql_softmax_rows: bad args");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)M), dim3(256), 0, stream, S, lds_, N, scale, P, ldp);
+  AQL_CHECK_LAUNCH("aql_softmax_rows");
+  return AQL_OK;
+}

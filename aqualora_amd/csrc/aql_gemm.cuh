@@ -44,6 +44,7 @@ struct ConvFwdLoader {
   const bf16_t* base;
   int B, Hin, Win, Cin, Hout, Wout, stride, ups;
   int rows, K;
+  int pad;  // leading (top/left) zero padding: 1, or 0 for the VAE's stride-2 convs that pad (0,1,0,1)
 };
 
 // Backward-data 3x3 conv: rows are input pixels (b,hi,wi) of dX; source is dY [B,Hout,Wout,Cout];
@@ -485,8 +486,8 @@ struct DmaStager<R, ConvFwdLoader> {
       const int r = row0 + (tid >> 3) + 32 * i;
       const int b = r / hw, rem = r - b * hw, ho = rem / l.Wout;
       rb[i] = b * l.Hin;
-      rh[i] = r < l.rows ? ho * l.stride - 1 : -FAR;
-      rw[i] = (rem - ho * l.Wout) * l.stride - 1;
+      rh[i] = r < l.rows ? ho * l.stride - l.pad : -FAR;
+      rw[i] = (rem - ho * l.Wout) * l.stride - l.pad;
       rowbase[i] = (uint32_t)(((rb[i] + rh[i]) * Win + rw[i]) * Cin + kc) * 2u;
     }
     t = t_first;

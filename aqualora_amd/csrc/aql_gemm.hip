@@ -481,10 +481,25 @@ extern "C" int aql_lora_down(const bf16_t* X, long ldx, long M, int K, const bf1
   return aql_lora_ds(T, Tref, (int)(M / rows_per_sample), rows_per_sample, r, dS, stream);
 }
 
+extern "C" int aql_conv3x3_fwd_pad(const bf16_t* X, int B, int Hin, int Win, int Cin, const bf16_t* Wk, const bf16_t* bias,
+                                   int Cout, int stride, int upsample, int pad_lo, const bf16_t* rowbias, long rowbias_ld,
+                                   const bf16_t* residual, bf16_t* Y, float* ws, size_t ws_bytes, hipStream_t stream);
+
 extern "C" int aql_conv3x3_fwd(const bf16_t* X, int B, int Hin, int Win, int Cin, const bf16_t* Wk, const bf16_t* bias,
                                int Cout, int stride, int upsample, const bf16_t* rowbias, long rowbias_ld,
                                const bf16_t* residual, bf16_t* Y, float* ws, size_t ws_bytes, hipStream_t stream) {
+  return aql_conv3x3_fwd_pad(X, B, Hin, Win, Cin, Wk, bias, Cout, stride, upsample, 1, rowbias, rowbias_ld, residual, Y, ws,
+                             ws_bytes, stream);
+}
+
+// pad_lo = 1: torch padding=1.  pad_lo = 0 (stride 2 only): zero padding on the bottom/right edge only, i.e.
+// F.pad(x, (0,1,0,1)) + Conv2d(padding=0) -- the Downsample2D of diffusers' AutoencoderKL encoder.
+extern "C" int aql_conv3x3_fwd_pad(const bf16_t* X, int B, int Hin, int Win, int Cin, const bf16_t* Wk, const bf16_t* bias,
+                                   int Cout, int stride, int upsample, int pad_lo, const bf16_t* rowbias, long rowbias_ld,
+                                   const bf16_t* residual, bf16_t* Y, float* ws, size_t ws_bytes, hipStream_t stream) {
   AQL_CHECK_ARG(X && Wk && Y, "aql_conv3x3_fwd: null operand");
+  AQL_CHECK_ARG(pad_lo == 1 || (pad_lo == 0 && stride == 2 && Hin % 2 == 0 && Win % 2 == 0),
+                "aql_conv3x3_fwd: pad_lo=0 needs stride 2 and even H, W");
   AQL_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0, "aql_conv3x3_fwd: Cin/Cout must be multiples of 8 (%d,%d)", Cin, Cout);
   AQL_CHECK_ARG((stride == 1 || stride == 2) && (upsample == 0 || upsample == 1) && !(upsample && stride == 2),
                 "aql_conv3x3_fwd: bad stride/upsample");
@@ -496,8 +511,9 @@ extern "C" int aql_conv3x3_fwd(const bf16_t* X, int B, int Hin, int Win, int Cin
   l.Cin = Cin;
   l.stride = stride;
   l.ups = upsample;
+  l.pad = pad_lo;
   const int Hl = Hin << upsample, Wl = Win << upsample;
-  l.Hout = (Hl + 2 - 3) / stride + 1;
+  l.Hout = (Hl + 2 - 3) / stride + 1;   // == Hl / 2 for pad (0,1) on even sizes as well
   l.Wout = (Wl + 2 - 3) / stride + 1;
   l.rows = B * l.Hout * l.Wout;
   l.K = 9 * Cin;

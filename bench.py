@@ -137,6 +137,39 @@ def cpu_baseline(tr, rank):
                       f"tensors) on the full-size SD-1.5 U-Net, batch 1, fp32: {step_s:.2f} s (warm-up forward {fwd_s:.2f} s)"}
 
 
+def vae_bench(args, device):
+    """Frozen VAE encode (ppft_train.py:993) and decode at 512x512 on the HIP kernels: SURVEY.md §8 (f) rank 1.  Not part
+    of the headline step (latent-in); reported so that a pixel-in step can be priced: step + batch / encode rate."""
+    from aqualora_amd import synth
+    from aqualora_amd.vae import SD15_VAE, AutoencoderKL, encode_gflop, synthetic_state_dict
+    vae = AutoencoderKL(synthetic_state_dict(SD15_VAE, device=device), SD15_VAE, device)
+    B = args.batch
+    x = synth.normal("vae.x", (B, 3, 512, 512), 0.5, 1, device).clamp(-1, 1)
+    noise = synth.normal("vae.n", (B, 4, 64, 64), 1.0, 1, device)
+    z = vae.encode(x, noise)
+    vae.decode(z)
+    torch.cuda.synchronize()
+    n = max(2, args.steps // 2)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        z = vae.encode(x, noise)
+    torch.cuda.synchronize()
+    te = (time.perf_counter() - t0) / n
+    t0 = time.perf_counter()
+    for _ in range(n):
+        img = vae.decode(z)
+    torch.cuda.synchronize()
+    td = (time.perf_counter() - t0) / n
+    gf = encode_gflop()
+    print(json.dumps({"metric": "frozen SD-1.5 VAE encode images/sec at 512x512", "value": B / te, "unit": "images/sec",
+                      "n_gpus": 1, "steps": n, "ms_per_batch": 1e3 * te, "dtype": "bf16", "higher_is_better": True,
+                      "data": "synthetic", "config": {"workload": f"AutoencoderKL.encode, batch {B}, 3x512x512 -> 4x64x64"},
+                      "roofline": {"bound": "mfma", "achieved": gf * B / te / 1e3, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                   "frac": gf * B / te / 1e3 / MFMA_PEAK_TF, "gflop_per_image": gf},
+                      "decode": {"images_per_sec": B / td, "ms_per_batch": 1e3 * td,
+                                 "finite": bool(torch.isfinite(img).all())}}), flush=True)
+
+
 def infer_bench(args, device):
     """BASELINE config 4 without the VAE (outside the path): 50-step DDIM, CFG 7.5, 64x64x4 latents, fused-LoRA U-Net
     (the LoRA is folded into W, utils_eval.py:81-82, so this is the plain SD-1.5 U-Net on batch 2 per image)."""
@@ -216,7 +249,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--mode", choices=["train", "infer", "robft"], default="train",
+    ap.add_argument("--pixel-in", action="store_true",
+                    help="train mode: run the frozen VAE encode (3x512x512 -> 4x64x64) inside every timed step")
+    ap.add_argument("--mode", choices=["train", "infer", "robft", "vae"], default="train",
                     help="train: the PPFT step (BASELINE metric); infer: 50-step DDIM + CFG latent sampling (config 4)")
     ap.add_argument("--micro", type=int, default=1, help="concurrent micro-batch slices per step")
     args = ap.parse_args()
@@ -233,6 +268,8 @@ def main():
 
     if args.mode == "infer":
         return infer_bench(args, device)
+    if args.mode == "vae":
+        return vae_bench(args, device)
     if args.mode == "robft":
         return robft_bench(args, device)
     tr = build(device, args.rank, micro=args.micro)
@@ -245,6 +282,22 @@ def main():
         if launched:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.pixel_in:
+        # the reference's own step starts from pixels (ppft_train.py:993): frozen VAE encode of the batch on the HIP
+        # kernels in front of the captured step (the CLIP text encoder stays outside: ctx is injected)
+        from aqualora_amd import synth
+        from aqualora_amd.vae import SD15_VAE, AutoencoderKL, synthetic_state_dict
+        vae = AutoencoderKL(synthetic_state_dict(SD15_VAE, device=device), SD15_VAE, device)
+        pixels = synth.normal("bench.px", (args.batch, 3, 512, 512), 0.5, 2048 + 977 * rank_id, device).clamp(-1, 1)
+        vnoise = synth.normal("bench.vn", (args.batch, 4, 64, 64), 1.0, 2048 + 977 * rank_id, device)
+        latent_runner = runner
+
+        def runner(**b):
+            b["z"] = vae.encode(pixels, vnoise)
+            return latent_runner(**b)
+
+        runner.is_graph = getattr(latent_runner, "is_graph", False)
 
     for _ in range(args.warmup):
         loss = runner(**batch)
@@ -270,7 +323,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"SD1.5 PPFT LoRA rank={args.rank}, 48-bit msg, 512x512 (64x64x4 latents in), "
-                                   f"batch={args.batch}/GPU, latent-in (VAE/CLIP outside the path)",
+                                   f"batch={args.batch}/GPU, " + ("pixel-in (frozen VAE encode inside the step, CLIP outside)"
+                                                                  if args.pixel_in else "latent-in (VAE/CLIP outside the path)"),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(getattr(runner, "is_graph", False)),
                        "loss": loss_v},
         }

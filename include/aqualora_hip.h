@@ -47,6 +47,11 @@ int aql_conv3x3_fwd(const bf16_t* X, int B, int Hin, int Win, int Cin, const bf1
                     int stride, int upsample, const bf16_t* rowbias, long rowbias_ld, const bf16_t* residual, bf16_t* Y,
                     float* ws, size_t ws_bytes, aql_stream_t stream);
 /* its input gradient (autograd of the same call); Wt[Cin][(kh*3+kw)*Cout+co]                                     */
+/* pad_lo = 1: identical to aql_conv3x3_fwd.  pad_lo = 0 (stride 2, even H/W): F.pad(x,(0,1,0,1)) + Conv2d(3, stride 2,
+ * padding 0), the Downsample2D of diffusers' AutoencoderKL encoder (frozen VAE encode, train/ppft_train.py:993).  */
+int aql_conv3x3_fwd_pad(const bf16_t* X, int B, int Hin, int Win, int Cin, const bf16_t* Wk, const bf16_t* bias, int Cout,
+                        int stride, int upsample, int pad_lo, const bf16_t* rowbias, long rowbias_ld,
+                        const bf16_t* residual, bf16_t* Y, float* ws, size_t ws_bytes, aql_stream_t stream);
 int aql_conv3x3_bwd_data(const bf16_t* dY, int B, int Hin, int Win, int Cin, const bf16_t* Wt, int Cout, int stride,
                          bf16_t* dX, float* ws, size_t ws_bytes, aql_stream_t stream);
 
@@ -106,6 +111,9 @@ int aql_geglu_fwd(const bf16_t* in, long M, int F, bf16_t* out, aql_stream_t str
 int aql_geglu_bwd(const bf16_t* in, const bf16_t* dy, long M, int F, bf16_t* din, aql_stream_t stream);
 /* backward of F.interpolate(scale_factor=2, "nearest") (original_unet.py:1076): 2x2 block sum                      */
 int aql_upsample2x_bwd(const bf16_t* du, int B, int H, int W, int C, bf16_t* dx, aql_stream_t stream);
+/* P[m,:] = softmax(scale * S[m,:]), S fp32 -> P bf16: the VAE mid-block's single-head 512-wide attention
+ * (AutoencoderKL, ppft_train.py:993), whose scores come from aql_gemm_nt_f32_accum                                   */
+int aql_softmax_rows(const float* S, long lds, long M, int N, float scale, bf16_t* P, long ldp, aql_stream_t stream);
 /* DDPMScheduler.add_noise on x0 and x0+wm with shared noise/timesteps  train/ppft_train.py:1010-1011              */
 int aql_add_noise(const float* x0, const float* wm, const float* eps, const long* t, const float* alphas_cumprod, int B,
                   int per_sample, bf16_t* noisy, bf16_t* noisy_wm, aql_stream_t stream);

@@ -1,0 +1,87 @@
+"""Frozen SD-1.5 VAE.  CPU: key inventory of the state dict and self-consistency of the
+oracle (tests/ may import oracle/).  GPU: the HIP encode / decode against the oracle on a reduced-width VAE and on the
+full-size encoder at 256x256 (tolerances below; the oracle is unpinned -- diffusers is not on disk)."""
+import pytest
+import torch
+
+from aqualora_amd import synth
+from aqualora_amd.vae import SD15_VAE, encode_gflop, synthetic_state_dict, vae_keys
+from oracle.vae_oracle import VAEOracle
+
+TINY_VAE = dict(SD15_VAE, block_out_channels=(32, 64, 64, 64))
+
+
+def test_vae_key_inventory_matches_sd15():
+    keys = vae_keys()
+    # diffusers AutoencoderKL (SD-1.5): 248 tensors, 83.65 M parameters
+    assert len(keys) == 248
+    n = sum(torch.Size(s).numel() for s in keys.values())
+    assert abs(n - 83_653_863) == 0, n
+    assert keys["encoder.down_blocks.1.resnets.0.conv_shortcut.weight"] == (256, 128, 1, 1)
+    assert keys["encoder.mid_block.attentions.0.to_q.weight"] == (512, 512)
+    assert keys["decoder.up_blocks.3.resnets.2.conv2.weight"] == (128, 128, 3, 3)
+    assert keys["quant_conv.weight"] == (8, 8, 1, 1) and keys["post_quant_conv.weight"] == (4, 4, 1, 1)
+    assert "encoder.down_blocks.3.downsamplers.0.conv.weight" not in keys
+    assert 1100 < encode_gflop() < 1150      # ~1.13 TFLOP per 512x512 image
+
+
+def test_vae_oracle_shapes_and_posterior():
+    sd = synthetic_state_dict(TINY_VAE)
+    o = VAEOracle(sd, TINY_VAE)
+    x = synth.normal("vae.x", (2, 3, 32, 32), 0.5, 7).clamp(-1, 1)
+    mean, logvar = o.encode_moments(x)
+    assert mean.shape == (2, 4, 4, 4) and logvar.shape == (2, 4, 4, 4)
+    noise = synth.normal("vae.n", (2, 4, 4, 4), 1.0, 7)
+    z = o.encode(x, noise)
+    assert torch.allclose(z, (mean + torch.exp(0.5 * logvar) * noise) * 0.18215)
+    assert torch.equal(o.encode(x, sample=False), mean * 0.18215)
+    img = o.decode(z)
+    assert img.shape == (2, 3, 32, 32) and torch.isfinite(img).all()
+    # the asymmetric pad of the encoder's Downsample2D: a stride-1 padding-1 convolution sampled at odd positions
+    w, b = sd["encoder.down_blocks.0.downsamplers.0.conv.weight"], sd["encoder.down_blocks.0.downsamplers.0.conv.bias"]
+    h = synth.normal("vae.h", (1, 32, 8, 8), 1.0, 7)
+    a = torch.nn.functional.conv2d(torch.nn.functional.pad(h, (0, 1, 0, 1)), w, b, stride=2)
+    c = torch.nn.functional.conv2d(h, w, b, padding=1)[:, :, 1::2, 1::2]
+    assert torch.allclose(a, c, atol=1e-5)
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / b.abs().max())
+
+
+@pytest.mark.gpu
+def test_vae_hip_vs_oracle_tiny():
+    """Reduced-width VAE, 64x64 image: HIP vs the bf16-mirroring oracle (tight) and vs the fp32 oracle (bf16 storage)."""
+    from aqualora_amd.vae import AutoencoderKL
+    sd = synthetic_state_dict(TINY_VAE)
+    vae = AutoencoderKL(sd, TINY_VAE, "cuda")
+    x = synth.normal("vae.x", (2, 3, 64, 64), 0.5, 7).clamp(-1, 1)
+    mean, logvar = vae.encode_moments(x.cuda())
+    om, ol = VAEOracle(sd, TINY_VAE, bf16=True).encode_moments(x)
+    fm, fl = VAEOracle(sd, TINY_VAE).encode_moments(x)
+    assert mean.shape == (2, 4, 8, 8)
+    assert _rel(mean, om) < 2e-2 and _rel(logvar, ol) < 2e-2, (_rel(mean, om), _rel(logvar, ol))
+    assert _rel(mean, fm) < 5e-2 and _rel(logvar, fl) < 5e-2
+    noise = synth.normal("vae.n", (2, 4, 8, 8), 1.0, 7)
+    z = vae.encode(x.cuda(), noise.cuda())
+    assert _rel(z, (fm + torch.exp(0.5 * fl) * noise) * 0.18215) < 5e-2
+    img = vae.decode(z)
+    oi = VAEOracle(sd, TINY_VAE, bf16=True).decode(z.cpu())
+    assert img.shape == (2, 3, 64, 64)
+    assert _rel(img, oi) < 3e-2, _rel(img, oi)
+    # determinism
+    assert torch.equal(vae.encode_moments(x.cuda())[0], mean)
+
+
+@pytest.mark.gpu
+def test_vae_full_size_encoder_vs_oracle():
+    """Full-width SD-1.5 encoder at 256x256 (attention over 1024 tokens, all four resolutions, both 1x1 shortcuts)."""
+    from aqualora_amd.vae import AutoencoderKL
+    sd = synthetic_state_dict(SD15_VAE)
+    vae = AutoencoderKL(sd, SD15_VAE, "cuda")
+    x = synth.normal("vae.x", (1, 3, 256, 256), 0.5, 11).clamp(-1, 1)
+    mean, logvar = vae.encode_moments(x.cuda())
+    om, ol = VAEOracle(sd, SD15_VAE, bf16=True).encode_moments(x)
+    assert mean.shape == (1, 4, 32, 32)
+    assert _rel(mean, om) < 3e-2 and _rel(logvar, ol) < 3e-2, (_rel(mean, om), _rel(logvar, ol))
