@@ -13,13 +13,13 @@
 // partial tiles are accumulated with fp32 atomics (the weight gradients are order-nondeterministic in the last bits
 // already).
 #include "aql_common.h"
+#include <stddef.h>
 
 namespace {
 
 constexpr int TK = 64;      // tokens per stage
 constexpr int BT = 128;     // tile width, both sides
 constexpr int PITCH = 256;  // bytes per LDS row
-constexpr int SLOTS = TK * (BT / 8) / 256;  // 16-byte slots per thread per operand tile (= 4)
 
 // conflict-free for the 8-row x 32-byte transpose gathers (same image as aql_attn.hip's row tiles)
 __device__ __forceinline__ int tile_off(int row, int chunk) { return row * PITCH + ((chunk ^ ((row & 7) << 1)) << 4); }
@@ -29,7 +29,9 @@ __device__ __forceinline__ uint4 mask4(const uint4& v, bool ok) {
   return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
 }
 
+template <int W>  // tile width in columns: 128 (16 chunks per row, 4 slots per thread) or 32 (4 chunks, 1 slot)
 struct TileStager {
+  static constexpr int CPRW = W / 8, SLOTS = TK * CPRW / 256;
   long p[SLOTS];   // element offset from g of the slot in the CURRENT tile
   uint4 v[SLOTS];
   int off[SLOTS];  // LDS byte offset, -1: column past the operand's width (zeroed once)
@@ -42,7 +44,7 @@ struct TileStager {
 #pragma unroll
     for (int it = 0; it < SLOTS; ++it) {
       const int id = tid + it * 256;
-      const int row = id >> 4, c = id & 15;
+      const int row = id / CPRW, c = id - row * CPRW;
       const bool live = col0 + c * 8 < width;
       off[it] = live ? tile_off(row, c) : -1;
       p[it] = live ? (m0 + row) * ld + col0 + c * 8 : 0;
@@ -57,7 +59,7 @@ struct TileStager {
     } else {
 #pragma unroll
       for (int it = 0; it < SLOTS; ++it) {
-        const int row = (tid + it * 256) >> 4;
+        const int row = (tid + it * 256) / CPRW;
         const bool ok = (m0 + row < M) & (off[it] >= 0);
         const uint4 x = *reinterpret_cast<const uint4*>(g + (ok ? p[it] : 0));
         v[it] = mask4(x, ok);
@@ -95,25 +97,33 @@ struct TnArgs {
   float* C;
   long ldc;
   int tiles_q, tiles_per_split;
+  int narrow;  // 1: Q <= 32 -> 128 x 32 tiles (LoRA rank <= 32); the caller swaps operands so the narrow side is Q
+  int trans;   // 1: the result is written transposed, element (p, q) -> C[q * ldc + p]
 };
 
+// BQ = 128: 2x2 wavefronts of 64x64.  BQ = 32 (rank <= 32 gradients): 4x1 wavefronts of 32x32, the narrow operand's tile
+// uses 64 of its 256-byte LDS rows (same swizzle, so the gathers stay conflict-free).  TRANS swaps the MFMA operand roles
+// so that consecutive lanes still hit consecutive addresses of the transposed output.
+template <int BQ, bool TRANS>
 __device__ __forceinline__ void tn_tr_body(const TnArgs& a, const int tile, const int split, char* sU, char* sV) {
+  constexpr int FM = BQ == 128 ? 4 : 2, FN = BQ == 128 ? 4 : 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tp = tile / a.tiles_q, tq = tile - tp * a.tiles_q;
-  const int p0 = tp * BT, q0 = tq * BT;
-  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int p0 = tp * BT, q0 = tq * BQ;
+  const int wm0 = BQ == 128 ? (wave >> 1) * 64 : wave * 32, wn0 = BQ == 128 ? (wave & 1) * 64 : 0;
   const long m_lo = (long)split * a.tiles_per_split * TK;
   long m_hi = m_lo + (long)a.tiles_per_split * TK;
   if (m_hi > a.M) m_hi = a.M;
   if (m_lo >= m_hi) return;
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[FM][FN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  TileStager su, sv;
+  TileStager<BT> su;
+  TileStager<BQ> sv;
   su.init(sU, a.U, a.ldu, m_lo, p0, a.P, tid);
   sv.init(sV, a.V, a.ldv, m_lo, q0, a.Q, tid);
   su.fetch(m_lo, a.M, tid);
@@ -131,47 +141,75 @@ __device__ __forceinline__ void tn_tr_body(const TnArgs& a, const int tile, cons
     }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8_t fa[4], fb[4];
+      bf16x8_t fa[FM], fb[FN];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = tr_frag(sU, s2, wm0 + i * 16, lane);
+      for (int i = 0; i < FM; ++i) fa[i] = tr_frag(sU, s2, wm0 + i * 16, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = tr_frag(sV, s2, wn0 + j * 16, lane);
+      for (int j = 0; j < FN; ++j) fb[j] = tr_frag(sV, s2, wn0 + j * 16, lane);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0)
+                            : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
   }
-  // acc[i][j][e]: row P = p0 + wm0 + 16 i + 4 (lane>>4) + e, column Q = q0 + wn0 + 16 j + (lane & 15)
+  if (!TRANS) {
+    // acc[i][j][e]: row P = p0 + wm0 + 16 i + 4 (lane>>4) + e, column Q = q0 + wn0 + 16 j + (lane & 15)
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int pr = p0 + wm0 + i * 16 + (lane >> 4) * 4 + e;
-      if (pr >= a.P) continue;
+      for (int e = 0; e < 4; ++e) {
+        const int pr = p0 + wm0 + i * 16 + (lane >> 4) * 4 + e;
+        if (pr >= a.P) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int qc = q0 + wn0 + j * 16 + (lane & 15);
-        if (qc < a.Q) atomicAdd(a.C + (long)pr * a.ldc + qc, a.alpha * acc[i][j][e]);
+        for (int j = 0; j < FN; ++j) {
+          const int qc = q0 + wn0 + j * 16 + (lane & 15);
+          if (qc < a.Q) atomicAdd(a.C + (long)pr * a.ldc + qc, a.alpha * acc[i][j][e]);
+        }
       }
-    }
+  } else {
+    // operands swapped: acc[i][j][e] is (Q = q0 + wn0 + 16 j + 4 (lane>>4) + e, P = p0 + wm0 + 16 i + (lane & 15)) -> C[Q][P]
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int qr = q0 + wn0 + j * 16 + (lane >> 4) * 4 + e;
+        if (qr >= a.Q) continue;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const int pc = p0 + wm0 + i * 16 + (lane & 15);
+          if (pc < a.P) atomicAdd(a.C + (long)qr * a.ldc + pc, a.alpha * acc[i][j][e]);
+        }
+      }
+  }
+}
+
+__device__ __forceinline__ void tn_tr_dispatch(const TnArgs& a, int tile, int split, char* sU, char* sV) {
+  if (a.narrow) {
+    if (a.trans) tn_tr_body<32, true>(a, tile, split, sU, sV);
+    else tn_tr_body<32, false>(a, tile, split, sU, sV);
+  } else {
+    if (a.trans) tn_tr_body<128, true>(a, tile, split, sU, sV);
+    else tn_tr_body<128, false>(a, tile, split, sU, sV);
+  }
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const TnArgs a) {
   __shared__ __attribute__((aligned(16))) char sU[TK * PITCH];
   __shared__ __attribute__((aligned(16))) char sV[TK * PITCH];
-  tn_tr_body(a, blockIdx.x, blockIdx.y, sU, sV);
+  tn_tr_dispatch(a, blockIdx.x, blockIdx.y, sU, sV);
 }
 
 // Grouped form: ONE launch for all wide weight gradients of a backward pass (or of one exchange bucket).  The table is
 // an array of TnTrDesc in device memory; first_block is a running prefix, block_base offsets a sub-range launch.
 struct TnTrDesc {
-  TnArgs a;         // 80 bytes
+  TnArgs a;         // 88 bytes
   int first_block;  // workgroups of all earlier descriptors
   int n_tiles;      // tiles_p * tiles_q
-  int pad[2];
 };
-static_assert(sizeof(TnArgs) == 80 && sizeof(TnTrDesc) == 96, "descriptor layout is part of the ABI");
+static_assert(offsetof(TnTrDesc, first_block) == 88, "ops.DeferredDW.KINDS patches first_block at byte 88");
+static_assert(sizeof(TnArgs) == 88 && sizeof(TnTrDesc) == 96, "descriptor layout is part of the ABI");
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_tr_grouped_kernel(const TnTrDesc* __restrict__ descs, int n, int block_base) {
   __shared__ __attribute__((aligned(16))) char sU[TK * PITCH];
@@ -185,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_grouped_kernel(const TnTrDe
   const TnTrDesc d = descs[lo];
   const int local = bid - d.first_block;
   // splits of one tile are adjacent block ids: they share the operand panels' columns in L2 while they run
-  tn_tr_body(d.a, local % d.n_tiles, local / d.n_tiles, sU, sV);
+  tn_tr_dispatch(d.a, local % d.n_tiles, local / d.n_tiles, sU, sV);
 }
 
 // token tiles per workgroup: enough to amortise the prologue and the 128x128 fp32 atomic epilogue
@@ -204,9 +242,18 @@ inline bool tn_tr_fill(TnArgs* a, const bf16_t* U, long ldu, const bf16_t* V, lo
                        float* C, long ldc, bool grouped, int* n_tiles, int* n_blocks) {
   if (!U || !V || !C || M <= 0 || P <= 0 || Q <= 0 || P % 8 || Q % 8 || ldu % 8 || ldv % 8) return false;
   if ((((uintptr_t)U | (uintptr_t)V) & 15) != 0) return false;
-  a->U = U; a->V = V; a->ldu = ldu; a->ldv = ldv; a->M = M; a->P = P; a->Q = Q; a->alpha = alpha; a->C = C; a->ldc = ldc;
-  a->tiles_q = aql_cdiv(Q, BT);
-  const int tiles = aql_cdiv(P, BT) * a->tiles_q;
+  // C[P,Q] = U^T V.  A rank <= 32 side becomes the 32-wide Q side of 128x32 tiles; if that side is P the operands are
+  // swapped (C^T = V^T U) and the result is written transposed.
+  const bool swap = P <= 32 && Q > 32;
+  a->narrow = (P <= 32 || Q <= 32) ? 1 : 0;
+  a->trans = swap ? 1 : 0;
+  a->U = swap ? V : U; a->V = swap ? U : V;
+  a->ldu = swap ? ldv : ldu; a->ldv = swap ? ldu : ldv;
+  a->M = M; a->P = swap ? Q : P; a->Q = swap ? P : Q;
+  a->alpha = alpha; a->C = C; a->ldc = ldc;
+  const int bq = a->narrow ? 32 : BT;
+  a->tiles_q = aql_cdiv(a->Q, bq);
+  const int tiles = aql_cdiv(a->P, BT) * a->tiles_q;
   const int ktiles = aql_cdiv(M, TK);
   int splits = tn_tr_splits(tiles, ktiles, grouped);
   a->tiles_per_split = aql_cdiv(ktiles, splits);

@@ -176,7 +176,7 @@ def gemm_tn_acc(U, V, C, alpha=1.0):
     AQL_TN_OLD=1 selects the previous wide path (transpose both operands once + pipelined NT kernels) for comparison."""
     M, P = U.shape
     Q = V.shape[1]
-    if min(P, Q) > 32 and U.stride(1) == 1 and V.stride(1) == 1 and not os.environ.get("AQL_TN_OLD"):
+    if U.stride(1) == 1 and V.stride(1) == 1 and not os.environ.get("AQL_TN_OLD"):
         L.call("aql_gemm_tn_tr_f32", L.ptr(U), U.stride(0), L.ptr(V), V.stride(0), M, P, Q, float(alpha), L.ptr(C),
                C.stride(0), L.stream_ptr())
         return
@@ -248,7 +248,7 @@ class DeferredDW:
 
     # kind -> (descriptor bytes, byte offset of first_block inside the descriptor, fill entry, grouped launch entry)
     KINDS = {"n": (80, 64, "aql_tn_desc_fill", "aql_gemm_tn_grouped_range"),
-             "w": (96, 80, "aql_tntr_desc_fill", "aql_gemm_tn_tr_grouped")}
+             "w": (96, 88, "aql_tntr_desc_fill", "aql_gemm_tn_tr_grouped")}   # TnTrDesc: 88-byte TnArgs, first_block
     DS_BYTES = 48
 
     def __init__(self, device, max_sites=1024, defer_wide=True):
@@ -277,7 +277,9 @@ class DeferredDW:
     def add_tn(self, U, V, C, alpha=1.0):
         """C[P,Q] += alpha * U^T V;  always taken (returns True): grouped when a table accepts it, else held back as a
         direct launch that `flush` / `run_bucket` issues."""
-        kinds = ("n", "w") if min(U.shape[1], V.shape[1]) <= 32 else ("w", "n")
+        # the transpose-read kernel takes every problem (128x32 tiles for a rank <= 32 side); the register-transposing
+        # kernel is the fallback (AQL_TN_OLD=1 prefers it, for comparison)
+        kinds = ("n", "w") if os.environ.get("AQL_TN_OLD") else ("w", "n")
         for k in kinds:
             nbytes, _, fill, _ = self.KINDS[k]
             slot = self.host[k].data_ptr() + self.n[k] * nbytes

@@ -30,7 +30,9 @@ def tntr(U, V, C, alpha=1.0):
 
 torch.manual_seed(0)
 for (M, P, Q) in [(32768, 320, 320), (32768, 2560, 320), (32768, 320, 1280), (8192, 640, 320), (8192, 320, 2560), (2048, 1280, 320),
-                  (2048, 320, 5120), (616, 320, 768), (512, 320, 1280), (1000, 40, 72), (77, 320, 768), (130, 8, 136)]:
+                  (2048, 320, 5120), (616, 320, 768), (512, 320, 1280), (1000, 40, 72), (77, 320, 768), (130, 8, 136),
+                  (16384, 320, 32), (16384, 32, 320), (16384, 2560, 32), (16384, 32, 1280), (4096, 640, 32), (4096, 32, 2560),
+                  (1024, 32, 1280), (1024, 5120, 32), (308, 32, 768), (256, 32, 32), (1000, 16, 72), (1000, 72, 8)]:
     U = torch.randn(M, P, device=dev).bfloat16()
     V = torch.randn(M, Q, device=dev).bfloat16()
     C = torch.full((P, Q), 0.5, device=dev)
@@ -40,7 +42,7 @@ for (M, P, Q) in [(32768, 320, 320), (32768, 2560, 320), (32768, 320, 1280), (81
     ok = err < 2e-5 * max(1.0, (M / 512) ** 0.5)   # fp32 accumulate, split order differs
     ok_all &= ok
     print(f"{'PASS' if ok else 'FAIL'} tn_tr M{M} P{P} Q{Q}: relerr={err:.2e}")
-    if M >= 512 and P >= 320:
+    if M >= 512 and max(P, Q) >= 320:
         Z = torch.zeros(P, Q, device=dev)
         t_new = timeit(lambda: tntr(U, V, Z))
         os.environ["AQL_TN_OLD"] = "1"
