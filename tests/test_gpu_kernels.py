@@ -30,3 +30,10 @@ def test_gemm_family_parity():
 def test_ops_parity():
     text = _run("probe_ops.py")
     assert text.count("PASS") >= 60
+
+
+def test_transpose_read_weight_gradient_gemm():
+    """aql_gemm_tn_tr_f32 (wide 128x128 and rank <= 32 128x32 tiles, swapped / transposed output, ragged M, P, Q, strided
+    operands) against fp32 torch."""
+    text = _run("probe_tntr.py")
+    assert text.count("PASS") >= 25
