@@ -147,11 +147,11 @@ struct Stager {
 };
 
 // owner rows -> B-operand fragments  f[frag][kstep]
-template <int DH>
-__device__ __forceinline__ void load_owner(bf16x8_t (&f)[2][DH / 32], const bf16_t* g, long ld, int row0, int nrows,
+template <int DH, int NOF>
+__device__ __forceinline__ void load_owner(bf16x8_t (&f)[NOF][DH / 32], const bf16_t* g, long ld, int row0, int nrows,
                                            int d, int lane) {
 #pragma unroll
-  for (int fr = 0; fr < 2; ++fr) {
+  for (int fr = 0; fr < NOF; ++fr) {
     const int row = row0 + fr * 16 + (lane & 15);
 #pragma unroll
     for (int s = 0; s < DH / 32; ++s) {
@@ -165,8 +165,8 @@ __device__ __forceinline__ void load_owner(bf16x8_t (&f)[2][DH / 32], const bf16
 }
 
 // acc[sf][of] += rowmajor tile frag sf (A)  x  owner frag of (B)
-template <int DH>
-__device__ __forceinline__ void s_product(f32x4_t (&acc)[4][2], const char* tile, const bf16x8_t (&own)[2][DH / 32],
+template <int DH, int NOF>
+__device__ __forceinline__ void s_product(f32x4_t (&acc)[4][NOF], const char* tile, const bf16x8_t (&own)[NOF][DH / 32],
                                           int lane) {
 #pragma unroll
   for (int s = 0; s < DH / 32; ++s) {
@@ -177,18 +177,19 @@ __device__ __forceinline__ void s_product(f32x4_t (&acc)[4][2], const char* tile
 #pragma unroll
     for (int sf = 0; sf < 4; ++sf)
 #pragma unroll
-      for (int of = 0; of < 2; ++of)
+      for (int of = 0; of < NOF; ++of)
         acc[sf][of] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[sf], own[of][s], acc[sf][of], 0, 0, 0);
   }
 }
 
 // p[sf][of] (fp32, rows = streamed index sf*16 + g*4 + reg) -> B fragments over streamed rows:
 // k-slot (g,e) of step s2  <->  streamed row 32*s2 + 16*(e>>2) + 4*g + (e&3)
-__device__ __forceinline__ void pack_p(bf16x8_t (&pb)[2][2], const f32x4_t (&p)[4][2]) {
+template <int NOF>
+__device__ __forceinline__ void pack_p(bf16x8_t (&pb)[2][NOF], const f32x4_t (&p)[4][NOF]) {
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-    for (int of = 0; of < 2; ++of) {
+    for (int of = 0; of < NOF; ++of) {
       uint4 v;
       v.x = pack_bf16x2(p[2 * s2][of][0], p[2 * s2][of][1]);
       v.y = pack_bf16x2(p[2 * s2][of][2], p[2 * s2][of][3]);
@@ -203,8 +204,8 @@ __device__ __forceinline__ void pack_p(bf16x8_t (&pb)[2][2], const f32x4_t (&p)[
 // the address of row p>>2, columns 4*(p&3).. and receives column p of that 4x16 block (verified on hardware with
 // tools/micro/tr_probe.hip).  k-slot (g,e) of step s2 <-> streamed row 32*s2 + 16*(e>>2) + 4*g + (e&3), as in pack_p.
 typedef short v4s_t __attribute__((ext_vector_type(4)));
-template <int DH, int DV>
-__device__ __forceinline__ void t_product(f32x4_t (&acc)[DV / 16][2], const char* tile, const bf16x8_t (&pb)[2][2],
+template <int DH, int DV, int NOF>
+__device__ __forceinline__ void t_product(f32x4_t (&acc)[DV / 16][NOF], const char* tile, const bf16x8_t (&pb)[2][NOF],
                                           int lane) {
   const int p = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -218,39 +219,52 @@ __device__ __forceinline__ void t_product(f32x4_t (&acc)[DV / 16][2], const char
           (v4s_t __attribute__((address_space(3)))*)(base + 16 * RowPitch<DH>::value));
       const bf16x8_t a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-      for (int of = 0; of < 2; ++of)
+      for (int of = 0; of < NOF; ++of)
         acc[df][of] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb[s2][of], acc[df][of], 0, 0, 0);
     }
   }
 }
 
-__device__ __forceinline__ float group4_max(float v) {  // across the 4 lanes sharing lane&15
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return fmaxf(v, __shfl_xor(v, 32, 64));
+// Reductions across the 4 lanes that share lane&15 (one per 16-lane row).  gfx950's v_permlane16_swap / v_permlane32_swap
+// exchange whole rows / halves between two registers in one VALU op: with both operands equal to v the pair of results
+// holds (v of the row-pair partner) in every lane, so xor-16 and xor-32 reductions cost two VALU ops each instead of a
+// ds_bpermute round trip through the LDS pipe (~100+ cycles of dependent latency, four of them per K/V tile in the
+// forward's online softmax).
+__device__ __forceinline__ float group4_max(float v) {
+  uint32_t u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  u = __float_as_uint(v);
+  auto s = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(s[0]), __uint_as_float(s[1]));
 }
 __device__ __forceinline__ float group4_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  return v + __shfl_xor(v, 32, 64);
+  uint32_t u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  u = __float_as_uint(v);
+  auto s = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(s[0]) + __uint_as_float(s[1]);
 }
 
-template <int N>
-__device__ __forceinline__ void zero_acc(f32x4_t (&a)[N][2]) {
+template <int N, int NOF>
+__device__ __forceinline__ void zero_acc(f32x4_t (&a)[N][NOF]) {
 #pragma unroll
   for (int i = 0; i < N; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NOF; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) a[i][j][e] = 0.f;
 }
 
 // store acc^T (d x owner rows) as out[row][d] bf16, 4 consecutive d per lane
-template <int DV>
-__device__ __forceinline__ void store_t(const f32x4_t (&acc)[DV / 16][2], bf16_t* g, long ld, int row0, int nrows, int d,
-                                        float mul0, float mul1, int lane) {
+template <int DV, int NOF>
+__device__ __forceinline__ void store_t(const f32x4_t (&acc)[DV / 16][NOF], bf16_t* g, long ld, int row0, int nrows, int d,
+                                        const float (&muls)[NOF], int lane) {
 #pragma unroll
-  for (int of = 0; of < 2; ++of) {
+  for (int of = 0; of < NOF; ++of) {
     const int row = row0 + of * 16 + (lane & 15);
-    const float mul = of ? mul1 : mul0;
+    const float mul = muls[of];
     if (row >= nrows) continue;
 #pragma unroll
     for (int df = 0; df < DV / 16; ++df) {
@@ -299,21 +313,26 @@ struct AttnArgs {
 // (exp2, max, sum, pack) already outweighs its 28 MFMAs.  Only the head sizes that fit 256 registers without spilling
 // get the hint.
 // ------------------------------------------------------------------------------------------------ forward
-template <int DH, int DV>
+// NOF = owner fragments (16 query rows each) per wavefront: 2 (32 rows, 128 per workgroup) or 4 (64 rows, 256 per
+// workgroup).  With 4 the K/V staging, the barriers and the LDS fragment reads of a tile are amortised over twice the
+// MFMA work and the two independent row halves give the scheduler something to overlap with the softmax chain.
+template <int DH, int DV, int NOF>
 __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char sK[TILE * RowPitch<DH>::value];
   __shared__ __attribute__((aligned(16))) char sV[TILE * RowPitch<DH>::value];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * (4 * OWN) + wave * OWN;
+  const int q0 = blockIdx.x * (64 * NOF) + wave * (16 * NOF);
   const bf16_t* qp = a.q + (long)b * a.Nq * a.ldq + h * a.d;
   const bf16_t* kp = a.k + (long)b * a.Nk * a.ldk + h * a.d;
   const bf16_t* vp = a.v + (long)b * a.Nk * a.ldv + h * a.d;
-  bf16x8_t qf[2][DH / 32];
+  bf16x8_t qf[NOF][DH / 32];
   load_owner<DH>(qf, qp, a.ldq, q0, a.Nq, a.d, lane);
-  f32x4_t o[DV / 16][2];
+  f32x4_t o[DV / 16][NOF];
   zero_acc(o);
-  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+  float m[NOF], l[NOF];
+#pragma unroll
+  for (int of = 0; of < NOF; ++of) m[of] = -INFINITY, l[of] = 0.f;
   const float c = a.scale * LOG2E;
   Stager<DH> stK, stV;
   stK.init(sK, kp, a.ldk, 0, a.Nk, a.d, tid);
@@ -331,7 +350,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const
       stK.fetch();
       stV.fetch();
     }
-    f32x4_t s[4][2];
+    f32x4_t s[4][NOF];
     zero_acc(s);
     s_product<DH>(s, sK, qf, lane);
     if (kt + TILE > a.Nk) {
@@ -339,10 +358,13 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const
       for (int sf = 0; sf < 4; ++sf)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (kt + sf * 16 + (lane >> 4) * 4 + e >= a.Nk) s[sf][0][e] = s[sf][1][e] = -INFINITY;
+          if (kt + sf * 16 + (lane >> 4) * 4 + e >= a.Nk) {
+#pragma unroll
+            for (int of = 0; of < NOF; ++of) s[sf][of][e] = -INFINITY;
+          }
     }
 #pragma unroll
-    for (int of = 0; of < 2; ++of) {
+    for (int of = 0; of < NOF; ++of) {
       float mx = -INFINITY;
 #pragma unroll
       for (int sf = 0; sf < 4; ++sf)
@@ -368,14 +390,17 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[df][of][e] *= alpha;
     }
-    bf16x8_t pb[2][2];
+    bf16x8_t pb[2][NOF];
     pack_p(pb, s);
     t_product<DH, DV>(o, sV, pb, lane);
   }
-  store_t<DV>(o, a.out + (long)b * a.Nq * a.ldo + h * a.d, a.ldo, q0, a.Nq, a.d, 1.f / l[0], 1.f / l[1], lane);
+  float inv[NOF];
+#pragma unroll
+  for (int of = 0; of < NOF; ++of) inv[of] = 1.f / l[of];
+  store_t<DV>(o, a.out + (long)b * a.Nq * a.ldo + h * a.d, a.ldo, q0, a.Nq, a.d, inv, lane);
   if ((lane >> 4) == 0) {
 #pragma unroll
-    for (int of = 0; of < 2; ++of) {
+    for (int of = 0; of < NOF; ++of) {
       const int row = q0 + of * 16 + (lane & 15);
       if (row < a.Nq) a.lse[((long)b * a.H + h) * a.Nq + row] = m[of] * a.scale + logf(l[of]);
     }
@@ -467,7 +492,8 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dq_kernel(const 
     pack_p(pb, s);
     t_product<DH, DV>(dq, sK, pb, lane);
   }
-  store_t<DV>(dq, a.dq + (long)b * a.Nq * a.ldq + h * a.d, a.ldq, q0, a.Nq, a.d, a.scale, a.scale, lane);
+  const float mq[2] = {a.scale, a.scale};
+  store_t<DV>(dq, a.dq + (long)b * a.Nq * a.ldq + h * a.d, a.ldq, q0, a.Nq, a.d, mq, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
@@ -567,8 +593,9 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dkv_kernel(const
     store_t_f32<DV>(dv, pk + slab, a.d, k0, a.Nk, a.d, lane);
     return;
   }
-  store_t<DV>(dk, a.dk + (long)b * a.Nk * ldo_kv + h * a.d, ldo_kv, k0, a.Nk, a.d, a.scale, a.scale, lane);
-  store_t<DV>(dv, a.dv + (long)b * a.Nk * ldo_kv + h * a.d, ldo_kv, k0, a.Nk, a.d, 1.f, 1.f, lane);
+  const float mk[2] = {a.scale, a.scale}, mv[2] = {1.f, 1.f};
+  store_t<DV>(dk, a.dk + (long)b * a.Nk * ldo_kv + h * a.d, ldo_kv, k0, a.Nk, a.d, mk, lane);
+  store_t<DV>(dv, a.dv + (long)b * a.Nk * ldo_kv + h * a.d, ldo_kv, k0, a.Nk, a.d, mv, lane);
 }
 
 // dk/dv[b][row][h*d + c] = bf16(mul * sum_split part[which][split][b][h][row][c]); 4 columns per thread
@@ -599,8 +626,14 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const AttnArgs a) 
 
 template <int DH, int DV>
 int launch_fwd(const AttnArgs& a, hipStream_t st) {
-  dim3 grid(aql_cdiv(a.Nq, 4 * OWN), a.H, a.B);
-  hipLaunchKernelGGL((attn_fwd_kernel<DH, DV>), grid, dim3(256), 0, st, a);
+  static const int force = getenv("AQL_ATTN_NOF") ? atoi(getenv("AQL_ATTN_NOF")) : 0;  // tuning hook
+  if constexpr (DH <= 64) {
+    if (force == 4 || (force == 0 && a.Nq >= 2048)) {
+      hipLaunchKernelGGL((attn_fwd_kernel<DH, DV, 4>), dim3(aql_cdiv(a.Nq, 256), a.H, a.B), dim3(256), 0, st, a);
+      return 0;
+    }
+  }
+  hipLaunchKernelGGL((attn_fwd_kernel<DH, DV, 2>), dim3(aql_cdiv(a.Nq, 128), a.H, a.B), dim3(256), 0, st, a);
   return 0;
 }
 template <int DH, int DV>
