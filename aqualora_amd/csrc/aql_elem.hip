@@ -553,3 +553,29 @@ extern "C" int aql_softmax_rows(const float* S, long lds_, long M, int N, float 
   AQL_CHECK_LAUNCH("aql_softmax_rows");
   return AQL_OK;
 }
+
+// backward of the row softmax above: dS[m,:] = scale * P[m,:] * (dP[m,:] - sum_j P[m,j] dP[m,j])   (bf16 in, bf16 out)
+namespace {
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const bf16_t* __restrict__ P, const bf16_t* __restrict__ dP,
+                                                               long ld, int N, float scale, bf16_t* __restrict__ dS) {
+  __shared__ float red[4];
+  const bf16_t* p = P + (long)blockIdx.x * ld;
+  const bf16_t* g = dP + (long)blockIdx.x * ld;
+  bf16_t* o = dS + (long)blockIdx.x * ld;
+  const int tid = threadIdx.x;
+  float dot = 0.f;
+  for (int i = tid; i < N; i += 256) dot += bf16_to_f32(p[i]) * bf16_to_f32(g[i]);
+  dot = wave_sum(dot);
+  if ((tid & 63) == 0) red[tid >> 6] = dot;
+  __syncthreads();
+  const float delta = (red[0] + red[1]) + (red[2] + red[3]);
+  for (int i = tid; i < N; i += 256) o[i] = f32_to_bf16(scale * bf16_to_f32(p[i]) * (bf16_to_f32(g[i]) - delta));
+}
+}  // namespace
+extern "C" int aql_softmax_rows_bwd(const bf16_t* P, const bf16_t* dP, long ld, long M, int N, float scale, bf16_t* dS,
+                                    hipStream_t stream) {
+  AQL_CHECK_ARG(P && dP && dS && M > 0 && N > 0, "aql_softmax_rows_bwd: bad args");
+  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)M), dim3(256), 0, stream, P, dP, ld, N, scale, dS);
+  AQL_CHECK_LAUNCH("aql_softmax_rows_bwd");
+  return AQL_OK;
+}

@@ -3,9 +3,10 @@ step of the message decoder (train/rob_enhance_finetune.py:996-1036), HIP-backed
 
 What is built here: ``PRVL_loss`` (:42-50), ``gen_combined_latents`` (:133-149), the step's loss schedule (:196-217), the
 trainable SecretEncoder / SecretDecoder (forward AND backward in HIP, see watermark.py / decoder.py) and the distortion
-layers (noise.py).  What stays outside (third-party and absent from this image): the VAE
-(``decode_latents`` is a caller-supplied differentiable callable), LPIPS (``lpips_fn`` callable, optional) and the
-diffusion sampling pipeline that feeds rob-finetune with images.
+layers (noise.py).  ``decode_latents`` is a differentiable callable: ``lambda z: vae.decode_grad(z, scaled=False)`` of
+``aqualora_amd.vae.AutoencoderKL`` runs the frozen decoder and its backward on the HIP kernels (the reference decodes raw,
+unscaled latents at :100-104).  What stays outside (third-party and absent from this image): LPIPS (``lpips_fn`` callable,
+optional) and the diffusion sampling pipeline that feeds rob-finetune with images.
 """
 import random
 

@@ -2,7 +2,9 @@
 ``vae.encode(pixel_values).latent_dist.sample() * 0.18215``) and decode (evaluation/utils_eval.py pipelines,
 train/latent_wm_pretrain.py:171,180-181 forward), SURVEY.md §8 row A17 / (f) rank 1.
 
-Inference only (the VAE is frozen everywhere in the reference).  It reuses the U-Net's kernels -- implicit-GEMM 3x3
+The VAE is frozen everywhere in the reference: weights never get a gradient.  ``encode`` / ``decode`` run without a graph;
+``decode_grad`` keeps the autograd graph back to the latents, because stage 1 trains the SecretEncoder THROUGH the decoder
+(latent_wm_pretrain.py:180-181) -- every backward op is a HIP kernel too.  It reuses the U-Net's kernels -- implicit-GEMM 3x3
 convolutions (with the nearest-x2 upsample folded into the gather on the decoder side and the encoder's
 ``F.pad(x, (0,1,0,1))`` + stride-2 convolution as a leading-pad-0 variant of the same loader), GroupNorm(32, 1e-6)+SiLU,
 bf16 GEMMs with bias/residual epilogues -- plus a row-softmax kernel for the mid-block's single-head 512-wide
@@ -95,6 +97,63 @@ def synthetic_state_dict(cfg=SD15_VAE, seed=2048, device="cpu"):
     return sd
 
 
+def _tn_f32(U, V):
+    """U[M,P]^T V[M,Q] in fp32 on the transpose-read GEMM (both operands token-major)."""
+    C = torch.zeros(U.shape[1], V.shape[1], dtype=torch.float32, device=U.device)
+    L.call("aql_gemm_tn_tr_f32", L.ptr(U), U.stride(0), L.ptr(V), V.stride(0), U.shape[0], U.shape[1], V.shape[1], 1.0,
+           L.ptr(C), C.stride(0), L.stream_ptr())
+    return C
+
+
+class WideHeadAttentionFn(torch.autograd.Function):
+    """softmax(Q K^T / sqrt(C)) V with ONE head of width C (512 in the VAE) on token-major q/k/v [B*N, C], built from
+    GEMMs because the flash kernels stop at d = 160:
+      forward : S = Q K^T (fp32, aql_gemm_nt_f32_accum) -> P = softmax(S / sqrt(C)) (aql_softmax_rows) -> O = P V
+      backward: dV = P^T dO, dK = dS^T Q (aql_gemm_tn_tr_f32);  dP = dO V^T;  dS = P * (dP - rowsum(P dP)) / sqrt(C)
+                (aql_softmax_rows_bwd);  dQ = dS K
+    P [N,N] bf16 per sample is saved for backward (33 MB at N = 4096)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, B):
+        N, C = q.shape[0] // B, q.shape[1]
+        dev, st = q.device, L.stream_ptr()
+        ws = ops.workspace(dev)
+        o = torch.empty_like(q)
+        vt = torch.empty(C, N, dtype=torch.bfloat16, device=dev)
+        probs = torch.empty(B, N, N, dtype=torch.bfloat16, device=dev)
+        for b in range(B):
+            sl = slice(b * N, (b + 1) * N)
+            s = torch.zeros(N, N, dtype=torch.float32, device=dev)
+            L.call("aql_gemm_nt_f32_accum", L.ptr(q[sl]), C, L.ptr(k[sl]), C, N, N, C, 1.0, L.ptr(s), N, L.ptr(ws),
+                   ws.numel() * 4, st)
+            L.call("aql_softmax_rows", L.ptr(s), N, N, N, float(C ** -0.5), L.ptr(probs[b]), N, st)
+            L.call("aql_transpose_bf16", L.ptr(v[sl]), N, C, C, L.ptr(vt), st)
+            ops.gemm_bf16(probs[b], vt, out=o[sl])
+        ctx.save_for_backward(q, k, v, probs)
+        ctx.B = B
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, probs = ctx.saved_tensors
+        B = ctx.B
+        N, C = q.shape[0] // B, q.shape[1]
+        dev, st = q.device, L.stream_ptr()
+        do = do.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        kt = torch.empty(C, N, dtype=torch.bfloat16, device=dev)
+        ds = torch.empty(N, N, dtype=torch.bfloat16, device=dev)
+        for b in range(B):
+            sl = slice(b * N, (b + 1) * N)
+            dv[sl] = _tn_f32(probs[b], do[sl]).to(torch.bfloat16)
+            dp = ops.gemm_bf16(do[sl], v[sl])                       # dO V^T  [N, N]
+            L.call("aql_softmax_rows_bwd", L.ptr(probs[b]), L.ptr(dp), N, N, N, float(C ** -0.5), L.ptr(ds), st)
+            L.call("aql_transpose_bf16", L.ptr(k[sl]), N, C, C, L.ptr(kt), st)
+            ops.gemm_bf16(ds, kt, out=dq[sl])                       # dS K
+            dk[sl] = _tn_f32(ds, q[sl]).to(torch.bfloat16)          # dS^T Q
+        return dq, dk, dv, None
+
+
 class AutoencoderKL:
     """``encode(x).latent_dist``-style moments and ``decode(z)`` of the SD-1.5 VAE; all activations bf16 channels-last."""
 
@@ -129,6 +188,8 @@ class AutoencoderKL:
     # ------------------------------------------------------------------------------------------------ ops
     def _conv3(self, x, key, upsample=False, residual=None, pad_lo=1):
         pk = self.p[key]
+        if pad_lo == 1:   # the U-Net's differentiable op (backward-data incl. the folded upsample's adjoint)
+            return ops.conv3x3(x, pk, upsample, None, residual)
         B, C, H, W = x.shape
         if C != pk.Cin:   # conv_in: zero-pad 3 (or 4) channels to 8
             xp = x.new_zeros((B, pk.Cin, H, W)).contiguous(memory_format=CL)
@@ -152,8 +213,7 @@ class AutoencoderKL:
         return x.permute(0, 2, 3, 1).reshape(B * H * W, C)   # a view: the map is channels-last
 
     def _lin(self, t, key, residual=None):
-        pk = self.p[key]
-        return ops.gemm_bf16(t, pk.w, pk.bias, residual=residual)
+        return ops.lora_linear(t, self.p[key], residual=residual)
 
     def _resnet(self, x, p):
         h = self._conv3(self._norm(x, p + ".norm1", True), p + ".conv1")
@@ -168,22 +228,9 @@ class AutoencoderKL:
     def _attn(self, x, p):
         """diffusers Attention with one head of width C, GroupNorm first, residual last."""
         B, C, H, W = x.shape
-        N = H * W
         t = self._tokens(self._norm(x, p + ".group_norm", False))
         q, k, v = (self._lin(t, f"{p}.{n}") for n in ("to_q", "to_k", "to_v"))
-        o = torch.empty_like(q)
-        ws = ops.workspace(x.device)
-        st = L.stream_ptr()
-        vt = torch.empty(C, N, dtype=torch.bfloat16, device=x.device)
-        prob = torch.empty(N, N, dtype=torch.bfloat16, device=x.device)
-        for b in range(B):
-            sl = slice(b * N, (b + 1) * N)
-            s = torch.zeros(N, N, dtype=torch.float32, device=x.device)
-            L.call("aql_gemm_nt_f32_accum", L.ptr(q[sl]), C, L.ptr(k[sl]), C, N, N, C, 1.0, L.ptr(s), N, L.ptr(ws),
-                   ws.numel() * 4, st)
-            L.call("aql_softmax_rows", L.ptr(s), N, N, N, float(C ** -0.5), L.ptr(prob), N, st)
-            L.call("aql_transpose_bf16", L.ptr(v[sl]), N, C, C, L.ptr(vt), st)
-            ops.gemm_bf16(prob, vt, out=o[sl])
+        o = WideHeadAttentionFn.apply(q, k, v, B)
         y = self._lin(o, p + ".to_out.0", residual=self._tokens(x))
         return y.view(B, H, W, C).permute(0, 3, 1, 2)
 
@@ -211,31 +258,41 @@ class AutoencoderKL:
         mean, logvar = m.float().chunk(2, dim=1)
         return mean.contiguous(), logvar.clamp(-30.0, 20.0).contiguous()
 
-    def encode(self, x, noise=None, sample=True):
+    def encode(self, x, noise=None, sample=True, scaled=True):
         """``vae.encode(x).latent_dist.sample() * scaling_factor`` (ppft_train.py:993-996); ``noise`` is the N(0,1) draw
-        (injected so that runs are reproducible), ``sample=False`` returns the mode."""
+        (injected so that runs are reproducible), ``sample=False`` returns the mode.  ``scaled=False`` leaves the 0.18215
+        factor out, as stage 1 does (latent_wm_pretrain.py:171)."""
         mean, logvar = self.encode_moments(x)
         z = mean
         if sample:
             if noise is None:
                 noise = torch.randn_like(mean)
             z = mean + torch.exp(0.5 * logvar) * noise.to(mean)
-        return z * self.cfg["scaling_factor"]
+        return z * self.cfg["scaling_factor"] if scaled else z
 
     @torch.no_grad()
-    def decode(self, z_scaled):
-        """``vae.decode(z / scaling_factor).sample``: z [B,4,h,w] (already multiplied by 0.18215) -> image [B,3,8h,8w]."""
+    def decode(self, z_scaled, scaled=True):
+        """``vae.decode(z / scaling_factor).sample``: z [B,4,h,w] (already multiplied by 0.18215) -> image [B,3,8h,8w].
+        ``scaled=False``: z is a raw posterior sample (``vae.decode(latents).sample`` of latent_wm_pretrain.py:100-104)."""
+        return self.decode_grad(z_scaled, scaled)
+
+    def decode_grad(self, z_scaled, scaled=True):
+        """``decode`` with the autograd graph back to ``z_scaled`` kept: stage 1 trains the SecretEncoder THROUGH the frozen
+        decoder (train/latent_wm_pretrain.py:180-181).  Every op's backward is a HIP kernel (conv backward-data with the
+        upsample adjoint, GroupNorm backward, GEMMs, the GEMM-built wide-head attention); weights get no gradient."""
         rch, L_ = tuple(reversed(self.cfg["block_out_channels"])), self.cfg["layers_per_block"]
-        z = (z_scaled.to(self.device).float() / self.cfg["scaling_factor"]).to(torch.bfloat16)
+        z = z_scaled.to(self.device).float()
+        z = (z / self.cfg["scaling_factor"] if scaled else z).to(torch.bfloat16)
         B, C, H, W = z.shape
-        zp = z.new_zeros((B, 8, H, W)).contiguous(memory_format=CL)   # 1x1 conv on 4 channels: pad K to 8
-        zp[:, :C] = z
-        pk = self.p["post_quant_conv"]
-        wq = pk.w.new_zeros((8, 8))
-        wq[:pk.N, :pk.K] = pk.w
-        bq = pk.bias.new_zeros(8)
-        bq[:pk.N] = pk.bias
-        h = ops.gemm_bf16(self._tokens(zp), wq, bq).view(B, H, W, 8).permute(0, 3, 1, 2)[:, :C]
+        zp = torch.cat([z, z.new_zeros((B, 8 - C, H, W))], dim=1).contiguous(memory_format=CL)   # 1x1 conv: pad K to 8
+        if "post_quant_conv8" not in self.p:
+            pk = self.p["post_quant_conv"]
+            wq = pk.w.new_zeros((8, 8))
+            wq[:pk.N, :pk.K] = pk.w
+            bq = pk.bias.new_zeros(8)
+            bq[:pk.N] = pk.bias
+            self.p["post_quant_conv8"] = ops.PackedLinear(wq, bq)
+        h = self._lin(self._tokens(zp), "post_quant_conv8").view(B, H, W, 8).permute(0, 3, 1, 2)[:, :C]
         h = self._conv3(h.contiguous(memory_format=CL), "decoder.conv_in")
         h = self._mid(h, "decoder.mid_block")
         for i in range(len(rch)):

@@ -114,6 +114,10 @@ int aql_upsample2x_bwd(const bf16_t* du, int B, int H, int W, int C, bf16_t* dx,
 /* P[m,:] = softmax(scale * S[m,:]), S fp32 -> P bf16: the VAE mid-block's single-head 512-wide attention
  * (AutoencoderKL, ppft_train.py:993), whose scores come from aql_gemm_nt_f32_accum                                   */
 int aql_softmax_rows(const float* S, long lds, long M, int N, float scale, bf16_t* P, long ldp, aql_stream_t stream);
+/* its backward (stage 1 trains the SecretEncoder THROUGH vae.decode, latent_wm_pretrain.py:180-181):
+ * dS[m,:] = scale * P[m,:] * (dP[m,:] - sum_j P[m,j] dP[m,j])                                                      */
+int aql_softmax_rows_bwd(const bf16_t* P, const bf16_t* dP, long ld, long M, int N, float scale, bf16_t* dS,
+                         aql_stream_t stream);
 /* DDPMScheduler.add_noise on x0 and x0+wm with shared noise/timesteps  train/ppft_train.py:1010-1011              */
 int aql_add_noise(const float* x0, const float* wm, const float* eps, const long* t, const float* alphas_cumprod, int B,
                   int per_sample, bf16_t* noisy, bf16_t* noisy_wm, aql_stream_t stream);

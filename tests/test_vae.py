@@ -85,3 +85,49 @@ def test_vae_full_size_encoder_vs_oracle():
     om, ol = VAEOracle(sd, SD15_VAE, bf16=True).encode_moments(x)
     assert mean.shape == (1, 4, 32, 32)
     assert _rel(mean, om) < 3e-2 and _rel(logvar, ol) < 3e-2, (_rel(mean, om), _rel(logvar, ol))
+
+
+@pytest.mark.gpu
+def test_vae_decode_is_differentiable_wrt_latents():
+    """Stage 1 back-propagates through the frozen decoder (latent_wm_pretrain.py:180-181): d<image, w>/dz from the HIP
+    graph (conv backward-data incl. upsample adjoint, GroupNorm backward, GEMM-built wide-head attention backward)
+    against torch autograd on the fp32 oracle."""
+    from aqualora_amd.vae import AutoencoderKL
+    sd = synthetic_state_dict(TINY_VAE)
+    vae = AutoencoderKL(sd, TINY_VAE, "cuda")
+    z0 = synth.normal("vae.z", (2, 4, 8, 8), 0.18215, 5)
+    w = synth.normal("vae.w", (2, 3, 64, 64), 1.0, 5)
+    z = z0.clone().cuda().requires_grad_(True)
+    img = vae.decode_grad(z)
+    (img * w.cuda()).sum().backward()
+    zr = z0.clone().requires_grad_(True)
+    ref = VAEOracle(sd, TINY_VAE).decode(zr)
+    (ref * w).sum().backward()
+    assert _rel(img, ref) < 5e-2
+    g, gr = z.grad.float().cpu(), zr.grad
+    l2 = float((g - gr).norm() / gr.norm())
+    assert l2 < 6e-2, l2          # bf16 storage of every activation and gradient along ~40 ops
+    assert z.grad.shape == z0.shape and torch.isfinite(z.grad).all()
+
+
+@pytest.mark.gpu
+def test_stage1_step_through_the_hip_vae_decoder():
+    """latent_wm_pretrain.py:164-221 with ``decode_latents = vae.decode`` on the HIP VAE (raw latents, :100-104): the step
+    runs end to end on the GPU and the SecretEncoder receives finite, non-zero gradients through the frozen decoder."""
+    from aqualora_amd import noise as NZ, stage1 as S1
+    from aqualora_amd.decoder import SecretDecoder
+    from aqualora_amd.vae import AutoencoderKL
+    from aqualora_amd.watermark import SecretEncoder
+    vae = AutoencoderKL(synthetic_state_dict(TINY_VAE), TINY_VAE, "cuda")
+    enc = SecretEncoder(48, base_res=4, resolution=8).cuda()
+    with torch.no_grad():
+        enc.secret_scaler[5].weight.copy_(synth.normal("s1.conv", (4, 4, 3, 3), 0.05, 3))
+    dec = SecretDecoder(48).cuda().train()
+    step = S1.Stage1Step(enc, dec, lambda z: vae.decode_grad(z, scaled=False), NZ.Noiser(["Identity"], [1.0]))
+    lat = synth.normal("s1.lat", (2, 4, 8, 8), 1.0, 3).cuda()
+    msg = synth.bits("s1.msg", (2, 48), 3).cuda()
+    out = step.losses(lat, msg, noiser_choice=[1.0])
+    loss = out["loss"] if isinstance(out, dict) else out[0]
+    loss.backward()
+    g = enc.secret_scaler[0].weight.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
