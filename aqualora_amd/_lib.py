@@ -26,6 +26,8 @@ SIGNATURES = {
     "aql_conv3x3_fwd": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_sz, c_p],
     "aql_conv3x3_fwd_pad": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_sz, c_p],
     "aql_softmax_rows": [c_p, c_l, c_l, c_i, c_f, c_p, c_l, c_p],
+    "aql_quick_gelu": [c_p, c_l, c_p, c_p],
+    "aql_causal_attn_small": [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p],
     "aql_softmax_rows_bwd": [c_p, c_p, c_l, c_l, c_i, c_f, c_p, c_p],
     "aql_conv3x3_bwd_data": [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_sz, c_p],
     "aql_gemm_tn_f32": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_f, c_p, c_l, c_p],

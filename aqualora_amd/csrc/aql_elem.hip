@@ -579,3 +579,96 @@ extern "C" int aql_softmax_rows_bwd(const bf16_t* P, const bf16_t* dP, long ld, 
   AQL_CHECK_LAUNCH("aql_softmax_rows_bwd");
   return AQL_OK;
 }
+
+// ---- CLIP text encoder pieces (transformers CLIPTextModel, reference call site train/ppft_train.py:1014-1019) ---------
+// quick_gelu(x) = x * sigmoid(1.702 x)   (CLIPMLP activation), bf16 in/out
+namespace {
+__global__ __launch_bounds__(256) void quick_gelu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long n8) {
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n8; id += (long)gridDim.x * blockDim.x) {
+    const uint4 v = reinterpret_cast<const uint4*>(x)[id];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float a = bf16lo(w[i]), b = bf16hi(w[i]);
+      o[i] = pack_bf16x2(a / (1.f + __expf(-1.702f * a)), b / (1.f + __expf(-1.702f * b)));
+    }
+    reinterpret_cast<uint4*>(y)[id] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// Causal self-attention for short sequences (N <= 128, d <= 128; CLIP text: N = 77, 12 heads of 64): one workgroup per
+// (head, sample), K and V of the head in LDS as fp32, one wavefront per query row: lanes over keys for the scores and
+// the softmax, lanes over channels for P.V.  q/k/v/o: [B, N, H*d] bf16 (head h owns columns h*d..), row stride ld.
+constexpr int CA_MAXN = 128, CA_MAXD = 128;
+__global__ __launch_bounds__(256) void causal_attn_small_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                                const bf16_t* __restrict__ v, long ld, int N, int d,
+                                                                float scale, bf16_t* __restrict__ o, long ldo) {
+  extern __shared__ float sm[];  // K [N][d+1], V [N][d+1], P [4][CA_MAXN], Q [4][CA_MAXD]
+  const int pitch = d + 1;
+  float* sK = sm;
+  float* sV = sK + N * pitch;
+  float* sP = sV + N * pitch;
+  float* sQ = sP + 4 * CA_MAXN;
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long base = (long)b * N * ld + (long)h * d;
+  for (int i = tid; i < N * d; i += 256) {
+    const int r = i / d, c = i - r * d;
+    sK[r * pitch + c] = bf16_to_f32(k[base + (long)r * ld + c]);
+    sV[r * pitch + c] = bf16_to_f32(v[base + (long)r * ld + c]);
+  }
+  __syncthreads();
+  for (int i = wave; i < N; i += 4) {
+    for (int c = lane; c < d; c += 64) sQ[wave * CA_MAXD + c] = bf16_to_f32(q[base + (long)i * ld + c]) * scale;
+    __builtin_amdgcn_wave_barrier();
+    float s[2], mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = lane + 64 * u;
+      float acc = -INFINITY;
+      if (j <= i) {  // causal: key j may be seen by query i iff j <= i
+        acc = 0.f;
+        for (int c = 0; c < d; ++c) acc += sQ[wave * CA_MAXD + c] * sK[j * pitch + c];
+      }
+      s[u] = acc;
+      mx = fmaxf(mx, acc);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = lane + 64 * u;
+      const float p = (j <= i) ? __expf(s[u] - mx) : 0.f;
+      if (j < CA_MAXN) sP[wave * CA_MAXN + j] = p;
+      sum += p;
+    }
+    sum = wave_sum(sum);
+    __builtin_amdgcn_wave_barrier();
+    const float inv = 1.f / sum;
+    for (int c = lane; c < d; c += 64) {
+      float acc = 0.f;
+      for (int j = 0; j <= i; ++j) acc += sP[wave * CA_MAXN + j] * sV[j * pitch + c];
+      o[(long)b * N * ldo + (long)i * ldo + (long)h * d + c] = f32_to_bf16(acc * inv);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+}  // namespace
+
+extern "C" int aql_quick_gelu(const bf16_t* x, long n, bf16_t* y, hipStream_t stream) {
+  AQL_CHECK_ARG(x && y && n > 0 && n % 8 == 0, "aql_quick_gelu: n must be a positive multiple of 8");
+  hipLaunchKernelGGL(quick_gelu_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, x, y, n / 8);
+  AQL_CHECK_LAUNCH("aql_quick_gelu");
+  return AQL_OK;
+}
+
+extern "C" int aql_causal_attn_small(const bf16_t* q, const bf16_t* k, const bf16_t* v, long ld, int B, int H, int N, int d,
+                                     float scale, bf16_t* o, long ldo, hipStream_t stream) {
+  AQL_CHECK_ARG(q && k && v && o, "aql_causal_attn_small: null operand");
+  AQL_CHECK_ARG(N > 0 && N <= CA_MAXN && d > 0 && d <= CA_MAXD, "aql_causal_attn_small: N <= 128 and d <= 128 (N=%d d=%d)", N, d);
+  const size_t lds = (size_t)(2 * N * (d + 1) + 4 * CA_MAXN + 4 * CA_MAXD) * sizeof(float);
+  AQL_CHECK_ARG(lds <= 64 * 1024, "aql_causal_attn_small: K/V of one head must fit 64 KB of LDS (N=%d d=%d)", N, d);
+  hipLaunchKernelGGL(causal_attn_small_kernel, dim3(H, B), dim3(256), lds, stream, q, k, v, ld, N, d, scale, o, ldo);
+  AQL_CHECK_LAUNCH("aql_causal_attn_small");
+  return AQL_OK;
+}

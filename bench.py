@@ -249,6 +249,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--text-in", action="store_true",
+                    help="train mode: run the frozen CLIP text encoder (ids [B,77] -> [B,77,768]) inside every timed step")
     ap.add_argument("--pixel-in", action="store_true",
                     help="train mode: run the frozen VAE encode (3x512x512 -> 4x64x64) inside every timed step")
     ap.add_argument("--mode", choices=["train", "infer", "robft", "vae"], default="train",
@@ -299,6 +301,27 @@ def main():
 
         runner.is_graph = getattr(latent_runner, "is_graph", False)
 
+    if args.text_in:
+        # ... and from token ids (ppft_train.py:1014-1019): frozen CLIP text encoder on the HIP kernels in front of the step
+        from aqualora_amd import synth
+        from aqualora_amd.clip import SD15_CLIP, CLIPTextModel, clip_keys
+        csd = {}
+        for k, shp in clip_keys().items():
+            if "layer_norm" in k:
+                csd[k] = torch.ones(shp, device=device) if k.endswith("weight") else torch.zeros(shp, device=device)
+            else:
+                csd[k] = synth.normal("clip." + k, shp, 0.02 if k.endswith("bias") else (0.5 if "embedding" in k else shp[-1] ** -0.5),
+                                      2048, device)
+        clip = CLIPTextModel(csd, SD15_CLIP, device)
+        ids = synth.randint("bench.ids", (args.batch, 77), 49408, 2048 + 977 * rank_id, device)
+        prev_runner = runner
+
+        def runner(**b):
+            b["ctx"] = clip(ids)
+            return prev_runner(**b)
+
+        runner.is_graph = getattr(prev_runner, "is_graph", False)
+
     for _ in range(args.warmup):
         loss = runner(**batch)
     barrier()
@@ -323,7 +346,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"SD1.5 PPFT LoRA rank={args.rank}, 48-bit msg, 512x512 (64x64x4 latents in), "
-                                   f"batch={args.batch}/GPU, " + ("pixel-in (frozen VAE encode inside the step, CLIP outside)"
+                                   f"batch={args.batch}/GPU, " + ("pixel-in (frozen VAE encode inside the step" + (", CLIP text encoder inside" if args.text_in else ", CLIP outside") + ")"
                                                                   if args.pixel_in else "latent-in (VAE/CLIP outside the path)"),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(getattr(runner, "is_graph", False)),
                        "loss": loss_v},

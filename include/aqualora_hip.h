@@ -118,6 +118,12 @@ int aql_softmax_rows(const float* S, long lds, long M, int N, float scale, bf16_
  * dS[m,:] = scale * P[m,:] * (dP[m,:] - sum_j P[m,j] dP[m,j])                                                      */
 int aql_softmax_rows_bwd(const bf16_t* P, const bf16_t* dP, long ld, long M, int N, float scale, bf16_t* dS,
                          aql_stream_t stream);
+/* ---- CLIP text encoder pieces (transformers CLIPTextModel; text_encoder(input_ids)[0] at train/ppft_train.py:1014-1019) */
+/* CLIPMLP activation quick_gelu(x) = x * sigmoid(1.702 x); n % 8 == 0                                               */
+int aql_quick_gelu(const bf16_t* x, long n, bf16_t* y, aql_stream_t stream);
+/* causal self-attention for short sequences (N <= 128, d <= 128): q/k/v/o [B,N,H*d], softmax(scale q k^T + causal) v */
+int aql_causal_attn_small(const bf16_t* q, const bf16_t* k, const bf16_t* v, long ld, int B, int H, int N, int d,
+                          float scale, bf16_t* o, long ldo, aql_stream_t stream);
 /* DDPMScheduler.add_noise on x0 and x0+wm with shared noise/timesteps  train/ppft_train.py:1010-1011              */
 int aql_add_noise(const float* x0, const float* wm, const float* eps, const long* t, const float* alphas_cumprod, int B,
                   int per_sample, bf16_t* noisy, bf16_t* noisy_wm, aql_stream_t stream);
