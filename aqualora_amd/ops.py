@@ -640,7 +640,7 @@ class AttentionFn(torch.autograd.Function):
         B, Nq, C = q.shape
         Nk = k.shape[1]
         d = C // heads
-        o = torch.empty_like(q)
+        o = torch.empty(q.shape, dtype=q.dtype, device=q.device)   # q may be a strided view of a packed q|k|v GEMM output
         lse = torch.empty(B, heads, Nq, dtype=torch.float32, device=q.device)
         L.call("aql_sdpa_fwd", L.ptr(q), q.stride(1), L.ptr(k), k.stride(1), L.ptr(v), v.stride(1), B, heads, Nq, Nk,
                d, float(d ** -0.5), L.ptr(o), o.stride(1), L.ptr(lse), L.stream_ptr())

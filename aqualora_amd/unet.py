@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import ops, synth
-from .lora import (LoRACompatibleConv, LoRACompatibleLinear, _packed_conv3)
+from .lora import (LoRACompatibleConv, LoRACompatibleLinear, _packed_conv3, _packed_linear)
 
 SD15 = dict(in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
             cross_attention_dim=768, attention_heads=8, norm_groups=32,
@@ -131,7 +131,42 @@ class Attention(nn.Module):
         self.to_v = LoRACompatibleLinear(cross_dim, query_dim, bias=False, **kw)
         self.to_out = nn.ModuleList([LoRACompatibleLinear(query_dim, query_dim, **kw), nn.Dropout(0.0)])
 
+    def _fused_weights(self, cross):
+        """Concatenated projection weights for the LoRA-free passes: [Wq;Wk;Wv] (self-attention) or [Wk;Wv] (cross).  Rebuilt
+        whenever a projection's packed copy is replaced (weights re-initialised or a LoRA fused into them)."""
+        pks = tuple(_packed_linear(m) for m in (self.to_q, self.to_k, self.to_v))
+        c = getattr(self, "_aql_qkv", None)
+        if c is None or c[0] is not pks[0] or c[1] is not pks[1] or c[2] is not pks[2]:
+            w = torch.cat([p.w for p in (pks[1:] if cross else pks)], dim=0).contiguous()
+            c = pks + (w,)
+            object.__setattr__(self, "_aql_qkv", c)
+        return c[3]
+
+    def _forward_nolora(self, x, ctx, residual):
+        """The frozen 'clean' pass and inference (scale None, no autograd): q|k|v come from ONE GEMM (two launches fewer per
+        self-attention, one fewer per cross-attention); the attention kernels read the packed result through row strides.
+        No split-K at these depths, so every element is accumulated in the same order as by the three separate GEMMs:
+        bit-identical (tests/test_gpu_parity.py compares the two paths with torch.equal)."""
+        B, N, C = x.shape
+        x2d = x.reshape(B * N, C)
+        if ctx is None:
+            qkv = ops.gemm_bf16(x2d, self._fused_weights(False)).view(B, N, 3 * C)
+            q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        else:
+            Bc, Nc, Cc = ctx.shape
+            q = self.to_q(x, None)
+            c2d = ctx.reshape(Bc * Nc, Cc)
+            if c2d.dtype != torch.bfloat16:
+                c2d = c2d.to(torch.bfloat16)
+            kv = ops.gemm_bf16(c2d.contiguous(), self._fused_weights(True)).view(Bc, Nc, 2 * C)
+            k, v = kv[..., :C], kv[..., C:]
+        o = ops.attention(q, k, v, self.heads)
+        return self.to_out[0](o, None, residual=residual)
+
     def forward(self, hidden_states, encoder_hidden_states=None, scale=1.0, residual=None):
+        if (scale is None and not torch.is_grad_enabled() and hidden_states.dim() == 3
+                and hidden_states.dtype == torch.bfloat16 and hidden_states.is_contiguous()):
+            return self._forward_nolora(hidden_states, encoder_hidden_states, residual)
         ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
         q, k, v = ops.parallel([lambda: self.to_q(hidden_states, scale), lambda: self.to_k(ctx, scale),
                                 lambda: self.to_v(ctx, scale)])
