@@ -88,3 +88,45 @@ class BucketedAllreduce:
             if chunk is not None:
                 chunk.div_(n)
         self.pending = []
+
+
+def allreduce_module_grads_(params, group=None, bucket_bytes=64 << 20):
+    """DDP's gradient averaging for an ordinary module (the SecretDecoder in rob_enhance_finetune.py, ~26 MB of fp32
+    gradients): gradients are packed into flat buckets of at most ``bucket_bytes`` (reverse parameter order, the order in
+    which backward produces them), each bucket is mean-all-reduced asynchronously, then scattered back."""
+    if not exchange_active(group):
+        return
+    grads = [p.grad for p in reversed(list(params)) if p.grad is not None]
+    if not grads:
+        return
+    red = BucketedAllreduce(group)
+    buckets, cur, size = [], [], 0
+    for g in grads:
+        nb = g.numel() * g.element_size()
+        if cur and size + nb > bucket_bytes:
+            buckets.append(cur)
+            cur, size = [], 0
+        cur.append(g)
+        size += nb
+    buckets.append(cur)
+    flats = []
+    for b in buckets:
+        flat = torch.cat([g.reshape(-1) for g in b])
+        red.launch(flat)
+        flats.append(flat)
+    red.finish()
+    for b, flat in zip(buckets, flats):
+        off = 0
+        for g in b:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
+
+def broadcast_buffers_(module, group=None, src=0):
+    """DDP(broadcast_buffers=True): rank ``src``'s buffers (BatchNorm running statistics) overwrite everyone's before a
+    forward pass, so that the replicas stay identical."""
+    if world_size(group) <= 1:
+        return
+    for b in module.buffers():
+        if b.numel():
+            dist.broadcast(b, src=src, group=group)

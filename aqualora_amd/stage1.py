@@ -125,9 +125,13 @@ class Stage1Step:
                 "logits": reveal_output, "watermarked_image": watermarked_image}
 
 
-def rob_finetune_step(msgdecoder, optimizer, images01, secret_bits, distort=None):
+def rob_finetune_step(msgdecoder, optimizer, images01, secret_bits, distort=None, process_group=None):
     """rob_enhance_finetune.py:1018-1036: generated images in [0,1] (no grad) -> distortion -> [-1,1] -> msgdecoder ->
-    BCE against one-hot bits -> backward -> optimizer step.  Returns (loss, bit accuracy)."""
+    BCE against one-hot bits -> backward -> optimizer step.  Returns (loss, bit accuracy).  Under torch.distributed (one
+    process per GPU, the reference wraps the decoder in DDP through accelerate) rank 0's BatchNorm buffers are broadcast
+    before the forward and the gradients are mean-all-reduced over RCCL in flat buckets before the optimizer step."""
+    from . import dp
+    dp.broadcast_buffers_(msgdecoder, process_group)
     x = images01.detach().float()
     if distort is not None:
         x = distort(x)
@@ -137,6 +141,7 @@ def rob_finetune_step(msgdecoder, optimizer, images01, secret_bits, distort=None
     acc = (decoded == secret_bits.long()).float().mean()
     loss = bce_with_logits(logits.float(), torch.nn.functional.one_hot(secret_bits.long(), num_classes=2).float())
     loss.backward()
+    dp.allreduce_module_grads_(msgdecoder.parameters(), process_group)
     optimizer.step()
     optimizer.zero_grad()
     return loss.detach(), acc

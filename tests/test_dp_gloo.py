@@ -35,7 +35,21 @@ def _worker(rank, world, port, q):
         red.launch(c[lo:hi])
     red.finish()
     ok_async = torch.allclose(c, want, atol=1e-6) and dp.exchange_active() and not red.pending
-    q.put((rank, torch.allclose(a, want, atol=1e-6), torch.equal(a, b) and ok_async,
+    # DDP-style exchange for an ordinary module (the SecretDecoder of rob-finetune): bucketed flat gradient mean + buffers
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 3))
+    x = synth.normal("dp.x", (6, 7), 1.0, seed=200 + rank)
+    net(x).square().sum().backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    gathered_g = [[torch.zeros_like(g) for _ in range(world)] for g in local]
+    for g, out in zip(local, gathered_g):
+        dist.all_gather(out, g)
+    dp.allreduce_module_grads_(net.parameters(), bucket_bytes=64)      # tiny buckets: several collectives
+    ok_mod = all(torch.allclose(p.grad, sum(o) / world, atol=1e-6) for p, o in zip(net.parameters(), gathered_g))
+    net[1].running_mean.fill_(float(rank + 1))
+    dp.broadcast_buffers_(net)
+    ok_mod = ok_mod and float(net[1].running_mean[0]) == 1.0
+    q.put((rank, torch.allclose(a, want, atol=1e-6), torch.equal(a, b) and ok_async and ok_mod,
            not torch.equal(gathered[0], gathered[1])))
     dist.destroy_process_group()
 
