@@ -1053,7 +1053,7 @@ struct TnGroupDesc {
 
 // `block_base` lets a launch cover a sub-range of the table (one gradient bucket of the data-parallel exchange): descs
 // then points at the bucket's first descriptor and block_base is that descriptor's first_block.
-__global__ __launch_bounds__(NTHREADS) void gemm_tn_grouped_kernel(const TnGroupDesc* __restrict__ descs, int n,
+static __global__ __launch_bounds__(NTHREADS) void gemm_tn_grouped_kernel(const TnGroupDesc* __restrict__ descs, int n,
                                                                    int block_base) {
   const int bid = (int)blockIdx.x + block_base;
   int lo = 0, hi = n - 1;

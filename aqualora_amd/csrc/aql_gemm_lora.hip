@@ -1,0 +1,300 @@
+// Fused rank-32 watermark-LoRA linear in ONE launch (utils/lora_modules.py:9-26 + 56-62):
+//     T  = X.A^T                  (side accumulator, shares the X fragments of the main product)
+//     Ts = T * S[sample]          (bf16, like the reference's `down(x) @ diag_embed(scale)` under autocast)
+//     Y  = X.W^T + Ts.Bup^T + bias + residual
+// and, with the operands exchanged, its backward-data form  dTs = dY.Bup, dT = dTs * S, dX = dY.W + dT.A.
+//
+// Why: the two-launch form (aql_lora_down, then aql_gemm_bf16 with Ts.Bup^T as a second K segment) spends 384 launches
+// per step on the skinny T products -- each 5-9 us of ramp and drain for <= 10 MB of traffic, 3.5 ms of a 28.6 ms step by
+// removal, the largest single item -- and reads X twice.  Here the workgroup that owns output tile (m, n) also stages the
+// 32 rows of A for every K tile (4 KB per stage next to the 128x160 / 64x160 / ... operand tiles, one more LDS-DMA per
+// thread) and accumulates T[m-tile, 32] with FM extra MFMAs per k-step (+20 % on a 160-wide tile) from the activation
+// fragments it already holds.  After the K loop T is scaled, rounded to bf16, written into the idle stage-0 A tile in
+// fragment layout together with the Bup[n-tile, 32] panel, and ONE more k-step adds Ts.Bup^T into the same accumulators.
+// The n-tile-0 workgroups write T and Ts for the backward pass.  T is recomputed by every n-tile of a row block; that
+// redundancy is the 20 %.
+//
+// Same LDS-DMA ring as gemm_body_d (aql_gemm.cuh): NSTG stages, one barrier per K tile, counted vmcnt waits.  No split-K
+// (T must be complete before the up-projection): deep-K / small-grid shapes return AQL_NOT_FUSED and the caller uses the
+// two-launch path.
+#include <type_traits>
+#include "aql_gemm.cuh"
+#include <stdlib.h>
+
+using namespace aqlgemm;
+
+#define AQL_NOT_FUSED 100
+
+namespace {
+
+constexpr int LR = 32;  // LoRA rank handled here
+
+struct LoraParams {
+  const bf16_t* S;    // [nsamples][32] bf16 scale rows
+  const bf16_t* Bup;  // [N][32]
+  bf16_t* T;          // [M][32] out (unscaled)
+  bf16_t* Ts;         // [M][32] out (scaled)
+  int rps;            // rows per sample
+};
+
+template <int BM, int BN, int WM, int WN, int NSTG>
+__global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<PlainLoader, PlainLoader> g, const PlainLoader la,
+                                                             const LoraParams lp) {
+  constexpr int FM = WM / 16, FN = WN / 16;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * (BN / WN) == 4, "4 wavefronts per workgroup");
+  constexpr int FT = LR / (16 * WAVES_N);  // T fragments (16 rank columns each) per wavefront
+  static_assert(FT >= 1, "at most two wavefronts along N");
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, L_BYTES = LR * 128;
+  constexpr int STAGE = A_BYTES + B_BYTES + L_BYTES;
+  constexpr int C_PITCH = (BN + 8) * 2;
+  constexpr int LDS_BYTES = (NSTG * STAGE > BM * C_PITCH) ? NSTG * STAGE : BM * C_PITCH;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+
+  // XCD-aware remap (as gemm_kernel_d): every XCD gets a contiguous run of logical tiles
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int qq = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
+  const int block_x = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+  const int wt0 = (wave % WAVES_N) * FT;  // first T fragment of this wavefront
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+  int tile_m, tile_n;
+  if (g.m_fast) {
+    tile_n = block_x / tiles_m;
+    tile_m = block_x - tile_n * tiles_m;
+  } else {
+    tile_m = block_x / tiles_n;
+    tile_n = block_x - tile_m * tiles_n;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kt_end = g.ktiles0;
+
+  DmaStager<BM, PlainLoader> sa;
+  DmaStager<BN, PlainLoader> sb;
+  DmaStager<LR, PlainLoader> sl;
+  constexpr int NLD = BM / 32 + BN / 32 + 1;
+  sa.begin(g.a0, g.a0, false, m0, tid, 0, kt_end, kt_end);
+  sb.begin(g.b0, g.b0, false, n0, tid, 0, kt_end, kt_end);
+  sl.begin(la, la, false, 0, tid, 0, kt_end, kt_end);
+
+  f32x4_t acc[FM][FN], tacc[FM][FT];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < FT; ++t) tacc[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+
+  auto issue = [&](int stage) {
+    char* sA = lds + stage * STAGE;
+    sa.dma(sA, wave);
+    sb.dma(sA + A_BYTES, wave);
+    sl.dma(sA + A_BYTES + B_BYTES, wave);
+  };
+#pragma unroll
+  for (int u = 0; u < NSTG - 1; ++u) issue(u);
+
+  int rd = 0, wr = NSTG - 1;
+  for (int kt = 0; kt < kt_end; ++kt) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * NLD) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue(wr);
+    const char* sA = lds + rd * STAGE;
+    const char* sB = sA + A_BYTES;
+    const char* sL = sB + B_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8_t fa[FM], fb[FN], fl[FT];
+      const int chunk = ks * 4 + (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+        fa[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(wm0 + i * 16 + (lane & 15), chunk));
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        fb[j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(wn0 + j * 16 + (lane & 15), chunk));
+#pragma unroll
+      for (int t = 0; t < FT; ++t)
+        fl[t] = *reinterpret_cast<const bf16x8_t*>(sL + lds_off((wt0 + t) * 16 + (lane & 15), chunk));
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < FT; ++t) tacc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[t], fa[i], tacc[i][t], 0, 0, 0);
+      }
+    }
+    rd = (rd + 1 == NSTG) ? 0 : rd + 1;
+    wr = (wr + 1 == NSTG) ? 0 : wr + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing zero-fill DMAs still write LDS
+  __syncthreads();
+
+  // ---- T -> (T, Ts) bf16; Ts into the stage-0 A tile (fragment layout), the Bup panel into the stage-0 B tile
+  // tacc[i][t][e]: row m = m0 + wm0 + 16 i + (lane & 15), rank column r = 16 (wt0 + t) + 4 (lane >> 4) + e
+  char* sA = lds;
+  char* sB = lds + A_BYTES;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int row = wm0 + i * 16 + (lane & 15);
+    const long m = (long)m0 + row;
+    const bool ok = m < g.M;
+#pragma unroll
+    for (int t = 0; t < FT; ++t) {
+      const int r = (wt0 + t) * 16 + (lane >> 4) * 4;
+      const uint2 tv = make_uint2(pack_bf16x2(tacc[i][t][0], tacc[i][t][1]), pack_bf16x2(tacc[i][t][2], tacc[i][t][3]));
+      uint2 sv = make_uint2(0u, 0u);
+      if (ok) sv = *reinterpret_cast<const uint2*>(lp.S + (m / lp.rps) * LR + r);
+      const uint2 ts = make_uint2(pack_bf16x2(bf16lo(tv.x) * bf16lo(sv.x), bf16hi(tv.x) * bf16hi(sv.x)),
+                                  pack_bf16x2(bf16lo(tv.y) * bf16lo(sv.y), bf16hi(tv.y) * bf16hi(sv.y)));
+      *reinterpret_cast<uint2*>(sA + lds_off(row, r >> 3) + (r & 7) * 2) = ts;
+      if (ok && tile_n == 0) {
+        *reinterpret_cast<uint2*>(lp.T + m * LR + r) = tv;
+        *reinterpret_cast<uint2*>(lp.Ts + m * LR + r) = ts;
+      }
+    }
+  }
+  for (int id = tid; id < BN * 4; id += NTHREADS) {
+    const int row = id >> 2, c = id & 3;
+    uint4 v = zero4();
+    if (n0 + row < g.N) v = *reinterpret_cast<const uint4*>(lp.Bup + (long)(n0 + row) * LR + c * 8);
+    *reinterpret_cast<uint4*>(sB + lds_off(row, c)) = v;
+  }
+  __syncthreads();
+  {
+    bf16x8_t fa[FM], fb[FN];
+    const int chunk = lane >> 4;  // the 32 rank columns are k-step 0 of the tile
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+      fa[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(wm0 + i * 16 + (lane & 15), chunk));
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+      fb[j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(wn0 + j * 16 + (lane & 15), chunk));
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+  }
+  __syncthreads();
+
+  // ---- epilogue (as gemm_body_d, EPI_BF16): bias in fp32, C tile staged through LDS, residual added in bf16
+  const EpiParams& ep = g.epi;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int row = wm0 + i * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int col = wn0 + j * 16 + (lane >> 4) * 4;
+      float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+      if (ep.bias != nullptr && (n0 + col) < g.N) {
+        const uint2 bb = *reinterpret_cast<const uint2*>(ep.bias + n0 + col);
+        v0 += bf16lo(bb.x);
+        v1 += bf16hi(bb.x);
+        v2 += bf16lo(bb.y);
+        v3 += bf16hi(bb.y);
+      }
+      *reinterpret_cast<uint2*>(lds + row * C_PITCH + col * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+    }
+  }
+  __syncthreads();
+  constexpr int CPR = BN / 8;
+  for (int id = tid; id < BM * CPR; id += NTHREADS) {
+    const int row = id / CPR, cc = id - row * CPR;
+    const int m = m0 + row, n = n0 + cc * 8;
+    if (m >= g.M || n >= g.N) continue;
+    uint4 v = *reinterpret_cast<const uint4*>(lds + row * C_PITCH + cc * 16);
+    if (ep.residual != nullptr) {
+      const uint4 r = *reinterpret_cast<const uint4*>(ep.residual + (long)m * ep.ldr + n);
+      v.x = pack_bf16x2(bf16lo(v.x) + bf16lo(r.x), bf16hi(v.x) + bf16hi(r.x));
+      v.y = pack_bf16x2(bf16lo(v.y) + bf16lo(r.y), bf16hi(v.y) + bf16hi(r.y));
+      v.z = pack_bf16x2(bf16lo(v.z) + bf16lo(r.z), bf16hi(v.z) + bf16hi(r.z));
+      v.w = pack_bf16x2(bf16lo(v.w) + bf16lo(r.w), bf16hi(v.w) + bf16hi(r.w));
+    }
+    *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + n) = v;
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int NSTG>
+void launch(const GemmArgs<PlainLoader, PlainLoader>& g, const PlainLoader& la, const LoraParams& lp, hipStream_t stream) {
+  dim3 grid(aql_cdiv(g.M, BM) * aql_cdiv(g.N, BN));
+  hipLaunchKernelGGL((lora_gemm_kernel<BM, BN, WM, WN, NSTG>), grid, dim3(NTHREADS), 0, stream, g, la, lp);
+}
+
+inline PlainLoader plain(const bf16_t* p, long ld, long rows, int K) {
+  PlainLoader l;
+  l.base = p;
+  l.ld = ld;
+  l.rows = (int)rows;
+  l.K = K;
+  return l;
+}
+
+}  // namespace
+
+// Y[M,N] = X[M,K].W[N,K]^T + ((X.A[32,K]^T) * S[m / rps]).Bup[N,32]^T + bias + residual;  T, Ts [M,32] are written too.
+// Returns AQL_OK, an error, or AQL_NOT_FUSED (100) when the shape belongs on the two-launch path (deep K on a small grid:
+// split-K; N <= 32).
+extern "C" int aql_lora_gemm_fused(const bf16_t* X, long ldx, const bf16_t* W, long ldw, long M, int N, int K,
+                                   const bf16_t* Adown, const bf16_t* S, int rows_per_sample, const bf16_t* Bup,
+                                   const bf16_t* bias, const bf16_t* residual, long ldr, bf16_t* Y, long ldy, bf16_t* T,
+                                   bf16_t* Ts, hipStream_t stream) {
+  AQL_CHECK_ARG(X && W && Adown && S && Bup && Y && T && Ts, "aql_lora_gemm_fused: null operand");
+  AQL_CHECK_ARG(M > 0 && M < (1L << 31) && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 &&
+                    ldy % 8 == 0 && rows_per_sample > 0 && (residual == nullptr || ldr % 8 == 0),
+                "aql_lora_gemm_fused: bad shape M=%ld N=%d K=%d", M, N, K);
+  if (N <= 32) return AQL_NOT_FUSED;
+  const int kt = aql_cdiv(K, BK);
+  GemmArgs<PlainLoader, PlainLoader> g;
+  g.a0 = plain(X, ldx, M, K);
+  g.b0 = plain(W, ldw, N, K);
+  g.a1 = g.a0;
+  g.b1 = g.b0;
+  g.ktiles0 = kt;
+  g.ktiles1 = 0;
+  g.M = (int)M;
+  g.N = N;
+  g.splits = 1;
+  g.m_fast = ((long)N * kt > (long)M * (kt < 9 ? kt : kt / 9 + 1)) ? 1 : 0;
+  g.epi = EpiParams{};
+  g.epi.C = Y;
+  g.epi.ldc = ldy;
+  g.epi.bias = bias;
+  g.epi.residual = residual;
+  g.epi.ldr = ldr;
+  g.epi.rows_per_sample = rows_per_sample;
+  const PlainLoader la = plain(Adown, K, LR, K);
+  LoraParams lp{S, Bup, T, Ts, rows_per_sample};
+  static const int deep_kt = getenv("AQL_DEEPKT") ? atoi(getenv("AQL_DEEPKT")) : 32;
+  // tile choice: the largest 160-wide (or square) tile that still gives about one workgroup per CU
+  if (N % 160 == 0) {
+    const int nt = N / 160;
+    const int t128 = aql_cdiv(M, 128) * nt, t64 = aql_cdiv(M, 64) * nt, t32 = aql_cdiv(M, 32) * nt;
+    const int tiles = t128 >= 448 ? t128 : t64 >= 200 ? t64 : t32;
+    if (tiles < 224 && kt >= deep_kt) return AQL_NOT_FUSED;  // the two-launch path would split K here
+    if (t128 >= 448) {
+      launch<128, 160, 64, 80, 2>(g, la, lp, stream);
+    } else if (t64 >= 200) {
+      if (t64 <= 288) launch<64, 160, 32, 80, 4>(g, la, lp, stream);
+      else launch<64, 160, 32, 80, 2>(g, la, lp, stream);
+    } else {
+      if (t32 <= 288) launch<32, 160, 16, 80, 5>(g, la, lp, stream);
+      else launch<32, 160, 16, 80, 2>(g, la, lp, stream);
+    }
+  } else {
+    const int t128 = aql_cdiv(M, 128) * aql_cdiv(N, 128), t64 = aql_cdiv(M, 64) * aql_cdiv(N, 64);
+    const int tiles = t128 >= 240 ? t128 : t64;
+    if (tiles < 224 && kt >= deep_kt) return AQL_NOT_FUSED;
+    if (t128 >= 240) {
+      launch<128, 128, 64, 64, 2>(g, la, lp, stream);
+    } else {
+      if (t64 <= 288) launch<64, 64, 32, 32, 6>(g, la, lp, stream);
+      else launch<64, 64, 32, 32, 2>(g, la, lp, stream);
+    }
+  }
+  AQL_CHECK_LAUNCH("aql_lora_gemm_fused");
+  return AQL_OK;
+}

@@ -386,6 +386,23 @@ DEFERRED = None  # set by a trainer around backward (ppft.PPFTTrainer); None => 
 
 
 # ------------------------------------------------------------------------------------ fused LoRA linear
+def _lora_gemm_fused(x2d, w, a16, S16, rps, b16, bias, residual, T, Ts):
+    """One-launch rank-32 LoRA linear (aql_lora_gemm_fused).  Returns Y, or None when the shape belongs on the two-launch
+    path (rank != 32, split-K shapes, narrow outputs; AQL_LORA_FUSED=0 disables it for comparison)."""
+    if a16.shape[0] != 32 or os.environ.get("AQL_LORA_FUSED", "1") == "0":
+        return None
+    M, K = x2d.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=x2d.device)
+    rc = L.call_raw("aql_lora_gemm_fused", L.ptr(x2d), x2d.stride(0), L.ptr(w), w.stride(0), M, N, K, L.ptr(a16), L.ptr(S16),
+                    rps, L.ptr(b16), L.ptr(bias), L.ptr(residual), 0 if residual is None else residual.stride(0), L.ptr(y),
+                    y.stride(0), L.ptr(T), L.ptr(Ts), L.stream_ptr())
+    if rc == 100:
+        return None
+    L.check(rc, "aql_lora_gemm_fused")
+    return y
+
+
 class LoraLinearFn(torch.autograd.Function):
     """Y = X.W^T + b [+ ((X.A^T) * S[sample]).Bup^T] [+ residual]   on token-major X [M,K].
 
@@ -408,11 +425,13 @@ class LoraLinearFn(torch.autograd.Function):
             r = site.rank
             T = torch.empty(M, r, dtype=torch.bfloat16, device=x2d.device)
             Ts = torch.empty_like(T)
-            L.call("aql_lora_down", L.ptr(x2d), x2d.stride(0), M, packed.K, L.ptr(site.a16), r, L.ptr(S16), rps,
-                   L.ptr(T), L.ptr(Ts), None, None, L.stream_ptr())
             # trainers can hand in one persistent fp32 accumulator for dS (shared by all 192 sites)
             ctx.ds_accum = getattr(S, "_aql_ds_accum", None)
-            y = gemm_bf16(x2d, packed.w, packed.bias, Ts, site.b16, residual=residual)
+            y = _lora_gemm_fused(x2d, packed.w, site.a16, S16, rps, site.b16, packed.bias, residual, T, Ts)
+            if y is None:   # two-launch form: skinny T product, then the GEMM with Ts.Bup^T as a second K segment
+                L.call("aql_lora_down", L.ptr(x2d), x2d.stride(0), M, packed.K, L.ptr(site.a16), r, L.ptr(S16), rps,
+                       L.ptr(T), L.ptr(Ts), None, None, L.stream_ptr())
+                y = gemm_bf16(x2d, packed.w, packed.bias, Ts, site.b16, residual=residual)
             ctx.save_for_backward(x2d, T, Ts, S16)
         else:
             y = gemm_bf16(x2d, packed.w, packed.bias, residual=residual)
@@ -439,12 +458,19 @@ class LoraLinearFn(torch.autograd.Function):
             dfr = DEFERRED
             ds_target = acc if acc is not None else dS
             ds_deferred = want_ds and dfr is not None and acc is not None
-            L.call("aql_lora_down", L.ptr(dy), dy.stride(0), M, packed.N, L.ptr(site.bt16), r, L.ptr(S16), ctx.rps,
-                   L.ptr(dTs), L.ptr(dT), L.ptr(T) if (want_ds and not ds_deferred) else None,
-                   L.ptr(ds_target) if (want_ds and not ds_deferred) else None, L.stream_ptr())
+            dx = None
+            if ctx.needs_input_grad[0]:   # dTs = dY.Bup, dT = dTs * S, dX = dY.W + dT.A in one launch
+                dx = _lora_gemm_fused(dy, packed.wt, site.bt16, S16, ctx.rps, site.at16, None, None, dTs, dT)
+            if dx is not None:
+                if want_ds and not ds_deferred:
+                    L.call("aql_lora_ds", L.ptr(dTs), L.ptr(T), nb, ctx.rps, r, L.ptr(ds_target), L.stream_ptr())
+            else:
+                L.call("aql_lora_down", L.ptr(dy), dy.stride(0), M, packed.N, L.ptr(site.bt16), r, L.ptr(S16), ctx.rps,
+                       L.ptr(dTs), L.ptr(dT), L.ptr(T) if (want_ds and not ds_deferred) else None,
+                       L.ptr(ds_target) if (want_ds and not ds_deferred) else None, L.stream_ptr())
+                dx = gemm_bf16(dy, packed.wt, None, dT, site.at16) if ctx.needs_input_grad[0] else None
             if ds_deferred and not dfr.add_ds(dTs, T, ds_target, nb, ctx.rps, r):
                 L.call("aql_lora_ds", L.ptr(dTs), L.ptr(T), nb, ctx.rps, r, L.ptr(ds_target), L.stream_ptr())
-            dx = gemm_bf16(dy, packed.wt, None, dT, site.at16) if ctx.needs_input_grad[0] else None
             # dBup[N,r] += dY^T Ts ; dA[r,K] += dT^T X   (grouped at the end of backward when a trainer defers them)
             if dfr is None or not dfr.add_tn(dy, Ts, site.gb):
                 gemm_tn_acc(dy, Ts, site.gb)

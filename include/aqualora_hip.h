@@ -52,6 +52,14 @@ int aql_conv3x3_fwd(const bf16_t* X, int B, int Hin, int Win, int Cin, const bf1
 int aql_conv3x3_fwd_pad(const bf16_t* X, int B, int Hin, int Win, int Cin, const bf16_t* Wk, const bf16_t* bias, int Cout,
                         int stride, int upsample, int pad_lo, const bf16_t* rowbias, long rowbias_ld,
                         const bf16_t* residual, bf16_t* Y, float* ws, size_t ws_bytes, aql_stream_t stream);
+/* ONE launch for the whole rank-32 LoRA linear (lora_modules.py:9-26 + 56-62):
+ *   T = X.A^T, Ts = T * S[m / rows_per_sample], Y = X.W^T + Ts.Bup^T + bias + residual      (A [32,K], Bup [N,32])
+ * T, Ts [M,32] are written for the backward pass.  With (X, W, A, Bup) := (dY, W^T, Bup^T, A^T) it is the backward-data
+ * form dTs = dY.Bup, dT = dTs * S, dX = dY.W + dT.A.  Returns 100 (not an error) when the shape belongs on the two-launch
+ * path aql_lora_down + aql_gemm_bf16 (split-K shapes, N <= 32).                                                      */
+int aql_lora_gemm_fused(const bf16_t* X, long ldx, const bf16_t* W, long ldw, long M, int N, int K, const bf16_t* Adown,
+                        const bf16_t* S, int rows_per_sample, const bf16_t* Bup, const bf16_t* bias,
+                        const bf16_t* residual, long ldr, bf16_t* Y, long ldy, bf16_t* T, bf16_t* Ts, aql_stream_t stream);
 int aql_conv3x3_bwd_data(const bf16_t* dY, int B, int Hin, int Win, int Cin, const bf16_t* Wt, int Cout, int stride,
                          bf16_t* dX, float* ws, size_t ws_bytes, aql_stream_t stream);
 
