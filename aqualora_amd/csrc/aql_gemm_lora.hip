@@ -89,6 +89,27 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
     for (int t = 0; t < FT; ++t) tacc[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
 
+  // the up-projection panel Bup[n-tile, 32] and this lane's scale rows are fetched now, so that their latency hides under
+  // the K loop instead of sitting between the loop and the final k-step
+  constexpr int NBP = (BN * 4 + NTHREADS - 1) / NTHREADS;
+  uint4 bup[NBP];
+#pragma unroll
+  for (int u = 0; u < NBP; ++u) {
+    const int id = tid + u * NTHREADS, row = id >> 2, c = id & 3;
+    bup[u] = zero4();
+    if (id < BN * 4 && n0 + row < g.N) bup[u] = *reinterpret_cast<const uint4*>(lp.Bup + (long)(n0 + row) * LR + c * 8);
+  }
+  uint2 srow[FM][FT];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const long m = (long)m0 + wm0 + i * 16 + (lane & 15);
+#pragma unroll
+    for (int t = 0; t < FT; ++t) {
+      srow[i][t] = make_uint2(0u, 0u);
+      if (m < g.M) srow[i][t] = *reinterpret_cast<const uint2*>(lp.S + (m / lp.rps) * LR + (wt0 + t) * 16 + (lane >> 4) * 4);
+    }
+  }
+
   auto issue = [&](int stage) {
     char* sA = lds + stage * STAGE;
     sa.dma(sA, wave);
@@ -147,8 +168,7 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
     for (int t = 0; t < FT; ++t) {
       const int r = (wt0 + t) * 16 + (lane >> 4) * 4;
       const uint2 tv = make_uint2(pack_bf16x2(tacc[i][t][0], tacc[i][t][1]), pack_bf16x2(tacc[i][t][2], tacc[i][t][3]));
-      uint2 sv = make_uint2(0u, 0u);
-      if (ok) sv = *reinterpret_cast<const uint2*>(lp.S + (m / lp.rps) * LR + r);
+      const uint2 sv = srow[i][t];
       const uint2 ts = make_uint2(pack_bf16x2(bf16lo(tv.x) * bf16lo(sv.x), bf16hi(tv.x) * bf16hi(sv.x)),
                                   pack_bf16x2(bf16lo(tv.y) * bf16lo(sv.y), bf16hi(tv.y) * bf16hi(sv.y)));
       *reinterpret_cast<uint2*>(sA + lds_off(row, r >> 3) + (r & 7) * 2) = ts;
@@ -158,11 +178,10 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
       }
     }
   }
-  for (int id = tid; id < BN * 4; id += NTHREADS) {
-    const int row = id >> 2, c = id & 3;
-    uint4 v = zero4();
-    if (n0 + row < g.N) v = *reinterpret_cast<const uint4*>(lp.Bup + (long)(n0 + row) * LR + c * 8);
-    *reinterpret_cast<uint4*>(sB + lds_off(row, c)) = v;
+#pragma unroll
+  for (int u = 0; u < NBP; ++u) {
+    const int id = tid + u * NTHREADS, row = id >> 2, c = id & 3;
+    if (id < BN * 4) *reinterpret_cast<uint4*>(sB + lds_off(row, c)) = bup[u];
   }
   __syncthreads();
   {
@@ -248,6 +267,12 @@ extern "C" int aql_lora_gemm_fused(const bf16_t* X, long ldx, const bf16_t* W, l
                 "aql_lora_gemm_fused: bad shape M=%ld N=%d K=%d", M, N, K);
   if (N <= 32) return AQL_NOT_FUSED;
   const int kt = aql_cdiv(K, BK);
+  // Short K under a very wide N (ff.net.0 at the 64x64 / 32x32 levels: 320 -> 2560, 640 -> 5120): 16-32 column tiles each
+  // recompute T for a 5-10 tile K loop, and in isolation the two-launch form is faster there (58.3 vs 66.9 us, 50.0 vs
+  // 51.2 us, tools/tune_lora_gemm.py) -- but inside the step the saved launch still wins (27.65 vs 27.9 ms/step measured
+  // on one box), so they are fused too; AQL_LORA_WIDE=0 restores the exclusion.
+  static const int wide_ok = getenv("AQL_LORA_WIDE") ? atoi(getenv("AQL_LORA_WIDE")) : 1;  // tuning hook
+  if (!wide_ok && kt <= 10 && N >= 2560) return AQL_NOT_FUSED;
   GemmArgs<PlainLoader, PlainLoader> g;
   g.a0 = plain(X, ldx, M, K);
   g.b0 = plain(W, ldw, N, K);
@@ -269,16 +294,18 @@ extern "C" int aql_lora_gemm_fused(const bf16_t* X, long ldx, const bf16_t* W, l
   const PlainLoader la = plain(Adown, K, LR, K);
   LoraParams lp{S, Bup, T, Ts, rows_per_sample};
   static const int deep_kt = getenv("AQL_DEEPKT") ? atoi(getenv("AQL_DEEPKT")) : 32;
+  static const int force_bm = getenv("AQL_LORA_BM") ? atoi(getenv("AQL_LORA_BM")) : 0;  // tuning hook (160-wide tiles)
   // tile choice: the largest 160-wide (or square) tile that still gives about one workgroup per CU
   if (N % 160 == 0) {
     const int nt = N / 160;
     const int t128 = aql_cdiv(M, 128) * nt, t64 = aql_cdiv(M, 64) * nt, t32 = aql_cdiv(M, 32) * nt;
     const int tiles = t128 >= 448 ? t128 : t64 >= 200 ? t64 : t32;
     if (tiles < 224 && kt >= deep_kt) return AQL_NOT_FUSED;  // the two-launch path would split K here
-    if (t128 >= 448) {
-      launch<128, 160, 64, 80, 2>(g, la, lp, stream);
-    } else if (t64 >= 200) {
-      if (t64 <= 288) launch<64, 160, 32, 80, 4>(g, la, lp, stream);
+    if (force_bm == 128 || (force_bm == 0 && t128 >= 448)) {
+      if (t128 <= 288) launch<128, 160, 64, 80, 3>(g, la, lp, stream);
+      else launch<128, 160, 64, 80, 2>(g, la, lp, stream);
+    } else if (force_bm == 64 || (force_bm == 0 && t64 >= 200)) {
+      if (t64 <= 288) launch<64, 160, 32, 80, 5>(g, la, lp, stream);
       else launch<64, 160, 32, 80, 2>(g, la, lp, stream);
     } else {
       if (t32 <= 288) launch<32, 160, 16, 80, 5>(g, la, lp, stream);
