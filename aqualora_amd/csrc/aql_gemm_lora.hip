@@ -237,6 +237,249 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
   }
 }
 
+// Wave-specialised form (as gemm_kernel_w in aql_gemm.cuh): 512 threads, wavefronts 4-7 only issue the LDS-DMA loads
+// (X tile, W tile and the 32 rows of A), wavefronts 0-3 only read fragments and issue MFMAs, with the fragments of the next
+// k-half fetched under the current MFMA batch.  Used when the grid is about one workgroup per CU and K >= 8 tiles; on the
+// plain GEMM that form measured 16-18 % faster than the 4-wave kernel on exactly the shapes the LoRA linears have
+// (1024x1280x1280: 12.7 vs 15.4 us, 4096x640x640: 12.9 vs 15.3 us).
+template <int BM, int BN, int WM, int WN, int NSTG>
+__global__ __launch_bounds__(2 * NTHREADS) void lora_gemm_kernel_w(const GemmArgs<PlainLoader, PlainLoader> g,
+                                                                   const PlainLoader la, const LoraParams lp) {
+  constexpr int FM = WM / 16, FN = WN / 16;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * (BN / WN) == 4, "4 compute wavefronts (+ 4 loader wavefronts) per workgroup");
+  constexpr int FT = LR / (16 * WAVES_N);
+  static_assert(FT >= 1 && NSTG >= 3, "ring of >= 3 stages");
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, L_BYTES = LR * 128;
+  constexpr int STAGE = A_BYTES + B_BYTES + L_BYTES;
+  constexpr int C_PITCH = (BN + 8) * 2;
+  constexpr int LDS_BYTES = (NSTG * STAGE > BM * C_PITCH) ? NSTG * STAGE : BM * C_PITCH;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int qq = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
+  const int block_x = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= 4;
+  const int ltid = tid & 255;
+  const int wm0 = ((wave & 3) / WAVES_N) * WM, wn0 = ((wave & 3) % WAVES_N) * WN;
+  const int wt0 = ((wave & 3) % WAVES_N) * FT;
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+  int tile_m, tile_n;
+  if (g.m_fast) {
+    tile_n = block_x / tiles_m;
+    tile_m = block_x - tile_n * tiles_m;
+  } else {
+    tile_m = block_x / tiles_n;
+    tile_n = block_x - tile_m * tiles_n;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kt_end = g.ktiles0;
+  constexpr int NLD = BM / 32 + BN / 32 + 1;
+
+  f32x4_t acc[FM][FN], tacc[FM][FT];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < FT; ++t) tacc[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  constexpr int NBP = (BN * 4 + NTHREADS - 1) / NTHREADS;
+  uint4 bup[NBP];          // loader wavefronts: the Bup panel, fetched before the K loop
+  uint2 srow[FM][FT];      // compute wavefronts: this lane's scale rows
+
+  if (loader) {
+#pragma unroll
+    for (int u = 0; u < NBP; ++u) {
+      const int id = ltid + u * NTHREADS, row = id >> 2, c = id & 3;
+      bup[u] = zero4();
+      if (id < BN * 4 && n0 + row < g.N) bup[u] = *reinterpret_cast<const uint4*>(lp.Bup + (long)(n0 + row) * LR + c * 8);
+    }
+    DmaStager<BM, PlainLoader> sa;
+    DmaStager<BN, PlainLoader> sb;
+    DmaStager<LR, PlainLoader> sl;
+    sa.begin(g.a0, g.a0, false, m0, ltid, 0, kt_end, kt_end);
+    sb.begin(g.b0, g.b0, false, n0, ltid, 0, kt_end, kt_end);
+    sl.begin(la, la, false, 0, ltid, 0, kt_end, kt_end);
+    auto issue = [&](int stage) {
+      char* sA = lds + stage * STAGE;
+      sa.dma(sA, wave - 4);
+      sb.dma(sA + A_BYTES, wave - 4);
+      sl.dma(sA + A_BYTES + B_BYTES, wave - 4);
+    };
+#pragma unroll
+    for (int u = 0; u < NSTG - 1; ++u) issue(u);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * NLD) : "memory");  // first tile landed (the Bup loads are older)
+    __builtin_amdgcn_s_barrier();
+    int wr = NSTG - 1;
+    for (int kt = 0; kt < kt_end; ++kt) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 3) * NLD) : "memory");  // tile kt+1 landed
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue(wr);
+      wr = (wr + 1 == NSTG) ? 0 : wr + 1;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const long m = (long)m0 + wm0 + i * 16 + (lane & 15);
+#pragma unroll
+      for (int t = 0; t < FT; ++t) {
+        srow[i][t] = make_uint2(0u, 0u);
+        if (m < g.M) srow[i][t] = *reinterpret_cast<const uint2*>(lp.S + (m / lp.rps) * LR + (wt0 + t) * 16 + (lane >> 4) * 4);
+      }
+    }
+    const int arow = wm0 + (lane & 15), brow = wn0 + (lane & 15), lrow = wt0 * 16 + (lane & 15);
+    const int ch0 = lane >> 4, ch1 = 4 + (lane >> 4);
+    bf16x8_t fa0[FM], fb0[FN], fl0[FT], fa1[FM], fb1[FN], fl1[FT];
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < FN; ++j) fb0[j] = *reinterpret_cast<const bf16x8_t*>(lds + A_BYTES + lds_off(brow + j * 16, ch0));
+#pragma unroll
+    for (int t = 0; t < FT; ++t) fl0[t] = *reinterpret_cast<const bf16x8_t*>(lds + A_BYTES + B_BYTES + lds_off(lrow + t * 16, ch0));
+#pragma unroll
+    for (int i = 0; i < FM; ++i) fa0[i] = *reinterpret_cast<const bf16x8_t*>(lds + lds_off(arow + i * 16, ch0));
+    int rd = 0;
+    for (int kt = 0; kt < kt_end; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char* sA = lds + rd * STAGE;
+      const char* sB = sA + A_BYTES;
+      const char* sL = sB + B_BYTES;
+      rd = (rd + 1 == NSTG) ? 0 : rd + 1;
+      const char* nA = lds + rd * STAGE;
+      const char* nB = nA + A_BYTES;
+      const char* nL = nB + B_BYTES;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) fb1[j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(brow + j * 16, ch1));
+#pragma unroll
+      for (int t = 0; t < FT; ++t) fl1[t] = *reinterpret_cast<const bf16x8_t*>(sL + lds_off(lrow + t * 16, ch1));
+#pragma unroll
+      for (int i = 0; i < FM; ++i) fa1[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(arow + i * 16, ch1));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < FT; ++t) tacc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl0[t], fa0[i], tacc[i][t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) fb0[j] = *reinterpret_cast<const bf16x8_t*>(nB + lds_off(brow + j * 16, ch0));
+#pragma unroll
+      for (int t = 0; t < FT; ++t) fl0[t] = *reinterpret_cast<const bf16x8_t*>(nL + lds_off(lrow + t * 16, ch0));
+#pragma unroll
+      for (int i = 0; i < FM; ++i) fa0[i] = *reinterpret_cast<const bf16x8_t*>(nA + lds_off(arow + i * 16, ch0));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < FT; ++t) tacc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl1[t], fa1[i], tacc[i][t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  char* sA = lds;
+  char* sB = lds + A_BYTES;
+  if (loader) {
+#pragma unroll
+    for (int u = 0; u < NBP; ++u) {
+      const int id = ltid + u * NTHREADS, row = id >> 2, c = id & 3;
+      if (id < BN * 4) *reinterpret_cast<uint4*>(sB + lds_off(row, c)) = bup[u];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int row = wm0 + i * 16 + (lane & 15);
+      const long m = (long)m0 + row;
+      const bool ok = m < g.M;
+#pragma unroll
+      for (int t = 0; t < FT; ++t) {
+        const int r = (wt0 + t) * 16 + (lane >> 4) * 4;
+        const uint2 tv = make_uint2(pack_bf16x2(tacc[i][t][0], tacc[i][t][1]), pack_bf16x2(tacc[i][t][2], tacc[i][t][3]));
+        const uint2 sv = srow[i][t];
+        const uint2 ts = make_uint2(pack_bf16x2(bf16lo(tv.x) * bf16lo(sv.x), bf16hi(tv.x) * bf16hi(sv.x)),
+                                    pack_bf16x2(bf16lo(tv.y) * bf16lo(sv.y), bf16hi(tv.y) * bf16hi(sv.y)));
+        *reinterpret_cast<uint2*>(sA + lds_off(row, r >> 3) + (r & 7) * 2) = ts;
+        if (ok && tile_n == 0) {
+          *reinterpret_cast<uint2*>(lp.T + m * LR + r) = tv;
+          *reinterpret_cast<uint2*>(lp.Ts + m * LR + r) = ts;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (!loader) {
+    bf16x8_t fa[FM], fb[FN];
+    const int chunk = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+      fa[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(wm0 + i * 16 + (lane & 15), chunk));
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+      fb[j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(wn0 + j * 16 + (lane & 15), chunk));
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+  }
+  __syncthreads();
+
+  const EpiParams& ep = g.epi;
+  if (!loader) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int row = wm0 + i * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int col = wn0 + j * 16 + (lane >> 4) * 4;
+        float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+        if (ep.bias != nullptr && (n0 + col) < g.N) {
+          const uint2 bb = *reinterpret_cast<const uint2*>(ep.bias + n0 + col);
+          v0 += bf16lo(bb.x);
+          v1 += bf16hi(bb.x);
+          v2 += bf16lo(bb.y);
+          v3 += bf16hi(bb.y);
+        }
+        *reinterpret_cast<uint2*>(lds + row * C_PITCH + col * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int CPR = BN / 8;
+  for (int id = tid; id < BM * CPR; id += 2 * NTHREADS) {
+    const int row = id / CPR, cc = id - row * CPR;
+    const int m = m0 + row, n = n0 + cc * 8;
+    if (m >= g.M || n >= g.N) continue;
+    uint4 v = *reinterpret_cast<const uint4*>(lds + row * C_PITCH + cc * 16);
+    if (ep.residual != nullptr) {
+      const uint4 r = *reinterpret_cast<const uint4*>(ep.residual + (long)m * ep.ldr + n);
+      v.x = pack_bf16x2(bf16lo(v.x) + bf16lo(r.x), bf16hi(v.x) + bf16hi(r.x));
+      v.y = pack_bf16x2(bf16lo(v.y) + bf16lo(r.y), bf16hi(v.y) + bf16hi(r.y));
+      v.z = pack_bf16x2(bf16lo(v.z) + bf16lo(r.z), bf16hi(v.z) + bf16hi(r.z));
+      v.w = pack_bf16x2(bf16lo(v.w) + bf16lo(r.w), bf16hi(v.w) + bf16hi(r.w));
+    }
+    *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + n) = v;
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int NSTG>
+void launch_w(const GemmArgs<PlainLoader, PlainLoader>& g, const PlainLoader& la, const LoraParams& lp, hipStream_t stream) {
+  dim3 grid(aql_cdiv(g.M, BM) * aql_cdiv(g.N, BN));
+  hipLaunchKernelGGL((lora_gemm_kernel_w<BM, BN, WM, WN, NSTG>), grid, dim3(2 * NTHREADS), 0, stream, g, la, lp);
+}
+
 template <int BM, int BN, int WM, int WN, int NSTG>
 void launch(const GemmArgs<PlainLoader, PlainLoader>& g, const PlainLoader& la, const LoraParams& lp, hipStream_t stream) {
   dim3 grid(aql_cdiv(g.M, BM) * aql_cdiv(g.N, BN));
@@ -301,6 +544,14 @@ extern "C" int aql_lora_gemm_fused(const bf16_t* X, long ldx, const bf16_t* W, l
     const int t128 = aql_cdiv(M, 128) * nt, t64 = aql_cdiv(M, 64) * nt, t32 = aql_cdiv(M, 32) * nt;
     const int tiles = t128 >= 448 ? t128 : t64 >= 200 ? t64 : t32;
     if (tiles < 224 && kt >= deep_kt) return AQL_NOT_FUSED;  // the two-launch path would split K here
+    static const int use_w = getenv("AQL_LORA_W") ? atoi(getenv("AQL_LORA_W")) : 1;
+    // wave-specialised kernels: ONE chip-wide round of 8-wave workgroups (two rounds of the 128-row tile measured slower than
+    // the 4-wave kernel: 52.2 vs 40.9 us at 1024x10240x1280)
+    if (use_w && kt >= 8 && force_bm == 0) {
+      if (t128 >= 240 && t128 <= 288) { launch_w<128, 160, 64, 80, 3>(g, la, lp, stream); AQL_CHECK_LAUNCH("aql_lora_gemm_fused"); return AQL_OK; }
+      if (t128 < 240 && t64 >= 240 && t64 <= 512) { launch_w<64, 160, 32, 80, 4>(g, la, lp, stream); AQL_CHECK_LAUNCH("aql_lora_gemm_fused"); return AQL_OK; }
+      if (t64 < 240 && t32 >= 240 && t32 <= 512) { launch_w<32, 160, 16, 80, 5>(g, la, lp, stream); AQL_CHECK_LAUNCH("aql_lora_gemm_fused"); return AQL_OK; }
+    }
     if (force_bm == 128 || (force_bm == 0 && t128 >= 448)) {
       if (t128 <= 288) launch<128, 160, 64, 80, 3>(g, la, lp, stream);
       else launch<128, 160, 64, 80, 2>(g, la, lp, stream);
