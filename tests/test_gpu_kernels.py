@@ -37,3 +37,9 @@ def test_transpose_read_weight_gradient_gemm():
     operands) against fp32 torch."""
     text = _run("probe_tntr.py")
     assert text.count("PASS") >= 25
+
+
+def test_one_launch_lora_linear():
+    """aql_lora_gemm_fused (T side accumulator + up-projection k-step, 4-wave and wave-specialised kernels) vs fp32 torch."""
+    text = _run("probe_lora_gemm.py")
+    assert text.count("PASS") >= 13

@@ -1,0 +1,46 @@
+"""Parity of the one-launch rank-32 LoRA linear (aql_lora_gemm_fused: 4-wave and wave-specialised kernels, every tile
+configuration, ragged M, N not a multiple of 160, bias + residual, per-sample scale rows) against fp32 torch.  Prints
+PASS/FAIL lines."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from aqualora_amd import _lib as L  # noqa: E402
+
+dev = "cuda"
+torch.manual_seed(0)
+ok_all = True
+rnd = lambda *s, std=1.0: (torch.randn(*s, device=dev) * std).to(torch.bfloat16)  # noqa: E731
+
+
+def rel(a, b):
+    return float((a.float() - b).abs().max() / b.abs().max())
+
+
+CASES = [(16384, 320, 320, 4), (16384, 320, 1280, 4), (4096, 640, 640, 4), (4096, 640, 2560, 4), (1024, 1280, 1280, 4),
+         (1024, 10240, 1280, 4), (4096, 5120, 640, 2), (308, 640, 768, 4), (1000, 192, 256, 5), (77, 320, 768, 1), (640, 64, 64, 2),
+         (2048, 1280, 5120, 2), (300, 320, 2560, 3)]
+for M, N, K, nb in CASES:
+    rps = (M + nb - 1) // nb
+    X, W, A, Bup, S = rnd(M, K), rnd(N, K, std=K ** -0.5), rnd(32, K, std=K ** -0.5), rnd(N, 32, std=0.2), rnd(nb, 32)
+    bias, R = rnd(N, std=0.1), rnd(M, N)
+    Y = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    T = torch.empty(M, 32, dtype=torch.bfloat16, device=dev)
+    Ts = torch.empty_like(T)
+    rc = L.call_raw("aql_lora_gemm_fused", L.ptr(X), K, L.ptr(W), K, M, N, K, L.ptr(A), L.ptr(S), rps, L.ptr(Bup), L.ptr(bias),
+                    L.ptr(R), N, L.ptr(Y), N, L.ptr(T), L.ptr(Ts), L.stream_ptr())
+    if rc == 100:
+        print(f"PASS lora_gemm M{M} N{N} K{K}: routed to the two-launch path (rc=100)")
+        continue
+    L.check(rc, "aql_lora_gemm_fused")
+    Tr = X.float() @ A.float().t()
+    rows = torch.arange(M, device=dev) // rps
+    Tb = Tr.to(torch.bfloat16).float()
+    Tsr = (Tb * S.float()[rows]).to(torch.bfloat16).float()
+    Yr = X.float() @ W.float().t() + Tsr @ Bup.float().t() + bias.float() + R.float()
+    eT, eTs, eY = rel(T, Tr), rel(Ts, Tsr), rel(Y, Yr)
+    ok = eT < 1e-2 and eTs < 1.5e-2 and eY < 1.5e-2
+    ok_all &= ok
+    print(f"{'PASS' if ok else 'FAIL'} lora_gemm M{M} N{N} K{K} nb{nb}: T {eT:.2e} Ts {eTs:.2e} Y {eY:.2e}")
+print("ALL PASS" if ok_all else "SOME FAILED")
