@@ -4,7 +4,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from aqualora_amd import _lib as L  # noqa: E402
 import os
 L.LIB_PATH = os.environ.get("AQL_LIB", L.LIB_PATH)   # ablation builds
