@@ -98,6 +98,33 @@ def dominant_kernels(B, device):
     out.append({"kernel": "gemm_kernel_d<128,160,64,80,PlainLoader,PlainLoader,EPI_BF16,2> ff.net.0.proj 320->2560 @4096 tok",
                 "ms": ms, "flops": fl, "achieved_tflops": fl / ms / 1e9,
                 "frac_of_mfma_peak": fl / ms / 1e9 / MFMA_PEAK_TF})
+    # the "attention GEMMs" of the north star: flash attention at the 64x64 level (8 heads of 40, 4096 tokens) ...
+    qkv = [synth.normal(f"k.{n}", (B, 4096, 320), 1.0, 1, device).to(torch.bfloat16) for n in "qkv"]
+    with torch.no_grad():
+        ms = time_kernel(lambda: ops.attention(qkv[0], qkv[1], qkv[2], 8))
+    fl = 4.0 * B * 8 * 4096 * 4096 * 40
+    out.append({"kernel": "attn_fwd_kernel<64,48,4> self-attention 8 heads x 40, 4096 tokens", "ms": ms, "flops": fl,
+                "achieved_tflops": fl / ms / 1e9, "frac_of_mfma_peak": fl / ms / 1e9 / MFMA_PEAK_TF,
+                "note": "d=40 is padded to 64 (QK^T) / 48 (PV): 1.4x the algorithmic MFMA work"})
+    # ... and the one-launch rank-32 LoRA linear of the same level (to_q / to_k / to_v / to_out, 320 -> 320)
+    from aqualora_amd import _lib as L
+    X = synth.normal("k.lx", (B * 4096, 320), 1.0, 1, device).to(torch.bfloat16)
+    Wl = synth.normal("k.lw", (320, 320), 0.05, 1, device).to(torch.bfloat16)
+    Al = synth.normal("k.la", (32, 320), 0.05, 1, device).to(torch.bfloat16)
+    Bl = synth.normal("k.lb", (320, 32), 0.05, 1, device).to(torch.bfloat16)
+    Sl = synth.normal("k.ls", (B, 32), 1.0, 1, device).to(torch.bfloat16)
+    Yl = torch.empty(B * 4096, 320, dtype=torch.bfloat16, device=device)
+    Tl = torch.empty(B * 4096, 32, dtype=torch.bfloat16, device=device)
+    Tsl = torch.empty_like(Tl)
+
+    def lora_call():
+        rc = L.call_raw("aql_lora_gemm_fused", L.ptr(X), 320, L.ptr(Wl), 320, B * 4096, 320, 320, L.ptr(Al), L.ptr(Sl), 4096,
+                        L.ptr(Bl), None, None, 0, L.ptr(Yl), 320, L.ptr(Tl), L.ptr(Tsl), L.stream_ptr())
+        assert rc == 0, rc
+    ms = time_kernel(lora_call)
+    fl = 2.0 * B * 4096 * 320 * (320 + 32) + 2.0 * B * 4096 * 32 * 320
+    out.append({"kernel": "lora_gemm_kernel<64,160,32,80,2> attention projection 320->320 + rank-32 LoRA @4096 tok", "ms": ms,
+                "flops": fl, "achieved_tflops": fl / ms / 1e9, "frac_of_mfma_peak": fl / ms / 1e9 / MFMA_PEAK_TF})
     return out
 
 
