@@ -316,7 +316,11 @@ struct AttnArgs {
 // NOF = owner fragments (16 query rows each) per wavefront: 2 (32 rows, 128 per workgroup) or 4 (64 rows, 256 per
 // workgroup).  With 4 the K/V staging, the barriers and the LDS fragment reads of a tile are amortised over twice the
 // MFMA work and the two independent row halves give the scheduler something to overlap with the softmax chain.
-template <int DH, int DV, int NOF>
+// ONES (needs d < DV, i.e. a padding column in the V tile): the first padding column of V is set to 1.0 once, so the P.V
+// product also yields the softmax denominator sum_j p_ij in accumulator column d -- the 16 packed adds, the two permlane
+// reductions and the running-sum update per row block and tile disappear from the VALU stream, and the denominator is the
+// sum of exactly the bf16 probabilities that multiply V.
+template <int DH, int DV, int NOF, bool ONES>
 __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char sK[TILE * RowPitch<DH>::value];
   __shared__ __attribute__((aligned(16))) char sV[TILE * RowPitch<DH>::value];
@@ -339,6 +343,10 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const
   stV.init(sV, vp, a.ldv, 0, a.Nk, a.d, tid);
   stK.fetch();
   stV.fetch();
+  if constexpr (ONES) {
+    __syncthreads();  // the padding chunks were zeroed by other threads
+    if (tid < TILE) *reinterpret_cast<bf16_t*>(sV + tile_off<DH>(tid, a.d >> 3) + (a.d & 7) * 2) = (bf16_t)0x3F80;  // 1.0
+  }
   for (int kt = 0; kt < a.Nk; kt += TILE) {
     __syncthreads();
     stK.commit(sK);
@@ -382,9 +390,9 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const
         for (int e = 0; e < 4; ++e) {
           const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sf][of][e], c, -mnc));  // one FMA + one v_exp_f32
           s[sf][of][e] = p;
-          rs += p;
+          if constexpr (!ONES) rs += p;
         }
-      l[of] = l[of] * alpha + group4_sum(rs);
+      if constexpr (!ONES) l[of] = l[of] * alpha + group4_sum(rs);
 #pragma unroll
       for (int df = 0; df < DV / 16; ++df)
 #pragma unroll
@@ -393,6 +401,19 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const
     bf16x8_t pb[2][NOF];
     pack_p(pb, s);
     t_product<DH, DV>(o, sV, pb, lane);
+  }
+  if constexpr (ONES) {  // the denominator of row (lane & 15) sits in accumulator column d: fragment d/16, lane group (d%16)/4
+    const int df = a.d >> 4, grp = (a.d & 15) >> 2, e = a.d & 3;
+#pragma unroll
+    for (int of = 0; of < NOF; ++of) {
+      float v = 0.f;
+#pragma unroll
+      for (int x = 0; x < DV / 16; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+          if (x == df && y == e && (lane >> 4) == grp) v = o[x][of][y];
+      l[of] = group4_sum(v);
+    }
   }
   float inv[NOF];
 #pragma unroll
@@ -627,13 +648,19 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const AttnArgs a) 
 template <int DH, int DV>
 int launch_fwd(const AttnArgs& a, hipStream_t st) {
   static const int force = getenv("AQL_ATTN_NOF") ? atoi(getenv("AQL_ATTN_NOF")) : 0;  // tuning hook
+  static const int ones = getenv("AQL_ATTN_ONES") ? atoi(getenv("AQL_ATTN_ONES")) : 1;  // tuning hook
   if constexpr (DH <= 64) {
     if (force == 4 || (force == 0 && a.Nq >= 2048)) {
-      hipLaunchKernelGGL((attn_fwd_kernel<DH, DV, 4>), dim3(aql_cdiv(a.Nq, 256), a.H, a.B), dim3(256), 0, st, a);
+      if (a.d < DV && ones) hipLaunchKernelGGL((attn_fwd_kernel<DH, DV, 4, true>), dim3(aql_cdiv(a.Nq, 256), a.H, a.B), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((attn_fwd_kernel<DH, DV, 4, false>), dim3(aql_cdiv(a.Nq, 256), a.H, a.B), dim3(256), 0, st, a);
+      return 0;
+    }
+    if (a.d < DV && ones) {
+      hipLaunchKernelGGL((attn_fwd_kernel<DH, DV, 2, true>), dim3(aql_cdiv(a.Nq, 128), a.H, a.B), dim3(256), 0, st, a);
       return 0;
     }
   }
-  hipLaunchKernelGGL((attn_fwd_kernel<DH, DV, 2>), dim3(aql_cdiv(a.Nq, 128), a.H, a.B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((attn_fwd_kernel<DH, DV, 2, false>), dim3(aql_cdiv(a.Nq, 128), a.H, a.B), dim3(256), 0, st, a);
   return 0;
 }
 template <int DH, int DV>
