@@ -186,17 +186,25 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
 constexpr int GNF_THREADS = 1024;
 constexpr int GNF_U = 8;  // pixels in flight per thread
 
-template <int MODE>
+// PHASE 0: the whole (sample, group) in one workgroup (maps up to 32x32).  Larger maps split the pixel range over `nsplit`
+// workgroups and two launches: PHASE 1 writes each piece's raw sums to `part` [B][32][nsplit][2], PHASE 2 adds the pieces in
+// a fixed order (every workgroup redundantly: nsplit <= 8 pairs), then normalises its own piece -- one chip-wide drain
+// instead of two, no slab scratch traffic, and the pieces of a group stay on one XCD.
+template <int MODE, int PHASE>
 __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                                const bf16_t* __restrict__ gamma,
                                                                const bf16_t* __restrict__ beta, float* __restrict__ stats,
                                                                int HW, int C, float eps, int silu,
-                                                               const bf16_t* __restrict__ dres, bf16_t* __restrict__ out) {
+                                                               const bf16_t* __restrict__ dres, bf16_t* __restrict__ out,
+                                                               int nsplit, float* __restrict__ part) {
   __shared__ float red[2][GNF_THREADS / 64];
   __shared__ float bc[2];
   const int bid = blockIdx.x;
-  const int b = bid >> 5, gi = bid & 31;
-  const int g = ((gi & 7) << 2) | (gi >> 3);  // XCD (bid % 8) hosts groups 4x..4x+3
+  // hardware block id -> XCD bid % 8, which hosts groups 4x..4x+3 of every sample and all their pixel pieces
+  const int rest = bid >> 3, jg = rest & 3, sp = (rest >> 2) % nsplit, b = (rest >> 2) / nsplit;
+  const int g = ((bid & 7) << 2) | jg;
+  const int ppw = (HW + nsplit - 1) / nsplit;           // pixels per piece
+  const int p_lo = sp * ppw, p_hi = min(HW, p_lo + ppw);
   const int cpg = C / G, D = cpg >> 1;        // dwords per pixel of this group
   const int active = (GNF_THREADS / D) * D;   // each thread keeps ONE channel pair
   const int tid = threadIdx.x;
@@ -225,18 +233,18 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const bf16_t* __r
   // ---- pass 1.  GNF_U pixels per thread are loaded before any is used: a thread has only HW*D/1020 (~20) dwords to
   // fetch per pass, so the pass is latency-bound unless they are all in flight
   float s1 = 0.f, s2 = 0.f;
-  if (live) {
-    for (int p = p0; p < HW; p += pstep * GNF_U) {
+  if (live && PHASE != 2) {
+    for (int p = p_lo + p0; p < p_hi; p += pstep * GNF_U) {
       uint32_t xw[GNF_U], dwv[GNF_U];
 #pragma unroll
       for (int u = 0; u < GNF_U; ++u) {
-        const int pp = min(p + u * pstep, HW - 1);
+        const int pp = min(p + u * pstep, p_hi - 1);
         xw[u] = *reinterpret_cast<const uint32_t*>(x + base + (long)pp * C);
         if (MODE == 1) dwv[u] = *reinterpret_cast<const uint32_t*>(dy + base + (long)pp * C);
       }
 #pragma unroll
       for (int u = 0; u < GNF_U; ++u) {
-        if (p + u * pstep >= HW) continue;
+        if (p + u * pstep >= p_hi) continue;
         const float x0 = bf16lo(xw[u]), x1 = bf16hi(xw[u]);
         if (MODE == 0) {
           s1 += x0 + x1;
@@ -250,17 +258,27 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const bf16_t* __r
       }
     }
   }
-  s1 = wave_sum(s1);
-  s2 = wave_sum(s2);
-  if ((tid & 63) == 0) {
-    red[0][tid >> 6] = s1;
-    red[1][tid >> 6] = s2;
-  }
-  __syncthreads();
-  if (tid < 2) {  // fixed-order sum over the 16 wavefronts: deterministic
-    float a = 0.f;
-    for (int w = 0; w < GNF_THREADS / 64; ++w) a += red[tid][w];
-    bc[tid] = a;
+  if (PHASE != 2) {
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if ((tid & 63) == 0) {
+      red[0][tid >> 6] = s1;
+      red[1][tid >> 6] = s2;
+    }
+    __syncthreads();
+    if (tid < 2) {  // fixed-order sum over the 16 wavefronts: deterministic
+      float a = 0.f;
+      for (int w = 0; w < GNF_THREADS / 64; ++w) a += red[tid][w];
+      bc[tid] = a;
+      if (PHASE == 1) part[(((long)b * G + g) * nsplit + sp) * 2 + tid] = a;
+    }
+    if (PHASE == 1) return;
+  } else {
+    if (tid < 2) {
+      float a = 0.f;
+      for (int q = 0; q < nsplit; ++q) a += part[(((long)b * G + g) * nsplit + q) * 2 + tid];
+      bc[tid] = a;
+    }
   }
   __syncthreads();
   const float inv = 1.f / ((float)HW * cpg);
@@ -268,7 +286,7 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const bf16_t* __r
   if (MODE == 0) {
     mu = bc[0] * inv;
     rs = rsqrtf(fmaxf(bc[1] * inv - mu * mu, 0.f) + eps);
-    if (tid == 0) {
+    if (tid == 0 && sp == 0) {
       stats[(b * G + g) * 2 + 0] = mu;
       stats[(b * G + g) * 2 + 1] = rs;
     }
@@ -278,11 +296,11 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const bf16_t* __r
   }
   // ---- pass 2 (re-read from L2)
   if (!live) return;
-  for (int p = p0; p < HW; p += pstep * GNF_U) {
+  for (int p = p_lo + p0; p < p_hi; p += pstep * GNF_U) {
     uint32_t xw[GNF_U], dwv[GNF_U], rw[GNF_U];
 #pragma unroll
     for (int u = 0; u < GNF_U; ++u) {
-      const long o = base + (long)min(p + u * pstep, HW - 1) * C;
+      const long o = base + (long)min(p + u * pstep, p_hi - 1) * C;
       xw[u] = *reinterpret_cast<const uint32_t*>(x + o);
       if (MODE == 1) {
         dwv[u] = *reinterpret_cast<const uint32_t*>(dy + o);
@@ -291,7 +309,7 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const bf16_t* __r
     }
 #pragma unroll
     for (int u = 0; u < GNF_U; ++u) {
-      if (p + u * pstep >= HW) continue;
+      if (p + u * pstep >= p_hi) continue;
       const long o = base + (long)(p + u * pstep) * C;
       const float h0 = (bf16lo(xw[u]) - mu) * rs, h1 = (bf16hi(xw[u]) - mu) * rs;
       float r0, r1;
@@ -434,6 +452,17 @@ inline bool gn_use_fused(int C, int HW) {
   return en == 2 || HW <= 2048;
 }
 
+// larger maps, forward only: two launches of the same kernel with the pixel range of every (sample, group) cut into pieces
+// (64x64, B=4, tools/tune_gn.py: 22.3 vs 26.5 us at 320 channels, 25.4 vs 34.9 at 640, 33.5 vs 41.7 at 960 against the slab
+// form).  0 = use the slab form; AQL_GN_SPLIT=0 disables, =n forces n pieces
+inline int gn_split(int C, int HW) {
+  static const int en = getenv("AQL_GN_SPLIT") ? atoi(getenv("AQL_GN_SPLIT")) : -1;
+  if (en == 0 || (C / G) % 2 != 0 || (C / G) / 2 > GNF_THREADS || HW <= 2048 || HW > 8192) return 0;
+  if (en > 0) return en > 8 ? 8 : en;
+  int ns = HW / 1024;
+  return ns > 8 ? 8 : ns;
+}
+
 }  // namespace
 
 // scratch: caller-owned fp32 workspace of at least aql_groupnorm_scratch_floats(B, HW) elements
@@ -448,8 +477,16 @@ extern "C" int aql_groupnorm_silu_fwd(const bf16_t* x, int B, int HW, int C, con
   AQL_CHECK_ARG(x && gamma && beta && y && stats && scratch, "aql_groupnorm_silu_fwd: null operand");
   AQL_CHECK_ARG(C % (8 * 1) == 0 && C % G == 0 && C / 8 <= 1024, "aql_groupnorm_silu_fwd: bad C=%d", C);
   if (gn_use_fused(C, HW)) {
-    hipLaunchKernelGGL(gn_fused_kernel<0>, dim3(B * G), dim3(GNF_THREADS), 0, stream, x, nullptr, gamma, beta, stats, HW, C,
-                       eps, silu, nullptr, y);
+    hipLaunchKernelGGL((gn_fused_kernel<0, 0>), dim3(B * G), dim3(GNF_THREADS), 0, stream, x, nullptr, gamma, beta, stats, HW,
+                       C, eps, silu, nullptr, y, 1, nullptr);
+    AQL_CHECK_LAUNCH("aql_groupnorm_silu_fwd");
+    return AQL_OK;
+  }
+  if (const int ns = gn_split(C, HW)) {
+    hipLaunchKernelGGL((gn_fused_kernel<0, 1>), dim3(B * G * ns), dim3(GNF_THREADS), 0, stream, x, nullptr, gamma, beta, stats,
+                       HW, C, eps, silu, nullptr, y, ns, scratch);
+    hipLaunchKernelGGL((gn_fused_kernel<0, 2>), dim3(B * G * ns), dim3(GNF_THREADS), 0, stream, x, nullptr, gamma, beta, stats,
+                       HW, C, eps, silu, nullptr, y, ns, scratch);
     AQL_CHECK_LAUNCH("aql_groupnorm_silu_fwd");
     return AQL_OK;
   }
@@ -474,11 +511,12 @@ extern "C" int aql_groupnorm_silu_bwd(const bf16_t* x, const bf16_t* dy, int B, 
   AQL_CHECK_ARG(x && dy && gamma && beta && dx && stats && scratch, "aql_groupnorm_silu_bwd: null operand");
   AQL_CHECK_ARG(C % 8 == 0 && C % G == 0 && C / 8 <= 1024, "aql_groupnorm_silu_bwd: bad C=%d", C);
   if (gn_use_fused(C, HW)) {
-    hipLaunchKernelGGL(gn_fused_kernel<1>, dim3(B * G), dim3(GNF_THREADS), 0, stream, x, dy, gamma, beta,
-                       const_cast<float*>(stats), HW, C, 0.f, silu, dres, dx);
+    hipLaunchKernelGGL((gn_fused_kernel<1, 0>), dim3(B * G), dim3(GNF_THREADS), 0, stream, x, dy, gamma, beta,
+                       const_cast<float*>(stats), HW, C, 0.f, silu, dres, dx, 1, nullptr);
     AQL_CHECK_LAUNCH("aql_groupnorm_silu_bwd");
     return AQL_OK;
   }
+  // (the two-launch split form of the forward is not used here: measured 36 vs 32 us at 64x64x320, 40 vs 44 at 640 channels)
   int threads, rps;
   const int nslab = gn_geometry(HW, C, &threads, &rps);
   float* dstats = scratch + (long)B * 128 * G * 2;
