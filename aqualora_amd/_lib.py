@@ -87,6 +87,7 @@ SIGNATURES = {
     "aql_prvl_loss_fwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "aql_prvl_loss_bwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "aql_ddim_step": [c_p, c_p, c_p, c_f, c_p, c_l, c_p],
+    "aql_dpmpp2m_step": [c_p, c_p, c_p, c_f, c_p, c_p, c_l, c_p],
     "aql_sdpa_fwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p, c_p],
     "aql_sdpa_bwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p,
                      c_p, c_p, c_sz, c_p],

@@ -672,3 +672,31 @@ extern "C" int aql_causal_attn_small(const bf16_t* q, const bf16_t* k, const bf1
   AQL_CHECK_LAUNCH("aql_causal_attn_small");
   return AQL_OK;
 }
+
+// ---- DPM-Solver++ (2M, data prediction, epsilon model) step with classifier-free guidance: the sampler that
+// train/rob_enhance_finetune.py:993,1012 puts in front of the decoder fine-tune (DPMSolverMultistepScheduler, 20 steps).
+//   eps = eps_u + g (eps_c - eps_u);  x0 = (x - sigma_t eps) / alpha_t
+//   x <- a x + b x0 + c x0_prev ;  x0_prev <- x0        coef (device) = {alpha_t, sigma_t, a, b, c}
+// (first-order steps pass c = 0; the host derives a, b, c from the lambda schedule, see inference.dpm_solver_sample)
+namespace {
+__global__ __launch_bounds__(256) void dpmpp2m_step_kernel(float* __restrict__ x, const bf16_t* __restrict__ eps_u,
+                                                           const bf16_t* __restrict__ eps_c, float g,
+                                                           float* __restrict__ x0_prev, const float* __restrict__ coef,
+                                                           long n) {
+  const float al = coef[0], sg = coef[1], a = coef[2], b = coef[3], c = coef[4];
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x) {
+    const float eu = bf16_to_f32(eps_u[id]), ec = bf16_to_f32(eps_c[id]);
+    const float e = eu + g * (ec - eu);
+    const float x0 = (x[id] - sg * e) / al;
+    x[id] = a * x[id] + b * x0 + c * x0_prev[id];
+    x0_prev[id] = x0;
+  }
+}
+}  // namespace
+extern "C" int aql_dpmpp2m_step(float* x, const bf16_t* eps_u, const bf16_t* eps_c, float guidance, float* x0_prev,
+                                const float* coef, long n, hipStream_t stream) {
+  AQL_CHECK_ARG(x && eps_u && eps_c && x0_prev && coef, "aql_dpmpp2m_step: bad args");
+  hipLaunchKernelGGL(dpmpp2m_step_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, eps_u, eps_c, guidance, x0_prev, coef, n);
+  AQL_CHECK_LAUNCH("aql_dpmpp2m_step");
+  return AQL_OK;
+}

@@ -273,18 +273,40 @@ def robft_bench(args, device):
     imgs = (synth.normal("rob.img", (B, 3, 512, 512), 0.25, 1, device) + 0.5).clamp(0, 1)
     bits = synth.bits("rob.bits", (B, 48), 1).to(device)
     distort = NZ.RobNoiser([0.6, 0.1, 0.15, 0.05, 0.1])
+    gen = None
+    if args.robft_sample:
+        # the whole iteration of rob_enhance_finetune.py:997-1036: 20-step DPM-Solver++ sampling of the batch (CFG 7.5) on the
+        # fused-LoRA U-Net -> frozen VAE decode -> [0,1] images -> distortion -> decoder training step
+        from aqualora_amd.inference import dpm_solver_sample
+        from aqualora_amd.unet import UNet2DConditionModel, init_synthetic
+        from aqualora_amd.vae import SD15_VAE, AutoencoderKL, synthetic_state_dict
+        unet = UNet2DConditionModel(device=device, dtype=torch.bfloat16)
+        init_synthetic(unet, 2048)
+        vae = AutoencoderKL(synthetic_state_dict(SD15_VAE, device=device), SD15_VAE, device)
+        ctx = synth.normal("rob.ctx", (B, 77, 768), 1.0, 1, device)
+        lat = synth.normal("rob.lat", (B, 4, 64, 64), 1.0, 1, device)
+
+        def gen():
+            z = dpm_solver_sample(unet, ctx, torch.zeros_like(ctx), lat, 20, 7.5)
+            return (vae.decode(z.clamp(-4, 4) * 0.18215) / 2 + 0.5).clamp(0, 1)
+
+    def iteration():
+        return S1.rob_finetune_step(dec, opt, gen() if gen is not None else imgs, bits, distort)
+
     for _ in range(max(1, args.warmup)):
-        loss, acc = S1.rob_finetune_step(dec, opt, imgs, bits, distort)
+        loss, acc = iteration()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, acc = S1.rob_finetune_step(dec, opt, imgs, bits, distort)
+        loss, acc = iteration()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     gf = 3 * 6.4 * B  # fwd + bwd-data + bwd-weight of the 6.4 GFLOP/img network
     print(json.dumps({"metric": "rob-finetune decoder step images/sec at 512x512 (EfficientNet-B1 train mode, fp32)",
                       "value": B / dt, "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "ms_per_step": 1e3 * dt,
                       "dtype": "f32", "higher_is_better": True, "data": "synthetic", "batch": B,
+                      "config": {"workload": "20-step DPM-Solver++ sampling + VAE decode + distortion + decoder fwd/bwd/AdamW"
+                                 if gen is not None else "distortion + decoder fwd/bwd/AdamW on given images"},
                       "achieved_tflops_fp32": gf / dt / 1e3, "loss": float(loss), "bit_acc": float(acc)}), flush=True)
 
 
@@ -297,6 +319,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--robft-sample", action="store_true",
+                    help="robft mode: generate the batch inside the timed iteration (20-step DPM-Solver++, VAE decode)")
     ap.add_argument("--infer-batch", type=int, default=1, help="infer mode: images sampled together")
     ap.add_argument("--text-in", action="store_true",
                     help="train mode: run the frozen CLIP text encoder (ids [B,77] -> [B,77,768]) inside every timed step")

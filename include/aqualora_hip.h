@@ -172,6 +172,11 @@ int aql_jpeg_mask(const float* x, float* y, int B, int H, int W, int keep_y, int
  * sqrt(a_prev), sqrt(1-a_prev)} on the device.                                                                          */
 int aql_ddim_step(float* x, const bf16_t* eps_uncond, const bf16_t* eps_cond, float guidance, const float* coef, long n,
                   aql_stream_t stream);
+/* DPM-Solver++ 2M step (DPMSolverMultistepScheduler as set at train/rob_enhance_finetune.py:993, 20 steps at :1012):
+ * eps = CFG(eps_u, eps_c); x0 = (x - sigma_t eps) / alpha_t; x <- a x + b x0 + c x0_prev; x0_prev <- x0;
+ * coef (device) = {alpha_t, sigma_t, a, b, c}                                                                         */
+int aql_dpmpp2m_step(float* x, const bf16_t* eps_u, const bf16_t* eps_c, float guidance, float* x0_prev,
+                     const float* coef, long n, aql_stream_t stream);
 
 /* csrc/aql_distort.hip: deterministic image maps of noises.py:34-85 / noiser.py:46-71 (random parameters are drawn by the
  * host like the reference does); NCHW fp32, BC = batch*channels; backward=1 applies the adjoint.                        */

@@ -299,3 +299,18 @@ def ddim_step(x, eps_u, eps_c, t, t_prev, guidance, acp=None):
     eps = eps_u.double() + guidance * (eps_c.double() - eps_u.double())
     x0 = (x.double() - (1 - a_t).sqrt() * eps) / a_t.sqrt()
     return (a_p.sqrt() * x0 + (1 - a_p).sqrt() * eps).float()
+
+
+def dpmpp2m_sample(eps_model, x, schedule, guidance=1.0):
+    """DPM-Solver++(2M) loop over ``schedule`` = [(t, alpha_t, sigma_t, a, b, c)] (aqualora_amd.inference.dpmpp2m_schedule;
+    the coefficient algebra is restated independently in tests/test_samplers.py).  ``eps_model(x, t) -> (eps_uncond,
+    eps_cond)``.  Recalled diffusers DPMSolverMultistepScheduler semantics (rob_enhance_finetune.py:993): UNPINNED."""
+    x = x.double()
+    x0_prev = torch.zeros_like(x)
+    for t, al, sg, a, b, c in schedule:
+        eu, ec = eps_model(x.float(), t)
+        eps = eu.double() + guidance * (ec.double() - eu.double())
+        x0 = (x - sg * eps) / al
+        x = a * x + b * x0 + c * x0_prev
+        x0_prev = x0
+    return x.float()

@@ -1,0 +1,82 @@
+"""Samplers in front of evaluation / rob-finetune: DDIM (utils_eval.py:83-126) and DPM-Solver++(2M)
+(rob_enhance_finetune.py:993,1012).  diffusers is not on disk (UNPINNED); what can be pinned are the solvers' own
+invariants: with an EXACT noise model eps(x,t) = (x - alpha_t x0*) / sigma_t every consistent solver must return x0* at the
+end of the trajectory, whatever the step count, and the 2M coefficients must equal an independent restatement of the
+published update."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from aqualora_amd.inference import dpmpp2m_schedule
+from oracle import ppft_oracle as O
+
+
+def test_dpmpp2m_schedule_matches_independent_restatement():
+    acp = O.alphas_cumprod().double().numpy()
+    for steps in (20, 10, 50):
+        sched = dpmpp2m_schedule(steps)
+        ts = [r[0] for r in sched]
+        want_ts = list(np.linspace(0, 999, steps + 1).round()[::-1][:-1].astype(int))
+        assert ts == want_ts and ts[0] == 999 and len(ts) == steps
+        lam = lambda t: 0.5 * math.log(acp[t] / (1 - acp[t]))  # noqa: E731
+        for i, (t, al, sg, a, b, c) in enumerate(sched):
+            nxt = ts[i + 1] if i + 1 < steps else 0
+            assert abs(al - math.sqrt(acp[t])) < 1e-12 and abs(sg - math.sqrt(1 - acp[t])) < 1e-12
+            h = lam(nxt) - lam(t)
+            E = -math.sqrt(acp[nxt]) * math.expm1(-h)
+            assert abs(a - math.sqrt((1 - acp[nxt]) / (1 - acp[t]))) < 1e-9
+            if i == 0 or (i == steps - 1 and steps < 15):
+                assert c == 0.0 and abs(b - E) < 1e-9
+            else:
+                r0 = (lam(t) - lam(ts[i - 1])) / h
+                assert abs(c + 0.5 * E / r0) < 1e-9 and abs(b - (E + 0.5 * E / r0)) < 1e-9
+
+
+def test_exact_noise_model_is_integrated_exactly():
+    torch.manual_seed(0)
+    x0_star = torch.randn(2, 4, 8, 8)
+    xT = torch.randn(2, 4, 8, 8)
+    acp = O.alphas_cumprod().double()
+
+    def eps_model(x, t):
+        e = (x.double() - acp[t].sqrt() * x0_star.double()) / (1 - acp[t]).sqrt()
+        return e.float(), e.float()
+    for steps in (20, 8):
+        out = O.dpmpp2m_sample(eps_model, xT, dpmpp2m_schedule(steps), guidance=7.5)
+        # the trajectory ends at alphas_cumprod[0]: x = alpha_0 x0* + sigma_0 eps_last; x0* is recovered up to that residual
+        a0, s0 = float(acp[0].sqrt()), float((1 - acp[0]).sqrt())
+        assert float((out / a0 - x0_star).abs().max()) < 4 * s0 / a0 * float(xT.abs().max()) + 1e-3
+    # DDIM under the same model
+    x = xT.clone()
+    ts = [t for t in range(981, 0, -20)]
+    for t in ts:
+        eu, ec = eps_model(x, t)
+        x = O.ddim_step(x, eu, ec, t, t - 20, 7.5)
+    assert float((x / float(acp[0].sqrt()) - x0_star).abs().max()) < 0.2
+
+
+@pytest.mark.gpu
+def test_dpm_solver_hip_vs_oracle_tiny_unet():
+    """The graph-replayed HIP sampler against the oracle loop driving the same tiny U-Net (fp32 update kernel, bf16 U-Net)."""
+    from aqualora_amd.inference import dpm_solver_sample
+    from tests.common import T, TINY, tiny_unet
+    dev = "cuda"
+    unet = tiny_unet(dev, torch.bfloat16)
+    ctx = T("s.ctx", (1, 77, TINY["cross_attention_dim"]), device=dev)
+    unc = torch.zeros_like(ctx)
+    lat = T("s.lat", (1, 4, 16, 16), device=dev)
+    got = dpm_solver_sample(unet, ctx, unc, lat, 6, 3.0)
+    got_eager = dpm_solver_sample(unet, ctx, unc, lat, 6, 3.0, graph=False)
+
+    def eps_model(x, t):
+        tt = torch.full((2,), t, dtype=torch.long, device=dev)
+        e = unet(torch.cat([x.to(dev), x.to(dev)]), tt, torch.cat([unc, ctx]).to(torch.bfloat16),
+                 cross_attention_kwargs={"scale": None}).sample.float().cpu()
+        return e[:1], e[1:]
+    with torch.no_grad():
+        want = O.dpmpp2m_sample(eps_model, lat.cpu(), dpmpp2m_schedule(6), guidance=3.0)
+    assert torch.isfinite(got).all()
+    assert float((got.cpu() - want).abs().max() / want.abs().max()) < 2e-2
+    assert float((got - got_eager).abs().max() / got_eager.abs().max()) < 1e-5
