@@ -396,7 +396,7 @@ extern "C" int aql_add_noise(const float* x0, const float* wm, const float* eps,
 extern "C" int aql_mse_fwd_bwd(const bf16_t* pred, const bf16_t* target, long n, float* loss, bf16_t* dpred,
                                hipStream_t stream) {
   AQL_CHECK_ARG(pred && target && loss, "aql_mse_fwd_bwd: bad args");
-  hipMemsetAsync(loss, 0, sizeof(float), stream);
+  (void)hipMemsetAsync(loss, 0, sizeof(float), stream);
   hipLaunchKernelGGL(mse_kernel, dim3(grid_for(n, 256, 256)), dim3(256), 0, stream, pred, target, n, loss, dpred);
   AQL_CHECK_LAUNCH("aql_mse_fwd_bwd");
   return AQL_OK;
@@ -481,7 +481,7 @@ extern "C" int aql_lora_ds_grouped(const void* dev_descs, int n, int total_block
 }
 extern "C" int aql_sumsq_f32(const float* g, long n, float* out, hipStream_t stream) {
   AQL_CHECK_ARG(g && out, "aql_sumsq_f32: bad args");
-  hipMemsetAsync(out, 0, sizeof(float), stream);
+  (void)hipMemsetAsync(out, 0, sizeof(float), stream);
   hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 1024, 1024)), dim3(256), 0, stream, g, n, out);
   AQL_CHECK_LAUNCH("aql_sumsq_f32");
   return AQL_OK;
