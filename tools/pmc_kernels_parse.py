@@ -16,6 +16,12 @@ for row in csv.DictReader(open(files[0])):
     k = re.sub(r"\(anonymous namespace\)::|aqlgemm::|void ", "", row["Kernel_Name"])
     k = re.sub(r"\(.*", "", k)[:70]
     agg[(k, row["Grid_Size"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+if not any("SQ_BUSY_CYCLES" in cs for cs in agg.values()):   # an HBM-traffic pass: just list the counters per kernel
+    for (k, grid), cs in sorted(agg.items(), key=lambda kv: -max(sum(v) for v in kv[1].values())):
+        if "at::native" in k or "elementwise" in k or "rocclr" in k:
+            continue
+        print(f"{k:70s} {grid:>9s} " + "  ".join(f"{c}={sum(v) / len(v):12.1f} (n={len(v)})" for c, v in cs.items()))
+    sys.exit(0)
 print(f"{'kernel':70s} {'grid':>9s} {'n':>4s} {'SQ_BUSY':>10s} {'MFMA_BUSY':>10s} {'mfma/busy':>9s} {'WAVE_CYC':>10s} {'wait_any':>8s} {'wait_inst':>9s} {'active':>7s} {'VALU insts':>10s}")
 for (k, grid), cs in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("SQ_BUSY_CYCLES", [0]))):
     if "at::native" in k or "elementwise" in k or "rocclr" in k:
