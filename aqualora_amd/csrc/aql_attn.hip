@@ -312,6 +312,19 @@ struct AttnArgs {
 // round-trips them through v_accvgpr_read/write: ~190 extra VALU moves per K/V tile in a loop whose VALU work
 // (exp2, max, sum, pack) already outweighs its 28 MFMAs.  Only the head sizes that fit 256 registers without spilling
 // get the hint.
+// XCD-aware block order: hardware block L (x fastest) runs on XCD L % 8, each with a private L2.  All row blocks of one
+// (sample, head) stream the SAME K/V (or Q/dO) panels, so they are given to one XCD: logical = (L % 8) * (total / 8) + L / 8
+// (a bijection when the grid is a multiple of 8; otherwise the identity).  Returns (row block, head, sample).
+__device__ __forceinline__ void attn_block(int& bx, int& h, int& b) {
+  const int nx = gridDim.x, ny = gridDim.y, total = nx * ny * gridDim.z;
+  int L = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+  if ((total & 7) == 0) L = (L & 7) * (total >> 3) + (L >> 3);
+  bx = L % nx;
+  const int r = L / nx;
+  h = r % ny;
+  b = r / ny;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 // NOF = owner fragments (16 query rows each) per wavefront: 2 (32 rows, 128 per workgroup) or 4 (64 rows, 256 per
 // workgroup).  With 4 the K/V staging, the barriers and the LDS fragment reads of a tile are amortised over twice the
@@ -325,8 +338,9 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const
   __shared__ __attribute__((aligned(16))) char sK[TILE * RowPitch<DH>::value];
   __shared__ __attribute__((aligned(16))) char sV[TILE * RowPitch<DH>::value];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * (64 * NOF) + wave * (16 * NOF);
+  int bx, h, b;
+  attn_block(bx, h, b);
+  const int q0 = bx * (64 * NOF) + wave * (16 * NOF);
   const bf16_t* qp = a.q + (long)b * a.Nq * a.ldq + h * a.d;
   const bf16_t* kp = a.k + (long)b * a.Nk * a.ldk + h * a.d;
   const bf16_t* vp = a.v + (long)b * a.Nk * a.ldv + h * a.d;
@@ -434,8 +448,9 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dq_kernel(const 
   __shared__ __attribute__((aligned(16))) char sK[TILE * RowPitch<DH>::value];
   __shared__ __attribute__((aligned(16))) char sV[TILE * RowPitch<DH>::value];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * (4 * OWN) + wave * OWN;
+  int bx, h, b;
+  attn_block(bx, h, b);
+  const int q0 = bx * (4 * OWN) + wave * OWN;
   const bf16_t* qp = a.q + (long)b * a.Nq * a.ldq + h * a.d;
   const bf16_t* dop = a.dout + (long)b * a.Nq * a.ldo + h * a.d;
   const bf16_t* kp = a.k + (long)b * a.Nk * a.ldk + h * a.d;
@@ -525,8 +540,10 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dkv_kernel(const
   __shared__ __attribute__((aligned(16))) float sLse[TILE];
   __shared__ __attribute__((aligned(16))) float sDelta[TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = blockIdx.y, b = blockIdx.z / a.qsplit, split = blockIdx.z - b * a.qsplit;
-  const int k0 = blockIdx.x * (4 * OWN) + wave * OWN;
+  int bx, h, bz;
+  attn_block(bx, h, bz);
+  const int b = bz / a.qsplit, split = bz - b * a.qsplit;
+  const int k0 = bx * (4 * OWN) + wave * OWN;
   // cross-attention has 77 key rows: one owner workgroup per (b, h) would stream all of Q on 32 CUs.  Split the Q range
   // over qsplit workgroups instead; each writes an fp32 partial that a small kernel reduces (deterministic, no atomics)
   const int tiles_per_split = ((a.Nq + TILE - 1) / TILE + a.qsplit - 1) / a.qsplit;
