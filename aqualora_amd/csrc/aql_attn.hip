@@ -672,6 +672,8 @@ int launch_fwd(const AttnArgs& a, hipStream_t st) {
       else hipLaunchKernelGGL((attn_fwd_kernel<DH, DV, 4, false>), dim3(aql_cdiv(a.Nq, 256), a.H, a.B), dim3(256), 0, st, a);
       return 0;
     }
+  }
+  if constexpr (DH <= 96) {   // d = 40 / 80 leave padding columns in the V tile: the denominator rides in the P.V product
     if (a.d < DV && ones) {
       hipLaunchKernelGGL((attn_fwd_kernel<DH, DV, 2, true>), dim3(aql_cdiv(a.Nq, 128), a.H, a.B), dim3(256), 0, st, a);
       return 0;
