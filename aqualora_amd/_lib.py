@@ -66,6 +66,7 @@ SIGNATURES = {
     "aql_pwconv_f32": [c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_i, c_i, c_p, c_p],
     "aql_crop_resize_bilinear": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "aql_gauss_blur": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p],
+    "aql_gauss_blur2": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p],
     "aql_add_gauss_noise": [c_p, c_p, c_f, c_i, c_l, c_p, c_p],
     "aql_color_jiggle": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
     "aql_rotate_bilinear": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p],

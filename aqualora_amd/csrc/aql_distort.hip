@@ -49,27 +49,32 @@ __device__ __forceinline__ int reflect(int i, int n) {  // 'reflect' padding: -1
   return i;
 }
 
-// one 1-D pass of the separable Gaussian (axis 0 = x, 1 = y); BWD applies the adjoint (scatter through the reflection)
+// one 1-D pass of the separable Gaussian (axis 0 = x, 1 = y); BWD applies the adjoint (scatter through the reflection).
+// taps: k weights shared by every image (tap_stride 0) or one row of k weights per SAMPLE (tap_stride = k; kornia's
+// RandomGaussianBlur draws one sigma per sample); C = channels per sample.
 template <bool BWD>
 __global__ __launch_bounds__(256) void blur1d_kernel(const float* __restrict__ src, float* __restrict__ dst, int BC, int H,
-                                                     int W, int axis, int k, const float* __restrict__ taps) {
+                                                     int W, int axis, int k, const float* __restrict__ taps, int C,
+                                                     int tap_stride) {
   const long n = (long)BC * H * W;
   const int r = k / 2;
   for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x) {
     const int x = (int)(id % W), y = (int)((id / W) % H);
-    const long base = (id / ((long)W * H)) * H * W;
+    const long img = id / ((long)W * H);
+    const long base = img * H * W;
+    const float* tp = taps + (img / C) * tap_stride;
     if (!BWD) {
       float a = 0.f;
       for (int t = 0; t < k; ++t) {
         const int xx = axis == 0 ? reflect(x + t - r, W) : x, yy = axis == 1 ? reflect(y + t - r, H) : y;
-        a += taps[t] * src[base + (long)yy * W + xx];
+        a += tp[t] * src[base + (long)yy * W + xx];
       }
       dst[id] = a;
     } else {
       const float g = src[id];
       for (int t = 0; t < k; ++t) {
         const int xx = axis == 0 ? reflect(x + t - r, W) : x, yy = axis == 1 ? reflect(y + t - r, H) : y;
-        atomicAdd(dst + base + (long)yy * W + xx, taps[t] * g);
+        atomicAdd(dst + base + (long)yy * W + xx, tp[t] * g);
       }
     }
   }
@@ -325,22 +330,35 @@ extern "C" int aql_crop_resize_bilinear(const float* src, float* dst, int BC, in
   return AQL_OK;
 }
 
-// taps: k normalised Gaussian weights on the device; tmp: scratch of BC*H*W floats
-extern "C" int aql_gauss_blur(const float* src, float* dst, float* tmp, int BC, int H, int W, int k, const float* taps,
-                              int backward, hipStream_t stream) {
-  AQL_CHECK_ARG(src && dst && tmp && taps && k % 2 == 1 && k >= 1 && k / 2 < H && k / 2 < W, "aql_gauss_blur: bad args");
+// Separable Gaussian blur with reflect borders, kernel (ky, kx) -- kornia's RandomGaussianBlur((ky, kx), sigma range) as
+// called at noises.py:68 ((3, 9)), noiser.py:63 ((3, 5)) and utils_eval.py:280 ((3, 3)).  taps_x: kx weights, taps_y: ky
+// weights, shared (per_sample = 0) or [B][k] rows, one per sample (per_sample = 1).  tmp: scratch of B*C*H*W floats.
+extern "C" int aql_gauss_blur2(const float* src, float* dst, float* tmp, int B, int C, int H, int W, int kx, int ky,
+                               const float* taps_x, const float* taps_y, int per_sample, int backward, hipStream_t stream) {
+  AQL_CHECK_ARG(src && dst && tmp && taps_x && taps_y && kx % 2 == 1 && ky % 2 == 1 && kx >= 1 && ky >= 1 && kx / 2 < W &&
+                    ky / 2 < H && B > 0 && C > 0,
+                "aql_gauss_blur2: bad args");
+  const int BC = B * C;
   const long n = (long)BC * H * W;
+  const int sx = per_sample ? kx : 0, sy = per_sample ? ky : 0;
   if (backward) {
     (void)hipMemsetAsync(tmp, 0, n * sizeof(float), stream);
     (void)hipMemsetAsync(dst, 0, n * sizeof(float), stream);
-    hipLaunchKernelGGL(blur1d_kernel<true>, dim3(grid_for(n)), dim3(256), 0, stream, src, tmp, BC, H, W, 1, k, taps);
-    hipLaunchKernelGGL(blur1d_kernel<true>, dim3(grid_for(n)), dim3(256), 0, stream, tmp, dst, BC, H, W, 0, k, taps);
+    hipLaunchKernelGGL(blur1d_kernel<true>, dim3(grid_for(n)), dim3(256), 0, stream, src, tmp, BC, H, W, 1, ky, taps_y, C, sy);
+    hipLaunchKernelGGL(blur1d_kernel<true>, dim3(grid_for(n)), dim3(256), 0, stream, tmp, dst, BC, H, W, 0, kx, taps_x, C, sx);
   } else {
-    hipLaunchKernelGGL(blur1d_kernel<false>, dim3(grid_for(n)), dim3(256), 0, stream, src, tmp, BC, H, W, 0, k, taps);
-    hipLaunchKernelGGL(blur1d_kernel<false>, dim3(grid_for(n)), dim3(256), 0, stream, tmp, dst, BC, H, W, 1, k, taps);
+    hipLaunchKernelGGL(blur1d_kernel<false>, dim3(grid_for(n)), dim3(256), 0, stream, src, tmp, BC, H, W, 0, kx, taps_x, C, sx);
+    hipLaunchKernelGGL(blur1d_kernel<false>, dim3(grid_for(n)), dim3(256), 0, stream, tmp, dst, BC, H, W, 1, ky, taps_y, C, sy);
   }
-  AQL_CHECK_LAUNCH("aql_gauss_blur");
+  AQL_CHECK_LAUNCH("aql_gauss_blur2");
   return AQL_OK;
+}
+
+// square kernel, one tap set for the whole batch (kept for callers of the round-1 ABI)
+extern "C" int aql_gauss_blur(const float* src, float* dst, float* tmp, int BC, int H, int W, int k, const float* taps,
+                              int backward, hipStream_t stream) {
+  AQL_CHECK_ARG(src && dst && tmp && taps && k % 2 == 1 && k >= 1 && k / 2 < H && k / 2 < W, "aql_gauss_blur: bad args");
+  return aql_gauss_blur2(src, dst, tmp, BC, 1, H, W, k, k, taps, taps, 0, backward, stream);
 }
 
 extern "C" int aql_add_gauss_noise(const float* x, const float* noise, float std, int clamp01, long n, float* y,

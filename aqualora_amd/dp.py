@@ -122,6 +122,26 @@ def allreduce_module_grads_(params, group=None, bucket_bytes=64 << 20):
             off += g.numel()
 
 
+def broadcast_(tensor, group=None, src=0):
+    """DDP's construction-time parameter sync (what accelerate's ``prepare`` does when it wraps the trainable modules,
+    train/ppft_train.py:905-912): rank ``src``'s values overwrite every rank's copy.  The reference runs with
+    ``seed=None`` by default, so without this every rank would start from its own LoRA / mapper draw and the replicas
+    would drift apart silently while averaging gradients.  No-op on a single rank."""
+    if world_size(group) <= 1:
+        return tensor
+    dist.broadcast(tensor, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+    return tensor
+
+
+def broadcast_module_(module, group=None, src=0):
+    """Parameters and buffers of an ordinary module (the SecretDecoder of rob-finetune) from rank ``src``."""
+    if world_size(group) <= 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        if t.numel():
+            broadcast_(t.data, group, src)
+
+
 def broadcast_buffers_(module, group=None, src=0):
     """DDP(broadcast_buffers=True): rank ``src``'s buffers (BatchNorm running statistics) overwrite everyone's before a
     forward pass, so that the replicas stay identical."""

@@ -68,10 +68,22 @@ def ddim_timesteps(num_inference_steps, num_train_timesteps=1000, steps_offset=1
 
 
 @torch.no_grad()
-def ddim_sample(unet, ctx_cond, ctx_uncond, latents, num_inference_steps=50, guidance_scale=7.5, graph=True):
+def _cfg_scale(scale, B):
+    """Per-sample LoRA scale of a guided (2B) U-Net call.  ``scale`` is None (LoRA-free / fused U-Net), a float, or the
+    [B, r] (or [1, r]) per-message diagonal of the un-fused watermark LoRA; rob_enhance_finetune.py:1002 concatenates it
+    for the unconditional and conditional halves: ``cat([mapper(m)] * 2) * 1.03``."""
+    if scale is None or not torch.is_tensor(scale):
+        return scale
+    s = scale if scale.shape[0] == B else scale.expand(B, scale.shape[1])
+    return torch.cat([s, s]).contiguous()
+
+
+@torch.no_grad()
+def ddim_sample(unet, ctx_cond, ctx_uncond, latents, num_inference_steps=50, guidance_scale=7.5, graph=True, scale=None):
     """latents: [B,4,h,w] fp32 ~ N(0,1) (init_noise_sigma = 1 for DDIM).  Returns the final fp32 latents.
     One HIP graph holds a full guided step (U-Net on batch 2B + the DDIM update); it is replayed once per timestep with
-    the timestep and the four schedule coefficients in device scalars."""
+    the timestep and the four schedule coefficients in device scalars.  ``scale``: see `_cfg_scale` (a [B, r] tensor
+    samples through the un-fused watermark LoRA with one message per image, ppft_train.py:1153-1154)."""
     dev = latents.device
     acp = sd15_alphas_cumprod(device="cpu").double()
     ts = ddim_timesteps(num_inference_steps)
@@ -82,9 +94,10 @@ def ddim_sample(unet, ctx_cond, ctx_uncond, latents, num_inference_steps=50, gui
     t_dev = torch.zeros(2 * B, dtype=torch.long, device=dev)
     coef = torch.zeros(4, dtype=torch.float32, device=dev)
     n = x.numel()
+    scale2 = _cfg_scale(scale, B)
 
     def one_step():
-        eps = unet(torch.cat([x, x]), t_dev, ctx, cross_attention_kwargs={"scale": None}).sample
+        eps = unet(torch.cat([x, x]), t_dev, ctx, cross_attention_kwargs={"scale": scale2}).sample
         eps = eps.contiguous()  # NCHW-contiguous so that it lines up with x element for element
         L.call("aql_ddim_step", L.ptr(x), L.ptr(eps[:B]), L.ptr(eps[B:]), float(guidance_scale), L.ptr(coef), n,
                L.stream_ptr())
@@ -149,10 +162,13 @@ def dpmpp2m_schedule(num_inference_steps=20, num_train_timesteps=1000, acp=None)
 
 
 @torch.no_grad()
-def dpm_solver_sample(unet, ctx_cond, ctx_uncond, latents, num_inference_steps=20, guidance_scale=7.5, graph=True):
+def dpm_solver_sample(unet, ctx_cond, ctx_uncond, latents, num_inference_steps=20, guidance_scale=7.5, graph=True,
+                      scale=None):
     """20-step DPM-Solver++(2M) sampling with classifier-free guidance, the generator in front of rob-finetune
     (rob_enhance_finetune.py:993-1015).  Same structure as `ddim_sample`: ONE HIP graph holds a guided step (U-Net on batch
-    2B + `aql_dpmpp2m_step`), replayed per timestep with the timestep and the five coefficients in device scalars."""
+    2B + `aql_dpmpp2m_step`), replayed per timestep with the timestep and the five coefficients in device scalars.
+    ``scale`` = ``mapper(msg) * 1.03`` ([B, r]) samples through the UN-fused watermark LoRA so that every image of the batch
+    carries its own message, as rob_enhance_finetune.py:999-1012 does; None = LoRA-free / fused U-Net."""
     dev = latents.device
     sched = dpmpp2m_schedule(num_inference_steps)
     x = latents.float().contiguous().clone()
@@ -162,9 +178,10 @@ def dpm_solver_sample(unet, ctx_cond, ctx_uncond, latents, num_inference_steps=2
     t_dev = torch.zeros(2 * B, dtype=torch.long, device=dev)
     coef = torch.zeros(5, dtype=torch.float32, device=dev)
     n = x.numel()
+    scale2 = _cfg_scale(scale, B)
 
     def one_step():
-        eps = unet(torch.cat([x, x]), t_dev, ctx, cross_attention_kwargs={"scale": None}).sample.contiguous()
+        eps = unet(torch.cat([x, x]), t_dev, ctx, cross_attention_kwargs={"scale": scale2}).sample.contiguous()
         L.call("aql_dpmpp2m_step", L.ptr(x), L.ptr(eps[:B]), L.ptr(eps[B:]), float(guidance_scale), L.ptr(x0_prev), L.ptr(coef),
                n, L.stream_ptr())
 

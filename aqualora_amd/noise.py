@@ -85,45 +85,82 @@ def crop_resize(x, top, left, ch, cw, oh, ow):
 
 
 def gaussian_taps(ksize, sigma, device):
+    """Normalised 1-D Gaussian window (kornia ``get_gaussian_kernel1d``).  ``sigma``: a float -> [ksize]; a [B] tensor
+    (one sigma per sample, as kornia's RandomGaussianBlur draws them) -> [B, ksize]."""
     x = torch.arange(ksize, dtype=torch.float32) - (ksize - 1) / 2
+    if torch.is_tensor(sigma):
+        sg = sigma.detach().float().cpu().reshape(-1, 1)
+        g = torch.exp(-(x[None] * x[None]) / (2.0 * sg * sg))
+        return (g / g.sum(dim=1, keepdim=True)).to(device).contiguous()
     g = torch.exp(-(x * x) / (2.0 * sigma * sigma))
     return (g / g.sum()).to(device)
 
 
 class _BlurFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, taps):
+    def forward(ctx, x, taps_x, taps_y):
         x = x.float().contiguous()
         B, C, H, W = x.shape
         y, tmp = torch.empty_like(x), torch.empty_like(x)
-        L.call("aql_gauss_blur", L.ptr(x), L.ptr(y), L.ptr(tmp), B * C, H, W, taps.numel(), L.ptr(taps), 0, L.stream_ptr())
-        ctx.save_for_backward(taps)
+        per = int(taps_x.dim() == 2)
+        L.call("aql_gauss_blur2", L.ptr(x), L.ptr(y), L.ptr(tmp), B, C, H, W, taps_x.shape[-1], taps_y.shape[-1], L.ptr(taps_x),
+               L.ptr(taps_y), per, 0, L.stream_ptr())
+        ctx.save_for_backward(taps_x, taps_y)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (taps,) = ctx.saved_tensors
+        taps_x, taps_y = ctx.saved_tensors
         dy = dy.float().contiguous()
         B, C, H, W = dy.shape
         dx, tmp = torch.empty_like(dy), torch.empty_like(dy)
-        L.call("aql_gauss_blur", L.ptr(dy), L.ptr(dx), L.ptr(tmp), B * C, H, W, taps.numel(), L.ptr(taps), 1, L.stream_ptr())
-        return dx, None
+        per = int(taps_x.dim() == 2)
+        L.call("aql_gauss_blur2", L.ptr(dy), L.ptr(dx), L.ptr(tmp), B, C, H, W, taps_x.shape[-1], taps_y.shape[-1],
+               L.ptr(taps_x), L.ptr(taps_y), per, 1, L.stream_ptr())
+        return dx, None, None
 
 
 def gaussian_blur(x, ksize, sigma):
+    """kornia ``gaussian_blur2d(x, (ky, kx), (sigma, sigma), border_type='reflect')``.  ``ksize``: int (square) or (ky, kx)
+    like kornia's kernel_size; ``sigma``: float, or a [B] tensor with one value per sample."""
     if not x.is_cuda:
         raise L.AqlError("gaussian_blur: the HIP path needs a GPU tensor; there is no CPU fallback")
-    return _BlurFn.apply(x, gaussian_taps(int(ksize), float(sigma), x.device))
+    ky, kx = (int(ksize), int(ksize)) if isinstance(ksize, int) or not hasattr(ksize, "__len__") else map(int, ksize)
+    if torch.is_tensor(sigma):
+        if sigma.numel() != x.shape[0]:
+            raise ValueError(f"per-sample sigma needs {x.shape[0]} values, got {sigma.numel()}")
+    else:
+        sigma = float(sigma)
+    return _BlurFn.apply(x, gaussian_taps(kx, sigma, x.device), gaussian_taps(ky, sigma, x.device))
+
+
+class _GaussNoiseFn(torch.autograd.Function):
+    """y = x + std * noise [clamped to [0,1]]: kornia's RandomGaussianNoise is differentiable in x (stage 1 back-propagates
+    msgloss through it to the SecretEncoder, latent_wm_pretrain.py:186-196); the clamp passes gradient inside (0,1)."""
+
+    @staticmethod
+    def forward(ctx, x, noise, std, clamp01):
+        x = x.float().contiguous()
+        y = torch.empty_like(x)
+        L.call("aql_add_gauss_noise", L.ptr(x), L.ptr(noise), float(std), int(clamp01), x.numel(), L.ptr(y), L.stream_ptr())
+        ctx.clamp01 = bool(clamp01)
+        if clamp01:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.clamp01:
+            return dy, None, None, None
+        (y,) = ctx.saved_tensors
+        return dy * ((y > 0) & (y < 1)).to(dy.dtype), None, None, None
 
 
 def add_gaussian_noise(x, std, clamp01=False, noise=None):
     if not x.is_cuda:
         raise L.AqlError("add_gaussian_noise: the HIP path needs a GPU tensor; there is no CPU fallback")
-    x = x.float().contiguous()
-    noise = torch.randn_like(x) if noise is None else noise.float().contiguous()
-    y = torch.empty_like(x)
-    L.call("aql_add_gauss_noise", L.ptr(x), L.ptr(noise), float(std), int(clamp01), x.numel(), L.ptr(y), L.stream_ptr())
-    return y
+    noise = torch.randn(x.shape, device=x.device, dtype=torch.float32) if noise is None else noise.float().contiguous()
+    return _GaussNoiseFn.apply(x, noise, float(std), bool(clamp01))
 
 
 class CropandResize(nn.Module):
@@ -147,16 +184,18 @@ class CropandResize(nn.Module):
 
 
 class GaussianBlur(nn.Module):
-    """noises.py:59-70 (kornia RandomGaussianBlur((3,9),(0,max)) -- kernel size and sigma sampling recalled)."""
+    """noises.py:59-70: kornia 0.6.12 ``RandomGaussianBlur((3, 9), (0, max), p=1)`` -- a FIXED anisotropic kernel of 3 rows x
+    9 columns (kornia's kernel_size is (ky, kx)), reflect border, one sigma ~ U(0, max) per SAMPLE (recalled from the
+    published implementation; kornia is not on disk)."""
 
     def __init__(self, blur=2.0):
         super().__init__()
         self.gaussian_blur_max = blur
 
     def forward(self, noised_and_cover):
-        k = int(np.random.choice([3, 5, 7, 9]))
-        sigma = max(1e-3, np.random.rand() * self.gaussian_blur_max)
-        noised_and_cover[0] = gaussian_blur(noised_and_cover[0], k, sigma)
+        x = noised_and_cover[0]
+        sigma = torch.from_numpy(np.random.rand(x.shape[0]) * self.gaussian_blur_max).float().clamp_min(1e-3)
+        noised_and_cover[0] = gaussian_blur(x, (3, 9), sigma)
         return noised_and_cover
 
 
@@ -383,14 +422,14 @@ def eval_distorsion_unit(encoded_image, type):
 
 def distorsion_unit(encoded_image, type):
     """noiser.py:46-71 (rob-finetune): 'color_jitter' (.8-1.2, hue +-.1), 'crop' (432..512 window -> 512x512), 'blur'
-    (k in 3..5, sigma 4), 'noise' (std 0.1, clamp to [0,1])."""
+    (3 x 5 kernel, sigma 4), 'noise' (std 0.1, clamp to [0,1])."""
     if type == "crop":
         ch, cw = np.random.randint(432, 512), np.random.randint(432, 512)
         H, W = encoded_image.shape[2:]
         top, left = np.random.randint(0, H - ch + 1), np.random.randint(0, W - cw + 1)
         return crop_resize(encoded_image, top, left, ch, cw, 512, 512)
-    if type == "blur":
-        return gaussian_blur(encoded_image, int(np.random.choice([3, 5])), 4.0)
+    if type == "blur":   # RandomGaussianBlur((3, 5), (4.0, 4.0)): fixed 3-row x 5-column kernel, sigma 4
+        return gaussian_blur(encoded_image, (3, 5), 4.0)
     if type == "noise":
         return add_gaussian_noise(encoded_image, 0.1, clamp01=True)
     if type == "color_jitter":

@@ -260,6 +260,7 @@ class DeferredDW:
             self.dev[k] = torch.zeros_like(self.host[k], device=device)
         self.ds_host = torch.zeros(max_sites * self.DS_BYTES, dtype=torch.uint8).pin_memory()
         self.ds_dev = torch.zeros_like(self.ds_host, device=device)
+        self._uploads = []   # events recorded behind the async H2D copies of the tables (eager mode only)
         self.reset()
 
     def reset(self):
@@ -274,9 +275,26 @@ class DeferredDW:
     def n_tn(self):
         return self.n["n"] + self.n["w"]
 
+    def _host_tables_free(self):
+        """Pinned memory does not protect an in-flight async H2D copy from later host writes: before the FIRST descriptor
+        of a new step is written, wait until the previous step's table uploads have executed (the CPU can run a whole
+        step ahead of a GPU-bound stream).  No-op while capturing (a captured memcpy node reads the table at every
+        replay: a capture owns its DeferredDW, see PPFTTrainer.capture)."""
+        if self._uploads:
+            for ev in self._uploads:
+                ev.synchronize()
+            self._uploads = []
+
+    def _uploaded(self):
+        if not torch.cuda.is_current_stream_capturing():
+            ev = torch.cuda.Event()
+            ev.record()
+            self._uploads.append(ev)
+
     def add_tn(self, U, V, C, alpha=1.0):
         """C[P,Q] += alpha * U^T V;  always taken (returns True): grouped when a table accepts it, else held back as a
         direct launch that `flush` / `run_bucket` issues."""
+        self._host_tables_free()
         # the transpose-read kernel takes every problem (128x32 tiles for a rank <= 32 side); the register-transposing
         # kernel is the fallback (AQL_TN_OLD=1 prefers it, for comparison)
         kinds = ("n", "w") if os.environ.get("AQL_TN_OLD") else ("w", "n")
@@ -296,6 +314,7 @@ class DeferredDW:
         return True
 
     def add_ds(self, dTs, T, dS, nb, rps, r):
+        self._host_tables_free()
         slot = self.ds_host.data_ptr() + self.n_ds * self.DS_BYTES
         nblk = L.call_raw("aql_ds_desc_fill", L.c_p(slot), L.ptr(dTs), L.ptr(T), nb, rps, r, L.ptr(dS), self.blk_ds)
         if nblk <= 0:
@@ -309,6 +328,7 @@ class DeferredDW:
         if self.n_ds:
             nbytes = self.n_ds * self.DS_BYTES
             self.ds_dev[:nbytes].copy_(self.ds_host[:nbytes], non_blocking=True)
+            self._uploaded()
             L.call("aql_lora_ds_grouped", L.ptr(self.ds_dev), self.n_ds, self.blk_ds, L.stream_ptr())
         self.n_ds = self.blk_ds = 0
 
@@ -316,6 +336,7 @@ class DeferredDW:
         nbytes, _, _, entry = self.KINDS[k]
         lo, hi = first * nbytes, (first + n) * nbytes
         self.dev[k][lo:hi].copy_(self.host[k][lo:hi], non_blocking=True)
+        self._uploaded()
         L.call(entry, L.ptr(self.dev[k]), first, n, base, nblk, L.stream_ptr())
 
     def flush_tn(self):

@@ -39,6 +39,14 @@ class PPFTTrainer:
         self.mapper.to(dev)
         self.sec_encoder.to(dev)
         self.bank = LoraBank(unet, extra_params=[mapper.bit_embeddings.weight])
+        self.pg = process_group
+        # DDP broadcasts rank 0's parameters when it wraps the trainable modules (accelerator.prepare,
+        # ppft_train.py:905-912).  inject_lora draws N(0, 1/r) and MapperNet an orthogonal table from each process's own
+        # RNG (the reference default is seed=None): without this sync every rank would train a different replica on
+        # averaged gradients.  All trainable state (LoRA + mapper) lives in the one flat buffer.
+        if dp.world_size(process_group) > 1:
+            dp.broadcast_(self.bank.flat, process_group, src=0)
+            self.bank.refresh()
         self.scheduler = customDDPMScheduler(device=dev)
         self.hp = (adam_beta1, adam_beta2, adam_epsilon, adam_weight_decay)
         self.max_grad_norm = max_grad_norm
@@ -51,7 +59,6 @@ class PPFTTrainer:
         self.ds_accum = None
         self.micro = micro_batches
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(2 * max(1, micro_batches))]
-        self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         # data parallel: weight-gradient GEMMs run in buckets, each followed by its slice of the all-reduce (see
         # exchange_bucketed); single GPU: one grouped launch at the end of backward, no collective
@@ -195,11 +202,17 @@ class PPFTTrainer:
         # thread_local capture mode: with a process group alive, RCCL's watchdog thread polls hipEventQuery on the
         # warm-up collectives; under the default global mode that call is illegal while ANY thread captures and aborts
         # the process ("operation not permitted when stream is capturing") -- found with AQL_FORCE_ALLREDUCE=1.
+        # the captured memcpy nodes re-read the pinned descriptor tables at every replay: the capture gets its own
+        # DeferredDW so that a later eager step() cannot rewrite them
+        eager_deferred = self.deferred
+        self.deferred = ops.DeferredDW(eager_deferred.device, defer_wide=False)
         with torch.cuda.graph(g_fb, capture_error_mode="thread_local"):
             loss, _, _ = self.forward_backward(**static)
         with torch.cuda.graph(g_opt, pool=g_fb.pool(), capture_error_mode="thread_local"):
             self.optimizer_step()
-        self._graphs = (g_fb, g_opt, static, loss)
+        captured = self.deferred
+        self.deferred = eager_deferred
+        self._graphs = (g_fb, g_opt, static, loss, captured)
 
         def run(z, msg, eps, t, ctx):
             for k, v in (("z", z), ("msg", msg), ("eps", eps), ("t", t), ("ctx", ctx)):

@@ -89,6 +89,11 @@ class Stage1Step:
         self.msgloss_10buffer = []
         self.warmup = True
 
+    def new_epoch(self):
+        """Call at the start of every epoch: the reference re-creates the 10-batch message-loss window per epoch
+        (latent_wm_pretrain.py:163), so the warm-up exit test never mixes batches of two epochs."""
+        self.msgloss_10buffer = []
+
     def losses(self, latents, msg, epochs_done=0, resumed=False, combine=None, noiser_choice=None):
         _, wm_latent = self.sec_encoder(latents, msg.float())
         combine = dict(combine or {})
@@ -123,6 +128,14 @@ class Stage1Step:
             loss = msgloss
         return {"loss": loss, "msgloss": msgloss, "lpips_loss": lpips_loss, "prvl_loss": prvl_loss,
                 "logits": reveal_output, "watermarked_image": watermarked_image}
+
+
+def prepare_rob_finetune(msgdecoder, process_group=None):
+    """What ``accelerator.prepare(msgdecoder)`` does in rob_enhance_finetune.py:917-919 besides moving the module: DDP's
+    construction-time broadcast of rank 0's parameters and buffers, so that every rank fine-tunes the same decoder."""
+    from . import dp
+    dp.broadcast_module_(msgdecoder, process_group)
+    return msgdecoder
 
 
 def rob_finetune_step(msgdecoder, optimizer, images01, secret_bits, distort=None, process_group=None):

@@ -54,14 +54,17 @@ def build(device, rank, seed=2048, micro=1):
     return tr
 
 
-def synthetic_batch(B, device, rank_id, seed=2048):
+def synthetic_batch(B, device, rank_id, seed=2048, step=0):
+    """One synthetic batch, resident in HBM.  ``step`` selects an independent draw (fresh latents, messages, noise and
+    timesteps for every step, like a data loader would deliver them)."""
     from aqualora_amd import synth
     s = seed + 977 * rank_id
-    return dict(z=synth.normal("bench.z", (B, 4, 64, 64), 1.0, s, device),
-                msg=synth.bits("bench.msg", (B, 48), s, device),
-                eps=synth.normal("bench.eps", (B, 4, 64, 64), 1.0, s, device),
-                t=synth.randint("bench.t", (B,), 1000, s, device),
-                ctx=synth.normal("bench.ctx", (B, 77, 768), 1.0, s, device).to(torch.bfloat16))
+    tag = "" if step == 0 else f".{step}"
+    return dict(z=synth.normal("bench.z" + tag, (B, 4, 64, 64), 1.0, s, device),
+                msg=synth.bits("bench.msg" + tag, (B, 48), s, device),
+                eps=synth.normal("bench.eps" + tag, (B, 4, 64, 64), 1.0, s, device),
+                t=synth.randint("bench.t" + tag, (B,), 1000, s, device),
+                ctx=synth.normal("bench.ctx" + tag, (B, 77, 768), 1.0, s, device).to(torch.bfloat16))
 
 
 def time_kernel(fn, iters=20):
@@ -275,20 +278,44 @@ def robft_bench(args, device):
     distort = NZ.RobNoiser([0.6, 0.1, 0.15, 0.05, 0.1])
     gen = None
     if args.robft_sample:
-        # the whole iteration of rob_enhance_finetune.py:997-1036: 20-step DPM-Solver++ sampling of the batch (CFG 7.5) on the
-        # fused-LoRA U-Net -> frozen VAE decode -> [0,1] images -> distortion -> decoder training step
+        # the whole iteration of rob_enhance_finetune.py:997-1036: a fresh random message per image -> S = mapper(m) * 1.03,
+        # concatenated for the two CFG halves (:999-1002) -> 20-step DPM-Solver++ sampling (CFG 7.5) through the UN-fused
+        # rank-r watermark LoRA at a random resolution from {512..768}^2 (:1004-1005) -> frozen VAE decode -> 8-bit
+        # quantised [0,1] images (:1015-1021) -> distortion -> decoder training step on THOSE messages
+        import random
         from aqualora_amd.inference import dpm_solver_sample
-        from aqualora_amd.unet import UNet2DConditionModel, init_synthetic
+        from aqualora_amd.lora import inject_lora, patch_lora_forwards
+        from aqualora_amd.unet import UNet2DConditionModel, init_synthetic, lora_keys
         from aqualora_amd.vae import SD15_VAE, AutoencoderKL, synthetic_state_dict
+        from aqualora_amd.watermark import MapperNet
+        r = args.rank
         unet = UNet2DConditionModel(device=device, dtype=torch.bfloat16)
         init_synthetic(unet, 2048)
+        keys = lora_keys(unet)
+        inject_lora(unet, r, keys)
+        with torch.no_grad():
+            for k in keys:
+                lay = unet.get_submodule(k).lora_layer
+                lay.down.weight.copy_(synth.normal(k + ".lora.down", lay.down.weight.shape, 1.0 / r, 2048, device))
+                lay.up.weight.copy_(synth.normal(k + ".lora.up", lay.up.weight.shape, 0.02, 2048, device))
+        patch_lora_forwards(unet)
+        mapper = MapperNet(48, r).to(device)
         vae = AutoencoderKL(synthetic_state_dict(SD15_VAE, device=device), SD15_VAE, device)
         ctx = synth.normal("rob.ctx", (B, 77, 768), 1.0, 1, device)
-        lat = synth.normal("rob.lat", (B, 4, 64, 64), 1.0, 1, device)
+        rng = random.Random(2048)
+        sizes = [512, 576, 640, 704, 768] if args.robft_res == "random" else [int(args.robft_res)]
+        it = [0]
 
         def gen():
-            z = dpm_solver_sample(unet, ctx, torch.zeros_like(ctx), lat, 20, 7.5)
-            return (vae.decode(z.clamp(-4, 4) * 0.18215) / 2 + 0.5).clamp(0, 1)
+            it[0] += 1
+            bits.copy_(synth.bits(f"rob.bits{it[0]}", (B, 48), 1).to(device))
+            with torch.no_grad():
+                S = mapper(bits.float()).to(torch.bfloat16) * 1.03
+            h, w = rng.choice(sizes) // 8, rng.choice(sizes) // 8
+            lat = synth.normal(f"rob.lat{it[0]}", (B, 4, h, w), 1.0, 1, device)
+            z = dpm_solver_sample(unet, ctx, torch.zeros_like(ctx), lat, 20, 7.5, scale=S)
+            img = (vae.decode(z.clamp(-4, 4) * 0.18215) / 2 + 0.5).clamp(0, 1)
+            return torch.round(img.float() * 255.0) / 255.0
 
     def iteration():
         return S1.rob_finetune_step(dec, opt, gen() if gen is not None else imgs, bits, distort)
@@ -305,62 +332,16 @@ def robft_bench(args, device):
     print(json.dumps({"metric": "rob-finetune decoder step images/sec at 512x512 (EfficientNet-B1 train mode, fp32)",
                       "value": B / dt, "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "ms_per_step": 1e3 * dt,
                       "dtype": "f32", "higher_is_better": True, "data": "synthetic", "batch": B,
-                      "config": {"workload": "20-step DPM-Solver++ sampling + VAE decode + distortion + decoder fwd/bwd/AdamW"
+                      "config": {"workload": f"per-image messages, 20-step DPM-Solver++ sampling through the un-fused rank-{args.rank} LoRA "
+                                             f"(res {args.robft_res}) + VAE decode + distortion + decoder fwd/bwd/AdamW"
                                  if gen is not None else "distortion + decoder fwd/bwd/AdamW on given images"},
                       "achieved_tflops_fp32": gf / dt / 1e3, "loss": float(loss), "bit_acc": float(acc)}), flush=True)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rank", type=int, default=32)
-    ap.add_argument("--batch", type=int, default=4)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--robft-sample", action="store_true",
-                    help="robft mode: generate the batch inside the timed iteration (20-step DPM-Solver++, VAE decode)")
-    ap.add_argument("--infer-batch", type=int, default=1, help="infer mode: images sampled together")
-    ap.add_argument("--text-in", action="store_true",
-                    help="train mode: run the frozen CLIP text encoder (ids [B,77] -> [B,77,768]) inside every timed step")
-    ap.add_argument("--pixel-in", action="store_true",
-                    help="train mode: run the frozen VAE encode (3x512x512 -> 4x64x64) inside every timed step")
-    ap.add_argument("--mode", choices=["train", "infer", "robft", "vae"], default="train",
-                    help="train: the PPFT step (BASELINE metric); infer: 50-step DDIM + CFG latent sampling (config 4)")
-    ap.add_argument("--micro", type=int, default=1, help="concurrent micro-batch slices per step")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank_id = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    launched = "RANK" in os.environ  # under torch.distributed.run (also for N=1, so the RCCL path is the one measured)
-    if launched:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
-
-    if args.mode == "infer":
-        return infer_bench(args, device)
-    if args.mode == "vae":
-        return vae_bench(args, device)
-    if args.mode == "robft":
-        return robft_bench(args, device)
-    tr = build(device, args.rank, micro=args.micro)
-    batch = synthetic_batch(args.batch, device, rank_id)
-    runner = tr.step
-    if not args.no_graph and hasattr(tr, "capture"):
-        runner = tr.capture(batch)
-
-    def barrier():
-        if launched:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    if args.pixel_in:
-        # the reference's own step starts from pixels (ppft_train.py:993): frozen VAE encode of the batch on the HIP
-        # kernels in front of the captured step (the CLIP text encoder stays outside: ctx is injected)
+def wrap_pixel_text(runner, args, device, rank_id, pixel, text):
+    """The reference's own step starts from pixels and token ids (ppft_train.py:993, 1014-1019): optionally put the frozen
+    VAE encode and / or the frozen CLIP text encoder (both on the HIP kernels) in front of the captured latent-in step."""
+    if pixel:
         from aqualora_amd import synth
         from aqualora_amd.vae import SD15_VAE, AutoencoderKL, synthetic_state_dict
         vae = AutoencoderKL(synthetic_state_dict(SD15_VAE, device=device), SD15_VAE, device)
@@ -373,9 +354,7 @@ def main():
             return latent_runner(**b)
 
         runner.is_graph = getattr(latent_runner, "is_graph", False)
-
-    if args.text_in:
-        # ... and from token ids (ppft_train.py:1014-1019): frozen CLIP text encoder on the HIP kernels in front of the step
+    if text:
         from aqualora_amd import synth
         from aqualora_amd.clip import SD15_CLIP, CLIPTextModel, clip_keys
         csd = {}
@@ -394,15 +373,87 @@ def main():
             return prev_runner(**b)
 
         runner.is_graph = getattr(prev_runner, "is_graph", False)
+    return runner
 
-    for _ in range(args.warmup):
-        loss = runner(**batch)
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3],
+                    help="BASELINE.json config: 2 = rank 32, batch 4/GPU (the headline, 1 GPU); 3 = rank 320, batch 8/GPU "
+                         "(the 8-GPU DDP recipe, train/README.md:34-48); --rank / --batch override")
+    ap.add_argument("--rank", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--no-extras", action="store_true", help="skip the pixel+text-in timing (VAE encode + CLIP inside the step)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--robft-sample", action="store_true",
+                    help="robft mode: generate the batch inside the timed iteration (20-step DPM-Solver++, VAE decode)")
+    ap.add_argument("--robft-res", default="random", help="robft --robft-sample: 'random' ({512..768}^2 like the reference) or a size")
+    ap.add_argument("--infer-batch", type=int, default=1, help="infer mode: images sampled together")
+    ap.add_argument("--text-in", action="store_true",
+                    help="train mode: run the frozen CLIP text encoder (ids [B,77] -> [B,77,768]) inside every timed step")
+    ap.add_argument("--pixel-in", action="store_true",
+                    help="train mode: run the frozen VAE encode (3x512x512 -> 4x64x64) inside every timed step")
+    ap.add_argument("--mode", choices=["train", "infer", "robft", "vae"], default="train",
+                    help="train: the PPFT step (BASELINE metric); infer: 50-step DDIM + CFG latent sampling (config 4)")
+    ap.add_argument("--micro", type=int, default=1, help="concurrent micro-batch slices per step")
+    args = ap.parse_args()
+    preset = {2: (32, 4), 3: (320, 8)}[args.config]
+    args.rank = preset[0] if args.rank is None else args.rank
+    args.batch = preset[1] if args.batch is None else args.batch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank_id = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    launched = "RANK" in os.environ  # under torch.distributed.run (also for N=1, so the RCCL path is the one measured)
+    rccl_ranks_seen = 1
+    if launched:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+        one = torch.ones(1, device=device)
+        dist.all_reduce(one)           # a real RCCL collective: every rank that is really there adds 1
+        rccl_ranks_seen = int(one.item())
+
+    if args.mode == "infer":
+        return infer_bench(args, device)
+    if args.mode == "vae":
+        return vae_bench(args, device)
+    if args.mode == "robft":
+        return robft_bench(args, device)
+    tr = build(device, args.rank, micro=args.micro)
+    batch = synthetic_batch(args.batch, device, rank_id)
+    runner = tr.step
+    if not args.no_graph and hasattr(tr, "capture"):
+        runner = tr.capture(batch)
+
+    def barrier():
+        if launched:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    runner = wrap_pixel_text(runner, args, device, rank_id, args.pixel_in, args.text_in)
+
+    # every step gets its own batch (fresh z / msg / eps / t / ctx), all generated up front so that the timed region
+    # only contains device-to-device copies into the captured step's static buffers
+    nset = min(args.steps, 16)
+    batches = [batch] + [synthetic_batch(args.batch, device, rank_id, step=i) for i in range(1, max(nset, 1))]
+    for i in range(args.warmup):
+        loss = runner(**batches[i % len(batches)])
     barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = runner(**batch)
+    for i in range(args.steps):
+        evs[i][0].record()            # torch's current stream == the stream every C-ABI launch and graph replay uses
+        loss = runner(**batches[i % len(batches)])
+        evs[i][1].record()
     barrier()
     dt = time.perf_counter() - t0
+    per_step = sorted(a.elapsed_time(b) for a, b in evs)
     if launched:
         tt = torch.tensor([dt], device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -417,11 +468,13 @@ def main():
         line = {
             "metric": "PPFT train-step images/sec at 512x512", "value": value, "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "ms_per_step_hip_event_median": per_step[len(per_step) // 2], "ms_per_step_hip_event_min": per_step[0],
+            "rccl_ranks_seen": rccl_ranks_seen,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"SD1.5 PPFT LoRA rank={args.rank}, 48-bit msg, 512x512 (64x64x4 latents in), "
                                    f"batch={args.batch}/GPU, " + ("pixel-in (frozen VAE encode inside the step" + (", CLIP text encoder inside" if args.text_in else ", CLIP outside") + ")"
                                                                   if args.pixel_in else "latent-in (VAE/CLIP outside the path)"),
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(getattr(runner, "is_graph", False)),
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "baseline_config": args.config, "inputs": "fresh random batch every step", "hip_graph": bool(getattr(runner, "is_graph", False)),
                        "loss": loss_v},
         }
         with torch.no_grad():
@@ -439,11 +492,28 @@ def main():
         line["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_tflops"],
                             "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": dom["frac_of_mfma_peak"],
                             "traffic": traffic, "traffic_unit": "bytes/launch (algorithmic: 22.8e6)",
+                            "traffic_source": None if traffic is None else
+                            "static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel+shape, " + os.path.basename(pmc_path),
                             "flops_per_launch": dom["flops"], "ms_per_launch": dom["ms"]}
         line["step_roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
                                  "frac": achieved / MFMA_PEAK_TF,
                                  "launch": f"one PPFT step = {tf_img:.3f} TFLOP/image x {args.batch} images"}
         line["kernels"] = ks
+        if world == 1 and not args.no_extras and not (args.pixel_in or args.text_in):
+            # the reference's real step boundary: pixels and token ids in (frozen VAE encode + CLIP text encoder inside)
+            full = wrap_pixel_text(runner, args, device, rank_id, True, True)
+            n_x = max(3, min(args.steps, 10))
+            for i in range(2):
+                full(**batches[i % len(batches)])
+            torch.cuda.synchronize()
+            tx = time.perf_counter()
+            for i in range(n_x):
+                full(**batches[i % len(batches)])
+            torch.cuda.synchronize()
+            dtx = (time.perf_counter() - tx) / n_x
+            line["pixel_text_in"] = {"value": args.batch / dtx, "unit": "images/sec", "ms_per_step": 1e3 * dtx, "steps": n_x,
+                                     "workload": "same step with the frozen VAE encode (3x512x512 -> 4x64x64) and CLIP text "
+                                                 "encoder (ids [B,77] -> [B,77,768]) inside, ppft_train.py:993,1014-1019"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tr, args.rank)
         print(json.dumps(line), flush=True)

@@ -184,6 +184,10 @@ int aql_crop_resize_bilinear(const float* src, float* dst, int BC, int H, int W,
                              int oh, int ow, int backward, aql_stream_t stream);
 int aql_gauss_blur(const float* src, float* dst, float* tmp, int BC, int H, int W, int k, const float* taps, int backward,
                    aql_stream_t stream);
+/* kornia RandomGaussianBlur((ky, kx), sigma) as the reference calls it (noises.py:68 (3,9); noiser.py:63 (3,5);
+ * utils_eval.py:280 (3,3)): anisotropic separable kernel, reflect border, taps shared or one row per sample            */
+int aql_gauss_blur2(const float* src, float* dst, float* tmp, int B, int C, int H, int W, int kx, int ky,
+                    const float* taps_x, const float* taps_y, int per_sample, int backward, aql_stream_t stream);
 int aql_add_gauss_noise(const float* x, const float* noise, float std, int clamp01, long n, float* y,
                         aql_stream_t stream);
 /* kornia ColorJiggle as called at noises.py:97-103, noiser.py:52-57, utils_eval.py:271-276 (kornia 0.6.12, recalled):

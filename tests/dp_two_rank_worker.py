@@ -1,0 +1,64 @@
+"""GPU worker for test_two_rank_rccl_replicas_stay_identical (run under torch.distributed.run, one process per GPU):
+PPFTTrainer on the tiny U-Net with rank-dependent seeds for the LoRA / mapper initialisation and rank-dependent data."""
+import json
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", device_id=dev)
+    one = torch.ones(1, device=dev)
+    dist.all_reduce(one)
+    from aqualora_amd import synth
+    from aqualora_amd.lora import inject_lora
+    from aqualora_amd.ppft import PPFTTrainer
+    from aqualora_amd.unet import lora_keys
+    from aqualora_amd.watermark import MapperNet, SecretEncoder
+    from tests.common import TINY_RANK, ppft_inputs, tiny_unet
+    torch.manual_seed(1000 + rank)             # every rank draws its OWN LoRA / mapper initialisation
+    unet = tiny_unet(dev, torch.bfloat16)
+    inject_lora(unet, TINY_RANK, lora_keys(unet))
+    with torch.no_grad():                       # diffusers initialises up = 0: make the branch live
+        for m in unet.modules():
+            if hasattr(m, "up") and hasattr(m, "down"):
+                m.up.weight.normal_(0, 0.05)
+    mapper = MapperNet(48, TINY_RANK)
+    first = torch.cat([p.detach().float().reshape(-1).to(dev) for p in unet.parameters() if p.requires_grad][:4])
+    gathered = [torch.zeros_like(first) for _ in range(world)]
+    dist.all_gather(gathered, first)
+    differs = not torch.equal(gathered[0], gathered[1])
+    tr = PPFTTrainer(unet, mapper, SecretEncoder(48, base_res=8, resolution=16), TINY_RANK, learning_rate=1e-3)
+
+    def same():
+        flat = tr.bank.flat.clone()
+        ref = flat.clone()
+        dist.broadcast(ref, src=0)
+        ok = torch.tensor([float(torch.equal(flat, ref))], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        return bool(ok.item())
+
+    eq0 = same()
+    start = tr.bank.flat.clone()
+    for i in range(3):
+        inp = ppft_inputs(device=dev)
+        s = 7000 + 13 * rank + i                # rank-dependent data
+        tr.step(synth.normal("w.z", inp["z"].shape, 1.0, s, dev), synth.bits("w.msg", inp["msg"].shape, s, dev),
+                synth.normal("w.eps", inp["eps"].shape, 1.0, s, dev), synth.randint("w.t", inp["t"].shape, 1000, s, dev),
+                synth.normal("w.ctx", inp["ctx"].shape, 1.0, s, dev).to(torch.bfloat16))
+    torch.cuda.synchronize()
+    eq3 = same()
+    moved = bool((tr.bank.flat - start).abs().max().item() > 0)
+    if rank == 0:
+        print(json.dumps({"world": world, "rccl_ranks_seen": int(one.item()), "init_differs_before_broadcast": differs,
+                          "params_equal_after_init": eq0, "params_equal_after_steps": eq3, "params_moved": moved}), flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

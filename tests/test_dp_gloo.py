@@ -49,6 +49,20 @@ def _worker(rank, world, port, q):
     net[1].running_mean.fill_(float(rank + 1))
     dp.broadcast_buffers_(net)
     ok_mod = ok_mod and float(net[1].running_mean[0]) == 1.0
+    # construction-time parameter sync (DDP's broadcast from rank 0): ranks start from DIFFERENT draws (the reference
+    # default is seed=None) and must hold rank 0's values afterwards -- the flat trainable buffer of the PPFT trainer ...
+    flat = synth.normal("init.flat", (4099,), 1.0, seed=500 + rank)
+    dp.broadcast_(flat)
+    ok_mod = ok_mod and torch.equal(flat, synth.normal("init.flat", (4099,), 1.0, seed=500))
+    # ... and an ordinary module (the rob-finetune decoder): parameters and buffers
+    torch.manual_seed(1234 + rank)
+    net2 = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.BatchNorm1d(5))
+    net2[1].running_var.fill_(float(rank + 2))
+    dp.broadcast_module_(net2)
+    torch.manual_seed(1234)
+    ref2 = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.BatchNorm1d(5))
+    ok_mod = ok_mod and all(torch.equal(a_, b_) for a_, b_ in zip(net2.parameters(), ref2.parameters()))
+    ok_mod = ok_mod and float(net2[1].running_var[0]) == 2.0
     q.put((rank, torch.allclose(a, want, atol=1e-6), torch.equal(a, b) and ok_async and ok_mod,
            not torch.equal(gathered[0], gathered[1])))
     dist.destroy_process_group()

@@ -99,8 +99,18 @@ def test_watermark_modules_vs_reference_golden(golden):
     z, e = T("an.x", (4, 4, 64, 64), device=DEV), T("an.n", (4, 4, 64, 64), device=DEV)
     t = torch.tensor([0, 1, 500, 999], device=DEV)
     a, b = sch.add_noise_pair(z, c, e, t)
-    assert relerr(a, O.add_noise(z.cpu(), e.cpu(), t.cpu())) < 5e-3
-    assert relerr(b, O.add_noise((z + c).cpu(), e.cpu(), t.cpu())) < 5e-3
+    # the kernel computes the fp32 closed form and stores bf16 (the reference casts to weight_dtype): compare with the
+    # bf16 rounding of the oracle's fp32 result ELEMENT BY ELEMENT -- equal bits except where the two fp32 values straddle
+    # a rounding boundary (then exactly one bf16 ulp apart)
+    for got, want32 in ((a, O.add_noise(z.cpu(), e.cpu(), t.cpu())), (b, O.add_noise((z + c).cpu(), e.cpu(), t.cpu()))):
+        want = want32.to(torch.bfloat16)
+        got = got.cpu()
+        off = got != want
+        assert off.float().mean().item() < 2e-3, off.float().mean().item()
+        # half a bf16 ulp of rounding + the fp32 cancellation noise of the two products (fma contraction vs two roundings)
+        slack = (got.float() - want32).abs() - (2.0 ** -8 * want32.abs() + 1e-6)
+        assert slack.max().item() <= 0.0, slack.max().item()
+        assert l2rel(got.float(), want32) < 3e-3
 
 
 def _gpu_tiny(rank=TINY_RANK, up_std=0.1):
@@ -179,8 +189,120 @@ def test_full_size_sd15_unet_forward_vs_oracle():
     assert torch.equal(clean, clean0) and torch.equal(pred, pred2)
     assert relerr(clean, clean_o) < 4e-2, relerr(clean, clean_o)
     assert relerr(pred, pred_o) < 4e-2, relerr(pred, pred_o)
+    assert l2rel(clean, clean_o) < 2e-2 and l2rel(pred, pred_o) < 2e-2, (l2rel(clean, clean_o), l2rel(pred, pred_o))
     lora_effect = relerr(pred_o, clean_o)
-    assert lora_effect > 1e-3 and relerr(pred.float() - clean.float(), pred_o - clean_o) < 0.35
+    eff = l2rel(pred.float() - clean.float(), pred_o - clean_o)
+    print(f"full-size forward: clean {relerr(clean, clean_o):.3e} pred {relerr(pred, pred_o):.3e} "
+          f"LoRA effect {lora_effect:.3e}, effect l2rel {eff:.3e}")
+    assert lora_effect > 1e-3 and eff < 0.1, (lora_effect, eff)
+
+
+@pytest.mark.parametrize("rank", [32, 320])
+def test_full_size_ppft_gradients_vs_oracle(rank):
+    """BASELINE sizes (config 2: rank 32; configs 3 / 5: rank 320): ONE full PPFT step at batch 1 on the full SD-1.5 U-Net --
+    clean forward, watermarked forward, MSE, backward to all 384 LoRA tensors + the mapper -- HIP against the
+    bf16-mirroring CPU oracle (oracle.ppft_loss).  Checked: loss, predicted noise (max-norm AND L2), the gradient norm of
+    every one of the 384 tensors, and every full gradient tensor in relative L2 (worst / median stated below)."""
+    import os
+    from aqualora_amd import synth
+    from aqualora_amd.lora import inject_lora
+    from aqualora_amd.ppft import PPFTTrainer
+    from aqualora_amd.unet import SD15, UNet2DConditionModel, init_synthetic, lora_keys
+    from aqualora_amd.watermark import MapperNet, SecretEncoder
+    from oracle import ppft_oracle as O
+    seed = 2048
+    unet = UNet2DConditionModel(device=DEV, dtype=torch.bfloat16)
+    init_synthetic(unet, seed)
+    keys = lora_keys(unet)
+    sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
+    inject_lora(unet, rank, keys)
+    lo = {}
+    with torch.no_grad():
+        for k in keys:
+            lay = unet.get_submodule(k).lora_layer
+            lay.down.weight.copy_(synth.normal(k + ".lora.down", lay.down.weight.shape, 1.0 / rank, seed, DEV))
+            lay.up.weight.copy_(synth.normal(k + ".lora.up", lay.up.weight.shape, 0.02, seed, DEV))
+            lo[k] = (lay.down.weight.detach().float().cpu().clone().requires_grad_(True),
+                     lay.up.weight.detach().float().cpu().clone().requires_grad_(True))
+    mapper = MapperNet(48, rank)
+    E = synth.normal("fullg.E", (48, rank), 1.0, seed)
+    with torch.no_grad():
+        mapper.bit_embeddings.weight.copy_(E)
+    tr = PPFTTrainer(unet, mapper, SecretEncoder(48), rank)
+    z = synth.normal("fullg.z", (1, 4, 64, 64), 1.0, seed)
+    wm = synth.normal("fullg.wm", (1, 4, 64, 64), 0.05, seed)
+    eps = synth.normal("fullg.eps", (1, 4, 64, 64), 1.0, seed)
+    msg = synth.bits("fullg.msg", (1, 48), seed)
+    ctx = synth.normal("fullg.ctx", (1, 77, 768), 1.0, seed)
+    t = torch.tensor([500])
+    tr.sec_encoder.encode = lambda m, out_scale=1.0: wm.to(DEV)
+    loss, pred, clean = tr.forward_backward(z.to(DEV), msg.to(DEV), eps.to(DEV), t.to(DEV), ctx.to(DEV).to(torch.bfloat16))
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
+    Eo = E.clone().requires_grad_(True)
+    lo_loss, pred_o, clean_o, _ = O.ppft_loss(sd, dict(SD15), lo, Eo, msg, z, wm, eps, t, ctx, bf16=True)
+    lo_loss.backward()
+    assert relerr(clean, clean_o) < 4e-2 and relerr(pred, pred_o) < 4e-2
+    assert l2rel(clean, clean_o) < 2e-2 and l2rel(pred, pred_o) < 2e-2
+    assert abs(loss.item() - lo_loss.item()) < 0.1 * lo_loss.item(), (loss.item(), lo_loss.item())
+    gmax = max(p.grad.norm().item() for pr in lo.values() for p in pr)
+    rels, norm_err = [], []
+    for k in keys:
+        lay = unet.get_submodule(k).lora_layer
+        for got, want in ((lay.down.weight.grad, lo[k][0].grad), (lay.up.weight.grad, lo[k][1].grad)):
+            assert torch.isfinite(got).all()
+            wn = want.norm().item()
+            if wn > 1e-3 * gmax:      # tensors that carry signal: norm within 10 %, full tensor in relative L2
+                norm_err.append(abs(got.norm().item() - wn) / wn)
+                rels.append(l2rel(got, want.reshape(got.shape)))
+    rels_s = sorted(rels)
+    print(f"full-size r={rank} gradients: {len(rels)} tensors, l2rel median {rels_s[len(rels_s) // 2]:.3f} worst "
+          f"{rels_s[-1]:.3f}; norm error median {sorted(norm_err)[len(norm_err) // 2]:.3f} worst {max(norm_err):.3f}; "
+          f"loss {loss.item():.5e} vs {lo_loss.item():.5e}")
+    assert len(rels) >= 300
+    # measured on MI355X: r=32 median 0.019 / worst 0.042, r=320 median 0.038 / worst 0.069 (bf16 activations + weights)
+    assert rels_s[len(rels_s) // 2] < 0.06 and rels_s[-1] < 0.12, (rels_s[len(rels_s) // 2], rels_s[-1])
+    assert max(norm_err) < 0.05, max(norm_err)   # measured worst 0.010 (r=32) / 0.017 (r=320)
+    assert l2rel(mapper.bit_embeddings.weight.grad, Eo.grad) < 0.1
+
+
+def test_secret_decoder_vs_torchvision_live():
+    """SURVEY.md section 8(c) option 2: when the box's own Python has torchvision, pin the decoder to the real
+    ``efficientnet_b1`` (utils/models.py:84-96).  torchvision is absent from the build image, so this normally skips."""
+    tv = pytest.importorskip("torchvision")
+    from aqualora_amd import metrics
+    from oracle.decoder_oracle import secret_decoder
+    net = tv.models.efficientnet_b1(weights=None)
+    net.classifier[1] = torch.nn.Linear(1280, 96)
+    dec = _synthetic_decoder(48)
+    net.load_state_dict({k[len("model."):]: v for k, v in dec.state_dict().items()})
+    net.eval()
+    x = T("dec.tv.x", (2, 3, 512, 512), 0.5).clamp(-1, 1)
+    with torch.no_grad():
+        want = net(x).view(-1, 48, 2)
+        ours_cpu = secret_decoder({k: v.clone() for k, v in dec.state_dict().items()}, x, 48)
+    got = dec.to(DEV).eval()(x.to(DEV))
+    assert relerr(ours_cpu, want) < 1e-4 and relerr(got, want) < 1e-3
+    assert torch.equal(metrics.extract_bits(got).cpu(), metrics.extract_bits(want))
+
+
+def test_two_rank_rccl_replicas_stay_identical():
+    """Two processes, two GPUs, RCCL: ranks start from DIFFERENT seeds (the reference default, seed=None) and different
+    data; after the construction-time broadcast and 3 steps of averaged gradients the trainable state must be identical on
+    both ranks.  Skips on 1-GPU boxes (the driver's multi-GPU node runs it)."""
+    import json, os, subprocess, sys
+    from tests.conftest import ROOT
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29547", "-m", "tests.dp_two_rank_worker"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["world"] == 2 and res["rccl_ranks_seen"] == 2
+    assert res["init_differs_before_broadcast"] and res["params_equal_after_init"]
+    assert res["params_equal_after_steps"] and res["params_moved"], res
 
 
 def test_tiny_ppft_step_vs_golden(golden):
@@ -320,10 +442,13 @@ def test_secret_decoder_vs_oracle_bits_exact():
         got = dec(x.to(DEV))
         assert got.shape == want.shape == (shape[0], 48, 2)
         assert relerr(got, want) < 1e-3, relerr(got, want)
+        # north star: extracted bits bit-exact -- EVERY bit, no margin mask (fp32 kernels against the fp32 oracle)
+        bits_got, bits_want = metrics.extract_bits(got).cpu(), metrics.extract_bits(want)
+        mism = int((bits_got != bits_want).sum())
         margin = (want[..., 0] - want[..., 1]).abs()
-        sure = margin > 1e-3 * want.abs().max()
-        assert torch.equal(metrics.extract_bits(got).cpu()[sure], metrics.extract_bits(want)[sure])
-        assert sure.float().mean() > 0.95
+        print(f"decoder {shape}: {mism} of {bits_want.numel()} bits differ; smallest logit margin "
+              f"{margin.min().item():.3e} (logit scale {want.abs().max().item():.3e}, logits relerr {relerr(got, want):.2e})")
+        assert mism == 0, (shape, mism)
     msg = metrics.extract_bits(want)
     acc, tpr = metrics.tpr_at_fpr(metrics.extract_bits(got).cpu(), msg, 1e-6)
     assert acc == 1.0 and tpr == 1.0
@@ -398,9 +523,32 @@ def test_distortion_maps_vs_torch():
         dy2 = T("dist.dy2", (2, 3, 64, 48), device=DEV)
         y2.backward(dy2); yr2.backward(dy2)
         assert relerr(y2, yr2) < 1e-5 and relerr(x2.grad, xr2.grad) < 1e-5
+    # kornia RandomGaussianBlur((3, 9), ...) as noises.py:68 calls it: 3 rows x 9 columns, one sigma per sample
+    sig = torch.tensor([0.6, 3.5])
+    x3 = T("dist.x3", (2, 3, 40, 56), 0.5, DEV).requires_grad_(True)
+    y3 = NZ.gaussian_blur(x3, (3, 9), sig)
+    xr3 = x3.detach().clone().requires_grad_(True)
+    rows = []
+    for i in range(2):
+        ty, tx = NZ.gaussian_taps(3, float(sig[i]), DEV), NZ.gaussian_taps(9, float(sig[i]), DEV)
+        w3 = (ty[:, None] * tx[None, :])[None, None].repeat(3, 1, 1, 1)
+        rows.append(F.conv2d(F.pad(xr3[i:i + 1], (4, 4, 1, 1), mode="reflect"), w3, groups=3))
+    yr3 = torch.cat(rows)
+    dy3 = T("dist.dy3", (2, 3, 40, 56), device=DEV)
+    y3.backward(dy3); yr3.backward(dy3)
+    assert relerr(y3, yr3) < 1e-5 and relerr(x3.grad, xr3.grad) < 1e-5
     n = T("dist.n", (2, 3, 64, 48), device=DEV)
     z = NZ.add_gaussian_noise(x2.detach(), 0.1, clamp01=True, noise=n)
     assert torch.allclose(z, (x2.detach() + 0.1 * n).clamp(0, 1), atol=1e-6)  # kernel contracts to one fma
+    # the additive noise is differentiable in x (kornia RandomGaussianNoise): identity gradient, masked by the clamp
+    for clamp in (False, True):
+        xn = (T("dist.xn", (2, 3, 64, 48), 0.4, DEV) + 0.5).requires_grad_(True)
+        yn = NZ.add_gaussian_noise(xn, 0.3, clamp01=clamp, noise=n)
+        assert yn.grad_fn is not None
+        yn.backward(dy2)
+        ref = (xn.detach() + 0.3 * n)
+        mask = ((ref > 0) & (ref < 1)).float() if clamp else torch.ones_like(ref)
+        assert torch.equal(xn.grad, dy2 * mask)
     out = NZ.distorsion_unit(T("dist.img", (1, 3, 512, 512), 0.2, DEV) + 0.5, "crop")
     assert out.shape == (1, 3, 512, 512)
 
