@@ -53,6 +53,22 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
+// erf(x) by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 -- two orders below fp32-in / bf16-out resolution of every
+// caller): one v_rcp, one v_exp and six FMAs instead of libm's branchy erff (~4x the VALU work).  The GEGLU activation
+// (scripts/lib/original_unet.py:721-729, F.gelu exact form) is VALU-bound inside a GEMM epilogue, where nothing overlaps it.
+// Used by the fused epilogue AND the stand-alone geglu kernels, so the two paths stay bit-identical to each other.
+__device__ __forceinline__ float aql_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f);
+  p = fmaf(t, p, -0.284496736f);
+  p = fmaf(t, p, 0.254829592f);
+  const float e = __expf(-ax * ax);
+  return copysignf(fmaf(-p * t, e, 1.f), x);
+}
+__device__ __forceinline__ float aql_gelu(float g) { return 0.5f * g * (1.f + aql_erf(g * 0.70710678118654752f)); }
+
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 

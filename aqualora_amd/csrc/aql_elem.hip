@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void geglu_fwd_kernel(const bf16_t* __restrict
     unpack8(*reinterpret_cast<const uint4*>(in + m * 2 * F + c), h);
     unpack8(*reinterpret_cast<const uint4*>(in + m * 2 * F + F + c), g);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = h[j] * (0.5f * g[j] * (1.f + erff(g[j] * 0.70710678118654752f)));
+    for (int j = 0; j < 8; ++j) o[j] = h[j] * aql_gelu(g[j]);
     *reinterpret_cast<uint4*>(out + m * F + c) = pack8(o);
   }
 }
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict
     unpack8(*reinterpret_cast<const uint4*>(dy + m * F + c), d);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float cdf = 0.5f * (1.f + erff(g[j] * 0.70710678118654752f));
+      const float cdf = 0.5f * (1.f + aql_erf(g[j] * 0.70710678118654752f));
       const float pdf = 0.3989422804014327f * __expf(-0.5f * g[j] * g[j]);
       dh[j] = d[j] * g[j] * cdf;
       dg[j] = d[j] * h[j] * (cdf + g[j] * pdf);

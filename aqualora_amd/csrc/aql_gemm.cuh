@@ -35,6 +35,9 @@ struct PlainLoader {
   long ld;
   int rows;
   int K;
+  // GEGLU tiles (EpiParams::geglu_F): tile-local row lr >= gsplit reads source row (row0 + lr + goff), so that one 160-row
+  // weight tile holds 80 "value" rows [n0, n0+80) and the matching 80 "gate" rows [F+n0, F+n0+80).  0 = plain rows.
+  int gsplit = 0, goff = 0;
 };
 
 // Forward 3x3 conv, NHWC input [B,Hin,Win,Cin]; row r = (b,ho,wo); k = (kh*3+kw)*Cin + ci.
@@ -84,6 +87,12 @@ struct EpiParams {
   const bf16_t* rowbias;   // [nsamples][rowbias_ld] added (bf16 add) after bias, before the residual; or null
   long rowbias_ld;
   int rows_per_sample;
+  // GEGLU epilogue (scripts/lib/original_unet.py:727-729), geglu_F = F > 0: the GEMM's N = 2F output columns are produced as
+  // [value | gate] column pairs inside one tile and  G[m][n] = value * gelu_erf(gate)  ([M][F]) is written; the pre-activation
+  // C ([M][2F]) is written only when C != null (the backward pass needs it, the frozen pass does not).
+  bf16_t* G = nullptr;
+  long ldg = 0;
+  int geglu_F = 0;
   int trans_out;           // EPI_ATOMIC only: write C^T, i.e. element (m,n) goes to Cf[n*ldcf + m]
   // EPI_SLAB / EPI_ATOMIC: fp32 output
   float* Cf;               // slab base [splits][M][ldcf] or atomic target [M][ldcf]
@@ -433,9 +442,11 @@ struct DmaStager<R, PlainLoader> {
     rs = in1 ? rs1 : make_rsrc(l0.base);
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const int r = row0 + (tid >> 3) + 32 * i;
+      const int lr = (tid >> 3) + 32 * i;
+      const int r = row0 + lr + ((l0.gsplit && lr >= l0.gsplit) ? l0.goff : 0);
+      const int r1 = row0 + lr + ((l1.gsplit && lr >= l1.gsplit) ? l1.goff : 0);
       const uint32_t v0 = r < l0.rows ? (uint32_t)r * (uint32_t)(l0.ld * 2) + kc * 2 : OOB_ROW;
-      voff1[i] = (dual && r < l1.rows) ? (uint32_t)r * (uint32_t)(l1.ld * 2) + kc * 2 : OOB_ROW;
+      voff1[i] = (dual && r1 < l1.rows) ? (uint32_t)r1 * (uint32_t)(l1.ld * 2) + kc * 2 : OOB_ROW;
       voff[i] = in1 ? voff1[i] : v0;
     }
     const int kend0 = min(l0.K, min(t_end, ktiles0) * BK);
@@ -595,6 +606,39 @@ struct DmaStager<R, ConvBwdLoader> {
   }
 };
 
+// ---- GEGLU epilogue helpers ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf(float g) { return aql_gelu(g); }
+
+// bias index of tile-local column `col` (a multiple of 4): plain tiles n0 + col; GEGLU tiles [value | gate] halves
+__device__ __forceinline__ int epi_bias_col(int n0, int col, int F, int half) {
+  return F == 0 ? n0 + col : (col < half ? n0 + col : F + n0 + col - half);
+}
+
+// The bf16 C tile [BM][BN] (value columns 0..BN/2-1, gate columns BN/2..BN-1) is staged in LDS: write
+// G[m][n0 + c] = value * gelu(gate) and, when ep.C != null, the two pre-activation halves.  NT = participating threads.
+template <int BM, int BN, int C_PITCH, int NT>
+__device__ __forceinline__ void geglu_store(const char* lds, int m0, int n0, int M, const EpiParams& ep, int tid) {
+  constexpr int HC = BN / 16;  // 16-byte chunks per half row
+  const int F = ep.geglu_F;
+  for (int id = tid; id < BM * HC; id += NT) {
+    const int row = id / HC, cc = id - row * HC;
+    const int m = m0 + row, n = n0 + cc * 8;
+    if (m >= M || n >= F) continue;
+    const uint4 v = *reinterpret_cast<const uint4*>(lds + row * C_PITCH + cc * 16);
+    const uint4 gt = *reinterpret_cast<const uint4*>(lds + row * C_PITCH + BN + cc * 16);
+    if (ep.C != nullptr) {
+      *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + n) = v;
+      *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + F + n) = gt;
+    }
+    uint4 o;
+    o.x = pack_bf16x2(bf16lo(v.x) * gelu_erf(bf16lo(gt.x)), bf16hi(v.x) * gelu_erf(bf16hi(gt.x)));
+    o.y = pack_bf16x2(bf16lo(v.y) * gelu_erf(bf16lo(gt.y)), bf16hi(v.y) * gelu_erf(bf16hi(gt.y)));
+    o.z = pack_bf16x2(bf16lo(v.z) * gelu_erf(bf16lo(gt.z)), bf16hi(v.z) * gelu_erf(bf16hi(gt.z)));
+    o.w = pack_bf16x2(bf16lo(v.w) * gelu_erf(bf16lo(gt.w)), bf16hi(v.w) * gelu_erf(bf16hi(gt.w)));
+    *reinterpret_cast<uint4*>(ep.G + (long)m * ep.ldg + n) = o;
+  }
+}
+
 template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG, int ABL = 0>
 __device__ __forceinline__ void gemm_body_d(const GemmArgs<LA, LB>& g, const int block_x, const int block_z) {
   static_assert(EPI != EPI_ATOMIC && !LA::kTrans, "bf16 / slab epilogues only");
@@ -623,7 +667,8 @@ __device__ __forceinline__ void gemm_body_d(const GemmArgs<LA, LB>& g, const int
     tile_m = block_x / tiles_n;
     tile_n = block_x - tile_m * tiles_n;
   }
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int gF = (EPI == EPI_BF16) ? g.epi.geglu_F : 0;  // GEGLU tiles: [80 value | 80 gate] columns
+  const int m0 = tile_m * BM, n0 = tile_n * (gF ? BN / 2 : BN);
 
   // K range of this split; tiles past kt_end read as zeros (K limit folded into the loaders)
   const int kt_total = g.ktiles0 + g.ktiles1;
@@ -714,8 +759,9 @@ __device__ __forceinline__ void gemm_body_d(const GemmArgs<LA, LB>& g, const int
       for (int j = 0; j < FN; ++j) {
         const int col = wn0 + j * 16 + (lane >> 4) * 4;
         float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-        if (ep.bias != nullptr && (n0 + col) < g.N) {
-          const uint2 bb = *reinterpret_cast<const uint2*>(ep.bias + n0 + col);
+        const int bc = epi_bias_col(n0, col, gF, BN / 2);
+        if (ep.bias != nullptr && bc < g.N) {
+          const uint2 bb = *reinterpret_cast<const uint2*>(ep.bias + bc);
           v0 += bf16lo(bb.x);
           v1 += bf16hi(bb.x);
           v2 += bf16lo(bb.y);
@@ -726,6 +772,8 @@ __device__ __forceinline__ void gemm_body_d(const GemmArgs<LA, LB>& g, const int
     }
     __syncthreads();
     constexpr int CPR = BN / 8;  // 16-byte chunks per row
+    if (gF) geglu_store<BM, BN, C_PITCH, NTHREADS>(lds, m0, n0, g.M, ep, tid);
+    else
     for (int id = tid; id < BM * CPR; id += NTHREADS) {
       const int row = id / CPR, cc = id - row * CPR;
       const int m = m0 + row, n = n0 + cc * 8;
@@ -821,7 +869,8 @@ __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int
     tile_m = block_x / tiles_n;
     tile_n = block_x - tile_m * tiles_n;
   }
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int gF = (EPI == EPI_BF16) ? g.epi.geglu_F : 0;  // GEGLU tiles: [80 value | 80 gate] columns
+  const int m0 = tile_m * BM, n0 = tile_n * (gF ? BN / 2 : BN);
 
   // K range of this split; tiles past kt_end read as zeros (K limit folded into the loaders)
   const int kt_total = g.ktiles0 + g.ktiles1;
@@ -953,8 +1002,9 @@ __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int
         for (int j = 0; j < FN; ++j) {
           const int col = wn0 + j * 16 + (lane >> 4) * 4;
           float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-          if (ep.bias != nullptr && (n0 + col) < g.N) {
-            const uint2 bb = *reinterpret_cast<const uint2*>(ep.bias + n0 + col);
+          const int bc = epi_bias_col(n0, col, gF, BN / 2);
+          if (ep.bias != nullptr && bc < g.N) {
+            const uint2 bb = *reinterpret_cast<const uint2*>(ep.bias + bc);
             v0 += bf16lo(bb.x);
             v1 += bf16hi(bb.x);
             v2 += bf16lo(bb.y);
@@ -966,6 +1016,8 @@ __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int
     }
     __syncthreads();
     constexpr int CPR = BN / 8;  // 16-byte chunks per row
+    if (gF) geglu_store<BM, BN, C_PITCH, 2 * NTHREADS>(lds, m0, n0, g.M, ep, tid);
+    else
     for (int id = tid; id < BM * CPR; id += 2 * NTHREADS) {
       const int row = id / CPR, cc = id - row * CPR;
       const int m = m0 + row, n = n0 + cc * 8;

@@ -7,6 +7,7 @@
 
 using namespace aqlgemm;
 
+#define AQL_NOT_FUSED 100
 static thread_local char g_err[512] = "";
 extern "C" const char* aql_last_error(void) { return g_err; }
 void aql_set_error(const char* fmt, ...) {
@@ -122,6 +123,9 @@ struct OutSpec {
   bf16_t* C2;
   long ldc2;
   const bf16_t* rowscale;
+  bf16_t* G = nullptr;  // GEGLU epilogue (EpiParams::geglu_F): activated output [M][geglu_F]
+  long ldg = 0;
+  int geglu_F = 0;
 };
 
 inline int pick_splits(int tiles, int kt_total, long M, int N, size_t ws_bytes) {
@@ -261,6 +265,9 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
   if (const char* e = getenv("AQL_MFAST")) g.m_fast = atoi(e);
   int tiles = 0, cfg = 0, pd = 1;
   pick_tile(g.M, g.N, kt_total, ws != nullptr && o.C2 == nullptr, &cfg, &tiles, &pd);
+  if (o.geglu_F > 0 && !(cfg == P_128x160 || cfg == P_64x160 || cfg == P_32x160 || cfg == P_W128x160 || cfg == P_W64x160 ||
+                         cfg == P_W32x160))
+    return AQL_NOT_FUSED;  // the [80 value | 80 gate] tile layout exists for the 160-wide tiles only
   int splits = 1;
   if (ws != nullptr && o.C2 == nullptr) splits = pick_splits(tiles, kt_total, g.M, g.N, ws_bytes);
   if ((cfg == P_W128x160 || cfg == P_W64x160 || cfg == P_W32x160) && splits > 1) {
@@ -299,6 +306,9 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
   g.epi.rowscale = o.rowscale;
   g.epi.rowbias = o.rowbias;
   g.epi.rowbias_ld = o.rowbias_ld > 0 ? o.rowbias_ld : (long)g.N;
+  g.epi.G = o.G;
+  g.epi.ldg = o.ldg;
+  g.epi.geglu_F = o.geglu_F;
   launch_cfg<LA, LB, EPI_BF16>(cfg, pd, g, stream);
   AQL_CHECK_LAUNCH(name);
   return AQL_OK;
@@ -344,6 +354,47 @@ extern "C" int aql_gemm_bf16(const bf16_t* A, long lda, const bf16_t* B, long ld
   g.N = N;
   OutSpec o{bias, rowbias, 0, rows_per_sample, residual, ldr, C, ldc, nullptr, 0, nullptr};
   return run_bf16_gemm(g, o, ws, ws_bytes, stream, "aql_gemm_bf16");
+}
+
+// ff.net.0.proj + GEGLU in one launch (scripts/lib/original_unet.py:727-729 on top of lora_modules.py:56-62):
+//   h = A.B^T (+ A2.B2^T) + bias            [M][2F]   (B: [2F][K], rows 0..F-1 "value", F..2F-1 "gate")
+//   G = h[:, :F] * gelu_erf(h[:, F:])       [M][F]
+// Every 160-wide output tile holds 80 value columns and the matching 80 gate columns (the weight-side loader reads the
+// two row ranges), so the activation is applied to the bf16-rounded tile in the epilogue -- bit-identical to the GEMM
+// followed by aql_geglu_fwd.  H (the pre-activation, needed by aql_geglu_bwd) is written only when H != null.
+// Returns AQL_NOT_FUSED (100) when no 160-wide tile serves the shape (F % 80 != 0, tiny grids): the caller then runs the
+// two kernels.
+extern "C" int aql_gemm_bf16_geglu(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, int F, int K,
+                                   const bf16_t* A2, long lda2, const bf16_t* B2, long ldb2, int K2, const bf16_t* bias,
+                                   bf16_t* H, long ldh, bf16_t* G, long ldg, hipStream_t stream) {
+  AQL_CHECK_ARG(A && B && G, "aql_gemm_bf16_geglu: null operand");
+  AQL_CHECK_ARG(M > 0 && F > 0 && K > 0 && M < (1L << 31) && F % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+                    ldg % 8 == 0 && (H == nullptr || ldh % 8 == 0),
+                "aql_gemm_bf16_geglu: bad shape M=%ld F=%d K=%d", M, F, K);
+  AQL_CHECK_ARG(aligned16(A) && aligned16(B) && aligned16(G) && aligned16(H), "aql_gemm_bf16_geglu: pointers must be 16-byte aligned");
+  if (F % 80 != 0) return AQL_NOT_FUSED;
+  GemmArgs<PlainLoader, PlainLoader> g;
+  g.a0 = plain(A, lda, M, K);
+  g.b0 = plain(B, ldb, 2L * F, K);
+  g.b0.gsplit = 80;
+  g.b0.goff = F - 80;
+  g.ktiles0 = aql_cdiv(K, BK);
+  g.ktiles1 = 0;
+  g.a1 = g.a0;
+  g.b1 = g.b0;
+  if (A2 != nullptr) {
+    AQL_CHECK_ARG(B2 && K2 > 0 && K2 % 8 == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0 && aligned16(A2) && aligned16(B2),
+                  "aql_gemm_bf16_geglu: bad second K segment");
+    g.a1 = plain(A2, lda2, M, K2);
+    g.b1 = plain(B2, ldb2, 2L * F, K2);
+    g.b1.gsplit = 80;
+    g.b1.goff = F - 80;
+    g.ktiles1 = aql_cdiv(K2, BK);
+  }
+  g.M = (int)M;
+  g.N = 2 * F;
+  OutSpec o{bias, nullptr, 0, 1, nullptr, 0, H, ldh, nullptr, 0, nullptr, G, ldg, F};
+  return run_bf16_gemm(g, o, nullptr, 0, stream, "aql_gemm_bf16_geglu");
 }
 
 // Skinny rank-r "down" GEMM for r <= 64: HBM-bound (reads X once), so no LDS staging of operands.  A workgroup owns

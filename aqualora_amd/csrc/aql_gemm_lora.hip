@@ -69,7 +69,8 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
     tile_m = block_x / tiles_n;
     tile_n = block_x - tile_m * tiles_n;
   }
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int gF = g.epi.geglu_F;  // GEGLU tiles: [80 value | 80 gate] columns (aql_gemm.cuh)
+  const int m0 = tile_m * BM, n0 = tile_n * (gF ? BN / 2 : BN);
   const int kt_end = g.ktiles0;
 
   DmaStager<BM, PlainLoader> sa;
@@ -96,8 +97,9 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
 #pragma unroll
   for (int u = 0; u < NBP; ++u) {
     const int id = tid + u * NTHREADS, row = id >> 2, c = id & 3;
+    const int brow = epi_bias_col(n0, row, gF, BN / 2);
     bup[u] = zero4();
-    if (id < BN * 4 && n0 + row < g.N) bup[u] = *reinterpret_cast<const uint4*>(lp.Bup + (long)(n0 + row) * LR + c * 8);
+    if (id < BN * 4 && brow < g.N) bup[u] = *reinterpret_cast<const uint4*>(lp.Bup + (long)brow * LR + c * 8);
   }
   uint2 srow[FM][FT];
 #pragma unroll
@@ -209,8 +211,9 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
     for (int j = 0; j < FN; ++j) {
       const int col = wn0 + j * 16 + (lane >> 4) * 4;
       float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-      if (ep.bias != nullptr && (n0 + col) < g.N) {
-        const uint2 bb = *reinterpret_cast<const uint2*>(ep.bias + n0 + col);
+      const int bc = epi_bias_col(n0, col, gF, BN / 2);
+      if (ep.bias != nullptr && bc < g.N) {
+        const uint2 bb = *reinterpret_cast<const uint2*>(ep.bias + bc);
         v0 += bf16lo(bb.x);
         v1 += bf16hi(bb.x);
         v2 += bf16lo(bb.y);
@@ -221,6 +224,8 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
   }
   __syncthreads();
   constexpr int CPR = BN / 8;
+  if (gF) geglu_store<BM, BN, C_PITCH, NTHREADS>(lds, m0, n0, g.M, ep, tid);
+  else
   for (int id = tid; id < BM * CPR; id += NTHREADS) {
     const int row = id / CPR, cc = id - row * CPR;
     const int m = m0 + row, n = n0 + cc * 8;
@@ -276,7 +281,8 @@ __global__ __launch_bounds__(2 * NTHREADS) void lora_gemm_kernel_w(const GemmArg
     tile_m = block_x / tiles_n;
     tile_n = block_x - tile_m * tiles_n;
   }
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int gF = g.epi.geglu_F;  // GEGLU tiles: [80 value | 80 gate] columns (aql_gemm.cuh)
+  const int m0 = tile_m * BM, n0 = tile_n * (gF ? BN / 2 : BN);
   const int kt_end = g.ktiles0;
   constexpr int NLD = BM / 32 + BN / 32 + 1;
 
@@ -296,8 +302,9 @@ __global__ __launch_bounds__(2 * NTHREADS) void lora_gemm_kernel_w(const GemmArg
 #pragma unroll
     for (int u = 0; u < NBP; ++u) {
       const int id = ltid + u * NTHREADS, row = id >> 2, c = id & 3;
+      const int brow = epi_bias_col(n0, row, gF, BN / 2);
       bup[u] = zero4();
-      if (id < BN * 4 && n0 + row < g.N) bup[u] = *reinterpret_cast<const uint4*>(lp.Bup + (long)(n0 + row) * LR + c * 8);
+      if (id < BN * 4 && brow < g.N) bup[u] = *reinterpret_cast<const uint4*>(lp.Bup + (long)brow * LR + c * 8);
     }
     DmaStager<BM, PlainLoader> sa;
     DmaStager<BN, PlainLoader> sb;
@@ -445,8 +452,9 @@ __global__ __launch_bounds__(2 * NTHREADS) void lora_gemm_kernel_w(const GemmArg
       for (int j = 0; j < FN; ++j) {
         const int col = wn0 + j * 16 + (lane >> 4) * 4;
         float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-        if (ep.bias != nullptr && (n0 + col) < g.N) {
-          const uint2 bb = *reinterpret_cast<const uint2*>(ep.bias + n0 + col);
+        const int bc = epi_bias_col(n0, col, gF, BN / 2);
+        if (ep.bias != nullptr && bc < g.N) {
+          const uint2 bb = *reinterpret_cast<const uint2*>(ep.bias + bc);
           v0 += bf16lo(bb.x);
           v1 += bf16hi(bb.x);
           v2 += bf16lo(bb.y);
@@ -458,6 +466,8 @@ __global__ __launch_bounds__(2 * NTHREADS) void lora_gemm_kernel_w(const GemmArg
   }
   __syncthreads();
   constexpr int CPR = BN / 8;
+  if (gF) geglu_store<BM, BN, C_PITCH, 2 * NTHREADS>(lds, m0, n0, g.M, ep, tid);
+  else
   for (int id = tid; id < BM * CPR; id += 2 * NTHREADS) {
     const int row = id / CPR, cc = id - row * CPR;
     const int m = m0 + row, n = n0 + cc * 8;
@@ -500,11 +510,11 @@ inline PlainLoader plain(const bf16_t* p, long ld, long rows, int K) {
 // Y[M,N] = X[M,K].W[N,K]^T + ((X.A[32,K]^T) * S[m / rps]).Bup[N,32]^T + bias + residual;  T, Ts [M,32] are written too.
 // Returns AQL_OK, an error, or AQL_NOT_FUSED (100) when the shape belongs on the two-launch path (deep K on a small grid:
 // split-K; N <= 32).
-extern "C" int aql_lora_gemm_fused(const bf16_t* X, long ldx, const bf16_t* W, long ldw, long M, int N, int K,
-                                   const bf16_t* Adown, const bf16_t* S, int rows_per_sample, const bf16_t* Bup,
-                                   const bf16_t* bias, const bf16_t* residual, long ldr, bf16_t* Y, long ldy, bf16_t* T,
-                                   bf16_t* Ts, hipStream_t stream) {
-  AQL_CHECK_ARG(X && W && Adown && S && Bup && Y && T && Ts, "aql_lora_gemm_fused: null operand");
+static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long ldw, long M, int N, int K,
+                                const bf16_t* Adown, const bf16_t* S, int rows_per_sample, const bf16_t* Bup,
+                                const bf16_t* bias, const bf16_t* residual, long ldr, bf16_t* Y, long ldy, bf16_t* T,
+                                bf16_t* Ts, bf16_t* G, long ldg, int geglu_F, hipStream_t stream) {
+  AQL_CHECK_ARG(X && W && Adown && S && Bup && (Y || geglu_F) && T && Ts, "aql_lora_gemm_fused: null operand");
   AQL_CHECK_ARG(M > 0 && M < (1L << 31) && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 &&
                     ldy % 8 == 0 && rows_per_sample > 0 && (residual == nullptr || ldr % 8 == 0),
                 "aql_lora_gemm_fused: bad shape M=%ld N=%d K=%d", M, N, K);
@@ -519,6 +529,7 @@ extern "C" int aql_lora_gemm_fused(const bf16_t* X, long ldx, const bf16_t* W, l
   GemmArgs<PlainLoader, PlainLoader> g;
   g.a0 = plain(X, ldx, M, K);
   g.b0 = plain(W, ldw, N, K);
+  if (geglu_F) g.b0.gsplit = 80, g.b0.goff = geglu_F - 80;
   g.a1 = g.a0;
   g.b1 = g.b0;
   g.ktiles0 = kt;
@@ -534,6 +545,9 @@ extern "C" int aql_lora_gemm_fused(const bf16_t* X, long ldx, const bf16_t* W, l
   g.epi.residual = residual;
   g.epi.ldr = ldr;
   g.epi.rows_per_sample = rows_per_sample;
+  g.epi.G = G;
+  g.epi.ldg = ldg;
+  g.epi.geglu_F = geglu_F;
   const PlainLoader la = plain(Adown, K, LR, K);
   LoraParams lp{S, Bup, T, Ts, rows_per_sample};
   static const int deep_kt = getenv("AQL_DEEPKT") ? atoi(getenv("AQL_DEEPKT")) : 32;
@@ -563,6 +577,7 @@ extern "C" int aql_lora_gemm_fused(const bf16_t* X, long ldx, const bf16_t* W, l
       else launch<32, 160, 16, 80, 2>(g, la, lp, stream);
     }
   } else {
+    if (geglu_F) return AQL_NOT_FUSED;  // the [value | gate] tile layout exists for the 160-wide tiles only
     const int t128 = aql_cdiv(M, 128) * aql_cdiv(N, 128), t64 = aql_cdiv(M, 64) * aql_cdiv(N, 64);
     const int tiles = t128 >= 240 ? t128 : t64;
     if (tiles < 224 && kt >= deep_kt) return AQL_NOT_FUSED;
@@ -575,4 +590,25 @@ extern "C" int aql_lora_gemm_fused(const bf16_t* X, long ldx, const bf16_t* W, l
   }
   AQL_CHECK_LAUNCH("aql_lora_gemm_fused");
   return AQL_OK;
+}
+
+extern "C" int aql_lora_gemm_fused(const bf16_t* X, long ldx, const bf16_t* W, long ldw, long M, int N, int K,
+                                   const bf16_t* Adown, const bf16_t* S, int rows_per_sample, const bf16_t* Bup,
+                                   const bf16_t* bias, const bf16_t* residual, long ldr, bf16_t* Y, long ldy, bf16_t* T,
+                                   bf16_t* Ts, hipStream_t stream) {
+  return lora_gemm_fused_impl(X, ldx, W, ldw, M, N, K, Adown, S, rows_per_sample, Bup, bias, residual, ldr, Y, ldy, T, Ts,
+                              nullptr, 0, 0, stream);
+}
+
+// ff.net.0.proj with the rank-32 watermark LoRA AND the GEGLU activation in one launch (aql_gemm_bf16_geglu's tile layout on
+// the one-launch LoRA linear): W [2F][K], Bup [2F][32], bias [2F];  H [M][2F] = pre-activation (null = not written),
+// G [M][F] = H[:, :F] * gelu_erf(H[:, F:]).  Returns AQL_NOT_FUSED (100) like aql_lora_gemm_fused, and when F % 80 != 0.
+extern "C" int aql_lora_gemm_fused_geglu(const bf16_t* X, long ldx, const bf16_t* W, long ldw, long M, int F, int K,
+                                         const bf16_t* Adown, const bf16_t* S, int rows_per_sample, const bf16_t* Bup,
+                                         const bf16_t* bias, bf16_t* H, long ldh, bf16_t* G, long ldg, bf16_t* T, bf16_t* Ts,
+                                         hipStream_t stream) {
+  AQL_CHECK_ARG(G && F > 0 && ldg % 8 == 0 && (H == nullptr || ldh % 8 == 0), "aql_lora_gemm_fused_geglu: bad args");
+  if (F % 80 != 0) return AQL_NOT_FUSED;
+  return lora_gemm_fused_impl(X, ldx, W, ldw, M, 2 * F, K, Adown, S, rows_per_sample, Bup, bias, nullptr, 0, H, ldh, T, Ts, G,
+                              ldg, F, stream);
 }

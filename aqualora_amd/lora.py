@@ -67,8 +67,8 @@ class LoRACompatibleLinear(nn.Linear):
     def set_lora_layer(self, lora_layer):
         self.lora_layer = lora_layer
 
-    def forward(self, hidden_states, scale=1.0, residual=None):
-        return CustomLoRACompatibleLinearforward(self, hidden_states, scale, residual=residual)
+    def forward(self, hidden_states, scale=1.0, residual=None, geglu=False):
+        return CustomLoRACompatibleLinearforward(self, hidden_states, scale, residual=residual, geglu=geglu)
 
 
 class LoRACompatibleConv(nn.Conv2d):
@@ -173,7 +173,7 @@ def _scale16(scale, nb, r, device):
     return torch.full((nb, r), float(scale), dtype=torch.bfloat16, device=device)
 
 
-def _run_linear(x2d, packed, lora_layer, scale, nb, rps, residual):
+def _run_linear(x2d, packed, lora_layer, scale, nb, rps, residual, geglu=False):
     site = S = S16 = None
     if lora_layer is not None and scale is not None:
         if getattr(lora_layer, "network_alpha", None) is not None:
@@ -184,12 +184,14 @@ def _run_linear(x2d, packed, lora_layer, scale, nb, rps, residual):
         if S16 is None:
             S16 = S.detach().to(torch.bfloat16).contiguous()
             S._aql_s16 = S16
-    return ops.lora_linear(x2d, packed, site, S, S16, rps, residual)
+    return ops.lora_linear(x2d, packed, site, S, S16, rps, residual, geglu)
 
 
 # ------------------------------------------------------------------------------------ the four forwards
-def CustomLoRACompatibleLinearforward(self, hidden_states, scale=1.0, residual=None):
-    """nn.Linear.forward(x) [+ lora_layer(x, scale)]  -- one fused MFMA GEMM (reference lora_modules.py:56-62)."""
+def CustomLoRACompatibleLinearforward(self, hidden_states, scale=1.0, residual=None, geglu=False):
+    """nn.Linear.forward(x) [+ lora_layer(x, scale)]  -- one fused MFMA GEMM (reference lora_modules.py:56-62).
+    ``geglu=True`` (the host is GEGLU.proj): returns  y[..., :F] * gelu(y[..., F:])  with the activation applied in the
+    GEMM epilogue (scripts/lib/original_unet.py:727-729)."""
     shp = hidden_states.shape
     x2d = hidden_states.reshape(-1, shp[-1])
     if x2d.dtype != torch.bfloat16:
@@ -198,8 +200,8 @@ def CustomLoRACompatibleLinearforward(self, hidden_states, scale=1.0, residual=N
     nb = shp[0] if hidden_states.dim() >= 2 else 1
     rps = x2d.shape[0] // nb
     res2d = None if residual is None else residual.reshape(-1, self.out_features).contiguous()
-    y = _run_linear(x2d, _packed_linear(self), self.lora_layer, scale, nb, rps, res2d)
-    return y.reshape(*shp[:-1], self.out_features)
+    y = _run_linear(x2d, _packed_linear(self), self.lora_layer, scale, nb, rps, res2d, geglu)
+    return y.reshape(*shp[:-1], y.shape[-1])
 
 
 def CustomLoRACompatibleConvforward(self, hidden_states, scale=1.0, residual=None):

@@ -424,16 +424,50 @@ def _lora_gemm_fused(x2d, w, a16, S16, rps, b16, bias, residual, T, Ts):
     return y
 
 
+def _geglu_fused(x2d, packed, site, S16, rps, T, Ts, want_h):
+    """ff.net.0.proj (+ LoRA) + GEGLU in one launch.  Returns (G, H) or None when the shape has no 160-wide tile."""
+    M, K = x2d.shape
+    F = packed.N // 2
+    if F % 80 != 0 or os.environ.get("AQL_GEGLU_FUSED", "1") == "0":
+        return None
+    G = torch.empty(M, F, dtype=torch.bfloat16, device=x2d.device)
+    H = torch.empty(M, 2 * F, dtype=torch.bfloat16, device=x2d.device) if want_h else None
+    ldh = 2 * F
+    if site is not None:
+        rc = 100
+        if site.rank == 32 and os.environ.get("AQL_LORA_FUSED", "1") != "0":
+            rc = L.call_raw("aql_lora_gemm_fused_geglu", L.ptr(x2d), x2d.stride(0), L.ptr(packed.w), packed.w.stride(0), M, F, K,
+                            L.ptr(site.a16), L.ptr(S16), rps, L.ptr(site.b16), L.ptr(packed.bias), L.ptr(H), ldh, L.ptr(G), F,
+                            L.ptr(T), L.ptr(Ts), L.stream_ptr())
+        if rc == 100:   # two-launch form: skinny T product, then the GEGLU GEMM with Ts.Bup^T as a second K segment
+            L.call("aql_lora_down", L.ptr(x2d), x2d.stride(0), M, K, L.ptr(site.a16), site.rank, L.ptr(S16), rps, L.ptr(T),
+                   L.ptr(Ts), None, None, L.stream_ptr())
+            rc = L.call_raw("aql_gemm_bf16_geglu", L.ptr(x2d), x2d.stride(0), L.ptr(packed.w), packed.w.stride(0), M, F, K,
+                            L.ptr(Ts), Ts.stride(0), L.ptr(site.b16), site.b16.stride(0), site.rank, L.ptr(packed.bias),
+                            L.ptr(H), ldh, L.ptr(G), F, L.stream_ptr())
+            if rc == 100:
+                return (None, None, True)   # T / Ts are done; the caller finishes with the plain GEMM + geglu kernel
+    else:
+        rc = L.call_raw("aql_gemm_bf16_geglu", L.ptr(x2d), x2d.stride(0), L.ptr(packed.w), packed.w.stride(0), M, F, K, None, 0,
+                        None, 0, 0, L.ptr(packed.bias), L.ptr(H), ldh, L.ptr(G), F, L.stream_ptr())
+        if rc == 100:
+            return None
+    L.check(rc, "geglu-fused linear")
+    return (G, H, True)
+
+
 class LoraLinearFn(torch.autograd.Function):
     """Y = X.W^T + b [+ ((X.A^T) * S[sample]).Bup^T] [+ residual]   on token-major X [M,K].
 
     Replaces CustomLoRACompatibleLinearforward + CustomLoRALinearLayerforward (reference
     utils/lora_modules.py:56-62, 9-26) and, for 1x1 convolutions on channels-last maps, the conv pair
     (:46-54, 28-44).  ``site`` is a lora.LoraSite (bf16 A, A^T, Bup, Bup^T and fp32 grad views) or None.
+    ``geglu``: the host is ff.net.0.proj -- return  Y[:, :F] * gelu(Y[:, F:])  (GEGLU.forward, original_unet.py:727-729),
+    applied in the GEMM epilogue; Y itself is kept only when a backward pass will need it (``want_h``).
     """
 
     @staticmethod
-    def forward(ctx, x2d, packed, site, S, S16, rps, residual):
+    def forward(ctx, x2d, packed, site, S, S16, rps, residual, geglu=False, want_h=True):
         _req(x2d, "lora_linear")
         M = x2d.shape[0]
         ctx.packed, ctx.site, ctx.rps = packed, site, rps
@@ -441,22 +475,41 @@ class LoraLinearFn(torch.autograd.Function):
         use_lora = site is not None and S16 is not None
         ctx.use_lora = use_lora
         ctx.s_dtype = S.dtype if S is not None else None
+        ctx.geglu = geglu
         T = Ts = None
+        h = None
         if use_lora:
             r = site.rank
             T = torch.empty(M, r, dtype=torch.bfloat16, device=x2d.device)
             Ts = torch.empty_like(T)
             # trainers can hand in one persistent fp32 accumulator for dS (shared by all 192 sites)
             ctx.ds_accum = getattr(S, "_aql_ds_accum", None)
-            y = _lora_gemm_fused(x2d, packed.w, site.a16, S16, rps, site.b16, packed.bias, residual, T, Ts)
-            if y is None:   # two-launch form: skinny T product, then the GEMM with Ts.Bup^T as a second K segment
-                L.call("aql_lora_down", L.ptr(x2d), x2d.stride(0), M, packed.K, L.ptr(site.a16), r, L.ptr(S16), rps,
-                       L.ptr(T), L.ptr(Ts), None, None, L.stream_ptr())
-                y = gemm_bf16(x2d, packed.w, packed.bias, Ts, site.b16, residual=residual)
-            ctx.save_for_backward(x2d, T, Ts, S16)
+        y = None
+        down_done = False
+        if geglu:
+            assert residual is None
+            fused = _geglu_fused(x2d, packed, site if use_lora else None, S16, rps, T, Ts, want_h)
+            if fused is not None:
+                y, h, down_done = fused
+        if y is None:
+            if use_lora:
+                if not down_done:
+                    y = _lora_gemm_fused(x2d, packed.w, site.a16, S16, rps, site.b16, packed.bias, residual, T, Ts)
+                if y is None:   # two-launch form: skinny T product, then the GEMM with Ts.Bup^T as a second K segment
+                    if not down_done:
+                        L.call("aql_lora_down", L.ptr(x2d), x2d.stride(0), M, packed.K, L.ptr(site.a16), r, L.ptr(S16), rps,
+                               L.ptr(T), L.ptr(Ts), None, None, L.stream_ptr())
+                    y = gemm_bf16(x2d, packed.w, packed.bias, Ts, site.b16, residual=residual)
+            else:
+                y = gemm_bf16(x2d, packed.w, packed.bias, residual=residual)
+            if geglu:   # unfused tail (shapes without a 160-wide tile): separate activation kernel
+                h = y
+                y = torch.empty(M, packed.N // 2, dtype=torch.bfloat16, device=x2d.device)
+                L.call("aql_geglu_fwd", L.ptr(h), M, packed.N // 2, L.ptr(y), L.stream_ptr())
+        if use_lora:
+            ctx.save_for_backward(x2d, T, Ts, S16, h if geglu else None)
         else:
-            y = gemm_bf16(x2d, packed.w, packed.bias, residual=residual)
-            ctx.save_for_backward(x2d)
+            ctx.save_for_backward(x2d, h if geglu else None)
         return y
 
     @staticmethod
@@ -465,8 +518,13 @@ class LoraLinearFn(torch.autograd.Function):
         packed, site = ctx.packed, ctx.site
         M = dy.shape[0]
         dS = None
+        if ctx.geglu:   # d(pre-activation) from d(activated): dy becomes [M, 2F]
+            h = ctx.saved_tensors[-1]
+            dh = torch.empty_like(h)
+            L.call("aql_geglu_bwd", L.ptr(h), L.ptr(dy), M, h.shape[1] // 2, L.ptr(dh), L.stream_ptr())
+            dy = dh
         if ctx.use_lora:
-            x2d, T, Ts, S16 = ctx.saved_tensors
+            x2d, T, Ts, S16 = ctx.saved_tensors[:4]
             r = site.rank
             # dTs = dY.Bup  (and dT = dTs * S) -- same two-output epilogue as the forward "down" GEMM
             dTs = torch.empty(M, r, dtype=torch.bfloat16, device=dy.device)
@@ -501,13 +559,14 @@ class LoraLinearFn(torch.autograd.Function):
                 dS = dS.to(ctx.s_dtype) if ctx.needs_input_grad[3] else None
         else:
             dx = gemm_bf16(dy, packed.wt) if ctx.needs_input_grad[0] else None
-        return dx, None, None, dS, None, None, (dy if ctx.has_res else None)
+        return dx, None, None, dS, None, None, (dy if ctx.has_res else None), None, None
 
 
-def lora_linear(x2d, packed, site=None, S=None, S16=None, rps=1, residual=None):
+def lora_linear(x2d, packed, site=None, S=None, S16=None, rps=1, residual=None, geglu=False):
     """S: the [nb, r] scale as seen by autograd (its gradient dS is returned in S.dtype, accumulated in fp32);
-    S16: its bf16 copy read by the kernels."""
-    return LoraLinearFn.apply(x2d, packed, site, S, S16, rps, residual)
+    S16: its bf16 copy read by the kernels.  ``geglu``: see LoraLinearFn."""
+    want_h = torch.is_grad_enabled() and (x2d.requires_grad or (S is not None and torch.is_tensor(S) and S.requires_grad))
+    return LoraLinearFn.apply(x2d, packed, site, S, S16, rps, residual, geglu, want_h)
 
 
 # --------------------------------------------------------------------------------------------- conv 3x3

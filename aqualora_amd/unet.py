@@ -180,8 +180,8 @@ class GEGLU(nn.Module):
         self.proj = LoRACompatibleLinear(dim_in, dim_out * 2, **kw)
 
     def forward(self, x, scale=1.0):
-        h = self.proj(x, scale)
-        return ops.geglu(h.reshape(-1, h.shape[-1])).view(*h.shape[:-1], h.shape[-1] // 2)
+        # proj + LoRA + value * gelu(gate) in ONE launch: the activation runs in the GEMM epilogue (original_unet.py:727-729)
+        return self.proj(x, scale, geglu=True)
 
 
 class FeedForward(nn.Module):

@@ -60,6 +60,20 @@ int aql_conv3x3_fwd_pad(const bf16_t* X, int B, int Hin, int Win, int Cin, const
 int aql_lora_gemm_fused(const bf16_t* X, long ldx, const bf16_t* W, long ldw, long M, int N, int K, const bf16_t* Adown,
                         const bf16_t* S, int rows_per_sample, const bf16_t* Bup, const bf16_t* bias,
                         const bf16_t* residual, long ldr, bf16_t* Y, long ldy, bf16_t* T, bf16_t* Ts, aql_stream_t stream);
+/* ff.net.0.proj + GEGLU in ONE launch (GEGLU.forward, scripts/lib/original_unet.py:727-729 -- diffusers' FeedForward --
+ * on top of lora_modules.py:56-62 / 9-26):  h = X.W^T (+ LoRA) + bias with W [2F,K];  G = h[:, :F] * gelu_erf(h[:, F:]).
+ * Each 160-wide output tile holds 80 value columns and their 80 gate columns, so the activation runs in the epilogue on the
+ * bf16-rounded tile (bit-identical to the GEMM followed by aql_geglu_fwd).  H [M,2F] (the pre-activation that
+ * aql_geglu_bwd needs) is written only when non-null: the frozen pass skips it.  Both return 100 (not an error) when the
+ * shape has no 160-wide tile (F % 80 != 0, tiny grids); aql_gemm_bf16_geglu takes the optional second K segment of
+ * aql_gemm_bf16 (the two-launch LoRA form for ranks other than 32).                                                    */
+int aql_gemm_bf16_geglu(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, int F, int K, const bf16_t* A2,
+                        long lda2, const bf16_t* B2, long ldb2, int K2, const bf16_t* bias, bf16_t* H, long ldh, bf16_t* G,
+                        long ldg, aql_stream_t stream);
+int aql_lora_gemm_fused_geglu(const bf16_t* X, long ldx, const bf16_t* W, long ldw, long M, int F, int K,
+                              const bf16_t* Adown, const bf16_t* S, int rows_per_sample, const bf16_t* Bup,
+                              const bf16_t* bias, bf16_t* H, long ldh, bf16_t* G, long ldg, bf16_t* T, bf16_t* Ts,
+                              aql_stream_t stream);
 int aql_conv3x3_bwd_data(const bf16_t* dY, int B, int Hin, int Win, int Cin, const bf16_t* Wt, int Cout, int stride,
                          bf16_t* dX, float* ws, size_t ws_bytes, aql_stream_t stream);
 
