@@ -97,6 +97,99 @@ def _req(t, name):
     return t
 
 
+# ------------------------------------------------------------------------------ twin ("dual") batches
+# The PPFT step runs the frozen U-Net twice per sample: the "clean" pass (no LoRA, no gradient, ppft_train.py:1026-1029)
+# and the watermarked pass (LoRA, gradient, :1032-1035).  At batch 4 every kernel of either pass is latency- or
+# weight-streaming-bound, so the two passes are run as ONE launch per op over a batch of 2B: clean samples in the first
+# half (their scale rows are all-zero, which is exactly the reference's clean pass), watermarked samples in the second.
+# Autograd only ever sees the second half: every activation tensor is the [B:] view of a 2B-sample buffer whose storage
+# is registered here, each op's forward finds the full buffer behind its input view (`_full`), launches on all 2B samples
+# and returns the [B:] view of its (registered) output.  Backward functions are unchanged -- they work on the saved
+# half-views.  Measured on MI355X (tools/exp_batched_fwd.py): forward of both passes 15.2 ms on two streams -> 13.9 ms.
+class _Dual:
+    def __init__(self):
+        self.storages = {}   # storage data_ptr -> the full tensor (keeps it alive for the duration of the forward)
+
+    def register(self, full):
+        self.storages[full.untyped_storage().data_ptr()] = full
+
+
+DUAL = None
+
+
+def dual_begin():
+    global DUAL
+    DUAL = _Dual()
+    return DUAL
+
+
+def dual_end():
+    global DUAL
+    DUAL = None
+
+
+def _twin_geometry(x):
+    """(registered full tensor, elements per half, dim-0 stride) of a second-half view, or None.  The batch is the outermost
+    dimension of every activation layout used here, so the halves are `half` elements apart whatever the view's shape;
+    a size-1 dim 0 (batch 1) carries no usable stride of its own (torch normalises it in view ops)."""
+    if DUAL is None or x is None:
+        return None
+    full = DUAL.storages.get(x.untyped_storage().data_ptr())
+    if full is None:
+        return None
+    half = full.numel() // 2
+    if x.storage_offset() < half:
+        raise L.AqlError("twin batch: a view that is not inside the second half of its buffer reached a kernel")
+    return full, half, (x.stride(0) if x.shape[0] > 1 else half)
+
+
+def _full(x):
+    """x = a view inside the second (batch-major) half of a registered twin buffer -> the view of BOTH halves (same inner
+    strides, 2x dim 0); None when x is an ordinary tensor or twin mode is off."""
+    geo = _twin_geometry(x)
+    if geo is None:
+        return None
+    _, half, s0 = geo
+    return x.detach().as_strided((2 * x.shape[0],) + tuple(x.shape[1:]), (s0,) + tuple(x.stride()[1:]),
+                                 x.storage_offset() - half)
+
+
+def clean_twin(x):
+    """The clean-pass counterpart (same view of the FIRST half of the twin buffer) of a second-half view, detached.
+    Call while the twin registry is alive (before dual_end)."""
+    geo = _twin_geometry(x)
+    if geo is None:
+        raise L.AqlError("clean_twin: not a twin tensor")
+    return x.detach().as_strided(tuple(x.shape), x.stride(), x.storage_offset() - geo[1])
+
+
+def make_twin(first, second):
+    """Build a registered twin buffer from two equally shaped tensors; returns the second-half view (what autograd sees)."""
+    full = torch.cat([first, second], dim=0)
+    if first.dim() == 4:
+        full = full.contiguous(memory_format=CL)
+    DUAL.register(full)
+    return full[first.shape[0]:]
+
+
+def _alloc(shape, dtype, device, twin, cl=False):
+    """-> (tensor the kernel writes, tensor autograd sees).  twin: allocate 2x dim 0, register, hand out the [n:] view."""
+    if not twin:
+        t = torch.empty(shape, dtype=dtype, device=device, memory_format=CL) if cl else torch.empty(shape, dtype=dtype, device=device)
+        return t, t
+    shp = (2 * shape[0],) + tuple(shape[1:])
+    full = torch.empty(shp, dtype=dtype, device=device, memory_format=CL) if cl else torch.empty(shp, dtype=dtype, device=device)
+    DUAL.register(full)
+    return full, full[shape[0]:]
+
+
+def _need_full(t, what):
+    f = _full(t)
+    if f is None:
+        raise L.AqlError(f"twin batch: {what} is not a twin tensor although the activation is")
+    return f
+
+
 def as_cl(x):
     """Logical NCHW -> channels_last storage (no-op when already so)."""
     return x.contiguous(memory_format=CL)
@@ -407,14 +500,15 @@ DEFERRED = None  # set by a trainer around backward (ppft.PPFTTrainer); None => 
 
 
 # ------------------------------------------------------------------------------------ fused LoRA linear
-def _lora_gemm_fused(x2d, w, a16, S16, rps, b16, bias, residual, T, Ts):
+def _lora_gemm_fused(x2d, w, a16, S16, rps, b16, bias, residual, T, Ts, y=None):
     """One-launch rank-32 LoRA linear (aql_lora_gemm_fused).  Returns Y, or None when the shape belongs on the two-launch
     path (rank != 32, split-K shapes, narrow outputs; AQL_LORA_FUSED=0 disables it for comparison)."""
     if a16.shape[0] != 32 or os.environ.get("AQL_LORA_FUSED", "1") == "0":
         return None
     M, K = x2d.shape
     N = w.shape[0]
-    y = torch.empty(M, N, dtype=torch.bfloat16, device=x2d.device)
+    if y is None:
+        y = torch.empty(M, N, dtype=torch.bfloat16, device=x2d.device)
     rc = L.call_raw("aql_lora_gemm_fused", L.ptr(x2d), x2d.stride(0), L.ptr(w), w.stride(0), M, N, K, L.ptr(a16), L.ptr(S16),
                     rps, L.ptr(b16), L.ptr(bias), L.ptr(residual), 0 if residual is None else residual.stride(0), L.ptr(y),
                     y.stride(0), L.ptr(T), L.ptr(Ts), L.stream_ptr())
@@ -424,14 +518,13 @@ def _lora_gemm_fused(x2d, w, a16, S16, rps, b16, bias, residual, T, Ts):
     return y
 
 
-def _geglu_fused(x2d, packed, site, S16, rps, T, Ts, want_h):
-    """ff.net.0.proj (+ LoRA) + GEGLU in one launch.  Returns (G, H) or None when the shape has no 160-wide tile."""
+def _geglu_fused(x2d, packed, site, S16, rps, T, Ts, G, H):
+    """ff.net.0.proj (+ LoRA) + GEGLU in one launch into G [M,F] (and H [M,2F] unless None).  Returns "done", "down" (only
+    the LoRA down product T / Ts was computed: finish with the plain GEMM + geglu kernel) or None (nothing done)."""
     M, K = x2d.shape
     F = packed.N // 2
     if F % 80 != 0 or os.environ.get("AQL_GEGLU_FUSED", "1") == "0":
         return None
-    G = torch.empty(M, F, dtype=torch.bfloat16, device=x2d.device)
-    H = torch.empty(M, 2 * F, dtype=torch.bfloat16, device=x2d.device) if want_h else None
     ldh = 2 * F
     if site is not None:
         rc = 100
@@ -446,14 +539,14 @@ def _geglu_fused(x2d, packed, site, S16, rps, T, Ts, want_h):
                             L.ptr(Ts), Ts.stride(0), L.ptr(site.b16), site.b16.stride(0), site.rank, L.ptr(packed.bias),
                             L.ptr(H), ldh, L.ptr(G), F, L.stream_ptr())
             if rc == 100:
-                return (None, None, True)   # T / Ts are done; the caller finishes with the plain GEMM + geglu kernel
+                return "down"
     else:
         rc = L.call_raw("aql_gemm_bf16_geglu", L.ptr(x2d), x2d.stride(0), L.ptr(packed.w), packed.w.stride(0), M, F, K, None, 0,
                         None, 0, 0, L.ptr(packed.bias), L.ptr(H), ldh, L.ptr(G), F, L.stream_ptr())
         if rc == 100:
             return None
     L.check(rc, "geglu-fused linear")
-    return (G, H, True)
+    return "done"
 
 
 class LoraLinearFn(torch.autograd.Function):
@@ -464,48 +557,59 @@ class LoraLinearFn(torch.autograd.Function):
     (:46-54, 28-44).  ``site`` is a lora.LoraSite (bf16 A, A^T, Bup, Bup^T and fp32 grad views) or None.
     ``geglu``: the host is ff.net.0.proj -- return  Y[:, :F] * gelu(Y[:, F:])  (GEGLU.forward, original_unet.py:727-729),
     applied in the GEMM epilogue; Y itself is kept only when a backward pass will need it (``want_h``).
+    Twin batches (see `_Dual`): the kernels run on both halves, autograd sees and saves the second-half views.
     """
 
     @staticmethod
     def forward(ctx, x2d, packed, site, S, S16, rps, residual, geglu=False, want_h=True):
         _req(x2d, "lora_linear")
         M = x2d.shape[0]
+        dev = x2d.device
+        xk = _full(x2d)
+        twin = xk is not None
+        if not twin:
+            xk = x2d
+        resk = residual if (residual is None or not twin) else _need_full(residual, "the residual")
         ctx.packed, ctx.site, ctx.rps = packed, site, rps
         ctx.has_res = residual is not None
         use_lora = site is not None and S16 is not None
         ctx.use_lora = use_lora
         ctx.s_dtype = S.dtype if S is not None else None
         ctx.geglu = geglu
-        T = Ts = None
-        h = None
+        T = Ts = Tk = Tsk = S16k = None
         if use_lora:
             r = site.rank
-            T = torch.empty(M, r, dtype=torch.bfloat16, device=x2d.device)
-            Ts = torch.empty_like(T)
+            S16k = _need_full(S16, "the LoRA scale") if twin else S16
+            Tk, T = _alloc((M, r), torch.bfloat16, dev, twin)
+            Tsk, Ts = _alloc((M, r), torch.bfloat16, dev, twin)
             # trainers can hand in one persistent fp32 accumulator for dS (shared by all 192 sites)
             ctx.ds_accum = getattr(S, "_aql_ds_accum", None)
-        y = None
-        down_done = False
+        F = packed.N // 2
+        yk, y = _alloc((M, F if geglu else packed.N), torch.bfloat16, dev, twin)
+        hk = h = None
+        done = None
         if geglu:
             assert residual is None
-            fused = _geglu_fused(x2d, packed, site if use_lora else None, S16, rps, T, Ts, want_h)
-            if fused is not None:
-                y, h, down_done = fused
-        if y is None:
+            if want_h:
+                hk, h = _alloc((M, packed.N), torch.bfloat16, dev, twin)
+            done = _geglu_fused(xk, packed, site if use_lora else None, S16k, rps, Tk, Tsk, yk, hk)
+        if done != "done":
+            if geglu and hk is None:
+                hk, h = _alloc((M, packed.N), torch.bfloat16, dev, twin)
+            out = hk if geglu else yk
             if use_lora:
-                if not down_done:
-                    y = _lora_gemm_fused(x2d, packed.w, site.a16, S16, rps, site.b16, packed.bias, residual, T, Ts)
-                if y is None:   # two-launch form: skinny T product, then the GEMM with Ts.Bup^T as a second K segment
-                    if not down_done:
-                        L.call("aql_lora_down", L.ptr(x2d), x2d.stride(0), M, packed.K, L.ptr(site.a16), r, L.ptr(S16), rps,
-                               L.ptr(T), L.ptr(Ts), None, None, L.stream_ptr())
-                    y = gemm_bf16(x2d, packed.w, packed.bias, Ts, site.b16, residual=residual)
+                ok = None
+                if done != "down":
+                    ok = _lora_gemm_fused(xk, packed.w, site.a16, S16k, rps, site.b16, packed.bias, resk, Tk, Tsk, out)
+                if ok is None:   # two-launch form: skinny T product, then the GEMM with Ts.Bup^T as a second K segment
+                    if done != "down":
+                        L.call("aql_lora_down", L.ptr(xk), xk.stride(0), xk.shape[0], packed.K, L.ptr(site.a16), r, L.ptr(S16k),
+                               rps, L.ptr(Tk), L.ptr(Tsk), None, None, L.stream_ptr())
+                    gemm_bf16(xk, packed.w, packed.bias, Tsk, site.b16, residual=resk, out=out)
             else:
-                y = gemm_bf16(x2d, packed.w, packed.bias, residual=residual)
+                gemm_bf16(xk, packed.w, packed.bias, residual=resk, out=out)
             if geglu:   # unfused tail (shapes without a 160-wide tile): separate activation kernel
-                h = y
-                y = torch.empty(M, packed.N // 2, dtype=torch.bfloat16, device=x2d.device)
-                L.call("aql_geglu_fwd", L.ptr(h), M, packed.N // 2, L.ptr(y), L.stream_ptr())
+                L.call("aql_geglu_fwd", L.ptr(hk), hk.shape[0], F, L.ptr(yk), L.stream_ptr())
         if use_lora:
             ctx.save_for_backward(x2d, T, Ts, S16, h if geglu else None)
         else:
@@ -579,19 +683,27 @@ class Conv3x3Fn(torch.autograd.Function):
         _req(x, "conv3x3")
         x = as_cl(x)
         B, C, H, W = x.shape
+        xk = _full(x)
+        twin = xk is not None
+        if not twin:
+            xk = x
+        Bk = xk.shape[0]
         if C != packed.Cin:  # conv_in: zero-pad channels to the packed width
-            xp = x.new_zeros((B, packed.Cin, H, W)).contiguous(memory_format=CL)
-            xp[:, :C] = x
-            x = xp
+            xp = xk.new_zeros((Bk, packed.Cin, H, W)).contiguous(memory_format=CL)
+            xp[:, :C] = xk
+            xk = xp
         Hl, Wl = (H * 2, W * 2) if upsample else (H, W)
         Ho = (Hl + 2 - 3) // packed.stride + 1
         Wo = (Wl + 2 - 3) // packed.stride + 1
-        y = torch.empty((B, packed.Cout, Ho, Wo), dtype=torch.bfloat16, device=x.device, memory_format=CL)
+        yk, y = _alloc((B, packed.Cout, Ho, Wo), torch.bfloat16, x.device, twin, cl=True)
         ws = workspace(x.device)
         res = None if residual is None else as_cl(residual)
-        L.call("aql_conv3x3_fwd", L.ptr(x), B, H, W, packed.Cin, L.ptr(packed.wk), L.ptr(packed.bias), packed.Cout,
-               packed.stride, int(upsample), L.ptr(rowbias), 0 if rowbias is None else rowbias.stride(0), L.ptr(res),
-               L.ptr(y), L.ptr(ws), ws.numel() * 4, L.stream_ptr())
+        resk = res if (res is None or not twin) else _need_full(res, "the conv residual")
+        if twin and rowbias is not None and rowbias.shape[0] != Bk:
+            raise L.AqlError("twin batch: the per-sample row bias must cover both halves")
+        L.call("aql_conv3x3_fwd", L.ptr(xk), Bk, H, W, packed.Cin, L.ptr(packed.wk), L.ptr(packed.bias), packed.Cout,
+               packed.stride, int(upsample), L.ptr(rowbias), 0 if rowbias is None else rowbias.stride(0), L.ptr(resk),
+               L.ptr(yk), L.ptr(ws), ws.numel() * 4, L.stream_ptr())
         ctx.packed, ctx.upsample, ctx.in_shape, ctx.c_in = packed, upsample, (B, H, W), C
         ctx.has_rb, ctx.has_res = rowbias is not None, residual is not None
         if packed.Cout_real != packed.Cout:
@@ -631,6 +743,36 @@ def conv3x3(x, packed, upsample=False, rowbias=None, residual=None):
     return Conv3x3Fn.apply(x, packed, upsample, rowbias, residual)
 
 
+# ------------------------------------------------------------------------------ skip-connection concat
+class CatChannelsFn(torch.autograd.Function):
+    """torch.cat([a, b], dim=1) on channels-last maps (the up-block skip connections, original_unet.py:1133,1224), twin-batch
+    aware: the concatenation is built for both halves, autograd sees the second half."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = as_cl(a), as_cl(b)
+        B, Ca, H, W = a.shape
+        Cb = b.shape[1]
+        ak = _full(a)
+        twin = ak is not None
+        bk = _need_full(b, "the skip connection") if twin else b
+        if not twin:
+            ak = a
+        outk, out = _alloc((B, Ca + Cb, H, W), a.dtype, a.device, twin, cl=True)
+        outk[:, :Ca] = ak
+        outk[:, Ca:] = bk
+        ctx.ca = Ca
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy[:, :ctx.ca], dy[:, ctx.ca:]
+
+
+def cat_channels(a, b):
+    return CatChannelsFn.apply(a, b)
+
+
 # ------------------------------------------------------------------------------------------- norms
 class GroupNormSiluFn(torch.autograd.Function):
     """GroupNorm(32)+SiLU.  With ``passthrough`` the input is ALSO returned (as a view) so that the residual / shortcut
@@ -642,10 +784,15 @@ class GroupNormSiluFn(torch.autograd.Function):
         _req(x, "groupnorm")
         x = as_cl(x)
         B, C, H, W = x.shape
-        y = torch.empty_like(x, memory_format=CL)
-        stats = torch.empty(B, 32, 2, dtype=torch.float32, device=x.device)
-        L.call("aql_groupnorm_silu_fwd", L.ptr(x), B, H * W, C, L.ptr(gamma), L.ptr(beta), float(eps), int(silu),
-               L.ptr(y), L.ptr(stats), L.ptr(_gn_scratch(x.device, B)), L.stream_ptr())
+        xk = _full(x)
+        twin = xk is not None
+        if not twin:
+            xk = x
+        Bk = xk.shape[0]
+        yk, y = _alloc((B, C, H, W), x.dtype, x.device, twin, cl=True)
+        statsk, stats = _alloc((B, 32, 2), torch.float32, x.device, twin)
+        L.call("aql_groupnorm_silu_fwd", L.ptr(xk), Bk, H * W, C, L.ptr(gamma), L.ptr(beta), float(eps), int(silu),
+               L.ptr(yk), L.ptr(statsk), L.ptr(_gn_scratch(x.device, Bk)), L.stream_ptr())
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.silu = silu
         if passthrough:
@@ -680,9 +827,13 @@ class LayerNormFn(torch.autograd.Function):
     def forward(ctx, x2d, gamma, beta, eps, passthrough=False):
         _req(x2d, "layernorm")
         M, C = x2d.shape
-        y = torch.empty_like(x2d)
-        stats = torch.empty(M, 2, dtype=torch.float32, device=x2d.device)
-        L.call("aql_layernorm_fwd", L.ptr(x2d), M, C, L.ptr(gamma), L.ptr(beta), float(eps), L.ptr(y), L.ptr(stats),
+        xk = _full(x2d)
+        twin = xk is not None
+        if not twin:
+            xk = x2d
+        yk, y = _alloc((M, C), x2d.dtype, x2d.device, twin)
+        statsk, stats = _alloc((M, 2), torch.float32, x2d.device, twin)
+        L.call("aql_layernorm_fwd", L.ptr(xk), xk.shape[0], C, L.ptr(gamma), L.ptr(beta), float(eps), L.ptr(yk), L.ptr(statsk),
                L.stream_ptr())
         ctx.save_for_backward(x2d, gamma, stats)
         if passthrough:
@@ -717,8 +868,12 @@ class GegluFn(torch.autograd.Function):
     def forward(ctx, h2d):
         _req(h2d, "geglu")
         M, F2 = h2d.shape
-        out = torch.empty(M, F2 // 2, dtype=torch.bfloat16, device=h2d.device)
-        L.call("aql_geglu_fwd", L.ptr(h2d), M, F2 // 2, L.ptr(out), L.stream_ptr())
+        hk = _full(h2d)
+        twin = hk is not None
+        if not twin:
+            hk = h2d
+        outk, out = _alloc((M, F2 // 2), torch.bfloat16, h2d.device, twin)
+        L.call("aql_geglu_fwd", L.ptr(hk), hk.shape[0], F2 // 2, L.ptr(outk), L.stream_ptr())
         ctx.save_for_backward(h2d)
         return out
 
@@ -746,10 +901,16 @@ class AttentionFn(torch.autograd.Function):
         B, Nq, C = q.shape
         Nk = k.shape[1]
         d = C // heads
-        o = torch.empty(q.shape, dtype=q.dtype, device=q.device)   # q may be a strided view of a packed q|k|v GEMM output
-        lse = torch.empty(B, heads, Nq, dtype=torch.float32, device=q.device)
-        L.call("aql_sdpa_fwd", L.ptr(q), q.stride(1), L.ptr(k), k.stride(1), L.ptr(v), v.stride(1), B, heads, Nq, Nk,
-               d, float(d ** -0.5), L.ptr(o), o.stride(1), L.ptr(lse), L.stream_ptr())
+        qk = _full(q)
+        twin = qk is not None
+        if twin:
+            kk, vk = _need_full(k, "attention k"), _need_full(v, "attention v")
+        else:
+            qk, kk, vk = q, k, v
+        ok, o = _alloc((B, Nq, C), q.dtype, q.device, twin)   # q may be a strided view of a packed q|k|v GEMM output
+        lsek, lse = _alloc((B, heads, Nq), torch.float32, q.device, twin)
+        L.call("aql_sdpa_fwd", L.ptr(qk), qk.stride(1), L.ptr(kk), kk.stride(1), L.ptr(vk), vk.stride(1), qk.shape[0], heads, Nq,
+               Nk, d, float(d ** -0.5), L.ptr(ok), ok.stride(1), L.ptr(lsek), L.stream_ptr())
         ctx.save_for_backward(q, k, v, o, lse)
         ctx.heads = heads
         return o

@@ -27,7 +27,7 @@ VAE_SCALING = 0.18215
 class PPFTTrainer:
     def __init__(self, unet, mapper, sec_encoder, rank, learning_rate=1e-4, adam_beta1=0.9, adam_beta2=0.999,
                  adam_weight_decay=1e-2, adam_epsilon=1e-8, max_grad_norm=1.0, lr_lambda=None, lora_state=None,
-                 process_group=None, micro_batches=1):
+                 process_group=None, micro_batches=1, twin=None):
         dev = unet.device
         if dev.type != "cuda":
             raise L.AqlError("PPFTTrainer needs the U-Net on an MI355X (cuda device); there is no CPU path")
@@ -58,6 +58,9 @@ class PPFTTrainer:
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.ds_accum = None
         self.micro = micro_batches
+        # twin batch: clean + watermarked forward as one 2B-sample pass (ops._Dual); AQL_TWIN=0 restores the two-stream form
+        import os
+        self.twin = (os.environ.get("AQL_TWIN", "1") != "0") if twin is None else bool(twin)
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(2 * max(1, micro_batches))]
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         # data parallel: weight-gradient GEMMs run in buckets, each followed by its slice of the all-reduce (see
@@ -89,28 +92,51 @@ class PPFTTrainer:
         preds, cleans, losses = [], [], []
         ops.DEFERRED = self.deferred  # weight-gradient GEMMs + dS reductions of every slice are collected ...
         try:
-            for i in range(micro):
-                sl = slice(i * n, (i + 1) * n)
-                wm_stream, clean_stream = self.streams[2 * i], self.streams[2 * i + 1]
-                wm_stream.wait_stream(main)
-                clean_stream.wait_stream(main)
-                # the frozen "clean" pass is independent of the watermarked pass until the loss
-                with torch.cuda.stream(clean_stream), torch.no_grad():
-                    clean = self.unet(x_t[sl], t[sl], ctx[sl], cross_attention_kwargs={"scale": None}).sample
-                    ops.join_branches()
-                with torch.cuda.stream(wm_stream):
-                    S_in = S[sl].detach().requires_grad_(True)  # the U-Net sees a leaf; all 192 sites accumulate dS
-                    S_in._aql_ds_accum = self.ds_accum[sl]       # into one fp32 buffer, pushed through the mapper once
-                    pred = self.unet(x_t_wm[sl], t[sl], ctx[sl], cross_attention_kwargs={"scale": S_in}).sample
-                    wm_stream.wait_stream(clean_stream)
-                    loss = ops.mse_loss(pred, clean)
-                    (loss / micro).backward()
-                    ops.join_branches()
+            if self.twin and micro == 1:
+                # ONE forward over a twin batch of 2B: clean samples (all-zero scale rows == the reference's clean pass,
+                # ppft_train.py:1026-1029) in the first half, watermarked samples in the second; autograd only sees the
+                # second half (ops._Dual).  Every kernel of the forward runs once on twice the rows.
+                ops.dual_begin()
+                try:
+                    x2 = ops.make_twin(x_t, x_t_wm)
+                    c16 = ctx if ctx.dtype == torch.bfloat16 else ctx.to(torch.bfloat16)
+                    ctx2 = ops.make_twin(c16, c16)
+                    S_in = S.detach().requires_grad_(True)
+                    S16 = S.detach().to(torch.bfloat16)
+                    S_in._aql_s16 = ops.make_twin(torch.zeros_like(S16), S16)
+                    S_in._aql_ds_accum = self.ds_accum
+                    pred = self.unet(x2, t, ctx2, cross_attention_kwargs={"scale": S_in}).sample
+                    clean = ops.clean_twin(pred)
+                finally:
+                    ops.dual_end()
+                loss = ops.mse_loss(pred, clean)
+                loss.backward()
                 preds.append(pred.detach())
                 cleans.append(clean)
                 losses.append(loss.detach())
-            for st in self.streams[:2 * micro]:
-                main.wait_stream(st)
+            else:
+                for i in range(micro):
+                    sl = slice(i * n, (i + 1) * n)
+                    wm_stream, clean_stream = self.streams[2 * i], self.streams[2 * i + 1]
+                    wm_stream.wait_stream(main)
+                    clean_stream.wait_stream(main)
+                    # the frozen "clean" pass is independent of the watermarked pass until the loss
+                    with torch.cuda.stream(clean_stream), torch.no_grad():
+                        clean = self.unet(x_t[sl], t[sl], ctx[sl], cross_attention_kwargs={"scale": None}).sample
+                        ops.join_branches()
+                    with torch.cuda.stream(wm_stream):
+                        S_in = S[sl].detach().requires_grad_(True)  # the U-Net sees a leaf; all 192 sites accumulate dS
+                        S_in._aql_ds_accum = self.ds_accum[sl]       # into one fp32 buffer, pushed through the mapper once
+                        pred = self.unet(x_t_wm[sl], t[sl], ctx[sl], cross_attention_kwargs={"scale": S_in}).sample
+                        wm_stream.wait_stream(clean_stream)
+                        loss = ops.mse_loss(pred, clean)
+                        (loss / micro).backward()
+                        ops.join_branches()
+                    preds.append(pred.detach())
+                    cleans.append(clean)
+                    losses.append(loss.detach())
+                for st in self.streams[:2 * micro]:
+                    main.wait_stream(st)
         finally:
             ops.DEFERRED = None
         for tns in preds + cleans + losses:

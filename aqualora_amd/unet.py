@@ -282,9 +282,7 @@ class UpBlock(nn.Module):
 
     def forward(self, h, skips, temb_act, ctx, scale):
         for i, res in enumerate(self.resnets):
-            h = torch.cat([h, skips[-1 - i]], dim=1)
-            if not h.is_contiguous(memory_format=torch.channels_last):
-                h = h.contiguous(memory_format=torch.channels_last)
+            h = ops.cat_channels(h, skips[-1 - i])
             h = res(h, temb_act, scale)
             if self.has_cross_attention:
                 h = self.attentions[i](h, ctx, scale)
@@ -364,12 +362,17 @@ class UNet2DConditionModel(nn.Module):
         if not torch.is_tensor(timestep):
             timestep = torch.tensor([timestep], device=sample.device)
         timestep = timestep.reshape(-1).expand(sample.shape[0])
+        sample = ops.as_cl(sample.to(self.dtype))
+        if ops._full(sample) is not None:
+            # twin batch (ops._Dual): `sample` is the watermarked half of a 2B buffer whose first half is the clean pass; both
+            # halves share the timesteps, and the per-ResNet time projections are per-sample row biases covering all 2B rows
+            timestep = timestep.repeat(2)
         t_emb = get_timestep_embedding(timestep, self.config.block_out_channels[0]).to(self.dtype)
         emb = self.time_embedding(t_emb, scale)
         temb_act = torch.nn.functional.silu(emb)  # every ResNet applies SiLU to temb first (original_unet.py:449)
         temb_act = self._all_time_projections(temb_act)
         ctx = encoder_hidden_states.to(self.dtype).contiguous()
-        h = self.conv_in(ops.as_cl(sample.to(self.dtype)), scale)
+        h = self.conv_in(sample, scale)
         skips = (h,)
         for blk in self.down_blocks:
             h, outs = blk(h, temb_act, ctx, scale)
