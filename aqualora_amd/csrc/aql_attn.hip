@@ -529,7 +529,8 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dq_kernel(const 
     t_product<DH, DV>(dq, sK, pb, lane);
   }
   const float mq[2] = {a.scale, a.scale};
-  store_t<DV>(dq, a.dq + (long)b * a.Nq * a.ldq + h * a.d, a.ldq, q0, a.Nq, a.d, mq, lane);
+  const long ld_dq = (long)a.H * a.d;  // dQ is written dense ([B][Nq][H*d]) whatever the row stride of q (q may be a column view)
+  store_t<DV>(dq, a.dq + (long)b * a.Nq * ld_dq + h * a.d, ld_dq, q0, a.Nq, a.d, mq, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV

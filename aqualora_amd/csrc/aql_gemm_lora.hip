@@ -20,6 +20,7 @@
 #include <type_traits>
 #include "aql_gemm.cuh"
 #include <stdlib.h>
+#include <string.h>
 
 using namespace aqlgemm;
 
@@ -29,12 +30,20 @@ namespace {
 
 constexpr int LR = 32;  // LoRA rank handled here
 
+constexpr int MAXG = 32;  // LoRA linears per grouped launch
+
 struct LoraParams {
   const bf16_t* S;    // [nsamples][32] bf16 scale rows
   const bf16_t* Bup;  // [N][32]
-  bf16_t* T;          // [M][32] out (unscaled)
-  bf16_t* Ts;         // [M][32] out (scaled)
+  bf16_t* T;          // [M][32] out (unscaled); grouped: [ngroups][M][32]
+  bf16_t* Ts;         // [M][32] out (scaled);   grouped: [ngroups][M][32]
   int rps;            // rows per sample
+  // Grouped launch: the N output columns are the concatenation of `ngroups` independent LoRA linears that share X (q|k|v of a
+  // self-attention; the k|v projections of the text states of all 16 cross-attentions).  Group i owns columns
+  // [col_start[i], col_start[i+1]) (multiples of the tile width), rows [32 i, 32 i + 32) of the stacked A and slab i of T / Ts;
+  // W, Bup and bias are stacked along N, so their row index stays the absolute column.  0 = one linear.
+  int ngroups;
+  int col_start[MAXG + 1];
 };
 
 template <int BM, int BN, int WM, int WN, int NSTG>
@@ -72,6 +81,14 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
   const int gF = g.epi.geglu_F;  // GEGLU tiles: [80 value | 80 gate] columns (aql_gemm.cuh)
   const int m0 = tile_m * BM, n0 = tile_n * (gF ? BN / 2 : BN);
   const int kt_end = g.ktiles0;
+  int grp = 0;
+  if (lp.ngroups > 0)
+    while (grp + 1 < lp.ngroups && n0 >= lp.col_start[grp + 1]) ++grp;
+  const bool t_writer = lp.ngroups > 0 ? (n0 == lp.col_start[grp]) : (tile_n == 0);
+  bf16_t* const Tg = lp.T + (long)grp * g.M * LR;
+  bf16_t* const Tsg = lp.Ts + (long)grp * g.M * LR;
+  PlainLoader lag = la;
+  lag.base += (long)grp * LR * la.ld;
 
   DmaStager<BM, PlainLoader> sa;
   DmaStager<BN, PlainLoader> sb;
@@ -79,7 +96,7 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
   constexpr int NLD = BM / 32 + BN / 32 + 1;
   sa.begin(g.a0, g.a0, false, m0, tid, 0, kt_end, kt_end);
   sb.begin(g.b0, g.b0, false, n0, tid, 0, kt_end, kt_end);
-  sl.begin(la, la, false, 0, tid, 0, kt_end, kt_end);
+  sl.begin(lag, lag, false, 0, tid, 0, kt_end, kt_end);
 
   f32x4_t acc[FM][FN], tacc[FM][FT];
 #pragma unroll
@@ -174,9 +191,9 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
       const uint2 ts = make_uint2(pack_bf16x2(bf16lo(tv.x) * bf16lo(sv.x), bf16hi(tv.x) * bf16hi(sv.x)),
                                   pack_bf16x2(bf16lo(tv.y) * bf16lo(sv.y), bf16hi(tv.y) * bf16hi(sv.y)));
       *reinterpret_cast<uint2*>(sA + lds_off(row, r >> 3) + (r & 7) * 2) = ts;
-      if (ok && tile_n == 0) {
-        *reinterpret_cast<uint2*>(lp.T + m * LR + r) = tv;
-        *reinterpret_cast<uint2*>(lp.Ts + m * LR + r) = ts;
+      if (ok && t_writer) {
+        *reinterpret_cast<uint2*>(Tg + m * LR + r) = tv;
+        *reinterpret_cast<uint2*>(Tsg + m * LR + r) = ts;
       }
     }
   }
@@ -285,6 +302,14 @@ __global__ __launch_bounds__(2 * NTHREADS) void lora_gemm_kernel_w(const GemmArg
   const int m0 = tile_m * BM, n0 = tile_n * (gF ? BN / 2 : BN);
   const int kt_end = g.ktiles0;
   constexpr int NLD = BM / 32 + BN / 32 + 1;
+  int grp = 0;
+  if (lp.ngroups > 0)
+    while (grp + 1 < lp.ngroups && n0 >= lp.col_start[grp + 1]) ++grp;
+  const bool t_writer = lp.ngroups > 0 ? (n0 == lp.col_start[grp]) : (tile_n == 0);
+  bf16_t* const Tg = lp.T + (long)grp * g.M * LR;
+  bf16_t* const Tsg = lp.Ts + (long)grp * g.M * LR;
+  PlainLoader lag = la;
+  lag.base += (long)grp * LR * la.ld;
 
   f32x4_t acc[FM][FN], tacc[FM][FT];
 #pragma unroll
@@ -311,7 +336,7 @@ __global__ __launch_bounds__(2 * NTHREADS) void lora_gemm_kernel_w(const GemmArg
     DmaStager<LR, PlainLoader> sl;
     sa.begin(g.a0, g.a0, false, m0, ltid, 0, kt_end, kt_end);
     sb.begin(g.b0, g.b0, false, n0, ltid, 0, kt_end, kt_end);
-    sl.begin(la, la, false, 0, ltid, 0, kt_end, kt_end);
+    sl.begin(lag, lag, false, 0, ltid, 0, kt_end, kt_end);
     auto issue = [&](int stage) {
       char* sA = lds + stage * STAGE;
       sa.dma(sA, wave - 4);
@@ -419,9 +444,9 @@ __global__ __launch_bounds__(2 * NTHREADS) void lora_gemm_kernel_w(const GemmArg
         const uint2 ts = make_uint2(pack_bf16x2(bf16lo(tv.x) * bf16lo(sv.x), bf16hi(tv.x) * bf16hi(sv.x)),
                                     pack_bf16x2(bf16lo(tv.y) * bf16lo(sv.y), bf16hi(tv.y) * bf16hi(sv.y)));
         *reinterpret_cast<uint2*>(sA + lds_off(row, r >> 3) + (r & 7) * 2) = ts;
-        if (ok && tile_n == 0) {
-          *reinterpret_cast<uint2*>(lp.T + m * LR + r) = tv;
-          *reinterpret_cast<uint2*>(lp.Ts + m * LR + r) = ts;
+        if (ok && t_writer) {
+          *reinterpret_cast<uint2*>(Tg + m * LR + r) = tv;
+          *reinterpret_cast<uint2*>(Tsg + m * LR + r) = ts;
         }
       }
     }
@@ -513,7 +538,8 @@ inline PlainLoader plain(const bf16_t* p, long ld, long rows, int K) {
 static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long ldw, long M, int N, int K,
                                 const bf16_t* Adown, const bf16_t* S, int rows_per_sample, const bf16_t* Bup,
                                 const bf16_t* bias, const bf16_t* residual, long ldr, bf16_t* Y, long ldy, bf16_t* T,
-                                bf16_t* Ts, bf16_t* G, long ldg, int geglu_F, hipStream_t stream) {
+                                bf16_t* Ts, bf16_t* G, long ldg, int geglu_F, int ngroups, const int* col_start,
+                                hipStream_t stream) {
   AQL_CHECK_ARG(X && W && Adown && S && Bup && (Y || geglu_F) && T && Ts, "aql_lora_gemm_fused: null operand");
   AQL_CHECK_ARG(M > 0 && M < (1L << 31) && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 &&
                     ldy % 8 == 0 && rows_per_sample > 0 && (residual == nullptr || ldr % 8 == 0),
@@ -549,9 +575,34 @@ static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long
   g.epi.ldg = ldg;
   g.epi.geglu_F = geglu_F;
   const PlainLoader la = plain(Adown, K, LR, K);
-  LoraParams lp{S, Bup, T, Ts, rows_per_sample};
+  LoraParams lp{};
+  lp.S = S, lp.Bup = Bup, lp.T = T, lp.Ts = Ts, lp.rps = rows_per_sample;
+  lp.ngroups = ngroups;
+  for (int i = 0; i <= ngroups && ngroups > 0; ++i) lp.col_start[i] = col_start[i];
+  if (ngroups > 0 && N % 160 != 0) return AQL_NOT_FUSED;  // groups are cut at 160-column tile boundaries
   static const int deep_kt = getenv("AQL_DEEPKT") ? atoi(getenv("AQL_DEEPKT")) : 32;
   static const int force_bm = getenv("AQL_LORA_BM") ? atoi(getenv("AQL_LORA_BM")) : 0;  // tuning hook (160-wide tiles)
+  // tuning hook (tools/tune_lora_cfg.py), re-read on every call: w128 / w64 / w32 = wave-specialised kernel with that tile
+  // height, d128 / d64 / d32 = 4-wave kernel (ring depth by grid size), d128s / d64s / d32s = 4-wave kernel, 2 stages
+  if (const char* cfg = getenv("AQL_LORA_CFG")) {
+    if (N % 160 == 0 && cfg[0]) {
+      const int bm = atoi(cfg + 1);
+      const int tiles = aql_cdiv(M, bm) * (N / 160);
+      const bool shallow = cfg[strlen(cfg) - 1] == 's' || tiles > 288;
+      bool ok = true;
+      if (cfg[0] == 'w' && bm == 128) launch_w<128, 160, 64, 80, 3>(g, la, lp, stream);
+      else if (cfg[0] == 'w' && bm == 64) launch_w<64, 160, 32, 80, 4>(g, la, lp, stream);
+      else if (cfg[0] == 'w' && bm == 32) launch_w<32, 160, 16, 80, 5>(g, la, lp, stream);
+      else if (cfg[0] == 'd' && bm == 128) { if (shallow) launch<128, 160, 64, 80, 2>(g, la, lp, stream); else launch<128, 160, 64, 80, 3>(g, la, lp, stream); }
+      else if (cfg[0] == 'd' && bm == 64) { if (shallow) launch<64, 160, 32, 80, 2>(g, la, lp, stream); else launch<64, 160, 32, 80, 5>(g, la, lp, stream); }
+      else if (cfg[0] == 'd' && bm == 32) { if (shallow) launch<32, 160, 16, 80, 2>(g, la, lp, stream); else launch<32, 160, 16, 80, 5>(g, la, lp, stream); }
+      else ok = false;
+      if (ok) {
+        AQL_CHECK_LAUNCH("aql_lora_gemm_fused");
+        return AQL_OK;
+      }
+    }
+  }
   // tile choice: the largest 160-wide (or square) tile that still gives about one workgroup per CU
   if (N % 160 == 0) {
     const int nt = N / 160;
@@ -597,7 +648,23 @@ extern "C" int aql_lora_gemm_fused(const bf16_t* X, long ldx, const bf16_t* W, l
                                    const bf16_t* bias, const bf16_t* residual, long ldr, bf16_t* Y, long ldy, bf16_t* T,
                                    bf16_t* Ts, hipStream_t stream) {
   return lora_gemm_fused_impl(X, ldx, W, ldw, M, N, K, Adown, S, rows_per_sample, Bup, bias, residual, ldr, Y, ldy, T, Ts,
-                              nullptr, 0, 0, stream);
+                              nullptr, 0, 0, 0, nullptr, stream);
+}
+
+// Several rank-32 LoRA linears that share their input in ONE launch (q|k|v of a self-attention,
+// scripts/lib/original_unet.py:688-704; the k|v projections of the text states of every cross-attention): W [N][K], Bup [N][32]
+// and bias are the linears stacked along N, Adown [ngroups*32][K] the stacked down matrices, T / Ts [ngroups][M][32].
+// col_start[0..ngroups] (host array): first output column of every linear, multiples of 160, col_start[ngroups] = N.
+extern "C" int aql_lora_gemm_fused_grouped(const bf16_t* X, long ldx, const bf16_t* W, long ldw, long M, int N, int K,
+                                           int ngroups, const int* col_start, const bf16_t* Adown, const bf16_t* S,
+                                           int rows_per_sample, const bf16_t* Bup, const bf16_t* bias, bf16_t* Y, long ldy,
+                                           bf16_t* T, bf16_t* Ts, hipStream_t stream) {
+  AQL_CHECK_ARG(ngroups >= 1 && ngroups <= MAXG && col_start != nullptr, "aql_lora_gemm_fused_grouped: 1..%d groups", MAXG);
+  AQL_CHECK_ARG(col_start[0] == 0 && col_start[ngroups] == N, "aql_lora_gemm_fused_grouped: col_start must span [0, N]");
+  for (int i = 0; i < ngroups; ++i)
+    AQL_CHECK_ARG(col_start[i] % 160 == 0 && col_start[i] < col_start[i + 1], "aql_lora_gemm_fused_grouped: bad group %d", i);
+  return lora_gemm_fused_impl(X, ldx, W, ldw, M, N, K, Adown, S, rows_per_sample, Bup, bias, nullptr, 0, Y, ldy, T, Ts, nullptr,
+                              0, 0, ngroups, col_start, stream);
 }
 
 // ff.net.0.proj with the rank-32 watermark LoRA AND the GEGLU activation in one launch (aql_gemm_bf16_geglu's tile layout on
@@ -610,5 +677,5 @@ extern "C" int aql_lora_gemm_fused_geglu(const bf16_t* X, long ldx, const bf16_t
   AQL_CHECK_ARG(G && F > 0 && ldg % 8 == 0 && (H == nullptr || ldh % 8 == 0), "aql_lora_gemm_fused_geglu: bad args");
   if (F % 80 != 0) return AQL_NOT_FUSED;
   return lora_gemm_fused_impl(X, ldx, W, ldw, M, 2 * F, K, Adown, S, rows_per_sample, Bup, bias, nullptr, 0, H, ldh, T, Ts, G,
-                              ldg, F, stream);
+                              ldg, F, 0, nullptr, stream);
 }

@@ -336,7 +336,7 @@ class LoraBank:
         # bf16 compute copies (A, A^T, Bup, Bup^T per site) in one flat buffer, refreshed by ONE batched launch
         import numpy as np
         total16 = sum(2 * (l.down.weight.numel() + l.up.weight.numel()) for l in self.layers)
-        self.c16 = torch.empty(total16 + 64, dtype=torch.bfloat16, device=dev)
+        self.c16 = torch.empty(total16 + 64 + 8 * 4 * len(self.layers), dtype=torch.bfloat16, device=dev)
         desc = np.zeros(2 * len(self.layers), dtype=np.dtype(
             [("w", "<u8"), ("out", "<u8"), ("outT", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("first", "<i4"),
              ("pad", "<i4")]))
@@ -349,14 +349,48 @@ class LoraBank:
             off16 += (n + 7) // 8 * 8  # keep every view 16-byte aligned
             return v
 
-        for layer in self.layers:
+        # Cohorts: sites whose linears read the same input run as ONE grouped launch (ops.GroupedLoraFn) and need their bf16
+        # A matrices stacked back to back (and their Bup matrices likewise): q|k|v of every self-attention, and the k|v
+        # projections of the text states of ALL cross-attentions (sorted key order = U-Net traversal order, k before v).
+        cohort_of, cohorts = {}, []
+        by_key = dict(zip(keys, self.layers))
+        for k in keys:
+            if k.endswith(".attn1.to_q"):
+                base = k[:-len("to_q")]
+                trio = [base + "to_q", base + "to_k", base + "to_v"]
+                if all(t in by_key for t in trio):
+                    cohorts.append(trio)
+        kv = sorted([k for k in keys if k.endswith(".attn2.to_k") or k.endswith(".attn2.to_v")],
+                    key=lambda k: (k.rsplit(".", 1)[0], k.rsplit(".", 1)[1]))
+        if kv:
+            cohorts.append(kv)
+        for c in cohorts:
+            for k in c:
+                cohort_of[k] = c
+        self.cohorts = cohorts
+        views, done = {}, set()
+        for key, layer in zip(keys, self.layers):
+            if key in done:
+                continue
+            members = cohort_of.get(key, [key])
+            dims = {}
+            for m in members:
+                lay = by_key[m]
+                r = lay.rank
+                dims[m] = (r, lay.down.weight.numel() // r, lay.up.weight.numel() // r)
+            a = {m: take(dims[m][0] * dims[m][1]).view(dims[m][0], dims[m][1]) for m in members}     # stacked A [r, K]
+            b = {m: take(dims[m][2] * dims[m][0]).view(dims[m][2], dims[m][0]) for m in members}     # stacked Bup [N, r]
+            for m in members:
+                r, K, N = dims[m]
+                views[m] = (a[m], take(r * K).view(K, r), b[m], take(N * r).view(r, N))
+                done.add(m)
+        for key, layer in zip(keys, self.layers):
             site = LoraSite(layer)
             site.managed = True
             r = layer.rank
             K = layer.down.weight.numel() // r
             N = layer.up.weight.numel() // r
-            site.a16, site.at16 = take(r * K).view(r, K), take(r * K).view(K, r)
-            site.b16, site.bt16 = take(N * r).view(N, r), take(N * r).view(r, N)
+            site.a16, site.at16, site.b16, site.bt16 = views[key]
             for w, rows, cols, o, ot in ((layer.down.weight, r, K, site.a16, site.at16),
                                          (layer.up.weight, N, r, site.b16, site.bt16)):
                 desc[di] = (w.data_ptr(), o.data_ptr(), ot.data_ptr(), rows, cols, tile, 0)

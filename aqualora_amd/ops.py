@@ -46,7 +46,7 @@ def _gn_scratch(device, B):
 
 
 # ---------------------------------------------------------------------------------- branch-level concurrency
-BRANCH_STREAMS = 0   # >0: independent sibling ops (attention q/k/v projections) are issued on this many side streams.
+BRANCH_STREAMS = int(os.environ.get("AQL_BRANCH_STREAMS", "0"))   # >0: independent sibling ops (attention q/k/v projections) are issued on this many side streams.
 # EXPERIMENTAL, eager only: nested stream forks inside a hipGraph capture crash hipStreamEndCapture on this ROCm
 # (measured round 1), so the captured trainer keeps it at 0.
 _BR = {}
@@ -629,41 +629,134 @@ class LoraLinearFn(torch.autograd.Function):
             dy = dh
         if ctx.use_lora:
             x2d, T, Ts, S16 = ctx.saved_tensors[:4]
-            r = site.rank
-            # dTs = dY.Bup  (and dT = dTs * S) -- same two-output epilogue as the forward "down" GEMM
-            dTs = torch.empty(M, r, dtype=torch.bfloat16, device=dy.device)
-            dT = torch.empty_like(dTs)
-            nb = S16.shape[0]
-            acc = ctx.ds_accum
-            want_ds = ctx.needs_input_grad[3] or acc is not None
-            if want_ds and acc is None:
-                dS = torch.zeros(nb, r, dtype=torch.float32, device=dy.device)
-            dfr = DEFERRED
-            ds_target = acc if acc is not None else dS
-            ds_deferred = want_ds and dfr is not None and acc is not None
-            dx = None
-            if ctx.needs_input_grad[0]:   # dTs = dY.Bup, dT = dTs * S, dX = dY.W + dT.A in one launch
-                dx = _lora_gemm_fused(dy, packed.wt, site.bt16, S16, ctx.rps, site.at16, None, None, dTs, dT)
-            if dx is not None:
-                if want_ds and not ds_deferred:
-                    L.call("aql_lora_ds", L.ptr(dTs), L.ptr(T), nb, ctx.rps, r, L.ptr(ds_target), L.stream_ptr())
-            else:
-                L.call("aql_lora_down", L.ptr(dy), dy.stride(0), M, packed.N, L.ptr(site.bt16), r, L.ptr(S16), ctx.rps,
-                       L.ptr(dTs), L.ptr(dT), L.ptr(T) if (want_ds and not ds_deferred) else None,
-                       L.ptr(ds_target) if (want_ds and not ds_deferred) else None, L.stream_ptr())
-                dx = gemm_bf16(dy, packed.wt, None, dT, site.at16) if ctx.needs_input_grad[0] else None
-            if ds_deferred and not dfr.add_ds(dTs, T, ds_target, nb, ctx.rps, r):
-                L.call("aql_lora_ds", L.ptr(dTs), L.ptr(T), nb, ctx.rps, r, L.ptr(ds_target), L.stream_ptr())
-            # dBup[N,r] += dY^T Ts ; dA[r,K] += dT^T X   (grouped at the end of backward when a trainer defers them)
-            if dfr is None or not dfr.add_tn(dy, Ts, site.gb):
-                gemm_tn_acc(dy, Ts, site.gb)
-            if dfr is None or not dfr.add_tn(dT, x2d, site.ga):
-                gemm_tn_acc(dT, x2d, site.ga)
-            if dS is not None:
-                dS = dS.to(ctx.s_dtype) if ctx.needs_input_grad[3] else None
+            dx, dS = _lora_backward(dy, x2d, T, Ts, S16, packed, site, ctx.rps, ctx.ds_accum, ctx.needs_input_grad[0],
+                                    ctx.needs_input_grad[3], ctx.s_dtype, None)
         else:
             dx = gemm_bf16(dy, packed.wt) if ctx.needs_input_grad[0] else None
         return dx, None, None, dS, None, None, (dy if ctx.has_res else None), None, None
+
+
+def _lora_backward(dy, x2d, T, Ts, S16, packed, site, rps, ds_accum, want_dx, ret_ds, s_dtype, dx_prev):
+    """Backward of one LoRA linear  Y = X.W^T + ((X.A^T)*S).Bup^T :  dTs = dY.Bup, dT = dTs*S, dX = dY.W + dT.A (+ dx_prev, added
+    in the GEMM epilogue), dS += rowsum(dTs*T) per sample, and the weight gradients dBup += dY^T.Ts, dA += dT^T.X (queued on the
+    trainer's DeferredDW when there is one).  Returns (dX or None, dS in s_dtype or None)."""
+    M = dy.shape[0]
+    r = site.rank
+    dS = None
+    dTs = torch.empty(M, r, dtype=torch.bfloat16, device=dy.device)
+    dT = torch.empty_like(dTs)
+    nb = S16.shape[0]
+    acc = ds_accum
+    want_ds = ret_ds or acc is not None
+    if want_ds and acc is None:
+        dS = torch.zeros(nb, r, dtype=torch.float32, device=dy.device)
+    dfr = DEFERRED
+    ds_target = acc if acc is not None else dS
+    ds_deferred = want_ds and dfr is not None and acc is not None
+    dx = None
+    if want_dx:   # dTs = dY.Bup, dT = dTs * S, dX = dY.W + dT.A in one launch
+        dx = _lora_gemm_fused(dy, packed.wt, site.bt16, S16, rps, site.at16, None, dx_prev, dTs, dT)
+    if dx is not None:
+        if want_ds and not ds_deferred:
+            L.call("aql_lora_ds", L.ptr(dTs), L.ptr(T), nb, rps, r, L.ptr(ds_target), L.stream_ptr())
+    else:
+        L.call("aql_lora_down", L.ptr(dy), dy.stride(0), M, packed.N, L.ptr(site.bt16), r, L.ptr(S16), rps,
+               L.ptr(dTs), L.ptr(dT), L.ptr(T) if (want_ds and not ds_deferred) else None,
+               L.ptr(ds_target) if (want_ds and not ds_deferred) else None, L.stream_ptr())
+        dx = gemm_bf16(dy, packed.wt, None, dT, site.at16, residual=dx_prev) if want_dx else None
+    if ds_deferred and not dfr.add_ds(dTs, T, ds_target, nb, rps, r):
+        L.call("aql_lora_ds", L.ptr(dTs), L.ptr(T), nb, rps, r, L.ptr(ds_target), L.stream_ptr())
+    # dBup[N,r] += dY^T Ts ; dA[r,K] += dT^T X   (grouped at the end of backward when a trainer defers them)
+    if dfr is None or not dfr.add_tn(dy, Ts, site.gb):
+        gemm_tn_acc(dy, Ts, site.gb)
+    if dfr is None or not dfr.add_tn(dT, x2d, site.ga):
+        gemm_tn_acc(dT, x2d, site.ga)
+    if dS is not None:
+        dS = dS.to(s_dtype) if ret_ds else None
+    return dx, dS
+
+
+# --------------------------------------------------------------------------- grouped LoRA linears (shared input)
+def adjacent(tensors):
+    """True when the tensors lie back to back in memory in this order (one contiguous stacked matrix)."""
+    for a, b in zip(tensors, tensors[1:]):
+        if not (a.is_contiguous() and b.is_contiguous()) or a.data_ptr() + a.numel() * a.element_size() != b.data_ptr():
+            return False
+    return True
+
+
+class GroupedLoraFn(torch.autograd.Function):
+    """G rank-32 LoRA linears that read the SAME input, as one launch (aql_lora_gemm_fused_grouped): q|k|v of a self-attention
+    (original_unet.py:688-704) or the k|v projections of the text states of all cross-attentions.  ``wcat`` [sum N_g, K] is the
+    stacked frozen weight; the sites' bf16 A / Bup copies must be stacked in memory in group order (lora.LoraBank lays them out
+    so); returns the G outputs as column views of one [M, sum N_g] buffer.  Backward: one fused backward-data launch per group,
+    each adding the previous group's dX in its epilogue (no separate accumulation kernels), weight gradients queued as usual."""
+
+    @staticmethod
+    def forward(ctx, x2d, wcat, packs, sites, S, S16, rps):
+        _req(x2d, "grouped lora_linear")
+        M, K = x2d.shape
+        G = len(sites)
+        dev = x2d.device
+        xk = _full(x2d)
+        twin = xk is not None
+        if not twin:
+            xk = x2d
+        S16k = _need_full(S16, "the LoRA scale") if twin else S16
+        cols = [0]
+        for p in packs:
+            cols.append(cols[-1] + p.N)
+        N = cols[-1]
+        Mk = xk.shape[0]
+        yk = torch.empty(Mk, N, dtype=torch.bfloat16, device=dev)
+        Tk = torch.empty(G, Mk, 32, dtype=torch.bfloat16, device=dev)
+        Tsk = torch.empty_like(Tk)
+        if twin:
+            DUAL.register(yk)
+        import ctypes
+        cs = (ctypes.c_int * (G + 1))(*cols)
+        rc = L.call_raw("aql_lora_gemm_fused_grouped", L.ptr(xk), xk.stride(0), L.ptr(wcat), wcat.stride(0), Mk, N, K, G, cs,
+                        L.ptr(sites[0].a16), L.ptr(S16k), rps, L.ptr(sites[0].b16), None, L.ptr(yk), N, L.ptr(Tk), L.ptr(Tsk),
+                        L.stream_ptr())
+        L.check(rc, "aql_lora_gemm_fused_grouped")
+        y = yk[M:] if twin else yk
+        ctx.packs, ctx.sites, ctx.rps, ctx.s_dtype = packs, sites, rps, S.dtype
+        ctx.ds_accum = getattr(S, "_aql_ds_accum", None)
+        T = Tk[:, M:] if twin else Tk
+        Ts = Tsk[:, M:] if twin else Tsk
+        ctx.save_for_backward(x2d, T, Ts, S16)
+        return tuple(y[:, cols[g]:cols[g + 1]] for g in range(G))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x2d, T, Ts, S16 = ctx.saved_tensors
+        dx, dS_sum = None, None
+        for g, dy in enumerate(dys):
+            if dy is None:
+                continue
+            dy = dy.contiguous()
+            dx_g, dS = _lora_backward(dy, x2d, T[g], Ts[g], S16, ctx.packs[g], ctx.sites[g], ctx.rps, ctx.ds_accum,
+                                      ctx.needs_input_grad[0], ctx.needs_input_grad[4], ctx.s_dtype, dx)
+            if dx_g is not None:
+                dx = dx_g
+            if dS is not None:
+                dS_sum = dS if dS_sum is None else dS_sum + dS
+        return dx, None, None, None, dS_sum, None, None
+
+
+def grouped_lora_ok(x2d, packs, sites, S16):
+    """The one-launch grouped form applies: rank 32 everywhere, 160-column groups, stacked bf16 copies, fused kernel enabled."""
+    if S16 is None or os.environ.get("AQL_LORA_FUSED", "1") == "0" or os.environ.get("AQL_GROUPED", "1") == "0":
+        return False
+    if len(sites) > 32 or any(s is None or s.rank != 32 for s in sites) or any(p.N % 160 != 0 or p.bias is not None for p in packs):
+        return False
+    if x2d.shape[1] % 8 != 0:
+        return False
+    return adjacent([s.a16 for s in sites]) and adjacent([s.b16 for s in sites])
+
+
+def lora_linear_grouped(x2d, wcat, packs, sites, S, S16, rps):
+    return GroupedLoraFn.apply(x2d, wcat, tuple(packs), tuple(sites), S, S16, rps)
 
 
 def lora_linear(x2d, packed, site=None, S=None, S16=None, rps=1, residual=None, geglu=False):
@@ -923,7 +1016,8 @@ class AttentionFn(torch.autograd.Function):
         Nk = k.shape[1]
         heads = ctx.heads
         d = C // heads
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        # dense gradients whatever the strides of q / k / v (they may be column views of a grouped projection's output)
+        dq, dk, dv = (torch.empty(t.shape, dtype=t.dtype, device=t.device) for t in (q, k, v))
         delta = torch.empty(B, heads, Nq, dtype=torch.float32, device=q.device)
         ws = workspace(q.device)
         ws = workspace(q.device)   # split-Q partials of dK/dV when Nk is short (cross-attention)

@@ -163,13 +163,48 @@ class Attention(nn.Module):
         o = ops.attention(q, k, v, self.heads)
         return self.to_out[0](o, None, residual=residual)
 
+    def _grouped_qkv(self, hidden_states, scale):
+        """q|k|v of a self-attention as ONE grouped LoRA launch (they read the same tokens); None when the grouped form does
+        not apply (no LoRA, rank != 32, float scale, bf16 copies not stacked by a LoraBank ...)."""
+        if not torch.is_tensor(scale) or hidden_states.dim() != 3 or hidden_states.dtype != torch.bfloat16:
+            return None
+        mods = (self.to_q, self.to_k, self.to_v)
+        if any(m.lora_layer is None or m.bias is not None for m in mods):
+            return None
+        from .lora import _scale16, _site_of
+        sites = [_site_of(m.lora_layer) for m in mods]
+        packs = [_packed_linear(m) for m in mods]
+        B, N, C = hidden_states.shape
+        x2d = hidden_states.reshape(B * N, C)
+        if any(st.rank != 32 for st in sites) or scale.dim() != 2 or scale.shape[1] != 32:
+            return None
+        S = _scale16(scale, B, 32, x2d.device)
+        S16 = getattr(S, "_aql_s16", None)
+        if S16 is None:
+            S16 = S.detach().to(torch.bfloat16).contiguous()
+            S._aql_s16 = S16
+        if not x2d.is_contiguous() or not ops.grouped_lora_ok(x2d, packs, sites, S16):
+            return None
+        q, k, v = ops.lora_linear_grouped(x2d, self._fused_weights(False), packs, sites, S, S16, N)
+        return q.view(B, N, C), k.view(B, N, C), v.view(B, N, C)
+
     def forward(self, hidden_states, encoder_hidden_states=None, scale=1.0, residual=None):
         if (scale is None and not torch.is_grad_enabled() and hidden_states.dim() == 3
                 and hidden_states.dtype == torch.bfloat16 and hidden_states.is_contiguous()):
             return self._forward_nolora(hidden_states, encoder_hidden_states, residual)
-        ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
-        q, k, v = ops.parallel([lambda: self.to_q(hidden_states, scale), lambda: self.to_k(ctx, scale),
+        qkv = None
+        if encoder_hidden_states is None:
+            qkv = self._grouped_qkv(hidden_states, scale)
+        else:
+            cache = getattr(encoder_hidden_states, "_aql_kv", None)   # k|v of all cross-attentions, one launch (UNet.forward)
+            if cache is not None and id(self) in cache:
+                k, v = cache[id(self)]
+                qkv = (self.to_q(hidden_states, scale), k, v)
+        if qkv is None:
+            ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
+            qkv = ops.parallel([lambda: self.to_q(hidden_states, scale), lambda: self.to_k(ctx, scale),
                                 lambda: self.to_v(ctx, scale)])
+        q, k, v = qkv
         o = ops.attention(q, k, v, self.heads)
         return self.to_out[0](o, scale, residual=residual)
 
@@ -346,6 +381,46 @@ class UNet2DConditionModel(nn.Module):
         allp = ops.lora_linear(temb_act.contiguous(), packed)
         return {key: allp[:, o:o + n] for key, o, n in offs}
 
+    def _ctx_kv(self, ctx, scale):
+        """attn2.to_k / to_v of ALL cross-attentions depend only on the text states: 32 small LoRA linears (616 x 768 -> C at
+        twin batch 8) become ONE grouped launch in front of the U-Net; every cross-attention picks its k, v column views from
+        ``ctx._aql_kv``.  Skipped (the per-site path runs) unless the grouped form applies."""
+        if hasattr(ctx, "_aql_kv"):
+            del ctx._aql_kv
+        if not torch.is_tensor(scale) or ctx.dim() != 3 or scale.dim() != 2 or scale.shape[1] != 32:
+            return
+        from .lora import _scale16, _site_of
+        cache = getattr(self, "_aql_ctxkv", None)
+        if cache is None:
+            attns = [m.attn2 for m in self.modules() if isinstance(m, BasicTransformerBlock)]
+            names = {id(m): n for n, m in self.named_modules()}
+            attns.sort(key=lambda a: names[id(a)])
+            mods = [m for a in attns for m in (a.to_k, a.to_v)]
+            cache = (attns, mods)
+            object.__setattr__(self, "_aql_ctxkv", cache)
+        attns, mods = cache
+        if not mods or any(m.lora_layer is None or m.bias is not None for m in mods):
+            return
+        sites = [_site_of(m.lora_layer) for m in mods]
+        packs = [_packed_linear(m) for m in mods]
+        if any(st.rank != 32 for st in sites):
+            return
+        B, N, C = ctx.shape
+        x2d = ctx.reshape(B * N, C)
+        S = _scale16(scale, B, 32, x2d.device)
+        S16 = getattr(S, "_aql_s16", None)
+        if S16 is None:
+            S16 = S.detach().to(torch.bfloat16).contiguous()
+            S._aql_s16 = S16
+        if not ops.grouped_lora_ok(x2d, packs, sites, S16):
+            return
+        wc = getattr(self, "_aql_ctxkv_w", None)
+        if wc is None or any(a is not b for a, b in zip(wc[0], packs)):
+            wc = (packs, torch.cat([p.w for p in packs], dim=0).contiguous())
+            object.__setattr__(self, "_aql_ctxkv_w", wc)
+        outs = ops.lora_linear_grouped(x2d, wc[1], packs, sites, S, S16, N)
+        ctx._aql_kv = {id(a): (outs[2 * i].view(B, N, -1), outs[2 * i + 1].view(B, N, -1)) for i, a in enumerate(attns)}
+
     @property
     def dtype(self):
         return self.conv_in.weight.dtype
@@ -372,6 +447,7 @@ class UNet2DConditionModel(nn.Module):
         temb_act = torch.nn.functional.silu(emb)  # every ResNet applies SiLU to temb first (original_unet.py:449)
         temb_act = self._all_time_projections(temb_act)
         ctx = encoder_hidden_states.to(self.dtype).contiguous()
+        self._ctx_kv(ctx, scale)
         h = self.conv_in(sample, scale)
         skips = (h,)
         for blk in self.down_blocks:

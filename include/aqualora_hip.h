@@ -74,6 +74,15 @@ int aql_lora_gemm_fused_geglu(const bf16_t* X, long ldx, const bf16_t* W, long l
                               const bf16_t* Adown, const bf16_t* S, int rows_per_sample, const bf16_t* Bup,
                               const bf16_t* bias, bf16_t* H, long ldh, bf16_t* G, long ldg, bf16_t* T, bf16_t* Ts,
                               aql_stream_t stream);
+/* Several rank-32 LoRA linears that share their input as ONE launch of aql_lora_gemm_fused: q|k|v of a self-attention
+ * (attn.to_q / to_k / to_v, scripts/lib/original_unet.py:688-704) or the k|v projections of the text states of all 16
+ * cross-attentions.  W [N,K], Bup [N,32], bias [N] are the linears stacked along N; Adown [ngroups*32, K] the stacked down
+ * matrices; T, Ts [ngroups][M][32].  col_start[0..ngroups] (HOST array): first output column of each linear (multiples of
+ * 160; col_start[ngroups] = N).  Returns 100 like aql_lora_gemm_fused.                                                  */
+int aql_lora_gemm_fused_grouped(const bf16_t* X, long ldx, const bf16_t* W, long ldw, long M, int N, int K, int ngroups,
+                                const int* col_start, const bf16_t* Adown, const bf16_t* S, int rows_per_sample,
+                                const bf16_t* Bup, const bf16_t* bias, bf16_t* Y, long ldy, bf16_t* T, bf16_t* Ts,
+                                aql_stream_t stream);
 int aql_conv3x3_bwd_data(const bf16_t* dY, int B, int Hin, int Win, int Cin, const bf16_t* Wt, int Cout, int stride,
                          bf16_t* dX, float* ws, size_t ws_bytes, aql_stream_t stream);
 

@@ -42,7 +42,7 @@ def test_transpose_read_weight_gradient_gemm():
 def test_one_launch_lora_linear():
     """aql_lora_gemm_fused (T side accumulator + up-projection k-step, 4-wave and wave-specialised kernels) vs fp32 torch."""
     text = _run("probe_lora_gemm.py")
-    assert text.count("PASS") >= 13
+    assert text.count("PASS") >= 17   # incl. the grouped launch (q|k|v, text-state k|v of all blocks) == separate launches
 
 
 def test_geglu_epilogue_equals_two_kernel_path():

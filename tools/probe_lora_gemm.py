@@ -43,4 +43,41 @@ for M, N, K, nb in CASES:
     ok = eT < 1e-2 and eTs < 1.5e-2 and eY < 1.5e-2
     ok_all &= ok
     print(f"{'PASS' if ok else 'FAIL'} lora_gemm M{M} N{N} K{K} nb{nb}: T {eT:.2e} Ts {eTs:.2e} Y {eY:.2e}")
+
+# ---- grouped launch (aql_lora_gemm_fused_grouped): G linears that share X == G separate launches, bit for bit
+import ctypes  # noqa: E402
+for M, K, widths, nb in [(8192, 320, (320, 320, 320), 4), (616, 768, (320, 320, 640, 640, 1280, 1280, 1280), 8),
+                         (2048, 1280, (1280, 1280, 1280), 2), (300, 640, (640, 160), 3)]:
+    rps = (M + nb - 1) // nb
+    G = len(widths)
+    N = sum(widths)
+    cols = [0]
+    for w in widths:
+        cols.append(cols[-1] + w)
+    X, W, A, Bup, S = rnd(M, K), rnd(N, K, std=K ** -0.5), rnd(32 * G, K, std=K ** -0.5), rnd(N, 32, std=0.2), rnd(nb, 32)
+    Y = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    T = torch.empty(G, M, 32, dtype=torch.bfloat16, device=dev)
+    Ts = torch.empty_like(T)
+    cs = (ctypes.c_int * (G + 1))(*cols)
+    rc = L.call_raw("aql_lora_gemm_fused_grouped", L.ptr(X), K, L.ptr(W), K, M, N, K, G, cs, L.ptr(A), L.ptr(S), rps, L.ptr(Bup),
+                    None, L.ptr(Y), N, L.ptr(T), L.ptr(Ts), L.stream_ptr())
+    L.check(rc, "aql_lora_gemm_fused_grouped")
+    same, worst = True, 0.0
+    for g in range(G):
+        c0, c1 = cols[g], cols[g + 1]
+        Wg, Ag, Bg = W[c0:c1].contiguous(), A[32 * g:32 * g + 32].contiguous(), Bup[c0:c1].contiguous()
+        Yg = torch.empty(M, c1 - c0, dtype=torch.bfloat16, device=dev)
+        Tg = torch.empty(M, 32, dtype=torch.bfloat16, device=dev)
+        Tsg = torch.empty_like(Tg)
+        rc = L.call_raw("aql_lora_gemm_fused", L.ptr(X), K, L.ptr(Wg), K, M, c1 - c0, K, L.ptr(Ag), L.ptr(S), rps, L.ptr(Bg), None,
+                        None, 0, L.ptr(Yg), c1 - c0, L.ptr(Tg), L.ptr(Tsg), L.stream_ptr())
+        if rc == 0:
+            same &= torch.equal(Yg, Y[:, c0:c1]) and torch.equal(Tg, T[g]) and torch.equal(Tsg, Ts[g])
+        rows = torch.arange(M, device=dev) // rps
+        Tb = (X.float() @ Ag.float().t()).to(torch.bfloat16).float()
+        Yr = X.float() @ Wg.float().t() + (Tb * S.float()[rows]).to(torch.bfloat16).float() @ Bg.float().t()
+        worst = max(worst, rel(Y[:, c0:c1], Yr))
+    ok = same and worst < 1.5e-2
+    ok_all &= ok
+    print(f"{'PASS' if ok else 'FAIL'} lora_gemm_grouped M{M} K{K} groups{widths}: equals the separate launches {same}, vs fp32 {worst:.2e}")
 print("ALL PASS" if ok_all else "SOME FAILED")
