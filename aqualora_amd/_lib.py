@@ -22,10 +22,14 @@ c_sz = ctypes.c_size_t
 SIGNATURES = {
     "aql_gemm_bf16": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_i, c_p, c_l, c_p, c_l,
                       c_p, c_sz, c_p],
-    "aql_lora_gemm_fused": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_p],
-    "aql_gemm_bf16_geglu": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_l, c_p],
-    "aql_lora_gemm_fused_geglu": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_p],
-    "aql_lora_gemm_fused_grouped": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_l, c_p, c_p, c_p],
+    "aql_gemm_bf16_ex": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_i, c_p, c_l, c_p, c_l,
+                         c_l, c_p, c_sz, c_p],
+    "aql_lora_gemm_fused": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p],
+    "aql_gemm_bf16_geglu": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_l, c_l, c_p],
+    "aql_lora_gemm_fused_geglu": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_l,
+                                  c_p],
+    "aql_lora_gemm_fused_grouped": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_l, c_p, c_p, c_l,
+                                    c_p],
     "aql_lora_down": [c_p, c_l, c_l, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p],
     "aql_conv3x3_fwd": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_sz, c_p],
     "aql_conv3x3_fwd_pad": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_sz, c_p],

@@ -38,6 +38,7 @@ struct PlainLoader {
   // GEGLU tiles (EpiParams::geglu_F): tile-local row lr >= gsplit reads source row (row0 + lr + goff), so that one 160-row
   // weight tile holds 80 "value" rows [n0, n0+80) and the matching 80 "gate" rows [F+n0, F+n0+80).  0 = plain rows.
   int gsplit = 0, goff = 0;
+  int row_lo = 0;  // rows below row_lo read as zeros (segment 1 of a twin batch: the clean half has no LoRA term)
 };
 
 // Forward 3x3 conv, NHWC input [B,Hin,Win,Cin]; row r = (b,ho,wo); k = (kh*3+kw)*Cin + ci.
@@ -93,6 +94,8 @@ struct EpiParams {
   bf16_t* G = nullptr;
   long ldg = 0;
   int geglu_F = 0;
+  int c_row0 = 0;          // GEGLU: the pre-activation C is written for rows >= c_row0 only (twin batches: the clean half
+                           // never runs backward)
   int trans_out;           // EPI_ATOMIC only: write C^T, i.e. element (m,n) goes to Cf[n*ldcf + m]
   // EPI_SLAB / EPI_ATOMIC: fp32 output
   float* Cf;               // slab base [splits][M][ldcf] or atomic target [M][ldcf]
@@ -112,6 +115,7 @@ struct GemmArgs {
   LB b1;
   int ktiles0, ktiles1;
   int M, N;
+  int seg1_row0 = 0;  // output tiles that end at or below this row skip K segment 1 (twin batch: clean rows carry no LoRA term)
   int splits;  // grid.z; k tiles of the concatenated K range are divided evenly
   int m_fast;  // tile order: 0 = N tiles of one M tile adjacent (activation reuse), 1 = M tiles adjacent (weight reuse)
   EpiParams epi;
@@ -446,7 +450,7 @@ struct DmaStager<R, PlainLoader> {
       const int r = row0 + lr + ((l0.gsplit && lr >= l0.gsplit) ? l0.goff : 0);
       const int r1 = row0 + lr + ((l1.gsplit && lr >= l1.gsplit) ? l1.goff : 0);
       const uint32_t v0 = r < l0.rows ? (uint32_t)r * (uint32_t)(l0.ld * 2) + kc * 2 : OOB_ROW;
-      voff1[i] = (dual && r1 < l1.rows) ? (uint32_t)r1 * (uint32_t)(l1.ld * 2) + kc * 2 : OOB_ROW;
+      voff1[i] = (dual && r1 < l1.rows && r1 >= l1.row_lo) ? (uint32_t)r1 * (uint32_t)(l1.ld * 2) + kc * 2 : OOB_ROW;
       voff[i] = in1 ? voff1[i] : v0;
     }
     const int kend0 = min(l0.K, min(t_end, ktiles0) * BK);
@@ -626,7 +630,7 @@ __device__ __forceinline__ void geglu_store(const char* lds, int m0, int n0, int
     if (m >= M || n >= F) continue;
     const uint4 v = *reinterpret_cast<const uint4*>(lds + row * C_PITCH + cc * 16);
     const uint4 gt = *reinterpret_cast<const uint4*>(lds + row * C_PITCH + BN + cc * 16);
-    if (ep.C != nullptr) {
+    if (ep.C != nullptr && m >= ep.c_row0) {
       *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + n) = v;
       *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + F + n) = gt;
     }
@@ -671,10 +675,11 @@ __device__ __forceinline__ void gemm_body_d(const GemmArgs<LA, LB>& g, const int
   const int m0 = tile_m * BM, n0 = tile_n * (gF ? BN / 2 : BN);
 
   // K range of this split; tiles past kt_end read as zeros (K limit folded into the loaders)
-  const int kt_total = g.ktiles0 + g.ktiles1;
+  const int kt1 = (m0 + BM <= g.seg1_row0) ? 0 : g.ktiles1;   // block-uniform: clean tiles of a twin batch skip segment 1
+  const int kt_total = g.ktiles0 + kt1;
   const int kt_begin = (int)(((long)kt_total * block_z) / g.splits);
   const int kt_end = (int)(((long)kt_total * (block_z + 1)) / g.splits);
-  const bool dual = g.ktiles1 > 0;
+  const bool dual = kt1 > 0;
 
   DmaStager<BM, LA> sa;  // row descriptors only: tiles go global -> LDS directly (no staging registers, no ds_write)
   DmaStager<BN, LB> sb;
@@ -873,10 +878,11 @@ __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int
   const int m0 = tile_m * BM, n0 = tile_n * (gF ? BN / 2 : BN);
 
   // K range of this split; tiles past kt_end read as zeros (K limit folded into the loaders)
-  const int kt_total = g.ktiles0 + g.ktiles1;
+  const int kt1 = (m0 + BM <= g.seg1_row0) ? 0 : g.ktiles1;   // block-uniform: clean tiles of a twin batch skip segment 1
+  const int kt_total = g.ktiles0 + kt1;
   const int kt_begin = (int)(((long)kt_total * block_z) / g.splits);
   const int kt_end = (int)(((long)kt_total * (block_z + 1)) / g.splits);
-  const bool dual = g.ktiles1 > 0;
+  const bool dual = kt1 > 0;
 
   constexpr int NLD = BM / 32 + BN / 32;  // LDS-DMA instructions per loader thread per K tile
   f32x4_t acc[FM][FN];

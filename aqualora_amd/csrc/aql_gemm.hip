@@ -126,6 +126,7 @@ struct OutSpec {
   bf16_t* G = nullptr;  // GEGLU epilogue (EpiParams::geglu_F): activated output [M][geglu_F]
   long ldg = 0;
   int geglu_F = 0;
+  int c_row0 = 0;
 };
 
 inline int pick_splits(int tiles, int kt_total, long M, int N, size_t ws_bytes) {
@@ -309,6 +310,7 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
   g.epi.G = o.G;
   g.epi.ldg = o.ldg;
   g.epi.geglu_F = o.geglu_F;
+  g.epi.c_row0 = o.c_row0;
   launch_cfg<LA, LB, EPI_BF16>(cfg, pd, g, stream);
   AQL_CHECK_LAUNCH(name);
   return AQL_OK;
@@ -326,10 +328,25 @@ inline PlainLoader plain(const bf16_t* p, long ld, long rows, int K) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
+extern "C" int aql_gemm_bf16_ex(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, int N, int K,
+                                const bf16_t* A2, long lda2, const bf16_t* B2, long ldb2, int K2, const bf16_t* bias,
+                                const bf16_t* rowbias, int rows_per_sample, const bf16_t* residual, long ldr,
+                                bf16_t* C, long ldc, long lora_row0, float* ws, size_t ws_bytes, hipStream_t stream);
+
 extern "C" int aql_gemm_bf16(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, int N, int K,
                              const bf16_t* A2, long lda2, const bf16_t* B2, long ldb2, int K2, const bf16_t* bias,
                              const bf16_t* rowbias, int rows_per_sample, const bf16_t* residual, long ldr,
                              bf16_t* C, long ldc, float* ws, size_t ws_bytes, hipStream_t stream) {
+  return aql_gemm_bf16_ex(A, lda, B, ldb, M, N, K, A2, lda2, B2, ldb2, K2, bias, rowbias, rows_per_sample, residual, ldr, C, ldc,
+                          0, ws, ws_bytes, stream);
+}
+
+// aql_gemm_bf16 for twin batches: rows below lora_row0 (the clean half, all-zero scale rows) have no second-K-segment term --
+// output tiles that end at or below it skip the segment, a straddling tile reads those rows of A2 as zeros.
+extern "C" int aql_gemm_bf16_ex(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, int N, int K,
+                                const bf16_t* A2, long lda2, const bf16_t* B2, long ldb2, int K2, const bf16_t* bias,
+                                const bf16_t* rowbias, int rows_per_sample, const bf16_t* residual, long ldr,
+                                bf16_t* C, long ldc, long lora_row0, float* ws, size_t ws_bytes, hipStream_t stream) {
   AQL_CHECK_ARG(A && B && C, "aql_gemm_bf16: null operand");
   AQL_CHECK_ARG(M > 0 && N > 0 && K > 0 && M < (1L << 31), "aql_gemm_bf16: bad shape M=%ld N=%d K=%d", M, N, K);
   AQL_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0,
@@ -349,6 +366,10 @@ extern "C" int aql_gemm_bf16(const bf16_t* A, long lda, const bf16_t* B, long ld
     g.a1 = plain(A2, lda2, M, K2);
     g.b1 = plain(B2, ldb2, N, K2);
     g.ktiles1 = aql_cdiv(K2, BK);
+    if (lora_row0 > 0) {   // twin batch: rows below lora_row0 have no second-segment (LoRA) term
+      g.seg1_row0 = (int)(lora_row0 > M ? M : lora_row0);
+      g.a1.row_lo = g.seg1_row0;
+    }
   }
   g.M = (int)M;
   g.N = N;
@@ -366,7 +387,7 @@ extern "C" int aql_gemm_bf16(const bf16_t* A, long lda, const bf16_t* B, long ld
 // two kernels.
 extern "C" int aql_gemm_bf16_geglu(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, int F, int K,
                                    const bf16_t* A2, long lda2, const bf16_t* B2, long ldb2, int K2, const bf16_t* bias,
-                                   bf16_t* H, long ldh, bf16_t* G, long ldg, hipStream_t stream) {
+                                   bf16_t* H, long ldh, bf16_t* G, long ldg, long lora_row0, hipStream_t stream) {
   AQL_CHECK_ARG(A && B && G, "aql_gemm_bf16_geglu: null operand");
   AQL_CHECK_ARG(M > 0 && F > 0 && K > 0 && M < (1L << 31) && F % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
                     ldg % 8 == 0 && (H == nullptr || ldh % 8 == 0),
@@ -390,10 +411,15 @@ extern "C" int aql_gemm_bf16_geglu(const bf16_t* A, long lda, const bf16_t* B, l
     g.b1.gsplit = 80;
     g.b1.goff = F - 80;
     g.ktiles1 = aql_cdiv(K2, BK);
+    if (lora_row0 > 0) {
+      g.seg1_row0 = (int)(lora_row0 > M ? M : lora_row0);
+      g.a1.row_lo = g.seg1_row0;
+    }
   }
   g.M = (int)M;
   g.N = 2 * F;
   OutSpec o{bias, nullptr, 0, 1, nullptr, 0, H, ldh, nullptr, 0, nullptr, G, ldg, F};
+  o.c_row0 = (int)(lora_row0 < 0 ? 0 : (lora_row0 > M ? M : lora_row0));   // H is only needed where backward runs
   return run_bf16_gemm(g, o, nullptr, 0, stream, "aql_gemm_bf16_geglu");
 }
 

@@ -38,6 +38,9 @@ struct LoraParams {
   bf16_t* T;          // [M][32] out (unscaled); grouped: [ngroups][M][32]
   bf16_t* Ts;         // [M][32] out (scaled);   grouped: [ngroups][M][32]
   int rps;            // rows per sample
+  // Rows below row0 carry an all-zero scale row (the clean half of a twin batch, ppft_train.py:1026-1029): tiles that lie
+  // entirely below it skip the LoRA branch -- no A-tile traffic, no T MFMAs, no up-projection k-step, no T / Ts output.
+  int row0;
   // Grouped launch: the N output columns are the concatenation of `ngroups` independent LoRA linears that share X (q|k|v of a
   // self-attention; the k|v projections of the text states of all 16 cross-attentions).  Group i owns columns
   // [col_start[i], col_start[i+1]) (multiples of the tile width), rows [32 i, 32 i + 32) of the stacked A and slab i of T / Ts;
@@ -89,6 +92,8 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
   bf16_t* const Tsg = lp.Ts + (long)grp * g.M * LR;
   PlainLoader lag = la;
   lag.base += (long)grp * LR * la.ld;
+  const bool lora_on = m0 + BM > lp.row0;   // block-uniform
+  if (!lora_on) lag.rows = 0;              // every row out of range: the stage's A DMAs are zero fills without traffic
 
   DmaStager<BM, PlainLoader> sa;
   DmaStager<BN, PlainLoader> sb;
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
     const int id = tid + u * NTHREADS, row = id >> 2, c = id & 3;
     const int brow = epi_bias_col(n0, row, gF, BN / 2);
     bup[u] = zero4();
-    if (id < BN * 4 && brow < g.N) bup[u] = *reinterpret_cast<const uint4*>(lp.Bup + (long)brow * LR + c * 8);
+    if (id < BN * 4 && brow < g.N && lora_on) bup[u] = *reinterpret_cast<const uint4*>(lp.Bup + (long)brow * LR + c * 8);
   }
   uint2 srow[FM][FT];
 #pragma unroll
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
 #pragma unroll
     for (int t = 0; t < FT; ++t) {
       srow[i][t] = make_uint2(0u, 0u);
-      if (m < g.M) srow[i][t] = *reinterpret_cast<const uint2*>(lp.S + (m / lp.rps) * LR + (wt0 + t) * 16 + (lane >> 4) * 4);
+      if (m < g.M && lora_on) srow[i][t] = *reinterpret_cast<const uint2*>(lp.S + (m / lp.rps) * LR + (wt0 + t) * 16 + (lane >> 4) * 4);
     }
   }
 
@@ -138,41 +143,54 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
 #pragma unroll
   for (int u = 0; u < NSTG - 1; ++u) issue(u);
 
-  int rd = 0, wr = NSTG - 1;
-  for (int kt = 0; kt < kt_end; ++kt) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * NLD) : "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    issue(wr);
-    const char* sA = lds + rd * STAGE;
-    const char* sB = sA + A_BYTES;
-    const char* sL = sB + B_BYTES;
+  // Two copies of the K loop, selected once per workgroup: with and without the T side product.  (A uniform branch around
+  // the T MFMAs INSIDE the k-step measured 19.5 -> 28.9 us on 32768x320x320: it cuts the compiler's ds_read / MFMA
+  // software pipeline in two.)
+  auto mainloop = [&](auto lora_tag) {
+    constexpr bool LORA = decltype(lora_tag)::value;
+    int rd = 0, wr = NSTG - 1;
+    for (int kt = 0; kt < kt_end; ++kt) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * NLD) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue(wr);
+      const char* sA = lds + rd * STAGE;
+      const char* sB = sA + A_BYTES;
+      const char* sL = sB + B_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8_t fa[FM], fb[FN], fl[FT];
-      const int chunk = ks * 4 + (lane >> 4);
+      for (int ks = 0; ks < BK / 32; ++ks) {
+        bf16x8_t fa[FM], fb[FN], fl[FT];
+        const int chunk = ks * 4 + (lane >> 4);
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
-        fa[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(wm0 + i * 16 + (lane & 15), chunk));
+        for (int i = 0; i < FM; ++i)
+          fa[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(wm0 + i * 16 + (lane & 15), chunk));
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
-        fb[j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(wn0 + j * 16 + (lane & 15), chunk));
+        for (int j = 0; j < FN; ++j)
+          fb[j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(wn0 + j * 16 + (lane & 15), chunk));
+        if constexpr (LORA) {
 #pragma unroll
-      for (int t = 0; t < FT; ++t)
-        fl[t] = *reinterpret_cast<const bf16x8_t*>(sL + lds_off((wt0 + t) * 16 + (lane & 15), chunk));
+          for (int t = 0; t < FT; ++t)
+            fl[t] = *reinterpret_cast<const bf16x8_t*>(sL + lds_off((wt0 + t) * 16 + (lane & 15), chunk));
+        }
 #pragma unroll
-      for (int i = 0; i < FM; ++i) {
+        for (int i = 0; i < FM; ++i) {
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+          if constexpr (LORA) {
 #pragma unroll
-        for (int t = 0; t < FT; ++t) tacc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[t], fa[i], tacc[i][t], 0, 0, 0);
+            for (int t = 0; t < FT; ++t) tacc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[t], fa[i], tacc[i][t], 0, 0, 0);
+          }
+        }
       }
+      rd = (rd + 1 == NSTG) ? 0 : rd + 1;
+      wr = (wr + 1 == NSTG) ? 0 : wr + 1;
     }
-    rd = (rd + 1 == NSTG) ? 0 : rd + 1;
-    wr = (wr + 1 == NSTG) ? 0 : wr + 1;
-  }
+  };
+  if (lora_on) mainloop(std::true_type{});
+  else mainloop(std::false_type{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing zero-fill DMAs still write LDS
   __syncthreads();
+  if (lora_on) {
 
   // ---- T -> (T, Ts) bf16; Ts into the stage-0 A tile (fragment layout), the Bup panel into the stage-0 B tile
   // tacc[i][t][e]: row m = m0 + wm0 + 16 i + (lane & 15), rank column r = 16 (wt0 + t) + 4 (lane >> 4) + e
@@ -218,6 +236,7 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
       for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
   }
   __syncthreads();
+  }  // lora_on
 
   // ---- epilogue (as gemm_body_d, EPI_BF16): bias in fp32, C tile staged through LDS, residual added in bf16
   const EpiParams& ep = g.epi;
@@ -310,6 +329,8 @@ __global__ __launch_bounds__(2 * NTHREADS) void lora_gemm_kernel_w(const GemmArg
   bf16_t* const Tsg = lp.Ts + (long)grp * g.M * LR;
   PlainLoader lag = la;
   lag.base += (long)grp * LR * la.ld;
+  const bool lora_on = m0 + BM > lp.row0;   // block-uniform
+  if (!lora_on) lag.rows = 0;
 
   f32x4_t acc[FM][FN], tacc[FM][FT];
 #pragma unroll
@@ -329,7 +350,7 @@ __global__ __launch_bounds__(2 * NTHREADS) void lora_gemm_kernel_w(const GemmArg
       const int id = ltid + u * NTHREADS, row = id >> 2, c = id & 3;
       const int brow = epi_bias_col(n0, row, gF, BN / 2);
       bup[u] = zero4();
-      if (id < BN * 4 && brow < g.N) bup[u] = *reinterpret_cast<const uint4*>(lp.Bup + (long)brow * LR + c * 8);
+      if (id < BN * 4 && brow < g.N && lora_on) bup[u] = *reinterpret_cast<const uint4*>(lp.Bup + (long)brow * LR + c * 8);
     }
     DmaStager<BM, PlainLoader> sa;
     DmaStager<BN, PlainLoader> sb;
@@ -362,7 +383,7 @@ __global__ __launch_bounds__(2 * NTHREADS) void lora_gemm_kernel_w(const GemmArg
 #pragma unroll
       for (int t = 0; t < FT; ++t) {
         srow[i][t] = make_uint2(0u, 0u);
-        if (m < g.M) srow[i][t] = *reinterpret_cast<const uint2*>(lp.S + (m / lp.rps) * LR + (wt0 + t) * 16 + (lane >> 4) * 4);
+        if (m < g.M && lora_on) srow[i][t] = *reinterpret_cast<const uint2*>(lp.S + (m / lp.rps) * LR + (wt0 + t) * 16 + (lane >> 4) * 4);
       }
     }
     const int arow = wm0 + (lane & 15), brow = wn0 + (lane & 15), lrow = wt0 * 16 + (lane & 15);
@@ -398,8 +419,12 @@ __global__ __launch_bounds__(2 * NTHREADS) void lora_gemm_kernel_w(const GemmArg
       for (int i = 0; i < FM; ++i) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
+      }
+      if (lora_on) {
 #pragma unroll
-        for (int t = 0; t < FT; ++t) tacc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl0[t], fa0[i], tacc[i][t], 0, 0, 0);
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int t = 0; t < FT; ++t) tacc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl0[t], fa0[i], tacc[i][t], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -413,8 +438,12 @@ __global__ __launch_bounds__(2 * NTHREADS) void lora_gemm_kernel_w(const GemmArg
       for (int i = 0; i < FM; ++i) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
+      }
+      if (lora_on) {
 #pragma unroll
-        for (int t = 0; t < FT; ++t) tacc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl1[t], fa1[i], tacc[i][t], 0, 0, 0);
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int t = 0; t < FT; ++t) tacc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl1[t], fa1[i], tacc[i][t], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -424,6 +453,7 @@ __global__ __launch_bounds__(2 * NTHREADS) void lora_gemm_kernel_w(const GemmArg
 
   char* sA = lds;
   char* sB = lds + A_BYTES;
+  if (lora_on) {
   if (loader) {
 #pragma unroll
     for (int u = 0; u < NBP; ++u) {
@@ -467,6 +497,7 @@ __global__ __launch_bounds__(2 * NTHREADS) void lora_gemm_kernel_w(const GemmArg
       for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
   }
   __syncthreads();
+  }  // lora_on
 
   const EpiParams& ep = g.epi;
   if (!loader) {
@@ -538,7 +569,7 @@ inline PlainLoader plain(const bf16_t* p, long ld, long rows, int K) {
 static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long ldw, long M, int N, int K,
                                 const bf16_t* Adown, const bf16_t* S, int rows_per_sample, const bf16_t* Bup,
                                 const bf16_t* bias, const bf16_t* residual, long ldr, bf16_t* Y, long ldy, bf16_t* T,
-                                bf16_t* Ts, bf16_t* G, long ldg, int geglu_F, int ngroups, const int* col_start,
+                                bf16_t* Ts, bf16_t* G, long ldg, int geglu_F, int ngroups, const int* col_start, long row0,
                                 hipStream_t stream) {
   AQL_CHECK_ARG(X && W && Adown && S && Bup && (Y || geglu_F) && T && Ts, "aql_lora_gemm_fused: null operand");
   AQL_CHECK_ARG(M > 0 && M < (1L << 31) && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 &&
@@ -577,6 +608,8 @@ static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long
   const PlainLoader la = plain(Adown, K, LR, K);
   LoraParams lp{};
   lp.S = S, lp.Bup = Bup, lp.T = T, lp.Ts = Ts, lp.rps = rows_per_sample;
+  lp.row0 = (int)(row0 < 0 ? 0 : (row0 > M ? M : row0));
+  g.epi.c_row0 = lp.row0;
   lp.ngroups = ngroups;
   for (int i = 0; i <= ngroups && ngroups > 0; ++i) lp.col_start[i] = col_start[i];
   if (ngroups > 0 && N % 160 != 0) return AQL_NOT_FUSED;  // groups are cut at 160-column tile boundaries
@@ -646,9 +679,9 @@ static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long
 extern "C" int aql_lora_gemm_fused(const bf16_t* X, long ldx, const bf16_t* W, long ldw, long M, int N, int K,
                                    const bf16_t* Adown, const bf16_t* S, int rows_per_sample, const bf16_t* Bup,
                                    const bf16_t* bias, const bf16_t* residual, long ldr, bf16_t* Y, long ldy, bf16_t* T,
-                                   bf16_t* Ts, hipStream_t stream) {
+                                   bf16_t* Ts, long lora_row0, hipStream_t stream) {
   return lora_gemm_fused_impl(X, ldx, W, ldw, M, N, K, Adown, S, rows_per_sample, Bup, bias, residual, ldr, Y, ldy, T, Ts,
-                              nullptr, 0, 0, 0, nullptr, stream);
+                              nullptr, 0, 0, 0, nullptr, lora_row0, stream);
 }
 
 // Several rank-32 LoRA linears that share their input in ONE launch (q|k|v of a self-attention,
@@ -658,13 +691,13 @@ extern "C" int aql_lora_gemm_fused(const bf16_t* X, long ldx, const bf16_t* W, l
 extern "C" int aql_lora_gemm_fused_grouped(const bf16_t* X, long ldx, const bf16_t* W, long ldw, long M, int N, int K,
                                            int ngroups, const int* col_start, const bf16_t* Adown, const bf16_t* S,
                                            int rows_per_sample, const bf16_t* Bup, const bf16_t* bias, bf16_t* Y, long ldy,
-                                           bf16_t* T, bf16_t* Ts, hipStream_t stream) {
+                                           bf16_t* T, bf16_t* Ts, long lora_row0, hipStream_t stream) {
   AQL_CHECK_ARG(ngroups >= 1 && ngroups <= MAXG && col_start != nullptr, "aql_lora_gemm_fused_grouped: 1..%d groups", MAXG);
   AQL_CHECK_ARG(col_start[0] == 0 && col_start[ngroups] == N, "aql_lora_gemm_fused_grouped: col_start must span [0, N]");
   for (int i = 0; i < ngroups; ++i)
     AQL_CHECK_ARG(col_start[i] % 160 == 0 && col_start[i] < col_start[i + 1], "aql_lora_gemm_fused_grouped: bad group %d", i);
   return lora_gemm_fused_impl(X, ldx, W, ldw, M, N, K, Adown, S, rows_per_sample, Bup, bias, nullptr, 0, Y, ldy, T, Ts, nullptr,
-                              0, 0, ngroups, col_start, stream);
+                              0, 0, ngroups, col_start, lora_row0, stream);
 }
 
 // ff.net.0.proj with the rank-32 watermark LoRA AND the GEGLU activation in one launch (aql_gemm_bf16_geglu's tile layout on
@@ -673,9 +706,9 @@ extern "C" int aql_lora_gemm_fused_grouped(const bf16_t* X, long ldx, const bf16
 extern "C" int aql_lora_gemm_fused_geglu(const bf16_t* X, long ldx, const bf16_t* W, long ldw, long M, int F, int K,
                                          const bf16_t* Adown, const bf16_t* S, int rows_per_sample, const bf16_t* Bup,
                                          const bf16_t* bias, bf16_t* H, long ldh, bf16_t* G, long ldg, bf16_t* T, bf16_t* Ts,
-                                         hipStream_t stream) {
+                                         long lora_row0, hipStream_t stream) {
   AQL_CHECK_ARG(G && F > 0 && ldg % 8 == 0 && (H == nullptr || ldh % 8 == 0), "aql_lora_gemm_fused_geglu: bad args");
   if (F % 80 != 0) return AQL_NOT_FUSED;
   return lora_gemm_fused_impl(X, ldx, W, ldw, M, 2 * F, K, Adown, S, rows_per_sample, Bup, bias, nullptr, 0, H, ldh, T, Ts, G,
-                              ldg, F, 0, nullptr, stream);
+                              ldg, F, 0, nullptr, lora_row0, stream);
 }

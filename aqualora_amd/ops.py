@@ -115,6 +115,7 @@ class _Dual:
 
 
 DUAL = None
+_TWIN_SKIP = os.environ.get("AQL_TWIN_SKIP", "1") != "0"   # skip the LoRA branch on clean tiles (A/B hook)
 
 
 def dual_begin():
@@ -235,16 +236,17 @@ class PackedConv3x3:
 
 
 # ------------------------------------------------------------------------------------- low-level calls
-def gemm_bf16(A, B, bias=None, A2=None, B2=None, rowbias=None, rps=1, residual=None, out=None):
-    """C[M,N] = A[M,K].B[N,K]^T (+A2.B2^T) + bias + rowbias[m//rps] + residual, bf16 with fp32 accumulation."""
+def gemm_bf16(A, B, bias=None, A2=None, B2=None, rowbias=None, rps=1, residual=None, out=None, lora_row0=0):
+    """C[M,N] = A[M,K].B[N,K]^T (+A2.B2^T) + bias + rowbias[m//rps] + residual, bf16 with fp32 accumulation.
+    lora_row0: rows below it have no A2.B2^T term (the clean half of a twin batch)."""
     M, K = A.shape
     N = B.shape[0]
     C = out if out is not None else torch.empty(M, N, dtype=torch.bfloat16, device=A.device)
     ws = workspace(A.device)
-    L.call("aql_gemm_bf16", L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), M, N, K,
+    L.call("aql_gemm_bf16_ex", L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), M, N, K,
            L.ptr(A2), 0 if A2 is None else A2.stride(0), L.ptr(B2), 0 if B2 is None else B2.stride(0),
            0 if A2 is None else A2.shape[1], L.ptr(bias), L.ptr(rowbias), rps,
-           L.ptr(residual), 0 if residual is None else residual.stride(0), L.ptr(C), C.stride(0),
+           L.ptr(residual), 0 if residual is None else residual.stride(0), L.ptr(C), C.stride(0), int(lora_row0),
            L.ptr(ws), ws.numel() * 4, L.stream_ptr())
     return C
 
@@ -500,7 +502,7 @@ DEFERRED = None  # set by a trainer around backward (ppft.PPFTTrainer); None => 
 
 
 # ------------------------------------------------------------------------------------ fused LoRA linear
-def _lora_gemm_fused(x2d, w, a16, S16, rps, b16, bias, residual, T, Ts, y=None):
+def _lora_gemm_fused(x2d, w, a16, S16, rps, b16, bias, residual, T, Ts, y=None, row0=0):
     """One-launch rank-32 LoRA linear (aql_lora_gemm_fused).  Returns Y, or None when the shape belongs on the two-launch
     path (rank != 32, split-K shapes, narrow outputs; AQL_LORA_FUSED=0 disables it for comparison)."""
     if a16.shape[0] != 32 or os.environ.get("AQL_LORA_FUSED", "1") == "0":
@@ -511,14 +513,22 @@ def _lora_gemm_fused(x2d, w, a16, S16, rps, b16, bias, residual, T, Ts, y=None):
         y = torch.empty(M, N, dtype=torch.bfloat16, device=x2d.device)
     rc = L.call_raw("aql_lora_gemm_fused", L.ptr(x2d), x2d.stride(0), L.ptr(w), w.stride(0), M, N, K, L.ptr(a16), L.ptr(S16),
                     rps, L.ptr(b16), L.ptr(bias), L.ptr(residual), 0 if residual is None else residual.stride(0), L.ptr(y),
-                    y.stride(0), L.ptr(T), L.ptr(Ts), L.stream_ptr())
+                    y.stride(0), L.ptr(T), L.ptr(Ts), int(row0), L.stream_ptr())
     if rc == 100:
         return None
     L.check(rc, "aql_lora_gemm_fused")
     return y
 
 
-def _geglu_fused(x2d, packed, site, S16, rps, T, Ts, G, H):
+def _lora_down_rows(xk, K, site, S16k, rps, Tk, Tsk, row0):
+    """T = X.A^T, Ts = T*S for the rows that have a LoRA term (rows >= row0; row0 is a multiple of rps): the clean half of a twin
+    batch is skipped -- its T / Ts rows are never read (aql_gemm_bf16_ex treats them as zeros)."""
+    M = xk.shape[0] - row0
+    L.call("aql_lora_down", L.ptr(xk[row0:]), xk.stride(0), M, K, L.ptr(site.a16), site.rank, L.ptr(S16k[row0 // rps:]), rps,
+           L.ptr(Tk[row0:]), L.ptr(Tsk[row0:]), None, None, L.stream_ptr())
+
+
+def _geglu_fused(x2d, packed, site, S16, rps, T, Ts, G, H, row0=0):
     """ff.net.0.proj (+ LoRA) + GEGLU in one launch into G [M,F] (and H [M,2F] unless None).  Returns "done", "down" (only
     the LoRA down product T / Ts was computed: finish with the plain GEMM + geglu kernel) or None (nothing done)."""
     M, K = x2d.shape
@@ -531,18 +541,17 @@ def _geglu_fused(x2d, packed, site, S16, rps, T, Ts, G, H):
         if site.rank == 32 and os.environ.get("AQL_LORA_FUSED", "1") != "0":
             rc = L.call_raw("aql_lora_gemm_fused_geglu", L.ptr(x2d), x2d.stride(0), L.ptr(packed.w), packed.w.stride(0), M, F, K,
                             L.ptr(site.a16), L.ptr(S16), rps, L.ptr(site.b16), L.ptr(packed.bias), L.ptr(H), ldh, L.ptr(G), F,
-                            L.ptr(T), L.ptr(Ts), L.stream_ptr())
+                            L.ptr(T), L.ptr(Ts), int(row0), L.stream_ptr())
         if rc == 100:   # two-launch form: skinny T product, then the GEGLU GEMM with Ts.Bup^T as a second K segment
-            L.call("aql_lora_down", L.ptr(x2d), x2d.stride(0), M, K, L.ptr(site.a16), site.rank, L.ptr(S16), rps, L.ptr(T),
-                   L.ptr(Ts), None, None, L.stream_ptr())
+            _lora_down_rows(x2d, K, site, S16, rps, T, Ts, row0)
             rc = L.call_raw("aql_gemm_bf16_geglu", L.ptr(x2d), x2d.stride(0), L.ptr(packed.w), packed.w.stride(0), M, F, K,
                             L.ptr(Ts), Ts.stride(0), L.ptr(site.b16), site.b16.stride(0), site.rank, L.ptr(packed.bias),
-                            L.ptr(H), ldh, L.ptr(G), F, L.stream_ptr())
+                            L.ptr(H), ldh, L.ptr(G), F, int(row0), L.stream_ptr())
             if rc == 100:
                 return "down"
     else:
         rc = L.call_raw("aql_gemm_bf16_geglu", L.ptr(x2d), x2d.stride(0), L.ptr(packed.w), packed.w.stride(0), M, F, K, None, 0,
-                        None, 0, 0, L.ptr(packed.bias), L.ptr(H), ldh, L.ptr(G), F, L.stream_ptr())
+                        None, 0, 0, L.ptr(packed.bias), L.ptr(H), ldh, L.ptr(G), F, int(row0), L.stream_ptr())
         if rc == 100:
             return None
     L.check(rc, "geglu-fused linear")
@@ -588,11 +597,12 @@ class LoraLinearFn(torch.autograd.Function):
         yk, y = _alloc((M, F if geglu else packed.N), torch.bfloat16, dev, twin)
         hk = h = None
         done = None
+        row0 = M if (twin and _TWIN_SKIP) else 0   # twin batch: rows [0, M) are the clean pass (all-zero scale): no LoRA term, no backward
         if geglu:
             assert residual is None
             if want_h:
                 hk, h = _alloc((M, packed.N), torch.bfloat16, dev, twin)
-            done = _geglu_fused(xk, packed, site if use_lora else None, S16k, rps, Tk, Tsk, yk, hk)
+            done = _geglu_fused(xk, packed, site if use_lora else None, S16k, rps, Tk, Tsk, yk, hk, row0)
         if done != "done":
             if geglu and hk is None:
                 hk, h = _alloc((M, packed.N), torch.bfloat16, dev, twin)
@@ -600,12 +610,11 @@ class LoraLinearFn(torch.autograd.Function):
             if use_lora:
                 ok = None
                 if done != "down":
-                    ok = _lora_gemm_fused(xk, packed.w, site.a16, S16k, rps, site.b16, packed.bias, resk, Tk, Tsk, out)
+                    ok = _lora_gemm_fused(xk, packed.w, site.a16, S16k, rps, site.b16, packed.bias, resk, Tk, Tsk, out, row0)
                 if ok is None:   # two-launch form: skinny T product, then the GEMM with Ts.Bup^T as a second K segment
                     if done != "down":
-                        L.call("aql_lora_down", L.ptr(xk), xk.stride(0), xk.shape[0], packed.K, L.ptr(site.a16), r, L.ptr(S16k),
-                               rps, L.ptr(Tk), L.ptr(Tsk), None, None, L.stream_ptr())
-                    gemm_bf16(xk, packed.w, packed.bias, Tsk, site.b16, residual=resk, out=out)
+                        _lora_down_rows(xk, packed.K, site, S16k, rps, Tk, Tsk, row0)
+                    gemm_bf16(xk, packed.w, packed.bias, Tsk, site.b16, residual=resk, out=out, lora_row0=row0)
             else:
                 gemm_bf16(xk, packed.w, packed.bias, residual=resk, out=out)
             if geglu:   # unfused tail (shapes without a 160-wide tile): separate activation kernel
@@ -717,7 +726,7 @@ class GroupedLoraFn(torch.autograd.Function):
         cs = (ctypes.c_int * (G + 1))(*cols)
         rc = L.call_raw("aql_lora_gemm_fused_grouped", L.ptr(xk), xk.stride(0), L.ptr(wcat), wcat.stride(0), Mk, N, K, G, cs,
                         L.ptr(sites[0].a16), L.ptr(S16k), rps, L.ptr(sites[0].b16), None, L.ptr(yk), N, L.ptr(Tk), L.ptr(Tsk),
-                        L.stream_ptr())
+                        M if (twin and _TWIN_SKIP) else 0, L.stream_ptr())
         L.check(rc, "aql_lora_gemm_fused_grouped")
         y = yk[M:] if twin else yk
         ctx.packs, ctx.sites, ctx.rps, ctx.s_dtype = packs, sites, rps, S.dtype

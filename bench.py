@@ -122,7 +122,7 @@ def dominant_kernels(B, device):
 
     def lora_call():
         rc = L.call_raw("aql_lora_gemm_fused", L.ptr(X), 320, L.ptr(Wl), 320, B * 4096, 320, 320, L.ptr(Al), L.ptr(Sl), 4096,
-                        L.ptr(Bl), None, None, 0, L.ptr(Yl), 320, L.ptr(Tl), L.ptr(Tsl), L.stream_ptr())
+                        L.ptr(Bl), None, None, 0, L.ptr(Yl), 320, L.ptr(Tl), L.ptr(Tsl), 0, L.stream_ptr())
         assert rc == 0, rc
     ms = time_kernel(lora_call)
     fl = 2.0 * B * 4096 * 320 * (320 + 32) + 2.0 * B * 4096 * 32 * 320

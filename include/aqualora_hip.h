@@ -32,6 +32,15 @@ int aql_gemm_bf16(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, 
                   long lda2, const bf16_t* B2, long ldb2, int K2, const bf16_t* bias, const bf16_t* rowbias,
                   int rows_per_sample, const bf16_t* residual, long ldr, bf16_t* C, long ldc, float* ws,
                   size_t ws_bytes, aql_stream_t stream);
+/* Twin batches (clean samples of ppft_train.py:1026-1029 in rows [0, lora_row0), watermarked samples after them, one launch
+ * for both passes): rows below lora_row0 carry an all-zero scale, i.e. no LoRA term -- tiles that end at or below it skip the
+ * second K segment, straddling tiles read those A2 rows as zeros.  The same trailing `lora_row0` argument of the one-launch
+ * entry points below additionally skips the A-tile traffic, the T product and the T / Ts (and GEGLU pre-activation) output of
+ * such tiles.  lora_row0 = 0: every row has a LoRA term.                                                                */
+int aql_gemm_bf16_ex(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, int N, int K, const bf16_t* A2,
+                     long lda2, const bf16_t* B2, long ldb2, int K2, const bf16_t* bias, const bf16_t* rowbias,
+                     int rows_per_sample, const bf16_t* residual, long ldr, bf16_t* C, long ldc, long lora_row0, float* ws,
+                     size_t ws_bytes, aql_stream_t stream);
 
 /* T = X.Adown^T ; Ts = T * S[m / rows_per_sample]   ==  down(x) @ diag_embed(scale)
  *   utils/lora_modules.py:13-17 (linear) and :33-36 (conv, scale[:, :, None, None]).                           */
@@ -59,7 +68,8 @@ int aql_conv3x3_fwd_pad(const bf16_t* X, int B, int Hin, int Win, int Cin, const
  * path aql_lora_down + aql_gemm_bf16 (split-K shapes, N <= 32).                                                      */
 int aql_lora_gemm_fused(const bf16_t* X, long ldx, const bf16_t* W, long ldw, long M, int N, int K, const bf16_t* Adown,
                         const bf16_t* S, int rows_per_sample, const bf16_t* Bup, const bf16_t* bias,
-                        const bf16_t* residual, long ldr, bf16_t* Y, long ldy, bf16_t* T, bf16_t* Ts, aql_stream_t stream);
+                        const bf16_t* residual, long ldr, bf16_t* Y, long ldy, bf16_t* T, bf16_t* Ts, long lora_row0,
+                        aql_stream_t stream);
 /* ff.net.0.proj + GEGLU in ONE launch (GEGLU.forward, scripts/lib/original_unet.py:727-729 -- diffusers' FeedForward --
  * on top of lora_modules.py:56-62 / 9-26):  h = X.W^T (+ LoRA) + bias with W [2F,K];  G = h[:, :F] * gelu_erf(h[:, F:]).
  * Each 160-wide output tile holds 80 value columns and their 80 gate columns, so the activation runs in the epilogue on the
@@ -69,11 +79,11 @@ int aql_lora_gemm_fused(const bf16_t* X, long ldx, const bf16_t* W, long ldw, lo
  * aql_gemm_bf16 (the two-launch LoRA form for ranks other than 32).                                                    */
 int aql_gemm_bf16_geglu(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, int F, int K, const bf16_t* A2,
                         long lda2, const bf16_t* B2, long ldb2, int K2, const bf16_t* bias, bf16_t* H, long ldh, bf16_t* G,
-                        long ldg, aql_stream_t stream);
+                        long ldg, long lora_row0, aql_stream_t stream);
 int aql_lora_gemm_fused_geglu(const bf16_t* X, long ldx, const bf16_t* W, long ldw, long M, int F, int K,
                               const bf16_t* Adown, const bf16_t* S, int rows_per_sample, const bf16_t* Bup,
                               const bf16_t* bias, bf16_t* H, long ldh, bf16_t* G, long ldg, bf16_t* T, bf16_t* Ts,
-                              aql_stream_t stream);
+                              long lora_row0, aql_stream_t stream);
 /* Several rank-32 LoRA linears that share their input as ONE launch of aql_lora_gemm_fused: q|k|v of a self-attention
  * (attn.to_q / to_k / to_v, scripts/lib/original_unet.py:688-704) or the k|v projections of the text states of all 16
  * cross-attentions.  W [N,K], Bup [N,32], bias [N] are the linears stacked along N; Adown [ngroups*32, K] the stacked down
@@ -82,7 +92,7 @@ int aql_lora_gemm_fused_geglu(const bf16_t* X, long ldx, const bf16_t* W, long l
 int aql_lora_gemm_fused_grouped(const bf16_t* X, long ldx, const bf16_t* W, long ldw, long M, int N, int K, int ngroups,
                                 const int* col_start, const bf16_t* Adown, const bf16_t* S, int rows_per_sample,
                                 const bf16_t* Bup, const bf16_t* bias, bf16_t* Y, long ldy, bf16_t* T, bf16_t* Ts,
-                                aql_stream_t stream);
+                                long lora_row0, aql_stream_t stream);
 int aql_conv3x3_bwd_data(const bf16_t* dY, int B, int Hin, int Win, int Cin, const bf16_t* Wt, int Cout, int stride,
                          bf16_t* dX, float* ws, size_t ws_bytes, aql_stream_t stream);
 

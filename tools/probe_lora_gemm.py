@@ -29,7 +29,7 @@ for M, N, K, nb in CASES:
     T = torch.empty(M, 32, dtype=torch.bfloat16, device=dev)
     Ts = torch.empty_like(T)
     rc = L.call_raw("aql_lora_gemm_fused", L.ptr(X), K, L.ptr(W), K, M, N, K, L.ptr(A), L.ptr(S), rps, L.ptr(Bup), L.ptr(bias),
-                    L.ptr(R), N, L.ptr(Y), N, L.ptr(T), L.ptr(Ts), L.stream_ptr())
+                    L.ptr(R), N, L.ptr(Y), N, L.ptr(T), L.ptr(Ts), 0, L.stream_ptr())
     if rc == 100:
         print(f"PASS lora_gemm M{M} N{N} K{K}: routed to the two-launch path (rc=100)")
         continue
@@ -60,7 +60,7 @@ for M, K, widths, nb in [(8192, 320, (320, 320, 320), 4), (616, 768, (320, 320, 
     Ts = torch.empty_like(T)
     cs = (ctypes.c_int * (G + 1))(*cols)
     rc = L.call_raw("aql_lora_gemm_fused_grouped", L.ptr(X), K, L.ptr(W), K, M, N, K, G, cs, L.ptr(A), L.ptr(S), rps, L.ptr(Bup),
-                    None, L.ptr(Y), N, L.ptr(T), L.ptr(Ts), L.stream_ptr())
+                    None, L.ptr(Y), N, L.ptr(T), L.ptr(Ts), 0, L.stream_ptr())
     L.check(rc, "aql_lora_gemm_fused_grouped")
     same, worst = True, 0.0
     for g in range(G):
@@ -70,7 +70,7 @@ for M, K, widths, nb in [(8192, 320, (320, 320, 320), 4), (616, 768, (320, 320, 
         Tg = torch.empty(M, 32, dtype=torch.bfloat16, device=dev)
         Tsg = torch.empty_like(Tg)
         rc = L.call_raw("aql_lora_gemm_fused", L.ptr(X), K, L.ptr(Wg), K, M, c1 - c0, K, L.ptr(Ag), L.ptr(S), rps, L.ptr(Bg), None,
-                        None, 0, L.ptr(Yg), c1 - c0, L.ptr(Tg), L.ptr(Tsg), L.stream_ptr())
+                        None, 0, L.ptr(Yg), c1 - c0, L.ptr(Tg), L.ptr(Tsg), 0, L.stream_ptr())
         if rc == 0:
             same &= torch.equal(Yg, Y[:, c0:c1]) and torch.equal(Tg, T[g]) and torch.equal(Tsg, Ts[g])
         rows = torch.arange(M, device=dev) // rps

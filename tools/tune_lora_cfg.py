@@ -61,13 +61,13 @@ for tag, M, N, K, geglu in shapes():
 
             def f():
                 return L.call_raw("aql_lora_gemm_fused_geglu", L.ptr(X), K, L.ptr(W), K, M, F, K, L.ptr(A), L.ptr(S), rps, L.ptr(Bup),
-                                  None, L.ptr(H), N, L.ptr(G), F, L.ptr(T), L.ptr(Ts), L.stream_ptr())
+                                  None, L.ptr(H), N, L.ptr(G), F, L.ptr(T), L.ptr(Ts), 0, L.stream_ptr())
             return f
         Y = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
 
         def f():
             return L.call_raw("aql_lora_gemm_fused", L.ptr(X), K, L.ptr(W), K, M, N, K, L.ptr(A), L.ptr(S), rps, L.ptr(Bup), None,
-                              None, 0, L.ptr(Y), N, L.ptr(T), L.ptr(Ts), L.stream_ptr())
+                              None, 0, L.ptr(Y), N, L.ptr(T), L.ptr(Ts), 0, L.stream_ptr())
         return f
     fns = [mk() for _ in range(NSET)]
     res = {}

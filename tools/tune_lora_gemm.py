@@ -42,7 +42,7 @@ for M, N, K in SHAPES:
         if fused:
             def f():
                 rc = L.call_raw("aql_lora_gemm_fused", L.ptr(X), K, L.ptr(W), K, M, N, K, L.ptr(A), L.ptr(S), rps, L.ptr(Bup), None,
-                                None, 0, L.ptr(Y), N, L.ptr(T), L.ptr(Ts), L.stream_ptr())
+                                None, 0, L.ptr(Y), N, L.ptr(T), L.ptr(Ts), 0, L.stream_ptr())
                 assert rc in (0, 100), rc
                 return rc
             return f
