@@ -96,6 +96,14 @@ SIGNATURES = {
     "aql_prvl_loss_bwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "aql_ddim_step": [c_p, c_p, c_p, c_f, c_p, c_l, c_p],
     "aql_dpmpp2m_step": [c_p, c_p, c_p, c_f, c_p, c_p, c_l, c_p],
+    "aql_lpips_scale": [c_p, c_i, c_i, c_i, c_p, c_p],
+    "aql_lpips_scale_bwd": [c_p, c_i, c_i, c_i, c_p, c_p],
+    "aql_relu_bf16": [c_p, c_l, c_p, c_p],
+    "aql_relu_bf16_bwd": [c_p, c_p, c_l, c_p, c_p],
+    "aql_maxpool2x2_nhwc": [c_p, c_i, c_i, c_i, c_i, c_p, c_p],
+    "aql_maxpool2x2_nhwc_bwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
+    "aql_lpips_layer": [c_p, c_p, c_p, c_i, c_l, c_i, c_p, c_p],
+    "aql_lpips_layer_bwd": [c_p, c_p, c_p, c_i, c_l, c_i, c_p, c_p, c_p],
     "aql_sdpa_fwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p, c_p],
     "aql_sdpa_bwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p,
                      c_p, c_p, c_sz, c_p],

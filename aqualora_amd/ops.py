@@ -17,6 +17,7 @@ from . import _lib as L
 
 CL = torch.channels_last
 _WS = {}
+_WS_RETIRED = []
 _GN = {}
 
 
@@ -30,6 +31,8 @@ def workspace(device, nfloats=64 << 20):
     key = _skey(device)
     ws = _WS.get(key)
     if ws is None or ws.numel() < nfloats:
+        if ws is not None:
+            _WS_RETIRED.append(ws)   # captured graphs may have baked the old pointer in: never hand it back to the allocator
         ws = torch.empty(nfloats, dtype=torch.float32, device=device)
         _WS[key] = ws
     return ws

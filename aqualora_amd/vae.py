@@ -117,7 +117,7 @@ class WideHeadAttentionFn(torch.autograd.Function):
     def forward(ctx, q, k, v, B):
         N, C = q.shape[0] // B, q.shape[1]
         dev, st = q.device, L.stream_ptr()
-        ws = ops.workspace(dev)
+        ws = ops.workspace(dev, max(64 << 20, N * N))   # fp32 scores of one sample (768x768 images: 9216 tokens, 340 MB)
         o = torch.empty_like(q)
         vt = torch.empty(C, N, dtype=torch.bfloat16, device=dev)
         probs = torch.empty(B, N, N, dtype=torch.bfloat16, device=dev)

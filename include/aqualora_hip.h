@@ -306,6 +306,24 @@ int aql_prvl_loss_fwd(const float* img1, const float* img2, int B, int C, int H,
 int aql_prvl_loss_bwd(const float* img1, const float* img2, const long* arg, const float* gout, int B, int C, int H, int W,
                       int win, float* d1, float* d2, aql_stream_t stream);
 
+/* ---- csrc/aql_lpips.hip: LPIPS(VGG16) around the 3x3 conv kernels -- stage 1's perceptual loss
+ * (`lpips.LPIPS(net='vgg')`, train/latent_wm_pretrain.py:111; `loss_fn_vgg(clean_image, watermarked_image)`, :182).
+ * aql_lpips_scale: ScalingLayer, fp32 NCHW [B,3,H,W] -> bf16 NHWC [B,H,W,8] (channels 3..7 zero) and its adjoint;
+ * aql_relu_bf16 / aql_maxpool2x2_nhwc: the VGG activations and pools with their backward;
+ * aql_lpips_layer: out[b] += mean_hw sum_c w_c (f0/(|f0|+1e-10) - f1/(|f1|+1e-10))^2 (normalize_tensor + lin head + spatial
+ * average of one feature tap; `out` accumulates the five taps), aql_lpips_layer_bwd: its gradient w.r.t. f1.            */
+int aql_lpips_scale(const float* x, int B, int H, int W, bf16_t* y, aql_stream_t stream);
+int aql_lpips_scale_bwd(const bf16_t* dy, int B, int H, int W, float* dx, aql_stream_t stream);
+int aql_relu_bf16(const bf16_t* x, long n, bf16_t* y, aql_stream_t stream);
+int aql_relu_bf16_bwd(const bf16_t* dy, const bf16_t* y, long n, bf16_t* dx, aql_stream_t stream);
+int aql_maxpool2x2_nhwc(const bf16_t* x, int B, int H, int W, int C, bf16_t* y, aql_stream_t stream);
+int aql_maxpool2x2_nhwc_bwd(const bf16_t* x, const bf16_t* y, const bf16_t* dy, int B, int H, int W, int C, bf16_t* dx,
+                            aql_stream_t stream);
+int aql_lpips_layer(const bf16_t* f0, const bf16_t* f1, const float* w, int B, long HW, int C, float* out,
+                    aql_stream_t stream);
+int aql_lpips_layer_bwd(const bf16_t* f0, const bf16_t* f1, const float* w, int B, long HW, int C, const float* gout,
+                        bf16_t* df1, aql_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

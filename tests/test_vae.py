@@ -131,3 +131,15 @@ def test_stage1_step_through_the_hip_vae_decoder():
     loss.backward()
     g = enc.secret_scaler[0].weight.grad
     assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
+    # the full stage-1 loss of the late phase (lpips * 5 + msgloss + prvl * 1.5, latent_wm_pretrain.py:207-209) with the HIP
+    # LPIPS(VGG16): the perceptual term reaches the SecretEncoder through the frozen VAE decoder as well
+    from aqualora_amd.lpips import LPIPS, synthetic_state_dict as lpips_sd
+    enc.zero_grad()
+    step2 = S1.Stage1Step(enc, dec, lambda z: vae.decode_grad(z, scaled=False), NZ.Noiser(["Identity"], [1.0]),
+                          lpips_fn=LPIPS(lpips_sd(), "cuda"))
+    step2.warmup = False
+    out2 = step2.losses(lat, msg, epochs_done=11, noiser_choice=[1.0])
+    assert float(out2["lpips_loss"]) > 0
+    (out2["lpips_loss"] * 5).backward()
+    g2 = enc.secret_scaler[0].weight.grad
+    assert g2 is not None and torch.isfinite(g2).all() and float(g2.abs().max()) > 0

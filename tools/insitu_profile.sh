@@ -4,7 +4,7 @@
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$tag
-env "$@" rocprofv3 --kernel-trace --output-format rocpd -d /tmp/prof_$tag -o run -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras > /tmp/prof_$tag.log 2>&1
+env "$@" rocprofv3 --kernel-trace --output-format rocpd -d /tmp/prof_$tag -o run -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras $BENCH_EXTRA > /tmp/prof_$tag.log 2>&1
 cd $GRAFT_REPO_ROOT
 DB=$(find /tmp/prof_$tag -name "*.db" | head -1)
 python tools/prof_summary.py $DB 3 > gpurun_out/insitu_${tag}_summary.txt
