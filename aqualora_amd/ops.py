@@ -501,6 +501,7 @@ class DeferredDW:
             gemm_tn_acc(U, V, C, alpha)
 
 
+REF_ROUNDING = os.environ.get("AQL_REF_ROUNDING", "0") == "1"   # see LoraLinearFn.forward
 DEFERRED = None  # set by a trainer around backward (ppft.PPFTTrainer); None => every site launches its own kernels
 
 
@@ -597,6 +598,24 @@ class LoraLinearFn(torch.autograd.Function):
             # trainers can hand in one persistent fp32 accumulator for dS (shared by all 192 sites)
             ctx.ds_accum = getattr(S, "_aql_ds_accum", None)
         F = packed.N // 2
+        if use_lora and REF_ROUNDING:
+            # Debug mode (AQL_REF_ROUNDING=1): the reference's rounding points under bf16 autocast (utils/lora_modules.py:13-19,
+            # 56-62) instead of the single fp32 accumulator -- T = bf16(x.A^T); Ts = bf16(T*S); lora = bf16(Ts.Bup^T);
+            # y = bf16(bf16(x.W^T + b) + lora); the host's residual is one more bf16 add.  Three launches; for bit-level
+            # comparisons of one site against an autocast run of the reference, not for training.
+            yk, y = _alloc((M, packed.N), torch.bfloat16, dev, twin)
+            _lora_down_rows(xk, packed.K, site, S16k, rps, Tk, Tsk, 0)
+            base = gemm_bf16(xk, packed.w, packed.bias)
+            gemm_bf16(Tsk, site.b16, None, residual=base, out=yk)
+            if resk is not None:
+                yk.add_(resk)
+            if geglu:
+                gk, g_out = _alloc((M, F), torch.bfloat16, dev, twin)
+                L.call("aql_geglu_fwd", L.ptr(yk), yk.shape[0], F, L.ptr(gk), L.stream_ptr())
+                ctx.save_for_backward(x2d, T, Ts, S16, y)
+                return g_out
+            ctx.save_for_backward(x2d, T, Ts, S16, None)
+            return y
         yk, y = _alloc((M, F if geglu else packed.N), torch.bfloat16, dev, twin)
         hk = h = None
         done = None
@@ -758,7 +777,7 @@ class GroupedLoraFn(torch.autograd.Function):
 
 def grouped_lora_ok(x2d, packs, sites, S16):
     """The one-launch grouped form applies: rank 32 everywhere, 160-column groups, stacked bf16 copies, fused kernel enabled."""
-    if S16 is None or os.environ.get("AQL_LORA_FUSED", "1") == "0" or os.environ.get("AQL_GROUPED", "1") == "0":
+    if S16 is None or os.environ.get("AQL_LORA_FUSED", "1") == "0" or os.environ.get("AQL_GROUPED", "1") == "0" or REF_ROUNDING:
         return False
     if len(sites) > 32 or any(s is None or s.rank != 32 for s in sites) or any(p.N % 160 != 0 or p.bias is not None for p in packs):
         return False

@@ -29,7 +29,7 @@ def test_gemm_family_parity():
 
 def test_ops_parity():
     text = _run("probe_ops.py")
-    assert text.count("PASS") >= 60
+    assert text.count("PASS") >= 76   # incl. attention at 9216 / 6336 tokens (768 px and non-square rob-finetune samples)
 
 
 def test_transpose_read_weight_gradient_gemm():

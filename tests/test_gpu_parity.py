@@ -149,6 +149,25 @@ def test_tiny_unet_forward_vs_oracle_and_golden(golden):
     assert relerr(clean, g["clean"]) < 5e-2 and relerr(pred, g["pred"]) < 5e-2
 
 
+def test_tiny_unet_large_non_square_latents_vs_oracle():
+    """rob-finetune samples at 512..768 px, height and width drawn independently (rob_enhance_finetune.py:1004-1005): the U-Net
+    runs on non-square latents up to 96x96.  Tiny U-Net, 72x88 latents (576x704 px; 9x11 at the lowest level), per-sample
+    scale rows, forward against the bf16-mirroring oracle."""
+    from oracle import ppft_oracle as O
+    unet, keys, lw = _gpu_tiny()
+    B, H, W = 2, 72, 88
+    x = T("ns.x", (B, 4, H, W))
+    ctx = T("ns.ctx", (B, 77, TINY["cross_attention_dim"]))
+    t = torch.tensor([40, 900])
+    S = 1.0 + 0.3 * T("ns.S", (B, TINY_RANK))
+    ref = O.UNetOracle(tiny_unet().state_dict(), TINY, lw, bf16=True)
+    with torch.no_grad():
+        want = ref.forward(x, t, ctx, S)
+        got = unet(x.to(DEV), t.to(DEV), ctx.to(DEV).to(torch.bfloat16), cross_attention_kwargs={"scale": S.to(DEV)}).sample
+    assert got.shape == (B, 4, H, W)
+    assert relerr(got, want) < 3e-2 and l2rel(got, want) < 2e-2, (relerr(got, want), l2rel(got, want))
+
+
 def test_full_size_sd15_unet_forward_vs_oracle():
     """BASELINE size: the full SD-1.5 U-Net (859.5 M synthetic parameters, 64x64x4 latents, 77x768 context) with the
     rank-32 watermark LoRA on all 192 sites -- HIP forward (clean and watermarked) against the bf16-mirroring CPU oracle.
@@ -303,6 +322,50 @@ def test_two_rank_rccl_replicas_stay_identical():
     assert res["world"] == 2 and res["rccl_ranks_seen"] == 2
     assert res["init_differs_before_broadcast"] and res["params_equal_after_init"]
     assert res["params_equal_after_steps"] and res["params_moved"], res
+
+
+def test_reference_rounding_mode_matches_autocast_restatement_per_element():
+    """AQL_REF_ROUNDING=1 inserts the reference's three bf16 roundings of the LoRA branch (utils/lora_modules.py:13-19 under
+    autocast: bf16(down(x)), bf16(T*S), bf16(up(.)), then the bf16 add at :61).  With the same rounding points an fp32 torch
+    restatement can be matched ELEMENT BY ELEMENT: every output within one bf16 ulp (2^-8 relative + accumulation-order noise),
+    instead of the 1.5e-2-of-max bound of the fused single-accumulator kernel."""
+    from aqualora_amd import lora as AL, ops
+    r16 = lambda t: t.to(torch.bfloat16).float()   # noqa: E731
+    old = ops.REF_ROUNDING
+    ops.REF_ROUNDING = True
+    try:
+        for tag, cin, cout, n, r in (("rr_a", 320, 320, 256, 32), ("rr_b", 768, 640, 77, 32), ("rr_c", 1280, 320, 64, 8)):
+            host = AL.LoRACompatibleLinear(cin, cout, device=DEV, dtype=torch.bfloat16)
+            ll = AL.LoRALinearLayer(cin, cout, r, device=DEV, dtype=torch.float32)
+            with torch.no_grad():
+                host.weight.copy_(T(f"{tag}.w", (cout, cin), cin ** -0.5))
+                host.bias.copy_(T(f"{tag}.b", (cout,), 0.02))
+                ll.down.weight.copy_(T(f"{tag}.down", (r, cin), 1.0 / r))
+                ll.up.weight.copy_(T(f"{tag}.up", (cout, r), 0.05))
+            host.set_lora_layer(ll)
+            x = T(f"{tag}.x", (2, n, cin), device=DEV).to(torch.bfloat16)
+            S = (T(f"{tag}.S", (2, r), 0.3, DEV) + 1.0)
+            y = AL.CustomLoRACompatibleLinearforward(host, x, S).float().cpu()
+            xf = x.float().cpu().double()
+            W, b = r16(host.weight.float().cpu()).double(), r16(host.bias.float().cpu()).double()
+            A, Bu = r16(ll.down.weight.cpu()).double(), r16(ll.up.weight.cpu()).double()
+            S16 = r16(S.cpu()).double()
+            base = r16((xf @ W.t() + b).float()).double()
+            Tm = r16((xf @ A.t()).float()).double()
+            Ts = r16((Tm * S16[:, None, :]).float()).double()
+            lo = r16((Ts @ Bu.t()).float()).double()
+            ref = r16((base + lo).float())
+            err = (y - ref).abs()
+            # one bf16 ulp of the result plus one ulp of either summand (an fp32 accumulation-order flip of a rounding upstream)
+            # ... and the propagation of a one-ulp flip of a single T (or Ts) element through the up projection
+            flip = 2.0 ** -8 * 2.0 * float((Tm.abs().max() * S16.abs().max() * Bu.abs().max()).detach())
+            bound = 2.0 ** -8 * (ref.abs() + base.abs().float() + lo.abs().float()) + flip + 1e-6
+            frac_exact = (y == ref).float().mean().item()
+            print(f"ref-rounding {tag}: {100 * frac_exact:.2f} % of elements bit-equal, worst excess over the bound "
+                  f"{(err - bound).max().item():.2e}")
+            assert (err <= bound).all() and frac_exact > 0.97, (tag, frac_exact)
+    finally:
+        ops.REF_ROUNDING = old
 
 
 def test_tiny_ppft_step_vs_golden(golden):

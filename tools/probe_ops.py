@@ -47,7 +47,9 @@ def attn_ref(q, k, v, H):
     qh = q.view(B, Nq, H, d).transpose(1, 2); kh = k.view(B, -1, H, d).transpose(1, 2); vh = v.view(B, -1, H, d).transpose(1, 2)
     o = torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, -1) @ vh
     return o.transpose(1, 2).reshape(B, Nq, C)
-for (B, H, Nq, Nk, d) in [(2, 8, 256, 256, 40), (1, 8, 1024, 1024, 80), (2, 8, 64, 64, 160), (2, 8, 256, 77, 40), (1, 8, 100, 77, 160), (1, 2, 200, 300, 64), (1, 8, 4096, 4096, 40)]:
+for (B, H, Nq, Nk, d) in [(2, 8, 256, 256, 40), (1, 8, 1024, 1024, 80), (2, 8, 64, 64, 160), (2, 8, 256, 77, 40), (1, 8, 100, 77, 160), (1, 2, 200, 300, 64), (1, 8, 4096, 4096, 40),
+                           # rob-finetune samples 512..768 px (rob_enhance_finetune.py:1004-1005): up to 96x96 = 9216 tokens, non-square maps
+                           (1, 2, 9216, 9216, 40), (1, 2, 6336, 6336, 40), (1, 2, 6336, 77, 40), (1, 2, 1584, 1584, 80)]:
     q = rnd(B, Nq, H * d).requires_grad_(True); k = rnd(B, Nk, H * d).requires_grad_(True); v = rnd(B, Nk, H * d).requires_grad_(True)
     o = ops.attention(q, k, v, H)
     qr, kr, vr = [t.detach().float().requires_grad_(True) for t in (q, k, v)]
