@@ -84,14 +84,17 @@ def dominant_kernels(B, device):
     carry most FLOPs: the implicit-GEMM 3x3 conv and the fused LoRA GEMM, at their largest U-Net shapes."""
     from aqualora_amd import ops, synth
     out = []
-    x = synth.normal("k.x", (B, 320, 64, 64), 1.0, 1, device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    # the forward runs both U-Net passes of the step as ONE twin batch of 2B samples (aqualora_amd/ops.py, _Dual): that is
+    # the shape the dominant kernel sees in the step; the backward-data convolutions run at B
     w = synth.normal("k.w", (320, 320, 3, 3), 0.02, 1, device)
     pk = ops.PackedConv3x3(w, torch.zeros(320, device=device), 1)
-    with torch.no_grad():
-        ms = time_kernel(lambda: ops.conv3x3(x, pk))
-    fl = 2.0 * B * 64 * 64 * 320 * 9 * 320
-    out.append({"kernel": "gemm_kernel_w<128,160,64,80,ConvFwdLoader,PlainLoader,EPI_BF16,4> conv3x3 320->320 @64x64", "ms": ms,
-                "flops": fl, "achieved_tflops": fl / ms / 1e9, "frac_of_mfma_peak": fl / ms / 1e9 / MFMA_PEAK_TF})
+    for nb, tag in ((2 * B, "twin forward"), (B, "batch-B shape")):
+        x = synth.normal("k.x", (nb, 320, 64, 64), 1.0, 1, device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            ms = time_kernel(lambda: ops.conv3x3(x, pk))
+        fl = 2.0 * nb * 64 * 64 * 320 * 9 * 320
+        out.append({"kernel": f"gemm_kernel_w<128,160,64,80,ConvFwdLoader,PlainLoader,EPI_BF16,4> conv3x3 320->320 @64x64, {nb} samples ({tag})",
+                    "ms": ms, "samples": nb, "flops": fl, "achieved_tflops": fl / ms / 1e9, "frac_of_mfma_peak": fl / ms / 1e9 / MFMA_PEAK_TF})
     xs = synth.normal("k.x2", (B * 4096, 320), 1.0, 1, device).to(torch.bfloat16)
     wl = synth.normal("k.w2", (2560, 320), 0.05, 1, device)
     pl = ops.PackedLinear(wl, torch.zeros(2560, device=device))
@@ -483,15 +486,17 @@ def main():
         # dominant kernel = the implicit-GEMM 3x3 convolution family (48 % of the step's algorithmic FLOPs); timed live
         # with HIP events on the launch stream.  `traffic` = HBM bytes per launch of the same kernel and shape from the
         # rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 2x FETCH correction), collected
-        # with tools/pmc_traffic.sh and committed as profiles/r01_pmc_traffic.json; null for other batch sizes.
+        # with tools/pmc_traffic.sh and committed as profiles/r02_pmc_traffic.json; null for batch sizes without a committed pass.
         traffic = None
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-        if args.batch == 4 and os.path.exists(pmc_path):
+        alg = 2.0 * dom["samples"] * 64 * 64 * 320 * 2 + 320 * 2880 * 2
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
+        if os.path.exists(pmc_path):
             with open(pmc_path) as f:
-                traffic = json.load(f)["conv3x3 320->320 @64x64 B=4"]["traffic_bytes"]
+                ent = json.load(f).get(f"conv3x3 320->320 @64x64 B={dom['samples']}")
+            traffic = None if ent is None else ent["traffic_bytes"]
         line["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_tflops"],
                             "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": dom["frac_of_mfma_peak"],
-                            "traffic": traffic, "traffic_unit": "bytes/launch (algorithmic: 22.8e6)",
+                            "traffic": traffic, "traffic_unit": f"bytes/launch (algorithmic: {alg:.4g})",
                             "traffic_source": None if traffic is None else
                             "static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel+shape, " + os.path.basename(pmc_path),
                             "flops_per_launch": dom["flops"], "ms_per_launch": dom["ms"]}
