@@ -19,7 +19,9 @@ def timeit(fn, n=10):
     t1.record(); torch.cuda.synchronize(); return t0.elapsed_time(t1) / n
 
 # GroupNorm + SiLU
-for (B, C, H, W, silu, eps) in [(2, 320, 64, 64, 1, 1e-5), (2, 640, 16, 16, 0, 1e-6), (3, 2560, 8, 8, 1, 1e-5), (2, 32, 4, 4, 1, 1e-5), (2, 960, 32, 32, 1, 1e-5)]:
+for (B, C, H, W, silu, eps) in [(2, 320, 64, 64, 1, 1e-5), (2, 640, 16, 16, 0, 1e-6), (3, 2560, 8, 8, 1, 1e-5), (2, 32, 4, 4, 1, 1e-5), (2, 960, 32, 32, 1, 1e-5),
+                                # maps above 32x32: the row-slab form (ragged slabs, non-square, VAE-like widths)
+                                (3, 640, 64, 64, 1, 1e-5), (2, 960, 64, 64, 0, 1e-6), (1, 320, 72, 88, 1, 1e-5), (1, 128, 160, 96, 1, 1e-6)]:
     x = (rnd(B, C, H, W) * 2 + 0.5).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     g = rnd(C) * 0.5 + 1; b = rnd(C) * 0.1
     y = ops.groupnorm_silu(x, g, b, eps, silu)
