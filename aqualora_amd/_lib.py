@@ -10,7 +10,8 @@ import os
 import torch  # noqa: F401  (must be imported first so that libamdhip64.so.7 resolves to torch's HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libaqualora_hip.so")
+# AQL_LIB selects another build of the same ABI (kernel A/B runs on one box, tools/ab_bench.sh)
+LIB_PATH = os.environ.get("AQL_LIB") or os.path.join(_HERE, "csrc", "libaqualora_hip.so")
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int

@@ -165,7 +165,8 @@ __device__ __forceinline__ void load_owner(bf16x8_t (&f)[NOF][DH / 32], const bf
 }
 
 // acc[sf][of] += rowmajor tile frag sf (A)  x  owner frag of (B)
-template <int DH, int NOF>
+// INIT: the accumulators start from zero -- the first k-step takes a literal-zero C operand instead of 16 x NOF v_mov per tile
+template <int DH, int NOF, bool INIT = false>
 __device__ __forceinline__ void s_product(f32x4_t (&acc)[4][NOF], const char* tile, const bf16x8_t (&own)[NOF][DH / 32],
                                           int lane) {
 #pragma unroll
@@ -177,8 +178,10 @@ __device__ __forceinline__ void s_product(f32x4_t (&acc)[4][NOF], const char* ti
 #pragma unroll
     for (int sf = 0; sf < 4; ++sf)
 #pragma unroll
-      for (int of = 0; of < NOF; ++of)
-        acc[sf][of] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[sf], own[of][s], acc[sf][of], 0, 0, 0);
+      for (int of = 0; of < NOF; ++of) {
+        if (INIT && s == 0) acc[sf][of] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[sf], own[of][s], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        else acc[sf][of] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[sf], own[of][s], acc[sf][of], 0, 0, 0);
+      }
   }
 }
 
@@ -373,8 +376,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const
       stV.fetch();
     }
     f32x4_t s[4][NOF];
-    zero_acc(s);
-    s_product<DH>(s, sK, qf, lane);
+    s_product<DH, NOF, true>(s, sK, qf, lane);
     if (kt + TILE > a.Nk) {
 #pragma unroll
       for (int sf = 0; sf < 4; ++sf)
@@ -393,10 +395,13 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const
 #pragma unroll
         for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[sf][of][e]);
       mx = group4_max(mx);
+      // (Deferring the rescale until the maximum grows by 2^8 -- guide T13 -- measured -2...4 % on this kernel, but makes the
+      // bf16 rounding of P depend on a threshold decision: a 1e-7 input perturbation then moves outputs by a bf16 ulp
+      // everywhere instead of nowhere, which the sampler-vs-restatement test (1e-4 over 5 guided steps) rightly rejects.)
       const float mn = fmaxf(m[of], mx);
       const float alpha = __builtin_amdgcn_exp2f((m[of] - mn) * c);
-      const float mnc = mn * c;
       m[of] = mn;
+      const float mnc = mn * c;
       float rs = 0.f;
 #pragma unroll
       for (int sf = 0; sf < 4; ++sf)
