@@ -427,12 +427,10 @@ extern "C" int aql_gemm_bf16_geglu(const bf16_t* A, long lda, const bf16_t* B, l
 // 16 rows; its 4 wavefronts split K in interleaved 32-wide steps (together they read 256 contiguous bytes per row),
 // stream X straight into MFMA B-operands, and the four partial r x 16 accumulators are summed through LDS.
 template <int RF>
-__global__ __launch_bounds__(256) void lora_down_skinny_kernel(const bf16_t* __restrict__ X, long ldx, long M, int K,
-                                                               const bf16_t* __restrict__ A,
-                                                               const bf16_t* __restrict__ S, int rps,
-                                                               bf16_t* __restrict__ T, bf16_t* __restrict__ Ts,
-                                                               const bf16_t* __restrict__ Tref,
-                                                               float* __restrict__ dS) {
+__device__ __forceinline__ void lora_down_skinny_body(const bf16_t* __restrict__ X, long ldx, long M, int K,
+                                                      const bf16_t* __restrict__ A, const bf16_t* __restrict__ S, int rps,
+                                                      bf16_t* __restrict__ T, bf16_t* __restrict__ Ts,
+                                                      const bf16_t* __restrict__ Tref, float* __restrict__ dS) {
   __shared__ f32x4_t part[4][RF][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long row = (long)blockIdx.x * 16 + (lane & 15);
@@ -521,6 +519,31 @@ __global__ __launch_bounds__(256) void lora_down_skinny_kernel(const bf16_t* __r
   }
 }
 
+template <int RF>
+__global__ __launch_bounds__(256) void lora_down_skinny_kernel(const bf16_t* __restrict__ X, long ldx, long M, int K,
+                                                               const bf16_t* __restrict__ A,
+                                                               const bf16_t* __restrict__ S, int rps,
+                                                               bf16_t* __restrict__ T, bf16_t* __restrict__ Ts,
+                                                               const bf16_t* __restrict__ Tref,
+                                                               float* __restrict__ dS) {
+  lora_down_skinny_body<RF>(X, ldx, M, K, A, S, rps, T, Ts, Tref, dS);
+}
+
+// Up to 32 rank-32 "down" products of equal row count in ONE launch (blockIdx.y = problem): the backward of the text-state
+// k|v projections of all cross-attentions, dTs_g = dY_g.Bup_g, dT_g = dTs_g * S  (32 launches of 5-7 us otherwise).
+struct DownGroup {
+  const bf16_t* X[32];
+  const bf16_t* A[32];
+  int K[32];
+};
+__global__ __launch_bounds__(256) void lora_down_skinny_grouped_kernel(const DownGroup g, long M, const bf16_t* __restrict__ S,
+                                                                       int rps, bf16_t* __restrict__ T,
+                                                                       bf16_t* __restrict__ Ts) {
+  const int i = blockIdx.y;
+  lora_down_skinny_body<2>(g.X[i], g.K[i], M, g.K[i], g.A[i], S, rps, T + (long)i * M * 32, Ts + (long)i * M * 32, nullptr,
+                           nullptr);
+}
+
 // T = X.Adown^T (bf16) and Ts = T * S[sample]  -- the rank-r "down" half of the watermark LoRA.
 extern "C" int aql_lora_ds(const bf16_t* dTs, const bf16_t* T, int nb, int rows_per_sample, int r, float* dS,
                            hipStream_t stream);
@@ -556,6 +579,23 @@ extern "C" int aql_lora_down(const bf16_t* X, long ldx, long M, int K, const bf1
   const int rc = run_bf16_gemm(g, o, nullptr, 0, stream, "aql_lora_down");
   if (rc != AQL_OK || Tref == nullptr) return rc;
   return aql_lora_ds(T, Tref, (int)(M / rows_per_sample), rows_per_sample, r, dS, stream);
+}
+
+// n <= 32 rank-32 down products sharing M, S and rows_per_sample: T[i] = X[i].A[i]^T, Ts[i] = T[i] * S[m / rps];
+// X[i] [M][K[i]] dense, A[i] [32][K[i]], K[i] % 32 == 0; T, Ts [n][M][32].  X, A, K are HOST arrays.
+extern "C" int aql_lora_down_grouped(int n, const bf16_t* const* X, const bf16_t* const* A, const int* K, long M,
+                                     const bf16_t* S, int rows_per_sample, bf16_t* T, bf16_t* Ts, hipStream_t stream) {
+  AQL_CHECK_ARG(n >= 1 && n <= 32 && X && A && K && S && T && Ts && M > 0 && rows_per_sample > 0,
+                "aql_lora_down_grouped: bad args");
+  DownGroup g{};
+  for (int i = 0; i < n; ++i) {
+    AQL_CHECK_ARG(X[i] && A[i] && K[i] > 0 && K[i] % 32 == 0, "aql_lora_down_grouped: bad problem %d", i);
+    g.X[i] = X[i], g.A[i] = A[i], g.K[i] = K[i];
+  }
+  hipLaunchKernelGGL(lora_down_skinny_grouped_kernel, dim3((unsigned)((M + 15) / 16), n), dim3(256), 0, stream, g, M, S,
+                     rows_per_sample, T, Ts);
+  AQL_CHECK_LAUNCH("aql_lora_down_grouped");
+  return AQL_OK;
 }
 
 extern "C" int aql_conv3x3_fwd_pad(const bf16_t* X, int B, int Hin, int Win, int Cin, const bf16_t* Wk, const bf16_t* bias,

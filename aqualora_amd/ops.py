@@ -762,6 +762,28 @@ class GroupedLoraFn(torch.autograd.Function):
     def backward(ctx, *dys):
         x2d, T, Ts, S16 = ctx.saved_tensors
         dx, dS_sum = None, None
+        if (not ctx.needs_input_grad[0] and not ctx.needs_input_grad[4] and ctx.ds_accum is not None and DEFERRED is not None
+                and all(dy is not None for dy in dys) and os.environ.get("AQL_GROUPED", "1") != "0"):
+            # input without gradient (the text states): only dTs / dT are needed (for dS, dA, dB) -- ONE grouped skinny launch
+            # for all groups instead of one per group, everything else is bookkeeping for the deferred grouped launches
+            import ctypes
+            G = len(dys)
+            M = x2d.shape[0]
+            dys = [dy.contiguous() for dy in dys]
+            dTs = torch.empty(G, M, 32, dtype=torch.bfloat16, device=x2d.device)
+            dT = torch.empty_like(dTs)
+            Xp = (ctypes.c_void_p * G)(*[dy.data_ptr() for dy in dys])
+            Ap = (ctypes.c_void_p * G)(*[s_.bt16.data_ptr() for s_ in ctx.sites])
+            Kp = (ctypes.c_int * G)(*[dy.shape[1] for dy in dys])
+            L.call("aql_lora_down_grouped", G, Xp, Ap, Kp, M, L.ptr(S16), ctx.rps, L.ptr(dTs), L.ptr(dT), L.stream_ptr())
+            nb = S16.shape[0]
+            for g, dy in enumerate(dys):
+                site = ctx.sites[g]
+                if not DEFERRED.add_ds(dTs[g], T[g], ctx.ds_accum, nb, ctx.rps, 32):
+                    L.call("aql_lora_ds", L.ptr(dTs[g]), L.ptr(T[g]), nb, ctx.rps, 32, L.ptr(ctx.ds_accum), L.stream_ptr())
+                DEFERRED.add_tn(dy, Ts[g], site.gb)
+                DEFERRED.add_tn(dT[g], x2d, site.ga)
+            return None, None, None, None, None, None, None
         for g, dy in enumerate(dys):
             if dy is None:
                 continue

@@ -93,6 +93,11 @@ int aql_lora_gemm_fused_grouped(const bf16_t* X, long ldx, const bf16_t* W, long
                                 const int* col_start, const bf16_t* Adown, const bf16_t* S, int rows_per_sample,
                                 const bf16_t* Bup, const bf16_t* bias, bf16_t* Y, long ldy, bf16_t* T, bf16_t* Ts,
                                 long lora_row0, aql_stream_t stream);
+/* n <= 32 rank-32 "down" products with a common row count in one launch: T[i] = X[i].A[i]^T, Ts[i] = T[i] * S[m / rps]
+ * (X[i] [M,K[i]] dense, A[i] [32,K[i]]; X, A, K are HOST arrays; T, Ts [n][M][32]).  The backward of the grouped text-state
+ * k|v projections: dTs = dY.Bup, dT = dTs * S (utils/lora_modules.py:13-17 transposed) for all 32 sites at once.        */
+int aql_lora_down_grouped(int n, const bf16_t* const* X, const bf16_t* const* A, const int* K, long M, const bf16_t* S,
+                          int rows_per_sample, bf16_t* T, bf16_t* Ts, aql_stream_t stream);
 int aql_conv3x3_bwd_data(const bf16_t* dY, int B, int Hin, int Win, int Cin, const bf16_t* Wt, int Cout, int stride,
                          bf16_t* dX, float* ws, size_t ws_bytes, aql_stream_t stream);
 
