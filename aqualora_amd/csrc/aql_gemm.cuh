@@ -96,6 +96,12 @@ struct EpiParams {
   int geglu_F = 0;
   int c_row0 = 0;          // GEGLU: the pre-activation C is written for rows >= c_row0 only (twin batches: the clean half
                            // never runs backward)
+  // GEGLU-backward epilogue (gb_F = F > 0; the one-launch LoRA linear in its backward-data form, ff.net.2): the GEMM's N = F
+  // outputs are d(activated) = d(value * gelu(gate)); with the saved pre-activation gb_h [M][2F] the epilogue writes
+  // d(value) to C[m][n] and d(gate) to C[m][F + n] (ldc = 2F) -- aql_geglu_bwd applied to the bf16-rounded tile.
+  const bf16_t* gb_h = nullptr;
+  long gb_ldh = 0;
+  int gb_F = 0;
   int trans_out;           // EPI_ATOMIC only: write C^T, i.e. element (m,n) goes to Cf[n*ldcf + m]
   // EPI_SLAB / EPI_ATOMIC: fp32 output
   float* Cf;               // slab base [splits][M][ldcf] or atomic target [M][ldcf]
@@ -616,6 +622,29 @@ __device__ __forceinline__ float gelu_erf(float g) { return aql_gelu(g); }
 // bias index of tile-local column `col` (a multiple of 4): plain tiles n0 + col; GEGLU tiles [value | gate] halves
 __device__ __forceinline__ int epi_bias_col(int n0, int col, int F, int half) {
   return F == 0 ? n0 + col : (col < half ? n0 + col : F + n0 + col - half);
+}
+
+// aql_geglu_bwd on 8 elements: d = d(activated), hv / hg = saved value / gate -> dv = d gate cdf(gate), dg = d value (cdf + gate pdf)
+__device__ __forceinline__ void geglu_bwd8(const uint4& d, const uint4& hv, const uint4& hg, uint4& dv, uint4& dg) {
+  const uint32_t dw[4] = {d.x, d.y, d.z, d.w}, vw[4] = {hv.x, hv.y, hv.z, hv.w}, gw[4] = {hg.x, hg.y, hg.z, hg.w};
+  uint32_t ov[4], og[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float rv[2], rg[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float dd = q ? bf16hi(dw[e]) : bf16lo(dw[e]), h = q ? bf16hi(vw[e]) : bf16lo(vw[e]);
+      const float gt = q ? bf16hi(gw[e]) : bf16lo(gw[e]);
+      const float cdf = 0.5f * (1.f + aql_erf(gt * 0.70710678118654752f));
+      const float pdf = 0.3989422804014327f * __expf(-0.5f * gt * gt);
+      rv[q] = dd * gt * cdf;
+      rg[q] = dd * h * (cdf + gt * pdf);
+    }
+    ov[e] = pack_bf16x2(rv[0], rv[1]);
+    og[e] = pack_bf16x2(rg[0], rg[1]);
+  }
+  dv = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+  dg = make_uint4(og[0], og[1], og[2], og[3]);
 }
 
 // The bf16 C tile [BM][BN] (value columns 0..BN/2-1, gate columns BN/2..BN-1) is staged in LDS: write

@@ -274,6 +274,15 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
       v.z = pack_bf16x2(bf16lo(v.z) + bf16lo(r.z), bf16hi(v.z) + bf16hi(r.z));
       v.w = pack_bf16x2(bf16lo(v.w) + bf16lo(r.w), bf16hi(v.w) + bf16hi(r.w));
     }
+    if (ep.gb_F) {   // the tile is d(value * gelu(gate)): write d(value), d(gate) from the saved pre-activation
+      const uint4 hv = *reinterpret_cast<const uint4*>(ep.gb_h + (long)m * ep.gb_ldh + n);
+      const uint4 hg = *reinterpret_cast<const uint4*>(ep.gb_h + (long)m * ep.gb_ldh + ep.gb_F + n);
+      uint4 dv, dg;
+      geglu_bwd8(v, hv, hg, dv, dg);
+      *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + n) = dv;
+      *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + ep.gb_F + n) = dg;
+      continue;
+    }
     *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + n) = v;
   }
 }
@@ -536,6 +545,15 @@ __global__ __launch_bounds__(2 * NTHREADS) void lora_gemm_kernel_w(const GemmArg
       v.z = pack_bf16x2(bf16lo(v.z) + bf16lo(r.z), bf16hi(v.z) + bf16hi(r.z));
       v.w = pack_bf16x2(bf16lo(v.w) + bf16lo(r.w), bf16hi(v.w) + bf16hi(r.w));
     }
+    if (ep.gb_F) {   // the tile is d(value * gelu(gate)): write d(value), d(gate) from the saved pre-activation
+      const uint4 hv = *reinterpret_cast<const uint4*>(ep.gb_h + (long)m * ep.gb_ldh + n);
+      const uint4 hg = *reinterpret_cast<const uint4*>(ep.gb_h + (long)m * ep.gb_ldh + ep.gb_F + n);
+      uint4 dv, dg;
+      geglu_bwd8(v, hv, hg, dv, dg);
+      *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + n) = dv;
+      *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + ep.gb_F + n) = dg;
+      continue;
+    }
     *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + n) = v;
   }
 }
@@ -570,7 +588,7 @@ static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long
                                 const bf16_t* Adown, const bf16_t* S, int rows_per_sample, const bf16_t* Bup,
                                 const bf16_t* bias, const bf16_t* residual, long ldr, bf16_t* Y, long ldy, bf16_t* T,
                                 bf16_t* Ts, bf16_t* G, long ldg, int geglu_F, int ngroups, const int* col_start, long row0,
-                                hipStream_t stream) {
+                                hipStream_t stream, const bf16_t* gb_h = nullptr, long gb_ldh = 0) {
   AQL_CHECK_ARG(X && W && Adown && S && Bup && (Y || geglu_F) && T && Ts, "aql_lora_gemm_fused: null operand");
   AQL_CHECK_ARG(M > 0 && M < (1L << 31) && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 &&
                     ldy % 8 == 0 && rows_per_sample > 0 && (residual == nullptr || ldr % 8 == 0),
@@ -605,6 +623,7 @@ static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long
   g.epi.G = G;
   g.epi.ldg = ldg;
   g.epi.geglu_F = geglu_F;
+  if (gb_h != nullptr) g.epi.gb_h = gb_h, g.epi.gb_ldh = gb_ldh, g.epi.gb_F = N;
   const PlainLoader la = plain(Adown, K, LR, K);
   LoraParams lp{};
   lp.S = S, lp.Bup = Bup, lp.T = T, lp.Ts = Ts, lp.rps = rows_per_sample;
@@ -711,4 +730,18 @@ extern "C" int aql_lora_gemm_fused_geglu(const bf16_t* X, long ldx, const bf16_t
   if (F % 80 != 0) return AQL_NOT_FUSED;
   return lora_gemm_fused_impl(X, ldx, W, ldw, M, 2 * F, K, Adown, S, rows_per_sample, Bup, bias, nullptr, 0, H, ldh, T, Ts, G,
                               ldg, F, 0, nullptr, lora_row0, stream);
+}
+
+// Backward-data of ff.net.2 fused with the backward of the GEGLU in front of it (scripts/lib/original_unet.py:727-729):
+// aql_lora_gemm_fused in its backward form (X = dY [M,K], W = W2^T [F,K], Adown = Bup2^T, Bup = A2^T: dTs, dT and
+// d(activated) = dY.W2 + dT.A2 [M,F]), whose epilogue turns d(activated) into d(pre-activation) with the saved H [M,2F]:
+// DH[m][n] = d * gate * cdf(gate), DH[m][F+n] = d * value * (cdf(gate) + gate pdf(gate)) -- aql_geglu_bwd applied to the
+// bf16-rounded tile (bit-identical to the two kernels).  Returns 100 like aql_lora_gemm_fused.
+extern "C" int aql_lora_gemm_fused_geglu_bwd(const bf16_t* X, long ldx, const bf16_t* W, long ldw, long M, int F, int K,
+                                             const bf16_t* Adown, const bf16_t* S, int rows_per_sample, const bf16_t* Bup,
+                                             const bf16_t* H, long ldh, bf16_t* DH, long lddh, bf16_t* T, bf16_t* Ts,
+                                             hipStream_t stream) {
+  AQL_CHECK_ARG(H && DH && ldh % 8 == 0 && lddh % 8 == 0 && F % 8 == 0, "aql_lora_gemm_fused_geglu_bwd: bad args");
+  return lora_gemm_fused_impl(X, ldx, W, ldw, M, F, K, Adown, S, rows_per_sample, Bup, nullptr, nullptr, 0, DH, lddh, T, Ts,
+                              nullptr, 0, 0, 0, nullptr, 0, stream, H, ldh);
 }

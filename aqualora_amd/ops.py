@@ -667,10 +667,12 @@ class LoraLinearFn(torch.autograd.Function):
         return dx, None, None, dS, None, None, (dy if ctx.has_res else None), None, None
 
 
-def _lora_backward(dy, x2d, T, Ts, S16, packed, site, rps, ds_accum, want_dx, ret_ds, s_dtype, dx_prev):
+def _lora_backward(dy, x2d, T, Ts, S16, packed, site, rps, ds_accum, want_dx, ret_ds, s_dtype, dx_prev, geglu_h=None):
     """Backward of one LoRA linear  Y = X.W^T + ((X.A^T)*S).Bup^T :  dTs = dY.Bup, dT = dTs*S, dX = dY.W + dT.A (+ dx_prev, added
     in the GEMM epilogue), dS += rowsum(dTs*T) per sample, and the weight gradients dBup += dY^T.Ts, dA += dT^T.X (queued on the
-    trainer's DeferredDW when there is one).  Returns (dX or None, dS in s_dtype or None)."""
+    trainer's DeferredDW when there is one).  Returns (dX or None, dS in s_dtype or None).
+    ``geglu_h`` (ff.net.2 only): X is GEGLU(H); the returned gradient is d(H) [M, 2F] -- the GEGLU backward runs in the epilogue
+    of the same launch (aql_lora_gemm_fused_geglu_bwd), or as aql_geglu_bwd behind the unfused forms."""
     M = dy.shape[0]
     r = site.rank
     dS = None
@@ -685,7 +687,18 @@ def _lora_backward(dy, x2d, T, Ts, S16, packed, site, rps, ds_accum, want_dx, re
     ds_target = acc if acc is not None else dS
     ds_deferred = want_ds and dfr is not None and acc is not None
     dx = None
-    if want_dx:   # dTs = dY.Bup, dT = dTs * S, dX = dY.W + dT.A in one launch
+    fused_gb = False
+    if want_dx and geglu_h is not None and r == 32 and os.environ.get("AQL_LORA_FUSED", "1") != "0" \
+            and os.environ.get("AQL_GEGLU_BWD_FUSED", "1") != "0":
+        F = packed.K
+        dh = torch.empty(M, 2 * F, dtype=torch.bfloat16, device=dy.device)
+        rc = L.call_raw("aql_lora_gemm_fused_geglu_bwd", L.ptr(dy), dy.stride(0), L.ptr(packed.wt), packed.wt.stride(0), M, F,
+                        packed.N, L.ptr(site.bt16), L.ptr(S16), rps, L.ptr(site.at16), L.ptr(geglu_h), geglu_h.stride(0),
+                        L.ptr(dh), 2 * F, L.ptr(dTs), L.ptr(dT), L.stream_ptr())
+        if rc != 100:
+            L.check(rc, "aql_lora_gemm_fused_geglu_bwd")
+            dx, fused_gb = dh, True
+    if want_dx and dx is None:   # dTs = dY.Bup, dT = dTs * S, dX = dY.W + dT.A in one launch
         dx = _lora_gemm_fused(dy, packed.wt, site.bt16, S16, rps, site.at16, None, dx_prev, dTs, dT)
     if dx is not None:
         if want_ds and not ds_deferred:
@@ -704,7 +717,55 @@ def _lora_backward(dy, x2d, T, Ts, S16, packed, site, rps, ds_accum, want_dx, re
         gemm_tn_acc(dT, x2d, site.ga)
     if dS is not None:
         dS = dS.to(s_dtype) if ret_ds else None
+    if geglu_h is not None and dx is not None and not fused_gb:   # unfused tail: d(activated) -> d(pre-activation)
+        dh = torch.empty_like(geglu_h)
+        L.call("aql_geglu_bwd", L.ptr(geglu_h), L.ptr(dx), M, geglu_h.shape[1] // 2, L.ptr(dh), L.stream_ptr())
+        dx = dh
     return dx, dS
+
+
+class _Saved:
+    """stand-in for an autograd ctx when one Function composes the forward of another"""
+
+    def save_for_backward(self, *t):
+        self.saved = t
+
+
+class FeedForwardFn(torch.autograd.Function):
+    """diffusers FeedForward (GEGLU proj -> GEGLU -> net.2; scripts/lib/original_unet.py:727-760) with LoRA on both linears as
+    ONE autograd node: forward = the ff.net.0 launch with the GEGLU epilogue, then the ff.net.2 launch (residual in its
+    epilogue); backward = the ff.net.2 backward-data launch whose epilogue applies the GEGLU backward, then the ff.net.0
+    backward-data launch -- no stand-alone GEGLU kernel in either direction, and d(activated) never touches HBM."""
+
+    @staticmethod
+    def forward(ctx, x2d, packed0, site0, packed2, site2, S, S16, rps, residual):
+        c0, c2 = _Saved(), _Saved()
+        g = LoraLinearFn.forward(c0, x2d, packed0, site0, S, S16, rps, None, True, True)
+        y = LoraLinearFn.forward(c2, g, packed2, site2, S, S16, rps, residual, False, True)
+        ctx.p0, ctx.s0, ctx.p2, ctx.s2, ctx.rps = packed0, site0, packed2, site2, rps
+        ctx.ds_accum, ctx.s_dtype, ctx.has_res = c0.ds_accum, S.dtype, residual is not None
+        _, T0, Ts0, _, h = c0.saved
+        _, T2, Ts2, _, _ = c2.saved
+        ctx.save_for_backward(x2d, T0, Ts0, S16, h, g, T2, Ts2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, T0, Ts0, S16, h, g, T2, Ts2 = ctx.saved_tensors
+        dy = dy.contiguous()
+        ret_ds = ctx.needs_input_grad[5]
+        dh, dS2 = _lora_backward(dy, g, T2, Ts2, S16, ctx.p2, ctx.s2, ctx.rps, ctx.ds_accum, True, ret_ds, ctx.s_dtype, None,
+                                 geglu_h=h)
+        dx, dS0 = _lora_backward(dh, x2d, T0, Ts0, S16, ctx.p0, ctx.s0, ctx.rps, ctx.ds_accum, ctx.needs_input_grad[0], ret_ds,
+                                 ctx.s_dtype, None)
+        dS = None
+        if dS0 is not None or dS2 is not None:
+            dS = dS0 if dS2 is None else (dS2 if dS0 is None else dS0 + dS2)
+        return dx, None, None, None, None, dS, None, None, (dy if ctx.has_res else None)
+
+
+def feed_forward(x2d, packed0, site0, packed2, site2, S, S16, rps, residual=None):
+    return FeedForwardFn.apply(x2d, packed0, site0, packed2, site2, S, S16, rps, residual)
 
 
 # --------------------------------------------------------------------------- grouped LoRA linears (shared input)

@@ -225,7 +225,33 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([GEGLU(dim, dim * 4, **kw), nn.Dropout(0.0), LoRACompatibleLinear(dim * 4, dim, **kw)])
 
     def forward(self, x, scale=1.0, residual=None):
+        y = self._fused(x, scale, residual)
+        if y is not None:
+            return y
         return self.net[2](self.net[0](x, scale), scale, residual=residual)
+
+    def _fused(self, x, scale, residual):
+        """Training with the watermark LoRA on both linears: the whole feed-forward as one autograd node (ops.FeedForwardFn)."""
+        p0, p2 = self.net[0].proj, self.net[2]
+        if (not torch.is_grad_enabled() or not torch.is_tensor(scale) or p0.lora_layer is None or p2.lora_layer is None
+                or x.dim() != 3 or x.dtype != torch.bfloat16 or ops.REF_ROUNDING):
+            return None
+        from .lora import _scale16, _site_of
+        s0, s2 = _site_of(p0.lora_layer), _site_of(p2.lora_layer)
+        if s0.rank != s2.rank or scale.dim() != 2 or scale.shape[1] != s0.rank:
+            return None
+        B, N, C = x.shape
+        x2d = x.reshape(B * N, C)
+        if not x2d.is_contiguous():
+            return None
+        S = _scale16(scale, B, s0.rank, x2d.device)
+        S16 = getattr(S, "_aql_s16", None)
+        if S16 is None:
+            S16 = S.detach().to(torch.bfloat16).contiguous()
+            S._aql_s16 = S16
+        res2d = None if residual is None else residual.reshape(B * N, -1).contiguous()
+        y = ops.feed_forward(x2d, _packed_linear(p0), s0, _packed_linear(p2), s2, S, S16, N, res2d)
+        return y.view(B, N, -1)
 
 
 class BasicTransformerBlock(nn.Module):

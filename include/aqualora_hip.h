@@ -93,6 +93,13 @@ int aql_lora_gemm_fused_grouped(const bf16_t* X, long ldx, const bf16_t* W, long
                                 const int* col_start, const bf16_t* Adown, const bf16_t* S, int rows_per_sample,
                                 const bf16_t* Bup, const bf16_t* bias, bf16_t* Y, long ldy, bf16_t* T, bf16_t* Ts,
                                 long lora_row0, aql_stream_t stream);
+/* Backward-data of ff.net.2 (aql_lora_gemm_fused with X = dY, W = W2^T, Adown = Bup2^T, Bup = A2^T) fused with the backward
+ * of the GEGLU in front of it (original_unet.py:727-729): the epilogue turns d(value * gelu(gate)) [M,F] into d(pre-activation)
+ * DH [M,2F] using the saved pre-activation H [M,2F]; T, Ts receive dTs, dT.  Returns 100 like aql_lora_gemm_fused.        */
+int aql_lora_gemm_fused_geglu_bwd(const bf16_t* X, long ldx, const bf16_t* W, long ldw, long M, int F, int K,
+                                  const bf16_t* Adown, const bf16_t* S, int rows_per_sample, const bf16_t* Bup,
+                                  const bf16_t* H, long ldh, bf16_t* DH, long lddh, bf16_t* T, bf16_t* Ts,
+                                  aql_stream_t stream);
 /* n <= 32 rank-32 "down" products with a common row count in one launch: T[i] = X[i].A[i]^T, Ts[i] = T[i] * S[m / rps]
  * (X[i] [M,K[i]] dense, A[i] [32,K[i]]; X, A, K are HOST arrays; T, Ts [n][M][32]).  The backward of the grouped text-state
  * k|v projections: dTs = dY.Bup, dT = dTs * S (utils/lora_modules.py:13-17 transposed) for all 32 sites at once.        */

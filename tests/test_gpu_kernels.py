@@ -49,4 +49,4 @@ def test_geglu_epilogue_equals_two_kernel_path():
     """aql_gemm_bf16_geglu / aql_lora_gemm_fused_geglu: G and H bit-identical to GEMM + aql_geglu_fwd on the U-Net's ff.net.0
     shapes (rank 0 / 32 / 8, ragged M, tiny F), within 1.5e-2 of fp32 torch, and the same gradients through autograd."""
     text = _run("probe_geglu.py")
-    assert text.count("PASS") >= 23
+    assert text.count("PASS") >= 26   # incl. the GEGLU backward in the ff.net.2 backward-data epilogue (ops.FeedForwardFn)

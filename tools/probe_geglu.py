@@ -109,4 +109,50 @@ for M, F, K in [(16384, 1280, 320), (4096, 2560, 640), (1024, 5120, 1280), (256,
         case(M, F, K, rank)
 grad_case(2048, 1280, 320, 32)
 grad_case(512, 160, 64, 8)
+
+
+def ff_case(M, C, rank, nb=2):
+    """ops.FeedForwardFn: the GEGLU backward in the epilogue of the ff.net.2 backward-data launch == the stand-alone kernel"""
+    global ok_all
+    F = 4 * C
+    pk0 = ops.PackedLinear(torch.randn(2 * F, C, device=dev) * C ** -0.5, torch.randn(2 * F, device=dev) * 0.1)
+    pk2 = ops.PackedLinear(torch.randn(C, F, device=dev) * F ** -0.5, torch.randn(C, device=dev) * 0.1)
+    s0, s2 = Site(rank, C, 2 * F), Site(rank, F, C)
+    for st, K, N in ((s0, C, 2 * F), (s2, F, C)):
+        st.ga = torch.zeros(rank, K, device=dev)
+        st.gb = torch.zeros(N, rank, device=dev)
+    S = (1.0 + 0.3 * torch.randn(nb, rank, device=dev)).requires_grad_(True)
+    S16 = S.detach().to(torch.bfloat16)
+    x0, res, dy = rnd(M, C), rnd(M, C), rnd(M, C)
+    outs = []
+    for flag in ("1", "0"):
+        os.environ["AQL_GEGLU_BWD_FUSED"] = flag
+        for st in (s0, s2):
+            st.ga.zero_(); st.gb.zero_()
+        x = x0.clone().requires_grad_(True)
+        S.grad = None
+        y = ops.feed_forward(x, pk0, s0, pk2, s2, S, S16, M // nb, res)
+        y.backward(dy)
+        outs.append((y.detach().clone(), x.grad.clone(), S.grad.clone(), s0.ga.clone(), s0.gb.clone(), s2.ga.clone(), s2.gb.clone()))
+    os.environ["AQL_GEGLU_BWD_FUSED"] = "1"
+    eq = [torch.equal(a, b) for a, b in zip(outs[0][:2], outs[1][:2])]
+    rel = [((a - b).abs().max() / b.abs().max()).item() for a, b in zip(outs[0][2:], outs[1][2:])]
+    # fp32 reference of the whole feed-forward gradient w.r.t. x
+    xr = x0.float().requires_grad_(True)
+    rows = torch.arange(M, device=dev) // (M // nb)
+    def lin(xx, pk, st):
+        T = (xx @ st.a16.float().t())
+        return xx @ pk.w.float().t() + pk.bias.float() + (T * S16.float()[rows]) @ st.b16.float().t()
+    h = lin(xr, pk0, s0)
+    yr = lin(h[:, :F] * Fn.gelu(h[:, F:]), pk2, s2) + res.float()
+    yr.backward(dy.float())
+    e = ((outs[0][1].float() - xr.grad).abs().max() / xr.grad.abs().max()).item()
+    good = all(eq) and all(r <= 1e-4 for r in rel) and e < 3e-2
+    ok_all &= good
+    print(f"{'PASS' if good else 'FAIL'} feed-forward M={M} C={C} rank={rank}: y, dx equal bits {eq}; dS/dA/dB rel {max(rel):.1e}; dx vs fp32 {e:.2e}", flush=True)
+
+
+ff_case(4096, 320, 32)
+ff_case(1024, 640, 32)
+ff_case(512, 160, 8)
 print("ALL PASS" if ok_all else "SOME FAILED")
