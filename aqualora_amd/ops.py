@@ -823,7 +823,7 @@ class GroupedLoraFn(torch.autograd.Function):
     def backward(ctx, *dys):
         x2d, T, Ts, S16 = ctx.saved_tensors
         dx, dS_sum = None, None
-        if (not ctx.needs_input_grad[0] and not ctx.needs_input_grad[4] and ctx.ds_accum is not None and DEFERRED is not None
+        if (not ctx.needs_input_grad[0] and ctx.ds_accum is not None and DEFERRED is not None
                 and all(dy is not None for dy in dys) and os.environ.get("AQL_GROUPED", "1") != "0"):
             # input without gradient (the text states): only dTs / dT are needed (for dS, dA, dB) -- ONE grouped skinny launch
             # for all groups instead of one per group, everything else is bookkeeping for the deferred grouped launches
