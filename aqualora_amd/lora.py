@@ -176,9 +176,13 @@ def _scale16(scale, nb, r, device):
 def _run_linear(x2d, packed, lora_layer, scale, nb, rps, residual, geglu=False):
     site = S = S16 = None
     if lora_layer is not None and scale is not None:
-        if getattr(lora_layer, "network_alpha", None) is not None:
-            raise NotImplementedError("network_alpha is always None on the PPFT path (ppft_train.py:662-666)")
         site = _site_of(lora_layer)
+        alpha = getattr(lora_layer, "network_alpha", None)
+        if alpha is not None:
+            # `up_hidden_states *= network_alpha / rank` (lora_modules.py:21-22, 39-40) commutes with the diagonal scale: fold
+            # it into S (autograd carries the factor back to dS).  Always None on the PPFT path (ppft_train.py:662-666).
+            k = float(alpha) / site.rank
+            scale = scale * k if torch.is_tensor(scale) else float(scale) * k
         S = _scale16(scale, nb, site.rank, x2d.device)
         S16 = getattr(S, "_aql_s16", None)  # bf16 copy made once per scale tensor, shared by all 192 sites
         if S16 is None:

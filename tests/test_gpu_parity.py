@@ -57,6 +57,9 @@ def test_lora_forwards_vs_reference_golden(golden):
         assert relerr(ll.up.weight.grad, g[f"{tag}.dup"]) < 2e-2
         assert relerr(AL.CustomLoRACompatibleLinearforward(host, x.detach(), 0.5), g[f"{tag}.y_float_scale"]) < 1.5e-2
         assert relerr(AL.CustomLoRALinearLayerforward(ll, x.detach(), S.detach()), g[f"{tag}.lora_only"]) < 2e-2
+        ll.network_alpha = r / 4.0      # `up_hidden_states *= network_alpha / rank` (lora_modules.py:21-22): a quarter of the branch
+        assert relerr(AL.CustomLoRALinearLayerforward(ll, x.detach(), S.detach()), 0.25 * g[f"{tag}.lora_only"]) < 2e-2
+        ll.network_alpha = None
         if f"{tag}.conv_y" in g:
             hc = AL.LoRACompatibleConv(cin, cout, 1, device=DEV, dtype=torch.bfloat16)
             lc = AL.LoRAConv2dLayer(cin, cout, r).to(DEV)
