@@ -58,6 +58,7 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf
 // (scripts/lib/original_unet.py:721-729, F.gelu exact form) is VALU-bound inside a GEMM epilogue, where nothing overlaps it.
 // Used by the fused epilogue AND the stand-alone geglu kernels, so the two paths stay bit-identical to each other.
 __device__ __forceinline__ float aql_erf(float x) {
+#pragma clang fp contract(off)   // every fused multiply-add below is an explicit fmaf: the same bits in every kernel that inlines this
   const float ax = fabsf(x);
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
   float p = fmaf(t, 1.061405429f, -1.453152027f);
@@ -67,7 +68,20 @@ __device__ __forceinline__ float aql_erf(float x) {
   const float e = __expf(-ax * ax);
   return copysignf(fmaf(-p * t, e, 1.f), x);
 }
-__device__ __forceinline__ float aql_gelu(float g) { return 0.5f * g * (1.f + aql_erf(g * 0.70710678118654752f)); }
+__device__ __forceinline__ float aql_gelu(float g) {
+#pragma clang fp contract(off)
+  return 0.5f * g * (1.f + aql_erf(g * 0.70710678118654752f));
+}
+// d(value * gelu(gate)) -> d(value), d(gate) (h = value, g = gate).  Shared by aql_geglu_bwd and the GEGLU-backward GEMM
+// epilogue, which must agree bit for bit: with -ffp-contract=fast the compiler's choice of which a*b+c to fuse depended on the
+// code around the inlined body (one element of a 4096x2560 tile rounded differently after an unrelated epilogue change).
+__device__ __forceinline__ void aql_geglu_bwd1(float d, float h, float g, float& dh, float& dg) {
+#pragma clang fp contract(off)
+  const float cdf = 0.5f * (1.f + aql_erf(g * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * g * g);
+  dh = d * g * cdf;
+  dg = d * h * fmaf(g, pdf, cdf);
+}
 
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }

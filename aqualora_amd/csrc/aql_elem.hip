@@ -53,10 +53,7 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict
     unpack8(*reinterpret_cast<const uint4*>(dy + m * F + c), d);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float cdf = 0.5f * (1.f + aql_erf(g[j] * 0.70710678118654752f));
-      const float pdf = 0.3989422804014327f * __expf(-0.5f * g[j] * g[j]);
-      dh[j] = d[j] * g[j] * cdf;
-      dg[j] = d[j] * h[j] * (cdf + g[j] * pdf);
+      aql_geglu_bwd1(d[j], h[j], g[j], dh[j], dg[j]);
     }
     *reinterpret_cast<uint4*>(din + m * 2 * F + c) = pack8(dh);
     *reinterpret_cast<uint4*>(din + m * 2 * F + F + c) = pack8(dg);

@@ -635,10 +635,7 @@ __device__ __forceinline__ void geglu_bwd8(const uint4& d, const uint4& hv, cons
     for (int q = 0; q < 2; ++q) {
       const float dd = q ? bf16hi(dw[e]) : bf16lo(dw[e]), h = q ? bf16hi(vw[e]) : bf16lo(vw[e]);
       const float gt = q ? bf16hi(gw[e]) : bf16lo(gw[e]);
-      const float cdf = 0.5f * (1.f + aql_erf(gt * 0.70710678118654752f));
-      const float pdf = 0.3989422804014327f * __expf(-0.5f * gt * gt);
-      rv[q] = dd * gt * cdf;
-      rg[q] = dd * h * (cdf + gt * pdf);
+      aql_geglu_bwd1(dd, h, gt, rv[q], rg[q]);
     }
     ov[e] = pack_bf16x2(rv[0], rv[1]);
     og[e] = pack_bf16x2(rg[0], rg[1]);
@@ -669,6 +666,143 @@ __device__ __forceinline__ void geglu_store(const char* lds, int m0, int n0, int
     o.z = pack_bf16x2(bf16lo(v.z) * gelu_erf(bf16lo(gt.z)), bf16hi(v.z) * gelu_erf(bf16hi(gt.z)));
     o.w = pack_bf16x2(bf16lo(v.w) * gelu_erf(bf16lo(gt.w)), bf16hi(v.w) * gelu_erf(bf16hi(gt.w)));
     *reinterpret_cast<uint4*>(ep.G + (long)m * ep.ldg + n) = o;
+  }
+}
+
+// ---- epilogue helpers shared by gemm_body_d / gemm_body_w / the one-launch LoRA kernels ----------------------------------
+// A global load behind a per-lane branch cannot be hoisted past the branch, so the old epilogue -- `if (bias && col < N) load`
+// inside the FM x FN fragment loop, `if (residual) load` inside the store loop -- ran every one of those loads as its own
+// L2 round trip (load, s_waitcnt vmcnt(0), use): 20 + 10 dependent round trips per workgroup, ~10k + ~4k cycles of a 33k-cycle
+// workgroup life on the short-K LoRA shapes (tools/trace_lora.py, MI355X).  Now the bias values of a lane's FN column groups
+// are fetched BEFORE the K loop (unconditional loads: clamped address, AND-mask), and the store loop issues the residual /
+// row-bias / row-scale / saved-activation loads of U items back to back before it touches any of them.
+__device__ __forceinline__ uint2 epi_mask2(const uint2& v, bool ok) {
+  const uint32_t m = 0u - (uint32_t)ok;
+  return make_uint2(v.x & m, v.y & m);
+}
+__device__ __forceinline__ uint4 epi_mask4(const uint4& v, bool ok) {
+  const uint32_t m = 0u - (uint32_t)ok;
+  return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
+}
+__device__ __forceinline__ uint4 epi_add8(const uint4& a, const uint4& b) {
+  return make_uint4(pack_bf16x2(bf16lo(a.x) + bf16lo(b.x), bf16hi(a.x) + bf16hi(b.x)),
+                    pack_bf16x2(bf16lo(a.y) + bf16lo(b.y), bf16hi(a.y) + bf16hi(b.y)),
+                    pack_bf16x2(bf16lo(a.z) + bf16lo(b.z), bf16hi(a.z) + bf16hi(b.z)),
+                    pack_bf16x2(bf16lo(a.w) + bf16lo(b.w), bf16hi(a.w) + bf16hi(b.w)));
+}
+__device__ __forceinline__ uint4 epi_mul8(const uint4& a, const uint4& b) {
+  return make_uint4(pack_bf16x2(bf16lo(a.x) * bf16lo(b.x), bf16hi(a.x) * bf16hi(b.x)),
+                    pack_bf16x2(bf16lo(a.y) * bf16lo(b.y), bf16hi(a.y) * bf16hi(b.y)),
+                    pack_bf16x2(bf16lo(a.z) * bf16lo(b.z), bf16hi(a.z) * bf16hi(b.z)),
+                    pack_bf16x2(bf16lo(a.w) * bf16lo(b.w), bf16hi(a.w) * bf16hi(b.w)));
+}
+
+// b[j] = bias[column group j of this lane] (4 bf16), zero when there is no bias or the group lies past N.  `safe` is any
+// readable address (the weight panel): lanes without a value read it instead of branching.
+template <int FN>
+__device__ __forceinline__ void epi_load_bias(uint2 (&b)[FN], const bf16_t* bias, const void* safe, int n0, int wn0, int lane,
+                                              int N, int gF, int half) {
+  const bool has = bias != nullptr;
+  const bf16_t* p = has ? bias : reinterpret_cast<const bf16_t*>(safe);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int col = wn0 + j * 16 + (lane >> 4) * 4;
+    const int bc = epi_bias_col(n0, col, gF, half);
+    const bool ok = has & (bc < N);
+    const uint2 v = *reinterpret_cast<const uint2*>(p + (ok ? bc : 0));
+    b[j] = epi_mask2(v, ok);
+  }
+}
+
+// The bf16 C tile [BM][BN] staged in LDS -> global, with the optional per-sample row bias, residual, second (row-scaled) output
+// and the GEGLU-backward form (tile = d(value * gelu(gate)); writes d(value), d(gate) from the saved pre-activation).
+template <int BM, int BN, int C_PITCH, int NT>
+__device__ __forceinline__ void epi_store_tile(const char* lds, int m0, int n0, int M, int N, const EpiParams& ep, int tid) {
+  constexpr int CPR = BN / 8, TOTAL = BM * CPR, NIT = (TOTAL + NT - 1) / NT;
+  const bool has_rb = ep.rowbias != nullptr, has_res = ep.residual != nullptr, has_c2 = ep.C2 != nullptr, has_gb = ep.gb_F != 0;
+  if (!(has_rb | has_res | has_c2 | has_gb)) {   // nothing to fetch: LDS -> global
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int id = tid + it * NT;
+      const int row = id / CPR, cc = id - row * CPR;
+      const int m = m0 + row, n = n0 + cc * 8;
+      if (id < TOTAL && m < M && n < N && ep.C != nullptr)
+        *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + n) = *reinterpret_cast<const uint4*>(lds + row * C_PITCH + cc * 16);
+    }
+    return;
+  }
+  // feature flags are workgroup-uniform: each batch of loads sits behind a scalar branch and is consumed behind the same one.
+  // Two exclusive forms (GEGLU-backward / everything else) so that at most three 16-byte values per item are live: the batch
+  // must fit beside the 4-wave kernels' AGPR accumulators at two workgroups per CU (<= 160 VGPRs).
+  constexpr int U = NIT < 4 ? NIT : 4;   // items in flight per batch
+#pragma unroll
+  for (int it0 = 0; it0 < NIT; it0 += U) {
+    bool ok[U];
+    long om[U];
+    int nn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int id = tid + (it0 + u) * NT;
+      const int row = id / CPR, cc = id - row * CPR;
+      const int m = m0 + row, n = n0 + cc * 8;
+      ok[u] = (it0 + u < NIT) & (id < TOTAL) & (m < M) & (n < N);
+      om[u] = ok[u] ? m : 0;   // lanes without an item read element 0 of the operand instead of branching
+      nn[u] = ok[u] ? n : 0;
+    }
+    if (has_gb) {
+      uint4 rs[U], hv[U], hg[U];
+      if (has_res) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) rs[u] = *reinterpret_cast<const uint4*>(ep.residual + om[u] * ep.ldr + nn[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        hv[u] = *reinterpret_cast<const uint4*>(ep.gb_h + om[u] * ep.gb_ldh + nn[u]);
+        hg[u] = *reinterpret_cast<const uint4*>(ep.gb_h + om[u] * ep.gb_ldh + ep.gb_F + nn[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int id = tid + (it0 + u) * NT;
+        const int row = id / CPR, cc = id - row * CPR;
+        if (!ok[u]) continue;
+        uint4 v = *reinterpret_cast<const uint4*>(lds + row * C_PITCH + cc * 16);
+        if (has_res) v = epi_add8(v, rs[u]);
+        uint4 dv, dg;
+        geglu_bwd8(v, hv[u], hg[u], dv, dg);
+        *reinterpret_cast<uint4*>(ep.C + om[u] * ep.ldc + nn[u]) = dv;
+        *reinterpret_cast<uint4*>(ep.C + om[u] * ep.ldc + ep.gb_F + nn[u]) = dg;
+      }
+    } else {
+      uint4 rb[U], rs[U], sc[U];
+      int smp[U];
+      if (has_rb | has_c2) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) smp[u] = (int)((uint32_t)om[u] / (uint32_t)ep.rows_per_sample);   // M < 2^31: 32-bit division
+      }
+      if (has_rb) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) rb[u] = *reinterpret_cast<const uint4*>(ep.rowbias + (long)smp[u] * ep.rowbias_ld + nn[u]);
+      }
+      if (has_res) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) rs[u] = *reinterpret_cast<const uint4*>(ep.residual + om[u] * ep.ldr + nn[u]);
+      }
+      if (has_c2) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) sc[u] = *reinterpret_cast<const uint4*>(ep.rowscale + (long)smp[u] * N + nn[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int id = tid + (it0 + u) * NT;
+        const int row = id / CPR, cc = id - row * CPR;
+        if (!ok[u]) continue;
+        uint4 v = *reinterpret_cast<const uint4*>(lds + row * C_PITCH + cc * 16);
+        if (has_rb) v = epi_add8(v, rb[u]);
+        if (has_res) v = epi_add8(v, rs[u]);
+        if (ep.C != nullptr) *reinterpret_cast<uint4*>(ep.C + om[u] * ep.ldc + nn[u]) = v;
+        if (has_c2) *reinterpret_cast<uint4*>(ep.C2 + om[u] * ep.ldc2 + nn[u]) = epi_mul8(v, sc[u]);
+      }
+    }
   }
 }
 
@@ -715,6 +849,9 @@ __device__ __forceinline__ void gemm_body_d(const GemmArgs<LA, LB>& g, const int
   constexpr int NLD = BM / 32 + BN / 32;  // LDS-DMA instructions per thread per K tile
   sa.begin(g.a0, g.a1, dual, m0, tid, kt_begin, kt_end, g.ktiles0);
   sb.begin(g.b0, g.b1, dual, n0, tid, kt_begin, kt_end, g.ktiles0);
+
+  uint2 biasr[FN];  // fetched ahead of the ring fill (older than every DMA: the counted vmcnt waits below retire them first)
+  if constexpr (EPI == EPI_BF16) epi_load_bias<FN>(biasr, g.epi.bias, g.b0.base, n0, wn0, lane, g.N, gF, BN / 2);
 
   f32x4_t acc[FM][FN];
 #pragma unroll
@@ -793,52 +930,16 @@ __device__ __forceinline__ void gemm_body_d(const GemmArgs<LA, LB>& g, const int
       for (int j = 0; j < FN; ++j) {
         const int col = wn0 + j * 16 + (lane >> 4) * 4;
         float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-        const int bc = epi_bias_col(n0, col, gF, BN / 2);
-        if (ep.bias != nullptr && bc < g.N) {
-          const uint2 bb = *reinterpret_cast<const uint2*>(ep.bias + bc);
-          v0 += bf16lo(bb.x);
-          v1 += bf16hi(bb.x);
-          v2 += bf16lo(bb.y);
-          v3 += bf16hi(bb.y);
-        }
+        v0 += bf16lo(biasr[j].x);
+        v1 += bf16hi(biasr[j].x);
+        v2 += bf16lo(biasr[j].y);
+        v3 += bf16hi(biasr[j].y);
         *reinterpret_cast<uint2*>(lds + row * C_PITCH + col * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
       }
     }
     __syncthreads();
-    constexpr int CPR = BN / 8;  // 16-byte chunks per row
     if (gF) geglu_store<BM, BN, C_PITCH, NTHREADS>(lds, m0, n0, g.M, ep, tid);
-    else
-    for (int id = tid; id < BM * CPR; id += NTHREADS) {
-      const int row = id / CPR, cc = id - row * CPR;
-      const int m = m0 + row, n = n0 + cc * 8;
-      if (m >= g.M || n >= g.N) continue;
-      uint4 v = *reinterpret_cast<const uint4*>(lds + row * C_PITCH + cc * 16);
-      if (ep.rowbias != nullptr) {
-        const uint4 r = *reinterpret_cast<const uint4*>(ep.rowbias + (long)(m / ep.rows_per_sample) * ep.rowbias_ld + n);
-        v.x = pack_bf16x2(bf16lo(v.x) + bf16lo(r.x), bf16hi(v.x) + bf16hi(r.x));
-        v.y = pack_bf16x2(bf16lo(v.y) + bf16lo(r.y), bf16hi(v.y) + bf16hi(r.y));
-        v.z = pack_bf16x2(bf16lo(v.z) + bf16lo(r.z), bf16hi(v.z) + bf16hi(r.z));
-        v.w = pack_bf16x2(bf16lo(v.w) + bf16lo(r.w), bf16hi(v.w) + bf16hi(r.w));
-      }
-      if (ep.residual != nullptr) {
-        const uint4 r = *reinterpret_cast<const uint4*>(ep.residual + (long)m * ep.ldr + n);
-        v.x = pack_bf16x2(bf16lo(v.x) + bf16lo(r.x), bf16hi(v.x) + bf16hi(r.x));
-        v.y = pack_bf16x2(bf16lo(v.y) + bf16lo(r.y), bf16hi(v.y) + bf16hi(r.y));
-        v.z = pack_bf16x2(bf16lo(v.z) + bf16lo(r.z), bf16hi(v.z) + bf16hi(r.z));
-        v.w = pack_bf16x2(bf16lo(v.w) + bf16lo(r.w), bf16hi(v.w) + bf16hi(r.w));
-      }
-      if (ep.C != nullptr) *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + n) = v;
-      if (ep.C2 != nullptr) {
-        const uint4 s =
-            *reinterpret_cast<const uint4*>(ep.rowscale + (long)(m / ep.rows_per_sample) * g.N + n);
-        uint4 o;
-        o.x = pack_bf16x2(bf16lo(v.x) * bf16lo(s.x), bf16hi(v.x) * bf16hi(s.x));
-        o.y = pack_bf16x2(bf16lo(v.y) * bf16lo(s.y), bf16hi(v.y) * bf16hi(s.y));
-        o.z = pack_bf16x2(bf16lo(v.z) * bf16lo(s.z), bf16hi(v.z) * bf16hi(s.z));
-        o.w = pack_bf16x2(bf16lo(v.w) * bf16lo(s.w), bf16hi(v.w) * bf16hi(s.w));
-        *reinterpret_cast<uint4*>(ep.C2 + (long)m * ep.ldc2 + n) = o;
-      }
-    }
+    else epi_store_tile<BM, BN, C_PITCH, NTHREADS>(lds, m0, n0, g.M, g.N, ep, tid);
   } else {
     float* out = ep.Cf + (long)block_z * g.M * ep.ldcf;
 #pragma unroll
@@ -914,6 +1015,10 @@ __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int
   const bool dual = kt1 > 0;
 
   constexpr int NLD = BM / 32 + BN / 32;  // LDS-DMA instructions per loader thread per K tile
+  uint2 biasr[FN];  // compute wavefronts: this lane's bias values, fetched before the K loop (epi_load_bias)
+  if constexpr (EPI == EPI_BF16) {
+    if (!loader) epi_load_bias<FN>(biasr, g.epi.bias, g.b0.base, n0, wn0, lane, g.N, gF, BN / 2);
+  }
   f32x4_t acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -1037,53 +1142,17 @@ __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int
         for (int j = 0; j < FN; ++j) {
           const int col = wn0 + j * 16 + (lane >> 4) * 4;
           float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-          const int bc = epi_bias_col(n0, col, gF, BN / 2);
-          if (ep.bias != nullptr && bc < g.N) {
-            const uint2 bb = *reinterpret_cast<const uint2*>(ep.bias + bc);
-            v0 += bf16lo(bb.x);
-            v1 += bf16hi(bb.x);
-            v2 += bf16lo(bb.y);
-            v3 += bf16hi(bb.y);
-          }
+          v0 += bf16lo(biasr[j].x);
+          v1 += bf16hi(biasr[j].x);
+          v2 += bf16lo(biasr[j].y);
+          v3 += bf16hi(biasr[j].y);
           *reinterpret_cast<uint2*>(lds + row * C_PITCH + col * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
         }
       }
     }
     __syncthreads();
-    constexpr int CPR = BN / 8;  // 16-byte chunks per row
     if (gF) geglu_store<BM, BN, C_PITCH, 2 * NTHREADS>(lds, m0, n0, g.M, ep, tid);
-    else
-    for (int id = tid; id < BM * CPR; id += 2 * NTHREADS) {
-      const int row = id / CPR, cc = id - row * CPR;
-      const int m = m0 + row, n = n0 + cc * 8;
-      if (m >= g.M || n >= g.N) continue;
-      uint4 v = *reinterpret_cast<const uint4*>(lds + row * C_PITCH + cc * 16);
-      if (ep.rowbias != nullptr) {
-        const uint4 r = *reinterpret_cast<const uint4*>(ep.rowbias + (long)(m / ep.rows_per_sample) * ep.rowbias_ld + n);
-        v.x = pack_bf16x2(bf16lo(v.x) + bf16lo(r.x), bf16hi(v.x) + bf16hi(r.x));
-        v.y = pack_bf16x2(bf16lo(v.y) + bf16lo(r.y), bf16hi(v.y) + bf16hi(r.y));
-        v.z = pack_bf16x2(bf16lo(v.z) + bf16lo(r.z), bf16hi(v.z) + bf16hi(r.z));
-        v.w = pack_bf16x2(bf16lo(v.w) + bf16lo(r.w), bf16hi(v.w) + bf16hi(r.w));
-      }
-      if (ep.residual != nullptr) {
-        const uint4 r = *reinterpret_cast<const uint4*>(ep.residual + (long)m * ep.ldr + n);
-        v.x = pack_bf16x2(bf16lo(v.x) + bf16lo(r.x), bf16hi(v.x) + bf16hi(r.x));
-        v.y = pack_bf16x2(bf16lo(v.y) + bf16lo(r.y), bf16hi(v.y) + bf16hi(r.y));
-        v.z = pack_bf16x2(bf16lo(v.z) + bf16lo(r.z), bf16hi(v.z) + bf16hi(r.z));
-        v.w = pack_bf16x2(bf16lo(v.w) + bf16lo(r.w), bf16hi(v.w) + bf16hi(r.w));
-      }
-      if (ep.C != nullptr) *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + n) = v;
-      if (ep.C2 != nullptr) {
-        const uint4 s =
-            *reinterpret_cast<const uint4*>(ep.rowscale + (long)(m / ep.rows_per_sample) * g.N + n);
-        uint4 o;
-        o.x = pack_bf16x2(bf16lo(v.x) * bf16lo(s.x), bf16hi(v.x) * bf16hi(s.x));
-        o.y = pack_bf16x2(bf16lo(v.y) * bf16lo(s.y), bf16hi(v.y) * bf16hi(s.y));
-        o.z = pack_bf16x2(bf16lo(v.z) * bf16lo(s.z), bf16hi(v.z) * bf16hi(s.z));
-        o.w = pack_bf16x2(bf16lo(v.w) * bf16lo(s.w), bf16hi(v.w) * bf16hi(s.w));
-        *reinterpret_cast<uint4*>(ep.C2 + (long)m * ep.ldc2 + n) = o;
-      }
-    }
+    else epi_store_tile<BM, BN, C_PITCH, 2 * NTHREADS>(lds, m0, n0, g.M, g.N, ep, tid);
   } else if (!loader) {
     float* out = ep.Cf + (long)block_z * g.M * ep.ldcf;
 #pragma unroll

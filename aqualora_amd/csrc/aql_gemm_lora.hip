@@ -30,6 +30,14 @@ namespace {
 
 constexpr int LR = 32;  // LoRA rank handled here
 
+// -DAQL_TRACE_L: per-workgroup phase timestamps of the 4-wave kernel (tools/trace_lora.py); the buffer address comes from
+// the environment (AQL_TRACE_BUF) and travels in EpiParams::Cf, which the bf16 epilogue does not use
+#ifdef AQL_TRACE_L
+#define LTRACE(slot) do { if (ltr) ltr[slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LTRACE(slot) do { } while (0)
+#endif
+
 constexpr int MAXG = 32;  // LoRA linears per grouped launch
 
 struct LoraParams {
@@ -70,6 +78,14 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
   const int block_x = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef AQL_TRACE_L
+  long long* ltr = (g.epi.Cf != nullptr && tid == 0) ? reinterpret_cast<long long*>(g.epi.Cf) + (long)bid * 16 : nullptr;
+  LTRACE(0);
+  if (ltr) {
+    ltr[8] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_ID
+    ltr[9] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // XCC_ID
+  }
+#endif
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
   const int wt0 = (wave % WAVES_N) * FT;  // first T fragment of this wavefront
   const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
@@ -102,6 +118,7 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
   sa.begin(g.a0, g.a0, false, m0, tid, 0, kt_end, kt_end);
   sb.begin(g.b0, g.b0, false, n0, tid, 0, kt_end, kt_end);
   sl.begin(lag, lag, false, 0, tid, 0, kt_end, kt_end);
+  LTRACE(10);
 
   f32x4_t acc[FM][FN], tacc[FM][FT];
 #pragma unroll
@@ -112,6 +129,8 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
     for (int t = 0; t < FT; ++t) tacc[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
 
+  uint2 biasr[FN];  // this lane's bias values, fetched before the K loop (epi_load_bias, aql_gemm.cuh)
+  epi_load_bias<FN>(biasr, g.epi.bias, g.b0.base, n0, wn0, lane, g.N, gF, BN / 2);
   // the up-projection panel Bup[n-tile, 32] and this lane's scale rows are fetched now, so that their latency hides under
   // the K loop instead of sitting between the loop and the final k-step
   constexpr int NBP = (BN * 4 + NTHREADS - 1) / NTHREADS;
@@ -120,8 +139,8 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
   for (int u = 0; u < NBP; ++u) {
     const int id = tid + u * NTHREADS, row = id >> 2, c = id & 3;
     const int brow = epi_bias_col(n0, row, gF, BN / 2);
-    bup[u] = zero4();
-    if (id < BN * 4 && brow < g.N && lora_on) bup[u] = *reinterpret_cast<const uint4*>(lp.Bup + (long)brow * LR + c * 8);
+    const bool ok = (id < BN * 4) & (brow < g.N) & lora_on;   // unconditional load, clamped address, AND-mask (see epi_load_bias)
+    bup[u] = epi_mask4(*reinterpret_cast<const uint4*>(lp.Bup + (ok ? (long)brow * LR + c * 8 : 0)), ok);
   }
   uint2 srow[FM][FT];
 #pragma unroll
@@ -129,8 +148,8 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
     const long m = (long)m0 + wm0 + i * 16 + (lane & 15);
 #pragma unroll
     for (int t = 0; t < FT; ++t) {
-      srow[i][t] = make_uint2(0u, 0u);
-      if (m < g.M && lora_on) srow[i][t] = *reinterpret_cast<const uint2*>(lp.S + (m / lp.rps) * LR + (wt0 + t) * 16 + (lane >> 4) * 4);
+      const bool ok = (m < g.M) & lora_on;
+      srow[i][t] = epi_mask2(*reinterpret_cast<const uint2*>(lp.S + (ok ? (long)((uint32_t)m / (uint32_t)lp.rps) * LR + (wt0 + t) * 16 + (lane >> 4) * 4 : 0)), ok);
     }
   }
 
@@ -140,8 +159,10 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
     sb.dma(sA + A_BYTES, wave);
     sl.dma(sA + A_BYTES + B_BYTES, wave);
   };
+  LTRACE(11);
 #pragma unroll
   for (int u = 0; u < NSTG - 1; ++u) issue(u);
+  LTRACE(1);
 
   // Two copies of the K loop, selected once per workgroup: with and without the T side product.  (A uniform branch around
   // the T MFMAs INSIDE the k-step measured 19.5 -> 28.9 us on 32768x320x320: it cuts the compiler's ds_read / MFMA
@@ -153,6 +174,9 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * NLD) : "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+#ifdef AQL_TRACE_L
+      if (kt == 0) LTRACE(2);
+#endif
       issue(wr);
       const char* sA = lds + rd * STAGE;
       const char* sB = sA + A_BYTES;
@@ -188,6 +212,7 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
   };
   if (lora_on) mainloop(std::true_type{});
   else mainloop(std::false_type{});
+  LTRACE(3);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing zero-fill DMAs still write LDS
   __syncthreads();
   if (lora_on) {
@@ -237,6 +262,7 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
   }
   __syncthreads();
   }  // lora_on
+  LTRACE(4);
 
   // ---- epilogue (as gemm_body_d, EPI_BF16): bias in fp32, C tile staged through LDS, residual added in bf16
   const EpiParams& ep = g.epi;
@@ -247,44 +273,22 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
     for (int j = 0; j < FN; ++j) {
       const int col = wn0 + j * 16 + (lane >> 4) * 4;
       float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-      const int bc = epi_bias_col(n0, col, gF, BN / 2);
-      if (ep.bias != nullptr && bc < g.N) {
-        const uint2 bb = *reinterpret_cast<const uint2*>(ep.bias + bc);
-        v0 += bf16lo(bb.x);
-        v1 += bf16hi(bb.x);
-        v2 += bf16lo(bb.y);
-        v3 += bf16hi(bb.y);
-      }
+      v0 += bf16lo(biasr[j].x);
+      v1 += bf16hi(biasr[j].x);
+      v2 += bf16lo(biasr[j].y);
+      v3 += bf16hi(biasr[j].y);
       *reinterpret_cast<uint2*>(lds + row * C_PITCH + col * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
     }
   }
   __syncthreads();
-  constexpr int CPR = BN / 8;
+  LTRACE(5);
   if (gF) geglu_store<BM, BN, C_PITCH, NTHREADS>(lds, m0, n0, g.M, ep, tid);
-  else
-  for (int id = tid; id < BM * CPR; id += NTHREADS) {
-    const int row = id / CPR, cc = id - row * CPR;
-    const int m = m0 + row, n = n0 + cc * 8;
-    if (m >= g.M || n >= g.N) continue;
-    uint4 v = *reinterpret_cast<const uint4*>(lds + row * C_PITCH + cc * 16);
-    if (ep.residual != nullptr) {
-      const uint4 r = *reinterpret_cast<const uint4*>(ep.residual + (long)m * ep.ldr + n);
-      v.x = pack_bf16x2(bf16lo(v.x) + bf16lo(r.x), bf16hi(v.x) + bf16hi(r.x));
-      v.y = pack_bf16x2(bf16lo(v.y) + bf16lo(r.y), bf16hi(v.y) + bf16hi(r.y));
-      v.z = pack_bf16x2(bf16lo(v.z) + bf16lo(r.z), bf16hi(v.z) + bf16hi(r.z));
-      v.w = pack_bf16x2(bf16lo(v.w) + bf16lo(r.w), bf16hi(v.w) + bf16hi(r.w));
-    }
-    if (ep.gb_F) {   // the tile is d(value * gelu(gate)): write d(value), d(gate) from the saved pre-activation
-      const uint4 hv = *reinterpret_cast<const uint4*>(ep.gb_h + (long)m * ep.gb_ldh + n);
-      const uint4 hg = *reinterpret_cast<const uint4*>(ep.gb_h + (long)m * ep.gb_ldh + ep.gb_F + n);
-      uint4 dv, dg;
-      geglu_bwd8(v, hv, hg, dv, dg);
-      *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + n) = dv;
-      *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + ep.gb_F + n) = dg;
-      continue;
-    }
-    *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + n) = v;
-  }
+  else epi_store_tile<BM, BN, C_PITCH, NTHREADS>(lds, m0, n0, g.M, g.N, ep, tid);
+#ifdef AQL_TRACE_L
+  LTRACE(6);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  LTRACE(7);
+#endif
 }
 
 // Wave-specialised form (as gemm_kernel_w in aql_gemm.cuh): 512 threads, wavefronts 4-7 only issue the LDS-DMA loads
@@ -352,14 +356,15 @@ __global__ __launch_bounds__(2 * NTHREADS) void lora_gemm_kernel_w(const GemmArg
   constexpr int NBP = (BN * 4 + NTHREADS - 1) / NTHREADS;
   uint4 bup[NBP];          // loader wavefronts: the Bup panel, fetched before the K loop
   uint2 srow[FM][FT];      // compute wavefronts: this lane's scale rows
+  uint2 biasr[FN];         // compute wavefronts: this lane's bias values (epi_load_bias, aql_gemm.cuh)
 
   if (loader) {
 #pragma unroll
     for (int u = 0; u < NBP; ++u) {
       const int id = ltid + u * NTHREADS, row = id >> 2, c = id & 3;
       const int brow = epi_bias_col(n0, row, gF, BN / 2);
-      bup[u] = zero4();
-      if (id < BN * 4 && brow < g.N && lora_on) bup[u] = *reinterpret_cast<const uint4*>(lp.Bup + (long)brow * LR + c * 8);
+      const bool ok = (id < BN * 4) & (brow < g.N) & lora_on;   // unconditional load, clamped address, AND-mask
+      bup[u] = epi_mask4(*reinterpret_cast<const uint4*>(lp.Bup + (ok ? (long)brow * LR + c * 8 : 0)), ok);
     }
     DmaStager<BM, PlainLoader> sa;
     DmaStager<BN, PlainLoader> sb;
@@ -386,13 +391,14 @@ __global__ __launch_bounds__(2 * NTHREADS) void lora_gemm_kernel_w(const GemmArg
       wr = (wr + 1 == NSTG) ? 0 : wr + 1;
     }
   } else {
+    epi_load_bias<FN>(biasr, g.epi.bias, g.b0.base, n0, wn0, lane, g.N, gF, BN / 2);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const long m = (long)m0 + wm0 + i * 16 + (lane & 15);
 #pragma unroll
       for (int t = 0; t < FT; ++t) {
-        srow[i][t] = make_uint2(0u, 0u);
-        if (m < g.M && lora_on) srow[i][t] = *reinterpret_cast<const uint2*>(lp.S + (m / lp.rps) * LR + (wt0 + t) * 16 + (lane >> 4) * 4);
+        const bool ok = (m < g.M) & lora_on;
+        srow[i][t] = epi_mask2(*reinterpret_cast<const uint2*>(lp.S + (ok ? (long)((uint32_t)m / (uint32_t)lp.rps) * LR + (wt0 + t) * 16 + (lane >> 4) * 4 : 0)), ok);
       }
     }
     const int arow = wm0 + (lane & 15), brow = wn0 + (lane & 15), lrow = wt0 * 16 + (lane & 15);
@@ -517,45 +523,17 @@ __global__ __launch_bounds__(2 * NTHREADS) void lora_gemm_kernel_w(const GemmArg
       for (int j = 0; j < FN; ++j) {
         const int col = wn0 + j * 16 + (lane >> 4) * 4;
         float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-        const int bc = epi_bias_col(n0, col, gF, BN / 2);
-        if (ep.bias != nullptr && bc < g.N) {
-          const uint2 bb = *reinterpret_cast<const uint2*>(ep.bias + bc);
-          v0 += bf16lo(bb.x);
-          v1 += bf16hi(bb.x);
-          v2 += bf16lo(bb.y);
-          v3 += bf16hi(bb.y);
-        }
+        v0 += bf16lo(biasr[j].x);
+        v1 += bf16hi(biasr[j].x);
+        v2 += bf16lo(biasr[j].y);
+        v3 += bf16hi(biasr[j].y);
         *reinterpret_cast<uint2*>(lds + row * C_PITCH + col * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
       }
     }
   }
   __syncthreads();
-  constexpr int CPR = BN / 8;
   if (gF) geglu_store<BM, BN, C_PITCH, 2 * NTHREADS>(lds, m0, n0, g.M, ep, tid);
-  else
-  for (int id = tid; id < BM * CPR; id += 2 * NTHREADS) {
-    const int row = id / CPR, cc = id - row * CPR;
-    const int m = m0 + row, n = n0 + cc * 8;
-    if (m >= g.M || n >= g.N) continue;
-    uint4 v = *reinterpret_cast<const uint4*>(lds + row * C_PITCH + cc * 16);
-    if (ep.residual != nullptr) {
-      const uint4 r = *reinterpret_cast<const uint4*>(ep.residual + (long)m * ep.ldr + n);
-      v.x = pack_bf16x2(bf16lo(v.x) + bf16lo(r.x), bf16hi(v.x) + bf16hi(r.x));
-      v.y = pack_bf16x2(bf16lo(v.y) + bf16lo(r.y), bf16hi(v.y) + bf16hi(r.y));
-      v.z = pack_bf16x2(bf16lo(v.z) + bf16lo(r.z), bf16hi(v.z) + bf16hi(r.z));
-      v.w = pack_bf16x2(bf16lo(v.w) + bf16lo(r.w), bf16hi(v.w) + bf16hi(r.w));
-    }
-    if (ep.gb_F) {   // the tile is d(value * gelu(gate)): write d(value), d(gate) from the saved pre-activation
-      const uint4 hv = *reinterpret_cast<const uint4*>(ep.gb_h + (long)m * ep.gb_ldh + n);
-      const uint4 hg = *reinterpret_cast<const uint4*>(ep.gb_h + (long)m * ep.gb_ldh + ep.gb_F + n);
-      uint4 dv, dg;
-      geglu_bwd8(v, hv, hg, dv, dg);
-      *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + n) = dv;
-      *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + ep.gb_F + n) = dg;
-      continue;
-    }
-    *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + n) = v;
-  }
+  else epi_store_tile<BM, BN, C_PITCH, 2 * NTHREADS>(lds, m0, n0, g.M, g.N, ep, tid);
 }
 
 template <int BM, int BN, int WM, int WN, int NSTG>
@@ -624,6 +602,9 @@ static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long
   g.epi.ldg = ldg;
   g.epi.geglu_F = geglu_F;
   if (gb_h != nullptr) g.epi.gb_h = gb_h, g.epi.gb_ldh = gb_ldh, g.epi.gb_F = N;
+#ifdef AQL_TRACE_L
+  if (const char* tb = getenv("AQL_TRACE_BUF")) g.epi.Cf = reinterpret_cast<float*>(strtoull(tb, nullptr, 0));
+#endif
   const PlainLoader la = plain(Adown, K, LR, K);
   LoraParams lp{};
   lp.S = S, lp.Bup = Bup, lp.T = T, lp.Ts = Ts, lp.rps = rows_per_sample;
