@@ -970,12 +970,15 @@ inline void launch_gemm_d(const GemmArgs<LA, LB>& g, hipStream_t stream) {
   hipLaunchKernelGGL((gemm_kernel_d<BM, BN, WM, WN, LA, LB, EPI, NSTG, ABL>), grid, dim3(NTHREADS), 0, stream, g);
 }
 
-template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG>
+// NCW = compute wavefronts: 4 (8-wave workgroup) or 8 (12-wave workgroup, 256x160 tile: two compute wavefronts per SIMD keep the
+// matrix pipe fed across each other's fragment-read latency, and a weight tile is shared by twice the rows).
+template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG, int NCW = 4>
 __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int block_x, const int block_z) {
   static_assert(EPI != EPI_ATOMIC && !LA::kTrans, "bf16 / slab epilogues only");
   constexpr int FM = WM / 16, FN = WN / 16;
   constexpr int WAVES_N = BN / WN;
-  static_assert((BM / WM) * (BN / WN) == 4, "4 compute wavefronts (+ 4 loader wavefronts) per workgroup");
+  constexpr int NT = (NCW + 4) * 64;   // threads per workgroup
+  static_assert((BM / WM) * (BN / WN) == NCW && (NCW == 4 || NCW == 8), "NCW compute wavefronts (+ 4 loader wavefronts) per workgroup");
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int C_PITCH = (BN + 8) * 2;  // bytes per row of the bf16 C tile staged in LDS
@@ -989,10 +992,10 @@ __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the role branch below is a uniform branch
-  const bool loader = wave >= 4;
-  const int ltid = tid & 255;                                   // loader waves: the 256-thread staging layout
-  const int wm0 = ((wave & 3) / WAVES_N) * WM;
-  const int wn0 = ((wave & 3) % WAVES_N) * WN;
+  const bool loader = wave >= NCW;
+  const int ltid = tid - NCW * 64;                              // loader waves: the 256-thread staging layout
+  const int wm0 = ((wave % NCW) / WAVES_N) * WM;
+  const int wn0 = ((wave % NCW) % WAVES_N) * WN;
 
   const int tiles_n = (g.N + BN - 1) / BN;
   const int tiles_m = (g.M + BM - 1) / BM;
@@ -1044,8 +1047,8 @@ __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int
     sb.begin(g.b0, g.b1, dual, n0, ltid, kt_begin, kt_end, g.ktiles0);
     auto issue = [&](int stage) {  // stages the NEXT tile of the K range (tiles are requested in order)
       char* sA = lds + stage * STAGE;
-      sa.dma(sA, wave - 4);
-      sb.dma(sA + A_BYTES, wave - 4);
+      sa.dma(sA, wave - NCW);
+      sb.dma(sA + A_BYTES, wave - NCW);
     };
 #pragma unroll
     for (int u = 0; u < NSTG - 1; ++u) issue(u);
@@ -1151,8 +1154,8 @@ __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int
       }
     }
     __syncthreads();
-    if (gF) geglu_store<BM, BN, C_PITCH, 2 * NTHREADS>(lds, m0, n0, g.M, ep, tid);
-    else epi_store_tile<BM, BN, C_PITCH, 2 * NTHREADS>(lds, m0, n0, g.M, g.N, ep, tid);
+    if (gF) geglu_store<BM, BN, C_PITCH, NT>(lds, m0, n0, g.M, ep, tid);
+    else epi_store_tile<BM, BN, C_PITCH, NT>(lds, m0, n0, g.M, g.N, ep, tid);
   } else if (!loader) {
     float* out = ep.Cf + (long)block_z * g.M * ep.ldcf;
 #pragma unroll
@@ -1169,18 +1172,18 @@ __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int
   }
 }
 
-template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG>
-__global__ __launch_bounds__(2 * NTHREADS) void gemm_kernel_w(const GemmArgs<LA, LB> g) {
+template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG, int NCW = 4>
+__global__ __launch_bounds__((NCW + 4) * 64) void gemm_kernel_w(const GemmArgs<LA, LB> g) {
   const int nblk = gridDim.x, bid = blockIdx.x;
   const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
   const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  gemm_body_w<BM, BN, WM, WN, LA, LB, EPI, NSTG>(g, logical, blockIdx.z);
+  gemm_body_w<BM, BN, WM, WN, LA, LB, EPI, NSTG, NCW>(g, logical, blockIdx.z);
 }
 
-template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG>
+template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG, int NCW = 4>
 inline void launch_gemm_w(const GemmArgs<LA, LB>& g, hipStream_t stream) {
   dim3 grid(aql_cdiv(g.M, BM) * aql_cdiv(g.N, BN), 1, g.splits);
-  hipLaunchKernelGGL((gemm_kernel_w<BM, BN, WM, WN, LA, LB, EPI, NSTG>), grid, dim3(2 * NTHREADS), 0, stream, g);
+  hipLaunchKernelGGL((gemm_kernel_w<BM, BN, WM, WN, LA, LB, EPI, NSTG, NCW>), grid, dim3((NCW + 4) * 64), 0, stream, g);
 }
 
 template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG = 2>
