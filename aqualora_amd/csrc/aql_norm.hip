@@ -172,6 +172,103 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
   }
 }
 
+// pass 2, second form (maps above 32x32).  A thread owns ONE 16-byte chunk column, so gamma / beta and the statistics of the (at
+// most two) groups its 8 channels belong to are fetched once instead of 2-4 scalar loads per element, and it keeps GNA_U pixel
+// rows in flight (the first form issues one chunk per thread and retires: at 21-42 MB per launch the kernel spent its time ramping
+// wavefronts up and down).  Whole pixel rows are read and written contiguously.  `part` != null: the statistics come from the
+// piece sums of gn_fused_kernel<0, 1> (summed in the same fixed order as its PHASE 2), and are written to `stats_out` for backward.
+constexpr int GNA_U = 4;
+template <int MODE>
+__global__ void gn_apply2_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, const bf16_t* __restrict__ gamma,
+                                 const bf16_t* __restrict__ beta, const float* __restrict__ stats,
+                                 const float* __restrict__ dstats, const float* __restrict__ part, int nsplit, float inv_count,
+                                 float eps, float* __restrict__ stats_out, int HW, int C, int rows_per_slab, int silu,
+                                 const bf16_t* __restrict__ dres, bf16_t* __restrict__ out) {
+  const int cols = C >> 3, cpg = C / G;
+  const int rp = blockDim.x / cols;
+  const int col = threadIdx.x % cols, rr = threadIdx.x / cols;
+  if (rr >= rp) return;
+  const int b = blockIdx.y, slab = blockIdx.x;
+  const int c0 = col * 8;
+  const int g0 = c0 / cpg, g1 = (c0 + 7) / cpg;   // cpg >= 8 is not required: with cpg < 8 the callers use the first form
+  const int split = (g0 + 1) * cpg - c0;          // channels j < split belong to g0, the rest to g1
+  float ga[8], be[8];
+  unpack8(*reinterpret_cast<const uint4*>(gamma + c0), ga);
+  unpack8(*reinterpret_cast<const uint4*>(beta + c0), be);
+  float mu2[2], rs2[2], m12[2] = {0.f, 0.f}, m22[2] = {0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int g = k ? g1 : g0;
+    if (part != nullptr) {
+      float a0 = 0.f, a1 = 0.f;
+      for (int q = 0; q < nsplit; ++q) {
+        a0 += part[(((long)b * G + g) * nsplit + q) * 2 + 0];
+        a1 += part[(((long)b * G + g) * nsplit + q) * 2 + 1];
+      }
+      mu2[k] = a0 * inv_count;
+      rs2[k] = rsqrtf(fmaxf(a1 * inv_count - mu2[k] * mu2[k], 0.f) + eps);
+      if (slab == 0 && rr == 0 && ((g * cpg) >> 3) == col && (k == 0 || g1 != g0)) {
+        stats_out[(b * G + g) * 2 + 0] = mu2[k];
+        stats_out[(b * G + g) * 2 + 1] = rs2[k];
+      }
+    } else {
+      mu2[k] = stats[(b * G + g) * 2 + 0];
+      rs2[k] = stats[(b * G + g) * 2 + 1];
+    }
+    if (MODE == 1) {
+      m12[k] = dstats[(b * G + g) * 2 + 0];
+      m22[k] = dstats[(b * G + g) * 2 + 1];
+    }
+  }
+  const int r0 = slab * rows_per_slab, r1 = min(HW, r0 + rows_per_slab);
+  for (int r = r0 + rr; r < r1; r += rp * GNA_U) {
+    uint4 xw[GNA_U], dw[GNA_U], rw[GNA_U];
+#pragma unroll
+    for (int u = 0; u < GNA_U; ++u) {
+      const int ru = min(r + u * rp, r1 - 1);   // rows past the slab re-read its last row (dropped below)
+      const long off = ((long)b * HW + ru) * C + c0;
+      xw[u] = *reinterpret_cast<const uint4*>(x + off);
+      if (MODE == 1) {
+        dw[u] = *reinterpret_cast<const uint4*>(dy + off);
+        if (dres != nullptr) rw[u] = *reinterpret_cast<const uint4*>(dres + off);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < GNA_U; ++u) {
+      if (r + u * rp >= r1) continue;
+      const long off = ((long)b * HW + r + u * rp) * C + c0;
+      float xv[8], dv[8], o[8];
+      unpack8(xw[u], xv);
+      if (MODE == 1) unpack8(dw[u], dv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = j < split ? 0 : 1;
+        const float mu = mu2[k], rs = rs2[k];
+        const float xh = (xv[j] - mu) * rs;
+        const float z = xh * ga[j] + be[j];
+        if (MODE == 0) {
+          o[j] = silu ? z * sigmoidf_(z) : z;
+        } else {
+          float d = dv[j];
+          if (silu) {
+            const float sg = sigmoidf_(z);
+            d *= sg * (1.f + z * (1.f - sg));
+          }
+          d *= ga[j];
+          o[j] = rs * (d - m12[k] - xh * m22[k]);
+        }
+      }
+      if (MODE == 1 && dres != nullptr) {
+        float rsd[8];
+        unpack8(rw[u], rsd);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] += rsd[j];
+      }
+      *reinterpret_cast<uint4*>(out + off) = pack8(o);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Fused GroupNorm: ONE launch, one workgroup per (sample, group).  The workgroup streams its HW x (C/32) slice twice --
 // pass 1 statistics, pass 2 normalise (+SiLU) -- and the second read is served by the XCD's L2 (a slice is 82 KB at
@@ -482,20 +579,32 @@ extern "C" int aql_groupnorm_silu_fwd(const bf16_t* x, int B, int HW, int C, con
     AQL_CHECK_LAUNCH("aql_groupnorm_silu_fwd");
     return AQL_OK;
   }
+  static const int apply2 = getenv("AQL_GN_APPLY2") ? atoi(getenv("AQL_GN_APPLY2")) : 1;   // A/B hook
+  int threads, rps;
+  const int nslab = gn_geometry(HW, C, &threads, &rps);
+  const bool a2_ok = apply2 && (C / G) >= 8;
   if (const int ns = gn_split(C, HW)) {
     hipLaunchKernelGGL((gn_fused_kernel<0, 1>), dim3(B * G * ns), dim3(GNF_THREADS), 0, stream, x, nullptr, gamma, beta, stats,
                        HW, C, eps, silu, nullptr, y, ns, scratch);
-    hipLaunchKernelGGL((gn_fused_kernel<0, 2>), dim3(B * G * ns), dim3(GNF_THREADS), 0, stream, x, nullptr, gamma, beta, stats,
-                       HW, C, eps, silu, nullptr, y, ns, scratch);
+    if (a2_ok)   // coalesced second pass that sums the piece statistics itself
+      hipLaunchKernelGGL(gn_apply2_kernel<0>, dim3(nslab, B), dim3(threads), 0, stream, x, nullptr, gamma, beta, nullptr, nullptr,
+                         scratch, ns, 1.f / ((float)HW * (C / G)), eps, stats, HW, C, rps, silu, nullptr, y);
+    else
+      hipLaunchKernelGGL((gn_fused_kernel<0, 2>), dim3(B * G * ns), dim3(GNF_THREADS), 0, stream, x, nullptr, gamma, beta, stats,
+                         HW, C, eps, silu, nullptr, y, ns, scratch);
     AQL_CHECK_LAUNCH("aql_groupnorm_silu_fwd");
     return AQL_OK;
   }
-  int threads, rps;
-  const int nslab = gn_geometry(HW, C, &threads, &rps);
   hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(nslab, B), dim3(threads), threads * 64, stream, x, nullptr, gamma, beta, nullptr,
                      HW, C, rps, silu, scratch);
   hipLaunchKernelGGL(gn_finalize_kernel<0>, dim3(B), dim3(256), 0, stream, scratch, nslab,
                      1.f / ((float)HW * (C / G)), eps, stats);
+  if (a2_ok) {
+    hipLaunchKernelGGL(gn_apply2_kernel<0>, dim3(nslab, B), dim3(threads), 0, stream, x, nullptr, gamma, beta, stats, nullptr,
+                       nullptr, 0, 0.f, 0.f, nullptr, HW, C, rps, silu, nullptr, y);
+    AQL_CHECK_LAUNCH("aql_groupnorm_silu_fwd");
+    return AQL_OK;
+  }
   const long nchunk = (long)HW * (C / 8);
   int blocks = (int)((nchunk + 255) / 256);
   if (blocks > 1024) blocks = 1024;
@@ -524,6 +633,13 @@ extern "C" int aql_groupnorm_silu_bwd(const bf16_t* x, const bf16_t* dy, int B, 
                      rps, silu, scratch);
   hipLaunchKernelGGL(gn_finalize_kernel<1>, dim3(B), dim3(256), 0, stream, scratch, nslab,
                      1.f / ((float)HW * (C / G)), 0.f, dstats);
+  static const int apply2 = getenv("AQL_GN_APPLY2") ? atoi(getenv("AQL_GN_APPLY2")) : 1;   // A/B hook
+  if (apply2 && (C / G) >= 8) {
+    hipLaunchKernelGGL(gn_apply2_kernel<1>, dim3(nslab, B), dim3(threads), 0, stream, x, dy, gamma, beta, stats, dstats, nullptr, 0,
+                       0.f, 0.f, nullptr, HW, C, rps, silu, dres, dx);
+    AQL_CHECK_LAUNCH("aql_groupnorm_silu_bwd");
+    return AQL_OK;
+  }
   const long nchunk = (long)HW * (C / 8);
   int blocks = (int)((nchunk + 255) / 256);
   if (blocks > 1024) blocks = 1024;

@@ -10,7 +10,7 @@ from aqualora_amd import _lib as L  # noqa: E402
 
 SHAPES = [(320, 64), (640, 64), (960, 64), (320, 32), (640, 32), (960, 32), (1280, 32), (1920, 32), (640, 16), (1280, 16),
           (1920, 16), (2560, 16), (1280, 8), (2560, 8)]
-B = 4
+B = int(__import__("os").environ.get("GN_B", "4"))
 dev = "cuda"
 
 
