@@ -301,12 +301,50 @@ def ddim_step(x, eps_u, eps_c, t, t_prev, guidance, acp=None):
     return (a_p.sqrt() * x0 + (1 - a_p).sqrt() * eps).float()
 
 
+def dpmpp2m_steps(num_inference_steps, num_train_timesteps=1000, acp=None):
+    """Own restatement of the DPM-Solver++(2M) trajectory (independent of aqualora_amd.inference.dpmpp2m_schedule): timesteps =
+    round(linspace(0, T-1, n+1))[::-1][:-1] (diffusers' "linspace" spacing), data-prediction multistep update of Lu et al. 2022
+    (arXiv:2211.01095, Alg. 2) in half-log-SNR lambda = log(alpha / sigma):
+        h = lambda_next - lambda_t;  x_next = (sigma_next / sigma_t) x - alpha_next (e^{-h} - 1) D,
+        D = x0_t (first step; last step too when n < 15: diffusers' lower_order_final) else x0_t + (x0_t - x0_prev) / (2 r0),
+        r0 = (lambda_t - lambda_prev) / h;   the final step lands on alphas_cumprod[0] (final_sigmas_type "zero" is not used by
+    the reference's rob-finetune sampler, rob_enhance_finetune.py:993,1012).  Returns [(t, t_next)] and the lambda function.
+    UNPINNED (diffusers is not on disk)."""
+    import math
+    import numpy as np
+    acp = (alphas_cumprod() if acp is None else acp).double().numpy()
+    ts = [int(v) for v in np.linspace(0, num_train_timesteps - 1, num_inference_steps + 1).round()[::-1][:-1]]
+    lam = lambda t: 0.5 * math.log(acp[t] / (1.0 - acp[t]))  # noqa: E731
+    return ts, lam, acp
+
+
 def dpmpp2m_sample(eps_model, x, schedule, guidance=1.0):
-    """DPM-Solver++(2M) loop over ``schedule`` = [(t, alpha_t, sigma_t, a, b, c)] (aqualora_amd.inference.dpmpp2m_schedule;
-    the coefficient algebra is restated independently in tests/test_samplers.py).  ``eps_model(x, t) -> (eps_uncond,
-    eps_cond)``.  Recalled diffusers DPMSolverMultistepScheduler semantics (rob_enhance_finetune.py:993): UNPINNED."""
+    """DPM-Solver++(2M) sampler.  ``schedule`` is either the number of inference steps (the oracle then builds the whole
+    trajectory itself from `dpmpp2m_steps` -- nothing of the product is involved) or, for backward compatibility, a list of
+    (t, alpha_t, sigma_t, a, b, c) rows.  ``eps_model(x, t) -> (eps_uncond, eps_cond)``.  UNPINNED (see dpmpp2m_steps)."""
+    import math
     x = x.double()
     x0_prev = torch.zeros_like(x)
+    if isinstance(schedule, int):
+        n = schedule
+        ts, lam, acp = dpmpp2m_steps(n)
+        for i, t in enumerate(ts):
+            nxt = ts[i + 1] if i + 1 < n else 0
+            al, sg = math.sqrt(acp[t]), math.sqrt(1.0 - acp[t])
+            al_n, sg_n = math.sqrt(acp[nxt]), math.sqrt(1.0 - acp[nxt])
+            eu, ec = eps_model(x.float(), t)
+            eps = eu.double() + guidance * (ec.double() - eu.double())
+            x0 = (x - sg * eps) / al
+            h = lam(nxt) - lam(t)
+            first_order = i == 0 or (i == n - 1 and n < 15)
+            if first_order:
+                D = x0
+            else:
+                r0 = (lam(t) - lam(ts[i - 1])) / h
+                D = x0 + (x0 - x0_prev) / (2.0 * r0)
+            x = (sg_n / sg) * x - al_n * math.expm1(-h) * D
+            x0_prev = x0
+        return x.float()
     for t, al, sg, a, b, c in schedule:
         eu, ec = eps_model(x.float(), t)
         eps = eu.double() + guidance * (ec.double() - eu.double())
