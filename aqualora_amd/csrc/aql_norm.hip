@@ -199,12 +199,14 @@ __global__ void gn_apply2_kernel(const bf16_t* __restrict__ x, const bf16_t* __r
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int g = k ? g1 : g0;
-    if (part != nullptr) {
-      float a0 = 0.f, a1 = 0.f;
+    float a0 = 0.f, a1 = 0.f;
+    if (part != nullptr) {   // piece sums of gn_fused_kernel<MODE, 1>, added in its fixed order
       for (int q = 0; q < nsplit; ++q) {
         a0 += part[(((long)b * G + g) * nsplit + q) * 2 + 0];
         a1 += part[(((long)b * G + g) * nsplit + q) * 2 + 1];
       }
+    }
+    if (MODE == 0 && part != nullptr) {
       mu2[k] = a0 * inv_count;
       rs2[k] = rsqrtf(fmaxf(a1 * inv_count - mu2[k] * mu2[k], 0.f) + eps);
       if (slab == 0 && rr == 0 && ((g * cpg) >> 3) == col && (k == 0 || g1 != g0)) {
@@ -215,9 +217,9 @@ __global__ void gn_apply2_kernel(const bf16_t* __restrict__ x, const bf16_t* __r
       mu2[k] = stats[(b * G + g) * 2 + 0];
       rs2[k] = stats[(b * G + g) * 2 + 1];
     }
-    if (MODE == 1) {
-      m12[k] = dstats[(b * G + g) * 2 + 0];
-      m22[k] = dstats[(b * G + g) * 2 + 1];
+    if (MODE == 1) {   // mean(dxhat), mean(dxhat * xhat): from the piece sums, or finalized by gn_finalize_kernel<1>
+      m12[k] = part != nullptr ? a0 * inv_count : dstats[(b * G + g) * 2 + 0];
+      m22[k] = part != nullptr ? a1 * inv_count : dstats[(b * G + g) * 2 + 1];
     }
   }
   const int r0 = slab * rows_per_slab, r1 = min(HW, r0 + rows_per_slab);
@@ -625,9 +627,25 @@ extern "C" int aql_groupnorm_silu_bwd(const bf16_t* x, const bf16_t* dy, int B, 
     AQL_CHECK_LAUNCH("aql_groupnorm_silu_bwd");
     return AQL_OK;
   }
-  // (the two-launch split form of the forward is not used here: measured 36 vs 32 us at 64x64x320, 40 vs 44 at 640 channels)
   int threads, rps;
   const int nslab = gn_geometry(HW, C, &threads, &rps);
+  // split form: per-(sample, group, piece) sums in one launch, the coalesced second pass adds the pieces itself -- two launches,
+  // no finalize (with the old per-group second pass this form measured 36 vs 32 us at 64x64x320 and was not used).  AQL_GN_BWD_SPLIT=0
+  // restores the three-launch slab form
+  static const int bwd_split = getenv("AQL_GN_BWD_SPLIT") ? atoi(getenv("AQL_GN_BWD_SPLIT")) : 1;
+  static const int apply2s = getenv("AQL_GN_APPLY2") ? atoi(getenv("AQL_GN_APPLY2")) : 1;
+  int ns_b = (bwd_split && apply2s && (C / G) >= 8) ? gn_split(C, HW) : 0;
+  // measured (tools/tune_gn.py, 64x64): B=4: 25.1 / 32.7 / 40.2 us against 29.2 / 38.8 / 47.9 at 320 / 640 / 960 channels;
+  // B=8: 44.9 / 57.2 / 73.1 against 41.3 / 58.7 / 75.3 -- the split form loses only with > 768 workgroups of 20-byte segments
+  if (ns_b && (long)B * G * ns_b > 768 && C < 640 && bwd_split == 1) ns_b = 0;
+  if (const int ns = ns_b) {
+    hipLaunchKernelGGL((gn_fused_kernel<1, 1>), dim3(B * G * ns), dim3(GNF_THREADS), 0, stream, x, dy, gamma, beta,
+                       const_cast<float*>(stats), HW, C, 0.f, silu, nullptr, dx, ns, scratch);
+    hipLaunchKernelGGL(gn_apply2_kernel<1>, dim3(nslab, B), dim3(threads), 0, stream, x, dy, gamma, beta, stats, nullptr, scratch, ns,
+                       1.f / ((float)HW * (C / G)), 0.f, nullptr, HW, C, rps, silu, dres, dx);
+    AQL_CHECK_LAUNCH("aql_groupnorm_silu_bwd");
+    return AQL_OK;
+  }
   float* dstats = scratch + (long)B * 128 * G * 2;
   hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(nslab, B), dim3(threads), threads * 64, stream, x, dy, gamma, beta, stats, HW, C,
                      rps, silu, scratch);
