@@ -127,6 +127,8 @@ struct OutSpec {
   long ldg = 0;
   int geglu_F = 0;
   int c_row0 = 0;
+  const bf16_t* gb_h = nullptr;  // GEGLU-backward epilogue (EpiParams::gb_F = N): saved pre-activation [M][2N]
+  long gb_ldh = 0;
 };
 
 inline int pick_splits(int tiles, int kt_total, long M, int N, size_t ws_bytes) {
@@ -285,6 +287,7 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
     while (s2 > 1 && (kt_total / s2 < 8 || (size_t)s2 * (size_t)g.M * (size_t)g.N * 4u > ws_bytes)) --s2;
     splits = s2;
   }
+  if (o.gb_h != nullptr && splits > 1) return AQL_NOT_FUSED;   // the slab + finalize path has no GEGLU-backward epilogue
   g.splits = splits;
   // LDS-DMA staging everywhere (measured fastest on every shape, hot or cold operands); a grid of <= 1 workgroup per CU
   // cannot hide latency with occupancy, so it gets the deep stage ring instead
@@ -318,6 +321,7 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
   g.epi.ldg = o.ldg;
   g.epi.geglu_F = o.geglu_F;
   g.epi.c_row0 = o.c_row0;
+  if (o.gb_h != nullptr) g.epi.gb_h = o.gb_h, g.epi.gb_ldh = o.gb_ldh, g.epi.gb_F = g.N;
   launch_cfg<LA, LB, EPI_BF16>(cfg, pd, g, stream);
   AQL_CHECK_LAUNCH(name);
   return AQL_OK;
@@ -382,6 +386,40 @@ extern "C" int aql_gemm_bf16_ex(const bf16_t* A, long lda, const bf16_t* B, long
   g.N = N;
   OutSpec o{bias, rowbias, 0, rows_per_sample, residual, ldr, C, ldc, nullptr, 0, nullptr};
   return run_bf16_gemm(g, o, ws, ws_bytes, stream, "aql_gemm_bf16");
+}
+
+// Backward-data of ff.net.2 in the two-launch LoRA form (any rank) fused with the backward of the GEGLU in front of it
+// (original_unet.py:727-729): d(activated) [M][F] = A.B^T + A2.B2^T is turned into d(pre-activation) DH [M][2F] by the epilogue
+// (aql_geglu_bwd on the bf16-rounded tile, saved pre-activation H [M][2F]).  Returns AQL_NOT_FUSED (100) when the shape would
+// take the split-K path: the caller then runs the plain GEMM and aql_geglu_bwd.
+extern "C" int aql_gemm_bf16_geglu_bwd(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, int F, int K,
+                                       const bf16_t* A2, long lda2, const bf16_t* B2, long ldb2, int K2, const bf16_t* H,
+                                       long ldh, bf16_t* DH, long lddh, float* ws, size_t ws_bytes, hipStream_t stream) {
+  AQL_CHECK_ARG(A && B && H && DH, "aql_gemm_bf16_geglu_bwd: null operand");
+  AQL_CHECK_ARG(M > 0 && F > 0 && K > 0 && M < (1L << 31) && F % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+                    ldh % 8 == 0 && lddh % 8 == 0 && ldh >= 2 * F && lddh >= 2 * F,
+                "aql_gemm_bf16_geglu_bwd: bad shape M=%ld F=%d K=%d", M, F, K);
+  AQL_CHECK_ARG(aligned16(A) && aligned16(B) && aligned16(H) && aligned16(DH), "aql_gemm_bf16_geglu_bwd: pointers must be 16-byte aligned");
+  GemmArgs<PlainLoader, PlainLoader> g;
+  g.a0 = plain(A, lda, M, K);
+  g.b0 = plain(B, ldb, F, K);
+  g.ktiles0 = aql_cdiv(K, BK);
+  g.ktiles1 = 0;
+  g.a1 = g.a0;
+  g.b1 = g.b0;
+  if (A2 != nullptr) {
+    AQL_CHECK_ARG(B2 && K2 > 0 && K2 % 8 == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0 && aligned16(A2) && aligned16(B2),
+                  "aql_gemm_bf16_geglu_bwd: bad second K segment");
+    g.a1 = plain(A2, lda2, M, K2);
+    g.b1 = plain(B2, ldb2, F, K2);
+    g.ktiles1 = aql_cdiv(K2, BK);
+  }
+  g.M = (int)M;
+  g.N = F;
+  OutSpec o{nullptr, nullptr, 0, 1, nullptr, 0, DH, lddh, nullptr, 0, nullptr};
+  o.gb_h = H;
+  o.gb_ldh = ldh;
+  return run_bf16_gemm(g, o, ws, ws_bytes, stream, "aql_gemm_bf16_geglu_bwd");
 }
 
 // ff.net.0.proj + GEGLU in one launch (scripts/lib/original_unet.py:727-729 on top of lora_modules.py:56-62):

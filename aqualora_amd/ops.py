@@ -707,7 +707,19 @@ def _lora_backward(dy, x2d, T, Ts, S16, packed, site, rps, ds_accum, want_dx, re
         L.call("aql_lora_down", L.ptr(dy), dy.stride(0), M, packed.N, L.ptr(site.bt16), r, L.ptr(S16), rps,
                L.ptr(dTs), L.ptr(dT), L.ptr(T) if (want_ds and not ds_deferred) else None,
                L.ptr(ds_target) if (want_ds and not ds_deferred) else None, L.stream_ptr())
-        dx = gemm_bf16(dy, packed.wt, None, dT, site.at16, residual=dx_prev) if want_dx else None
+        if want_dx and geglu_h is not None and dx_prev is None and os.environ.get("AQL_GEGLU_BWD_FUSED", "1") != "0":
+            # ff.net.2 at rank != 32: the GEGLU backward in the epilogue of the two-K-segment GEMM
+            F = packed.K
+            dh = torch.empty(M, 2 * F, dtype=torch.bfloat16, device=dy.device)
+            ws = workspace(dy.device)
+            rc = L.call_raw("aql_gemm_bf16_geglu_bwd", L.ptr(dy), dy.stride(0), L.ptr(packed.wt), packed.wt.stride(0), M, F,
+                            packed.N, L.ptr(dT), dT.stride(0), L.ptr(site.at16), site.at16.stride(0), r, L.ptr(geglu_h),
+                            geglu_h.stride(0), L.ptr(dh), 2 * F, L.ptr(ws), ws.numel() * 4, L.stream_ptr())
+            if rc != 100:
+                L.check(rc, "aql_gemm_bf16_geglu_bwd")
+                dx, fused_gb = dh, True
+        if want_dx and dx is None:
+            dx = gemm_bf16(dy, packed.wt, None, dT, site.at16, residual=dx_prev)
     if ds_deferred and not dfr.add_ds(dTs, T, ds_target, nb, rps, r):
         L.call("aql_lora_ds", L.ptr(dTs), L.ptr(T), nb, rps, r, L.ptr(ds_target), L.stream_ptr())
     # dBup[N,r] += dY^T Ts ; dA[r,K] += dT^T X   (grouped at the end of backward when a trainer defers them)

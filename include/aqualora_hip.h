@@ -100,6 +100,13 @@ int aql_lora_gemm_fused_geglu_bwd(const bf16_t* X, long ldx, const bf16_t* W, lo
                                   const bf16_t* Adown, const bf16_t* S, int rows_per_sample, const bf16_t* Bup,
                                   const bf16_t* H, long ldh, bf16_t* DH, long lddh, bf16_t* T, bf16_t* Ts,
                                   aql_stream_t stream);
+/* The same fusion for the two-launch LoRA form (any rank; configs 3 / 5 train at rank 320, train/README.md:34-48):
+ * d(activated) [M,F] = A.B^T + A2.B2^T (A = dY, B = W2^T, A2 = dT, B2 = A2^T of the ff.net.2 site), written as d(pre-activation)
+ * DH [M,2F] through the GEGLU backward (original_unet.py:727-729) of the saved pre-activation H [M,2F].  Returns 100 when the shape
+ * takes the split-K path (caller: aql_gemm_bf16 + aql_geglu_bwd).                                                          */
+int aql_gemm_bf16_geglu_bwd(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, int F, int K, const bf16_t* A2,
+                            long lda2, const bf16_t* B2, long ldb2, int K2, const bf16_t* H, long ldh, bf16_t* DH, long lddh,
+                            float* ws, size_t ws_bytes, aql_stream_t stream);
 /* n <= 32 rank-32 "down" products with a common row count in one launch: T[i] = X[i].A[i]^T, Ts[i] = T[i] * S[m / rps]
  * (X[i] [M,K[i]] dense, A[i] [32,K[i]]; X, A, K are HOST arrays; T, Ts [n][M][32]).  The backward of the grouped text-state
  * k|v projections: dTs = dY.Bup, dT = dTs * S (utils/lora_modules.py:13-17 transposed) for all 32 sites at once.        */
