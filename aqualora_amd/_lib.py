@@ -52,6 +52,8 @@ SIGNATURES = {
     "aql_geglu_fwd": [c_p, c_l, c_i, c_p, c_p],
     "aql_geglu_bwd": [c_p, c_p, c_l, c_i, c_p, c_p],
     "aql_upsample2x_bwd": [c_p, c_i, c_i, c_i, c_i, c_p, c_p],
+    "aql_cat_channels": [c_p, c_p, c_l, c_i, c_i, c_p, c_p],
+    "aql_split_channels": [c_p, c_l, c_i, c_i, c_p, c_p, c_p],
     "aql_add_noise": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p],
     "aql_mse_fwd_bwd": [c_p, c_p, c_l, c_p, c_p, c_p],
     "aql_mapper_fwd": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],

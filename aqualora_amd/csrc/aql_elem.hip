@@ -86,6 +86,34 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const bf16_t* __res
   }
 }
 
+// ---- skip-connection concat on channels-last maps (original_unet.py:1133,1224): out[p][0:Ca] = a[p], out[p][Ca:] = b[p] in ONE
+// launch, and its backward (one launch, two dense outputs).  DIR 0: (a, b) -> cat;  DIR 1: cat -> (a, b).  Four 16-byte chunks
+// per thread in flight.
+template <int DIR>
+__global__ __launch_bounds__(256) void cat_channels_kernel(bf16_t* __restrict__ a, bf16_t* __restrict__ b, bf16_t* __restrict__ cat,
+                                                           long npix, int Ca, int Cb) {
+  const int ca = Ca >> 3, cols = (Ca + Cb) >> 3;
+  const long n = npix * cols, stride = (long)gridDim.x * blockDim.x;
+  for (long id0 = (long)blockIdx.x * blockDim.x + threadIdx.x; id0 < n; id0 += 4 * stride) {
+    uint4 v[4];
+    bf16_t* part[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long id = id0 + u * stride < n ? id0 + u * stride : id0;
+      const long p = id / cols;
+      const int c = (int)(id - p * cols);
+      part[u] = c < ca ? a + p * Ca + c * 8 : b + p * Cb + (c - ca) * 8;
+      v[u] = *reinterpret_cast<const uint4*>(DIR == 0 ? part[u] : cat + id * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long id = id0 + u * stride;
+      if (id >= n) continue;
+      *reinterpret_cast<uint4*>(DIR == 0 ? cat + id * 8 : part[u]) = v[u];
+    }
+  }
+}
+
 // ---- add_noise (diffusers DDPMScheduler.add_noise via utils/cschedulers.py:15; ppft_train.py:1010-1011) -----
 // out = sqrt(acp[t]) * x + sqrt(1-acp[t]) * eps, computed in fp32, stored bf16.  Two inputs share eps and t.
 __global__ __launch_bounds__(256) void add_noise_kernel(const float* __restrict__ x0, const float* __restrict__ wm,
@@ -379,6 +407,20 @@ extern "C" int aql_upsample2x_bwd(const bf16_t* du, int B, int H, int W, int C, 
   hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for((long)B * H * W * (C / 8))), dim3(256), 0, stream, du, B, H,
                      W, C, dx);
   AQL_CHECK_LAUNCH("aql_upsample2x_bwd");
+  return AQL_OK;
+}
+extern "C" int aql_cat_channels(const bf16_t* a, const bf16_t* b, long npix, int Ca, int Cb, bf16_t* cat, hipStream_t stream) {
+  AQL_CHECK_ARG(a && b && cat && npix > 0 && Ca > 0 && Cb > 0 && Ca % 8 == 0 && Cb % 8 == 0, "aql_cat_channels: bad args");
+  hipLaunchKernelGGL(cat_channels_kernel<0>, dim3(grid_for((npix * ((Ca + Cb) / 8) + 3) / 4)), dim3(256), 0, stream,
+                     const_cast<bf16_t*>(a), const_cast<bf16_t*>(b), cat, npix, Ca, Cb);
+  AQL_CHECK_LAUNCH("aql_cat_channels");
+  return AQL_OK;
+}
+extern "C" int aql_split_channels(const bf16_t* cat, long npix, int Ca, int Cb, bf16_t* a, bf16_t* b, hipStream_t stream) {
+  AQL_CHECK_ARG(a && b && cat && npix > 0 && Ca > 0 && Cb > 0 && Ca % 8 == 0 && Cb % 8 == 0, "aql_split_channels: bad args");
+  hipLaunchKernelGGL(cat_channels_kernel<1>, dim3(grid_for((npix * ((Ca + Cb) / 8) + 3) / 4)), dim3(256), 0, stream, a, b,
+                     const_cast<bf16_t*>(cat), npix, Ca, Cb);
+  AQL_CHECK_LAUNCH("aql_split_channels");
   return AQL_OK;
 }
 extern "C" int aql_add_noise(const float* x0, const float* wm, const float* eps, const long* t, const float* acp,

@@ -963,6 +963,9 @@ def conv3x3(x, packed, upsample=False, rowbias=None, residual=None):
 
 
 # ------------------------------------------------------------------------------ skip-connection concat
+_CAT_FUSED = os.environ.get("AQL_CAT_FUSED", "1") != "0"   # A/B hook: 0 = two strided torch copies forward, slice views backward
+
+
 class CatChannelsFn(torch.autograd.Function):
     """torch.cat([a, b], dim=1) on channels-last maps (the up-block skip connections, original_unet.py:1133,1224), twin-batch
     aware: the concatenation is built for both halves, autograd sees the second half."""
@@ -978,14 +981,28 @@ class CatChannelsFn(torch.autograd.Function):
         if not twin:
             ak = a
         outk, out = _alloc((B, Ca + Cb, H, W), a.dtype, a.device, twin, cl=True)
-        outk[:, :Ca] = ak
-        outk[:, Ca:] = bk
+        if _CAT_FUSED and a.dtype == torch.bfloat16 and Ca % 8 == 0 and Cb % 8 == 0 and ak.is_contiguous(memory_format=CL) \
+                and bk.is_contiguous(memory_format=CL):
+            L.call("aql_cat_channels", L.ptr(ak), L.ptr(bk), outk.shape[0] * H * W, Ca, Cb, L.ptr(outk), L.stream_ptr())
+        else:
+            outk[:, :Ca] = ak
+            outk[:, Ca:] = bk
         ctx.ca = Ca
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        return dy[:, :ctx.ca], dy[:, ctx.ca:]
+        Ca = ctx.ca
+        B, C, H, W = dy.shape
+        Cb = C - Ca
+        if _CAT_FUSED and dy.dtype == torch.bfloat16 and Ca % 8 == 0 and Cb % 8 == 0 and dy.is_contiguous(memory_format=CL):
+            # both slices dense in one launch: their consumers (conv / GEMM backward) need dense operands, and the gradient
+            # accumulation of the skip tensor then adds two dense tensors
+            da = torch.empty((B, Ca, H, W), dtype=dy.dtype, device=dy.device, memory_format=CL)
+            db = torch.empty((B, Cb, H, W), dtype=dy.dtype, device=dy.device, memory_format=CL)
+            L.call("aql_split_channels", L.ptr(dy), B * H * W, Ca, Cb, L.ptr(da), L.ptr(db), L.stream_ptr())
+            return da, db
+        return dy[:, :Ca], dy[:, Ca:]
 
 
 def cat_channels(a, b):

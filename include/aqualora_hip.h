@@ -171,6 +171,11 @@ int aql_geglu_fwd(const bf16_t* in, long M, int F, bf16_t* out, aql_stream_t str
 int aql_geglu_bwd(const bf16_t* in, const bf16_t* dy, long M, int F, bf16_t* din, aql_stream_t stream);
 /* backward of F.interpolate(scale_factor=2, "nearest") (original_unet.py:1076): 2x2 block sum                      */
 int aql_upsample2x_bwd(const bf16_t* du, int B, int H, int W, int C, bf16_t* dx, aql_stream_t stream);
+/* Skip-connection concat of the up blocks (torch.cat([h, skip], dim=1), scripts/lib/original_unet.py:1133,1224) on channels-last
+ * maps: cat[p][0:Ca] = a[p], cat[p][Ca:Ca+Cb] = b[p] for npix = B*H*W pixels in one launch, and its backward (the two dense
+ * gradient slices in one launch).  Ca, Cb multiples of 8.                                                               */
+int aql_cat_channels(const bf16_t* a, const bf16_t* b, long npix, int Ca, int Cb, bf16_t* cat, aql_stream_t stream);
+int aql_split_channels(const bf16_t* cat, long npix, int Ca, int Cb, bf16_t* a, bf16_t* b, aql_stream_t stream);
 /* P[m,:] = softmax(scale * S[m,:]), S fp32 -> P bf16: the VAE mid-block's single-head 512-wide attention
  * (AutoencoderKL, ppft_train.py:993), whose scores come from aql_gemm_nt_f32_accum                                   */
 int aql_softmax_rows(const float* S, long lds, long M, int N, float scale, bf16_t* P, long ldp, aql_stream_t stream);

@@ -31,6 +31,15 @@ for (B, C, H, W, silu, eps) in [(2, 320, 64, 64, 1, 1e-5), (2, 640, 16, 16, 0, 1
     dy = rnd(B, C, H, W).contiguous(memory_format=torch.channels_last)
     y.backward(dy); yr.backward(dy.float())
     report(f"groupnorm bwd", relerr(x.grad, xr.grad), 2e-2)
+# skip-connection concat (one launch forward, one launch backward)
+for (B, Ca, Cb, H, W) in [(2, 320, 320, 16, 16), (1, 640, 320, 9, 7), (3, 8, 24, 5, 5)]:
+    a = rnd(B, Ca, H, W).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    b = rnd(B, Cb, H, W).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = ops.cat_channels(a, b)
+    report(f"cat_channels fwd {Ca}+{Cb} {H}x{W}", 0.0 if torch.equal(y, torch.cat([a, b], 1)) else 1.0, 1e-9)
+    dy = rnd(B, Ca + Cb, H, W).contiguous(memory_format=torch.channels_last)
+    y.backward(dy)
+    report("cat_channels bwd", 0.0 if (torch.equal(a.grad, dy[:, :Ca]) and torch.equal(b.grad, dy[:, Ca:])) else 1.0, 1e-9)
 # LayerNorm
 for (M, C) in [(4096, 320), (1000, 640), (77, 1280), (5, 64)]:
     x = (rnd(M, C) * 2 + 0.3).requires_grad_(True); g = rnd(C) * 0.5 + 1; b = rnd(C) * 0.1
