@@ -33,6 +33,7 @@ SIGNATURES = {
                                     c_p],
     "aql_lora_gemm_fused_geglu_bwd": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_p],
     "aql_gemm_bf16_geglu_bwd": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_p, c_sz, c_p],
+    "aql_lora_gemm_fused_kgroups": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_p, c_i, c_p, c_l, c_p, c_l, c_p, c_p, c_p],
     "aql_lora_down_grouped": [c_i, c_p, c_p, c_p, c_l, c_p, c_i, c_p, c_p, c_p],
     "aql_lora_down": [c_p, c_l, c_l, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p],
     "aql_conv3x3_fwd": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_sz, c_p],

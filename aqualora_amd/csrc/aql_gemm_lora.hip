@@ -19,6 +19,7 @@
 // two-launch path.
 #include <type_traits>
 #include "aql_gemm.cuh"
+#include "aql_gemm_lora_kgroups.cuh"
 #include <stdlib.h>
 #include <string.h>
 
@@ -718,6 +719,47 @@ extern "C" int aql_lora_gemm_fused_geglu(const bf16_t* X, long ldx, const bf16_t
 // d(activated) = dY.W2 + dT.A2 [M,F]), whose epilogue turns d(activated) into d(pre-activation) with the saved H [M,2F]:
 // DH[m][n] = d * gate * cdf(gate), DH[m][F+n] = d * value * (cdf(gate) + gate pdf(gate)) -- aql_geglu_bwd applied to the
 // bf16-rounded tile (bit-identical to the two kernels).  Returns 100 like aql_lora_gemm_fused.
+// ng <= 3 rank-32 LoRA linears summed into ONE output (aql_gemm_lora_kgroups.cuh): the backward-data pass of q | k | v.
+// X, W, Adown, Bup, T, Ts, ldx, ldw, K are HOST arrays of ng entries.  Returns 100 when no wave-specialised tile gives one
+// chip-wide round for (M, N): the caller then chains aql_lora_gemm_fused launches.
+extern "C" int aql_lora_gemm_fused_kgroups(int ng, const void* const* X, const long* ldx, const void* const* W, const long* ldw,
+                                           const int* K, const void* const* Adown, const void* const* Bup, long M, int N,
+                                           const bf16_t* S, int rows_per_sample, const bf16_t* residual, long ldr, bf16_t* Y,
+                                           long ldy, void* const* T, void* const* Ts, hipStream_t stream) {
+  AQL_CHECK_ARG(ng >= 1 && ng <= aqlkg::KG_MAX && X && ldx && W && ldw && K && Adown && Bup && T && Ts && S && Y,
+                "aql_lora_gemm_fused_kgroups: bad operands (ng=%d)", ng);
+  AQL_CHECK_ARG(M > 0 && M < (1L << 31) && N > 0 && N % 8 == 0 && ldy % 8 == 0 && rows_per_sample > 0 &&
+                    (residual == nullptr || ldr % 8 == 0), "aql_lora_gemm_fused_kgroups: bad shape M=%ld N=%d", M, N);
+  if (N % 160 != 0) return AQL_NOT_FUSED;
+  aqlkg::KGArgs a{};
+  a.ng = ng;
+  int kt_sum = 0;
+  for (int g = 0; g < ng; ++g) {
+    AQL_CHECK_ARG(X[g] && W[g] && Adown[g] && Bup[g] && T[g] && Ts[g] && K[g] > 0 && K[g] % 8 == 0 && ldx[g] % 8 == 0 && ldw[g] % 8 == 0,
+                  "aql_lora_gemm_fused_kgroups: bad group %d", g);
+    a.x[g] = plain(static_cast<const bf16_t*>(X[g]), ldx[g], M, K[g]);
+    a.w[g] = plain(static_cast<const bf16_t*>(W[g]), ldw[g], N, K[g]);
+    a.ad[g] = plain(static_cast<const bf16_t*>(Adown[g]), K[g], LR, K[g]);
+    a.bup[g] = static_cast<const bf16_t*>(Bup[g]);
+    a.T[g] = static_cast<bf16_t*>(T[g]);
+    a.Ts[g] = static_cast<bf16_t*>(Ts[g]);
+    a.kt[g] = aql_cdiv(K[g], BK);
+    kt_sum += a.kt[g];
+  }
+  a.S = S, a.rps = rows_per_sample, a.M = (int)M, a.N = N;
+  a.m_fast = ((long)N * kt_sum > (long)M * (kt_sum < 9 ? kt_sum : kt_sum / 9 + 1)) ? 1 : 0;
+  a.epi = EpiParams{};
+  a.epi.C = Y, a.epi.ldc = ldy, a.epi.residual = residual, a.epi.ldr = ldr, a.epi.rows_per_sample = rows_per_sample;
+  const int nt = N / 160;
+  const int t128 = aql_cdiv(M, 128) * nt, t64 = aql_cdiv(M, 64) * nt, t32 = aql_cdiv(M, 32) * nt;
+  if (t128 >= 240 && t128 <= 288) aqlkg::launch_wk<128, 160, 64, 80, 3>(a, stream);
+  else if (t128 < 240 && t64 >= 240 && t64 <= 512) aqlkg::launch_wk<64, 160, 32, 80, 4>(a, stream);
+  else if (t64 < 240 && t32 >= 240 && t32 <= 512) aqlkg::launch_wk<32, 160, 16, 80, 5>(a, stream);
+  else return AQL_NOT_FUSED;
+  AQL_CHECK_LAUNCH("aql_lora_gemm_fused_kgroups");
+  return AQL_OK;
+}
+
 extern "C" int aql_lora_gemm_fused_geglu_bwd(const bf16_t* X, long ldx, const bf16_t* W, long ldw, long M, int F, int K,
                                              const bf16_t* Adown, const bf16_t* S, int rows_per_sample, const bf16_t* Bup,
                                              const bf16_t* H, long ldh, bf16_t* DH, long lddh, bf16_t* T, bf16_t* Ts,

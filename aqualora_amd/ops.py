@@ -789,6 +789,9 @@ def adjacent(tensors):
     return True
 
 
+_KGROUPS = os.environ.get("AQL_KGROUPS", "1") != "0"   # A/B hook: 0 = three chained backward-data launches for q | k | v
+
+
 class GroupedLoraFn(torch.autograd.Function):
     """G rank-32 LoRA linears that read the SAME input, as one launch (aql_lora_gemm_fused_grouped): q|k|v of a self-attention
     (original_unet.py:688-704) or the k|v projections of the text states of all cross-attentions.  ``wcat`` [sum N_g, K] is the
@@ -857,6 +860,35 @@ class GroupedLoraFn(torch.autograd.Function):
                 DEFERRED.add_tn(dy, Ts[g], site.gb)
                 DEFERRED.add_tn(dT[g], x2d, site.ga)
             return None, None, None, None, None, None, None
+        G = len(dys)
+        if (ctx.needs_input_grad[0] and 2 <= G <= 3 and all(dy is not None for dy in dys) and ctx.ds_accum is not None
+                and DEFERRED is not None and _KGROUPS):   # (dS goes to the trainer's accumulator, as in the branch above)
+            # q | k | v backward-data as ONE launch: dX = sum_g (dY_g.W_g + ((dY_g.Bup_g) * S).A_g), accumulators in registers
+            import ctypes
+            M, Kin = x2d.shape
+            dys = [dy.contiguous() for dy in dys]
+            dTs = torch.empty(G, M, 32, dtype=torch.bfloat16, device=x2d.device)
+            dT = torch.empty_like(dTs)
+            dx = torch.empty(M, Kin, dtype=torch.bfloat16, device=x2d.device)
+            vp, lp_, ip = ctypes.c_void_p * G, ctypes.c_long * G, ctypes.c_int * G
+            rc = L.call_raw("aql_lora_gemm_fused_kgroups", G, vp(*[dy.data_ptr() for dy in dys]), lp_(*[dy.stride(0) for dy in dys]),
+                            vp(*[p.wt.data_ptr() for p in ctx.packs]), lp_(*[p.wt.stride(0) for p in ctx.packs]),
+                            ip(*[dy.shape[1] for dy in dys]), vp(*[s_.bt16.data_ptr() for s_ in ctx.sites]),
+                            vp(*[s_.at16.data_ptr() for s_ in ctx.sites]), M, Kin, L.ptr(S16), ctx.rps, None, 0, L.ptr(dx), Kin,
+                            vp(*[dTs[g].data_ptr() for g in range(G)]), vp(*[dT[g].data_ptr() for g in range(G)]), L.stream_ptr())
+            if rc != 100:
+                L.check(rc, "aql_lora_gemm_fused_kgroups")
+                nb = S16.shape[0]
+                for g, dy in enumerate(dys):
+                    site = ctx.sites[g]
+                    if not DEFERRED.add_ds(dTs[g], T[g], ctx.ds_accum, nb, ctx.rps, 32):
+                        L.call("aql_lora_ds", L.ptr(dTs[g]), L.ptr(T[g]), nb, ctx.rps, 32, L.ptr(ctx.ds_accum), L.stream_ptr())
+                    if not DEFERRED.add_tn(dy, Ts[g], site.gb):
+                        gemm_tn_acc(dy, Ts[g], site.gb)
+                    if not DEFERRED.add_tn(dT[g], x2d, site.ga):
+                        gemm_tn_acc(dT[g], x2d, site.ga)
+                return dx, None, None, None, None, None, None
+            dx = None
         for g, dy in enumerate(dys):
             if dy is None:
                 continue

@@ -107,6 +107,16 @@ int aql_lora_gemm_fused_geglu_bwd(const bf16_t* X, long ldx, const bf16_t* W, lo
 int aql_gemm_bf16_geglu_bwd(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, int F, int K, const bf16_t* A2,
                             long lda2, const bf16_t* B2, long ldb2, int K2, const bf16_t* H, long ldh, bf16_t* DH, long lddh,
                             float* ws, size_t ws_bytes, aql_stream_t stream);
+/* ng <= 3 rank-32 LoRA linears whose results are SUMMED into one output, in one launch:
+ *   Y[M,N] = sum_g ( X_g.W_g^T + ((X_g.Adown_g^T) * S[m / rps]).Bup_g^T ) + residual;   T_g, Ts_g [M,32] are written per group.
+ * The backward-data pass of the q | k | v projections of a self-attention (scripts/lib/original_unet.py:688-704 through
+ * utils/lora_modules.py:56-62): X_g = dQ | dK | dV, W_g = W_g^T, Adown_g = Bup_g^T, Bup_g = A_g^T, T_g / Ts_g = dTs_g / dT_g.
+ * X, ldx, W, ldw, K, Adown, Bup, T, Ts are HOST arrays of ng entries.  Returns 100 when (M, N) does not fit one chip-wide
+ * round of a wave-specialised tile (caller: chained aql_lora_gemm_fused launches).                                          */
+int aql_lora_gemm_fused_kgroups(int ng, const void* const* X, const long* ldx, const void* const* W, const long* ldw,
+                                const int* K, const void* const* Adown, const void* const* Bup, long M, int N, const bf16_t* S,
+                                int rows_per_sample, const bf16_t* residual, long ldr, bf16_t* Y, long ldy, void* const* T,
+                                void* const* Ts, aql_stream_t stream);
 /* n <= 32 rank-32 "down" products with a common row count in one launch: T[i] = X[i].A[i]^T, Ts[i] = T[i] * S[m / rps]
  * (X[i] [M,K[i]] dense, A[i] [32,K[i]]; X, A, K are HOST arrays; T, Ts [n][M][32]).  The backward of the grouped text-state
  * k|v projections: dTs = dY.Bup, dT = dTs * S (utils/lora_modules.py:13-17 transposed) for all 32 sites at once.        */

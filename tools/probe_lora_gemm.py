@@ -80,4 +80,42 @@ for M, K, widths, nb in [(8192, 320, (320, 320, 320), 4), (616, 768, (320, 320, 
     ok = same and worst < 1.5e-2
     ok_all &= ok
     print(f"{'PASS' if ok else 'FAIL'} lora_gemm_grouped M{M} K{K} groups{widths}: equals the separate launches {same}, vs fp32 {worst:.2e}")
+# K-grouped form (aql_lora_gemm_fused_kgroups): up to 3 LoRA linears summed into one output (q | k | v backward-data)
+for (M, N, Ks, nb, res) in [(16384, 320, (320, 320, 320), 4, False), (4096, 640, (640, 640, 640), 4, True),
+                            (1000, 1280, (1280, 1280, 1280), 2, False), (4000, 640, (640, 320), 4, False), (512, 320, (320, 320, 320), 2, False)]:
+    G = len(Ks)
+    rps = (M + nb - 1) // nb
+    Xs = [rnd(M, k) for k in Ks]
+    Ws = [rnd(N, k, std=k ** -0.5) for k in Ks]
+    As = [rnd(32, k, std=k ** -0.5) for k in Ks]
+    Bs = [rnd(N, 32, std=0.2) for _ in Ks]
+    S = rnd(nb, 32)
+    R = rnd(M, N) if res else None
+    Y = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    T = torch.empty(G, M, 32, dtype=torch.bfloat16, device=dev)
+    Ts = torch.empty_like(T)
+    vp, lp_, ip = ctypes.c_void_p * G, ctypes.c_long * G, ctypes.c_int * G
+    rc = L.call_raw("aql_lora_gemm_fused_kgroups", G, vp(*[t.data_ptr() for t in Xs]), lp_(*Ks), vp(*[t.data_ptr() for t in Ws]), lp_(*Ks),
+                    ip(*Ks), vp(*[t.data_ptr() for t in As]), vp(*[t.data_ptr() for t in Bs]), M, N, L.ptr(S), rps, L.ptr(R),
+                    0 if R is None else N, L.ptr(Y), N, vp(*[T[g].data_ptr() for g in range(G)]), vp(*[Ts[g].data_ptr() for g in range(G)]),
+                    L.stream_ptr())
+    if rc == 100:
+        print(f"PASS lora_gemm_kgroups M{M} N{N} K{Ks}: no one-round tile, routed to the chained launches (rc=100)")
+        continue
+    L.check(rc, "aql_lora_gemm_fused_kgroups")
+    rows = torch.arange(M, device=dev) // rps
+    Yr = torch.zeros(M, N, device=dev)
+    worst_t = 0.0
+    for g in range(G):
+        Tf = Xs[g].float() @ As[g].float().t()
+        Tb = Tf.to(torch.bfloat16).float()
+        Tsb = (Tb * S.float()[rows]).to(torch.bfloat16).float()
+        Yr += Xs[g].float() @ Ws[g].float().t() + Tsb @ Bs[g].float().t()
+        worst_t = max(worst_t, rel(T[g], Tf), rel(Ts[g], Tsb))
+    if R is not None:
+        Yr += R.float()
+    e = rel(Y, Yr)
+    ok = e < 1.5e-2 and worst_t < 1.5e-2
+    ok_all &= ok
+    print(f"{'PASS' if ok else 'FAIL'} lora_gemm_kgroups M{M} N{N} K{Ks} res={res}: Y vs fp32 {e:.2e}, T / Ts {worst_t:.2e}")
 print("ALL PASS" if ok_all else "SOME FAILED")
