@@ -385,8 +385,8 @@ def wrap_pixel_text(runner, args, device, rank_id, pixel, text):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, choices=[2, 3],
                     help="BASELINE.json config: 2 = rank 32, batch 4/GPU (the headline, 1 GPU); 3 = rank 320, batch 8/GPU "
                          "(the 8-GPU DDP recipe, train/README.md:34-48); --rank / --batch override")
