@@ -13,9 +13,9 @@ from tests.conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _run(script):
+def _run(script, env=None):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script)], capture_output=True, text=True,
-                         timeout=900)
+                         timeout=900, env=None if env is None else {**os.environ, **env})
     text = out.stdout + out.stderr
     fails = [l for l in text.splitlines() if l.startswith("FAIL")]
     assert out.returncode == 0 and "ALL PASS" in text and not fails, "\n".join(fails[:20]) or text[-2000:]
@@ -24,6 +24,13 @@ def _run(script):
 
 def test_gemm_family_parity():
     text = _run("probe_gemm.py")
+    assert text.count("PASS") >= 30
+
+
+def test_gemm_family_parity_on_the_12_wave_256x160_kernel():
+    """The picker takes the 256x160 kernel only for grids of one chip-wide round (the batch-4 twin forward); AQL_TILE=14 forces
+    it on every 160-wide shape of the sweep (ragged M, split-K, conv forward / backward-data, residual / row-bias epilogues)."""
+    text = _run("probe_gemm.py", {"AQL_TILE": "14"})
     assert text.count("PASS") >= 30
 
 
