@@ -1,0 +1,205 @@
+// Row-tile form of the 12-wave 3x3 convolution kernel (stride 1, pad 1, 64-pixel-wide maps, Cin % 64 == 0): the forward
+// convolutions of the 64x64 level of the U-Net (scripts/lib/original_unet.py ResnetBlock2D conv1 / conv2 as reached from the
+// PPFT step, train/ppft_train.py:1026-1035).
+//
+// Why: a per-K-tile timeline of gemm_kernel_w<256,160,...,3,8> (tools/trace_gemm_w256.py, MI355X) shows the K loop at 1960 cycles
+// per tile for 1304 cycles of MFMA per SIMD, and the four loader wavefronts busy the whole time: 13 LDS-DMA instructions per
+// loader thread per tile at ~100 cycles each -- the CU takes ~40 B/clk of global -> LDS traffic, and an implicit-GEMM tile
+// of 256 pixels x 64 channels is fetched again for every one of the 9 taps.  Here the workgroup's output tile is 4 whole image
+// rows; for one (kh, 64-channel slab) it stages the 4 x 66 input pixels ONCE (two zero columns of padding included) and the
+// three kw taps read their A fragments from that tile at a pixel offset of kw: per three K tiles 34 + 3 x 20 KB of DMA instead
+// of 3 x 53 KB, 8 (not 13) DMA instructions per loader thread per tile.  K order: kh outer, channel slab, kw inner (the
+// fp32 accumulation order differs from the tap-major kernels; same products).
+//   LDS: two A tiles (9 x 32 pixel rows x 128 B = 36 KB each) + a 4-stage ring of 160 x 64 weight tiles (20 KB each) = 152 KB.
+//   Loaders, per K tile t = 3 g + kw: [wait] [barrier] [A tile of group g+1: 5 instructions at kw = 0, 4 at kw = 1] [W tile t+3]
+//   with counted vmcnt waits of 10 / 15 / 19 outstanding loads (derivation in DESIGN.md), compute wavefronts: [barrier]
+//   [fragments of tile t] [40 MFMAs].
+#pragma once
+#include "aql_gemm.cuh"
+
+namespace aqlconvrow {
+using namespace aqlgemm;
+
+constexpr int RW = 64;                         // image width
+constexpr int TROWS = 4;                       // image rows per output tile
+constexpr int CR_BM = TROWS * RW, CR_BN = 160, CR_WM = 64, CR_WN = 80;
+constexpr int APX = TROWS * (RW + 2);          // 264 pixel rows in an A tile
+constexpr int A_INSTR = (APX + 31) / 32;       // 9 DMA instructions per loader thread per A tile
+constexpr int ABUF = A_INSTR * 32 * 128;       // 36,864 B
+constexpr int WST = CR_BN * 128;               // 20,480 B
+constexpr int NSTW = 4;
+constexpr int CR_THREADS = 12 * 64;
+
+inline bool conv_row_ok_host(const ConvFwdLoader& l, int N, int splits, int geglu_F) {
+  return l.stride == 1 && l.ups == 0 && l.pad == 1 && l.Win == RW && l.Wout == RW && l.Hin == l.Hout && l.Hin % TROWS == 0 &&
+         l.Cin % 64 == 0 && N % 8 == 0 && splits == 1 && geglu_F == 0;
+}
+
+__global__ __launch_bounds__(CR_THREADS) void conv_row_kernel(const GemmArgs<ConvFwdLoader, PlainLoader> g) {
+  constexpr int FM = CR_WM / 16, FN = CR_WN / 16;
+  constexpr int WAVES_N = CR_BN / CR_WN;
+  constexpr int C_PITCH = (CR_BN + 8) * 2;
+  constexpr int RING = 2 * ABUF + NSTW * WST;
+  constexpr int LDS_BYTES = RING > CR_BM * C_PITCH ? RING : CR_BM * C_PITCH;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+  char* const abuf = lds;
+  char* const wring = lds + 2 * ABUF;
+
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int qq = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
+  const int block_x = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= 8;
+  const int tiles_n = (g.N + CR_BN - 1) / CR_BN, tiles_m = g.M / CR_BM;
+  int tile_m, tile_n;
+  if (g.m_fast) {
+    tile_n = block_x / tiles_m;
+    tile_m = block_x - tile_n * tiles_m;
+  } else {
+    tile_m = block_x / tiles_n;
+    tile_n = block_x - tile_m * tiles_n;
+  }
+  const int m0 = tile_m * CR_BM, n0 = tile_n * CR_BN;
+  const int H = g.a0.Hin, Cin = g.a0.Cin;
+  const int nslab = Cin >> 6;
+  const int NG = 3 * nslab;                       // (kh, slab) groups; 3 K tiles each
+  const int T = 3 * NG;
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  uint2 biasr[FN];
+
+  if (loader) {
+    const int lw = wave - 8;
+    const int ltid = tid - 8 * 64;
+    const int b = m0 / (H * RW), h0 = (m0 - b * H * RW) / RW;
+    __amdgpu_buffer_rsrc_t rsx = make_rsrc(g.a0.base), rsw = make_rsrc(g.b0.base);
+    // A tile: instruction j stages pixel rows 32 j .. 32 j + 31; this lane: row 32 j + (ltid >> 3), 16-byte slot ltid & 7
+    uint32_t abase[A_INSTR];
+    int arh[A_INSTR];           // input image row of the pixel for kh = 0 (h0 + r - 1), or a value that never passes the test
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) {
+      const int p = 32 * j + (ltid >> 3);
+      const int r = p / (RW + 2), wc = p - r * (RW + 2) - 1;
+      const int kc = ((ltid & 7) ^ ((p >> 1) & 7)) * 8;
+      const bool okc = (p < APX) & (wc >= 0) & (wc < RW);
+      arh[j] = okc ? h0 + r - 1 : -(1 << 20);
+      abase[j] = (uint32_t)((((long)b * H + (h0 + r - 1)) * RW + wc) * Cin + kc) * 2u;
+    }
+    uint32_t wv[CR_BN / 32];
+#pragma unroll
+    for (int i = 0; i < CR_BN / 32; ++i) {
+      const int row = n0 + (ltid >> 3) + 32 * i;
+      const int kc = ((ltid & 7) ^ ((ltid >> 4) & 7)) * 8;
+      wv[i] = row < g.b0.rows ? (uint32_t)row * (uint32_t)(g.b0.ld * 2) + kc * 2 : OOB_ROW;
+    }
+    auto issueA = [&](int gi, int lo, int hi) {   // group gi = kh * nslab + c; instructions [lo, hi)
+      const int kh = gi / nslab, c = gi - kh * nslab;
+      const uint32_t add = (uint32_t)((kh * RW * Cin + c * 64) * 2);
+      char* dst = abuf + (gi & 1) * ABUF;
+      const bool live = gi < NG;
+#pragma unroll
+      for (int j = 0; j < A_INSTR; ++j) {
+        if (j < lo || j >= hi) continue;
+        const bool ok = live & ((unsigned)(arh[j] + kh) < (unsigned)H);
+        dma16(rsx, dst + (32 * j + 8 * lw) * 128, ok ? abase[j] + add : OOB_ROW, 0);
+      }
+    };
+    auto issueW = [&](int t) {   // K tile t = 3 (kh * nslab + c) + kw  ->  weight columns (kh * 3 + kw) * Cin + 64 c
+      const int gi = t / 3, kw = t - gi * 3;
+      const int kh = gi / nslab, c = gi - kh * nslab;
+      const uint32_t soff = (uint32_t)(((kh * 3 + kw) * Cin + c * 64) * 2);
+      char* dst = wring + (t & (NSTW - 1)) * WST;
+      const bool live = t < T;
+#pragma unroll
+      for (int i = 0; i < CR_BN / 32; ++i) dma16(rsw, dst + (32 * i + 8 * lw) * 128, live ? wv[i] : OOB_ROW, live ? soff : 0);
+    };
+    issueA(0, 0, A_INSTR);
+    issueW(0);
+    issueW(1);
+    issueW(2);
+    for (int gi = 0; gi < NG; ++gi) {
+      const int t = 3 * gi;
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // A(gi) and W(t) landed; W(t+1), W(t+2) may be in flight
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issueA(gi + 1, 0, 5);
+      issueW(t + 3);
+      asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   // W(t+1) landed
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issueA(gi + 1, 5, A_INSTR);
+      issueW(t + 4);
+      asm volatile("s_waitcnt vmcnt(19)" ::: "memory");   // W(t+2) landed
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issueW(t + 5);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing zero-fill DMAs still write LDS
+  } else {
+    const int wn0 = (wave % WAVES_N) * CR_WN;
+    epi_load_bias<FN>(biasr, g.epi.bias, g.b0.base, n0, wn0, lane, g.N, 0, CR_BN / 2);
+    // this wavefront's 64 pixels are image row (wave / WAVES_N) of the tile: A-tile pixel row = r (RW + 2) + w + kw
+    const int prow0 = (wave / WAVES_N) * (RW + 2) + (lane & 15);
+    const int brow = wn0 + (lane & 15);
+    const int g4 = lane >> 4;
+    for (int gi = 0; gi < NG; ++gi) {
+      const char* sA = abuf + (gi & 1) * ABUF;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int t = 3 * gi + kw;
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* sB = wring + (t & (NSTW - 1)) * WST;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int chunk = ks * 4 + g4;
+          bf16x8_t fa[FM], fb[FN];
+#pragma unroll
+          for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(prow0 + i * 16 + kw, chunk));
+#pragma unroll
+          for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(brow + j * 16, chunk));
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue (as gemm_body_w): bias in fp32, bf16 tile through LDS, row bias / residual in the store loop
+  const EpiParams& ep = g.epi;
+  if (!loader) {
+    const int wm0 = (wave / WAVES_N) * CR_WM, wn0 = (wave % WAVES_N) * CR_WN;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int row = wm0 + i * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int col = wn0 + j * 16 + (lane >> 4) * 4;
+        float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+        v0 += bf16lo(biasr[j].x);
+        v1 += bf16hi(biasr[j].x);
+        v2 += bf16lo(biasr[j].y);
+        v3 += bf16hi(biasr[j].y);
+        *reinterpret_cast<uint2*>(lds + row * C_PITCH + col * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+      }
+    }
+  }
+  __syncthreads();
+  epi_store_tile<CR_BM, CR_BN, C_PITCH, CR_THREADS>(lds, m0, n0, g.M, g.N, ep, tid);
+}
+
+inline void launch_conv_row(const GemmArgs<ConvFwdLoader, PlainLoader>& g, hipStream_t stream) {
+  dim3 grid((g.M / CR_BM) * aql_cdiv(g.N, CR_BN));
+  hipLaunchKernelGGL(conv_row_kernel, grid, dim3(CR_THREADS), 0, stream, g);
+}
+
+}  // namespace aqlconvrow

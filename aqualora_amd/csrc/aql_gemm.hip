@@ -2,6 +2,7 @@
 // contract of every symbol and the reference interface (file:line) it replaces.
 #include <type_traits>
 #include "aql_gemm.cuh"
+#include "aql_conv_row.cuh"
 #include <stdarg.h>
 #include <stdlib.h>
 
@@ -176,6 +177,12 @@ void launch_cfg(int cfg, int pd, const GemmArgs<LA, LB>& g, hipStream_t stream) 
         if (abl == 9) return launch_gemm_d<64, 160, 32, 80, LA, LB, EPI, 2, 9>(g, stream);
         return launch_gemm_d<64, 160, 32, 80, LA, LB, EPI, 2, 4>(g, stream);
       }
+    }
+    if constexpr (std::is_same<LA, ConvFwdLoader>::value && std::is_same<LB, PlainLoader>::value && EPI == EPI_BF16) {
+      // 64-pixel-wide stride-1 maps: the row-tile form (one A tile per (kh, channel slab) serves the three kw taps)
+      static const int conv_row = env_int("AQL_CONV_ROW", 1);   // A/B hook
+      if (cfg == P_W256x160 && conv_row && aqlconvrow::conv_row_ok_host(g.a0, g.N, g.splits, g.epi.geglu_F))
+        return aqlconvrow::launch_conv_row(g, stream);
     }
     if (cfg == P_W256x160) return launch_gemm_w<256, 160, 64, 80, LA, LB, EPI, 3, 8>(g, stream);
     if (cfg == P_W128x160) return launch_gemm_w<128, 160, 64, 80, LA, LB, EPI, 4>(g, stream);

@@ -90,6 +90,11 @@ conv_case(2, 16, 12, 32, 64, 2, 0)
 conv_case(1, 8, 8, 64, 64, 1, 1)
 conv_case(2, 8, 8, 1280, 1280, 1, 0)
 conv_case(1, 64, 64, 8, 320, 1, 0)
+# 64-pixel-wide stride-1 maps with Cin % 64 == 0: the row-tile kernel (aql_conv_row.cuh) whenever the 256x160 tile is chosen -- forced
+# by AQL_TILE=14 (tests/test_gpu_kernels.py), by itself at 8 x 64 x 64 x 320 outputs (one chip-wide round)
+conv_case(2, 64, 64, 128, 160, 1, 0)
+conv_case(1, 12, 64, 64, 328, 1, 0)
+conv_case(8, 64, 64, 64, 320, 1, 0)
 
 # 5. TN gemm (weight grads)
 for (M, P, Q) in [(4096, 320, 32), (1000, 32, 768), (2048, 640, 320), (308, 1280, 8)]:
