@@ -73,6 +73,12 @@ __global__ __launch_bounds__(CR_THREADS) void conv_row_kernel(const GemmArgs<Con
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   uint2 biasr[FN];
+#ifdef AQL_TRACE_W
+  long* trw = (block_x == 0 && lane == 0 && g.epi.Cf != nullptr) ? reinterpret_cast<long*>(g.epi.Cf) + wave * 1024 : nullptr;
+#define CRT(i, slot) do { if (trw && (i) < 255) trw[(i) * 4 + (slot)] = clock64(); } while (0)
+#else
+#define CRT(i, slot) do { } while (0)
+#endif
 
   if (loader) {
     const int lw = wave - 8;
@@ -123,54 +129,96 @@ __global__ __launch_bounds__(CR_THREADS) void conv_row_kernel(const GemmArgs<Con
     issueW(0);
     issueW(1);
     issueW(2);
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");     // A(0), W(0) landed
+    __builtin_amdgcn_s_barrier();                         // pre: the compute wavefronts fetch the first fragments
     for (int gi = 0; gi < NG; ++gi) {
       const int t = 3 * gi;
-      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // A(gi) and W(t) landed; W(t+1), W(t+2) may be in flight
+      CRT(t, 0);
+      // barrier(t) certifies that tile t+1 has landed (the compute wavefronts prefetch its first k-half during tile t) and that
+      // nobody reads tile t-1 any more.  Outstanding loads allowed at each wait, in issue order (A part before W tile in an iteration):
+      //   t = 3g  : W(t+2) of iteration t-1                                    ->  5
+      //   t = 3g+1: A(g+1) part 1 + W(t+2) of iteration t-1                    -> 10
+      //   t = 3g+2: W(t+2) of iteration t-1 (its A part 2 must have landed)    ->  5
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      CRT(t, 1);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      CRT(t, 2);
       issueA(gi + 1, 0, 5);
       issueW(t + 3);
-      asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   // W(t+1) landed
+      CRT(t, 3);
+      CRT(t + 1, 0);
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      CRT(t + 1, 1);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      CRT(t + 1, 2);
       issueA(gi + 1, 5, A_INSTR);
       issueW(t + 4);
-      asm volatile("s_waitcnt vmcnt(19)" ::: "memory");   // W(t+2) landed
+      CRT(t + 1, 3);
+      CRT(t + 2, 0);
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      CRT(t + 2, 1);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      CRT(t + 2, 2);
       issueW(t + 5);
+      CRT(t + 2, 3);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing zero-fill DMAs still write LDS
   } else {
     const int wn0 = (wave % WAVES_N) * CR_WN;
-    epi_load_bias<FN>(biasr, g.epi.bias, g.b0.base, n0, wn0, lane, g.N, 0, CR_BN / 2);
     // this wavefront's 64 pixels are image row (wave / WAVES_N) of the tile: A-tile pixel row = r (RW + 2) + w + kw
     const int prow0 = (wave / WAVES_N) * (RW + 2) + (lane & 15);
     const int brow = wn0 + (lane & 15);
     const int g4 = lane >> 4;
+    const int ch0 = g4, ch1 = 4 + g4;
+    bf16x8_t fa0[FM], fb0[FN], fa1[FM], fb1[FN];
+    __builtin_amdgcn_s_barrier();   // pre
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < FN; ++j) fb0[j] = *reinterpret_cast<const bf16x8_t*>(wring + lds_off(brow + j * 16, ch0));
+#pragma unroll
+    for (int i = 0; i < FM; ++i) fa0[i] = *reinterpret_cast<const bf16x8_t*>(abuf + lds_off(prow0 + i * 16, ch0));
     for (int gi = 0; gi < NG; ++gi) {
       const char* sA = abuf + (gi & 1) * ABUF;
+      const char* sAn = abuf + ((gi + 1) & 1) * ABUF;
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int t = 3 * gi + kw;
+        CRT(t, 0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        CRT(t, 1);
+        CRT(t, 2);
         const char* sB = wring + (t & (NSTW - 1)) * WST;
+        const char* nB = wring + ((t + 1) & (NSTW - 1)) * WST;
+        const char* nA = kw < 2 ? sA : sAn;          // A tile and pixel offset of K tile t+1
+        const int nkw = kw < 2 ? kw + 1 : 0;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int chunk = ks * 4 + g4;
-          bf16x8_t fa[FM], fb[FN];
+        for (int j = 0; j < FN; ++j) fb1[j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(brow + j * 16, ch1));
 #pragma unroll
-          for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(prow0 + i * 16 + kw, chunk));
+        for (int i = 0; i < FM; ++i) fa1[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(prow0 + i * 16 + kw, ch1));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(brow + j * 16, chunk));
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-          for (int i = 0; i < FM; ++i)
+          for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < FN; ++j) fb0[j] = *reinterpret_cast<const bf16x8_t*>(nB + lds_off(brow + j * 16, ch0));
+#pragma unroll
+        for (int i = 0; i < FM; ++i) fa0[i] = *reinterpret_cast<const bf16x8_t*>(nA + lds_off(prow0 + i * 16 + nkw, ch0));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    // (after the loop: five batched loads, one round trip per workgroup; held across the loop they spilled)
+    epi_load_bias<FN>(biasr, g.epi.bias, g.b0.base, n0, wn0, lane, g.N, 0, CR_BN / 2);
   }
   __syncthreads();
 

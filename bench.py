@@ -94,7 +94,7 @@ def dominant_kernels(B, device):
             ms = time_kernel(lambda: ops.conv3x3(x, pk))
         fl = 2.0 * nb * 64 * 64 * 320 * 9 * 320
         # 2B samples: 256 tiles of 256x160 on the 12-wave kernel (one chip-wide round); B samples: 256 tiles of 128x160, 8 waves
-        kname = ("gemm_kernel_w<256,160,64,80,ConvFwdLoader,PlainLoader,EPI_BF16,3,8>" if nb * 4096 // 256 * 2 in range(240, 257)
+        kname = ("conv_row_kernel (256x160 row tile, 12 waves)" if nb * 4096 // 256 * 2 in range(240, 257)
                  else "gemm_kernel_w<128,160,64,80,ConvFwdLoader,PlainLoader,EPI_BF16,4>")
         out.append({"kernel": f"{kname} conv3x3 320->320 @64x64, {nb} samples ({tag})",
                     "ms": ms, "samples": nb, "flops": fl, "achieved_tflops": fl / ms / 1e9, "frac_of_mfma_peak": fl / ms / 1e9 / MFMA_PEAK_TF})
