@@ -181,7 +181,7 @@ void launch_cfg(int cfg, int pd, const GemmArgs<LA, LB>& g, hipStream_t stream) 
     if constexpr (std::is_same<LA, ConvFwdLoader>::value && std::is_same<LB, PlainLoader>::value && EPI == EPI_BF16) {
       // 64-pixel-wide stride-1 maps: the row-tile form (one A tile per (kh, channel slab) serves the three kw taps)
       static const int conv_row = env_int("AQL_CONV_ROW", 1);   // A/B hook
-      static const int conv_row_rounds = env_int("AQL_CONV_ROW_ROUNDS", 1);   // tuning hook: grids of up to this many whole rounds
+      static const int conv_row_rounds = env_int("AQL_CONV_ROW_ROUNDS", 2);   // grids of up to this many whole chip-wide rounds (config 3: 50.8 -> 50.4 ms with 2)
       const int t256 = (g.M / 256) * aql_cdiv(g.N, 160);
       const bool rounds_ok = cfg == P_W256x160 || (g.M % 256 == 0 && t256 % 256 == 0 && t256 / 256 <= conv_row_rounds);
       if (rounds_ok && conv_row && aqlconvrow::conv_row_ok_host(g.a0, g.N, g.splits, g.epi.geglu_F))
