@@ -12,8 +12,8 @@
 // fp32 accumulation order differs from the tap-major kernels; same products).
 //   LDS: two A tiles (9 x 32 pixel rows x 128 B = 36 KB each) + a 4-stage ring of 160 x 64 weight tiles (20 KB each) = 152 KB.
 //   Loaders, per K tile t = 3 g + kw: [wait] [barrier] [A tile of group g+1: 5 instructions at kw = 0, 4 at kw = 1] [W tile t+3]
-//   with counted vmcnt waits of 10 / 15 / 19 outstanding loads (derivation in DESIGN.md), compute wavefronts: [barrier]
-//   [fragments of tile t] [40 MFMAs].
+//   with counted vmcnt waits of 5 / 10 / 5 outstanding loads (derivation in DESIGN.md, section 4), compute wavefronts: [barrier]
+//   [second k-half fragments of tile t] [20 MFMAs] [first k-half fragments of tile t+1] [20 MFMAs].
 #pragma once
 #include "aql_gemm.cuh"
 
