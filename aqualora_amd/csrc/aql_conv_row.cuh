@@ -20,22 +20,38 @@
 namespace aqlconvrow {
 using namespace aqlgemm;
 
-constexpr int RW = 64;                         // image width
-constexpr int TROWS = 4;                       // image rows per output tile
-constexpr int CR_BM = TROWS * RW, CR_BN = 160, CR_WM = 64, CR_WN = 80;
-constexpr int APX = TROWS * (RW + 2);          // 264 pixel rows in an A tile
-constexpr int A_INSTR = (APX + 31) / 32;       // 9 DMA instructions per loader thread per A tile
-constexpr int ABUF = A_INSTR * 32 * 128;       // 36,864 B
-constexpr int WST = CR_BN * 128;               // 20,480 B
+constexpr int CR_BN = 160, CR_WM = 64, CR_WN = 80;
+constexpr int WST = CR_BN * 128;               // 20,480 B per weight tile
 constexpr int NSTW = 4;
-constexpr int CR_THREADS = 12 * 64;
+constexpr int NW = CR_BN / 32;                 // DMA instructions per loader thread per weight tile
 
-inline bool conv_row_ok_host(const ConvFwdLoader& l, int N, int splits, int geglu_F) {
-  return l.stride == 1 && l.ups == 0 && l.pad == 1 && l.Win == RW && l.Wout == RW && l.Hin == l.Hout && l.Hin % TROWS == 0 &&
-         l.Cin % 64 == 0 && N % 8 == 0 && splits == 1 && geglu_F == 0;
-}
+// What the kernel needs of the convolution (forward: ConvFwdLoader, backward-data: ConvBwdLoader with the taps flipped)
+struct RowArgs {
+  const bf16_t* x;      // [B][H][RW][C] channels-last input (forward) / output gradient (backward-data)
+  int H, C;             // image rows, contraction channels
+  PlainLoader w;        // [N][9 C] weights, column (kh*3+kw)*C + c
+  int M, N, m_fast;
+  EpiParams epi;
+};
 
-__global__ __launch_bounds__(CR_THREADS) void conv_row_kernel(const GemmArgs<ConvFwdLoader, PlainLoader> g) {
+// RW = image width, TROWS = image rows per output tile (BM = RW * TROWS = 256: 8 compute wavefronts, 128: 4), FLIP = backward-data
+// (tap (kh, kw) reads pixel (h + 1 - kh, w + 1 - kw) of dY; forward: (h + kh - 1, w + kw - 1)).
+template <int RW, int TROWS, bool FLIP>
+struct RowCfg {
+  static constexpr int BM = RW * TROWS;
+  static constexpr int NCW = BM / 64 * 2;
+  static constexpr int THREADS = (NCW + 4) * 64;
+  static constexpr int APX = TROWS * (RW + 2);
+  static constexpr int A_INSTR = (APX + 31) / 32;
+  static constexpr int P1 = (A_INSTR + 1) / 2, P2 = A_INSTR - P1;   // A instructions issued at kw = 0 / kw = 1
+  static constexpr int ABUF = A_INSTR * 32 * 128;
+};
+
+template <int RW, int TROWS, bool FLIP>
+__global__ __launch_bounds__((RowCfg<RW, TROWS, FLIP>::THREADS)) void conv_row_kernel(const RowArgs g) {
+  using CFG = RowCfg<RW, TROWS, FLIP>;
+  constexpr int CR_BM = CFG::BM, NCW = CFG::NCW, CR_THREADS = CFG::THREADS, APX = CFG::APX, A_INSTR = CFG::A_INSTR, ABUF = CFG::ABUF;
+  constexpr int P1 = CFG::P1;
   constexpr int FM = CR_WM / 16, FN = CR_WN / 16;
   constexpr int WAVES_N = CR_BN / CR_WN;
   constexpr int C_PITCH = (CR_BN + 8) * 2;
@@ -51,7 +67,7 @@ __global__ __launch_bounds__(CR_THREADS) void conv_row_kernel(const GemmArgs<Con
   const int block_x = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool loader = wave >= 8;
+  const bool loader = wave >= NCW;
   const int tiles_n = (g.N + CR_BN - 1) / CR_BN, tiles_m = g.M / CR_BM;
   int tile_m, tile_n;
   if (g.m_fast) {
@@ -62,7 +78,7 @@ __global__ __launch_bounds__(CR_THREADS) void conv_row_kernel(const GemmArgs<Con
     tile_n = block_x - tile_m * tiles_n;
   }
   const int m0 = tile_m * CR_BM, n0 = tile_n * CR_BN;
-  const int H = g.a0.Hin, Cin = g.a0.Cin;
+  const int H = g.H, Cin = g.C;
   const int nslab = Cin >> 6;
   const int NG = 3 * nslab;                       // (kh, slab) groups; 3 K tiles each
   const int T = 3 * NG;
@@ -81,10 +97,10 @@ __global__ __launch_bounds__(CR_THREADS) void conv_row_kernel(const GemmArgs<Con
 #endif
 
   if (loader) {
-    const int lw = wave - 8;
-    const int ltid = tid - 8 * 64;
+    const int lw = wave - NCW;
+    const int ltid = tid - NCW * 64;
     const int b = m0 / (H * RW), h0 = (m0 - b * H * RW) / RW;
-    __amdgpu_buffer_rsrc_t rsx = make_rsrc(g.a0.base), rsw = make_rsrc(g.b0.base);
+    __amdgpu_buffer_rsrc_t rsx = make_rsrc(g.x), rsw = make_rsrc(g.w.base);
     // A tile: instruction j stages pixel rows 32 j .. 32 j + 31; this lane: row 32 j + (ltid >> 3), 16-byte slot ltid & 7
     uint32_t abase[A_INSTR];
     int arh[A_INSTR];           // input image row of the pixel for kh = 0 (h0 + r - 1), or a value that never passes the test
@@ -102,17 +118,18 @@ __global__ __launch_bounds__(CR_THREADS) void conv_row_kernel(const GemmArgs<Con
     for (int i = 0; i < CR_BN / 32; ++i) {
       const int row = n0 + (ltid >> 3) + 32 * i;
       const int kc = ((ltid & 7) ^ ((ltid >> 4) & 7)) * 8;
-      wv[i] = row < g.b0.rows ? (uint32_t)row * (uint32_t)(g.b0.ld * 2) + kc * 2 : OOB_ROW;
+      wv[i] = row < g.w.rows ? (uint32_t)row * (uint32_t)(g.w.ld * 2) + kc * 2 : OOB_ROW;
     }
     auto issueA = [&](int gi, int lo, int hi) {   // group gi = kh * nslab + c; instructions [lo, hi)
       const int kh = gi / nslab, c = gi - kh * nslab;
-      const uint32_t add = (uint32_t)((kh * RW * Cin + c * 64) * 2);
+      const int khe = FLIP ? 2 - kh : kh;          // image-row offset of the tap, plus one
+      const uint32_t add = (uint32_t)((khe * RW * Cin + c * 64) * 2);
       char* dst = abuf + (gi & 1) * ABUF;
       const bool live = gi < NG;
 #pragma unroll
       for (int j = 0; j < A_INSTR; ++j) {
         if (j < lo || j >= hi) continue;
-        const bool ok = live & ((unsigned)(arh[j] + kh) < (unsigned)H);
+        const bool ok = live & ((unsigned)(arh[j] + khe) < (unsigned)H);
         dma16(rsx, dst + (32 * j + 8 * lw) * 128, ok ? abase[j] + add : OOB_ROW, 0);
       }
     };
@@ -129,35 +146,35 @@ __global__ __launch_bounds__(CR_THREADS) void conv_row_kernel(const GemmArgs<Con
     issueW(0);
     issueW(1);
     issueW(2);
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");     // A(0), W(0) landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NW) : "memory");     // A(0), W(0) landed
     __builtin_amdgcn_s_barrier();                         // pre: the compute wavefronts fetch the first fragments
     for (int gi = 0; gi < NG; ++gi) {
       const int t = 3 * gi;
       CRT(t, 0);
       // barrier(t) certifies that tile t+1 has landed (the compute wavefronts prefetch its first k-half during tile t) and that
       // nobody reads tile t-1 any more.  Outstanding loads allowed at each wait, in issue order (A part before W tile in an iteration):
-      //   t = 3g  : W(t+2) of iteration t-1                                    ->  5
-      //   t = 3g+1: A(g+1) part 1 + W(t+2) of iteration t-1                    -> 10
-      //   t = 3g+2: W(t+2) of iteration t-1 (its A part 2 must have landed)    ->  5
-      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      //   t = 3g  : W(t+2) of iteration t-1                                    -> NW
+      //   t = 3g+1: A(g+1) part 1 + W(t+2) of iteration t-1                    -> P1 + NW
+      //   t = 3g+2: W(t+2) of iteration t-1 (its A part 2 must have landed)    -> NW
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
       CRT(t, 1);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       CRT(t, 2);
-      issueA(gi + 1, 0, 5);
+      issueA(gi + 1, 0, P1);
       issueW(t + 3);
       CRT(t, 3);
       CRT(t + 1, 0);
-      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P1 + NW) : "memory");
       CRT(t + 1, 1);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       CRT(t + 1, 2);
-      issueA(gi + 1, 5, A_INSTR);
+      issueA(gi + 1, P1, A_INSTR);
       issueW(t + 4);
       CRT(t + 1, 3);
       CRT(t + 2, 0);
-      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
       CRT(t + 2, 1);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -168,8 +185,14 @@ __global__ __launch_bounds__(CR_THREADS) void conv_row_kernel(const GemmArgs<Con
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing zero-fill DMAs still write LDS
   } else {
     const int wn0 = (wave % WAVES_N) * CR_WN;
-    // this wavefront's 64 pixels are image row (wave / WAVES_N) of the tile: A-tile pixel row = r (RW + 2) + w + kw
-    const int prow0 = (wave / WAVES_N) * (RW + 2) + (lane & 15);
+    // this wavefront's 64 pixels: tile pixels (wave / WAVES_N) * 64 ..; a 16-pixel fragment lies inside one image row (RW >= 16):
+    // A-tile pixel row of pixel (r, w) for tap kw = r (RW + 2) + w + kw  (backward-data: + 2 - kw)
+    int prow[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int pt = (wave / WAVES_N) * CR_WM + i * 16 + (lane & 15);
+      prow[i] = (pt / RW) * (RW + 2) + pt % RW;
+    }
     const int brow = wn0 + (lane & 15);
     const int g4 = lane >> 4;
     const int ch0 = g4, ch1 = 4 + g4;
@@ -179,7 +202,7 @@ __global__ __launch_bounds__(CR_THREADS) void conv_row_kernel(const GemmArgs<Con
 #pragma unroll
     for (int j = 0; j < FN; ++j) fb0[j] = *reinterpret_cast<const bf16x8_t*>(wring + lds_off(brow + j * 16, ch0));
 #pragma unroll
-    for (int i = 0; i < FM; ++i) fa0[i] = *reinterpret_cast<const bf16x8_t*>(abuf + lds_off(prow0 + i * 16, ch0));
+    for (int i = 0; i < FM; ++i) fa0[i] = *reinterpret_cast<const bf16x8_t*>(abuf + lds_off(prow[i] + (FLIP ? 2 : 0), ch0));
     for (int gi = 0; gi < NG; ++gi) {
       const char* sA = abuf + (gi & 1) * ABUF;
       const char* sAn = abuf + ((gi + 1) & 1) * ABUF;
@@ -195,10 +218,11 @@ __global__ __launch_bounds__(CR_THREADS) void conv_row_kernel(const GemmArgs<Con
         const char* nB = wring + ((t + 1) & (NSTW - 1)) * WST;
         const char* nA = kw < 2 ? sA : sAn;          // A tile and pixel offset of K tile t+1
         const int nkw = kw < 2 ? kw + 1 : 0;
+        const int po = FLIP ? 2 - kw : kw, npo = FLIP ? 2 - nkw : nkw;   // pixel offsets of tile t / t+1
 #pragma unroll
         for (int j = 0; j < FN; ++j) fb1[j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(brow + j * 16, ch1));
 #pragma unroll
-        for (int i = 0; i < FM; ++i) fa1[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(prow0 + i * 16 + kw, ch1));
+        for (int i = 0; i < FM; ++i) fa1[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(prow[i] + po, ch1));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < FM; ++i)
@@ -208,7 +232,7 @@ __global__ __launch_bounds__(CR_THREADS) void conv_row_kernel(const GemmArgs<Con
 #pragma unroll
         for (int j = 0; j < FN; ++j) fb0[j] = *reinterpret_cast<const bf16x8_t*>(nB + lds_off(brow + j * 16, ch0));
 #pragma unroll
-        for (int i = 0; i < FM; ++i) fa0[i] = *reinterpret_cast<const bf16x8_t*>(nA + lds_off(prow0 + i * 16 + nkw, ch0));
+        for (int i = 0; i < FM; ++i) fa0[i] = *reinterpret_cast<const bf16x8_t*>(nA + lds_off(prow[i] + npo, ch0));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < FM; ++i)
@@ -218,7 +242,7 @@ __global__ __launch_bounds__(CR_THREADS) void conv_row_kernel(const GemmArgs<Con
       }
     }
     // (after the loop: five batched loads, one round trip per workgroup; held across the loop they spilled)
-    epi_load_bias<FN>(biasr, g.epi.bias, g.b0.base, n0, wn0, lane, g.N, 0, CR_BN / 2);
+    epi_load_bias<FN>(biasr, g.epi.bias, g.w.base, n0, wn0, lane, g.N, 0, CR_BN / 2);
   }
   __syncthreads();
 
@@ -245,9 +269,34 @@ __global__ __launch_bounds__(CR_THREADS) void conv_row_kernel(const GemmArgs<Con
   epi_store_tile<CR_BM, CR_BN, C_PITCH, CR_THREADS>(lds, m0, n0, g.M, g.N, ep, tid);
 }
 
-inline void launch_conv_row(const GemmArgs<ConvFwdLoader, PlainLoader>& g, hipStream_t stream) {
-  dim3 grid((g.M / CR_BM) * aql_cdiv(g.N, CR_BN));
-  hipLaunchKernelGGL(conv_row_kernel, grid, dim3(CR_THREADS), 0, stream, g);
+template <int RW, int TROWS, bool FLIP>
+inline void launch_conv_row(const RowArgs& a, hipStream_t stream) {
+  using CFG = RowCfg<RW, TROWS, FLIP>;
+  dim3 grid((a.M / CFG::BM) * aql_cdiv(a.N, CR_BN));
+  hipLaunchKernelGGL((conv_row_kernel<RW, TROWS, FLIP>), grid, dim3(CFG::THREADS), 0, stream, a);
+}
+
+// bm = 256 or 128 (the tile height the picker chose).  Returns false when the convolution does not fit a row tile.
+template <class LA>
+inline bool try_conv_row(const GemmArgs<LA, PlainLoader>& g, int bm, hipStream_t stream) {
+  constexpr bool FLIP = std::is_same<LA, ConvBwdLoader>::value;
+  const auto& l = g.a0;
+  int H, W, C;
+  if constexpr (FLIP) {
+    if (l.stride != 1 || l.Hin != l.Hout || l.Win != l.Wout) return false;
+    H = l.Hin, W = l.Win, C = l.Cout;
+  } else {
+    if (l.stride != 1 || l.ups != 0 || l.pad != 1 || l.Hin != l.Hout || l.Win != l.Wout) return false;
+    H = l.Hin, W = l.Win, C = l.Cin;
+  }
+  if (C % 64 != 0 || g.N % 8 != 0 || g.splits != 1 || g.epi.geglu_F != 0 || g.ktiles1 != 0) return false;
+  RowArgs a;
+  a.x = l.base, a.H = H, a.C = C, a.w = g.b0, a.M = g.M, a.N = g.N, a.m_fast = g.m_fast, a.epi = g.epi;
+  if (bm == 256 && W == 64 && H % 4 == 0) launch_conv_row<64, 4, FLIP>(a, stream);
+  else if (bm == 128 && W == 64 && H % 2 == 0) launch_conv_row<64, 2, FLIP>(a, stream);
+  else if (bm == 128 && W == 32 && H % 4 == 0) launch_conv_row<32, 4, FLIP>(a, stream);
+  else return false;
+  return true;
 }
 
 }  // namespace aqlconvrow
