@@ -16,6 +16,7 @@
 //   [second k-half fragments of tile t] [20 MFMAs] [first k-half fragments of tile t+1] [20 MFMAs].
 #pragma once
 #include "aql_gemm.cuh"
+#include <stdlib.h>
 
 namespace aqlconvrow {
 using namespace aqlgemm;
@@ -31,6 +32,7 @@ struct RowArgs {
   int H, C;             // image rows, contraction channels
   PlainLoader w;        // [N][9 C] weights, column (kh*3+kw)*C + c
   int M, N, m_fast;
+  int splits;           // grid.z: the (kh, slab) groups are divided evenly; > 1 only with the fp32 slab epilogue
   EpiParams epi;
 };
 
@@ -47,7 +49,7 @@ struct RowCfg {
   static constexpr int ABUF = A_INSTR * 32 * 128;
 };
 
-template <int RW, int TROWS, bool FLIP>
+template <int RW, int TROWS, bool FLIP, bool SLAB>
 __global__ __launch_bounds__((RowCfg<RW, TROWS, FLIP>::THREADS)) void conv_row_kernel(const RowArgs g) {
   using CFG = RowCfg<RW, TROWS, FLIP>;
   constexpr int CR_BM = CFG::BM, NCW = CFG::NCW, CR_THREADS = CFG::THREADS, APX = CFG::APX, A_INSTR = CFG::A_INSTR, ABUF = CFG::ABUF;
@@ -80,7 +82,9 @@ __global__ __launch_bounds__((RowCfg<RW, TROWS, FLIP>::THREADS)) void conv_row_k
   const int m0 = tile_m * CR_BM, n0 = tile_n * CR_BN;
   const int H = g.H, Cin = g.C;
   const int nslab = Cin >> 6;
-  const int NG = 3 * nslab;                       // (kh, slab) groups; 3 K tiles each
+  const int NGall = 3 * nslab;                    // (kh, slab) groups; 3 K tiles each
+  const int ga = (int)(((long)NGall * blockIdx.z) / g.splits);          // this split's groups [ga, NG)
+  const int NG = (int)(((long)NGall * (blockIdx.z + 1)) / g.splits);
   const int T = 3 * NG;
 
   f32x4_t acc[FM][FN];
@@ -142,13 +146,13 @@ __global__ __launch_bounds__((RowCfg<RW, TROWS, FLIP>::THREADS)) void conv_row_k
 #pragma unroll
       for (int i = 0; i < CR_BN / 32; ++i) dma16(rsw, dst + (32 * i + 8 * lw) * 128, live ? wv[i] : OOB_ROW, live ? soff : 0);
     };
-    issueA(0, 0, A_INSTR);
-    issueW(0);
-    issueW(1);
-    issueW(2);
+    issueA(ga, 0, A_INSTR);
+    issueW(3 * ga);
+    issueW(3 * ga + 1);
+    issueW(3 * ga + 2);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NW) : "memory");     // A(0), W(0) landed
     __builtin_amdgcn_s_barrier();                         // pre: the compute wavefronts fetch the first fragments
-    for (int gi = 0; gi < NG; ++gi) {
+    for (int gi = ga; gi < NG; ++gi) {
       const int t = 3 * gi;
       CRT(t, 0);
       // barrier(t) certifies that tile t+1 has landed (the compute wavefronts prefetch its first k-half during tile t) and that
@@ -200,10 +204,10 @@ __global__ __launch_bounds__((RowCfg<RW, TROWS, FLIP>::THREADS)) void conv_row_k
     __builtin_amdgcn_s_barrier();   // pre
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < FN; ++j) fb0[j] = *reinterpret_cast<const bf16x8_t*>(wring + lds_off(brow + j * 16, ch0));
+    for (int j = 0; j < FN; ++j) fb0[j] = *reinterpret_cast<const bf16x8_t*>(wring + ((3 * ga) & (NSTW - 1)) * WST + lds_off(brow + j * 16, ch0));
 #pragma unroll
-    for (int i = 0; i < FM; ++i) fa0[i] = *reinterpret_cast<const bf16x8_t*>(abuf + lds_off(prow[i] + (FLIP ? 2 : 0), ch0));
-    for (int gi = 0; gi < NG; ++gi) {
+    for (int i = 0; i < FM; ++i) fa0[i] = *reinterpret_cast<const bf16x8_t*>(abuf + (ga & 1) * ABUF + lds_off(prow[i] + (FLIP ? 2 : 0), ch0));
+    for (int gi = ga; gi < NG; ++gi) {
       const char* sA = abuf + (gi & 1) * ABUF;
       const char* sAn = abuf + ((gi + 1) & 1) * ABUF;
 #pragma unroll
@@ -242,7 +246,24 @@ __global__ __launch_bounds__((RowCfg<RW, TROWS, FLIP>::THREADS)) void conv_row_k
       }
     }
     // (after the loop: five batched loads, one round trip per workgroup; held across the loop they spilled)
-    epi_load_bias<FN>(biasr, g.epi.bias, g.w.base, n0, wn0, lane, g.N, 0, CR_BN / 2);
+    if constexpr (!SLAB) epi_load_bias<FN>(biasr, g.epi.bias, g.w.base, n0, wn0, lane, g.N, 0, CR_BN / 2);
+  }
+  if constexpr (SLAB) {   // split K: this split's fp32 partial tile, finished by splitk_finalize_kernel
+    if (!loader) {
+      const int wm0 = (wave / WAVES_N) * CR_WM, wn0 = (wave % WAVES_N) * CR_WN;
+      float* out = g.epi.Cf + (long)blockIdx.z * g.M * g.epi.ldcf;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm0 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int n = n0 + wn0 + j * 16 + (lane >> 4) * 4;
+          if (m >= g.M || n >= g.N) continue;
+          *reinterpret_cast<float4*>(out + (long)m * g.epi.ldcf + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+      }
+    }
+    return;
   }
   __syncthreads();
 
@@ -269,17 +290,18 @@ __global__ __launch_bounds__((RowCfg<RW, TROWS, FLIP>::THREADS)) void conv_row_k
   epi_store_tile<CR_BM, CR_BN, C_PITCH, CR_THREADS>(lds, m0, n0, g.M, g.N, ep, tid);
 }
 
-template <int RW, int TROWS, bool FLIP>
+template <int RW, int TROWS, bool FLIP, bool SLAB>
 inline void launch_conv_row(const RowArgs& a, hipStream_t stream) {
   using CFG = RowCfg<RW, TROWS, FLIP>;
-  dim3 grid((a.M / CFG::BM) * aql_cdiv(a.N, CR_BN));
-  hipLaunchKernelGGL((conv_row_kernel<RW, TROWS, FLIP>), grid, dim3(CFG::THREADS), 0, stream, a);
+  dim3 grid((a.M / CFG::BM) * aql_cdiv(a.N, CR_BN), 1, a.splits);
+  hipLaunchKernelGGL((conv_row_kernel<RW, TROWS, FLIP, SLAB>), grid, dim3(CFG::THREADS), 0, stream, a);
 }
 
 // bm = 256 or 128 (the tile height the picker chose).  Returns false when the convolution does not fit a row tile.
-template <class LA>
+template <class LA, int EPI>
 inline bool try_conv_row(const GemmArgs<LA, PlainLoader>& g, int bm, hipStream_t stream) {
   constexpr bool FLIP = std::is_same<LA, ConvBwdLoader>::value;
+  constexpr bool SLAB = EPI == EPI_SLAB;
   const auto& l = g.a0;
   int H, W, C;
   if constexpr (FLIP) {
@@ -289,12 +311,15 @@ inline bool try_conv_row(const GemmArgs<LA, PlainLoader>& g, int bm, hipStream_t
     if (l.stride != 1 || l.ups != 0 || l.pad != 1 || l.Hin != l.Hout || l.Win != l.Wout) return false;
     H = l.Hin, W = l.Win, C = l.Cin;
   }
-  if (C % 64 != 0 || g.N % 8 != 0 || g.splits != 1 || g.epi.geglu_F != 0 || g.ktiles1 != 0) return false;
+  if (C % 64 != 0 || g.N % 8 != 0 || g.epi.geglu_F != 0 || g.ktiles1 != 0) return false;
+  static const int slab_ok = getenv("AQL_CONV_ROW_SLAB") ? atoi(getenv("AQL_CONV_ROW_SLAB")) : 1;   // A/B hook
+  if ((g.splits != 1) != SLAB || g.splits > 3 * (C / 64) || (SLAB && !slab_ok)) return false;
   RowArgs a;
-  a.x = l.base, a.H = H, a.C = C, a.w = g.b0, a.M = g.M, a.N = g.N, a.m_fast = g.m_fast, a.epi = g.epi;
-  if (bm == 256 && W == 64 && H % 4 == 0) launch_conv_row<64, 4, FLIP>(a, stream);
-  else if (bm == 128 && W == 64 && H % 2 == 0) launch_conv_row<64, 2, FLIP>(a, stream);
-  else if (bm == 128 && W == 32 && H % 4 == 0) launch_conv_row<32, 4, FLIP>(a, stream);
+  a.x = l.base, a.H = H, a.C = C, a.w = g.b0, a.M = g.M, a.N = g.N, a.m_fast = g.m_fast, a.splits = g.splits, a.epi = g.epi;
+  if (bm == 256 && W == 64 && H % 4 == 0) launch_conv_row<64, 4, FLIP, SLAB>(a, stream);
+  else if (bm == 128 && W == 64 && H % 2 == 0) launch_conv_row<64, 2, FLIP, SLAB>(a, stream);
+  else if (bm == 128 && W == 32 && H % 4 == 0) launch_conv_row<32, 4, FLIP, SLAB>(a, stream);
+  else if (bm == 128 && W == 16 && H % 8 == 0) launch_conv_row<16, 8, FLIP, SLAB>(a, stream);
   else return false;
   return true;
 }

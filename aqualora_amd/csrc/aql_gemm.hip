@@ -179,7 +179,7 @@ void launch_cfg(int cfg, int pd, const GemmArgs<LA, LB>& g, hipStream_t stream) 
       }
     }
     if constexpr ((std::is_same<LA, ConvFwdLoader>::value || std::is_same<LA, ConvBwdLoader>::value) &&
-                  std::is_same<LB, PlainLoader>::value && EPI == EPI_BF16) {
+                  std::is_same<LB, PlainLoader>::value && (EPI == EPI_BF16 || EPI == EPI_SLAB)) {
       // stride-1 convs on 64- / 32-pixel-wide maps: the row-tile form (one A tile per (kh, channel slab) serves the three kw taps),
       // forward and backward-data, on the 256-row tile (one or two whole rounds) and on the 128-row wave-specialised tile
       static const int conv_row = env_int("AQL_CONV_ROW", 1);                 // A/B hook (0 = off, 1 = all, 2 = only the 256-row tile)
@@ -187,8 +187,8 @@ void launch_cfg(int cfg, int pd, const GemmArgs<LA, LB>& g, hipStream_t stream) 
       const int t256 = (g.M / 256) * aql_cdiv(g.N, 160);
       const bool r256 = cfg == P_W256x160 || (std::is_same<LA, ConvFwdLoader>::value && g.M % 256 == 0 && t256 % 256 == 0 &&
                                               t256 / 256 <= conv_row_rounds);
-      if (conv_row && r256 && aqlconvrow::try_conv_row(g, 256, stream)) return;
-      if (conv_row == 1 && cfg == P_W128x160 && g.M % 128 == 0 && aqlconvrow::try_conv_row(g, 128, stream)) return;
+      if (conv_row && r256 && aqlconvrow::try_conv_row<LA, EPI>(g, 256, stream)) return;
+      if (conv_row == 1 && cfg == P_W128x160 && g.M % 128 == 0 && aqlconvrow::try_conv_row<LA, EPI>(g, 128, stream)) return;
     }
     if (cfg == P_W256x160) return launch_gemm_w<256, 160, 64, 80, LA, LB, EPI, 3, 8>(g, stream);
     if (cfg == P_W128x160) return launch_gemm_w<128, 160, 64, 80, LA, LB, EPI, 4>(g, stream);

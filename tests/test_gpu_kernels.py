@@ -34,6 +34,13 @@ def test_gemm_family_parity_on_the_12_wave_256x160_kernel():
     assert text.count("PASS") >= 30
 
 
+def test_gemm_family_parity_on_the_8_wave_128x160_kernel():
+    """AQL_TILE=11 forces the wave-specialised 128x160 tile: the stride-1 convolutions of the sweep then run the 128-row row-tile
+    kernels (64- / 32- / 16-pixel-wide maps, forward and flipped-tap backward-data, with and without split K)."""
+    text = _run("probe_gemm.py", {"AQL_TILE": "11"})
+    assert text.count("PASS") >= 30
+
+
 def test_ops_parity():
     text = _run("probe_ops.py")
     assert text.count("PASS") >= 76   # incl. attention at 9216 / 6336 tokens (768 px and non-square rob-finetune samples)

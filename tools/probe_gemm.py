@@ -98,6 +98,8 @@ conv_case(8, 64, 64, 64, 320, 1, 0)
 conv_case(2, 64, 64, 320, 320, 1, 0)     # forward and backward-data (flipped taps) on 64-wide maps
 conv_case(2, 32, 32, 320, 640, 1, 0)     # 32-wide maps: 4 image rows per 128-pixel tile
 conv_case(1, 6, 64, 320, 160, 1, 0)      # H not a multiple of 4
+conv_case(4, 16, 16, 1280, 1280, 1, 0)   # 16-wide maps, split K (fp32 slabs + finalize)
+conv_case(4, 32, 32, 640, 640, 1, 0)     # 32-wide maps, split K
 
 # 5. TN gemm (weight grads)
 for (M, P, Q) in [(4096, 320, 32), (1000, 32, 768), (2048, 640, 320), (308, 1280, 8)]:
