@@ -12,8 +12,8 @@
 // fp32 accumulation order differs from the tap-major kernels; same products).
 //   LDS: two A tiles (9 x 32 pixel rows x 128 B = 36 KB each) + a 4-stage ring of 160 x 64 weight tiles (20 KB each) = 152 KB.
 //   Loaders, per K tile t = 3 g + kw: [wait] [barrier] [A tile of group g+1: 5 instructions at kw = 0, 4 at kw = 1] [W tile t+3]
-//   with counted vmcnt waits of 5 / 10 / 5 outstanding loads (derivation in DESIGN.md, section 4), compute wavefronts: [barrier]
-//   [second k-half fragments of tile t] [20 MFMAs] [first k-half fragments of tile t+1] [20 MFMAs].
+//   with counted vmcnt waits of 10 / 15 / 19 outstanding loads (two weight tiles always in flight; derivation in DESIGN.md,
+//   section 4), compute wavefronts: [barrier] 2 x ([9 fragment reads] [20 MFMAs]).
 #pragma once
 #include "aql_gemm.cuh"
 #include <stdlib.h>
@@ -150,17 +150,18 @@ __global__ __launch_bounds__((RowCfg<RW, TROWS, FLIP>::THREADS)) void conv_row_k
     issueW(3 * ga);
     issueW(3 * ga + 1);
     issueW(3 * ga + 2);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NW) : "memory");     // A(0), W(0) landed
-    __builtin_amdgcn_s_barrier();                         // pre: the compute wavefronts fetch the first fragments
     for (int gi = ga; gi < NG; ++gi) {
       const int t = 3 * gi;
       CRT(t, 0);
-      // barrier(t) certifies that tile t+1 has landed (the compute wavefronts prefetch its first k-half during tile t) and that
-      // nobody reads tile t-1 any more.  Outstanding loads allowed at each wait, in issue order (A part before W tile in an iteration):
-      //   t = 3g  : W(t+2) of iteration t-1                                    -> NW
-      //   t = 3g+1: A(g+1) part 1 + W(t+2) of iteration t-1                    -> P1 + NW
-      //   t = 3g+2: W(t+2) of iteration t-1 (its A part 2 must have landed)    -> NW
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
+      // barrier(t) certifies that tile t (and, at t = 3g, A tile g) has landed and that nobody reads tile t-1 any more.  Loads that
+      // may still be in flight at each wait, in issue order (A part before W tile in an iteration):
+      //   t = 3g  : W(t+1), W(t+2)                                              -> 2 NW
+      //   t = 3g+1: W(t+1), A(g+1) part 1, W(t+2)                               -> P1 + 2 NW
+      //   t = 3g+2: A(g+1) part 1, W(t+1), A(g+1) part 2, W(t+2)                -> A_INSTR + 2 NW
+      // (a register-double-buffered form that fetched the first fragments of tile t+1 during tile t measures the same in sustained
+      // runs, 48-49 us at 8 x 64 x 64 x 320 -> 320, and needs 164 instead of 123 VGPRs; with 14 of them spilled it was 17 % slower:
+      // profiles/r02_ab_conv_row_prefetch.txt.  tools/check_spills.py lists every kernel's scratch use.)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NW) : "memory");
       CRT(t, 1);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -169,7 +170,7 @@ __global__ __launch_bounds__((RowCfg<RW, TROWS, FLIP>::THREADS)) void conv_row_k
       issueW(t + 3);
       CRT(t, 3);
       CRT(t + 1, 0);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P1 + NW) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P1 + 2 * NW) : "memory");
       CRT(t + 1, 1);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -178,7 +179,7 @@ __global__ __launch_bounds__((RowCfg<RW, TROWS, FLIP>::THREADS)) void conv_row_k
       issueW(t + 4);
       CRT(t + 1, 3);
       CRT(t + 2, 0);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INSTR + 2 * NW) : "memory");
       CRT(t + 2, 1);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -191,25 +192,14 @@ __global__ __launch_bounds__((RowCfg<RW, TROWS, FLIP>::THREADS)) void conv_row_k
     const int wn0 = (wave % WAVES_N) * CR_WN;
     // this wavefront's 64 pixels: tile pixels (wave / WAVES_N) * 64 ..; a 16-pixel fragment lies inside one image row (RW >= 16):
     // A-tile pixel row of pixel (r, w) for tap kw = r (RW + 2) + w + kw  (backward-data: + 2 - kw)
-    int prow[FM];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int pt = (wave / WAVES_N) * CR_WM + i * 16 + (lane & 15);
-      prow[i] = (pt / RW) * (RW + 2) + pt % RW;
-    }
+    const int pt0 = (wave / WAVES_N) * CR_WM + (lane & 15);
+    const int prow0 = (pt0 / RW) * (RW + 2) + pt0 % RW;
+    // fragment i starts 16 i pixels further: a compile-time offset in A-tile pixel rows (RW divides 64)
+    auto prow = [&](int i) { return prow0 + (i * 16 / RW) * (RW + 2) + (i * 16) % RW; };
     const int brow = wn0 + (lane & 15);
     const int g4 = lane >> 4;
-    const int ch0 = g4, ch1 = 4 + g4;
-    bf16x8_t fa0[FM], fb0[FN], fa1[FM], fb1[FN];
-    __builtin_amdgcn_s_barrier();   // pre
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int j = 0; j < FN; ++j) fb0[j] = *reinterpret_cast<const bf16x8_t*>(wring + ((3 * ga) & (NSTW - 1)) * WST + lds_off(brow + j * 16, ch0));
-#pragma unroll
-    for (int i = 0; i < FM; ++i) fa0[i] = *reinterpret_cast<const bf16x8_t*>(abuf + (ga & 1) * ABUF + lds_off(prow[i] + (FLIP ? 2 : 0), ch0));
     for (int gi = ga; gi < NG; ++gi) {
       const char* sA = abuf + (gi & 1) * ABUF;
-      const char* sAn = abuf + ((gi + 1) & 1) * ABUF;
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int t = 3 * gi + kw;
@@ -217,32 +207,22 @@ __global__ __launch_bounds__((RowCfg<RW, TROWS, FLIP>::THREADS)) void conv_row_k
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         CRT(t, 1);
-        CRT(t, 2);
         const char* sB = wring + (t & (NSTW - 1)) * WST;
-        const char* nB = wring + ((t + 1) & (NSTW - 1)) * WST;
-        const char* nA = kw < 2 ? sA : sAn;          // A tile and pixel offset of K tile t+1
-        const int nkw = kw < 2 ? kw + 1 : 0;
-        const int po = FLIP ? 2 - kw : kw, npo = FLIP ? 2 - nkw : nkw;   // pixel offsets of tile t / t+1
+        const int po = FLIP ? 2 - kw : kw;
 #pragma unroll
-        for (int j = 0; j < FN; ++j) fb1[j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(brow + j * 16, ch1));
+        for (int ks = 0; ks < 2; ++ks) {
+          const int chunk = ks * 4 + g4;
+          bf16x8_t fa[FM], fb[FN];
 #pragma unroll
-        for (int i = 0; i < FM; ++i) fa1[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(prow[i] + po, ch1));
-        __builtin_amdgcn_sched_barrier(0);
+          for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(prow(i) + po, chunk));
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+          for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(brow + j * 16, chunk));
 #pragma unroll
-          for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) fb0[j] = *reinterpret_cast<const bf16x8_t*>(nB + lds_off(brow + j * 16, ch0));
-#pragma unroll
-        for (int i = 0; i < FM; ++i) fa0[i] = *reinterpret_cast<const bf16x8_t*>(nA + lds_off(prow[i] + npo, ch0));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        CRT(t, 2);
       }
     }
     // (after the loop: five batched loads, one round trip per workgroup; held across the loop they spilled)
