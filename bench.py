@@ -113,8 +113,10 @@ def dominant_kernels(B, device):
             ms = time_kernel(lambda: ops.conv3x3(x, pk))
         fl = 2.0 * nb * 64 * 64 * 320 * 9 * 320
         # 2B samples: 256 tiles of 256x160 on the 12-wave kernel (one chip-wide round); B samples: 256 tiles of 128x160, 8 waves
-        kname = ("conv_row_kernel (256x160 row tile, 12 waves)" if nb * 4096 // 256 * 2 in range(240, 257)
-                 else "gemm_kernel_w<128,160,64,80,ConvFwdLoader,PlainLoader,EPI_BF16,4>")
+        # (also two whole rounds of 256x160 tiles: config 3's twin forward; the picker is aql_gemm.hip launch_cfg)
+        t256 = nb * 4096 // 256 * 2
+        kname = ("conv_row_kernel (256x160 row tile, 12 waves)" if t256 in range(240, 257) or t256 == 512
+                 else "conv_row_kernel (128x160 row tile, 8 waves)")
         out.append({"kernel": f"{kname} conv3x3 320->320 @64x64, {nb} samples ({tag})",
                     "ms": ms, "samples": nb, "flops": fl, "achieved_tflops": fl / ms / 1e9, "frac_of_mfma_peak": fl / ms / 1e9 / MFMA_PEAK_TF})
     xs = synth.normal("k.x2", (B * 4096, 320), 1.0, 1, device).to(torch.bfloat16)
