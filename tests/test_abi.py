@@ -45,3 +45,16 @@ def test_product_path_fails_loudly_without_gpu():
     from aqualora_amd.watermark import MapperNet
     with pytest.raises(_lib.AqlError):
         MapperNet(8, 8)(torch.zeros(1, 8))
+
+
+def test_no_kernel_spills_registers_or_uses_scratch():
+    """Every gfx950 kernel of the built library: zero spilled VGPRs, no scratch segment (metadata notes of the objects the
+    build leaves next to the library, tools/check_spills.py).  A spill inside a K loop is a silent 10-20 %."""
+    import sys
+    import __graft_entry__ as ge
+    ge.build()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_spills
+    n, bad = check_spills.scan()
+    assert n >= 250, n
+    assert not bad, bad[:5]

@@ -118,6 +118,33 @@ __global__ __launch_bounds__(512) void k(float* out, long long* cyc, int iters) 
           asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(v) : "v"(v));
           x[i] = v[0], x[i + 1] = v[1];
         }
+      } else if constexpr (MODE >= 17 && MODE <= 20) {   // 32x32x16 MFMA (32 cycles): alone / + 5 fma / + 2 exp + 2 fma / + 1 exp + 1 fma + 1 max3 + 1 cvt
+        typedef float f32x16_t __attribute__((ext_vector_type(16)));
+        static_assert(sizeof(f32x16_t) == 64, "");
+        f32x16_t* big = reinterpret_cast<f32x16_t*>(acc);   // 4 independent 32x32 accumulators in the 16 f32x4 registers
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          big[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, big[i & 3], 0, 0, 0);
+          if constexpr (MODE == 18) {
+            asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x[i]) : "v"(c));
+            asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x[(i + 3) & 15]) : "v"(c));
+            asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x[(i + 6) & 15]) : "v"(c));
+            asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x[(i + 9) & 15]) : "v"(c));
+            asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x[(i + 12) & 15]) : "v"(c));
+          } else if constexpr (MODE == 19) {
+            asm volatile("v_exp_f32 %0, %0" : "+v"(x[i]));
+            asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x[(i + 3) & 15]) : "v"(c));
+            asm volatile("v_exp_f32 %0, %0" : "+v"(x[(i + 6) & 15]));
+            asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x[(i + 9) & 15]) : "v"(c));
+          } else if constexpr (MODE == 20) {
+            unsigned r;
+            asm volatile("v_exp_f32 %0, %0" : "+v"(x[i]));
+            asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x[(i + 3) & 15]) : "v"(c));
+            asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x[(i + 6) & 15]) : "v"(x[(i + 7) & 15]), "v"(c));
+            asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x[(i + 9) & 15]), "v"(x[(i + 10) & 15]));
+            x[(i + 12) & 15] = __uint_as_float(r);
+          }
+        }
       } else if constexpr (MODE == 11) {
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
@@ -178,5 +205,9 @@ int main() {
   run<14>("v_max_f32", 16, 0);
   run<15>("v_mul_f32", 16, 0);
   run<16>("v_pk_fma_f32", 16, 0);
+  run<17>("mfma 32x32x16 bf16", 0, 16);
+  run<18>("mfma 32x32x16 + 5 fma each", 80, 16);
+  run<19>("mfma 32x32x16 + 2 exp + 2 fma", 64, 16);
+  run<20>("mfma 32x32x16 + exp fma max3 cvt", 64, 16);
   return 0;
 }
