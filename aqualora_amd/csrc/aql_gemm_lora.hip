@@ -647,7 +647,16 @@ static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long
     // wave-specialised kernels: ONE chip-wide round of 8-wave workgroups (two rounds of the 128-row tile measured slower than
     // the 4-wave kernel: 52.2 vs 40.9 us at 1024x10240x1280)
     if (use_w && kt >= 8 && force_bm == 0) {
-      if (t128 >= 240 && t128 <= 288) { launch_w<128, 160, 64, 80, 3>(g, la, lp, stream); AQL_CHECK_LAUNCH("aql_lora_gemm_fused"); return AQL_OK; }
+      // one round of 128-row tiles: with the weights coming from HBM (the train step: every weight is read once per pass) the
+      // 4-wave kernel with a 3-stage ring is 9-15 % faster than the wave-specialised one at K >= 1280 (COLD=1 tools/tune_lora_cfg.py,
+      // profiles/r02_tune_lora_cfg_cold_weights.txt); with L2-warm weights it was the other way round by 2-4 %
+      static const int use_w128 = getenv("AQL_LORA_W128") ? atoi(getenv("AQL_LORA_W128")) : 0;
+      if (t128 >= 240 && t128 <= 288) {
+        if (use_w128) launch_w<128, 160, 64, 80, 3>(g, la, lp, stream);
+        else launch<128, 160, 64, 80, 3>(g, la, lp, stream);
+        AQL_CHECK_LAUNCH("aql_lora_gemm_fused");
+        return AQL_OK;
+      }
       if (t128 < 240 && t64 >= 240 && t64 <= 512) { launch_w<64, 160, 32, 80, 4>(g, la, lp, stream); AQL_CHECK_LAUNCH("aql_lora_gemm_fused"); return AQL_OK; }
       if (t64 < 240 && t32 >= 240 && t32 <= 512) { launch_w<32, 160, 16, 80, 5>(g, la, lp, stream); AQL_CHECK_LAUNCH("aql_lora_gemm_fused"); return AQL_OK; }
     }

@@ -1,6 +1,8 @@
 """Tile sweep of the one-launch LoRA linear (aql_lora_gemm_fused / _geglu) on the shapes of the TWIN forward (2B samples)
 and of the backward-data pass (B samples): every kernel configuration is forced through AQL_LORA_CFG and timed inside a
-HIP graph over rotating operand sets (cold L2).  Prints one line per shape with all timings and the winner."""
+HIP graph over rotating operand sets (cold L2).  Prints one line per shape with all timings and the winner.
+COLD=1: the regime of the train step -- every launch of the graph reads its OWN weight / A / B panels and a 600 MB fill between
+replays evicts them from the L2s and the Infinity Cache, so weights come from HBM while the activations rotate over NSET sets."""
 import os
 import sys
 
@@ -11,6 +13,8 @@ from aqualora_amd import _lib as L  # noqa: E402
 dev = "cuda"
 NSET = int(os.environ.get("NSET", "6"))
 B = int(os.environ.get("B", "4"))
+COLD = os.environ.get("COLD", "0") == "1"
+FLUSH = torch.empty(600 << 20, dtype=torch.uint8, device="cuda") if COLD else None
 CFGS = ["auto", "w128", "w64", "w32", "d128", "d128s", "d64", "d64s", "d32", "d32s"]
 rnd = lambda *s: torch.randn(*s, device=dev).to(torch.bfloat16)  # noqa: E731
 
@@ -26,6 +30,16 @@ def graph_time(fns, n=24):
     g.replay()
     torch.cuda.synchronize()
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if COLD:
+        ts = []
+        for _ in range(3):
+            FLUSH.fill_(1)
+            t0.record()
+            g.replay()
+            t1.record()
+            torch.cuda.synchronize()
+            ts.append(t0.elapsed_time(t1) / n * 1e3)
+        return sorted(ts)[1]
     t0.record()
     for _ in range(4):
         g.replay()
@@ -69,7 +83,20 @@ for tag, M, N, K, geglu in shapes():
             return L.call_raw("aql_lora_gemm_fused", L.ptr(X), K, L.ptr(W), K, M, N, K, L.ptr(A), L.ptr(S), rps, L.ptr(Bup), None,
                               None, 0, L.ptr(Y), N, L.ptr(T), L.ptr(Ts), 0, L.stream_ptr())
         return f
-    fns = [mk() for _ in range(NSET)]
+    if COLD:   # 24 weight sets (one per launch of the graph), NSET activation sets
+        acts = [rnd(M, K) for _ in range(NSET)]
+        _rnd = rnd
+        cnt = [0]
+
+        def rnd(*shape):   # noqa: F811  (mk() draws X first: hand it a rotating activation set instead)
+            if shape == (M, K):
+                cnt[0] += 1
+                return acts[cnt[0] % NSET]
+            return _rnd(*shape)
+        fns = [mk() for _ in range(24)]
+        rnd = _rnd
+    else:
+        fns = [mk() for _ in range(NSET)]
     res = {}
     for cfg in CFGS:
         if cfg == "auto":
