@@ -101,6 +101,41 @@ struct TnArgs {
   int trans;   // 1: the result is written transposed, element (p, q) -> C[q * ldc + p]
 };
 
+template <int BQ, bool TRANS>
+__device__ __forceinline__ void tn_tr_store(const TnArgs& a, const f32x4_t (&acc)[BQ == 128 ? 4 : 2][BQ == 128 ? 4 : 2], int p0, int q0,
+                                            int wm0, int wn0, int lane) {
+  constexpr int FM = BQ == 128 ? 4 : 2, FN = BQ == 128 ? 4 : 2;
+  if (!TRANS) {
+    // acc[i][j][e]: row P = p0 + wm0 + 16 i + 4 (lane>>4) + e, column Q = q0 + wn0 + 16 j + (lane & 15)
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int pr = p0 + wm0 + i * 16 + (lane >> 4) * 4 + e;
+        if (pr >= a.P) continue;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int qc = q0 + wn0 + j * 16 + (lane & 15);
+          if (qc < a.Q) atomicAdd(a.C + (long)pr * a.ldc + qc, a.alpha * acc[i][j][e]);
+        }
+      }
+  } else {
+    // operands swapped: acc[i][j][e] is (Q = q0 + wn0 + 16 j + 4 (lane>>4) + e, P = p0 + wm0 + 16 i + (lane & 15)) -> C[Q][P]
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int qr = q0 + wn0 + j * 16 + (lane >> 4) * 4 + e;
+        if (qr >= a.Q) continue;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const int pc = p0 + wm0 + i * 16 + (lane & 15);
+          if (pc < a.P) atomicAdd(a.C + (long)qr * a.ldc + pc, a.alpha * acc[i][j][e]);
+        }
+      }
+  }
+}
+
 // BQ = 128: 2x2 wavefronts of 64x64.  BQ = 32 (rank <= 32 gradients): 4x1 wavefronts of 32x32, the narrow operand's tile
 // uses 64 of its 256-byte LDS rows (same swizzle, so the gathers stay conflict-free).  TRANS swaps the MFMA operand roles
 // so that consecutive lanes still hit consecutive addresses of the transposed output.
@@ -154,38 +189,134 @@ __device__ __forceinline__ void tn_tr_body(const TnArgs& a, const int tile, cons
                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
   }
-  if (!TRANS) {
-    // acc[i][j][e]: row P = p0 + wm0 + 16 i + 4 (lane>>4) + e, column Q = q0 + wn0 + 16 j + (lane & 15)
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int pr = p0 + wm0 + i * 16 + (lane >> 4) * 4 + e;
-        if (pr >= a.P) continue;
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          const int qc = q0 + wn0 + j * 16 + (lane & 15);
-          if (qc < a.Q) atomicAdd(a.C + (long)pr * a.ldc + qc, a.alpha * acc[i][j][e]);
-        }
-      }
-  } else {
-    // operands swapped: acc[i][j][e] is (Q = q0 + wn0 + 16 j + 4 (lane>>4) + e, P = p0 + wm0 + 16 i + (lane & 15)) -> C[Q][P]
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int qr = q0 + wn0 + j * 16 + (lane >> 4) * 4 + e;
-        if (qr >= a.Q) continue;
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-          const int pc = p0 + wm0 + i * 16 + (lane & 15);
-          if (pc < a.P) atomicAdd(a.C + (long)qr * a.ldc + pc, a.alpha * acc[i][j][e]);
-        }
-      }
-  }
+  tn_tr_store<BQ, TRANS>(a, acc, p0, q0, wm0, wn0, lane);
 }
 
-__device__ __forceinline__ void tn_tr_dispatch(const TnArgs& a, int tile, int split, char* sU, char* sV) {
+// ---- LDS-DMA ring form.  The register-prefetch body above keeps ONE token tile per workgroup in flight (2 x 32 KB per CU): by
+// Little's law ~16 B/clk/CU at the ~4k-cycle latency the loads see under load, which is what it measures (447 TFLOP/s on the
+// rank-320 gradients).  Here the tiles go global -> LDS directly (buffer_load ... lds, 1 KB per wave instruction, the XOR
+// swizzle of tile_off applied on the SOURCE side) into a ring of NST stages: NST-1 tiles in flight, no commit phase, ONE
+// barrier per tile.  Rows past M and columns past the operand's width are fetched with an out-of-range offset (zero fill).
+constexpr uint32_t TNTR_OOB = 0x80000000u;
+constexpr uint32_t TNTR_BUF = 0x40000000u;   // operands must span < 1 GiB from their base (tn_tr_fill checks)
+constexpr int TNTR_NI = 8;                   // DMA instructions per wavefront per stage: 4 (U tile) + 4 (V tile)
+
+template <int BQ, bool TRANS, int NST>
+__device__ __forceinline__ void tn_tr_body_dma(const TnArgs& a, const int tile, const int split, char* lds) {
+  constexpr int FM = BQ == 128 ? 4 : 2, FN = BQ == 128 ? 4 : 2;
+  constexpr int TILE_B = TK * PITCH, STAGE = 2 * TILE_B;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tp = tile / a.tiles_q, tq = tile - tp * a.tiles_q;
+  const int p0 = tp * BT, q0 = tq * BQ;
+  const int wm0 = BQ == 128 ? (wave >> 1) * 64 : wave * 32, wn0 = BQ == 128 ? (wave & 1) * 64 : 0;
+  const long m_lo = (long)split * a.tiles_per_split * TK;
+  long m_hi = m_lo + (long)a.tiles_per_split * TK;
+  if (m_hi > a.M) m_hi = a.M;
+  if (m_lo >= m_hi) return;
+  const int ntiles = (int)((m_hi - m_lo + TK - 1) / TK);
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.U), 0, TNTR_BUF, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.V), 0, TNTR_BUF, 0x00020000);
+  // instruction i of this wavefront fills LDS rows 16 i + 4 wave + (lane >> 4) of a tile; lane slot (lane & 15) holds source chunk
+  // slot ^ ((row & 7) << 1)
+  uint32_t vu[4], vv[4];
+  int rw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 16 * i + 4 * wave + (lane >> 4);
+    const int c = (lane & 15) ^ ((row & 7) << 1);
+    rw[i] = row;
+    vu[i] = (p0 + c * 8 < a.P) ? (uint32_t)(((long)row * a.ldu + p0 + c * 8) * 2) : TNTR_OOB;
+    vv[i] = (c * 8 < BQ && q0 + c * 8 < a.Q) ? (uint32_t)(((long)row * a.ldv + q0 + c * 8) * 2) : TNTR_OOB;
+  }
+  // piece idx of tile t: 0..3 = this wavefront's four U instructions, 4..7 = its V instructions
+  auto issue1 = [&](int t, int idx) {
+    char* st = lds + (t % NST) * STAGE;
+    const long m = m_lo + (long)t * TK;
+    const bool live = t < ntiles;
+    const bool full = m + TK <= a.M;
+    const int i = idx & 3;
+    const bool ok = live & (full | (m + rw[i] < a.M));
+    if (idx < 4) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (__attribute__((address_space(3))) void*)(st + (4 * i + wave) * 1024), 16,
+                                               ok ? vu[i] : TNTR_OOB, live ? (uint32_t)(m * a.ldu * 2) : 0u, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (__attribute__((address_space(3))) void*)(st + TILE_B + (4 * i + wave) * 1024), 16,
+                                               ok ? vv[i] : TNTR_OOB, live ? (uint32_t)(m * a.ldv * 2) : 0u, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int t = 0; t < NST - 1; ++t)
+#pragma unroll
+    for (int idx = 0; idx < TNTR_NI; ++idx) issue1(t, idx);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * TNTR_NI) : "memory");   // this wavefront's pieces of tile kt have landed
+    __builtin_amdgcn_s_barrier();                                                // everyone's have; nobody reads tile kt-1 any more
+    asm volatile("" ::: "memory");
+    const char* sU = lds + (kt % NST) * STAGE;
+    const char* sV = sU + TILE_B;
+#ifndef TNTR_NO_MFMA
+    // all 16 fragments of the tile first, then 8 groups of 4 MFMAs with ONE DMA piece of tile kt+NST-1 after each group: a
+    // wavefront that issues its 8 pieces in a burst sits in the (saturated) DMA queue while its SIMD has nothing to run
+    bf16x8_t fa[2][FM], fb[2][FN];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) fa[s2][i] = tr_frag(sU, s2, wm0 + i * 16, lane);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) fb[s2][j] = tr_frag(sV, s2, wn0 + j * 16, lane);
+    }
+    constexpr int PER = TNTR_NI / (2 * FM);   // pieces per MFMA group: 1 (64x64 per wavefront) or 2 (32x32)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[s2][j], fa[s2][i], acc[i][j], 0, 0, 0)
+                            : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s2][i], fb[s2][j], acc[i][j], 0, 0, 0);
+#ifndef TNTR_NO_DMA
+#pragma unroll
+        for (int q = 0; q < PER; ++q) issue1(kt + NST - 1, (s2 * FM + i) * PER + q);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#else
+#pragma unroll
+    for (int idx = 0; idx < TNTR_NI; ++idx) issue1(kt + NST - 1, idx);
+    if (sV[lane] == 77 && kt == 1 << 30) acc[0][0][0] += 1.f;
+#endif
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing zero-fill DMAs still write LDS
+  tn_tr_store<BQ, TRANS>(a, acc, p0, q0, wm0, wn0, lane);
+}
+
+// NST = 0: the register-prefetch body (32 KB of LDS); NST >= 2: the LDS-DMA ring (NST x 32 KB), unless an operand spans >= 1 GiB
+template <int NST>
+__device__ __forceinline__ void tn_tr_dispatch(const TnArgs& a, int tile, int split, char* lds) {
+  bool dma = NST >= 2;
+  if (NST >= 2) dma = (a.M * a.ldu * 2 < (long)TNTR_BUF) & (a.M * a.ldv * 2 < (long)TNTR_BUF);
+  if constexpr (NST >= 2) {
+    if (dma) {
+      if (a.narrow) {
+        if (a.trans) tn_tr_body_dma<32, true, NST>(a, tile, split, lds);
+        else tn_tr_body_dma<32, false, NST>(a, tile, split, lds);
+      } else {
+        if (a.trans) tn_tr_body_dma<128, true, NST>(a, tile, split, lds);
+        else tn_tr_body_dma<128, false, NST>(a, tile, split, lds);
+      }
+      return;
+    }
+  }
+  char* sU = lds;
+  char* sV = lds + TK * PITCH;
   if (a.narrow) {
     if (a.trans) tn_tr_body<32, true>(a, tile, split, sU, sV);
     else tn_tr_body<32, false>(a, tile, split, sU, sV);
@@ -195,10 +326,20 @@ __device__ __forceinline__ void tn_tr_dispatch(const TnArgs& a, int tile, int sp
   }
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const TnArgs a) {
-  __shared__ __attribute__((aligned(16))) char sU[TK * PITCH];
-  __shared__ __attribute__((aligned(16))) char sV[TK * PITCH];
-  tn_tr_dispatch(a, blockIdx.x, blockIdx.y, sU, sV);
+// Hardware block b runs on XCD b % 8.  The workgroups that share operand rows (the tiles of ONE token split: every P tile re-reads
+// the split's V rows, every Q tile its U rows) must share an L2, or each XCD fetches its own copy over the fabric (measured: 923 MB
+// through the fabric for 189 MB of operands on 32768 x 2560 x 320).  Logical blocks are numbered split-major / tile-minor and XCD x
+// takes a contiguous range of them.
+__device__ __forceinline__ int xcd_contiguous(int bid, int nblk) {
+  const int qq = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
+  return (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+}
+
+template <int NST, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_tn_tr_kernel(const TnArgs a, int tiles) {
+  __shared__ __attribute__((aligned(16))) char lds[(NST >= 2 ? NST : 1) * 2 * TK * PITCH];
+  const int l = a.narrow ? (int)blockIdx.x : xcd_contiguous(blockIdx.x, gridDim.x);   // 128x32 tiles share no operand rows
+  tn_tr_dispatch<NST>(a, l % tiles, l / tiles, lds);
 }
 
 // Grouped form: ONE launch for all wide weight gradients of a backward pass (or of one exchange bucket).  The table is
@@ -211,10 +352,13 @@ struct TnTrDesc {
 static_assert(offsetof(TnTrDesc, first_block) == 88, "ops.DeferredDW.KINDS patches first_block at byte 88");
 static_assert(sizeof(TnArgs) == 88 && sizeof(TnTrDesc) == 96, "descriptor layout is part of the ABI");
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_tr_grouped_kernel(const TnTrDesc* __restrict__ descs, int n, int block_base) {
-  __shared__ __attribute__((aligned(16))) char sU[TK * PITCH];
-  __shared__ __attribute__((aligned(16))) char sV[TK * PITCH];
-  const int bid = (int)blockIdx.x + block_base;
+template <int NST, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_tn_tr_grouped_kernel(const TnTrDesc* __restrict__ descs, int n, int block_base) {
+  __shared__ __attribute__((aligned(16))) char lds[(NST >= 2 ? NST : 1) * 2 * TK * PITCH];
+  // the mapping must be one bijection for the whole launch: the first problem decides (a table holds the gradients of ONE rank:
+  // all 128x32 tiles -- no shared operand rows, the round-robin order balances better: +0.1 ms with the contiguous one at rank
+  // 32 -- or all 128x128, -0.5 ms at rank 320)
+  const int bid = (descs[0].a.narrow ? (int)blockIdx.x : xcd_contiguous(blockIdx.x, gridDim.x)) + block_base;
   int lo = 0, hi = n - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -222,8 +366,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_grouped_kernel(const TnTrDe
   }
   const TnTrDesc d = descs[lo];
   const int local = bid - d.first_block;
-  // splits of one tile are adjacent block ids: they share the operand panels' columns in L2 while they run
-  tn_tr_dispatch(d.a, local % d.n_tiles, local / d.n_tiles, sU, sV);
+  // split-major / tile-minor: the tiles of one token split are consecutive logical blocks, i.e. on one XCD (see xcd_contiguous)
+  tn_tr_dispatch<NST>(d.a, local % d.n_tiles, local / d.n_tiles, lds);
+}
+
+// body of the launch: AQL_TNTR_NST = 0 (register prefetch, 2 workgroups per CU; the default), 2 (DMA ring of 64 KB, 2 per CU), 3 / 4
+// (96 / 128 KB, 1 per CU).  Measured (profiles/r02_tntr_dma_ring.txt): alone, on rotating operands, the 2-stage ring is 10-16 %
+// faster than the register body (32768 x 2560 x 320: 141 -> 111 us) and one workgroup per CU with a deeper ring much slower
+// (189 us: the loop is bound by the ~40 B/clk a CU takes in, not by bytes in flight); inside the rank-320 train step the ring is
+// 1.0 ms SLOWER than the register body (52.1 vs 51.2 ms on one box), so the register body stays.
+inline int tn_tr_nst() {
+  static const int v = getenv("AQL_TNTR_NST") ? atoi(getenv("AQL_TNTR_NST")) : 0;
+  return v;
 }
 
 // token tiles per workgroup: enough to amortise the prologue and the 128x128 fp32 atomic epilogue
@@ -284,8 +438,13 @@ extern "C" int aql_tntr_desc_fill(void* host_desc, const bf16_t* U, long ldu, co
 extern "C" int aql_gemm_tn_tr_grouped(const void* dev_descs, int first, int n, int block_base, int n_blocks,
                                       hipStream_t stream) {
   AQL_CHECK_ARG(dev_descs && first >= 0 && n > 0 && block_base >= 0 && n_blocks > 0, "aql_gemm_tn_tr_grouped: bad args");
-  hipLaunchKernelGGL(gemm_tn_tr_grouped_kernel, dim3(n_blocks), dim3(256), 0, stream,
-                     static_cast<const TnTrDesc*>(dev_descs) + first, n, block_base);
+  const TnTrDesc* dd = static_cast<const TnTrDesc*>(dev_descs) + first;
+  switch (tn_tr_nst()) {
+    case 0: hipLaunchKernelGGL((gemm_tn_tr_grouped_kernel<0, 2>), dim3(n_blocks), dim3(256), 0, stream, dd, n, block_base); break;
+    case 2: hipLaunchKernelGGL((gemm_tn_tr_grouped_kernel<2, 2>), dim3(n_blocks), dim3(256), 0, stream, dd, n, block_base); break;
+    case 3: hipLaunchKernelGGL((gemm_tn_tr_grouped_kernel<3, 1>), dim3(n_blocks), dim3(256), 0, stream, dd, n, block_base); break;
+    default: hipLaunchKernelGGL((gemm_tn_tr_grouped_kernel<4, 1>), dim3(n_blocks), dim3(256), 0, stream, dd, n, block_base); break;
+  }
   AQL_CHECK_LAUNCH("aql_gemm_tn_tr_grouped");
   return AQL_OK;
 }
@@ -300,7 +459,12 @@ extern "C" int aql_gemm_tn_tr_f32(const bf16_t* U, long ldu, const bf16_t* V, lo
   int tiles = 0, n_blocks = 0;
   AQL_CHECK_ARG(tn_tr_fill(&a, U, ldu, V, ldv, M, P, Q, alpha, C, ldc, false, &tiles, &n_blocks), "aql_gemm_tn_tr_f32: bad problem");
   const int splits = n_blocks / tiles;
-  hipLaunchKernelGGL(gemm_tn_tr_kernel, dim3(tiles, splits), dim3(256), 0, stream, a);
+  switch (tn_tr_nst()) {
+    case 0: hipLaunchKernelGGL((gemm_tn_tr_kernel<0, 2>), dim3(tiles * splits), dim3(256), 0, stream, a, tiles); break;
+    case 2: hipLaunchKernelGGL((gemm_tn_tr_kernel<2, 2>), dim3(tiles * splits), dim3(256), 0, stream, a, tiles); break;
+    case 3: hipLaunchKernelGGL((gemm_tn_tr_kernel<3, 1>), dim3(tiles * splits), dim3(256), 0, stream, a, tiles); break;
+    default: hipLaunchKernelGGL((gemm_tn_tr_kernel<4, 1>), dim3(tiles * splits), dim3(256), 0, stream, a, tiles); break;
+  }
   AQL_CHECK_LAUNCH("aql_gemm_tn_tr_f32");
   return AQL_OK;
 }
