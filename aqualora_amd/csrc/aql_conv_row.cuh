@@ -294,9 +294,11 @@ inline bool try_conv_row(const GemmArgs<LA, PlainLoader>& g, int bm, hipStream_t
   if (C % 64 != 0 || g.N % 8 != 0 || g.epi.geglu_F != 0 || g.ktiles1 != 0) return false;
   static const int slab_ok = getenv("AQL_CONV_ROW_SLAB") ? atoi(getenv("AQL_CONV_ROW_SLAB")) : 1;   // A/B hook
   if ((g.splits != 1) != SLAB || g.splits > 3 * (C / 64) || (SLAB && !slab_ok)) return false;
+  static const int row32x8 = getenv("AQL_CONV_ROW_32X8") ? atoi(getenv("AQL_CONV_ROW_32X8")) : 1;   // A/B hook
   RowArgs a;
   a.x = l.base, a.H = H, a.C = C, a.w = g.b0, a.M = g.M, a.N = g.N, a.m_fast = g.m_fast, a.splits = g.splits, a.epi = g.epi;
   if (bm == 256 && W == 64 && H % 4 == 0) launch_conv_row<64, 4, FLIP, SLAB>(a, stream);
+  else if (bm == 256 && W == 32 && H % 8 == 0 && row32x8) launch_conv_row<32, 8, FLIP, SLAB>(a, stream);
   else if (bm == 128 && W == 64 && H % 2 == 0) launch_conv_row<64, 2, FLIP, SLAB>(a, stream);
   else if (bm == 128 && W == 32 && H % 4 == 0) launch_conv_row<32, 4, FLIP, SLAB>(a, stream);
   else if (bm == 128 && W == 16 && H % 8 == 0) launch_conv_row<16, 8, FLIP, SLAB>(a, stream);
