@@ -300,6 +300,13 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
     while (s2 > 1 && (kt_total / s2 < 8 || (size_t)s2 * (size_t)g.M * (size_t)g.N * 4u > ws_bytes)) --s2;
     splits = s2;
   }
+  if (ws != nullptr && o.C2 == nullptr) {   // tuning hook (tools/experiments/time_conv8.py), re-read on every call
+    if (const char* e = getenv("AQL_SPLITS")) {
+      int s = atoi(e);
+      while (s > 1 && (kt_total / s < 2 || (size_t)s * (size_t)g.M * (size_t)g.N * 4u > ws_bytes)) --s;
+      if (s >= 1) splits = s;
+    }
+  }
   if (o.gb_h != nullptr && splits > 1) return AQL_NOT_FUSED;   // the slab + finalize path has no GEGLU-backward epilogue
   g.splits = splits;
   // LDS-DMA staging everywhere (measured fastest on every shape, hot or cold operands); a grid of <= 1 workgroup per CU
