@@ -53,6 +53,12 @@ def test_transpose_read_weight_gradient_gemm():
     assert text.count("PASS") >= 25
 
 
+def test_transpose_read_weight_gradient_gemm_dma_ring():
+    """The LDS-DMA ring body of the same kernel (AQL_TNTR_NST=2: kept as an option, faster alone, slower inside the step)."""
+    text = _run("probe_tntr.py", {"AQL_TNTR_NST": "2"})
+    assert text.count("PASS") >= 25
+
+
 def test_one_launch_lora_linear():
     """aql_lora_gemm_fused (T side accumulator + up-projection k-step, 4-wave and wave-specialised kernels) vs fp32 torch."""
     text = _run("probe_lora_gemm.py")
