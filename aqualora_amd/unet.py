@@ -59,16 +59,25 @@ class LayerNorm(nn.Module):
         return y.view(shp), xr.view(shp)
 
 
+_FREQ_TABLES = {}
+
+
 def get_timestep_embedding(timesteps, dim, flip_sin_to_cos=True, downscale_freq_shift=0, max_period=10000):
-    """Sinusoidal embedding (original_unet.py:323-361), fp32."""
+    """Sinusoidal embedding (original_unet.py:323-361), fp32.  The frequency table depends on the arguments only: built once per
+    (device, dim, shift, period) instead of four launches per step; sin / cos are concatenated directly in the requested order."""
     half = dim // 2
-    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32, device=timesteps.device)
-    exponent = exponent / (half - downscale_freq_shift)
-    emb = timesteps[:, None].float() * torch.exp(exponent)[None, :]
-    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    key = (str(timesteps.device), dim, downscale_freq_shift, max_period)
+    freq = _FREQ_TABLES.get(key)
+    if freq is None:
+        exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32, device=timesteps.device)
+        exponent = exponent / (half - downscale_freq_shift)
+        freq = torch.exp(exponent)[None, :]
+        if not (timesteps.is_cuda and torch.cuda.is_current_stream_capturing()):   # a table built inside a capture lives in its pool
+            _FREQ_TABLES[key] = freq
+    emb = timesteps[:, None].float() * freq
     if flip_sin_to_cos:
-        emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
-    return emb
+        return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
+    return torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
 
 
 class TimestepEmbedding(nn.Module):
