@@ -26,6 +26,14 @@ constexpr int WST = CR_BN * 128;               // 20,480 B per weight tile
 constexpr int NSTW = 4;
 constexpr int NW = CR_BN / 32;                 // DMA instructions per loader thread per weight tile
 
+// Swizzle of the A tile.  The tap kw reads 16 consecutive pixel rows starting at ANY row (r (RW + 2) + 16 i + kw), and the (row >> 1) & 7
+// swizzle of the weight tiles (lds_off) is conflict-free for ds_read_b128 only when that start is a multiple of 4: two of the three
+// taps paid 8 LDS cycles per fragment instead of 4 (SQ_LDS_BANK_CONFLICT 2.21 M of 9.09 M LDS cycles per launch against 0.25 M on the
+// implicit-GEMM kernel, profiles/r02_pmc_conv_row_lds.txt).  ((row >> 1) & 3) << 1 leaves bit 0 of the chunk to the lane group and is
+// conflict-free for every start row (checked exhaustively, tools/experiments/lds_swizzle_check.py).
+__device__ __forceinline__ int a_swz(int row) { return ((row >> 1) & 3) << 1; }
+__device__ __forceinline__ int a_off(int row, int chunk) { return row * 128 + ((chunk ^ a_swz(row)) << 4); }
+
 // What the kernel needs of the convolution (forward: ConvFwdLoader, backward-data: ConvBwdLoader with the taps flipped)
 struct RowArgs {
   const bf16_t* x;      // [B][H][RW][C] channels-last input (forward) / output gradient (backward-data)
@@ -112,7 +120,7 @@ __global__ __launch_bounds__((RowCfg<RW, TROWS, FLIP>::THREADS)) void conv_row_k
     for (int j = 0; j < A_INSTR; ++j) {
       const int p = 32 * j + (ltid >> 3);
       const int r = p / (RW + 2), wc = p - r * (RW + 2) - 1;
-      const int kc = ((ltid & 7) ^ ((p >> 1) & 7)) * 8;
+      const int kc = ((ltid & 7) ^ a_swz(p)) * 8;
       const bool okc = (p < APX) & (wc >= 0) & (wc < RW);
       arh[j] = okc ? h0 + r - 1 : -(1 << 20);
       abase[j] = (uint32_t)((((long)b * H + (h0 + r - 1)) * RW + wc) * Cin + kc) * 2u;
@@ -214,7 +222,7 @@ __global__ __launch_bounds__((RowCfg<RW, TROWS, FLIP>::THREADS)) void conv_row_k
           const int chunk = ks * 4 + g4;
           bf16x8_t fa[FM], fb[FN];
 #pragma unroll
-          for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(prow(i) + po, chunk));
+          for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(sA + a_off(prow(i) + po, chunk));
 #pragma unroll
           for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(brow + j * 16, chunk));
 #pragma unroll
