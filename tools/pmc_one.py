@@ -1,5 +1,5 @@
 """One GEMM / conv shape, a handful of launches: the workload for rocprofv3 --pmc passes (tools/pmc_run.sh).
-usage: pmc_one.py gemm M N K | conv B H Cin Cout"""
+usage: pmc_one.py gemm M N K | conv B H Cin Cout | lora M N K | attn B S heads | tntr M P Q"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,6 +16,29 @@ if kind == "gemm":
         A = rnd(M, K); B = rnd(N, K); C = torch.empty(M, N, dtype=torch.bfloat16, device=dev); bias = rnd(N)
         return lambda: L.call("aql_gemm_bf16", L.ptr(A), K, L.ptr(B), K, M, N, K, None, 0, None, 0, 0, L.ptr(bias), None, 1,
                               None, 0, L.ptr(C), N, L.ptr(ws), ws.numel() * 4, L.stream_ptr())
+elif kind == "lora":   # one-launch LoRA linear, rank 32
+    M, N, K = a
+    def mk():
+        X, W, A, Bup, S = rnd(M, K), rnd(N, K), rnd(32, K), rnd(N, 32), rnd(8, 32)
+        Y = torch.empty(M, N, dtype=torch.bfloat16, device=dev); T = torch.empty(M, 32, dtype=torch.bfloat16, device=dev); Ts = torch.empty_like(T)
+        return lambda: L.call("aql_lora_gemm_fused", L.ptr(X), K, L.ptr(W), K, M, N, K, L.ptr(A), L.ptr(S), M // 8, L.ptr(Bup), None,
+                              None, 0, L.ptr(Y), N, L.ptr(T), L.ptr(Ts), 0, L.stream_ptr())
+elif kind == "attn":   # self-attention forward + backward, head dim 40
+    from aqualora_amd import ops
+    Bn, S, heads = a
+    def mk():
+        q, k, v = (rnd(Bn, S, heads * 40).requires_grad_(True) for _ in range(3))
+        do = rnd(Bn, S, heads * 40)
+        def f():
+            o = ops.attention(q, k, v, heads)
+            o.backward(do)
+        return f
+elif kind == "tntr":
+    from aqualora_amd import ops
+    M, P, Q = a
+    def mk():
+        U, V = rnd(M, P), rnd(M, Q); C = torch.zeros(P, Q, device=dev)
+        return lambda: ops.gemm_tn_acc(U, V, C)
 else:
     Bn, H, Cin, Cout = a
     def mk():

@@ -10,6 +10,7 @@ G5="FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum
 i=0
 for G in "$G1" "$G2" "$G3" "$G4" "$G5"; do
   i=$((i+1)); rm -rf /tmp/pmc_${tag}_$i
+  if [ -n "$PMC_ONLY" ] && [[ " $PMC_ONLY " != *" $i "* ]]; then continue; fi   # e.g. PMC_ONLY="1 3": only those groups
   timeout 300 rocprofv3 --kernel-trace --pmc $G --output-format csv -d /tmp/pmc_${tag}_$i -o run -- python $GRAFT_REPO_ROOT/tools/pmc_one.py "$@" > /tmp/pmc_${tag}_$i.log 2>&1
 done
 python $GRAFT_REPO_ROOT/tools/pmc_parse.py /tmp/pmc_${tag}_ 5 > $GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}.txt
