@@ -353,12 +353,14 @@ static_assert(offsetof(TnTrDesc, first_block) == 88, "ops.DeferredDW.KINDS patch
 static_assert(sizeof(TnArgs) == 88 && sizeof(TnTrDesc) == 96, "descriptor layout is part of the ABI");
 
 template <int NST, int OCC>
-__global__ __launch_bounds__(256, OCC) void gemm_tn_tr_grouped_kernel(const TnTrDesc* __restrict__ descs, int n, int block_base) {
+__global__ __launch_bounds__(256, OCC) void gemm_tn_tr_grouped_kernel(const TnTrDesc* __restrict__ descs, int n, int block_base,
+                                                                      int remap) {
   __shared__ __attribute__((aligned(16))) char lds[(NST >= 2 ? NST : 1) * 2 * TK * PITCH];
   // the mapping must be one bijection for the whole launch: the first problem decides (a table holds the gradients of ONE rank:
   // all 128x32 tiles -- no shared operand rows, the round-robin order balances better: +0.1 ms with the contiguous one at rank
   // 32 -- or all 128x128, -0.5 ms at rank 320)
-  const int bid = (descs[0].a.narrow ? (int)blockIdx.x : xcd_contiguous(blockIdx.x, gridDim.x)) + block_base;
+  const bool contiguous = remap < 0 ? !descs[0].a.narrow : remap != 0;   // remap: -1 = by the first problem, 0 / 1 = A/B hook
+  const int bid = (contiguous ? xcd_contiguous(blockIdx.x, gridDim.x) : (int)blockIdx.x) + block_base;
   int lo = 0, hi = n - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -439,11 +441,12 @@ extern "C" int aql_gemm_tn_tr_grouped(const void* dev_descs, int first, int n, i
                                       hipStream_t stream) {
   AQL_CHECK_ARG(dev_descs && first >= 0 && n > 0 && block_base >= 0 && n_blocks > 0, "aql_gemm_tn_tr_grouped: bad args");
   const TnTrDesc* dd = static_cast<const TnTrDesc*>(dev_descs) + first;
+  static const int remap = getenv("AQL_TNTR_REMAP") ? atoi(getenv("AQL_TNTR_REMAP")) : -1;
   switch (tn_tr_nst()) {
-    case 0: hipLaunchKernelGGL((gemm_tn_tr_grouped_kernel<0, 2>), dim3(n_blocks), dim3(256), 0, stream, dd, n, block_base); break;
-    case 2: hipLaunchKernelGGL((gemm_tn_tr_grouped_kernel<2, 2>), dim3(n_blocks), dim3(256), 0, stream, dd, n, block_base); break;
-    case 3: hipLaunchKernelGGL((gemm_tn_tr_grouped_kernel<3, 1>), dim3(n_blocks), dim3(256), 0, stream, dd, n, block_base); break;
-    default: hipLaunchKernelGGL((gemm_tn_tr_grouped_kernel<4, 1>), dim3(n_blocks), dim3(256), 0, stream, dd, n, block_base); break;
+    case 0: hipLaunchKernelGGL((gemm_tn_tr_grouped_kernel<0, 2>), dim3(n_blocks), dim3(256), 0, stream, dd, n, block_base, remap); break;
+    case 2: hipLaunchKernelGGL((gemm_tn_tr_grouped_kernel<2, 2>), dim3(n_blocks), dim3(256), 0, stream, dd, n, block_base, remap); break;
+    case 3: hipLaunchKernelGGL((gemm_tn_tr_grouped_kernel<3, 1>), dim3(n_blocks), dim3(256), 0, stream, dd, n, block_base, remap); break;
+    default: hipLaunchKernelGGL((gemm_tn_tr_grouped_kernel<4, 1>), dim3(n_blocks), dim3(256), 0, stream, dd, n, block_base, remap); break;
   }
   AQL_CHECK_LAUNCH("aql_gemm_tn_tr_grouped");
   return AQL_OK;
