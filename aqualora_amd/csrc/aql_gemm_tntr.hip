@@ -377,6 +377,12 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_tr_grouped_kernel(const TnTr
 // faster than the register body (32768 x 2560 x 320: 141 -> 111 us) and one workgroup per CU with a deeper ring much slower
 // (189 us: the loop is bound by the ~40 B/clk a CU takes in, not by bytes in flight); inside the rank-320 train step the ring is
 // 1.0 ms SLOWER than the register body (52.1 vs 51.2 ms on one box), so the register body stays.
+// workgroups per CU of the register body: 3 (168 VGPRs, no scratch; the default: config 3 49.53 -> 49.11 ms on one box, config 2
+// unchanged) or 2 (196 VGPRs); 4 would spill 213 VGPRs
+inline int tn_tr_occ() {
+  static const int v = getenv("AQL_TNTR_OCC") ? atoi(getenv("AQL_TNTR_OCC")) : 3;
+  return v;
+}
 inline int tn_tr_nst() {
   static const int v = getenv("AQL_TNTR_NST") ? atoi(getenv("AQL_TNTR_NST")) : 0;
   return v;
@@ -443,7 +449,10 @@ extern "C" int aql_gemm_tn_tr_grouped(const void* dev_descs, int first, int n, i
   const TnTrDesc* dd = static_cast<const TnTrDesc*>(dev_descs) + first;
   static const int remap = getenv("AQL_TNTR_REMAP") ? atoi(getenv("AQL_TNTR_REMAP")) : -1;
   switch (tn_tr_nst()) {
-    case 0: hipLaunchKernelGGL((gemm_tn_tr_grouped_kernel<0, 2>), dim3(n_blocks), dim3(256), 0, stream, dd, n, block_base, remap); break;
+    case 0:
+      if (tn_tr_occ() == 3) hipLaunchKernelGGL((gemm_tn_tr_grouped_kernel<0, 3>), dim3(n_blocks), dim3(256), 0, stream, dd, n, block_base, remap);
+      else hipLaunchKernelGGL((gemm_tn_tr_grouped_kernel<0, 2>), dim3(n_blocks), dim3(256), 0, stream, dd, n, block_base, remap);
+      break;
     case 2: hipLaunchKernelGGL((gemm_tn_tr_grouped_kernel<2, 2>), dim3(n_blocks), dim3(256), 0, stream, dd, n, block_base, remap); break;
     case 3: hipLaunchKernelGGL((gemm_tn_tr_grouped_kernel<3, 1>), dim3(n_blocks), dim3(256), 0, stream, dd, n, block_base, remap); break;
     default: hipLaunchKernelGGL((gemm_tn_tr_grouped_kernel<4, 1>), dim3(n_blocks), dim3(256), 0, stream, dd, n, block_base, remap); break;
@@ -463,7 +472,10 @@ extern "C" int aql_gemm_tn_tr_f32(const bf16_t* U, long ldu, const bf16_t* V, lo
   AQL_CHECK_ARG(tn_tr_fill(&a, U, ldu, V, ldv, M, P, Q, alpha, C, ldc, false, &tiles, &n_blocks), "aql_gemm_tn_tr_f32: bad problem");
   const int splits = n_blocks / tiles;
   switch (tn_tr_nst()) {
-    case 0: hipLaunchKernelGGL((gemm_tn_tr_kernel<0, 2>), dim3(tiles * splits), dim3(256), 0, stream, a, tiles); break;
+    case 0:
+      if (tn_tr_occ() == 3) hipLaunchKernelGGL((gemm_tn_tr_kernel<0, 3>), dim3(tiles * splits), dim3(256), 0, stream, a, tiles);
+      else hipLaunchKernelGGL((gemm_tn_tr_kernel<0, 2>), dim3(tiles * splits), dim3(256), 0, stream, a, tiles);
+      break;
     case 2: hipLaunchKernelGGL((gemm_tn_tr_kernel<2, 2>), dim3(tiles * splits), dim3(256), 0, stream, a, tiles); break;
     case 3: hipLaunchKernelGGL((gemm_tn_tr_kernel<3, 1>), dim3(tiles * splits), dim3(256), 0, stream, a, tiles); break;
     default: hipLaunchKernelGGL((gemm_tn_tr_kernel<4, 1>), dim3(tiles * splits), dim3(256), 0, stream, a, tiles); break;
