@@ -393,7 +393,10 @@ inline int tn_tr_splits(int tiles, int ktiles, bool grouped) {
   static const int force = getenv("AQL_TN_SPLITS") ? atoi(getenv("AQL_TN_SPLITS")) : 0;
   int splits;
   if (force > 0) splits = force;
-  else if (grouped) splits = ktiles / 32;            // the launch as a whole fills the chip
+  else if (grouped) {
+    static const int tps = getenv("AQL_TN_TPS") ? atoi(getenv("AQL_TN_TPS")) : 32;   // token tiles per workgroup (tuning hook)
+    splits = ktiles / tps;                              // the launch as a whole fills the chip
+  }
   else splits = (320 + tiles - 1) / tiles;           // a lone problem: about one workgroup per CU (measured optimum)
   if (splits > ktiles / 2) splits = ktiles / 2;
   if (splits < 1) splits = 1;
