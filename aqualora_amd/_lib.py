@@ -114,7 +114,18 @@ SIGNATURES = {
     "aql_sdpa_fwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p, c_p],
     "aql_sdpa_bwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p,
                      c_p, c_p, c_sz, c_p],
+    "aql_abi_version": [],
+    "aql_comm_unique_id": [c_p],
+    "aql_comm_init": [c_p, c_i, c_i, c_p],
+    "aql_comm_size": [c_p],
+    "aql_comm_all_reduce_f32": [c_p, c_p, c_l, c_i, c_p],
+    "aql_comm_reduce_scatter_f32": [c_p, c_p, c_p, c_l, c_i, c_p],
+    "aql_comm_all_gather": [c_p, c_p, c_p, c_l, c_p],
+    "aql_comm_broadcast": [c_p, c_p, c_l, c_i, c_p],
+    "aql_comm_abort": [c_p],
+    "aql_comm_destroy": [c_p],
 }
+ABI_VERSION = 3   # == AQL_ABI_VERSION of include/aqualora_hip.h this table was written against
 
 _lib = None
 
@@ -145,6 +156,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError here = ABI drift, fail loudly
         fn.argtypes = argtypes
         fn.restype = c_i
+    built = lib.aql_abi_version()
+    if built != ABI_VERSION:
+        raise AqlError(f"{LIB_PATH} was built with AQL_ABI_VERSION {built}, this binding expects {ABI_VERSION}: rebuild it "
+                       "(`make -C aqualora_amd/csrc`); calling across versions would pass arguments in the wrong slots")
     _lib = lib
     return lib
 

@@ -90,6 +90,154 @@ class BucketedAllreduce:
         self.pending = []
 
 
+class AqlComm:
+    """RCCL communicator behind our own C-ABI (include/aqualora_hip.h: aql_comm_*), one per process / GPU.
+
+    Unlike ProcessGroupNCCL the collectives are enqueued on the stream the CALLER names (torch's current stream by default),
+    so the trainer can fork them onto a side stream under the rest of backward and capture them into the step's HIP graph
+    (ppft.PPFTTrainer, "overlap" exchange).  The 128-byte id travels over the already initialised torch.distributed group --
+    the launcher's rendezvous, plumbing -- or is created locally for a single-rank communicator (tests, AQL_FORCE_ALLREDUCE)."""
+
+    def __init__(self, group=None, single=False):
+        import ctypes
+        from . import _lib as L
+        self._L = L
+        if single or not (dist.is_available() and dist.is_initialized()):
+            self.rank, self.world = 0, 1
+        else:
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        idbuf = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            L.call("aql_comm_unique_id", idbuf)
+        box = [bytes(idbuf.raw)]
+        if self.world > 1:
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=group)
+        self._id = ctypes.create_string_buffer(box[0], 128)
+        self.handle = ctypes.c_void_p()
+        L.call("aql_comm_init", self._id, self.world, self.rank, ctypes.byref(self.handle))
+        n = L.call_raw("aql_comm_size", self.handle)
+        if n != self.world:
+            raise L.AqlError(f"aql_comm_init: communicator reports {n} ranks, expected {self.world}")
+
+    def _stream(self, stream):
+        return self._L.c_p((stream or torch.cuda.current_stream()).cuda_stream)
+
+    def all_reduce_(self, flat, average=True, stream=None):
+        if flat.dtype != torch.float32 or not flat.is_contiguous():
+            raise self._L.AqlError("AqlComm.all_reduce_: contiguous fp32 only")
+        self._L.call("aql_comm_all_reduce_f32", self.handle, self._L.ptr(flat), flat.numel(), int(bool(average)),
+                     self._stream(stream))
+        return flat
+
+    def reduce_scatter(self, send, recv, average=True, stream=None):
+        if send.numel() != recv.numel() * self.world:
+            raise self._L.AqlError("AqlComm.reduce_scatter: send must hold world x recv elements")
+        self._L.call("aql_comm_reduce_scatter_f32", self.handle, self._L.ptr(send), self._L.ptr(recv), recv.numel(),
+                     int(bool(average)), self._stream(stream))
+        return recv
+
+    def all_gather(self, send, recv, stream=None):
+        nbytes = send.numel() * send.element_size()
+        if recv.numel() * recv.element_size() != nbytes * self.world:
+            raise self._L.AqlError("AqlComm.all_gather: recv must hold world x send bytes")
+        self._L.call("aql_comm_all_gather", self.handle, self._L.ptr(send), self._L.ptr(recv), nbytes, self._stream(stream))
+        return recv
+
+    def broadcast_(self, t, root=0, stream=None):
+        self._L.call("aql_comm_broadcast", self.handle, self._L.ptr(t), t.numel() * t.element_size(), int(root),
+                     self._stream(stream))
+        return t
+
+    def self_test(self, timeout_s=60.0):
+        """One captured, forked all-reduce replayed twice and checked, with a deadline: the trainer only switches to the captured
+        exchange when this passes on the box it runs on (the captured form cannot be exercised across ranks on the 1-GPU
+        development boxes; a communicator that fails or stalls here is aborted and the torch.distributed exchange is used)."""
+        import time
+        dev = torch.device("cuda", torch.cuda.current_device())
+        buf = torch.ones(4096, dtype=torch.float32, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        cap = torch.cuda.Stream(device=dev)
+        cap.wait_stream(torch.cuda.current_stream())
+        try:
+            with torch.cuda.stream(cap):
+                self.all_reduce_(buf, average=False)      # eager warm-up: RCCL sets its channels up outside the capture
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    buf.mul_(2.0)
+                    side.wait_stream(torch.cuda.current_stream())
+                    self.all_reduce_(buf, average=False, stream=side)
+                    torch.cuda.current_stream().wait_stream(side)
+                    buf.add_(1.0)
+                g.replay()
+                g.replay()
+                done = torch.cuda.Event()
+                done.record()
+            t0 = time.time()
+            while not done.query():
+                if time.time() - t0 > timeout_s:
+                    return False, f"captured all-reduce did not complete within {timeout_s:.0f} s"
+                time.sleep(0.01)
+            torch.cuda.current_stream().wait_stream(cap)
+            w = float(self.world)
+            want = (2.0 * w * w + 1.0) * 2.0 * w + 1.0    # eager: w; replay 1: 2w*w + 1; replay 2: (2w*w + 1) * 2w + 1
+            got = buf.cpu()
+            if not bool((got == want).all()):
+                return False, f"captured all-reduce returned {float(got[0])}, expected {want}"
+            self._keep = (g, buf, side, cap)
+            return True, "ok"
+        except Exception as e:   # noqa: BLE001  (any failure means: do not use the captured exchange)
+            return False, f"{type(e).__name__}: {e}"
+
+    def abort(self):
+        if self.handle:
+            self._L.call_raw("aql_comm_abort", self.handle)
+            self.handle = None
+
+    def destroy(self):
+        if getattr(self, "handle", None):
+            self._L.call_raw("aql_comm_destroy", self.handle)
+            self.handle = None
+
+
+def make_comm(group=None):
+    """The communicator of the captured / overlapped exchange, or (None, reason) when it is not to be used: no exchange active,
+    a non-RCCL backend (the gloo CPU tests), AQL_COMM=0, or a failed self-test."""
+    if not exchange_active(group):
+        return None, "no exchange (single rank)"
+    if os.environ.get("AQL_COMM", "1") == "0":
+        return None, "AQL_COMM=0"
+    if dist.get_backend(group) != "nccl" or not torch.cuda.is_available():
+        return None, f"backend {dist.get_backend(group)}"
+    if group in _COMMS:                 # one communicator (and one self-test) per process group
+        return _COMMS[group]
+    _COMMS[group] = res = _make_comm(group)
+    return res
+
+
+_COMMS = {}
+
+
+def _make_comm(group):
+    comm, ok, why = None, False, ""
+    try:
+        comm = AqlComm(group)
+        ok, why = comm.self_test()
+    except Exception as e:   # noqa: BLE001
+        why = f"aql_comm_init failed: {e}"
+    # every rank must take the same decision: a rank that fell back alone would wait in a torch.distributed collective forever
+    flag = torch.tensor([1.0 if ok else 0.0], device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if flag.item() < 1.0:
+        if comm is not None:
+            try:
+                comm.abort()
+            except Exception:   # noqa: BLE001
+                pass
+        return None, f"self-test failed ({why or 'on another rank'})"
+    return comm, "ok"
+
+
 def allreduce_module_grads_(params, group=None, bucket_bytes=64 << 20):
     """DDP's gradient averaging for an ordinary module (the SecretDecoder in rob_enhance_finetune.py, ~26 MB of fp32
     gradients): gradients are packed into flat buckets of at most ``bucket_bytes`` (reverse parameter order, the order in

@@ -303,6 +303,21 @@ def patch_lora_forwards(unet):
 
 
 # ------------------------------------------------------------------------------------------ flat bank
+def bank_order(keys):
+    """-> (site indices in buffer order, number of leading sites that belong to the up path).  Pure host logic (CPU-tested):
+    reverse traversal order with the text-state projections attn2.to_k / to_v moved to the end (see LoraBank)."""
+    def is_kv(k):
+        return k.endswith(".attn2.to_k") or k.endswith(".attn2.to_v")
+    rev = list(reversed(range(len(keys))))
+    order = [i for i in rev if not is_kv(keys[i])] + [i for i in rev if is_kv(keys[i])]
+    n_lead = 0
+    for i in order:
+        if not keys[i].startswith("up_blocks.") or is_kv(keys[i]):
+            break
+        n_lead += 1
+    return order, n_lead
+
+
 class LoraBank:
     """Re-homes every LoRA parameter of a U-Net into ONE flat fp32 buffer (+ flat grad / exp_avg / exp_avg_sq),
     so that clip-norm, AdamW and the data-parallel gradient exchange are single kernels / collectives over
@@ -313,10 +328,19 @@ class LoraBank:
     def __init__(self, unet, keys=None, extra_params=()):
         keys = keys if keys is not None else load_unet_keys(unet)
         self.layers = [_walk(unet, k).lora_layer for k in keys]
-        order = list(reversed(range(len(keys))))
+        # Gradient-ready order: reverse traversal, EXCEPT the text-state projections attn2.to_k / to_v -- at rank 32 all 32 of
+        # them are one grouped launch in front of the U-Net (unet._ctx_kv) whose backward is the LAST node of the graph, so
+        # their gradients complete last wherever their block sits: they go to the end of the buffer.  The buffer then reads
+        #   [ up_blocks sites | mid + down_blocks sites | text k|v sites | extra (mapper) ]
+        # and the first region (`n_early` elements) is complete the moment backward leaves the up path: the overlapped
+        # exchange all-reduces it under the mid / down backward (ppft.PPFTTrainer, DDP's early buckets at ppft_train.py:1058).
+        order, n_lead = bank_order(keys)
         plist = []
-        for i in order:
+        self.n_early = 0
+        for j, i in enumerate(order):
             plist += [self.layers[i].down.weight, self.layers[i].up.weight]
+            if j < n_lead:
+                self.n_early += self.layers[i].down.weight.numel() + self.layers[i].up.weight.numel()
         self.n_lora = sum(p.numel() for p in plist)
         plist += list(extra_params)
         self.params = plist

@@ -501,6 +501,23 @@ class DeferredDW:
             gemm_tn_acc(U, V, C, alpha)
 
 
+class SplitDeferred:
+    """Router in front of two DeferredDW tables for the overlapped data-parallel exchange: a weight gradient whose output
+    lies inside [lo_ptr, hi_ptr) -- the leading region of the flat gradient buffer, complete when backward leaves the up path
+    (lora.LoraBank) -- is queued on ``early``, everything else (and every dS reduction) on ``late``.  The trainer flushes and
+    all-reduces ``early`` from a hook in the middle of backward and ``late`` at its end."""
+
+    def __init__(self, early, late, lo_ptr, hi_ptr):
+        self.early, self.late, self.lo, self.hi = early, late, int(lo_ptr), int(hi_ptr)
+
+    def add_tn(self, U, V, C, alpha=1.0):
+        tgt = self.early if self.lo <= C.data_ptr() < self.hi else self.late
+        return tgt.add_tn(U, V, C, alpha)
+
+    def add_ds(self, dTs, T, dS, nb, rps, r):
+        return self.late.add_ds(dTs, T, dS, nb, rps, r)
+
+
 REF_ROUNDING = os.environ.get("AQL_REF_ROUNDING", "0") == "1"   # see LoraLinearFn.forward
 DEFERRED = None  # set by a trainer around backward (ppft.PPFTTrainer); None => every site launches its own kernels
 

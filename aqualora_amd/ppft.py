@@ -40,12 +40,20 @@ class PPFTTrainer:
         self.sec_encoder.to(dev)
         self.bank = LoraBank(unet, extra_params=[mapper.bit_embeddings.weight])
         self.pg = process_group
+        # Our own RCCL communicator (aql_comm_*, include/aqualora_hip.h): collectives on a stream of OUR choice, capturable
+        # into the step graph.  None on a single GPU, under a non-RCCL backend (gloo CPU tests), with AQL_COMM=0, or when its
+        # self-test fails on this box -- then the torch.distributed exchange below is used (`comm_note` says which and why).
+        self.comm, self.comm_note = dp.make_comm(process_group)
+        self.overlap = self.comm is not None
         # DDP broadcasts rank 0's parameters when it wraps the trainable modules (accelerator.prepare,
         # ppft_train.py:905-912).  inject_lora draws N(0, 1/r) and MapperNet an orthogonal table from each process's own
         # RNG (the reference default is seed=None): without this sync every rank would train a different replica on
         # averaged gradients.  All trainable state (LoRA + mapper) lives in the one flat buffer.
         if dp.world_size(process_group) > 1:
-            dp.broadcast_(self.bank.flat, process_group, src=0)
+            if self.overlap:
+                self.comm.broadcast_(self.bank.flat, root=0)
+            else:
+                dp.broadcast_(self.bank.flat, process_group, src=0)
             self.bank.refresh()
         self.scheduler = customDDPMScheduler(device=dev)
         self.hp = (adam_beta1, adam_beta2, adam_epsilon, adam_weight_decay)
@@ -65,9 +73,24 @@ class PPFTTrainer:
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         # data parallel: weight-gradient GEMMs run in buckets, each followed by its slice of the all-reduce (see
         # exchange_bucketed); single GPU: one grouped launch at the end of backward, no collective
-        self.bucketed = dp.exchange_active(process_group) and dp.bucket_count(4 * self.bank.n_lora) > 1
-        self.deferred = ops.DeferredDW(dev, defer_wide=self.bucketed)
+        self.bucketed = (not self.overlap and dp.exchange_active(process_group)
+                         and dp.bucket_count(4 * self.bank.n_lora) > 1)
         self.reducer = dp.BucketedAllreduce(process_group)
+        self.side = torch.cuda.Stream(device=dev) if self.overlap else None   # the collectives' stream (forked / joined)
+        if self.overlap and max(1, micro_batches) != 1:
+            raise L.AqlError("the overlapped exchange runs one backward pass per step (micro_batches = 1)")
+        self._new_deferred()
+
+    def _new_deferred(self):
+        """Descriptor tables of the held-back weight-gradient GEMMs.  Overlapped exchange: two tables behind a router -- the
+        leading `n_early` elements of the flat gradient buffer (the up path) and the rest (ops.SplitDeferred)."""
+        dev = self.bank.grad.device
+        self.deferred = ops.DeferredDW(dev, defer_wide=self.bucketed)
+        self.deferred_early = self.router = None
+        if self.overlap:
+            self.deferred_early = ops.DeferredDW(dev)
+            base = self.bank.grad.data_ptr()
+            self.router = ops.SplitDeferred(self.deferred_early, self.deferred, base, base + 4 * self.bank.n_early)
 
     # ---------------------------------------------------------------------------------------------
     def forward_backward(self, z, msg, eps, t, ctx, flush_dw=True):
@@ -90,7 +113,10 @@ class PPFTTrainer:
         main = torch.cuda.current_stream()
         n = B // micro
         preds, cleans, losses = [], [], []
-        ops.DEFERRED = self.deferred  # weight-gradient GEMMs + dS reductions of every slice are collected ...
+        ops.DEFERRED = self.router if self.overlap else self.deferred  # weight-gradient GEMMs + dS reductions are collected ...
+        if self.overlap:
+            self._early_done = False
+            self.unet._aql_up_path_done = self._early_exchange   # fires inside backward, when it leaves the up path
         try:
             if self.twin and micro == 1:
                 # ONE forward over a twin batch of 2B: clean samples (all-zero scale rows == the reference's clean pass,
@@ -139,15 +165,78 @@ class PPFTTrainer:
                     main.wait_stream(st)
         finally:
             ops.DEFERRED = None
+            if self.overlap:
+                self.unet._aql_up_path_done = None
         for tns in preds + cleans + losses:
             tns.record_stream(main)
-        if flush_dw:
-            self.deferred.flush()     # ... and run as two grouped launches here
-        else:
+        if self.overlap:
             self.deferred.flush_ds()
-        S.backward(self.ds_accum)
+            S.backward(self.ds_accum)
+            self._late_exchange()
+        else:
+            if flush_dw:
+                self.deferred.flush()     # ... and run as two grouped launches here
+            else:
+                self.deferred.flush_ds()
+            S.backward(self.ds_accum)
         loss = torch.stack(losses).mean()
         return loss, torch.cat(preds), torch.cat(cleans)
+
+    # ------------------------------------------------------------------- overlapped exchange (aql_comm_*, one graph)
+    def _tiles(self, dfr, lo, hi):
+        """The outputs of the problems queued on ``dfr`` tile [lo, hi) of the flat gradient buffer exactly."""
+        base, items = self.bank.grad.data_ptr(), dfr.items
+        offs = sorted(((C.data_ptr() - base) // 4, C.numel()) for C, _, _, _ in items)
+        pos = lo
+        for o, n in offs:
+            if o != pos:
+                return False
+            pos += n
+        return pos == hi
+
+    def _early_exchange(self):
+        """Called from the backward hook on the mid-block output (unet._aql_up_path_done): every LoRA site of the up blocks
+        has queued its weight-gradient GEMMs, whose outputs are the leading `n_early` elements of the flat gradient buffer.
+        Fork the side stream here: grouped weight-gradient launch(es) + all-reduce(mean) of that region run under the mid /
+        down backward (DDP's first-ready buckets, ppft_train.py:1058).  Inside a capture this becomes a branch of the graph."""
+        if self._early_done:
+            return
+        self._early_done = True
+        b, e = self.bank, self.deferred_early
+        if not e.items:
+            return
+        if not self._tiles(e, 0, b.n_early):
+            raise L.AqlError("overlapped exchange: the up-path weight gradients do not tile the head of the gradient buffer")
+        ranges = e.plan(b.grad, dp.bucket_count(4 * b.n_early))
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            for k, (lo, hi) in enumerate(ranges):
+                e.run_bucket(k)
+                self.comm.all_reduce_(b.grad[lo:hi], average=True)
+        self.early_ranges = ranges
+
+    def _late_exchange(self):
+        """End of backward: the remaining weight gradients in buckets on the main stream, each bucket's all-reduce on the
+        side stream under the next bucket's GEMMs; the mapper gradient (complete after S.backward) rides with the last one."""
+        b, d = self.bank, self.deferred
+        main = torch.cuda.current_stream()
+        if not self._early_done:      # no gradient reached the mid-block output (cannot happen on the PPFT path): do it now
+            self._early_exchange()
+        lo0 = b.n_early if self.deferred_early.items else 0
+        if not self._tiles(d, lo0, b.n_lora):
+            raise L.AqlError("overlapped exchange: the weight gradients do not tile the gradient buffer")
+        ranges = d.plan(b.grad, dp.bucket_count(4 * (b.n_lora - lo0)))
+        ranges[-1] = (ranges[-1][0], b.numel)          # + the mapper gradient
+        for k, (lo, hi) in enumerate(ranges):
+            d.run_bucket(k)
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                self.comm.all_reduce_(b.grad[lo:hi], average=True)
+        main.wait_stream(self.side)
+        self.late_ranges = ranges
+        self.deferred_early.reset()
+        d.reset()
 
     def exchange_gradients(self):
         """DDP's gradient all-reduce(mean) (accelerator.backward, ppft_train.py:1058) as ONE collective over the flat
@@ -192,7 +281,9 @@ class PPFTTrainer:
         b.zero_grad()
 
     def _step_body(self, z, msg, eps, t, ctx):
-        if self.bucketed:
+        if self.overlap:
+            loss, _, _ = self.forward_backward(z, msg, eps, t, ctx)    # the exchange is part of it
+        elif self.bucketed:
             loss, _, _ = self.forward_backward(z, msg, eps, t, ctx, flush_dw=False)
             self.exchange_bucketed(self.plan_exchange(), self.deferred.run_bucket)
             self.deferred.reset()
@@ -225,6 +316,9 @@ class PPFTTrainer:
         g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         if self.bucketed:
             return self._capture_bucketed(static, g_fb, g_opt)
+        import os
+        if self.overlap or (not dp.exchange_active(self.pg) and os.environ.get("AQL_ONE_GRAPH", "1") != "0"):
+            return self._capture_single(static, g_fb)
         # thread_local capture mode: with a process group alive, RCCL's watchdog thread polls hipEventQuery on the
         # warm-up collectives; under the default global mode that call is illegal while ANY thread captures and aborts
         # the process ("operation not permitted when stream is capturing") -- found with AQL_FORCE_ALLREDUCE=1.
@@ -252,6 +346,32 @@ class PPFTTrainer:
             return loss
 
         run.is_graph = True
+        return run
+
+    def _capture_single(self, static, g):
+        """The whole step as ONE HIP graph: forward + backward (+ the gradient exchange as a forked branch: the early buckets
+        under the mid / down backward, the rest behind the last weight-gradient launch, all through aql_comm_* on the side
+        stream) + clip + AdamW + re-cast.  Single GPU: the same graph without collectives."""
+        eager = (self.deferred, self.deferred_early, self.router)
+        self._new_deferred()          # the captured memcpy nodes re-read these pinned tables at every replay
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            loss, _, _ = self.forward_backward(**static)
+            self.optimizer_step()
+        captured = (self.deferred, self.deferred_early, self.router)
+        self.deferred, self.deferred_early, self.router = eager
+        self._graphs = (g, static, loss, captured)
+
+        def run(z, msg, eps, t, ctx):
+            for k, v in (("z", z), ("msg", msg), ("eps", eps), ("t", t), ("ctx", ctx)):
+                if v is not static[k]:
+                    static[k].copy_(v)
+            g.replay()
+            self.global_step += 1
+            self.lr_t.fill_(self.base_lr * self.lr_lambda(self.global_step))
+            return loss
+
+        run.is_graph = True
+        run.n_graphs = 1
         return run
 
     def _capture_bucketed(self, static, g_fb, g_opt):

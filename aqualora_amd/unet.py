@@ -130,6 +130,14 @@ class Upsample2D(nn.Module):
         return ops.conv3x3(x, _packed_conv3(self.conv), True, None, None)
 
 
+def _has_alpha(host):
+    """`up_hidden_states *= network_alpha / rank` (lora_modules.py:21-22, 39-40) is folded into the scale by lora._run_linear
+    only: the grouped q|k|v, grouped text-state k|v and fused feed-forward launches take S as it is, so a site that carries a
+    network_alpha sends its host down the per-site path.  (Always None on the PPFT path, ppft_train.py:662-666.)"""
+    ll = getattr(host, "lora_layer", None)
+    return ll is not None and getattr(ll, "network_alpha", None) is not None
+
+
 class Attention(nn.Module):
     def __init__(self, query_dim, cross_dim, heads, **kw):
         super().__init__()
@@ -178,7 +186,7 @@ class Attention(nn.Module):
         if not torch.is_tensor(scale) or hidden_states.dim() != 3 or hidden_states.dtype != torch.bfloat16:
             return None
         mods = (self.to_q, self.to_k, self.to_v)
-        if any(m.lora_layer is None or m.bias is not None for m in mods):
+        if any(m.lora_layer is None or m.bias is not None or _has_alpha(m) for m in mods):
             return None
         from .lora import _scale16, _site_of
         sites = [_site_of(m.lora_layer) for m in mods]
@@ -243,7 +251,7 @@ class FeedForward(nn.Module):
         """Training with the watermark LoRA on both linears: the whole feed-forward as one autograd node (ops.FeedForwardFn)."""
         p0, p2 = self.net[0].proj, self.net[2]
         if (not torch.is_grad_enabled() or not torch.is_tensor(scale) or p0.lora_layer is None or p2.lora_layer is None
-                or x.dim() != 3 or x.dtype != torch.bfloat16 or ops.REF_ROUNDING):
+                or x.dim() != 3 or x.dtype != torch.bfloat16 or ops.REF_ROUNDING or _has_alpha(p0) or _has_alpha(p2)):
             return None
         from .lora import _scale16, _site_of
         s0, s2 = _site_of(p0.lora_layer), _site_of(p2.lora_layer)
@@ -434,7 +442,7 @@ class UNet2DConditionModel(nn.Module):
             cache = (attns, mods)
             object.__setattr__(self, "_aql_ctxkv", cache)
         attns, mods = cache
-        if not mods or any(m.lora_layer is None or m.bias is not None for m in mods):
+        if not mods or any(m.lora_layer is None or m.bias is not None or _has_alpha(m) for m in mods):
             return
         sites = [_site_of(m.lora_layer) for m in mods]
         packs = [_packed_linear(m) for m in mods]
@@ -483,16 +491,27 @@ class UNet2DConditionModel(nn.Module):
         temb_act = self._all_time_projections(temb_act)
         ctx = encoder_hidden_states.to(self.dtype).contiguous()
         self._ctx_kv(ctx, scale)
-        h = self.conv_in(sample, scale)
-        skips = (h,)
-        for blk in self.down_blocks:
-            h, outs = blk(h, temb_act, ctx, scale)
-            skips += outs
-        h = self.mid_block(h, temb_act, ctx, scale)
-        for blk in self.up_blocks:
-            n = len(blk.resnets)
-            h = blk(h, skips[-n:], temb_act, ctx, scale)
-            skips = skips[:-n]
+        try:
+            h = self.conv_in(sample, scale)
+            skips = (h,)
+            for blk in self.down_blocks:
+                h, outs = blk(h, temb_act, ctx, scale)
+                skips += outs
+            h = self.mid_block(h, temb_act, ctx, scale)
+            hook = getattr(self, "_aql_up_path_done", None)
+            if hook is not None and h.requires_grad:
+                # d(loss)/d(mid-block output) is complete exactly when backward has left the up path (every up block's
+                # backward precedes it, nothing of the mid / down blocks has run): the trainer's cue for the early exchange
+                h.register_hook(lambda g, _f=hook: (_f(), None)[1])
+            for blk in self.up_blocks:
+                n = len(blk.resnets)
+                h = blk(h, skips[-n:], temb_act, ctx, scale)
+                skips = skips[:-n]
+        finally:
+            # `ctx` can be the caller's own tensor (bf16, contiguous): the grouped k|v side channel must not outlive this
+            # forward -- it would pin the [M, sum N] buffer between steps and hand stale k, v to a later direct block call
+            if hasattr(ctx, "_aql_kv"):
+                del ctx._aql_kv
         h = self.conv_norm_out(h, silu=True)
         h = self.conv_out(h, scale)
         if not return_dict:

@@ -157,14 +157,33 @@ class customDDPMScheduler:
     def add_noise(self, original_samples, noise, timesteps):
         return self.add_noise_pair(original_samples, None, noise, timesteps)[0]
 
+    def _sqrt_pair(self, timesteps, like):
+        acp = self.alphas_cumprod.to(device=like.device, dtype=like.dtype)[timesteps.to(like.device)]
+        sa, sb = (acp ** 0.5).flatten(), ((1 - acp) ** 0.5).flatten()
+        while sa.dim() < like.dim():
+            sa, sb = sa.unsqueeze(-1), sb.unsqueeze(-1)
+        return sa, sb
+
+    def subtract_noise(self, noisy_samples, pred_noise, timesteps):
+        """x0 = (x_t - sqrt(1 - acp_t) * eps) / sqrt(acp_t)   (utils/cschedulers.py:17-38; off the PPFT step: validation only,
+        a handful of elementwise torch ops on the caller's device)."""
+        sa, sb = self._sqrt_pair(timesteps, noisy_samples)
+        return (noisy_samples - sb * pred_noise) / sa
+
+    def get_sqrt_alpha_prod_div_sqrt_one_minus_alpha_prod(self, timesteps):
+        """sqrt(acp_t) / sqrt(1 - acp_t) per timestep (utils/cschedulers.py:40-54)."""
+        acp = self.alphas_cumprod.to(device=timesteps.device)[timesteps]
+        return (acp ** 0.5).flatten() / ((1 - acp) ** 0.5).flatten()
+
     def velocity_to_eplison(self, velocity_pred, noisy_model_input, timesteps):
         acp = self.alphas_cumprod.to(timesteps.device)[timesteps]
         sa, sb = acp ** 0.5, (1 - acp) ** 0.5
         return sb[:, None, None, None] * noisy_model_input + sa[:, None, None, None] * velocity_pred
 
 
-def get_cosine_schedule_with_warmup_lr_end(num_warmup_steps, num_training_steps, num_cycles=0.5, lr_end=0.0):
-    """lr multiplier lambda(step) of utils/misc.py:23-33."""
+def cosine_lr_lambda(num_warmup_steps, num_training_steps, num_cycles=0.5, lr_end=0.0):
+    """The lr multiplier lambda(step) of utils/misc.py:27-31 as a bare function of the step (what PPFTTrainer's device-side
+    learning-rate scalar is refreshed from; no torch.optim object exists on the flat-buffer path)."""
 
     def lr_lambda(current_step):
         if current_step < num_warmup_steps:
@@ -173,3 +192,12 @@ def get_cosine_schedule_with_warmup_lr_end(num_warmup_steps, num_training_steps,
         return max(lr_end, 0.5 * (1.0 + math.cos(math.pi * float(num_cycles) * 2.0 * progress)))
 
     return lr_lambda
+
+
+def get_cosine_schedule_with_warmup_lr_end(optimizer, num_warmup_steps, num_training_steps, num_cycles=0.5, last_epoch=-1,
+                                           lr_end=0.0):
+    """Drop-in for utils/misc.py:23-33 (call site train/ppft_train.py:896-901): same positional signature, returns a
+    ``torch.optim.lr_scheduler.LambdaLR`` over ``optimizer``.  The multiplier itself is `cosine_lr_lambda`; a trainer that keeps
+    its learning rate in a device scalar (PPFTTrainer) takes that function directly."""
+    from torch.optim.lr_scheduler import LambdaLR
+    return LambdaLR(optimizer, cosine_lr_lambda(num_warmup_steps, num_training_steps, num_cycles, lr_end), last_epoch)

@@ -35,7 +35,7 @@ def build(device, rank, seed=2048, micro=1):
     from aqualora_amd.lora import inject_lora
     from aqualora_amd.ppft import PPFTTrainer
     from aqualora_amd.unet import UNet2DConditionModel, init_synthetic, lora_keys
-    from aqualora_amd.watermark import MapperNet, SecretEncoder, get_cosine_schedule_with_warmup_lr_end
+    from aqualora_amd.watermark import MapperNet, SecretEncoder, cosine_lr_lambda
     unet = UNet2DConditionModel(device=device, dtype=torch.bfloat16)
     init_synthetic(unet, seed)
     keys = lora_keys(unet)
@@ -50,7 +50,7 @@ def build(device, rank, seed=2048, micro=1):
     with torch.no_grad():
         enc.secret_scaler[5].weight.copy_(synth.normal("enc.conv.w", (4, 4, 3, 3), 0.05, seed))
     tr = PPFTTrainer(unet, mapper, enc, rank, learning_rate=1e-4,
-                     lr_lambda=get_cosine_schedule_with_warmup_lr_end(0, 100000, lr_end=0.01), micro_batches=micro)
+                     lr_lambda=cosine_lr_lambda(0, 100000, lr_end=0.01), micro_batches=micro)
     return tr
 
 
@@ -68,22 +68,26 @@ def synthetic_batch(B, device, rank_id, seed=2048, step=0):
 
 
 def time_kernel(fn, iters=20):
-    """Average GPU time of one call of fn (ms): `iters` calls are captured into one HIP graph and the replay is bracketed by HIP
+    """GPU time of one call of fn -> (ms, how).  `iters` calls are captured into one HIP graph and the replay is bracketed by HIP
     events on torch's current stream (the stream the C-ABI launches go to) -- eager calls of a ~50 us kernel are bound by the
-    Python / ctypes call overhead, not by the kernel."""
+    Python / ctypes call overhead, not by the kernel.  Reported: the MINIMUM over 3 replays of the per-call average (`how` says
+    so, and says "eager" if the capture was refused and the calls were timed one by one instead)."""
     fn()
     torch.cuda.synchronize()
+    how = f"hip-graph replay of {iters} launches, min of 3 replays"
+    gr = torch.cuda.CUDAGraph()
     try:
-        gr = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gr):
             for _ in range(iters):
                 fn()
-        run, n = gr.replay, iters
-    except Exception:   # not capturable: time the eager calls
+        run = gr.replay
+    except RuntimeError as e:   # capture refused: torch.cuda.graph's __exit__ has ended the capture; time the eager calls
+        torch.cuda.synchronize()
+        how = f"EAGER ({iters} launches, min of 3; graph capture failed: {str(e)[:80]})"
+
         def run():
             for _ in range(iters):
                 fn()
-        n = iters
     run()
     torch.cuda.synchronize()
     best = None
@@ -93,51 +97,73 @@ def time_kernel(fn, iters=20):
         run()
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / n
+        ms = e0.elapsed_time(e1) / iters
         best = ms if best is None else min(best, ms)
-    return best  # ms
+    return best, how
 
 
 def dominant_kernels(B, device):
-    """HIP-event timing (torch's current stream == the launch stream of the C-ABI calls) of the two kernels that
-    carry most FLOPs: the implicit-GEMM 3x3 conv and the fused LoRA GEMM, at their largest U-Net shapes."""
+    """HIP-event timings (torch's current stream == the launch stream of the C-ABI calls) of the heaviest launch of each
+    kernel family, at the shapes the step runs them.  kernels[0] is the heaviest launch of the TIME-dominant family (the
+    one-launch LoRA linears: 34 % of the step, profiles/r03_families.json): ff.net.0.proj + rank-32 LoRA + GEGLU on the twin
+    batch of the 64x64 level.  The forward runs both U-Net passes as ONE twin batch of 2B samples (ops._Dual), so forward
+    launches see 2B samples; rows of the clean half skip the LoRA branch (lora_row0)."""
+    from aqualora_amd import _lib as L
     from aqualora_amd import ops, synth
     out = []
-    # the forward runs both U-Net passes of the step as ONE twin batch of 2B samples (aqualora_amd/ops.py, _Dual): that is
-    # the shape the dominant kernel sees in the step; the backward-data convolutions run at B
+
+    def entry(kernel, ms_how, fl, **kw):
+        ms, how = ms_how
+        d = {"kernel": kernel, "ms": ms, "timing": how, "flops": fl, "achieved_tflops": fl / ms / 1e9,
+             "frac_of_mfma_peak": fl / ms / 1e9 / MFMA_PEAK_TF}
+        d.update(kw)
+        out.append(d)
+
+    # (0) ff.net.0.proj 320 -> 2x1280 + LoRA + GEGLU, twin batch: M = 2B x 4096 rows, LoRA on rows >= M/2, the pre-activation H
+    # written for those rows only (what FeedForwardFn's backward needs)
+    M, K, F = 2 * B * 4096, 320, 1280
+    X = synth.normal("k.gx", (M, K), 1.0, 1, device).to(torch.bfloat16)
+    W = synth.normal("k.gw", (2 * F, K), K ** -0.5, 1, device).to(torch.bfloat16)
+    bias = synth.normal("k.gb", (2 * F,), 0.02, 1, device).to(torch.bfloat16)
+    A = synth.normal("k.ga", (32, K), 1.0 / 32, 1, device).to(torch.bfloat16)
+    Bu = synth.normal("k.gu", (2 * F, 32), 0.02, 1, device).to(torch.bfloat16)
+    S = torch.cat([torch.zeros(B, 32, device=device), synth.normal("k.gs", (B, 32), 1.0, 1, device)]).to(torch.bfloat16)
+    H = torch.empty(M, 2 * F, dtype=torch.bfloat16, device=device)
+    G = torch.empty(M, F, dtype=torch.bfloat16, device=device)
+    T = torch.empty(M, 32, dtype=torch.bfloat16, device=device)
+    Ts = torch.empty_like(T)
+
+    def geglu_call():
+        rc = L.call_raw("aql_lora_gemm_fused_geglu", L.ptr(X), K, L.ptr(W), K, M, F, K, L.ptr(A), L.ptr(S), 4096, L.ptr(Bu),
+                        L.ptr(bias), L.ptr(H), 2 * F, L.ptr(G), F, L.ptr(T), L.ptr(Ts), M // 2, L.stream_ptr())
+        assert rc == 0, rc
+    fl = 2.0 * M * K * 2 * F + (M // 2) * 2.0 * (K * 32 + 32 * 2 * F)
+    alg = 2.0 * (M * K + 2 * F * K + M * F + (M // 2) * 2 * F + 2 * (M // 2) * 32)
+    entry("lora_gemm_kernel<128,160,64,80,2> (GEGLU epilogue) ff.net.0.proj 320->2x1280 + rank-32 LoRA + GEGLU, "
+          f"{2 * B} samples x 4096 tokens (twin forward)", time_kernel(geglu_call), fl, samples=2 * B, algorithmic_bytes=alg,
+          pmc_key=f"lora_geglu 320->2x1280 M={M}")
+    del X, W, H, G, T, Ts
+    # (1, 2) the FLOP-dominant family: 3x3 conv 320->320 @64x64 (48 % of the step's algorithmic FLOPs)
     w = synth.normal("k.w", (320, 320, 3, 3), 0.02, 1, device)
     pk = ops.PackedConv3x3(w, torch.zeros(320, device=device), 1)
     for nb, tag in ((2 * B, "twin forward"), (B, "batch-B shape")):
         x = synth.normal("k.x", (nb, 320, 64, 64), 1.0, 1, device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         with torch.no_grad():
-            ms = time_kernel(lambda: ops.conv3x3(x, pk))
+            th = time_kernel(lambda: ops.conv3x3(x, pk))
         fl = 2.0 * nb * 64 * 64 * 320 * 9 * 320
         # 2B samples: 256 tiles of 256x160 on the 12-wave kernel (one chip-wide round); B samples: 256 tiles of 128x160, 8 waves
         # (also two whole rounds of 256x160 tiles: config 3's twin forward; the picker is aql_gemm.hip launch_cfg)
         t256 = nb * 4096 // 256 * 2
         kname = ("conv_row_kernel (256x160 row tile, 12 waves)" if t256 in range(240, 257) or t256 == 512
                  else "conv_row_kernel (128x160 row tile, 8 waves)")
-        out.append({"kernel": f"{kname} conv3x3 320->320 @64x64, {nb} samples ({tag})",
-                    "ms": ms, "samples": nb, "flops": fl, "achieved_tflops": fl / ms / 1e9, "frac_of_mfma_peak": fl / ms / 1e9 / MFMA_PEAK_TF})
-    xs = synth.normal("k.x2", (B * 4096, 320), 1.0, 1, device).to(torch.bfloat16)
-    wl = synth.normal("k.w2", (2560, 320), 0.05, 1, device)
-    pl = ops.PackedLinear(wl, torch.zeros(2560, device=device))
-    with torch.no_grad():
-        ms = time_kernel(lambda: ops.lora_linear(xs, pl))
-    fl = 2.0 * B * 4096 * 320 * 2560
-    out.append({"kernel": "gemm_kernel_d<128,160,64,80,PlainLoader,PlainLoader,EPI_BF16,2> ff.net.0.proj 320->2560 @4096 tok",
-                "ms": ms, "flops": fl, "achieved_tflops": fl / ms / 1e9,
-                "frac_of_mfma_peak": fl / ms / 1e9 / MFMA_PEAK_TF})
-    # the "attention GEMMs" of the north star: flash attention at the 64x64 level (8 heads of 40, 4096 tokens) ...
+        entry(f"{kname} conv3x3 320->320 @64x64, {nb} samples ({tag})", th, fl, samples=nb,
+              algorithmic_bytes=2.0 * nb * 64 * 64 * 320 * 2 + 320 * 2880 * 2, pmc_key=f"conv3x3 320->320 @64x64 B={nb}")
+    # (3) the "attention GEMMs" of the north star: flash attention at the 64x64 level (8 heads of 40, 4096 tokens) ...
     qkv = [synth.normal(f"k.{n}", (B, 4096, 320), 1.0, 1, device).to(torch.bfloat16) for n in "qkv"]
     with torch.no_grad():
-        ms = time_kernel(lambda: ops.attention(qkv[0], qkv[1], qkv[2], 8))
-    fl = 4.0 * B * 8 * 4096 * 4096 * 40
-    out.append({"kernel": "attn_fwd_kernel<64,48,4> self-attention 8 heads x 40, 4096 tokens", "ms": ms, "flops": fl,
-                "achieved_tflops": fl / ms / 1e9, "frac_of_mfma_peak": fl / ms / 1e9 / MFMA_PEAK_TF,
-                "note": "d=40 is padded to 64 (QK^T) / 48 (PV): 1.4x the algorithmic MFMA work"})
-    # ... and the one-launch rank-32 LoRA linear of the same level (to_q / to_k / to_v / to_out, 320 -> 320)
-    from aqualora_amd import _lib as L
+        th = time_kernel(lambda: ops.attention(qkv[0], qkv[1], qkv[2], 8))
+    entry("attn_fwd_kernel self-attention 8 heads x 40, 4096 tokens", th, 4.0 * B * 8 * 4096 * 4096 * 40, samples=B)
+    # (4) ... and the one-launch rank-32 LoRA linear of the same level (to_out / attn2.to_q / proj_in / proj_out, 320 -> 320)
     X = synth.normal("k.lx", (B * 4096, 320), 1.0, 1, device).to(torch.bfloat16)
     Wl = synth.normal("k.lw", (320, 320), 0.05, 1, device).to(torch.bfloat16)
     Al = synth.normal("k.la", (32, 320), 0.05, 1, device).to(torch.bfloat16)
@@ -151,11 +177,48 @@ def dominant_kernels(B, device):
         rc = L.call_raw("aql_lora_gemm_fused", L.ptr(X), 320, L.ptr(Wl), 320, B * 4096, 320, 320, L.ptr(Al), L.ptr(Sl), 4096,
                         L.ptr(Bl), None, None, 0, L.ptr(Yl), 320, L.ptr(Tl), L.ptr(Tsl), 0, L.stream_ptr())
         assert rc == 0, rc
-    ms = time_kernel(lora_call)
-    fl = 2.0 * B * 4096 * 320 * (320 + 32) + 2.0 * B * 4096 * 32 * 320
-    out.append({"kernel": "lora_gemm_kernel<64,160,32,80,2> attention projection 320->320 + rank-32 LoRA @4096 tok", "ms": ms,
-                "flops": fl, "achieved_tflops": fl / ms / 1e9, "frac_of_mfma_peak": fl / ms / 1e9 / MFMA_PEAK_TF})
+    entry("lora_gemm_kernel attention projection 320->320 + rank-32 LoRA @4096 tok (backward-data shape)", time_kernel(lora_call),
+          2.0 * B * 4096 * 320 * (320 + 32) + 2.0 * B * 4096 * 32 * 320, samples=B)
     return out
+
+
+def load_profile_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
+def config3_record(device, rank_id, steps=10, warmup=3):
+    """BASELINE config 3 per GPU (rank 320, batch 8; train/README.md:34-48) on this GPU, as a sub-record of the default line:
+    the same captured step, HIP-event median over `steps` replays with a fresh batch each."""
+    rank, B = 320, 8
+    tr = build(device, rank)
+    batches = [synthetic_batch(B, device, rank_id, step=i) for i in range(4)]
+    run = tr.capture(batches[0])
+    for i in range(warmup):
+        run(**batches[i % 4])
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        evs[i][0].record()
+        loss = run(**batches[i % 4])
+        evs[i][1].record()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    per = sorted(a.elapsed_time(b) for a, b in evs)
+    tf = step_tflop_per_image(rank) * B
+    rec = {"workload": f"SD1.5 PPFT LoRA rank={rank}, batch={B}/GPU (BASELINE config 3 per GPU), latent-in, 1 GPU",
+           "value": B / dt, "unit": "images/sec", "ms_per_step": 1e3 * dt, "ms_per_step_hip_event_median": per[len(per) // 2],
+           "steps": steps, "warmup": warmup, "loss": float(loss), "hip_graph": bool(getattr(run, "is_graph", False)),
+           "step_roofline": {"bound": "mfma", "achieved": tf / dt, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
+                             "frac": tf / dt / MFMA_PEAK_TF,
+                             "launch": f"one PPFT step = {step_tflop_per_image(rank):.3f} TFLOP/image x {B} images"}}
+    del tr, run
+    torch.cuda.empty_cache()
+    return rec
 
 
 def cpu_baseline(tr, rank):
@@ -185,13 +248,21 @@ def cpu_baseline(tr, rank):
         t0 = time.perf_counter()
         O.UNetOracle(sd, dict(SD15)).forward(z, t, ctx, None)
         fwd_s = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    loss, _, _, _ = O.ppft_loss(sd, dict(SD15), lora, E, msg, z, wm, eps, t, ctx)
-    loss.backward()
-    step_s = time.perf_counter() - t0
+    times = []
+    for _ in range(3):   # 1 warm-up + 3 timed steps, median
+        for pr in lora.values():
+            for p in pr:
+                p.grad = None
+        E.grad = None
+        t0 = time.perf_counter()
+        loss, _, _, _ = O.ppft_loss(sd, dict(SD15), lora, E, msg, z, wm, eps, t, ctx)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+    step_s = sorted(times)[1]
     return {"value": 1.0 / step_s, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"one full PPFT step of oracle/ppft_oracle.py (clean fwd + LoRA fwd + backward to {2 * len(keys)} LoRA "
-                      f"tensors) on the full-size SD-1.5 U-Net, batch 1, fp32: {step_s:.2f} s (warm-up forward {fwd_s:.2f} s)"}
+            "sample": f"median of 3 full PPFT steps of oracle/ppft_oracle.py (clean fwd + LoRA fwd + backward to {2 * len(keys)} "
+                      f"LoRA tensors) on the full-size SD-1.5 U-Net, batch 1, fp32, {cores} threads: "
+                      + " / ".join(f"{x:.2f}" for x in times) + f" s (after a warm-up forward of {fwd_s:.2f} s)"}
 
 
 def vae_bench(args, device):
@@ -502,28 +573,42 @@ def main():
                                    f"batch={args.batch}/GPU, " + ("pixel-in (frozen VAE encode inside the step" + (", CLIP text encoder inside" if args.text_in else ", CLIP outside") + ")"
                                                                   if args.pixel_in else "latent-in (VAE/CLIP outside the path)"),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "baseline_config": args.config, "inputs": "fresh random batch every step", "hip_graph": bool(getattr(runner, "is_graph", False)),
+                       "graphs_per_step": getattr(runner, "n_graphs", None),
+                       "exchange": ("aql_comm_* (RCCL) on a forked stream, captured in the step graph; early buckets overlap backward"
+                                    if tr.overlap else ("torch.distributed all-reduce between graphs (" + tr.comm_note + ")"
+                                                        if world > 1 or os.environ.get("AQL_FORCE_ALLREDUCE") else "none (single GPU)")),
                        "loss": loss_v},
         }
         with torch.no_grad():
             ks = dominant_kernels(args.batch, device)
         dom = ks[0]
-        # dominant kernel = the implicit-GEMM 3x3 convolution family (48 % of the step's algorithmic FLOPs); timed live
-        # with HIP events on the launch stream.  `traffic` = HBM bytes per launch of the same kernel and shape from the
-        # rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 2x FETCH correction), collected
-        # with tools/pmc_traffic.sh and committed as profiles/r02_pmc_traffic.json; null for batch sizes without a committed pass.
-        traffic = None
-        alg = 2.0 * dom["samples"] * 64 * 64 * 320 * 2 + 320 * 2880 * 2
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
-        if os.path.exists(pmc_path):
-            with open(pmc_path) as f:
-                ent = json.load(f).get(f"conv3x3 320->320 @64x64 B={dom['samples']}")
-            traffic = None if ent is None else ent["traffic_bytes"]
+        # `roofline` = the heaviest launch of the TIME-dominant kernel family (the one-launch LoRA linears, `families` below),
+        # timed live with HIP events on the launch stream.  `traffic` = HBM bytes per launch of the same kernel and shape from
+        # the rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 2x FETCH correction, tools/pmc_traffic.sh),
+        # read from the committed profiles/r03_pmc_traffic.json -- NOT measured in this run; null without a committed pass.
+        pmc = load_profile_json("r03_pmc_traffic.json") or {}
+        ent = pmc.get(dom.get("pmc_key", ""))
+        traffic = None if ent is None else ent["traffic_bytes"]
         line["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_tflops"],
                             "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": dom["frac_of_mfma_peak"],
-                            "traffic": traffic, "traffic_unit": f"bytes/launch (algorithmic: {alg:.4g})",
+                            "traffic": traffic, "traffic_unit": f"bytes/launch (algorithmic: {dom['algorithmic_bytes']:.4g})",
                             "traffic_source": None if traffic is None else
-                            "static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel+shape, " + os.path.basename(pmc_path),
-                            "flops_per_launch": dom["flops"], "ms_per_launch": dom["ms"]}
+                            "static, not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel + shape, "
+                            "profiles/r03_pmc_traffic.json",
+                            "flops_per_launch": dom["flops"], "ms_per_launch": dom["ms"], "timing": dom["timing"],
+                            "selected_by": "largest ms/step family of the committed kernel trace (families), heaviest launch of it",
+                            "hbm_view": {"achieved_GBps": dom["algorithmic_bytes"] / dom["ms"] / 1e6, "peak_GBps": 8000.0,
+                                         "frac": dom["algorithmic_bytes"] / dom["ms"] / 1e6 / 8000.0}}
+        for k in ks:
+            e = pmc.get(k.get("pmc_key", ""))
+            if e is not None:
+                k["traffic_bytes_static"] = e["traffic_bytes"]
+        fam = load_profile_json(f"r03_families_config{args.config}.json")
+        if fam is not None:
+            line["families"] = {"source": f"static, not measured in this run: profiles/r03_families_config{args.config}.json "
+                                          "(tools/prof_families.py over a rocprofv3 --kernel-trace of this command)",
+                                "ms_per_step_profiled": fam.get("ms_per_step"), "launches_per_step": fam.get("launches_per_step"),
+                                "rows": fam.get("families")}
         line["step_roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
                                  "frac": achieved / MFMA_PEAK_TF,
                                  "launch": f"one PPFT step = {tf_img:.3f} TFLOP/image x {args.batch} images"}
@@ -543,6 +628,8 @@ def main():
             line["pixel_text_in"] = {"value": args.batch / dtx, "unit": "images/sec", "ms_per_step": 1e3 * dtx, "steps": n_x,
                                      "workload": "same step with the frozen VAE encode (3x512x512 -> 4x64x64) and CLIP text "
                                                  "encoder (ids [B,77] -> [B,77,768]) inside, ppft_train.py:993,1014-1019"}
+        if world == 1 and not args.no_extras and args.config == 2 and args.rank == 32 and not (args.pixel_in or args.text_in):
+            line["config3"] = config3_record(device, rank_id)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tr, args.rank)
         print(json.dumps(line), flush=True)

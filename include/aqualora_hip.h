@@ -358,6 +358,34 @@ int aql_lpips_layer(const bf16_t* f0, const bf16_t* f1, const float* w, int B, l
 int aql_lpips_layer_bwd(const bf16_t* f0, const bf16_t* f1, const float* w, int B, long HW, int C, const float* gout,
                         bf16_t* df1, aql_stream_t stream);
 
+/* ---- csrc/aql_comm.hip: the data-parallel exchange over RCCL / xGMI (one process per GPU) ---------------------------------
+ * Replaces what accelerate's DDP wrapper does for the trainable LoRA + mapper parameters: the construction-time parameter
+ * broadcast (train/ppft_train.py:905-912, accelerator.prepare) and the gradient all-reduce(mean) fired from
+ * accelerator.backward (:1058); aql_comm_all_gather also serves the logged-loss gather (:1054).  Every collective is enqueued
+ * on the CALLER's stream: it can sit on a forked side stream under the rest of backward and be captured into the step's
+ * hipGraph.  RCCL is bound at run time (dlopen librccl.so.1: the instance PyTorch-ROCm already loaded, when there is one).
+ *   aql_comm_unique_id   rank 0: 128 opaque bytes, handed to every rank by the launcher's side channel
+ *   aql_comm_init        collective: communicator of the current HIP device  ->  *comm
+ *   aql_comm_size        number of ranks (or -1): a count, not a status
+ *   aql_comm_all_reduce_f32      buf <- sum | mean over ranks, in place
+ *   aql_comm_reduce_scatter_f32  recv[recv_n] <- this rank's slice of the sum | mean of send[recv_n * nranks]
+ *   aql_comm_all_gather          recv[rank * send_bytes ...] <- send of every rank (ZeRO-1 parameter gather, loss gather)
+ *   aql_comm_broadcast           buf of `root` overwrites everyone's
+ *   aql_comm_abort / aql_comm_destroy
+ * aql_abi_version: AQL_ABI_VERSION of the built library; bumped when an existing entry point changes its signature
+ * (round 2 inserted `lora_row0` into aql_lora_gemm_fused): a binding built against another version must refuse to load.   */
+#define AQL_ABI_VERSION 3
+int aql_abi_version(void);
+int aql_comm_unique_id(void* id128);
+int aql_comm_init(const void* id128, int nranks, int rank, void** comm);
+int aql_comm_size(void* comm);
+int aql_comm_all_reduce_f32(void* comm, float* buf, long n, int average, aql_stream_t stream);
+int aql_comm_reduce_scatter_f32(void* comm, const float* send, float* recv, long recv_n, int average, aql_stream_t stream);
+int aql_comm_all_gather(void* comm, const void* send, void* recv, long send_bytes, aql_stream_t stream);
+int aql_comm_broadcast(void* comm, void* buf, long nbytes, int root, aql_stream_t stream);
+int aql_comm_abort(void* comm);
+int aql_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

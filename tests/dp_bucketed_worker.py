@@ -35,23 +35,34 @@ def main():
         inp = ppft_inputs(device=dev, rank=rank)
         batch = dict(z=inp["z"], msg=inp["msg"], eps=inp["eps"], t=inp["t"], ctx=inp["ctx"].to(torch.bfloat16))
         res = {}
-        for mode in ("plain", "bucketed_eager", "bucketed_graph"):
-            if mode == "plain":
-                os.environ.pop("AQL_FORCE_ALLREDUCE", None)
-            else:
+        # plain: single-GPU form.  overlap_*: our RCCL communicator (aql_comm_*), collectives forked onto a side stream from the
+        # backward hook and captured into the ONE step graph.  bucketed_*: the torch.distributed form (AQL_COMM=0), bucket
+        # graphs with eager collectives between them -- the fallback when the communicator's self-test fails.
+        for mode in ("plain", "overlap_eager", "overlap_graph", "bucketed_eager", "bucketed_graph"):
+            os.environ.pop("AQL_FORCE_ALLREDUCE", None)
+            os.environ.pop("AQL_COMM", None)
+            os.environ.pop("AQL_BUCKETS", None)
+            if mode != "plain":
                 os.environ["AQL_FORCE_ALLREDUCE"] = "1"
                 os.environ["AQL_BUCKETS"] = "3"     # the tiny bank is far below the size where bucketing switches on
+            if mode.startswith("bucketed"):
+                os.environ["AQL_COMM"] = "0"
             tr = build(rank, inp)
-            assert tr.bucketed == (mode != "plain")
-            run = tr.capture(batch, warmup=0) if mode == "bucketed_graph" else tr.step
+            assert tr.bucketed == mode.startswith("bucketed"), (mode, tr.bucketed, tr.comm_note)
+            assert tr.overlap == mode.startswith("overlap"), (mode, tr.overlap, tr.comm_note)
+            run = tr.capture(batch, warmup=0) if mode.endswith("_graph") else tr.step
             losses = [float(run(**batch)) for _ in range(3)]
             torch.cuda.synchronize()
             res[mode] = (losses, tr.bank.flat.clone())
             if mode == "bucketed_graph":
                 out[f"r{rank}_ranges"] = [list(map(int, r)) for r in tr.exchange_ranges]
                 out[f"r{rank}_n_lora"] = int(tr.bank.n_lora)
+            if mode == "overlap_graph":
+                out[f"r{rank}_overlap_ranges"] = [list(map(int, r)) for r in list(tr.early_ranges) + list(tr.late_ranges)]
+                out[f"r{rank}_n_early"], out[f"r{rank}_numel"] = int(tr.bank.n_early), int(tr.bank.numel)
+                out[f"r{rank}_overlap_graphs"] = int(getattr(run, "n_graphs", 0))
         lp, pp = res["plain"]
-        for mode in ("bucketed_eager", "bucketed_graph"):
+        for mode in ("overlap_eager", "overlap_graph", "bucketed_eager", "bucketed_graph"):
             l, p = res[mode]
             out[f"r{rank}_{mode}_param_relerr"] = float((p - pp).abs().max() / pp.abs().max())
             out[f"r{rank}_{mode}_losses"] = l

@@ -31,6 +31,13 @@ def test_header_matches_binding_and_library():
     for name in bound:
         assert name in decls, f"{name} bound in _lib.py but missing from include/aqualora_hip.h"
     assert set(decls) - set(bound) <= {"aql_last_error", "aql_groupnorm_scratch_floats", "aql_bn_scratch_floats", "aql_prvl_scratch_floats"}
+    # the version the header declares == the one the binding was written against == the one the built library reports
+    hdr = open(os.path.join(ROOT, "include", "aqualora_hip.h")).read()
+    ver = int(re.search(r"#define\s+AQL_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert ver == _lib.ABI_VERSION == lib.aql_abi_version()
+    # the SURVEY section 8(b) minimum set of the exchange is exported
+    for name in ("aql_comm_init", "aql_comm_all_reduce_f32", "aql_comm_reduce_scatter_f32", "aql_comm_all_gather", "aql_comm_destroy"):
+        assert name in decls and hasattr(lib, name)
 
 
 def test_product_path_fails_loudly_without_gpu():

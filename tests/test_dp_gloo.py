@@ -63,6 +63,26 @@ def _worker(rank, world, port, q):
     ref2 = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.BatchNorm1d(5))
     ok_mod = ok_mod and all(torch.equal(a_, b_) for a_, b_ in zip(net2.parameters(), ref2.parameters()))
     ok_mod = ok_mod and float(net2[1].running_var[0]) == 2.0
+    # the overlapped exchange of PPFTTrainer (aql_comm_* on the GPU; the same protocol over gloo here): the buffer is
+    # [early region | late region | mapper]; the early region is planned and reduced first (from the backward hook), the late
+    # one at the end of backward with the mapper gradient riding on its last bucket -- together they must give the plain mean
+    from aqualora_amd import ops
+    sizes = [257, 1024, 33, 512, 4096, 7, 900, 2048, 129]                # nine weight-gradient outputs, back to back
+    offs = [sum(sizes[:i]) for i in range(len(sizes))]
+    n_lora, n_early = sum(sizes), sum(sizes[:4])
+    d = synth.normal("grad", (n,), 1.0, seed=100 + rank)[:n_lora + 100].clone()   # + a 100-element "mapper" tail
+    want_d = want[:n_lora + 100]
+    early = ops.plan_buckets(offs[:4], sizes[:4], 2)
+    late = ops.plan_buckets(offs[4:], sizes[4:], 3)
+    ranges = [(lo, hi) for lo, hi, _ in early] + [(lo, hi) for lo, hi, _ in late]
+    ranges[-1] = (ranges[-1][0], d.numel())
+    ok_tile = (ranges[0][0] == 0 and any(hi == n_early for _, hi in ranges)
+               and all(x[1] == y[0] for x, y in zip(ranges, ranges[1:])))
+    red2 = dp.BucketedAllreduce()
+    for lo, hi in ranges:
+        red2.launch(d[lo:hi])
+    red2.finish()
+    ok_async = ok_async and ok_tile and torch.allclose(d, want_d, atol=1e-6)
     q.put((rank, torch.allclose(a, want, atol=1e-6), torch.equal(a, b) and ok_async and ok_mod,
            not torch.equal(gathered[0], gathered[1])))
     dist.destroy_process_group()
@@ -120,3 +140,23 @@ def test_plan_buckets_tiles_the_flat_buffer():
     except ValueError:
         pass
     assert dp.bucket_count(54 << 20) == 1 and dp.bucket_count(543 << 20) == 8 and dp.bucket_count(200 << 20) == 3
+
+
+def test_bank_order_puts_the_up_path_first_and_the_text_projections_last():
+    """lora.bank_order (host logic of the flat gradient buffer's layout): reverse traversal, text-state k|v projections at the
+    end, the up path a gap-free prefix -- what lets the overlapped exchange all-reduce the head of the buffer from the hook on
+    the mid-block output while the mid / down backward is still running."""
+    from aqualora_amd.lora import bank_order
+    from aqualora_amd.unet import lora_keys
+    from tests.common import tiny_unet
+    keys = lora_keys(tiny_unet())
+    order, n_lead = bank_order(keys)
+    assert sorted(order) == list(range(len(keys)))
+    names = [keys[i] for i in order]
+    is_kv = lambda k: k.endswith(".attn2.to_k") or k.endswith(".attn2.to_v")   # noqa: E731
+    n_kv = sum(is_kv(k) for k in keys)
+    assert all(is_kv(k) for k in names[-n_kv:]) and not any(is_kv(k) for k in names[:-n_kv])
+    assert n_lead == sum(k.startswith("up_blocks.") and not is_kv(k) for k in keys) > 0
+    assert all(k.startswith("up_blocks.") for k in names[:n_lead]) and names[n_lead].startswith("mid_block.")
+    body = names[:-n_kv]
+    assert body == [k for k in reversed(keys) if not is_kv(k)]                 # gradient-ready order otherwise

@@ -130,6 +130,55 @@ def _gpu_tiny(rank=TINY_RANK, up_std=0.1):
     return unet, keys, lw
 
 
+def test_network_alpha_reaches_every_site_of_the_unet():
+    """`up_hidden_states *= network_alpha / rank` (utils/lora_modules.py:21-22, 39-40) at U-Net level, rank 32 with a LoraBank
+    (the configuration in which q|k|v, the text-state k|v and the feed-forward take the grouped / fused launches): a model
+    whose 192 LoRA layers carry network_alpha = 8 under scale S must equal the same model without alpha under S * 8/32 --
+    forward and the gradient that reaches S -- i.e. no site drops or double-applies the factor."""
+    from aqualora_amd.lora import LoraBank, inject_lora, patch_lora_forwards
+    from aqualora_amd.unet import lora_keys
+    rank = 32
+    # channel counts that are multiples of 160 (head dims 80 / 160): the shapes the grouped launches accept
+    cfg = dict(block_out_channels=(160, 320, 320, 320), cross_attention_dim=32, attention_heads=2, layers_per_block=1)
+    unet = tiny_unet(DEV, torch.bfloat16, cfg)
+    keys = lora_keys(unet)
+    state = {}
+    for k, (d, u) in tiny_lora(keys, unet, rank, 0.1).items():
+        state[k + ".down.weight"], state[k + ".up.weight"] = d, u
+    inject_lora(unet, rank, keys, state)
+    patch_lora_forwards(unet)
+    bank = LoraBank(unet)      # stacks the bf16 A / Bup copies: the grouped launches become eligible
+    inp = ppft_inputs(cfg, rank=rank, device=DEV)
+    x, t, ctx = inp["z"].to(torch.bfloat16), inp["t"], inp["ctx"].to(torch.bfloat16)
+    S0 = 1.0 + 0.3 * T("alpha.S", (x.shape[0], rank), 1.0, DEV)
+
+    def run(alpha, S):
+        for k in keys:
+            unet.get_submodule(k).lora_layer.network_alpha = alpha
+        S = S.clone().requires_grad_(True)
+        y = unet(x, t, ctx, cross_attention_kwargs={"scale": S}).sample
+        y.float().square().mean().backward()
+        return y.detach(), S.grad.detach()
+
+    from aqualora_amd import ops
+    calls = []
+    real = ops.lora_linear_grouped
+    ops.lora_linear_grouped = lambda *a: (calls.append(len(a[3])), real(*a))[1]
+    try:
+        y_ref, g_ref = run(None, S0 * (8.0 / rank))
+        assert calls and max(calls) > 3, calls      # the alpha-free model does take the grouped q|k|v and text k|v launches
+        calls.clear()
+        y_a, g_a = run(8.0, S0)
+        assert not calls                            # ... and a model with network_alpha does not
+    finally:
+        ops.lora_linear_grouped = real
+    y_none, _ = run(None, S0)
+    assert relerr(y_a, y_ref) < 1e-2, relerr(y_a, y_ref)
+    assert relerr(y_none, y_ref) > 4 * relerr(y_a, y_ref) + 1e-3   # the factor matters here: a dropped alpha would be seen
+    # dL/dS carries the chain-rule factor alpha / rank
+    assert l2rel(g_a, g_ref * (8.0 / rank)) < 3e-2, l2rel(g_a, g_ref * (8.0 / rank))
+
+
 def test_tiny_unet_forward_vs_oracle_and_golden(golden):
     from oracle import ppft_oracle as O
     g = golden("tiny_ppft.npz")
@@ -282,9 +331,11 @@ def test_full_size_ppft_gradients_vs_oracle(rank):
           f"{rels_s[-1]:.3f}; norm error median {sorted(norm_err)[len(norm_err) // 2]:.3f} worst {max(norm_err):.3f}; "
           f"loss {loss.item():.5e} vs {lo_loss.item():.5e}")
     assert len(rels) >= 300
-    # measured on MI355X: r=32 median 0.019 / worst 0.042, r=320 median 0.038 / worst 0.069 (bf16 activations + weights)
-    assert rels_s[len(rels_s) // 2] < 0.06 and rels_s[-1] < 0.12, (rels_s[len(rels_s) // 2], rels_s[-1])
-    assert max(norm_err) < 0.05, max(norm_err)   # measured worst 0.010 (r=32) / 0.017 (r=320)
+    # measured on MI355X: r=32 median 0.019 / worst 0.042, r=320 median 0.038 / worst 0.069 (bf16 activations + weights);
+    # bounds = 2x measured (never looser than round 2's 0.06 / 0.12); norm error measured worst 0.010 / 0.017
+    b_med, b_worst, b_norm = {32: (0.04, 0.085, 0.02), 320: (0.06, 0.12, 0.035)}[rank]
+    assert rels_s[len(rels_s) // 2] < b_med and rels_s[-1] < b_worst, (rels_s[len(rels_s) // 2], rels_s[-1])
+    assert max(norm_err) < b_norm, max(norm_err)
     assert l2rel(mapper.bit_embeddings.weight.grad, Eo.grad) < 0.1
 
 
@@ -324,6 +375,17 @@ def test_full_size_batch4_twin_step_equals_the_mean_of_four_batch1_steps():
     tr.bank.zero_grad()
     loss4, pred4, clean4 = tr.forward_backward(z, msg, eps, t, ctx)
     g4 = tr.bank.grad[:n].clone()
+    # Run-to-run spread: dA / dB (gemm_tn_tr_grouped_kernel) and dS (lora_ds) accumulate with fp32 atomics, so the summation
+    # order -- and the last bits -- change from run to run; everything upstream is deterministic.  The same step again:
+    tr.bank.zero_grad()
+    loss4b, pred4b, _ = tr.forward_backward(z, msg, eps, t, ctx)
+    g4b = tr.bank.grad[:n]
+    assert torch.equal(pred4b, pred4) and loss4b.item() == loss4.item()           # forward + loss: bit-identical
+    spread_l2 = l2rel(g4b, g4)
+    spread_max = ((g4b - g4).abs().max() / g4.abs().max()).item()
+    print(f"atomic accumulation spread between two identical steps: l2rel {spread_l2:.2e}, max |diff| / max |g| {spread_max:.2e}")
+    assert spread_l2 < 2e-5 and spread_max < 2e-5, (spread_l2, spread_max)        # fp32 reassociation only (eps = 6e-8 per add)
+    tr.bank.zero_grad()
     acc = torch.zeros_like(g4)
     losses = []
     for i in range(B):
@@ -342,6 +404,35 @@ def test_full_size_batch4_twin_step_equals_the_mean_of_four_batch1_steps():
     e = l2rel(g4, acc)
     print(f"batch-4 twin step vs four batch-1 steps: loss {loss4.item():.5e} vs {sum(losses) / B:.5e}, flat gradient l2rel {e:.3e}")
     assert e < 5e-2, e
+
+
+def test_full_size_batch8_rank320_twin_step_equals_mean_of_batch1_steps():
+    """BASELINE config 3 per GPU (rank 320, batch 8) end to end at full size, through the data-parallel form of the step
+    (single-rank RCCL group, AQL_FORCE_ALLREDUCE=1: wide-rank weight gradients held back, exchange buckets with one
+    all-reduce each through aql_comm_*, early buckets forked from the backward hook): ONE batch-8 twin step equals the mean of eight batch-1 steps -- predicted noise per sample, loss, the whole
+    flat gradient (LoRA + mapper).  The batch-1 step at rank 320 is pinned to the CPU oracle by
+    test_full_size_ppft_gradients_vs_oracle[320]; this closes the shapes that only exist at batch 8 (tests/dp_config3_worker.py)."""
+    import json, os, subprocess, sys
+    from tests.conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29549")
+    out = subprocess.run([sys.executable, "-m", "tests.dp_config3_worker"], env=env, cwd=ROOT, capture_output=True, text=True,
+                         timeout=1500)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    print(rec)
+    assert (rec["overlap"] or rec["bucketed"]) and rec["twin"] and "w" in rec["problem_kinds"], rec
+    ranges = rec["ranges"]
+    # overlapped exchange: 3 early (up path, 245 MB) + 4 late buckets covering the mapper gradient too; fallback: 8 buckets
+    end = rec["numel"] if rec["overlap"] else rec["n_lora"]
+    assert len(ranges) >= 6 and ranges[0][0] == 0 and ranges[-1][1] == end, rec
+    assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    assert rec["grad_finite"] and rec["params_finite"] and rec["graph_buckets"] == len(ranges)
+    assert not rec["overlap"] or (rec["n_graphs"] == 1 and any(a[1] == rec["n_early"] for a in ranges)), rec
+    # different tiles / kernels at the two batch sizes: bf16 rounding differences only (batch 4 / rank 32 measures 1.2-1.6e-2)
+    assert max(rec["pred_l2rel"]) < 3e-2 and max(rec["clean_l2rel"]) < 3e-2, rec
+    assert abs(rec["loss8"] - rec["loss_mean_b1"]) < 2e-2 * rec["loss8"], rec
+    assert rec["grad_l2rel"] < 5e-2 and rec["grad_lora_l2rel"] < 5e-2 and rec["grad_mapper_l2rel"] < 5e-2, rec
+    assert all(abs(l - rec["loss8"]) < 0.1 * rec["loss8"] for l in rec["graph_losses"]), rec
 
 
 def test_secret_decoder_vs_torchvision_live():
@@ -941,9 +1032,10 @@ def test_bench_under_torchrun_with_rccl_collective():
 
 
 def test_bucketed_exchange_equals_single_flush():
-    """Data-parallel form of the step on one GPU (single-rank RCCL group, collectives forced): bucketed weight-gradient
-    launches + one async all-reduce per bucket, eager and as bucket graphs, at rank 8 (grouped problems) and rank 40
-    (wide problems held back as direct launches) -- parameters after 3 steps equal the single-GPU form's."""
+    """Data-parallel forms of the step on one GPU (single-rank RCCL group, collectives forced), at rank 8 (grouped problems)
+    and rank 40 (wide problems): (a) the overlapped exchange through aql_comm_* -- early buckets forked from the backward hook,
+    late buckets behind the last weight-gradient launch, eager and captured into ONE graph; (b) the torch.distributed
+    fallback -- bucket graphs with an async all-reduce between them.  Parameters after 3 steps equal the single-GPU form's."""
     import json, os, subprocess, sys
     from tests.conftest import ROOT
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
@@ -956,7 +1048,12 @@ def test_bucketed_exchange_equals_single_flush():
         ranges = rec[f"r{r}_ranges"]
         assert len(ranges) >= 2 and ranges[0][0] == 0 and ranges[-1][1] == rec[f"r{r}_n_lora"]
         assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))      # the buckets tile the LoRA gradients
+        # overlapped exchange: early buckets tile the up-path head of the buffer, late buckets the rest + the mapper gradient
+        ov = rec[f"r{r}_overlap_ranges"]
+        assert ov[0][0] == 0 and ov[-1][1] == rec[f"r{r}_numel"] and all(a[1] == b[0] for a, b in zip(ov, ov[1:]))
+        assert any(a[1] == rec[f"r{r}_n_early"] for a in ov) and 0 < rec[f"r{r}_n_early"] < rec[f"r{r}_n_lora"]
+        assert rec[f"r{r}_overlap_graphs"] == 1                            # collectives captured: the step is ONE graph
         lp = rec[f"r{r}_plain_losses"]
-        for mode in ("bucketed_eager", "bucketed_graph"):
+        for mode in ("overlap_eager", "overlap_graph", "bucketed_eager", "bucketed_graph"):
             assert rec[f"r{r}_{mode}_param_relerr"] < 2e-3, rec
             assert all(abs(a - b) < 2e-3 * abs(a) for a, b in zip(lp, rec[f"r{r}_{mode}_losses"])), rec

@@ -13,7 +13,9 @@ def kernels_of(obj):
     """{mangled kernel name: {metadata key: int}} of one host object with an embedded gfx950 code object."""
     with tempfile.TemporaryDirectory() as d:
         fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "k.co")
-        subprocess.run([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj], check=True, capture_output=True)
+        r = subprocess.run([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj], capture_output=True)
+        if r.returncode != 0:     # a host-only object (aql_comm.o: RCCL binding, no device code of ours)
+            return {}
         subprocess.run([f"{LLVM}/clang-offload-bundler", "--type=o", "--unbundle", f"--input={fat}",
                         "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True, capture_output=True)
         notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout

@@ -9,4 +9,5 @@ cd $GRAFT_REPO_ROOT
 DB=$(find /tmp/prof_$tag -name "*.db" | head -1)
 python tools/prof_summary.py $DB 3 > gpurun_out/insitu_${tag}_summary.txt
 python tools/prof_shapes.py $DB 3 400 > gpurun_out/insitu_${tag}_shapes.txt
+python tools/prof_families.py $DB 3 ${FAM_BATCH:-4} ${FAM_RANK:-32} > gpurun_out/insitu_${tag}_families.json
 head -1 gpurun_out/insitu_${tag}_summary.txt

@@ -1,5 +1,5 @@
 """One GEMM / conv shape, a handful of launches: the workload for rocprofv3 --pmc passes (tools/pmc_run.sh).
-usage: pmc_one.py gemm M N K | conv B H Cin Cout | lora M N K | attn B S heads | tntr M P Q"""
+usage: pmc_one.py gemm M N K | conv B H Cin Cout | lora M N K | geglu M F K | attn B S heads | tntr M P Q"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,6 +23,15 @@ elif kind == "lora":   # one-launch LoRA linear, rank 32
         Y = torch.empty(M, N, dtype=torch.bfloat16, device=dev); T = torch.empty(M, 32, dtype=torch.bfloat16, device=dev); Ts = torch.empty_like(T)
         return lambda: L.call("aql_lora_gemm_fused", L.ptr(X), K, L.ptr(W), K, M, N, K, L.ptr(A), L.ptr(S), M // 8, L.ptr(Bup), None,
                               None, 0, L.ptr(Y), N, L.ptr(T), L.ptr(Ts), 0, L.stream_ptr())
+elif kind == "geglu":   # ff.net.0.proj + rank-32 LoRA + GEGLU on a twin batch: LoRA and the pre-activation H on rows >= M/2 only
+    M, F, K = a
+    def mk():
+        X, W, A, Bup, bias = rnd(M, K), rnd(2 * F, K), rnd(32, K), rnd(2 * F, 32), rnd(2 * F)
+        S = torch.cat([torch.zeros(4, 32, device=dev), torch.randn(4, 32, device=dev)]).to(torch.bfloat16)
+        H = torch.empty(M, 2 * F, dtype=torch.bfloat16, device=dev); G = torch.empty(M, F, dtype=torch.bfloat16, device=dev)
+        T = torch.empty(M, 32, dtype=torch.bfloat16, device=dev); Ts = torch.empty_like(T)
+        return lambda: L.call("aql_lora_gemm_fused_geglu", L.ptr(X), K, L.ptr(W), K, M, F, K, L.ptr(A), L.ptr(S), M // 8, L.ptr(Bup),
+                              L.ptr(bias), L.ptr(H), 2 * F, L.ptr(G), F, L.ptr(T), L.ptr(Ts), M // 2, L.stream_ptr())
 elif kind == "attn":   # self-attention forward + backward, head dim 40
     from aqualora_amd import ops
     Bn, S, heads = a
