@@ -497,7 +497,11 @@ __device__ __forceinline__ void lora_down_skinny_body(const bf16_t* __restrict__
                                                       bf16_t* __restrict__ T, bf16_t* __restrict__ Ts,
                                                       const bf16_t* __restrict__ Tref, float* __restrict__ dS) {
   __shared__ f32x4_t part[4][RF][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // `wave` must be PROVABLY wave-uniform (an SGPR): the `s < nsteps` guards below then compile to scalar branches.  As a plain
+  // threadIdx expression hipcc predicated the d = 1 step with EXEC instead (s_and_saveexec, no s_cbranch_execz) -- and MFMA
+  // ignores EXEC: a wavefront whose step 4 + wave lies past K accumulated uninitialised registers (NaN for every K < 256;
+  // the U-Net's K >= 320 never skip that step, found with a 160-channel test model in round 3)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long row = (long)blockIdx.x * 16 + (lane & 15);
   const int g = lane >> 4;
   const bool ok = row < M;

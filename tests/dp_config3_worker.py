@@ -93,15 +93,30 @@ def main():
                grad_finite=bool(torch.isfinite(g8).all()), grad_l2rel=l2rel(g8, acc),
                grad_lora_l2rel=l2rel(g8[:tr.bank.n_lora], acc[:tr.bank.n_lora]),
                grad_mapper_l2rel=l2rel(g8[tr.bank.n_lora:], acc[tr.bank.n_lora:]), grad_norm=float(g8.norm()))
-    # the captured form of the same step (what bench.py --config 3 under torchrun replays) -- two replays must leave finite
-    # parameters and a loss near the eager one
+    # the captured form of the same step (what bench.py --config 3 under torchrun replays) against the eager form, from the
+    # same parameters: two optimizer steps each
     batch = dict(z=z, msg=msg, eps=eps, t=t, ctx=ctx)
     cur["sl"] = slice(0, B)
-    tr.bank.zero_grad()
-    run = tr.capture(batch, warmup=1)
+    flat0 = tr.bank.flat.clone()
+
+    def rewind():
+        tr.bank.flat.copy_(flat0)
+        tr.bank.exp_avg.zero_()
+        tr.bank.exp_avg_sq.zero_()
+        tr.step_t.zero_()
+        tr.bank.zero_grad()
+        tr.bank.refresh()
+
+    rewind()
+    le = [float(tr.step(**batch)) for _ in range(2)]
+    p_eager = tr.bank.flat.clone()
+    rewind()
+    run = tr.capture(batch, warmup=0)
     lg = [float(run(**batch)) for _ in range(2)]
     torch.cuda.synchronize()
-    out.update(graph_losses=lg, graph_buckets=len(tr.early_ranges) + len(tr.late_ranges) if tr.overlap else len(tr.exchange_ranges),
+    out.update(eager_losses=le, graph_losses=lg,
+               graph_vs_eager_param_relerr=float((tr.bank.flat - p_eager).abs().max() / p_eager.abs().max()),
+               graph_buckets=len(tr.early_ranges) + len(tr.late_ranges) if tr.overlap else len(tr.exchange_ranges),
                n_graphs=int(getattr(run, "n_graphs", 0)), params_finite=bool(torch.isfinite(tr.bank.flat).all()))
     print(json.dumps(out))
 

@@ -65,3 +65,17 @@ def test_no_kernel_spills_registers_or_uses_scratch():
     n, bad = check_spills.scan()
     assert n >= 250, n
     assert not bad, bad[:5]
+
+
+def test_no_mfma_under_an_exec_mask_without_a_skip_branch():
+    """MFMA ignores EXEC.  hipcc may predicate a short guarded block with `s_and_saveexec` and no `s_cbranch_execz`; an MFMA in such
+    a block runs for a wavefront whose guard is false, on uninitialised operands (lora_down_skinny_kernel: NaN for K < 256, fixed
+    in round 3 by making the guard provably wave-uniform).  Scan the disassembly of every built gfx950 code object."""
+    import sys
+    import __graft_entry__ as ge
+    ge.build()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_mfma_exec
+    n, bad = check_mfma_exec.scan()
+    assert n >= 5000, n
+    assert not bad, bad[:5]

@@ -7,6 +7,7 @@ import subprocess
 import sys
 
 import pytest
+import torch
 
 from tests.conftest import ROOT
 
@@ -70,3 +71,28 @@ def test_geglu_epilogue_equals_two_kernel_path():
     shapes (rank 0 / 32 / 8, ragged M, tiny F), within 1.5e-2 of fp32 torch, and the same gradients through autograd."""
     text = _run("probe_geglu.py")
     assert text.count("PASS") >= 26   # incl. the GEGLU backward in the ff.net.2 backward-data epilogue (ops.FeedForwardFn)
+
+
+def test_lora_down_skinny_every_k_step_count():
+    """aql_lora_down (rank 32: the skinny MFMA kernel) for every K step count 1..12 and a ragged row count, with and without the
+    fused dS reduction, against fp32 torch.  K < 256 leaves some wavefronts without a second K step: until round 3 their MFMAs ran
+    anyway under an EXEC mask (MFMA ignores EXEC) and returned NaN -- never reached by the U-Net's K >= 320."""
+    from aqualora_amd import _lib as L
+    torch.manual_seed(0)
+    for M in (154, 512):
+        for K in range(32, 32 * 13, 32):
+            X = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+            A = (torch.randn(32, K, device="cuda") / 8).to(torch.bfloat16)
+            S = torch.randn(2, 32, device="cuda").to(torch.bfloat16)
+            Tref = torch.randn(M, 32, device="cuda").to(torch.bfloat16)
+            T = torch.full((M, 32), float("nan"), device="cuda", dtype=torch.bfloat16)
+            Ts, dS = T.clone(), torch.zeros(2, 32, device="cuda")
+            L.call("aql_lora_down", L.ptr(X), K, M, K, L.ptr(A), 32, L.ptr(S), M // 2, L.ptr(T), L.ptr(Ts), L.ptr(Tref), L.ptr(dS),
+                   L.stream_ptr())
+            ref = X.float() @ A.float().t()
+            assert torch.isfinite(T.float()).all() and torch.isfinite(Ts.float()).all(), (M, K)
+            assert float((T.float() - ref).abs().max() / ref.abs().max()) < 1e-2, (M, K)
+            ts_ref = T.float() * S.float().repeat_interleave(M // 2, dim=0)
+            assert float((Ts.float() - ts_ref).abs().max() / ts_ref.abs().max()) < 1e-2, (M, K)
+            ds_ref = (T.float() * Tref.float()).view(2, M // 2, 32).sum(1)
+            assert float((dS - ds_ref).abs().max() / ds_ref.abs().max()) < 1e-4, (M, K)
