@@ -76,9 +76,16 @@ class PPFTTrainer:
         self.bucketed = (not self.overlap and dp.exchange_active(process_group)
                          and dp.bucket_count(4 * self.bank.n_lora) > 1)
         self.reducer = dp.BucketedAllreduce(process_group)
-        self.side = torch.cuda.Stream(device=dev) if self.overlap else None   # the collectives' stream (forked / joined)
         if self.overlap and max(1, micro_batches) != 1:
             raise L.AqlError("the overlapped exchange runs one backward pass per step (micro_batches = 1)")
+        # `split`: the weight-gradient GEMMs of the up path are launched from the backward hook on the mid-block output, so that
+        # the all-reduce of their region (forked onto the side stream) runs under the mid / down backward.  The GEMMs themselves
+        # stay on the main stream: on a side stream, concurrent with backward, they cost the step +0.53 ms (23.33 -> 23.86 ms, A/B
+        # on one MI355X) -- the backward kernels lose more to the contention than the HBM-bound launch hides.  Single GPU: off
+        # (nothing to overlap; AQL_EARLY_DW=1 forces the split form for tests / A-B).
+        self.split = self.overlap or (not dp.exchange_active(process_group) and max(1, micro_batches) == 1
+                                      and os.environ.get("AQL_EARLY_DW", "0") == "1")
+        self.side = torch.cuda.Stream(device=dev) if self.split else None   # forked / joined inside the step (and its graph)
         self._new_deferred()
 
     def _new_deferred(self):
@@ -87,7 +94,7 @@ class PPFTTrainer:
         dev = self.bank.grad.device
         self.deferred = ops.DeferredDW(dev, defer_wide=self.bucketed)
         self.deferred_early = self.router = None
-        if self.overlap:
+        if self.split:
             self.deferred_early = ops.DeferredDW(dev)
             base = self.bank.grad.data_ptr()
             self.router = ops.SplitDeferred(self.deferred_early, self.deferred, base, base + 4 * self.bank.n_early)
@@ -113,8 +120,8 @@ class PPFTTrainer:
         main = torch.cuda.current_stream()
         n = B // micro
         preds, cleans, losses = [], [], []
-        ops.DEFERRED = self.router if self.overlap else self.deferred  # weight-gradient GEMMs + dS reductions are collected ...
-        if self.overlap:
+        ops.DEFERRED = self.router if self.split else self.deferred  # weight-gradient GEMMs + dS reductions are collected ...
+        if self.split:
             self._early_done = False
             self.unet._aql_up_path_done = self._early_exchange   # fires inside backward, when it leaves the up path
         try:
@@ -165,11 +172,11 @@ class PPFTTrainer:
                     main.wait_stream(st)
         finally:
             ops.DEFERRED = None
-            if self.overlap:
+            if self.split:
                 self.unet._aql_up_path_done = None
         for tns in preds + cleans + losses:
             tns.record_stream(main)
-        if self.overlap:
+        if self.split:
             self.deferred.flush_ds()
             S.backward(self.ds_accum)
             self._late_exchange()
@@ -197,8 +204,8 @@ class PPFTTrainer:
     def _early_exchange(self):
         """Called from the backward hook on the mid-block output (unet._aql_up_path_done): every LoRA site of the up blocks
         has queued its weight-gradient GEMMs, whose outputs are the leading `n_early` elements of the flat gradient buffer.
-        Fork the side stream here: grouped weight-gradient launch(es) + all-reduce(mean) of that region run under the mid /
-        down backward (DDP's first-ready buckets, ppft_train.py:1058).  Inside a capture this becomes a branch of the graph."""
+        Launch them now and fork the side stream behind them: the all-reduce(mean) of that region runs under the mid / down
+        backward (DDP's first-ready buckets, ppft_train.py:1058).  Inside a capture this becomes a branch of the graph."""
         if self._early_done:
             return
         self._early_done = True
@@ -207,13 +214,14 @@ class PPFTTrainer:
             return
         if not self._tiles(e, 0, b.n_early):
             raise L.AqlError("overlapped exchange: the up-path weight gradients do not tile the head of the gradient buffer")
-        ranges = e.plan(b.grad, dp.bucket_count(4 * b.n_early))
+        ranges = e.plan(b.grad, dp.bucket_count(4 * b.n_early) if self.overlap else 1)
         main = torch.cuda.current_stream()
-        self.side.wait_stream(main)
-        with torch.cuda.stream(self.side):
-            for k, (lo, hi) in enumerate(ranges):
-                e.run_bucket(k)
-                self.comm.all_reduce_(b.grad[lo:hi], average=True)
+        for k, (lo, hi) in enumerate(ranges):
+            e.run_bucket(k)                       # on the backward stream
+            if self.overlap:
+                self.side.wait_stream(main)       # fork: the collective of bucket k runs under what follows on `main`
+                with torch.cuda.stream(self.side):
+                    self.comm.all_reduce_(b.grad[lo:hi], average=True)
         self.early_ranges = ranges
 
     def _late_exchange(self):
@@ -226,13 +234,14 @@ class PPFTTrainer:
         lo0 = b.n_early if self.deferred_early.items else 0
         if not self._tiles(d, lo0, b.n_lora):
             raise L.AqlError("overlapped exchange: the weight gradients do not tile the gradient buffer")
-        ranges = d.plan(b.grad, dp.bucket_count(4 * (b.n_lora - lo0)))
+        ranges = d.plan(b.grad, dp.bucket_count(4 * (b.n_lora - lo0)) if self.overlap else 1)
         ranges[-1] = (ranges[-1][0], b.numel)          # + the mapper gradient
         for k, (lo, hi) in enumerate(ranges):
             d.run_bucket(k)
-            self.side.wait_stream(main)
-            with torch.cuda.stream(self.side):
-                self.comm.all_reduce_(b.grad[lo:hi], average=True)
+            if self.overlap:
+                self.side.wait_stream(main)
+                with torch.cuda.stream(self.side):
+                    self.comm.all_reduce_(b.grad[lo:hi], average=True)
         main.wait_stream(self.side)
         self.late_ranges = ranges
         self.deferred_early.reset()
@@ -281,7 +290,7 @@ class PPFTTrainer:
         b.zero_grad()
 
     def _step_body(self, z, msg, eps, t, ctx):
-        if self.overlap:
+        if self.split:
             loss, _, _ = self.forward_backward(z, msg, eps, t, ctx)    # the exchange is part of it
         elif self.bucketed:
             loss, _, _ = self.forward_backward(z, msg, eps, t, ctx, flush_dw=False)
@@ -317,7 +326,7 @@ class PPFTTrainer:
         if self.bucketed:
             return self._capture_bucketed(static, g_fb, g_opt)
         import os
-        if self.overlap or (not dp.exchange_active(self.pg) and os.environ.get("AQL_ONE_GRAPH", "1") != "0"):
+        if self.split or (not dp.exchange_active(self.pg) and os.environ.get("AQL_ONE_GRAPH", "1") != "0"):
             return self._capture_single(static, g_fb)
         # thread_local capture mode: with a process group alive, RCCL's watchdog thread polls hipEventQuery on the
         # warm-up collectives; under the default global mode that call is illegal while ANY thread captures and aborts
