@@ -36,6 +36,7 @@ SIGNATURES = {
     "aql_lora_gemm_fused_kgroups": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_p, c_i, c_p, c_l, c_p, c_l, c_p, c_p, c_p],
     "aql_lora_down_grouped": [c_i, c_p, c_p, c_p, c_l, c_p, c_i, c_p, c_p, c_p],
     "aql_lora_down": [c_p, c_l, c_l, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p],
+    "aql_lora_down_splitk": [c_p, c_l, c_l, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_sz, c_p, c_sz, c_p],
     "aql_conv3x3_fwd": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_sz, c_p],
     "aql_conv3x3_fwd_pad": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_sz, c_p],
     "aql_softmax_rows": [c_p, c_l, c_l, c_i, c_f, c_p, c_l, c_p],

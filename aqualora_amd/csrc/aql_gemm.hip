@@ -650,6 +650,139 @@ extern "C" int aql_lora_down(const bf16_t* X, long ldx, long M, int K, const bf1
   return aql_lora_ds(T, Tref, (int)(M / rows_per_sample), rows_per_sample, r, dS, stream);
 }
 
+// Deep-K / few-rows form of the rank-32 down product (M <= ~2048, K >= 2048: the backward-data pass of ff.net.0 at the 16x16 and
+// 8x8 levels contracts over 10240 features with 1024 / 256 rows).  The 16-row workgroups of lora_down_skinny_kernel are then
+// too few to fill the chip (64 / 16 workgroups: 26 us for 21 MB), so the K range is cut into `ks` pieces (grid.y): every
+// workgroup writes its fp32 partial [16][32] to `part` [ks][M][32], takes a ticket on the row block's counter, and the LAST
+// arrival adds the pieces in piece order (deterministic) and writes T / Ts.  The counters are zero before the launch and are
+// left zero by it.  Release / acquire fences around the ticket: the pieces come from other XCDs' L2s.
+__global__ __launch_bounds__(256) void lora_down_splitk_kernel(const bf16_t* __restrict__ X, long ldx, long M, int K, int kchunk,
+                                                               const bf16_t* __restrict__ A, const bf16_t* __restrict__ S,
+                                                               int rps, bf16_t* __restrict__ T, bf16_t* __restrict__ Ts,
+                                                               float* __restrict__ part, int* __restrict__ counters) {
+  constexpr int RF = 2;
+  __shared__ f32x4_t red[4][RF][64];
+  __shared__ int s_last;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long row = (long)blockIdx.x * 16 + (lane & 15);
+  const int g = lane >> 4;
+  const bool ok = row < M;
+  const int ks = gridDim.y, piece = blockIdx.y;
+  const int k0 = piece * kchunk, k1 = min(K, k0 + kchunk);
+  const __amdgpu_buffer_rsrc_t rx = aqlgemm::make_rsrc(X), ra = aqlgemm::make_rsrc(A);
+  const uint32_t xoff = ok ? (uint32_t)(row * ldx + k0 + g * 8) * 2u : aqlgemm::OOB_ROW;
+  const uint32_t aoff = (uint32_t)((lane & 15) * K + k0 + g * 8) * 2u;
+  f32x4_t acc[RF];
+#pragma unroll
+  for (int f = 0; f < RF; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  constexpr int D = 8;
+  const int nsteps = (k1 - k0) / 32;   // wave-uniform (kchunk, K multiples of 32)
+  for (int s0 = wave; s0 < nsteps; s0 += 4 * D) {
+    aqlgemm::u32x4_t xv[D], av[D][RF];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int s = s0 + 4 * d;
+      if (s < nsteps) {   // scalar branch (see lora_down_skinny_body: MFMA ignores EXEC)
+        const uint32_t so = (uint32_t)s * 64u;
+        xv[d] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff + so, 0, 0);
+#pragma unroll
+        for (int f = 0; f < RF; ++f)
+          av[d][f] = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff + (uint32_t)(f * 16 * K) * 2u + so, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (s0 + 4 * d < nsteps) {
+#pragma unroll
+        for (int f = 0; f < RF; ++f)
+          acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&av[d][f]),
+                                                           *reinterpret_cast<const bf16x8_t*>(&xv[d]), acc[f], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < RF; ++f) red[wave][f][lane] = acc[f];
+  __syncthreads();
+  // wavefronts 0 / 1 sum fragment 0 / 1 over the four wavefronts: rows j = lane & 15, rank columns f*16 + g*4 + e
+  if (wave < RF) {
+    f32x4_t v = red[0][wave][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const f32x4_t u = red[w][wave][lane];
+      v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+    }
+    if (ok) {   // device-scope (sc1, write-through) stores: the piece is in memory, not dirty in this XCD's L2
+      float* dst = part + ((long)piece * M + row) * 32 + wave * 16 + g * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) __hip_atomic_store(dst + e, v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // No fence: a device-scope release fence writes back the WHOLE L2 (buffer_wbl2) -- measured 50-65 us for this kernel with
+  // 512 workgroups doing it.  The pieces are the only data exchanged, they are written through (above) and read around the
+  // L2 (below); the wait makes every wavefront's stores complete before the workgroup's ticket is taken.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int old = __hip_atomic_fetch_add(counters + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = old == ks - 1;
+    if (s_last) __hip_atomic_store(counters + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every other piece has taken its ticket
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x < 128) {   // 16 rows x 8 groups of 4 rank columns
+    const int r16 = threadIdx.x >> 3, c = (threadIdx.x & 7) * 4;
+    const long m = (long)blockIdx.x * 16 + r16;
+    if (m < M) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int p0 = 0; p0 < ks; p0 += 8) {   // eight pieces in flight (each load is a round trip to memory), added in piece order
+        float u[8][4];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float* src = part + ((long)min(p0 + q, ks - 1) * M + m) * 32 + c;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) u[q][e] = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (p0 + q < ks) v.x += u[q][0], v.y += u[q][1], v.z += u[q][2], v.w += u[q][3];
+      }
+      const uint2 t = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+      *reinterpret_cast<uint2*>(T + m * 32 + c) = t;
+      const uint2 sv = *reinterpret_cast<const uint2*>(S + (m / rps) * 32 + c);
+      *reinterpret_cast<uint2*>(Ts + m * 32 + c) =
+          make_uint2(pack_bf16x2(bf16lo(t.x) * bf16lo(sv.x), bf16hi(t.x) * bf16hi(sv.x)),
+                     pack_bf16x2(bf16lo(t.y) * bf16lo(sv.y), bf16hi(t.y) * bf16hi(sv.y)));
+    }
+  }
+}
+
+// aql_lora_down for rank 32 with the K range split over workgroups when the row count alone cannot fill the chip; `part`
+// (>= ks * M * 32 floats, ks <= 32) and `counters` (>= ceil(M / 16) ints, zero, left zero) are caller-owned scratch.  Falls
+// through to aql_lora_down when no split pays (many rows or shallow K) or the scratch is too small.
+extern "C" int aql_lora_down_splitk(const bf16_t* X, long ldx, long M, int K, const bf16_t* Adown, int r, const bf16_t* S,
+                                    int rows_per_sample, bf16_t* T, bf16_t* Ts, float* part, size_t part_bytes, int* counters,
+                                    size_t counters_bytes, hipStream_t stream) {
+  AQL_CHECK_ARG(X && Adown && S && T && Ts, "aql_lora_down_splitk: null operand");
+  AQL_CHECK_ARG(M > 0 && r > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && rows_per_sample > 0,
+                "aql_lora_down_splitk: bad shape M=%ld r=%d K=%d", M, r, K);
+  const long rb = (M + 15) / 16;
+  int ks = 1;
+  if (r == 32 && K % 32 == 0 && part != nullptr && counters != nullptr && rb * sizeof(int) <= counters_bytes) {
+    static const int target = env_int("AQL_DOWN_SPLIT_WGS", 512);   // tuning hook: workgroups aimed at
+    ks = (int)((target + rb - 1) / rb);
+    if (ks > K / 256) ks = K / 256;          // at least 256 columns (two K steps per wavefront) per piece
+    if (ks > 32) ks = 32;
+    while (ks > 1 && (size_t)ks * (size_t)M * 32u * sizeof(float) > part_bytes) --ks;
+  }
+  if (ks <= 1) return aql_lora_down(X, ldx, M, K, Adown, r, S, rows_per_sample, T, Ts, nullptr, nullptr, stream);
+  int kchunk = ((K / 32 + ks - 1) / ks) * 32;
+  ks = (K + kchunk - 1) / kchunk;            // no empty pieces
+  hipLaunchKernelGGL(lora_down_splitk_kernel, dim3((unsigned)rb, (unsigned)ks), dim3(256), 0, stream, X, ldx, M, K, kchunk, Adown,
+                     S, rows_per_sample, T, Ts, part, counters);
+  AQL_CHECK_LAUNCH("aql_lora_down_splitk");
+  return AQL_OK;
+}
+
 // n <= 32 rank-32 down products sharing M, S and rows_per_sample: T[i] = X[i].A[i]^T, Ts[i] = T[i] * S[m / rps];
 // X[i] [M][K[i]] dense, A[i] [32][K[i]], K[i] % 32 == 0; T, Ts [n][M][32].  X, A, K are HOST arrays.
 extern "C" int aql_lora_down_grouped(int n, const bf16_t* const* X, const bf16_t* const* A, const int* K, long M,

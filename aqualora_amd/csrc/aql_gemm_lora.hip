@@ -643,6 +643,12 @@ static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long
     const int t128 = aql_cdiv(M, 128) * nt, t64 = aql_cdiv(M, 64) * nt, t32 = aql_cdiv(M, 32) * nt;
     const int tiles = t128 >= 448 ? t128 : t64 >= 200 ? t64 : t32;
     if (tiles < 224 && kt >= deep_kt) return AQL_NOT_FUSED;  // the two-launch path would split K here
+    // Deep K under few rows (d(ff.net.0) at the 16x16 level: 1024 x 1280 x 10240): the only one-launch grid that fills the chip
+    // is 32-row tiles, whose weight panel traffic (3.3 MB per workgroup) makes the launch L2-bound -- 86 us against 47 us of the
+    // plain split-K GEMM on 128-row tiles (tools/cmp_lora_paths.py).  With aql_lora_down_splitk the two-launch form costs
+    // GEMM + ~8 us there.  AQL_LORA_DEEP_T128 = 0 restores the one-launch choice.
+    static const int deep_t128 = getenv("AQL_LORA_DEEP_T128") ? atoi(getenv("AQL_LORA_DEEP_T128")) : 100;
+    if (kt >= deep_kt && t128 < deep_t128 && !geglu_F && ngroups == 0 && gb_h == nullptr) return AQL_NOT_FUSED;
     static const int use_w = getenv("AQL_LORA_W") ? atoi(getenv("AQL_LORA_W")) : 1;
     // wave-specialised kernels: ONE chip-wide round of 8-wave workgroups (two rounds of the 128-row tile measured slower than
     // the 4-wave kernel: 52.2 vs 40.9 us at 1024x10240x1280)

@@ -541,12 +541,35 @@ def _lora_gemm_fused(x2d, w, a16, S16, rps, b16, bias, residual, T, Ts, y=None, 
     return y
 
 
+_DOWN_COUNTERS = {}
+
+
+def _down_counters(device):
+    """Ticket counters of aql_lora_down_splitk (one int per 16-row block; zero between launches, the kernel resets them)."""
+    k = _skey(device)
+    c = _DOWN_COUNTERS.get(k)
+    if c is None:
+        c = _DOWN_COUNTERS[k] = torch.zeros(4096, dtype=torch.int32, device=device)
+    return c
+
+
+def lora_down(x, ldx, M, K, a16, rank, S16, rps, T, Ts):
+    """T = X.A^T, Ts = T * S[row // rps] (aql_lora_down); few rows under a deep K split the K range over workgroups
+    (aql_lora_down_splitk: partial sums in the shared workspace, last-arrival reduction)."""
+    if rank == 32 and K >= 2048 and M <= 4096 and M <= 16 * 4096:
+        ws, cnt = workspace(x.device), _down_counters(x.device)
+        L.call("aql_lora_down_splitk", L.ptr(x), ldx, M, K, L.ptr(a16), rank, L.ptr(S16), rps, L.ptr(T), L.ptr(Ts), L.ptr(ws),
+               ws.numel() * 4, L.ptr(cnt), cnt.numel() * 4, L.stream_ptr())
+    else:
+        L.call("aql_lora_down", L.ptr(x), ldx, M, K, L.ptr(a16), rank, L.ptr(S16), rps, L.ptr(T), L.ptr(Ts), None, None,
+               L.stream_ptr())
+
+
 def _lora_down_rows(xk, K, site, S16k, rps, Tk, Tsk, row0):
     """T = X.A^T, Ts = T*S for the rows that have a LoRA term (rows >= row0; row0 is a multiple of rps): the clean half of a twin
     batch is skipped -- its T / Ts rows are never read (aql_gemm_bf16_ex treats them as zeros)."""
     M = xk.shape[0] - row0
-    L.call("aql_lora_down", L.ptr(xk[row0:]), xk.stride(0), M, K, L.ptr(site.a16), site.rank, L.ptr(S16k[row0 // rps:]), rps,
-           L.ptr(Tk[row0:]), L.ptr(Tsk[row0:]), None, None, L.stream_ptr())
+    lora_down(xk[row0:], xk.stride(0), M, K, site.a16, site.rank, S16k[row0 // rps:], rps, Tk[row0:], Tsk[row0:])
 
 
 def _geglu_fused(x2d, packed, site, S16, rps, T, Ts, G, H, row0=0):
@@ -721,9 +744,11 @@ def _lora_backward(dy, x2d, T, Ts, S16, packed, site, rps, ds_accum, want_dx, re
         if want_ds and not ds_deferred:
             L.call("aql_lora_ds", L.ptr(dTs), L.ptr(T), nb, rps, r, L.ptr(ds_target), L.stream_ptr())
     else:
-        L.call("aql_lora_down", L.ptr(dy), dy.stride(0), M, packed.N, L.ptr(site.bt16), r, L.ptr(S16), rps,
-               L.ptr(dTs), L.ptr(dT), L.ptr(T) if (want_ds and not ds_deferred) else None,
-               L.ptr(ds_target) if (want_ds and not ds_deferred) else None, L.stream_ptr())
+        if want_ds and not ds_deferred:
+            L.call("aql_lora_down", L.ptr(dy), dy.stride(0), M, packed.N, L.ptr(site.bt16), r, L.ptr(S16), rps,
+                   L.ptr(dTs), L.ptr(dT), L.ptr(T), L.ptr(ds_target), L.stream_ptr())
+        else:
+            lora_down(dy, dy.stride(0), M, packed.N, site.bt16, r, S16, rps, dTs, dT)
         if want_dx and geglu_h is not None and dx_prev is None and os.environ.get("AQL_GEGLU_BWD_FUSED", "1") != "0":
             # ff.net.2 at rank != 32: the GEGLU backward in the epilogue of the two-K-segment GEMM
             F = packed.K

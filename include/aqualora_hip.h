@@ -48,6 +48,13 @@ int aql_gemm_bf16_ex(const bf16_t* A, long lda, const bf16_t* B, long ldb, long 
  * additionally accumulates dS[sample,:] += sum_rows dTs*Tref, the gradient of the diagonal.                       */
 int aql_lora_down(const bf16_t* X, long ldx, long M, int K, const bf16_t* Adown, int r, const bf16_t* S,
                   int rows_per_sample, bf16_t* T, bf16_t* Ts, const bf16_t* Tref, float* dS, aql_stream_t stream);
+/* The same product (utils/lora_modules.py:13-17) for few rows under a deep contraction (M <= ~2048, K >= 2048: the
+ * backward-data pass of ff.net.0 at the 16x16 / 8x8 levels): the K range is cut over workgroups, fp32 partials in `part`
+ * (>= 32 * M * 32 floats covers every split), the last arrival of a 16-row block (ticket in `counters`: >= ceil(M/16) ints,
+ * zero before the call, left zero) adds them in piece order -- deterministic.  Calls aql_lora_down when no split pays.  */
+int aql_lora_down_splitk(const bf16_t* X, long ldx, long M, int K, const bf16_t* Adown, int r, const bf16_t* S,
+                         int rows_per_sample, bf16_t* T, bf16_t* Ts, float* part, size_t part_bytes, int* counters,
+                         size_t counters_bytes, aql_stream_t stream);
 
 /* 3x3 convolution, pad 1, stride 1|2, NHWC, weights Wk[Cout][(kh*3+kw)*Cin+ci]; upsample=1 folds the nearest x2
  * of Upsample2D into the gather.  Replaces F.conv2d in CustomLoRACompatibleConvforward (lora_modules.py:47-52)

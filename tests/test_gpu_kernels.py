@@ -73,6 +73,42 @@ def test_geglu_epilogue_equals_two_kernel_path():
     assert text.count("PASS") >= 26   # incl. the GEGLU backward in the ff.net.2 backward-data epilogue (ops.FeedForwardFn)
 
 
+def test_lora_down_splitk_equals_one_piece_sum():
+    """aql_lora_down_splitk (deep K under few rows: K range cut over workgroups, last-arrival reduction by ticket) against fp32
+    torch and against aql_lora_down on the backward-data shapes of ff.net.0 at the 16x16 / 8x8 levels, a ragged row count and a K
+    that is not a multiple of the piece size; repeated launches reuse the self-resetting counters and give identical bits."""
+    from aqualora_amd import _lib as L
+    torch.manual_seed(1)
+    cnt = torch.zeros(4096, dtype=torch.int32, device="cuda")
+    ws = torch.empty(32 * 2048 * 32, dtype=torch.float32, device="cuda")
+    for M, K in ((1024, 10240), (256, 10240), (1024, 5120), (154, 2080), (2048, 5120), (16, 4096)):
+        X = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+        A = (torch.randn(32, K, device="cuda") / 32).to(torch.bfloat16)
+        S = torch.randn(2, 32, device="cuda").to(torch.bfloat16)
+        outs = []
+        for rep in range(3):
+            T = torch.full((M, 32), float("nan"), device="cuda", dtype=torch.bfloat16)
+            Ts = T.clone()
+            ws.fill_(float("nan"))
+            L.call("aql_lora_down_splitk", L.ptr(X), K, M, K, L.ptr(A), 32, L.ptr(S), M // 2, L.ptr(T), L.ptr(Ts), L.ptr(ws),
+                   ws.numel() * 4, L.ptr(cnt), cnt.numel() * 4, L.stream_ptr())
+            outs.append((T, Ts))
+        assert int(cnt.abs().max()) == 0, (M, K)
+        T, Ts = outs[0]
+        ref = X.float() @ A.float().t()
+        assert torch.isfinite(T.float()).all() and torch.isfinite(Ts.float()).all(), (M, K)
+        assert float((T.float() - ref).abs().max() / ref.abs().max()) < 1e-2, (M, K)
+        ts_ref = T.float() * S.float().repeat_interleave(M // 2, dim=0)
+        assert float((Ts.float() - ts_ref).abs().max() / ts_ref.abs().max()) < 1e-2, (M, K)
+        for T2, Ts2 in outs[1:]:
+            assert torch.equal(T2, T) and torch.equal(Ts2, Ts), (M, K)
+        T1 = torch.empty_like(T)
+        Ts1 = torch.empty_like(T)
+        L.call("aql_lora_down", L.ptr(X), K, M, K, L.ptr(A), 32, L.ptr(S), M // 2, L.ptr(T1), L.ptr(Ts1), None, None, L.stream_ptr())
+        # different summation order in fp32, then one bf16 rounding: equal up to a bf16 ulp at rounding boundaries
+        assert float((T.float() - T1.float()).abs().max() / ref.abs().max()) < 8e-3, (M, K)
+
+
 def test_lora_down_skinny_every_k_step_count():
     """aql_lora_down (rank 32: the skinny MFMA kernel) for every K step count 1..12 and a ragged row count, with and without the
     fused dS reduction, against fp32 torch.  K < 256 leaves some wavefronts without a second K step: until round 3 their MFMAs ran

@@ -11,3 +11,4 @@ python tools/prof_summary.py $DB 3 > gpurun_out/insitu_${tag}_summary.txt
 python tools/prof_shapes.py $DB 3 400 > gpurun_out/insitu_${tag}_shapes.txt
 python tools/prof_families.py $DB 3 ${FAM_BATCH:-4} ${FAM_RANK:-32} > gpurun_out/insitu_${tag}_families.json
 head -1 gpurun_out/insitu_${tag}_summary.txt
+python tools/prof_sequence.py $DB > gpurun_out/insitu_${tag}_sequence.txt

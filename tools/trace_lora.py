@@ -86,6 +86,26 @@ def run(M, N, K, geglu, nb=8, twin=True, cfg=None):
     if int(t[0, 10]) != 0:
         print(f"   issue ring = setup {float((t[:, 10] - t[:, 0]).double().mean()):.0f} + register prefetches "
               f"{float((t[:, 11] - t[:, 10]).double().mean()):.0f} + DMA issue {float((t[:, 1] - t[:, 11]).double().mean()):.0f}")
+    # phase relation of co-resident workgroups: fraction of a workgroup's K loop [t2, t3] that lies inside the K loop of another
+    # workgroup of the same CU (1.0 = the two share the matrix pipe for their whole K loops, 0 = perfectly de-phased)
+    k0, k1 = t[:, 2].double(), t[:, 3].double()
+    ov = []
+    for k in key.unique():
+        sel = (key == k).nonzero().flatten()
+        a0, a1 = k0[sel], k1[sel]
+        inter = (torch.minimum(a1[:, None], a1[None, :]) - torch.maximum(a0[:, None], a0[None, :])).clamp(min=0)
+        inter.fill_diagonal_(0)
+        ov.append((inter.sum(1) / (a1 - a0).clamp(min=1)).mean().item())
+    slot = (hw & 0xF)
+    print(f"   K-loop overlap with co-resident workgroups {sum(ov) / len(ov):.2f}; wave-slot histogram of wave 0 "
+          f"{torch.bincount(slot.long(), minlength=8).tolist()}")
+    if os.environ.get("TRACE_DUMP"):
+        k = key.unique()[0]
+        sel = (key == k).nonzero().flatten()
+        base = float(start.min())
+        for i in sel[start[sel].argsort()][:24]:
+            print(f"      cu0 wg: slot {int(slot[i])} simd {int((hw[i] >> 4) & 3)} start {float(start[i]) - base:8.0f} kloop "
+                  f"{float(k0[i]) - base:8.0f}..{float(k1[i]) - base:8.0f} end {float(end[i]) - base:8.0f}")
     if twin:
         ops.dual_end()
 

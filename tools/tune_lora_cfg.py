@@ -15,7 +15,7 @@ NSET = int(os.environ.get("NSET", "6"))
 B = int(os.environ.get("B", "4"))
 COLD = os.environ.get("COLD", "0") == "1"
 FLUSH = torch.empty(600 << 20, dtype=torch.uint8, device="cuda") if COLD else None
-CFGS = ["auto", "w128", "w64", "w32", "d128", "d128s", "d64", "d64s", "d32", "d32s"]
+CFGS = os.environ.get("CFGS", "auto,w128,w64,w32,d128,d128s,d64,d64s,d32,d32s").split(",")
 rnd = lambda *s: torch.randn(*s, device=dev).to(torch.bfloat16)  # noqa: E731
 
 
@@ -109,7 +109,7 @@ for tag, M, N, K, geglu in shapes():
             continue
         res[cfg] = graph_time(fns)
     os.environ.pop("AQL_LORA_CFG", None)
-    best = min((v, k) for k, v in res.items() if v == v and k != "auto")
+    best = min((v, k) for k, v in res.items() if v == v and (k != "auto" or len(res) == 1))
     fl = 2.0 * M * K * (N + 32) + 2.0 * M * 32 * N
     print(f"{tag:15s} M{M:6d} N{N:6d} K{K:5d}: " + " ".join(f"{k}={v:6.1f}" for k, v in res.items()) +
           f"  | best {best[1]} {best[0]:.1f} us = {fl / best[0] / 1e6:.0f} TF/s (auto {res['auto']:.1f})", flush=True)
