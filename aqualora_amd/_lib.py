@@ -59,6 +59,8 @@ SIGNATURES = {
     "aql_add_noise": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p],
     "aql_mse_fwd_bwd": [c_p, c_p, c_l, c_p, c_p, c_p],
     "aql_mapper_fwd": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
+    "aql_ppft_prologue": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_p, c_p, c_p, c_p,
+                          c_p, c_p, c_p],
     "aql_mapper_bwd": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     "aql_secret_encoder_fwd": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p],
     "aql_cast_transpose": [c_p, c_i, c_i, c_p, c_p, c_p],

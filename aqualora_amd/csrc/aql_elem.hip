@@ -131,6 +131,100 @@ __global__ __launch_bounds__(256) void add_noise_kernel(const float* __restrict_
   }
 }
 
+// ---- PPFT step prologue in ONE launch (train/ppft_train.py:994-1011 + the head of the U-Net forward, original_unet.py:323-361)
+// Everything between the batch and the first GEMM of the twin (clean | watermarked) forward is a handful of tiny independent
+// element-wise jobs: 15 launches of 4-6 us each on the critical path of the step (profiles/r03: 0.4 ms from the start of the graph to
+// the first U-Net kernel).  Jobs, by block range:
+//   noise : x2 [2B][H][W][8] bf16 (channels-last, 4 latent channels + 4 zero channels = conv_in's packed width):
+//           first half  sqrt(acp[t]) z        + sqrt(1 - acp[t]) eps      (the clean pass sees the un-watermarked latents)
+//           second half sqrt(acp[t]) (z + wm) + sqrt(1 - acp[t]) eps      -- aql_add_noise's arithmetic, both roundings identical
+//   ctx   : ctx2 [2B][L][D] bf16 = the text states twice (fp32 or bf16 in)
+//   temb  : temb [2B][2 half] bf16 = [cos(t f_i) | sin(t f_i)], timesteps repeated for the second half; f from the caller's table
+//           (get_timestep_embedding with flip_sin_to_cos: fp32 product, cosf / sinf, one rounding to bf16)
+//   map   : S32 [B][r] = sum_i msg_i E[i,:] / sqrt(bits) + 1 (MapperNet, utils/models.py:110-115); S16 [2B][r] bf16 = [0 | S32];
+//           ds [B][r] fp32 = 0 (the step's dS accumulator)
+struct PrologueArgs {
+  const float *z, *wm, *eps, *acp, *msg, *E, *freq;
+  const long* t;
+  const void* ctx;
+  bf16_t *x2, *ctx2, *temb, *S16;
+  float *S32, *ds;
+  int B, HW, bits, r, half, ctx_elems, ctx_f32;
+  int nb_noise, nb_ctx, nb_temb;
+};
+__global__ __launch_bounds__(256) void ppft_prologue_kernel(const PrologueArgs a) {
+  int blk = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (blk < a.nb_noise) {   // one thread per (sample, pixel): 4 strided fp32 reads per operand, one 16-byte store per half
+    const int id = blk * 256 + tid;
+    if (id >= a.B * a.HW) return;
+    const int b = id / a.HW, p = id - b * a.HW;
+    const float ac = a.acp[a.t[b]];
+    const float sa = sqrtf(ac), sb = sqrtf(1.f - ac);
+    float xc[4], xw[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const long src = ((long)b * 4 + c) * a.HW + p;
+      const float x0 = a.z[src], e = a.eps[src];
+      xc[c] = sa * x0 + sb * e;
+      xw[c] = sa * (x0 + a.wm[src]) + sb * e;
+    }
+    const uint4 vc = make_uint4(pack_bf16x2(xc[0], xc[1]), pack_bf16x2(xc[2], xc[3]), 0u, 0u);
+    const uint4 vw = make_uint4(pack_bf16x2(xw[0], xw[1]), pack_bf16x2(xw[2], xw[3]), 0u, 0u);
+    *reinterpret_cast<uint4*>(a.x2 + (long)id * 8) = vc;
+    *reinterpret_cast<uint4*>(a.x2 + ((long)a.B * a.HW + id) * 8) = vw;
+    return;
+  }
+  blk -= a.nb_noise;
+  if (blk < a.nb_ctx) {   // 8 elements per thread
+    const long id = ((long)blk * 256 + tid) * 8;
+    if (id >= a.ctx_elems) return;
+    uint4 v;
+    if (a.ctx_f32) {
+      const float4 lo = *reinterpret_cast<const float4*>(static_cast<const float*>(a.ctx) + id);
+      const float4 hi = *reinterpret_cast<const float4*>(static_cast<const float*>(a.ctx) + id + 4);
+      v = make_uint4(pack_bf16x2(lo.x, lo.y), pack_bf16x2(lo.z, lo.w), pack_bf16x2(hi.x, hi.y), pack_bf16x2(hi.z, hi.w));
+    } else {
+      v = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.ctx) + id);
+    }
+    *reinterpret_cast<uint4*>(a.ctx2 + id) = v;
+    *reinterpret_cast<uint4*>(a.ctx2 + a.ctx_elems + id) = v;
+    return;
+  }
+  blk -= a.nb_ctx;
+  if (blk < a.nb_temb) {
+    const int id = blk * 256 + tid;
+    if (id >= 2 * a.B * a.half) return;
+    const int row = id / a.half, i = id - row * a.half;
+    const float arg = (float)a.t[row % a.B] * a.freq[i];
+    a.temb[(long)row * 2 * a.half + i] = f32_to_bf16(cosf(arg));
+    a.temb[(long)row * 2 * a.half + a.half + i] = f32_to_bf16(sinf(arg));
+    return;
+  }
+  // mapper: one thread per (sample, rank column); the bits-long dot product with all loads in flight
+  for (int id = tid; id < a.B * a.r; id += 256) {
+    const int b = id / a.r, j = id - b * a.r;
+    float acc = 0.f;
+    for (int i0 = 0; i0 < a.bits; i0 += 16) {
+      float e[16], m[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int i = min(i0 + u, a.bits - 1);
+        e[u] = a.E[i * a.r + j];
+        m[u] = a.msg[b * a.bits + i];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (i0 + u < a.bits) acc += e[u] * m[u];   // same order as mapper_fwd_kernel: bit-identical S
+    }
+    const float v = acc * rsqrtf((float)a.bits) + 1.f;
+    a.S32[id] = v;
+    a.S16[id] = 0;
+    a.S16[a.B * a.r + id] = f32_to_bf16(v);
+    a.ds[id] = 0.f;
+  }
+}
+
 // ---- MSE loss (ppft_train.py:1051): loss = mean((p-t)^2) in fp32; dpred = 2 (p-t)/n ------------------
 __global__ __launch_bounds__(256) void mse_kernel(const bf16_t* __restrict__ p, const bf16_t* __restrict__ t, long n,
                                                   float* __restrict__ loss, bf16_t* __restrict__ dpred) {
@@ -430,6 +524,28 @@ extern "C" int aql_add_noise(const float* x0, const float* wm, const float* eps,
   hipLaunchKernelGGL(add_noise_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x0, wm, eps, t, acp, per_sample, noisy,
                      noisy_wm, n);
   AQL_CHECK_LAUNCH("aql_add_noise");
+  return AQL_OK;
+}
+// See ppft_prologue_kernel.  z / wm / eps [B][4][H*W] fp32 (NCHW), t [B] int64, acp [T] fp32, msg [B][bits] fp32, E [bits][r] fp32,
+// freq [half] fp32, ctx [B][ctx_per_sample] (fp32 when ctx_f32 else bf16; ctx_per_sample % 8 == 0).
+// Out: x2 [2B][H*W][8] bf16, ctx2 [2B][ctx_per_sample] bf16, temb [2B][2*half] bf16, S32 [B][r], S16 [2B][r] bf16, ds [B][r] = 0.
+extern "C" int aql_ppft_prologue(const float* z, const float* wm, const float* eps, const long* t, const float* acp,
+                                 const float* msg, const float* E, const float* freq, const void* ctx, int ctx_f32, int B,
+                                 int HW, int bits, int r, int half, long ctx_per_sample, bf16_t* x2, bf16_t* ctx2,
+                                 bf16_t* temb, float* S32, bf16_t* S16, float* ds, hipStream_t stream) {
+  AQL_CHECK_ARG(z && wm && eps && t && acp && msg && E && freq && ctx && x2 && ctx2 && temb && S32 && S16 && ds,
+                "aql_ppft_prologue: null operand");
+  AQL_CHECK_ARG(B > 0 && HW > 0 && bits > 0 && r > 0 && half > 0 && ctx_per_sample > 0 && ctx_per_sample % 8 == 0 &&
+                    (long)B * ctx_per_sample < (1L << 31), "aql_ppft_prologue: bad shape");
+  PrologueArgs a{};
+  a.z = z, a.wm = wm, a.eps = eps, a.acp = acp, a.msg = msg, a.E = E, a.freq = freq, a.t = t, a.ctx = ctx;
+  a.x2 = x2, a.ctx2 = ctx2, a.temb = temb, a.S16 = S16, a.S32 = S32, a.ds = ds;
+  a.B = B, a.HW = HW, a.bits = bits, a.r = r, a.half = half, a.ctx_elems = (int)(B * ctx_per_sample), a.ctx_f32 = ctx_f32;
+  a.nb_noise = (B * HW + 255) / 256;
+  a.nb_ctx = (a.ctx_elems / 8 + 255) / 256;
+  a.nb_temb = (2 * B * half + 255) / 256;
+  hipLaunchKernelGGL(ppft_prologue_kernel, dim3(a.nb_noise + a.nb_ctx + a.nb_temb + 1), dim3(256), 0, stream, a);
+  AQL_CHECK_LAUNCH("aql_ppft_prologue");
   return AQL_OK;
 }
 extern "C" int aql_mse_fwd_bwd(const bf16_t* pred, const bf16_t* target, long n, float* loss, bf16_t* dpred,

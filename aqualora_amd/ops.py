@@ -130,6 +130,23 @@ def dual_begin():
 def dual_end():
     global DUAL
     DUAL = None
+    _CPAD.clear()
+
+
+# Channel-padded inputs: a [B, C, H, W] view of a channels-last buffer that is Cp > C channels wide with the channels C..Cp-1 ZERO
+# (written so by ppft's prologue kernel at conv_in's packed width).  conv3x3 then reads the buffer as it is instead of building the
+# padded copy (a fill + a strided copy in front of the first conv of every forward).  Keyed by (address, shape, strides); cleared with
+# the twin registry.
+_CPAD = set()
+
+
+def register_cpad(x):
+    _CPAD.add((x.data_ptr(), tuple(x.shape), tuple(x.stride())))
+    return x
+
+
+def is_cpad(x, cp):
+    return x.dim() == 4 and x.stride(1) == 1 and x.stride(3) == cp and (x.data_ptr(), tuple(x.shape), tuple(x.stride())) in _CPAD
 
 
 def _twin_geometry(x):
@@ -974,14 +991,18 @@ class Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, packed, upsample, rowbias, residual):
         _req(x, "conv3x3")
-        x = as_cl(x)
+        cpad = x.shape[1] != packed.Cin and is_cpad(x, packed.Cin)
+        if not cpad:
+            x = as_cl(x)
         B, C, H, W = x.shape
         xk = _full(x)
         twin = xk is not None
         if not twin:
             xk = x
         Bk = xk.shape[0]
-        if C != packed.Cin:  # conv_in: zero-pad channels to the packed width
+        if cpad:   # already packed.Cin channels wide in memory, zero beyond C
+            xk = xk.as_strided((Bk, packed.Cin, H, W), xk.stride(), xk.storage_offset())
+        elif C != packed.Cin:  # conv_in: zero-pad channels to the packed width
             xp = xk.new_zeros((Bk, packed.Cin, H, W)).contiguous(memory_format=CL)
             xp[:, :C] = xk
             xk = xp

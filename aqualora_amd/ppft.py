@@ -13,6 +13,8 @@ Inputs are injected (z = already-scaled VAE latents, ctx = text-encoder states):
 outside this path.  All LoRA + mapper parameters, gradients and AdamW moments live in one flat
 fp32 buffer (lora.LoraBank), so the exchange is a single collective and the optimizer two kernel launches.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -20,6 +22,8 @@ from . import _lib as L
 from . import dp, ops
 from .lora import LoraBank, inject_lora, patch_lora_forwards
 from .watermark import customDDPMScheduler
+
+_PROLOGUE = os.environ.get("AQL_PROLOGUE", "1") != "0"   # A/B hook: 0 = the generic (15-launch) head of the twin step
 
 VAE_SCALING = 0.18215
 
@@ -111,12 +115,18 @@ class PPFTTrainer:
         same flat buffer (fp32 atomics), dS into disjoint rows of one accumulator."""
         B = z.shape[0]
         micro = self.micro if (B % max(self.micro, 1) == 0) else 1
-        S = self.mapper(msg)
-        if self.ds_accum is None or self.ds_accum.shape != S.shape:
-            self.ds_accum = torch.zeros_like(S, dtype=torch.float32)
-        self.ds_accum.zero_()
-        wm = self.sec_encoder.encode(msg, out_scale=VAE_SCALING)
-        x_t, x_t_wm = self.scheduler.add_noise_pair(z, wm, eps, t)
+        pro = None
+        if self.twin and micro == 1 and _PROLOGUE:
+            pro = self._twin_prologue(z, msg, eps, t, ctx)
+        if pro is None:
+            S = self.mapper(msg)
+            if self.ds_accum is None or self.ds_accum.shape != S.shape:
+                self.ds_accum = torch.zeros_like(S, dtype=torch.float32)
+            self.ds_accum.zero_()
+            wm = self.sec_encoder.encode(msg, out_scale=VAE_SCALING)
+            x_t, x_t_wm = self.scheduler.add_noise_pair(z, wm, eps, t)
+        else:
+            S = pro["S"]
         main = torch.cuda.current_stream()
         n = B // micro
         preds, cleans, losses = [], [], []
@@ -131,14 +141,23 @@ class PPFTTrainer:
                 # second half (ops._Dual).  Every kernel of the forward runs once on twice the rows.
                 ops.dual_begin()
                 try:
-                    x2 = ops.make_twin(x_t, x_t_wm)
-                    c16 = ctx if ctx.dtype == torch.bfloat16 else ctx.to(torch.bfloat16)
-                    ctx2 = ops.make_twin(c16, c16)
                     S_in = S.detach().requires_grad_(True)
-                    S16 = S.detach().to(torch.bfloat16)
-                    S_in._aql_s16 = ops.make_twin(torch.zeros_like(S16), S16)
+                    if pro is not None:   # the prologue kernel wrote the twin buffers; register them and hand out the second halves
+                        for k in ("x2", "ctx2", "S16"):
+                            ops.DUAL.register(pro[k])
+                        x2 = ops.register_cpad(pro["x2"][B:, :z.shape[1]])
+                        ctx2 = pro["ctx2"][B:]
+                        S_in._aql_s16 = pro["S16"][B:]
+                        t_emb = pro["temb"]
+                    else:
+                        x2 = ops.make_twin(x_t, x_t_wm)
+                        c16 = ctx if ctx.dtype == torch.bfloat16 else ctx.to(torch.bfloat16)
+                        ctx2 = ops.make_twin(c16, c16)
+                        S16 = S.detach().to(torch.bfloat16)
+                        S_in._aql_s16 = ops.make_twin(torch.zeros_like(S16), S16)
+                        t_emb = None
                     S_in._aql_ds_accum = self.ds_accum
-                    pred = self.unet(x2, t, ctx2, cross_attention_kwargs={"scale": S_in}).sample
+                    pred = self.unet(x2, t, ctx2, cross_attention_kwargs={"scale": S_in}, _aql_t_emb=t_emb).sample
                     clean = ops.clean_twin(pred)
                 finally:
                     ops.dual_end()
@@ -188,6 +207,45 @@ class PPFTTrainer:
             S.backward(self.ds_accum)
         loss = torch.stack(losses).mean()
         return loss, torch.cat(preds), torch.cat(cleans)
+
+    def _twin_prologue(self, z, msg, eps, t, ctx):
+        """Everything between the batch and the first GEMM of the twin forward as ONE launch (aql_ppft_prologue): MapperNet, the
+        noisy latents of both passes channels-last at conv_in's packed width, the text states twice, the timestep embedding of all 2B
+        rows, the [0 | S] bf16 scale rows and the zeroed dS accumulator -- 15 launches of 4-6 us on the generic path (mapper, fill,
+        add_noise, three concatenations, the bf16 casts, seven element-wise kernels of the embedding, conv_in's channel padding).
+        Returns None when the model / batch is not the SD-1.5 PPFT shape it is written for (the generic path runs)."""
+        from .unet import timestep_freq_table
+        from .watermark import _MapperGivenFn
+        cfg = self.unet.config
+        B = z.shape[0]
+        if not (z.dim() == 4 and z.shape[1] == 4 and z.dtype == torch.float32 and eps.dtype == torch.float32 and z.is_contiguous()
+                and eps.is_contiguous() and t.dtype == torch.int64 and t.numel() == B and ctx.dim() == 3 and ctx.shape[0] == B
+                and ctx.is_contiguous() and ctx.dtype in (torch.float32, torch.bfloat16) and (ctx.shape[1] * ctx.shape[2]) % 8 == 0
+                and msg.dim() == 2 and self.unet.dtype == torch.bfloat16 and cfg.in_channels == 4):
+            return None
+        E = self.mapper.bit_embeddings.weight
+        bits, r = E.shape
+        dev = z.device
+        HW = z.shape[2] * z.shape[3]
+        dim = cfg.block_out_channels[0]
+        freq = timestep_freq_table(dev, dim)
+        wm = self.sec_encoder.encode(msg, out_scale=VAE_SCALING)
+        if wm.shape != z.shape:
+            return None
+        x2 = torch.empty(2 * B, z.shape[2], z.shape[3], 8, dtype=torch.bfloat16, device=dev).permute(0, 3, 1, 2)
+        ctx2 = torch.empty((2 * B,) + tuple(ctx.shape[1:]), dtype=torch.bfloat16, device=dev)
+        temb = torch.empty(2 * B, dim, dtype=torch.bfloat16, device=dev)
+        S32 = torch.empty(B, r, dtype=torch.float32, device=dev)
+        S16 = torch.empty(2 * B, r, dtype=torch.bfloat16, device=dev)
+        if self.ds_accum is None or self.ds_accum.shape != S32.shape:
+            self.ds_accum = torch.zeros_like(S32)
+        msg32 = msg.float().contiguous()
+        L.call("aql_ppft_prologue", L.ptr(z), L.ptr(wm.float().contiguous()), L.ptr(eps), L.ptr(t), L.ptr(self.scheduler.alphas_cumprod),
+               L.ptr(msg32), L.ptr(E), L.ptr(freq), L.ptr(ctx), int(ctx.dtype == torch.float32), B, HW, bits, r, dim // 2,
+               ctx.shape[1] * ctx.shape[2], L.ptr(x2), L.ptr(ctx2), L.ptr(temb), L.ptr(S32), L.ptr(S16), L.ptr(self.ds_accum),
+               L.stream_ptr())
+        S = _MapperGivenFn.apply(msg32, E, S32)
+        return {"S": S, "x2": x2, "ctx2": ctx2, "temb": temb, "S16": S16}
 
     # ------------------------------------------------------------------- overlapped exchange (aql_comm_*, one graph)
     def _tiles(self, dfr, lo, hi):

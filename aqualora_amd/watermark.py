@@ -34,6 +34,26 @@ class _MapperFn(torch.autograd.Function):
         return None, dE
 
 
+class _MapperGivenFn(torch.autograd.Function):
+    """MapperNet whose forward value was already computed (ppft's prologue kernel writes S next to the other inputs of the
+    step): hands the value to autograd, backward is _MapperFn's."""
+
+    @staticmethod
+    def forward(ctx, msg, E, S):
+        ctx.save_for_backward(msg)
+        ctx.shape = tuple(E.shape)
+        return S.view_as(S)
+
+    @staticmethod
+    def backward(ctx, dS):
+        (msg,) = ctx.saved_tensors
+        bits, r = ctx.shape
+        dS = dS.contiguous().float()
+        dE = torch.zeros(bits, r, dtype=torch.float32, device=dS.device)
+        L.call("aql_mapper_bwd", L.ptr(msg), L.ptr(dS), msg.shape[0], bits, r, L.ptr(dE), L.stream_ptr())
+        return None, dE, None
+
+
 class MapperNet(nn.Module):
     """S(m) = sum_i m_i E[i,:] / sqrt(bits) + 1  (utils/models.py:98-115).  Init: orthogonal rows, each divided by its
     own std, times ``std``."""

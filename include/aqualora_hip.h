@@ -212,6 +212,15 @@ int aql_add_noise(const float* x0, const float* wm, const float* eps, const long
 /* F.mse_loss(pred.float(), target.float()) and its gradient  train/ppft_train.py:1051                              */
 int aql_mse_fwd_bwd(const bf16_t* pred, const bf16_t* target, long n, float* loss, bf16_t* dpred, aql_stream_t stream);
 /* MapperNet.forward / its weight gradient  utils/models.py:110-115                                                 */
+/* Everything between the batch and the first GEMM of the twin (clean | watermarked) PPFT forward in one launch:
+ * noisy latents of both passes (train/ppft_train.py:1010-1011, utils/cschedulers.py:15: aql_add_noise's arithmetic) written
+ * channels-last at conv_in's packed width, the text states twice, the sinusoidal timestep embedding
+ * (scripts/lib/original_unet.py:323-361, flip_sin_to_cos), MapperNet (utils/models.py:110-115) as S32 / S16 = [0 | S], and
+ * the zeroed dS accumulator.  Layouts in csrc/aql_elem.hip.                                                              */
+int aql_ppft_prologue(const float* z, const float* wm, const float* eps, const long* t, const float* acp, const float* msg,
+                      const float* E, const float* freq, const void* ctx, int ctx_f32, int B, int HW, int bits, int r,
+                      int half, long ctx_per_sample, bf16_t* x2, bf16_t* ctx2, bf16_t* temb, float* S32, bf16_t* S16,
+                      float* ds, aql_stream_t stream);
 int aql_mapper_fwd(const float* msg, const float* E, int nb, int bits, int r, float* S32, bf16_t* S16,
                    aql_stream_t stream);
 int aql_mapper_bwd(const float* msg, const float* dS, int nb, int bits, int r, float* dE, aql_stream_t stream);

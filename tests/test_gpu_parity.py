@@ -587,6 +587,40 @@ def test_tiny_ppft_step_vs_golden(golden):
     assert abs(tr.grad_norm() - total) < 0.1 * total
 
 
+def test_fused_step_prologue_equals_generic_head():
+    """aql_ppft_prologue (mapper, noisy twin latents at conv_in's packed width, text states twice, timestep embedding, [0 | S] scale
+    rows, zeroed dS accumulator in ONE launch) against the generic 15-launch head of the twin step: identical prediction, clean
+    target, loss and S bits; gradients equal up to the fp32-atomic order of the weight-gradient kernels."""
+    import aqualora_amd.ppft as P
+    from aqualora_amd.watermark import MapperNet, SecretEncoder
+    outs = []
+    for fused in (True, False):
+        unet, keys, lw = _gpu_tiny()
+        inp = ppft_inputs(device=DEV)
+        mapper = MapperNet(48, TINY_RANK)
+        with torch.no_grad():
+            mapper.bit_embeddings.weight.copy_(inp["E"])
+        tr = P.PPFTTrainer(unet, mapper, SecretEncoder(48, base_res=8, resolution=16), TINY_RANK, learning_rate=1e-4)
+        tr.sec_encoder.encode = lambda m, out_scale=1.0: inp["wm"]
+        old = P._PROLOGUE
+        P._PROLOGUE = fused
+        try:
+            used = []
+            orig = tr._twin_prologue
+            tr._twin_prologue = lambda *a: (used.append(1), orig(*a))[1]
+            loss, pred, clean = tr.forward_backward(inp["z"], inp["msg"], inp["eps"], inp["t"], inp["ctx"])
+        finally:
+            P._PROLOGUE = old
+        assert bool(used) == fused
+        grads = torch.cat([unet.get_submodule(k).lora_layer.down.weight.grad.flatten() for k in keys] +
+                          [mapper.bit_embeddings.weight.grad.flatten()])
+        outs.append((loss.item(), pred.float().clone(), clean.float().clone(), grads.clone()))
+    (l0, p0, c0, g0), (l1, p1, c1, g1) = outs
+    assert torch.equal(p0, p1) and torch.equal(c0, c1), ((p0 - p1).abs().max().item(), (c0 - c1).abs().max().item())
+    assert l0 == l1
+    assert float((g0 - g1).norm() / g1.norm()) < 1e-5
+
+
 def test_checkpoint_roundtrip_and_consumer_contract(tmp_path, golden):
     from aqualora_amd.checkpoint import load_lora_state, save_lora_weights
     from aqualora_amd.lora import inject_lora
