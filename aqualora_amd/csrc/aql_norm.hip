@@ -16,7 +16,14 @@ __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
 __device__ __forceinline__ uint4 pack8(const float* f) {
   return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
 }
+// v_rcp_f32 (1 ulp) instead of the IEEE division sequence (v_div_scale x2, v_rcp, 5 FMAs, v_div_fmas, v_div_fixup: ~10 of the
+// ~27 VALU instructions per element of the GroupNorm + SiLU apply pass, which is VALU-bound, not HBM-bound: tools/tune_gn.py);
+// the result is rounded to bf16 after one more multiply, three decimal digits above the difference
+#ifdef AQL_SIGMOID_DIV   // A/B build (tools/build_alt.sh): the IEEE division
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + __expf(-z)); }
+#else
+__device__ __forceinline__ float sigmoidf_(float z) { return __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // GroupNorm pass 1: per-(sample, group) partial sums over a slab of pixels.
