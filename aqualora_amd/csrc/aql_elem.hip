@@ -439,8 +439,21 @@ __global__ __launch_bounds__(256) void lora_ds_grouped_kernel(const DsGroupDesc*
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
   __shared__ float sm[4];
   float acc = 0.f;
-  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x)
-    acc += g[id] * g[id];
+  // 16-byte loads, four in flight per thread (scalar 4-byte loads: 34 us for the 54 MB of the rank-32 gradients, 1.6 TB/s)
+  const long n4 = (reinterpret_cast<uintptr_t>(g) & 15u) == 0 ? n >> 2 : 0;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  const long stride = (long)gridDim.x * blockDim.x;
+  long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; id + 3 * stride < n4; id += 4 * stride) {
+    const float4 a = g4[id], b = g4[id + stride], c = g4[id + 2 * stride], d = g4[id + 3 * stride];
+    acc += (a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w) + (b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w) +
+           (c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w) + (d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w);
+  }
+  for (; id < n4; id += stride) {
+    const float4 a = g4[id];
+    acc += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+  }
+  for (long t = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) acc += g[t] * g[t];
   const float s = block_sum(acc, sm);
   if (threadIdx.x == 0) atomicAdd(out, s);
 }
@@ -602,7 +615,7 @@ extern "C" int aql_lora_ds(const bf16_t* dTs, const bf16_t* T, int nb, int rows_
   AQL_CHECK_ARG(dTs && T && dS && r % 8 == 0 && r <= 1024, "aql_lora_ds: bad args (r=%d)", r);
   const int cols = r / 8;
   const int threads = cols * (256 / cols > 0 ? 256 / cols : 1);
-  int slabs = (rows_per_sample + 255) / 256;
+  int slabs = (rows_per_sample + 1023) / 1024;   // every workgroup ends in r atomics onto the SAME [nb][r] accumulator: few, fat slabs
   if (slabs > 32) slabs = 32;
   hipLaunchKernelGGL(lora_ds_kernel, dim3(slabs, nb), dim3(threads), 0, stream, dTs, T, rows_per_sample, r, dS);
   AQL_CHECK_LAUNCH("aql_lora_ds");
@@ -618,7 +631,7 @@ extern "C" int aql_ds_desc_fill(void* host_desc, const bf16_t* dTs, const bf16_t
   d.nb = nb;
   d.rps = rows_per_sample;
   d.r = r;
-  int slabs = (rows_per_sample + 255) / 256;
+  int slabs = (rows_per_sample + 1023) / 1024;   // every workgroup ends in r atomics onto the SAME [nb][r] accumulator: few, fat slabs
   if (slabs > 32) slabs = 32;
   d.slabs = slabs;
   d.first_block = first_block;

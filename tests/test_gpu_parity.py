@@ -617,7 +617,7 @@ def test_fused_step_prologue_equals_generic_head():
         outs.append((loss.item(), pred.float().clone(), clean.float().clone(), grads.clone()))
     (l0, p0, c0, g0), (l1, p1, c1, g1) = outs
     assert torch.equal(p0, p1) and torch.equal(c0, c1), ((p0 - p1).abs().max().item(), (c0 - c1).abs().max().item())
-    assert l0 == l1
+    assert abs(l0 - l1) <= 1e-6 * abs(l1)   # the MSE kernel adds its block sums with fp32 atomics: last-bit order dependence
     assert float((g0 - g1).norm() / g1.norm()) < 1e-5
 
 
