@@ -552,10 +552,17 @@ inline int gn_geometry(int HW, int C, int* threads, int* rows_per_slab) {
 // 23.4 at 1280 ch; backward 4.7 vs 22.3 us at 8x8x1280), slower at 64x64 (33.5 vs 26.5 us at 320 ch: a group's 20-byte
 // pixel segments touch 6x their bytes in cache lines and 128 workgroups cannot hide it), so large maps keep the slab
 // form.  AQL_GN_FUSED=0 forces the 3-kernel path, =2 forces the fused one (tuning).
-inline bool gn_use_fused(int C, int HW) {
+// 32x32 maps, backward, <= 960 channels: the split form (two launches) is 2-4 us faster than the one-launch form (B=4,
+// tools/tune_gn.py: 16.1 -> 12.6 us at 640 channels, 18.9 -> 15.3 at 960, 11.8 -> 9.9 at 320; 1280 / 1920 channels and every
+// forward shape are within 1 us or slower).  AQL_GN_FUSED_MAXHW forces the threshold for all shapes (tuning hook).
+inline bool gn_use_fused(int C, int HW, bool bwd = false) {
   static const int en = getenv("AQL_GN_FUSED") ? atoi(getenv("AQL_GN_FUSED")) : 1;
   if (!en || (C / G) % 2 != 0 || (C / G) / 2 > GNF_THREADS) return false;
-  return en == 2 || HW <= 2048;
+  static const int max_hw = getenv("AQL_GN_FUSED_MAXHW") ? atoi(getenv("AQL_GN_FUSED_MAXHW")) : 0;
+  if (en == 2) return true;
+  if (max_hw > 0) return HW <= max_hw;
+  if (bwd && HW > 512 && C <= 960 && C / G >= 8) return false;
+  return HW <= 2048;
 }
 
 // larger maps, forward only: two launches of the same kernel with the pixel range of every (sample, group) cut into pieces
@@ -563,9 +570,10 @@ inline bool gn_use_fused(int C, int HW) {
 // form).  0 = use the slab form; AQL_GN_SPLIT=0 disables, =n forces n pieces
 inline int gn_split(int C, int HW) {
   static const int en = getenv("AQL_GN_SPLIT") ? atoi(getenv("AQL_GN_SPLIT")) : -1;
-  if (en == 0 || (C / G) % 2 != 0 || (C / G) / 2 > GNF_THREADS || HW <= 2048 || HW > 8192) return 0;
+  if (en == 0 || (C / G) % 2 != 0 || (C / G) / 2 > GNF_THREADS || HW <= 512 || HW > 8192) return 0;   // callers ask only when the one-launch form is off
   if (en > 0) return en > 8 ? 8 : en;
   int ns = HW / 1024;
+  if (ns < 2) ns = 2;
   return ns > 8 ? 8 : ns;
 }
 
@@ -628,7 +636,7 @@ extern "C" int aql_groupnorm_silu_bwd(const bf16_t* x, const bf16_t* dy, int B, 
                                       float* scratch, hipStream_t stream) {
   AQL_CHECK_ARG(x && dy && gamma && beta && dx && stats && scratch, "aql_groupnorm_silu_bwd: null operand");
   AQL_CHECK_ARG(C % 8 == 0 && C % G == 0 && C / 8 <= 1024, "aql_groupnorm_silu_bwd: bad C=%d", C);
-  if (gn_use_fused(C, HW)) {
+  if (gn_use_fused(C, HW, true)) {
     hipLaunchKernelGGL((gn_fused_kernel<1, 0>), dim3(B * G), dim3(GNF_THREADS), 0, stream, x, dy, gamma, beta,
                        const_cast<float*>(stats), HW, C, 0.f, silu, dres, dx, 1, nullptr);
     AQL_CHECK_LAUNCH("aql_groupnorm_silu_bwd");
