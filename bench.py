@@ -613,6 +613,11 @@ def main():
                                  "frac": achieved / MFMA_PEAK_TF,
                                  "launch": f"one PPFT step = {tf_img:.3f} TFLOP/image x {args.batch} images"}
         line["kernels"] = ks
+        mu = load_profile_json("r03_pmc_mfma_util.json")
+        if mu is not None:   # rocprofv3 MfmaUtil (matrix-pipe busy fraction) of the attention / conv / LoRA kernels: static evidence
+            line["mfma_util_pmc"] = {"source": "static, not measured in this run: profiles/r03_pmc_mfma_util.json (rocprofv3 --pmc pass)",
+                                     "kernels": {k: v["mfma_util"] for k, v in mu["kernels"].items()},
+                                     "attention_64x64_time_weighted": mu.get("attention_64x64_time_weighted")}
         if world == 1 and not args.no_extras and not (args.pixel_in or args.text_in):
             # the reference's real step boundary: pixels and token ids in (frozen VAE encode + CLIP text encoder inside)
             full = wrap_pixel_text(runner, args, device, rank_id, True, True)
