@@ -34,6 +34,15 @@ def allreduce_mean_(flat, group=None, bucket_elems=None):
     return flat
 
 
+def logged_loss(loss, group=None):
+    """The loss value the reference LOGS: ``accelerator.gather(loss.repeat(train_batch_size)).mean()`` (train/ppft_train.py:1054),
+    i.e. the mean of the per-rank batch-mean losses (every rank contributes the same number of copies).  Off the step's critical path:
+    one scalar all-reduce, called only when a log line is written.  Returns a Python float."""
+    t = loss.detach().float().reshape(1).clone()
+    allreduce_mean_(t, group)
+    return float(t.item())
+
+
 def exchange_active(group=None):
     """True when a gradient collective has to run: more than one rank, or AQL_FORCE_ALLREDUCE=1 (exercises the RCCL
     path on a single GPU)."""

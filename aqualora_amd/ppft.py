@@ -484,3 +484,7 @@ class PPFTTrainer:
 
     def grad_norm(self):
         return float(torch.sqrt(self.sumsq)[0])
+
+    def logged_loss(self, loss):
+        """The cross-rank mean the reference logs (ppft_train.py:1054); synchronises, call it at logging steps only."""
+        return dp.logged_loss(loss, self.pg)

@@ -352,3 +352,51 @@ def dpmpp2m_sample(eps_model, x, schedule, guidance=1.0):
         x = a * x + b * x0 + c * x0_prev
         x0_prev = x0
     return x.float()
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Sigma-space samplers (evaluation/utils_eval.py:83-101: euler / heun / lms / kdpm2), independent restatement of the step rules
+# for tests/test_samplers.py.  UNPINNED (diffusers absent): Karras et al. 2022 / k-diffusion, SD-1.5 scheduler conventions.
+def k_sigmas_oracle(num_inference_steps, acp):
+    """(timesteps, sigmas + [0]) with leading spacing and steps_offset 1; acp: float64 alphas_cumprod [1000]."""
+    ratio = 1000 // num_inference_steps
+    ts = [i * ratio + 1 for i in range(num_inference_steps)][::-1]
+    sig = [float(((1 - acp[t]) / acp[t]) ** 0.5) for t in ts] + [0.0]
+    return ts, sig
+
+
+def lms_coeff_oracle(sig, order, i, j):
+    """Exact integral of the Lagrange basis polynomial (polynomial arithmetic with numpy.poly1d instead of quadrature)."""
+    import numpy as np
+    poly = np.poly1d([1.0])
+    for k in range(order):
+        if k == j:
+            continue
+        poly = poly * np.poly1d([1.0, -sig[i - k]]) / (sig[i - j] - sig[i - k])
+    P = poly.integ()
+    return float(P(sig[i + 1]) - P(sig[i]))
+
+
+def k_sample_oracle(eps_fn, x, ts, sig, sampler):
+    """eps_fn(x, sigma, t) -> eps in k-space.  Python loops, float64-friendly."""
+    import math
+    hist = []
+    for i in range(len(ts)):
+        s, sn = sig[i], sig[i + 1]
+        d = eps_fn(x, s, ts[i])
+        if sampler == "euler":
+            x = x + (sn - s) * d
+        elif sampler == "heun":
+            xp = x + (sn - s) * d
+            x = xp if sn == 0 else x + 0.5 * (sn - s) * (d + eps_fn(xp, sn, ts[i + 1]))
+        elif sampler == "kdpm2":
+            if sn == 0:
+                x = x + (sn - s) * d
+            else:
+                sm = math.sqrt(s * sn)            # geometric mean == exp of the mean log
+                x = x + (sn - s) * eps_fn(x + (sm - s) * d, sm, None)
+        elif sampler == "lms":
+            hist = ([d] + hist)[:4]
+            x = x + sum(lms_coeff_oracle(sig, len(hist), i, j) * hist[j] for j in range(len(hist)))
+        else:
+            raise ValueError(sampler)
+    return x

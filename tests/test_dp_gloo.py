@@ -28,13 +28,15 @@ def _worker(rank, world, port, q):
     z0 = synth.normal("bench.z", (2, 4, 8, 8), 1.0, 2048 + 977 * rank)
     gathered = [torch.zeros_like(z0) for _ in range(world)]
     dist.all_gather(gathered, z0)
+    # the logged loss (ppft_train.py:1054): mean over ranks of the per-rank loss
+    ok_log = abs(dp.logged_loss(torch.tensor(float(rank + 1))) - sum(range(1, world + 1)) / world) < 1e-6
     # bucketed asynchronous form used by the trainer: one collective per contiguous range, finished together
     c = g.clone()
     red = dp.BucketedAllreduce()
     for lo, hi in ((0, 3000), (3000, 3001), (3001, n)):
         red.launch(c[lo:hi])
     red.finish()
-    ok_async = torch.allclose(c, want, atol=1e-6) and dp.exchange_active() and not red.pending
+    ok_async = torch.allclose(c, want, atol=1e-6) and dp.exchange_active() and not red.pending and ok_log
     # DDP-style exchange for an ordinary module (the SecretDecoder of rob-finetune): bucketed flat gradient mean + buffers
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 3))

@@ -82,3 +82,63 @@ def test_dpm_solver_hip_vs_oracle_tiny_unet():
     assert torch.isfinite(got).all()
     assert float((got.cpu() - want).abs().max() / want.abs().max()) < 2e-2
     assert float((got - got_eager).abs().max() / got_eager.abs().max()) < 1e-5
+
+@pytest.mark.parametrize("sampler", ["euler", "heun", "kdpm2", "lms"])
+def test_k_samplers_integrate_the_exact_noise_model_and_match_the_restatement(sampler):
+    """Sigma-space samplers (evaluation/utils_eval.py:83-101).  (1) With the exact noise model eps(x, sigma) = (x - x0) / sigma the
+    probability-flow ODE is linear in sigma and every consistent solver must land on x0 at sigma = 0.  (2) With a nonlinear
+    stand-in model the host loop equals the independent restatement in oracle/ppft_oracle.py step for step (1e-9, float64)."""
+    from aqualora_amd.ksamplers import k_sample_core, k_schedule, lms_coefficient, sigma_to_t, k_sigma_table
+    from aqualora_amd.watermark import sd15_alphas_cumprod
+    torch.manual_seed(0)
+    ts, sig = k_schedule(12)
+    ts_o, sig_o = O.k_sigmas_oracle(12, sd15_alphas_cumprod().double())
+    assert ts == ts_o and float((sig - torch.tensor(sig_o, dtype=torch.float64)).abs().max()) < 1e-12
+    x0 = torch.randn(2, 4, 8, 8, dtype=torch.float64)
+    noise = torch.randn_like(x0)
+    x = x0 + float(sig[0]) * noise
+    got = k_sample_core(lambda x_, s, t: (x_ - x0) / s, x, ts, sig, sampler)
+    assert float((got - x0).abs().max()) < 1e-9
+    # nonlinear model: the two implementations must walk the same trajectory
+    f = lambda x_, s, t: torch.tanh(x_ / (1 + s)) * (1 + 0.1 * s)   # noqa: E731
+    a = k_sample_core(f, x, ts, sig, sampler)
+    b = O.k_sample_oracle(f, x, ts_o, sig_o, sampler)
+    assert float((a - b).abs().max() / b.abs().max()) < 1e-9
+    if sampler == "lms":
+        for i, order in ((0, 1), (1, 2), (5, 4)):
+            for j in range(order):
+                assert abs(lms_coefficient(sig, order, i, j) - O.lms_coeff_oracle(sig_o, order, i, j)) < 1e-9
+    if sampler == "kdpm2":   # the fractional timestep of a table sigma is its index; midpoints fall strictly between
+        tab = k_sigma_table()
+        assert abs(sigma_to_t(tab[417], tab) - 417.0) < 1e-6
+        assert 400.0 < sigma_to_t(math.sqrt(float(tab[400]) * float(tab[401])), tab) < 401.0
+
+
+@pytest.mark.gpu
+def test_k_sampler_hip_vs_oracle_tiny_unet():
+    """euler and heun on the HIP tiny U-Net (fractional-free timesteps) against the oracle loop driving the same U-Net."""
+    from aqualora_amd.ksamplers import k_sample, k_schedule
+    from tests.common import T, TINY, tiny_unet
+    dev = "cuda"
+    unet = tiny_unet(dev, torch.bfloat16)
+    ctx = T("k.ctx", (1, 77, TINY["cross_attention_dim"]), device=dev)
+    unc = torch.zeros_like(ctx)
+    lat = T("k.lat", (1, 4, 16, 16), device=dev)
+    ts, sig = k_schedule(5)
+    for sampler in ("euler", "heun", "kdpm2"):
+        got = k_sample(unet, ctx, unc, lat, sampler, 5, 3.0)
+
+        def eps(x, s, t):
+            if t is None:
+                from aqualora_amd.ksamplers import sigma_to_t
+                t = sigma_to_t(s)
+            inp = (x / math.sqrt(s * s + 1)).to(dev).float()
+            tt = torch.full((2,), float(t), dtype=torch.long if float(t) == int(t) else torch.float32, device=dev)
+            e = unet(torch.cat([inp, inp]), tt, torch.cat([unc, ctx]).to(torch.bfloat16),
+                     cross_attention_kwargs={"scale": None}).sample.float().cpu()
+            return e[:1] + 3.0 * (e[1:] - e[:1])
+        with torch.no_grad():
+            want = O.k_sample_oracle(eps, lat.cpu().float() * math.sqrt(float(sig[0]) ** 2 + 1), ts, [float(v) for v in sig], sampler)
+        assert torch.isfinite(got).all()
+        # bf16 U-Net inputs: an fp32 ulp between the host-side and device-side update flips input roundings (the DPM-Solver test's bound)
+        assert float((got.cpu() - want).abs().max() / want.abs().max()) < 2e-2, sampler
