@@ -20,7 +20,10 @@ def graph_time(fn, iters=20):
 
 torch.manual_seed(0)
 out = []
-for B, H, N, d in ((4, 8, 4096, 40), (8, 8, 4096, 40), (4, 8, 1024, 80), (8, 8, 1024, 80)):
+SHAPES = ((4, 8, 4096, 40), (8, 8, 4096, 40), (4, 8, 1024, 80), (8, 8, 1024, 80))
+if os.environ.get("SMALL"):   # the low-resolution levels: 16x16 (d = 160) and 8x8
+    SHAPES = ((4, 8, 256, 160), (8, 8, 256, 160), (4, 8, 64, 160), (8, 8, 64, 160), (4, 8, 1024, 80), (8, 8, 1024, 80))
+for B, H, N, d in SHAPES:
     C = H * d
     q, k, v, do = (torch.randn(B, N, C, device="cuda", dtype=torch.bfloat16) for _ in range(4))
     o = torch.empty_like(q); lse = torch.empty(B, H, N, device="cuda"); delta = torch.empty_like(lse)
