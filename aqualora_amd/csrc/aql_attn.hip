@@ -146,6 +146,70 @@ struct Stager {
   }
 };
 
+// LDS-DMA form of the streamed-tile staging, for the head sizes that run ONE workgroup per CU (DH > 64: d = 80 / 160, the 32x32 and
+// 16x16 levels).  There the register-prefetch of Stager is off (its live registers cost more than they hide) and nothing else on the CU
+// covers a tile's global-load latency: the 32x32 self-attention spent ~45 % of every 1.4 us tile waiting between its two barriers.
+// buffer_load ... lds needs no staging registers: tile t+1 is requested into the OTHER LDS image at the top of iteration t and has
+// landed when the iteration's single barrier is reached.  A wave instruction fills 1 KB of LDS = RPI whole image rows; lane (sub-row,
+// physical chunk) fetches the logical chunk that the XOR swizzle of tile_off() maps there.  Lanes of padding chunks (>= d/8) never
+// issue (EXEC-masked), so the zero padding and the ONES column written once at start-up survive; rows past the end of a partial tile
+// are requested out of range (hardware zero fill) -- the callers mask them.
+typedef unsigned int attn_u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t attn_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x40000000u, 0x00020000);
+}
+template <int DH>
+struct DmaTile {
+  static constexpr int PITCH = RowPitch<DH>::value;
+  static constexpr int CPP = PITCH / 16;             // 16-byte chunks per image row (live + padding + unused)
+  static constexpr int RPI = 1024 / PITCH;           // image rows per wave instruction
+  static constexpr int NI = TILE / RPI / 4;          // instructions per wavefront and tile
+  static constexpr int IMG = TILE * PITCH;
+  __amdgpu_buffer_rsrc_t rs;
+  uint32_t voff[NI];   // byte offset of the lane's 16 bytes inside tile 0 (row * ld + chunk), without the tile's first row
+  int lrow[NI];        // the lane's row inside the tile, per instruction
+  bool live;           // this lane carries a live chunk (same for every instruction: the chunk column only depends on the lane)
+  uint32_t rowbytes;
+  int nrows, blk0;
+  __device__ __forceinline__ void init(const bf16_t* g, long ld, int nrows_, int d, int wave, int lane) {
+    rs = attn_rsrc(g);
+    rowbytes = (uint32_t)(ld * 2);
+    nrows = nrows_;
+    blk0 = wave;
+    const int sub = lane / CPP, pc = lane % CPP;
+    live = false;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int row = (i * 4 + wave) * RPI + sub;
+      const int c = pc ^ ((row & 7) << 1);   // (row & 7) is the same for every i: rows of one lane differ by multiples of 4 * RPI = 8 or 16
+      lrow[i] = row;
+      voff[i] = (uint32_t)row * rowbytes + (uint32_t)c * 16u;
+      live = (c * 8 < d);
+    }
+  }
+  // request the tile whose first row is row0 into image `img` (asynchronous: covered by the issuing wavefront's vmcnt)
+  __device__ __forceinline__ void issue(char* img, int row0) {
+    const uint32_t soff = (uint32_t)row0 * rowbytes;
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const uint32_t v = (row0 + lrow[i] < nrows) ? voff[i] : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(img + ((i * 4 + blk0) << 10)), 16, v, soff, 0, 0);
+      }
+    }
+  }
+  // zero the padding chunks d/8 .. DH/8 of both images once (they are never written afterwards)
+  __device__ __forceinline__ static void pad(char* imgs, int nimg, int d, int tid) {
+    constexpr int CPR = DH / 8;
+    const int dl = d >> 3;
+    for (int id = tid; id < nimg * TILE * CPR; id += 256) {
+      const int im = id / (TILE * CPR), r = id - im * TILE * CPR;
+      const int row = r / CPR, pc = r - row * CPR;
+      if (pc >= dl) *reinterpret_cast<uint4*>(imgs + im * IMG + tile_off<DH>(row, pc)) = zero4();
+    }
+  }
+};
+
 // owner rows -> B-operand fragments  f[frag][kstep]
 template <int DH, int NOF>
 __device__ __forceinline__ void load_owner(bf16x8_t (&f)[NOF][DH / 32], const bf16_t* g, long ld, int row0, int nrows,
@@ -338,9 +402,11 @@ __device__ __forceinline__ void attn_block(int& bx, int& h, int& b) {
 // sum of exactly the bf16 probabilities that multiply V.
 template <int DH, int DV, int NOF, bool ONES>
 __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) char sK[TILE * RowPitch<DH>::value];
-  __shared__ __attribute__((aligned(16))) char sV[TILE * RowPitch<DH>::value];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr bool DMA = DH > 64;                      // one workgroup per CU: LDS-DMA into two images, one barrier per tile
+  constexpr int IMG = TILE * RowPitch<DH>::value;
+  __shared__ __attribute__((aligned(1024))) char sK[(DMA ? 2 : 1) * IMG];
+  __shared__ __attribute__((aligned(1024))) char sV[(DMA ? 2 : 1) * IMG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bx, h, b;
   attn_block(bx, h, b);
   const int q0 = bx * (64 * NOF) + wave * (16 * NOF);
@@ -356,27 +422,57 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const
   for (int of = 0; of < NOF; ++of) m[of] = -INFINITY, l[of] = 0.f;
   const float c = a.scale * LOG2E;
   Stager<DH> stK, stV;
-  stK.init(sK, kp, a.ldk, 0, a.Nk, a.d, tid);
-  stV.init(sV, vp, a.ldv, 0, a.Nk, a.d, tid);
-  stK.fetch();
-  stV.fetch();
+  DmaTile<DH> dmK, dmV;
+  if constexpr (DMA) {
+    dmK.init(kp, a.ldk, a.Nk, a.d, wave, lane);
+    dmV.init(vp, a.ldv, a.Nk, a.d, wave, lane);
+    DmaTile<DH>::pad(sK, 2, a.d, tid);
+    DmaTile<DH>::pad(sV, 2, a.d, tid);
+    dmK.issue(sK, 0);
+    dmV.issue(sV, 0);
+  } else {
+    stK.init(sK, kp, a.ldk, 0, a.Nk, a.d, tid);
+    stV.init(sV, vp, a.ldv, 0, a.Nk, a.d, tid);
+    stK.fetch();
+    stV.fetch();
+  }
   if constexpr (ONES) {
     __syncthreads();  // the padding chunks were zeroed by other threads
-    if (tid < TILE) *reinterpret_cast<bf16_t*>(sV + tile_off<DH>(tid, a.d >> 3) + (a.d & 7) * 2) = (bf16_t)0x3F80;  // 1.0
+    if (tid < TILE) {
+#pragma unroll
+      for (int i = 0; i < (DMA ? 2 : 1); ++i)
+        *reinterpret_cast<bf16_t*>(sV + i * IMG + tile_off<DH>(tid, a.d >> 3) + (a.d & 7) * 2) = (bf16_t)0x3F80;  // 1.0
+    }
   }
+  if constexpr (DMA) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // tile 0 has landed in image 0 (every wavefront waited for its own requests)
+  }
+  int cur = 0;
   for (int kt = 0; kt < a.Nk; kt += TILE) {
-    __syncthreads();
-    stK.commit(sK);
-    stV.commit(sV);
-    __syncthreads();
-    if (kt + TILE < a.Nk) {  // next tile's loads fly under this tile's MFMAs and softmax
-      stK.next(kt + TILE, tid);
-      stV.next(kt + TILE, tid);
-      stK.fetch();
-      stV.fetch();
+    const char* tK = sK;
+    const char* tV = sV;
+    if constexpr (DMA) {
+      tK = sK + cur * IMG;
+      tV = sV + cur * IMG;
+      if (kt + TILE < a.Nk) {   // tile t+1 flies into the other image under this tile's MFMAs and softmax
+        dmK.issue(sK + (cur ^ 1) * IMG, kt + TILE);
+        dmV.issue(sV + (cur ^ 1) * IMG, kt + TILE);
+      }
+    } else {
+      __syncthreads();
+      stK.commit(sK);
+      stV.commit(sV);
+      __syncthreads();
+      if (kt + TILE < a.Nk) {  // next tile's loads fly under this tile's MFMAs and softmax
+        stK.next(kt + TILE, tid);
+        stV.next(kt + TILE, tid);
+        stK.fetch();
+        stV.fetch();
+      }
     }
     f32x4_t s[4][NOF];
-    s_product<DH, NOF, true>(s, sK, qf, lane);
+    s_product<DH, NOF, true>(s, tK, qf, lane);
     if (kt + TILE > a.Nk) {
 #pragma unroll
       for (int sf = 0; sf < 4; ++sf)
@@ -419,7 +515,12 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const
     }
     bf16x8_t pb[2][NOF];
     pack_p(pb, s);
-    t_product<DH, DV>(o, sV, pb, lane);
+    t_product<DH, DV>(o, tV, pb, lane);
+    if constexpr (DMA) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's share of tile t+1 has landed
+      __syncthreads();   // everyone's has, and nobody reads image `cur` any more
+      cur ^= 1;
+    }
   }
   if constexpr (ONES) {  // the denominator of row (lane & 15) sits in accumulator column d: fragment d/16, lane group (d%16)/4
     const int df = a.d >> 4, grp = (a.d & 15) >> 2, e = a.d & 3;
@@ -450,9 +551,11 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const
 // ------------------------------------------------------------------------------------------------ dQ
 template <int DH, int DV>
 __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dq_kernel(const AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) char sK[TILE * RowPitch<DH>::value];
-  __shared__ __attribute__((aligned(16))) char sV[TILE * RowPitch<DH>::value];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr bool DMA = DH > 64;   // see attn_fwd_kernel / DmaTile
+  constexpr int IMG = TILE * RowPitch<DH>::value;
+  __shared__ __attribute__((aligned(1024))) char sK[(DMA ? 2 : 1) * IMG];
+  __shared__ __attribute__((aligned(1024))) char sV[(DMA ? 2 : 1) * IMG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bx, h, b;
   attn_block(bx, h, b);
   const int q0 = bx * (4 * OWN) + wave * OWN;
@@ -493,26 +596,50 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dq_kernel(const 
   zero_acc(dq);
   const float c = a.scale * LOG2E;
   Stager<DH> stK, stV;
-  stK.init(sK, kp, a.ldk, 0, a.Nk, a.d, tid);
-  stV.init(sV, vp, a.ldv, 0, a.Nk, a.d, tid);
-  stK.fetch();
-  stV.fetch();
+  DmaTile<DH> dmK, dmV;
+  if constexpr (DMA) {
+    dmK.init(kp, a.ldk, a.Nk, a.d, wave, lane);
+    dmV.init(vp, a.ldv, a.Nk, a.d, wave, lane);
+    DmaTile<DH>::pad(sK, 2, a.d, tid);
+    DmaTile<DH>::pad(sV, 2, a.d, tid);
+    dmK.issue(sK, 0);
+    dmV.issue(sV, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  } else {
+    stK.init(sK, kp, a.ldk, 0, a.Nk, a.d, tid);
+    stV.init(sV, vp, a.ldv, 0, a.Nk, a.d, tid);
+    stK.fetch();
+    stV.fetch();
+  }
+  int cur = 0;
   for (int kt = 0; kt < a.Nk; kt += TILE) {
-    __syncthreads();
-    stK.commit(sK);
-    stV.commit(sV);
-    __syncthreads();
-    if (kt + TILE < a.Nk) {
-      stK.next(kt + TILE, tid);
-      stV.next(kt + TILE, tid);
-      stK.fetch();
-      stV.fetch();
+    const char* tK = sK;
+    const char* tV = sV;
+    if constexpr (DMA) {
+      tK = sK + cur * IMG;
+      tV = sV + cur * IMG;
+      if (kt + TILE < a.Nk) {
+        dmK.issue(sK + (cur ^ 1) * IMG, kt + TILE);
+        dmV.issue(sV + (cur ^ 1) * IMG, kt + TILE);
+      }
+    } else {
+      __syncthreads();
+      stK.commit(sK);
+      stV.commit(sV);
+      __syncthreads();
+      if (kt + TILE < a.Nk) {
+        stK.next(kt + TILE, tid);
+        stV.next(kt + TILE, tid);
+        stK.fetch();
+        stV.fetch();
+      }
     }
     f32x4_t s[4][2], dp[4][2];
     zero_acc(s);
     zero_acc(dp);
-    s_product<DH>(s, sK, qf, lane);
-    s_product<DH>(dp, sV, dof, lane);
+    s_product<DH>(s, tK, qf, lane);
+    s_product<DH>(dp, tV, dof, lane);
 #pragma unroll
     for (int sf = 0; sf < 4; ++sf)
 #pragma unroll
@@ -531,7 +658,12 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dq_kernel(const 
     }
     bf16x8_t pb[2][2];
     pack_p(pb, s);
-    t_product<DH, DV>(dq, sK, pb, lane);
+    t_product<DH, DV>(dq, tK, pb, lane);
+    if constexpr (DMA) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    }
   }
   const float mq[2] = {a.scale, a.scale};
   const long ld_dq = (long)a.H * a.d;  // dQ is written dense ([B][Nq][H*d]) whatever the row stride of q (q may be a column view)
@@ -541,11 +673,13 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dq_kernel(const 
 // ------------------------------------------------------------------------------------------------ dK, dV
 template <int DH, int DV>
 __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dkv_kernel(const AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) char sQ[TILE * RowPitch<DH>::value];
-  __shared__ __attribute__((aligned(16))) char sdO[TILE * RowPitch<DH>::value];
-  __shared__ __attribute__((aligned(16))) float sLse[TILE];
-  __shared__ __attribute__((aligned(16))) float sDelta[TILE];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr bool DMA = DH > 64;   // see attn_fwd_kernel / DmaTile
+  constexpr int IMG = TILE * RowPitch<DH>::value, NIMG = DMA ? 2 : 1;
+  __shared__ __attribute__((aligned(1024))) char sQ[NIMG * IMG];
+  __shared__ __attribute__((aligned(1024))) char sdO[NIMG * IMG];
+  __shared__ __attribute__((aligned(16))) float sLse[NIMG * TILE];
+  __shared__ __attribute__((aligned(16))) float sDelta[NIMG * TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bx, h, bz;
   attn_block(bx, h, bz);
   const int b = bz / a.qsplit, split = bz - b * a.qsplit;
@@ -567,51 +701,82 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dkv_kernel(const
   zero_acc(dv);
   const float c = a.scale * LOG2E;
   Stager<DH> stQ, stO;
-  stQ.init(sQ, qp, a.ldq, qt_lo, a.Nq, a.d, tid);
-  stO.init(sdO, dop, a.ldo, qt_lo, a.Nq, a.d, tid);
+  DmaTile<DH> dmQ, dmO;
   const float* lse_row = a.lse + ((long)b * a.H + h) * a.Nq;
   const float* delta_row = a.delta + ((long)b * a.H + h) * a.Nq;
   float lse_r = 0.f, delta_r = 0.f;   // threads 0..63: row statistics of the tile in flight
-  if (qt_lo < qt_hi) {
-    stQ.fetch();
-    stO.fetch();
+  auto fetch_stats = [&](int qt) {
     if (tid < TILE) {
-      const int r = min(qt_lo + tid, a.Nq - 1);
+      const int r = min(qt + tid, a.Nq - 1);
       lse_r = lse_row[r];
       delta_r = delta_row[r];
     }
-  }
-  for (int qt = qt_lo; qt < qt_hi; qt += TILE) {
-    __syncthreads();
-    stQ.commit(sQ);
-    stO.commit(sdO);
+  };
+  auto put_stats = [&](int img, int qt) {
     if (tid < TILE) {
       const bool ok = (qt + tid) < a.Nq;   // rows past the end: p = exp2(s - inf) = 0
-      sLse[tid] = ok ? lse_r * LOG2E : INFINITY;
-      sDelta[tid] = ok ? delta_r : 0.f;
+      sLse[img * TILE + tid] = ok ? lse_r * LOG2E : INFINITY;
+      sDelta[img * TILE + tid] = ok ? delta_r : 0.f;
     }
+  };
+  if constexpr (DMA) {
+    dmQ.init(qp, a.ldq, a.Nq, a.d, wave, lane);
+    dmO.init(dop, a.ldo, a.Nq, a.d, wave, lane);
+    DmaTile<DH>::pad(sQ, 2, a.d, tid);
+    DmaTile<DH>::pad(sdO, 2, a.d, tid);
+    if (qt_lo < qt_hi) {
+      dmQ.issue(sQ, qt_lo);
+      dmO.issue(sdO, qt_lo);
+      fetch_stats(qt_lo);
+      put_stats(0, qt_lo);
+      if (qt_lo + TILE < qt_hi) fetch_stats(qt_lo + TILE);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (qt + TILE < qt_hi) {
-      stQ.next(qt + TILE, tid);
-      stO.next(qt + TILE, tid);
+  } else {
+    stQ.init(sQ, qp, a.ldq, qt_lo, a.Nq, a.d, tid);
+    stO.init(sdO, dop, a.ldo, qt_lo, a.Nq, a.d, tid);
+    if (qt_lo < qt_hi) {
       stQ.fetch();
       stO.fetch();
-      if (tid < TILE) {
-        const int r = min(qt + TILE + tid, a.Nq - 1);
-        lse_r = lse_row[r];
-        delta_r = delta_row[r];
+      fetch_stats(qt_lo);
+    }
+  }
+  int cur = 0;
+  for (int qt = qt_lo; qt < qt_hi; qt += TILE) {
+    if constexpr (DMA) {
+      if (qt + TILE < qt_hi) {   // tile t+1: operands by LDS-DMA into the other image, its row statistics from the registers
+        dmQ.issue(sQ + (cur ^ 1) * IMG, qt + TILE);
+        dmO.issue(sdO + (cur ^ 1) * IMG, qt + TILE);
+        put_stats(cur ^ 1, qt + TILE);
+        if (qt + 2 * TILE < qt_hi) fetch_stats(qt + 2 * TILE);
+      }
+    } else {
+      __syncthreads();
+      stQ.commit(sQ);
+      stO.commit(sdO);
+      put_stats(0, qt);
+      __syncthreads();
+      if (qt + TILE < qt_hi) {
+        stQ.next(qt + TILE, tid);
+        stO.next(qt + TILE, tid);
+        stQ.fetch();
+        stO.fetch();
+        fetch_stats(qt + TILE);
       }
     }
+    const char* tQ = sQ + cur * IMG;
+    const char* tO = sdO + cur * IMG;
     f32x4_t s[4][2], dp[4][2];
     zero_acc(s);
     zero_acc(dp);
-    s_product<DH>(s, sQ, kf, lane);
-    s_product<DH>(dp, sdO, vf, lane);
+    s_product<DH>(s, tQ, kf, lane);
+    s_product<DH>(dp, tO, vf, lane);
     f32x4_t ds[4][2];
 #pragma unroll
     for (int sf = 0; sf < 4; ++sf) {
-      const float4 ls = *reinterpret_cast<const float4*>(&sLse[sf * 16 + (lane >> 4) * 4]);
-      const float4 de = *reinterpret_cast<const float4*>(&sDelta[sf * 16 + (lane >> 4) * 4]);
+      const float4 ls = *reinterpret_cast<const float4*>(&sLse[cur * TILE + sf * 16 + (lane >> 4) * 4]);
+      const float4 de = *reinterpret_cast<const float4*>(&sDelta[cur * TILE + sf * 16 + (lane >> 4) * 4]);
       const float lsv[4] = {ls.x, ls.y, ls.z, ls.w};
       const float dev[4] = {de.x, de.y, de.z, de.w};
 #pragma unroll
@@ -625,9 +790,14 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dkv_kernel(const
     }
     bf16x8_t pb[2][2];
     pack_p(pb, s);
-    t_product<DH, DV>(dv, sdO, pb, lane);
+    t_product<DH, DV>(dv, tO, pb, lane);
     pack_p(pb, ds);
-    t_product<DH, DV>(dk, sQ, pb, lane);
+    t_product<DH, DV>(dk, tQ, pb, lane);
+    if constexpr (DMA) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    }
   }
   const long ldo_kv = (long)a.H * a.d;
   if (a.qsplit > 1) {
