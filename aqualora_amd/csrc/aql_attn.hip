@@ -158,6 +158,9 @@ typedef unsigned int attn_u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t attn_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x40000000u, 0x00020000);
 }
+#ifndef AQL_ATTN_DMA_ABOVE
+#define AQL_ATTN_DMA_ABOVE 64   // head sizes above this stage by LDS-DMA (experiment builds: 0 = all)
+#endif
 template <int DH>
 struct DmaTile {
   static constexpr int PITCH = RowPitch<DH>::value;
@@ -402,7 +405,7 @@ __device__ __forceinline__ void attn_block(int& bx, int& h, int& b) {
 // sum of exactly the bf16 probabilities that multiply V.
 template <int DH, int DV, int NOF, bool ONES>
 __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const AttnArgs a) {
-  constexpr bool DMA = DH > 64;                      // one workgroup per CU: LDS-DMA into two images, one barrier per tile
+  constexpr bool DMA = DH > AQL_ATTN_DMA_ABOVE;                      // one workgroup per CU: LDS-DMA into two images, one barrier per tile
   constexpr int IMG = TILE * RowPitch<DH>::value;
   __shared__ __attribute__((aligned(1024))) char sK[(DMA ? 2 : 1) * IMG];
   __shared__ __attribute__((aligned(1024))) char sV[(DMA ? 2 : 1) * IMG];
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const
 // ------------------------------------------------------------------------------------------------ dQ
 template <int DH, int DV>
 __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dq_kernel(const AttnArgs a) {
-  constexpr bool DMA = DH > 64;   // see attn_fwd_kernel / DmaTile
+  constexpr bool DMA = DH > AQL_ATTN_DMA_ABOVE;   // see attn_fwd_kernel / DmaTile
   constexpr int IMG = TILE * RowPitch<DH>::value;
   __shared__ __attribute__((aligned(1024))) char sK[(DMA ? 2 : 1) * IMG];
   __shared__ __attribute__((aligned(1024))) char sV[(DMA ? 2 : 1) * IMG];
@@ -673,7 +676,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dq_kernel(const 
 // ------------------------------------------------------------------------------------------------ dK, dV
 template <int DH, int DV>
 __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dkv_kernel(const AttnArgs a) {
-  constexpr bool DMA = DH > 64;   // see attn_fwd_kernel / DmaTile
+  constexpr bool DMA = DH > AQL_ATTN_DMA_ABOVE;   // see attn_fwd_kernel / DmaTile
   constexpr int IMG = TILE * RowPitch<DH>::value, NIMG = DMA ? 2 : 1;
   __shared__ __attribute__((aligned(1024))) char sQ[NIMG * IMG];
   __shared__ __attribute__((aligned(1024))) char sdO[NIMG * IMG];
