@@ -552,8 +552,11 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
+#ifndef AQL_ATTN_DQ_OCC2_UPTO
+#define AQL_ATTN_DQ_OCC2_UPTO 96   // head sizes up to this are compiled for two workgroups per CU (d = 80: 284 -> 250 registers, no spill; 80.1 -> 78.5 us backward at 4 x 1024 x 8 x 80)
+#endif
 template <int DH, int DV>
-__global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dq_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, (DH <= AQL_ATTN_DQ_OCC2_UPTO ? 2 : 1)) void attn_dq_kernel(const AttnArgs a) {
   constexpr bool DMA = DH > AQL_ATTN_DMA_ABOVE;   // see attn_fwd_kernel / DmaTile
   constexpr int IMG = TILE * RowPitch<DH>::value;
   __shared__ __attribute__((aligned(1024))) char sK[(DMA ? 2 : 1) * IMG];
