@@ -109,7 +109,11 @@ for tag, M, N, K, geglu in shapes():
             continue
         res[cfg] = graph_time(fns)
     os.environ.pop("AQL_LORA_CFG", None)
-    best = min((v, k) for k, v in res.items() if v == v and (k != "auto" or len(res) == 1))
+    cand = [(v, k) for k, v in res.items() if v == v and (k != "auto" or len(res) == 1)]
+    if not cand:
+        print(f"{tag:15s} M{M:6d} N{N:6d} K{K:5d}: not served by the one-launch kernel (two-launch form)", flush=True)
+        continue
+    best = min(cand)
     fl = 2.0 * M * K * (N + 32) + 2.0 * M * 32 * N
     print(f"{tag:15s} M{M:6d} N{N:6d} K{K:5d}: " + " ".join(f"{k}={v:6.1f}" for k, v in res.items()) +
           f"  | best {best[1]} {best[0]:.1f} us = {fl / best[0] / 1e6:.0f} TF/s (auto {res['auto']:.1f})", flush=True)
