@@ -86,14 +86,36 @@ __device__ __forceinline__ void aql_geglu_bwd1(float d, float h, float g, float&
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// All-lanes reductions over the 64 lanes of a wavefront WITHOUT the LDS pipe.  `__shfl_xor` compiles to ds_bpermute_b32: six dependent
+// LDS round trips (~120 cycles each) per reduction -- 12 of them were a quarter of a LayerNorm wavefront's life (one row per wavefront,
+// two dependent reductions).  Same butterfly, same operand pairs, so the same bits (IEEE add / max are commutative): the xor-32 and xor-16
+// steps are gfx950's v_permlane32_swap / v_permlane16_swap (both results of swap(v, v) together hold own and partner value in every
+// lane), the steps inside a 16-lane row are DPP row rotations -- lane (l + n) % 16 is not lane l ^ n when bit log2(n) of l is set, but it
+// differs from l ^ n only in the bits the earlier steps have already merged, so it holds the same partial sum.
+template <int CTRL>
+__device__ __forceinline__ float aql_dpp_row(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+  v += aql_dpp_row<0x128>(v);   // row_ror:8
+  v += aql_dpp_row<0x124>(v);   // row_ror:4
+  v += aql_dpp_row<0x122>(v);   // row_ror:2
+  v += aql_dpp_row<0x121>(v);   // row_ror:1
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+  v = fmaxf(v, aql_dpp_row<0x128>(v));
+  v = fmaxf(v, aql_dpp_row<0x124>(v));
+  v = fmaxf(v, aql_dpp_row<0x122>(v));
+  v = fmaxf(v, aql_dpp_row<0x121>(v));
   return v;
 }
 
