@@ -437,101 +437,156 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const bf16_t* __r
 // ---------------------------------------------------------------------------------------------------
 constexpr int LN_MAXC = 3;  // up to 1536 channels
 
-template <int MODE>
+// R rows per wavefront, every row's loads issued before the first is consumed: with one row per wavefront the kernel has
+// 32 waves x 640 B = 20 KB in flight per CU at 320 channels (5 MB on the chip: ~3 TB/s at ~1.7 us of latency, what it measured);
+// two rows double that at the same occupancy now that the reductions no longer go through the LDS pipe.
+template <int MODE, int R, int NT>
 __global__ __launch_bounds__(256) void ln_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                  const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
                                                  float* __restrict__ stats, long M, int C, float eps,
                                                  bf16_t* __restrict__ out) {
+#pragma clang fp contract(off)   // every fused multiply-add below is an explicit fmaf: the same bits in every (R, NT) instance
   const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= M) return;
   const int cols = C >> 3;
-  float xv[LN_MAXC][8];
-  float dv[LN_MAXC][8];
-  float s = 0.f;
+  uint4 xr[R][NT], dr[R][NT], rr[R][NT];
+  float st0[R], st1[R];
 #pragma unroll
-  for (int t = 0; t < LN_MAXC; ++t) {
+  for (int r = 0; r < R; ++r) {
+    const long row = min(row0 + r, M - 1);   // rows past the end re-read the last row (not stored)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int c = lane + t * 64;
+      if (c < cols) {
+        xr[r][t] = *reinterpret_cast<const uint4*>(x + row * C + c * 8);
+        if (MODE == 1) {
+          dr[r][t] = *reinterpret_cast<const uint4*>(dy + row * C + c * 8);
+          if (beta != nullptr) rr[r][t] = *reinterpret_cast<const uint4*>(beta + row * C + c * 8);
+        }
+      }
+    }
+    if (MODE == 1) {
+      st0[r] = stats[row * 2 + 0];
+      st1[r] = stats[row * 2 + 1];
+    }
+  }
+  uint4 gr[NT], br[NT];   // gamma (and beta) as loaded: unpacked where they are used (registers bound the rows in flight)
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
     const int c = lane + t * 64;
     if (c < cols) {
-      unpack8(*reinterpret_cast<const uint4*>(x + row * C + c * 8), xv[t]);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s += xv[t][j];
+      gr[t] = *reinterpret_cast<const uint4*>(gamma + c * 8);
+      if (MODE == 0) br[t] = *reinterpret_cast<const uint4*>(beta + c * 8);
     }
   }
-  float mean, rstd;
-  if (MODE == 0) {
-    mean = wave_sum(s) / C;
-    float v = 0.f;
 #pragma unroll
-    for (int t = 0; t < LN_MAXC; ++t) {
+  for (int r = 0; r < R; ++r) {
+    const long row = row0 + r;
+    if (row >= M) break;
+    float xv[NT][8];
+    float dv[NT][8];
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
       const int c = lane + t * 64;
       if (c < cols) {
+        unpack8(xr[r][t], xv[t]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float d = xv[t][j] - mean;
-          v += d * d;
+        for (int j = 0; j < 8; ++j) s += xv[t][j];
+      }
+    }
+    float mean, rstd;
+    if (MODE == 0) {
+      mean = wave_sum(s) / C;
+      float v = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int c = lane + t * 64;
+        if (c < cols) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float d = xv[t][j] - mean;
+            v = fmaf(d, d, v);
+          }
+        }
+      }
+      rstd = rsqrtf(wave_sum(v) / C + eps);
+      if (lane == 0) {
+        stats[row * 2 + 0] = mean;
+        stats[row * 2 + 1] = rstd;
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int c = lane + t * 64;
+        if (c < cols) {
+          float o[8], ga[8], be[8];
+          unpack8(gr[t], ga);
+          unpack8(br[t], be);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = fmaf((xv[t][j] - mean) * rstd, ga[j], be[j]);
+          *reinterpret_cast<uint4*>(out + row * C + c * 8) = pack8(o);
+        }
+      }
+    } else {
+      mean = st0[r];
+      rstd = st1[r];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int c = lane + t * 64;
+        if (c < cols) {
+          float ga[8];
+          unpack8(gr[t], ga);
+          unpack8(dr[r][t], dv[t]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            dv[t][j] *= ga[j];
+            xv[t][j] = (xv[t][j] - mean) * rstd;
+            s1 += dv[t][j];
+            s2 = fmaf(dv[t][j], xv[t][j], s2);
+          }
+        }
+      }
+      s1 = wave_sum(s1) / C;
+      s2 = wave_sum(s2) / C;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int c = lane + t * 64;
+        if (c < cols) {
+          float o[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = rstd * fmaf(-xv[t][j], s2, dv[t][j] - s1);
+          if (beta != nullptr) {  // backward: `beta` carries the gradient of the residual branch (same shape as x)
+            float rsd[8];
+            unpack8(rr[r][t], rsd);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += rsd[j];
+          }
+          *reinterpret_cast<uint4*>(out + row * C + c * 8) = pack8(o);
         }
       }
     }
-    rstd = rsqrtf(wave_sum(v) / C + eps);
-    if (lane == 0) {
-      stats[row * 2 + 0] = mean;
-      stats[row * 2 + 1] = rstd;
-    }
+  }
+}
+
+template <int MODE>
+void ln_launch(bool two_rows, const bf16_t* x, const bf16_t* dy, const bf16_t* gamma, const bf16_t* beta, float* stats, long M, int C,
+               float eps, bf16_t* out, hipStream_t stream) {
+  const int nt = (C / 8 + 63) / 64;   // 16-byte chunk slots per lane: 1 up to 512 channels, 2 up to 1024, 3 up to 1536
+#define AQL_LN(R, NT)                                                                                                         \
+  hipLaunchKernelGGL((ln_kernel<MODE, R, NT>), dim3((unsigned)((M + 4 * R - 1) / (4 * R))), dim3(256), 0, stream, x, dy, gamma, beta, \
+                     stats, M, C, eps, out)
+  if (two_rows) {
+    if (nt == 1) AQL_LN(2, 1);
+    else if (nt == 2) AQL_LN(2, 2);
+    else AQL_LN(2, 3);
   } else {
-    mean = stats[row * 2 + 0];
-    rstd = stats[row * 2 + 1];
+    if (nt == 1) AQL_LN(1, 1);
+    else if (nt == 2) AQL_LN(1, 2);
+    else AQL_LN(1, 3);
   }
-  if (MODE == 0) {
-#pragma unroll
-    for (int t = 0; t < LN_MAXC; ++t) {
-      const int c = lane + t * 64;
-      if (c < cols) {
-        float ga[8], be[8], o[8];
-        unpack8(*reinterpret_cast<const uint4*>(gamma + c * 8), ga);
-        unpack8(*reinterpret_cast<const uint4*>(beta + c * 8), be);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (xv[t][j] - mean) * rstd * ga[j] + be[j];
-        *reinterpret_cast<uint4*>(out + row * C + c * 8) = pack8(o);
-      }
-    }
-  } else {
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int t = 0; t < LN_MAXC; ++t) {
-      const int c = lane + t * 64;
-      if (c < cols) {
-        float ga[8];
-        unpack8(*reinterpret_cast<const uint4*>(gamma + c * 8), ga);
-        unpack8(*reinterpret_cast<const uint4*>(dy + row * C + c * 8), dv[t]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          dv[t][j] *= ga[j];
-          xv[t][j] = (xv[t][j] - mean) * rstd;
-          s1 += dv[t][j];
-          s2 += dv[t][j] * xv[t][j];
-        }
-      }
-    }
-    s1 = wave_sum(s1) / C;
-    s2 = wave_sum(s2) / C;
-#pragma unroll
-    for (int t = 0; t < LN_MAXC; ++t) {
-      const int c = lane + t * 64;
-      if (c < cols) {
-        float o[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = rstd * (dv[t][j] - s1 - xv[t][j] * s2);
-        if (beta != nullptr) {  // backward: `beta` carries the gradient of the residual branch (same shape as x)
-          float rsd[8];
-          unpack8(*reinterpret_cast<const uint4*>(beta + row * C + c * 8), rsd);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] += rsd[j];
-        }
-        *reinterpret_cast<uint4*>(out + row * C + c * 8) = pack8(o);
-      }
-    }
-  }
+#undef AQL_LN
 }
 
 inline int gn_geometry(int HW, int C, int* threads, int* rows_per_slab) {
@@ -686,8 +741,8 @@ extern "C" int aql_layernorm_fwd(const bf16_t* x, long M, int C, const bf16_t* g
                                  bf16_t* y, float* stats, hipStream_t stream) {
   AQL_CHECK_ARG(x && gamma && beta && y && stats, "aql_layernorm_fwd: null operand");
   AQL_CHECK_ARG(C % 8 == 0 && C <= 64 * 8 * LN_MAXC, "aql_layernorm_fwd: unsupported C=%d", C);
-  hipLaunchKernelGGL(ln_kernel<0>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, x, nullptr, gamma, beta, stats,
-                     M, C, eps, y);
+  static const int rows = getenv("AQL_LN_ROWS") ? atoi(getenv("AQL_LN_ROWS")) : 1;   // tuning hook: rows per wavefront (2: measured equal or slower, tools/time_ln.py)
+  ln_launch<0>(rows >= 2 && M >= 4096, x, nullptr, gamma, beta, stats, M, C, eps, y, stream);
   AQL_CHECK_LAUNCH("aql_layernorm_fwd");
   return AQL_OK;
 }
@@ -696,8 +751,8 @@ extern "C" int aql_layernorm_bwd(const bf16_t* x, const bf16_t* dy, long M, int 
                                  const float* stats, const bf16_t* dres, bf16_t* dx, hipStream_t stream) {
   AQL_CHECK_ARG(x && dy && gamma && dx && stats, "aql_layernorm_bwd: null operand");
   AQL_CHECK_ARG(C % 8 == 0 && C <= 64 * 8 * LN_MAXC, "aql_layernorm_bwd: unsupported C=%d", C);
-  hipLaunchKernelGGL(ln_kernel<1>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, x, dy, gamma, dres,
-                     const_cast<float*>(stats), M, C, 0.f, dx);
+  static const int rows = getenv("AQL_LN_ROWS") ? atoi(getenv("AQL_LN_ROWS")) : 1;
+  ln_launch<1>(rows >= 2 && M >= 4096, x, dy, gamma, dres, const_cast<float*>(stats), M, C, 0.f, dx, stream);
   AQL_CHECK_LAUNCH("aql_layernorm_bwd");
   return AQL_OK;
 }
