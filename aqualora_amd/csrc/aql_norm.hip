@@ -179,6 +179,101 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
   }
 }
 
+// pass 1, coalesced form for maps above 32x32 (round 3, session 5).  gn_fused_kernel<MODE, 1> reads a (sample, group, piece) as 4-byte
+// accesses to 20-byte pixel segments (10 channels per group at 320): every 128-byte line is fetched by the workgroups of the ~6 groups
+// that share it, and the pass measured 14 us for 21 MB (8 x 64x64 x 320) -- 1.5 TB/s.  Here a workgroup owns a slab of WHOLE pixel rows
+// (the geometry of gn_apply2_kernel: one 16-byte chunk column per thread, GNS_U rows in flight), keeps per-channel fp32 sums in
+// registers, folds them into the (at most two) groups its 8 channels belong to, and 64 threads add the workgroup's contributions in a
+// fixed order: piece sums `part` [B][nslab][G][2] (slab-major: gn_apply2_kernel reads a piece's 64 sums as two cache lines).  Deterministic, no atomics, stateless.
+// MODE 0: sum x, sum x^2.  MODE 1: sum dxhat, sum dxhat * xhat (the formulas of gn_apply2_kernel<1>).
+constexpr int GNS_U = 4;
+template <int MODE>
+__global__ void gn_rowstats_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, const bf16_t* __restrict__ gamma,
+                                   const bf16_t* __restrict__ beta, const float* __restrict__ stats, int HW, int C,
+                                   int rows_per_slab, int silu, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float sp[];   // [blockDim.x][4]: (g0 s1, g0 s2, g1 s1, g1 s2) of every thread
+  const int cols = C >> 3, cpg = C / G;
+  const int rp = blockDim.x / cols;
+  const int col = threadIdx.x % cols, rr = threadIdx.x / cols;
+  const int b = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
+  const int c0 = col * 8;
+  const int g0 = c0 / cpg, g1 = (c0 + 7) / cpg;
+  const int split = (g0 + 1) * cpg - c0;   // channels j < split belong to g0, the rest to g1
+  float ga[8], be[8], mu2[2] = {0.f, 0.f}, rs2[2] = {0.f, 0.f};
+  if (MODE == 1) {
+    unpack8(*reinterpret_cast<const uint4*>(gamma + c0), ga);
+    unpack8(*reinterpret_cast<const uint4*>(beta + c0), be);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int g = k ? g1 : g0;
+      mu2[k] = stats[(b * G + g) * 2 + 0];
+      rs2[k] = stats[(b * G + g) * 2 + 1];
+    }
+  }
+  float a1[8], a2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a1[j] = a2[j] = 0.f;
+  const int r0 = slab * rows_per_slab, r1 = min(HW, r0 + rows_per_slab);
+  for (int r = r0 + rr; r < r1; r += rp * GNS_U) {
+    uint4 xw[GNS_U], dw[GNS_U];
+#pragma unroll
+    for (int u = 0; u < GNS_U; ++u) {
+      const int ru = min(r + u * rp, r1 - 1);   // rows past the slab re-read its last row (dropped below)
+      const long off = ((long)b * HW + ru) * C + c0;
+      xw[u] = *reinterpret_cast<const uint4*>(x + off);
+      if (MODE == 1) dw[u] = *reinterpret_cast<const uint4*>(dy + off);
+    }
+#pragma unroll
+    for (int u = 0; u < GNS_U; ++u) {
+      if (r + u * rp >= r1) continue;
+      float xv[8], dv[8];
+      unpack8(xw[u], xv);
+      if (MODE == 1) unpack8(dw[u], dv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (MODE == 0) {
+          a1[j] += xv[j];
+          a2[j] += xv[j] * xv[j];
+        } else {
+          const int k = j < split ? 0 : 1;
+          const float xh = (xv[j] - mu2[k]) * rs2[k];
+          float d = dv[j];
+          if (silu) {
+            const float z = xh * ga[j] + be[j];
+            const float sg = sigmoidf_(z);
+            d *= sg * (1.f + z * (1.f - sg));
+          }
+          d *= ga[j];
+          a1[j] += d;
+          a2[j] += d * xh;
+        }
+      }
+    }
+  }
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const bool lo = j < split;
+    s[0] += lo ? a1[j] : 0.f;
+    s[1] += lo ? a2[j] : 0.f;
+    s[2] += lo ? 0.f : a1[j];
+    s[3] += lo ? 0.f : a2[j];
+  }
+  *reinterpret_cast<float4*>(sp + threadIdx.x * 4) = make_float4(s[0], s[1], s[2], s[3]);
+  __syncthreads();
+  if (threadIdx.x < 2 * G) {   // fixed-order sum of the workgroup's contributions to (group, which)
+    const int g = threadIdx.x >> 1, which = threadIdx.x & 1;
+    const int c_lo = (g * cpg) >> 3, c_hi = ((g + 1) * cpg - 1) >> 3;
+    float acc = 0.f;
+    for (int q = 0; q < rp; ++q)
+      for (int c = c_lo; c <= c_hi; ++c) {
+        const int k = ((c * 8) / cpg == g) ? 0 : 1;   // the column starts inside g, or inside g - 1 and ends in g
+        acc += sp[(q * cols + c) * 4 + k * 2 + which];
+      }
+    part[(((long)b * nslab + slab) * G + g) * 2 + which] = acc;   // slab-major: a piece's 64 sums are two cache lines
+  }
+}
+
 // pass 2, second form (maps above 32x32).  A thread owns ONE 16-byte chunk column, so gamma / beta and the statistics of the (at
 // most two) groups its 8 channels belong to are fetched once instead of 2-4 scalar loads per element, and it keeps GNA_U pixel
 // rows in flight (the first form issues one chunk per thread and retires: at 21-42 MB per launch the kernel spent its time ramping
@@ -188,17 +283,51 @@ constexpr int GNA_U = 4;
 template <int MODE>
 __global__ void gn_apply2_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, const bf16_t* __restrict__ gamma,
                                  const bf16_t* __restrict__ beta, const float* __restrict__ stats,
-                                 const float* __restrict__ dstats, const float* __restrict__ part, int nsplit, float inv_count,
+                                 const float* __restrict__ dstats, const float* __restrict__ part, int nsplit, int slab_major,
+                                 float inv_count,
                                  float eps, float* __restrict__ stats_out, int HW, int C, int rows_per_slab, int silu,
                                  const bf16_t* __restrict__ dres, bf16_t* __restrict__ out) {
   const int cols = C >> 3, cpg = C / G;
   const int rp = blockDim.x / cols;
   const int col = threadIdx.x % cols, rr = threadIdx.x / cols;
-  if (rr >= rp) return;
   const int b = blockIdx.y, slab = blockIdx.x;
   const int c0 = col * 8;
   const int g0 = c0 / cpg, g1 = (c0 + 7) / cpg;   // cpg >= 8 is not required: with cpg < 8 the callers use the first form
   const int split = (g0 + 1) * cpg - c0;          // channels j < split belong to g0, the rest to g1
+  // Piece sums (gn_fused_kernel<MODE, 1>: <= 8 pieces; gn_rowstats_kernel: up to 128 slabs): the workgroup adds them ONCE,
+  // cooperatively -- (group, which) = t & 63, pieces t >> 6, t >> 6 + nq, ... with eight loads in flight, then the nq partial sums in
+  // order -- instead of every thread walking the pieces of its two groups one L2 round trip at a time.  Fixed order: deterministic.
+  __shared__ float gn_red[8][2 * G];
+  __shared__ float gn_tot[2 * G];
+  if (part != nullptr) {
+    const int t = threadIdx.x;
+    int nq = blockDim.x >> 6;
+    nq = nq > 8 ? 8 : (nq < 1 ? 1 : nq);
+    if (t < nq * 64 && t < (int)blockDim.x) {
+      const int gw = t & 63, q0 = t >> 6;
+      // group-major [B][G][nsplit][2] (gn_fused_kernel<MODE, 1>) or slab-major [B][nsplit][G][2] (gn_rowstats_kernel)
+      const float* src = slab_major ? part + (long)b * nsplit * (2 * G) + gw : part + ((long)b * G + (gw >> 1)) * nsplit * 2 + (gw & 1);
+      const long qs = slab_major ? 2 * G : 2;
+      float acc = 0.f;
+      for (int q = q0; q < nsplit; q += nq * 8) {
+        float u[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u[i] = src[(long)min(q + i * nq, nsplit - 1) * qs];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (q + i * nq < nsplit) acc += u[i];
+      }
+      gn_red[q0][gw] = acc;
+    }
+    __syncthreads();
+    if (t < 2 * G) {
+      float a = 0.f;
+      for (int q = 0; q < nq; ++q) a += gn_red[q][t];
+      gn_tot[t] = a;
+    }
+    __syncthreads();
+  }
+  if (rr >= rp) return;
   float ga[8], be[8];
   unpack8(*reinterpret_cast<const uint4*>(gamma + c0), ga);
   unpack8(*reinterpret_cast<const uint4*>(beta + c0), be);
@@ -207,11 +336,9 @@ __global__ void gn_apply2_kernel(const bf16_t* __restrict__ x, const bf16_t* __r
   for (int k = 0; k < 2; ++k) {
     const int g = k ? g1 : g0;
     float a0 = 0.f, a1 = 0.f;
-    if (part != nullptr) {   // piece sums of gn_fused_kernel<MODE, 1>, added in its fixed order
-      for (int q = 0; q < nsplit; ++q) {
-        a0 += part[(((long)b * G + g) * nsplit + q) * 2 + 0];
-        a1 += part[(((long)b * G + g) * nsplit + q) * 2 + 1];
-      }
+    if (part != nullptr) {
+      a0 = gn_tot[2 * g + 0];
+      a1 = gn_tot[2 * g + 1];
     }
     if (MODE == 0 && part != nullptr) {
       mu2[k] = a0 * inv_count;
@@ -595,7 +722,11 @@ inline int gn_geometry(int HW, int C, int* threads, int* rows_per_slab) {
   if (rp < 1) rp = 1;
   if (rp > HW) rp = HW;
   *threads = cols * rp;
-  int nslab = (HW + 31) / 32;  // ~32 pixel rows per slab
+  // ~32 pixel rows per slab; 64 up to 320 channels (12 rows in flight per workgroup: two rounds of GNA_U loads instead of one short
+  // one -- 64x64x320: 21.3 -> 18.3 us forward at 8 samples, 14.3 -> 12.8 at 4; neutral or slower at 640 / 960).  Tuning hook.
+  static const int slab_env = getenv("AQL_GN_SLAB_ROWS") ? atoi(getenv("AQL_GN_SLAB_ROWS")) : 0;
+  const int slab_rows = slab_env > 0 ? slab_env : (C <= 320 ? 64 : 32);
+  int nslab = (HW + slab_rows - 1) / slab_rows;
   if (nslab > 128) nslab = 128;
   if (nslab < 1) nslab = 1;
   *rows_per_slab = (HW + nslab - 1) / nslab;
@@ -618,6 +749,23 @@ inline bool gn_use_fused(int C, int HW, bool bwd = false) {
   if (max_hw > 0) return HW <= max_hw;
   if (bwd && HW > 512 && C <= 960 && C / G >= 8) return false;
   return HW <= 2048;
+}
+
+// Coalesced statistics pass (gn_rowstats_kernel) + gn_apply2_kernel for every map the one-launch form does not take, forward and
+// backward: AQL_GN_ROWSTATS=0 restores the per-(sample, group, piece) first pass (gn_split), =n sets the slab count of the pass.
+// Measured (tools/tune_gn.py, profiles/r03_gn_rowstats.txt): 64x64 forward at 8 samples 25.6 -> 21.1 us (320 channels), 32.5 -> 28.4 (640),
+// 40.3 -> 36.6 (960); backward at 4 samples 23.7 -> 17.3, 30.4 -> 26.1, 38.5 -> 34.4; 32x32 backward: 4 samples 10.3 -> 11.5 (kept on the
+// old form), 8 samples 15.1 -> 12.1.  Slabs: ~512 workgroups in all (128 slabs at 4 samples, 64 at 8).
+inline int gn_rowstats_slabs(int B, int HW, int C, int nslab_apply) {
+  static const int en = getenv("AQL_GN_ROWSTATS") ? atoi(getenv("AQL_GN_ROWSTATS")) : 1;
+  if (en == 0 || (C / G) < 8 || C / 8 > 512) return 0;
+  if (en == 1 && HW <= 1024 && B < 8) return 0;
+  int ns = en > 1 ? en : 512 / (B > 0 ? B : 1);
+  if (ns < 32) ns = 32;
+  if (ns > 128) ns = 128;
+  if (ns > nslab_apply && en == 1) ns = nslab_apply;
+  if (ns > HW) ns = HW;
+  return ns;
 }
 
 // larger maps, forward only: two launches of the same kernel with the pixel range of every (sample, group) cut into pieces
@@ -655,12 +803,21 @@ extern "C" int aql_groupnorm_silu_fwd(const bf16_t* x, int B, int HW, int C, con
   int threads, rps;
   const int nslab = gn_geometry(HW, C, &threads, &rps);
   const bool a2_ok = apply2 && (C / G) >= 8;
+  if (const int nss = a2_ok ? gn_rowstats_slabs(B, HW, C, nslab) : 0) {
+    const int rps_s = (HW + nss - 1) / nss, ns = (HW + rps_s - 1) / rps_s;
+    hipLaunchKernelGGL(gn_rowstats_kernel<0>, dim3(ns, B), dim3(threads), threads * 16, stream, x, nullptr, gamma, beta, nullptr, HW, C,
+                       rps_s, silu, scratch);
+    hipLaunchKernelGGL(gn_apply2_kernel<0>, dim3(nslab, B), dim3(threads), 0, stream, x, nullptr, gamma, beta, nullptr, nullptr,
+                       scratch, ns, 1, 1.f / ((float)HW * (C / G)), eps, stats, HW, C, rps, silu, nullptr, y);
+    AQL_CHECK_LAUNCH("aql_groupnorm_silu_fwd");
+    return AQL_OK;
+  }
   if (const int ns = gn_split(C, HW)) {
     hipLaunchKernelGGL((gn_fused_kernel<0, 1>), dim3(B * G * ns), dim3(GNF_THREADS), 0, stream, x, nullptr, gamma, beta, stats,
                        HW, C, eps, silu, nullptr, y, ns, scratch);
     if (a2_ok)   // coalesced second pass that sums the piece statistics itself
       hipLaunchKernelGGL(gn_apply2_kernel<0>, dim3(nslab, B), dim3(threads), 0, stream, x, nullptr, gamma, beta, nullptr, nullptr,
-                         scratch, ns, 1.f / ((float)HW * (C / G)), eps, stats, HW, C, rps, silu, nullptr, y);
+                         scratch, ns, 0, 1.f / ((float)HW * (C / G)), eps, stats, HW, C, rps, silu, nullptr, y);
     else
       hipLaunchKernelGGL((gn_fused_kernel<0, 2>), dim3(B * G * ns), dim3(GNF_THREADS), 0, stream, x, nullptr, gamma, beta, stats,
                          HW, C, eps, silu, nullptr, y, ns, scratch);
@@ -673,7 +830,7 @@ extern "C" int aql_groupnorm_silu_fwd(const bf16_t* x, int B, int HW, int C, con
                      1.f / ((float)HW * (C / G)), eps, stats);
   if (a2_ok) {
     hipLaunchKernelGGL(gn_apply2_kernel<0>, dim3(nslab, B), dim3(threads), 0, stream, x, nullptr, gamma, beta, stats, nullptr,
-                       nullptr, 0, 0.f, 0.f, nullptr, HW, C, rps, silu, nullptr, y);
+                       nullptr, 0, 0, 0.f, 0.f, nullptr, HW, C, rps, silu, nullptr, y);
     AQL_CHECK_LAUNCH("aql_groupnorm_silu_fwd");
     return AQL_OK;
   }
@@ -708,10 +865,19 @@ extern "C" int aql_groupnorm_silu_bwd(const bf16_t* x, const bf16_t* dy, int B, 
   // measured (tools/tune_gn.py, 64x64): B=4: 25.1 / 32.7 / 40.2 us against 29.2 / 38.8 / 47.9 at 320 / 640 / 960 channels;
   // B=8: 44.9 / 57.2 / 73.1 against 41.3 / 58.7 / 75.3 -- the split form loses only with > 768 workgroups of 20-byte segments
   if (ns_b && (long)B * G * ns_b > 768 && C < 640 && bwd_split == 1) ns_b = 0;
+  if (const int nss = (apply2s && (C / G) >= 8) ? gn_rowstats_slabs(B, HW, C, nslab) : 0) {
+    const int rps_s = (HW + nss - 1) / nss, ns = (HW + rps_s - 1) / rps_s;
+    hipLaunchKernelGGL(gn_rowstats_kernel<1>, dim3(ns, B), dim3(threads), threads * 16, stream, x, dy, gamma, beta, stats, HW, C, rps_s,
+                       silu, scratch);
+    hipLaunchKernelGGL(gn_apply2_kernel<1>, dim3(nslab, B), dim3(threads), 0, stream, x, dy, gamma, beta, stats, nullptr, scratch, ns, 1,
+                       1.f / ((float)HW * (C / G)), 0.f, nullptr, HW, C, rps, silu, dres, dx);
+    AQL_CHECK_LAUNCH("aql_groupnorm_silu_bwd");
+    return AQL_OK;
+  }
   if (const int ns = ns_b) {
     hipLaunchKernelGGL((gn_fused_kernel<1, 1>), dim3(B * G * ns), dim3(GNF_THREADS), 0, stream, x, dy, gamma, beta,
                        const_cast<float*>(stats), HW, C, 0.f, silu, nullptr, dx, ns, scratch);
-    hipLaunchKernelGGL(gn_apply2_kernel<1>, dim3(nslab, B), dim3(threads), 0, stream, x, dy, gamma, beta, stats, nullptr, scratch, ns,
+    hipLaunchKernelGGL(gn_apply2_kernel<1>, dim3(nslab, B), dim3(threads), 0, stream, x, dy, gamma, beta, stats, nullptr, scratch, ns, 0,
                        1.f / ((float)HW * (C / G)), 0.f, nullptr, HW, C, rps, silu, dres, dx);
     AQL_CHECK_LAUNCH("aql_groupnorm_silu_bwd");
     return AQL_OK;
@@ -723,7 +889,7 @@ extern "C" int aql_groupnorm_silu_bwd(const bf16_t* x, const bf16_t* dy, int B, 
                      1.f / ((float)HW * (C / G)), 0.f, dstats);
   static const int apply2 = getenv("AQL_GN_APPLY2") ? atoi(getenv("AQL_GN_APPLY2")) : 1;   // A/B hook
   if (apply2 && (C / G) >= 8) {
-    hipLaunchKernelGGL(gn_apply2_kernel<1>, dim3(nslab, B), dim3(threads), 0, stream, x, dy, gamma, beta, stats, dstats, nullptr, 0,
+    hipLaunchKernelGGL(gn_apply2_kernel<1>, dim3(nslab, B), dim3(threads), 0, stream, x, dy, gamma, beta, stats, dstats, nullptr, 0, 0,
                        0.f, 0.f, nullptr, HW, C, rps, silu, dres, dx);
     AQL_CHECK_LAUNCH("aql_groupnorm_silu_bwd");
     return AQL_OK;
