@@ -844,8 +844,278 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const AttnArgs a) 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ short key side (cross-attention)
+// Text-state attention has Nk = 77 keys (original_unet.py:688-704 with encoder_hidden_states): negligible FLOPs, and in the streaming
+// kernels above every workgroup staged the same two K/V tiles behind four barriers, handled one 256-row Q block and retired -- 21 us per
+// launch at the 64x64 level for 42 MB of Q / O traffic, 14 us at 16x16 for 2.6 MB (profiles/r03_step_sequence.txt).  Here the whole key
+// side (<= CTX_ROWS rows) is RESIDENT: K and V are staged once into two LDS images, ONE barrier, and then the four wavefronts run free,
+// each walking 32-row owner blocks of the workgroup's Q range with the next block's Q (and dO / O) fragments already in flight.  The
+// softmax is the plain two-pass one (all 80 scores of a row are in registers: no running maximum, no rescale of the accumulator).
+constexpr int CTX_ROWS = 80;   // five 16-row fragments
+constexpr int CTX_NSF = CTX_ROWS / 16;
+
+template <int DH>
+__device__ __forceinline__ void ctx_stage(char* img, const bf16_t* g, long ld, int nrows, int d, int tid) {
+  constexpr int CPR = DH / 8;
+  constexpr int NIT = (CTX_ROWS * CPR + 255) / 256;
+  uint4 v[NIT];
+  // every load first (unconditional, clamped address, masked after): one round trip for the whole image instead of NIT
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int id = tid + it * 256;
+    const int row = id / CPR, c = id - row * CPR;
+    const bool ok = (id < CTX_ROWS * CPR) & (row < nrows) & (c * 8 < d);
+    const uint4 x = *reinterpret_cast<const uint4*>(g + (ok ? (long)row * ld + c * 8 : 0));
+    v[it] = mask4(x, ok);   // rows >= nrows and the d..DH padding: zero
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int id = tid + it * 256;
+    const int row = id / CPR, c = id - row * CPR;
+    if (id < CTX_ROWS * CPR) *reinterpret_cast<uint4*>(img + tile_off<DH>(row, c)) = v[it];
+  }
+}
+
+// acc[sf][of] = image rows sf*16.. (A) x owner frag of (B), all CTX_NSF fragments of the resident image
+template <int DH>
+__device__ __forceinline__ void ctx_s_product(f32x4_t (&acc)[CTX_NSF][2], const char* img, const bf16x8_t (&own)[2][DH / 32], int lane) {
+#pragma unroll
+  for (int s = 0; s < DH / 32; ++s) {
+    bf16x8_t a[CTX_NSF];
+#pragma unroll
+    for (int sf = 0; sf < CTX_NSF; ++sf)
+      a[sf] = *reinterpret_cast<const bf16x8_t*>(img + tile_off<DH>(sf * 16 + (lane & 15), s * 4 + (lane >> 4)));
+#pragma unroll
+    for (int sf = 0; sf < CTX_NSF; ++sf)
+#pragma unroll
+      for (int of = 0; of < 2; ++of) {
+        if (s == 0) acc[sf][of] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[sf], own[of][s], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        else acc[sf][of] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[sf], own[of][s], acc[sf][of], 0, 0, 0);
+      }
+  }
+}
+
+// p (fp32, rows = key sf*16 + g*4 + reg) -> B fragments of the three 32-key steps; the second half of step 2 (keys 80..95) is zero
+__device__ __forceinline__ void ctx_pack_p(bf16x8_t (&pb)[3][2], const f32x4_t (&p)[CTX_NSF][2]) {
+#pragma unroll
+  for (int s2 = 0; s2 < 3; ++s2)
+#pragma unroll
+    for (int of = 0; of < 2; ++of) {
+      uint4 v;
+      v.x = pack_bf16x2(p[2 * s2][of][0], p[2 * s2][of][1]);
+      v.y = pack_bf16x2(p[2 * s2][of][2], p[2 * s2][of][3]);
+      if (2 * s2 + 1 < CTX_NSF) {
+        v.z = pack_bf16x2(p[(2 * s2 + 1) % CTX_NSF][of][0], p[(2 * s2 + 1) % CTX_NSF][of][1]);
+        v.w = pack_bf16x2(p[(2 * s2 + 1) % CTX_NSF][of][2], p[(2 * s2 + 1) % CTX_NSF][of][3]);
+      } else {
+        v.z = 0u;
+        v.w = 0u;
+      }
+      pb[s2][of] = *reinterpret_cast<bf16x8_t*>(&v);
+    }
+}
+
+// acc[df][of] += (image)^T frag df (A) x pb (B) over the 80 resident rows (see t_product; the missing rows 80..95 of step 2 re-read
+// rows 64..79 -- finite -- against zero probabilities)
 template <int DH, int DV>
-int launch_fwd(const AttnArgs& a, hipStream_t st) {
+__device__ __forceinline__ void ctx_t_product(f32x4_t (&acc)[DV / 16][2], const char* img, const bf16x8_t (&pb)[3][2], int lane) {
+  const int p = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int s2 = 0; s2 < 3; ++s2) {
+    const int row = s2 * 32 + g * 4 + (p >> 2);
+#pragma unroll
+    for (int df = 0; df < DV / 16; ++df) {
+      const char* base = img + tile_off<DH>(row, df * 2 + ((p & 3) >> 1)) + (p & 1) * 8;
+      const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3)))*)(base));
+      const v4s_t hi = s2 < 2 ? __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                    (v4s_t __attribute__((address_space(3)))*)(base + 16 * RowPitch<DH>::value))
+                              : lo;
+      const bf16x8_t a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int of = 0; of < 2; ++of)
+        acc[df][of] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb[s2][of], acc[df][of], 0, 0, 0);
+    }
+  }
+}
+
+// grid (ceil(Nq / (128 * a.qsplit)), H, B): a.qsplit = owner blocks per wavefront (the forward / dQ kernels reuse the field), <= NB.
+// The Q fragments of ALL the wavefront's blocks are requested before the barrier (16 registers per block at d = 40): with one block
+// of look-ahead a wavefront had 2.5 KB in flight, 20 KB per CU, and the launch ran at the latency-bound 2.2 TB/s.
+template <int DH>
+struct CtxNB {
+  static constexpr int fwd = DH <= 64 ? 4 : (DH <= 96 ? 2 : 1);
+  static constexpr int bwd = DH <= 64 ? 2 : 1;
+};
+template <int DH, int DV>
+__global__ __launch_bounds__(256, (DH <= 96 ? 2 : 1)) void attn_ctx_fwd_kernel(const AttnArgs a) {
+  constexpr int IMG = CTX_ROWS * RowPitch<DH>::value;
+  constexpr int NB = CtxNB<DH>::fwd;
+  __shared__ __attribute__((aligned(1024))) char sK[IMG];
+  __shared__ __attribute__((aligned(1024))) char sV[IMG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bx, h, b;
+  attn_block(bx, h, b);
+  const int nb = a.qsplit;
+  const int wg_q0 = bx * (4 * OWN * nb);
+  const bf16_t* qp = a.q + (long)b * a.Nq * a.ldq + h * a.d;
+  bf16x8_t qf[NB][2][DH / 32];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+    if (i < nb) load_owner<DH>(qf[i], qp, a.ldq, wg_q0 + (i * 4 + wave) * OWN, a.Nq, a.d, lane);
+  ctx_stage<DH>(sK, a.k + (long)b * a.Nk * a.ldk + h * a.d, a.ldk, a.Nk, a.d, tid);
+  ctx_stage<DH>(sV, a.v + (long)b * a.Nk * a.ldv + h * a.d, a.ldv, a.Nk, a.d, tid);
+  __syncthreads();
+  const float c = a.scale * LOG2E;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int q0 = wg_q0 + (i * 4 + wave) * OWN;
+    if (i >= nb || q0 >= a.Nq) break;   // wave-uniform
+    f32x4_t s[CTX_NSF][2];
+    ctx_s_product<DH>(s, sK, qf[i], lane);
+    float inv[2], lsev[2];
+#pragma unroll
+    for (int of = 0; of < 2; ++of) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int sf = 0; sf < CTX_NSF; ++sf)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (sf * 16 + (lane >> 4) * 4 + e >= a.Nk) s[sf][of][e] = -INFINITY;
+          mx = fmaxf(mx, s[sf][of][e]);
+        }
+      mx = group4_max(mx);
+      const float mxc = mx * c;
+      float rs = 0.f;
+#pragma unroll
+      for (int sf = 0; sf < CTX_NSF; ++sf)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sf][of][e], c, -mxc));
+          s[sf][of][e] = p;
+          rs += p;
+        }
+      rs = group4_sum(rs);
+      inv[of] = 1.f / rs;
+      lsev[of] = mx * a.scale + logf(rs);
+    }
+    bf16x8_t pb[3][2];
+    ctx_pack_p(pb, s);
+    f32x4_t o[DV / 16][2];
+    zero_acc(o);
+    ctx_t_product<DH, DV>(o, sV, pb, lane);
+    store_t<DV>(o, a.out + (long)b * a.Nq * a.ldo + h * a.d, a.ldo, q0, a.Nq, a.d, inv, lane);
+    if ((lane >> 4) == 0) {
+#pragma unroll
+      for (int of = 0; of < 2; ++of) {
+        const int row = q0 + of * 16 + (lane & 15);
+        if (row < a.Nq) a.lse[((long)b * a.H + h) * a.Nq + row] = lsev[of];
+      }
+    }
+  }
+}
+
+// dQ (and delta) with the key side resident: owner = Q, dO (and O for delta)
+template <int DH, int DV>
+__global__ __launch_bounds__(256, (DH <= 96 ? 2 : 1)) void attn_ctx_dq_kernel(const AttnArgs a) {
+  constexpr int IMG = CTX_ROWS * RowPitch<DH>::value;
+  __shared__ __attribute__((aligned(1024))) char sK[IMG];
+  __shared__ __attribute__((aligned(1024))) char sV[IMG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bx, h, b;
+  attn_block(bx, h, b);
+  const int nb = a.qsplit;
+  const int wg_q0 = bx * (4 * OWN * nb);
+  const bf16_t* qp = a.q + (long)b * a.Nq * a.ldq + h * a.d;
+  const bf16_t* dop = a.dout + (long)b * a.Nq * a.ldo + h * a.d;
+  const bf16_t* op = a.o + (long)b * a.Nq * a.ldo + h * a.d;
+  constexpr int NB = CtxNB<DH>::bwd;
+  bf16x8_t qfa[NB][2][DH / 32], dofa[NB][2][DH / 32], ofa[NB][2][DH / 32];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+    if (i < nb) {   // every operand of every block of this wavefront is in flight before the barrier
+      const int q0 = wg_q0 + (i * 4 + wave) * OWN;
+      load_owner<DH>(qfa[i], qp, a.ldq, q0, a.Nq, a.d, lane);
+      load_owner<DH>(dofa[i], dop, a.ldo, q0, a.Nq, a.d, lane);
+      load_owner<DH>(ofa[i], op, a.ldo, q0, a.Nq, a.d, lane);
+    }
+  ctx_stage<DH>(sK, a.k + (long)b * a.Nk * a.ldk + h * a.d, a.ldk, a.Nk, a.d, tid);
+  ctx_stage<DH>(sV, a.v + (long)b * a.Nk * a.ldv + h * a.d, a.ldv, a.Nk, a.d, tid);
+  __syncthreads();
+  const float c = a.scale * LOG2E;
+  const long ld_dq = (long)a.H * a.d;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int q0 = wg_q0 + (i * 4 + wave) * OWN;
+    if (i >= nb || q0 >= a.Nq) break;   // wave-uniform
+    const bf16x8_t (&qf)[2][DH / 32] = qfa[i];
+    const bf16x8_t (&dof)[2][DH / 32] = dofa[i];
+    float lse2[2], dl[2];
+    {
+      const bf16x8_t (&ofr)[2][DH / 32] = ofa[i];
+#pragma unroll
+      for (int of = 0; of < 2; ++of) {
+        float acc = 0.f;
+#pragma unroll
+        for (int x = 0; x < DH / 32; ++x) {
+          const uint4 u = *reinterpret_cast<const uint4*>(&dof[of][x]);
+          const uint4 y = *reinterpret_cast<const uint4*>(&ofr[of][x]);
+          acc += bf16lo(u.x) * bf16lo(y.x) + bf16hi(u.x) * bf16hi(y.x) + bf16lo(u.y) * bf16lo(y.y) + bf16hi(u.y) * bf16hi(y.y) +
+                 bf16lo(u.z) * bf16lo(y.z) + bf16hi(u.z) * bf16hi(y.z) + bf16lo(u.w) * bf16lo(y.w) + bf16hi(u.w) * bf16hi(y.w);
+        }
+        dl[of] = group4_sum(acc);
+      }
+    }
+#pragma unroll
+    for (int of = 0; of < 2; ++of) {
+      const int row = q0 + of * 16 + (lane & 15);
+      const bool ok = row < a.Nq;
+      lse2[of] = ok ? a.lse[((long)b * a.H + h) * a.Nq + row] * LOG2E : INFINITY;
+      if (ok && (lane >> 4) == 0) a.delta[((long)b * a.H + h) * a.Nq + row] = dl[of];
+    }
+    f32x4_t s[CTX_NSF][2], dp[CTX_NSF][2];
+    ctx_s_product<DH>(s, sK, qf, lane);
+    ctx_s_product<DH>(dp, sV, dof, lane);
+#pragma unroll
+    for (int sf = 0; sf < CTX_NSF; ++sf)
+#pragma unroll
+      for (int of = 0; of < 2; ++of)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sf][of][e], c, -lse2[of]));
+          const bool live = sf * 16 + (lane >> 4) * 4 + e < a.Nk;   // zero key rows past Nk score 0, not -inf: drop them
+          s[sf][of][e] = live ? p * (dp[sf][of][e] - dl[of]) : 0.f;
+        }
+    bf16x8_t pb[3][2];
+    ctx_pack_p(pb, s);
+    f32x4_t dq[DV / 16][2];
+    zero_acc(dq);
+    ctx_t_product<DH, DV>(dq, sK, pb, lane);
+    const float mq[2] = {a.scale, a.scale};
+    store_t<DV>(dq, a.dq + (long)b * a.Nq * ld_dq + h * a.d, ld_dq, q0, a.Nq, a.d, mq, lane);
+  }
+}
+
+// owner blocks per wavefront: enough workgroups for two per CU, at most `nbmax` (the kernel's register budget) blocks
+inline int ctx_blocks(const AttnArgs& a, int nbmax) {
+  static const int force = getenv("AQL_ATTN_CTX_NB") ? atoi(getenv("AQL_ATTN_CTX_NB")) : 0;   // tuning hook
+  const long wgs1 = (long)aql_cdiv(a.Nq, 4 * OWN) * a.H * a.B;
+  int nb = force > 0 ? force : (int)(wgs1 / 512);
+  return nb < 1 ? 1 : (nb > nbmax ? nbmax : nb);
+}
+inline bool ctx_on(const AttnArgs& a) {
+  static const int en = getenv("AQL_ATTN_CTX") ? atoi(getenv("AQL_ATTN_CTX")) : 1;   // A/B hook: 0 = the streaming kernels
+  return en && a.Nk <= CTX_ROWS;
+}
+
+template <int DH, int DV>
+int launch_fwd(const AttnArgs& a0, hipStream_t st) {
+  if (ctx_on(a0)) {
+    AttnArgs a = a0;
+    a.qsplit = ctx_blocks(a, CtxNB<DH>::fwd);
+    hipLaunchKernelGGL((attn_ctx_fwd_kernel<DH, DV>), dim3(aql_cdiv(a.Nq, 4 * OWN * a.qsplit), a.H, a.B), dim3(256), 0, st, a);
+    return 0;
+  }
+  const AttnArgs& a = a0;
   static const int force = getenv("AQL_ATTN_NOF") ? atoi(getenv("AQL_ATTN_NOF")) : 0;  // tuning hook
   static const int ones = getenv("AQL_ATTN_ONES") ? atoi(getenv("AQL_ATTN_ONES")) : 1;  // tuning hook
   if constexpr (DH <= 64) {
@@ -866,7 +1136,13 @@ int launch_fwd(const AttnArgs& a, hipStream_t st) {
 }
 template <int DH, int DV>
 int launch_bwd(const AttnArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL((attn_dq_kernel<DH, DV>), dim3(aql_cdiv(a.Nq, 4 * OWN), a.H, a.B), dim3(256), 0, st, a);
+  if (ctx_on(a)) {
+    AttnArgs c = a;
+    c.qsplit = ctx_blocks(a, CtxNB<DH>::bwd);
+    hipLaunchKernelGGL((attn_ctx_dq_kernel<DH, DV>), dim3(aql_cdiv(a.Nq, 4 * OWN * c.qsplit), a.H, a.B), dim3(256), 0, st, c);
+  } else {
+    hipLaunchKernelGGL((attn_dq_kernel<DH, DV>), dim3(aql_cdiv(a.Nq, 4 * OWN), a.H, a.B), dim3(256), 0, st, a);
+  }
   hipLaunchKernelGGL((attn_dkv_kernel<DH, DV>), dim3(aql_cdiv(a.Nk, 4 * OWN), a.H, a.B * a.qsplit), dim3(256), 0, st, a);
   if (a.qsplit > 1) {
     const long n = 2L * a.B * a.H * a.Nk * (a.d / 4);

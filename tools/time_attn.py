@@ -23,17 +23,21 @@ out = []
 SHAPES = ((4, 8, 4096, 40), (8, 8, 4096, 40), (4, 8, 1024, 80), (8, 8, 1024, 80))
 if os.environ.get("SMALL"):   # the low-resolution levels: 16x16 (d = 160) and 8x8
     SHAPES = ((4, 8, 256, 160), (8, 8, 256, 160), (4, 8, 64, 160), (8, 8, 64, 160), (4, 8, 1024, 80), (8, 8, 1024, 80))
+NK = int(os.environ.get("CTX", "0"))   # CTX=77: the text-state (cross-attention) shapes, forward at 8 samples, backward at 4
+if NK:
+    SHAPES = ((8, 8, 4096, 40), (4, 8, 4096, 40), (8, 8, 1024, 80), (4, 8, 1024, 80), (8, 8, 256, 160), (4, 8, 256, 160), (8, 8, 64, 160), (4, 8, 64, 160))
 for B, H, N, d in SHAPES:
     C = H * d
-    q, k, v, do = (torch.randn(B, N, C, device="cuda", dtype=torch.bfloat16) for _ in range(4))
+    q, do = (torch.randn(B, N, C, device="cuda", dtype=torch.bfloat16) for _ in range(2))
+    k, v = (torch.randn(B, NK or N, C, device="cuda", dtype=torch.bfloat16) for _ in range(2))
     o = torch.empty_like(q); lse = torch.empty(B, H, N, device="cuda"); delta = torch.empty_like(lse)
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     ws = torch.empty(16 << 20, device="cuda"); sc = float(d ** -0.5); st = L.stream_ptr
-    fwd = lambda: L.call("aql_sdpa_fwd", L.ptr(q), C, L.ptr(k), C, L.ptr(v), C, B, H, N, N, d, sc, L.ptr(o), C, L.ptr(lse), st())
-    bwd = lambda: L.call("aql_sdpa_bwd", L.ptr(q), C, L.ptr(k), C, L.ptr(v), C, L.ptr(o), L.ptr(do), C, L.ptr(lse), L.ptr(delta), B, H, N, N,
+    fwd = lambda: L.call("aql_sdpa_fwd", L.ptr(q), C, L.ptr(k), C, L.ptr(v), C, B, H, N, NK or N, d, sc, L.ptr(o), C, L.ptr(lse), st())
+    bwd = lambda: L.call("aql_sdpa_bwd", L.ptr(q), C, L.ptr(k), C, L.ptr(v), C, L.ptr(o), L.ptr(do), C, L.ptr(lse), L.ptr(delta), B, H, N, NK or N,
                          d, sc, L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(ws), ws.numel() * 4, st())
     tf = graph_time(fwd)
-    fl = 4.0 * B * H * N * N * d
+    fl = 4.0 * B * H * N * (NK or N) * d
     line = f"B={B} N={N} d={d}: fwd {tf:7.1f} us ({fl / tf / 1e6:6.0f} TF/s = {fl / tf / 1e6 / 2500:.3f})"
     if os.environ.get("BWD"):
         tb = graph_time(bwd)
