@@ -94,19 +94,29 @@ if "gemm" in what:
 
 if "conv" in what:
     print("# 3x3 conv, stride 1, pad 1, channels-last bf16; us per launch")
-    for Bn, H, Ci, Co in ((2 * B, 64, 320, 320), (B, 64, 320, 320), (2 * B, 32, 640, 640), (B, 32, 640, 640), (2 * B, 16, 1280, 1280),
-                          (B, 16, 1280, 1280), (2 * B, 8, 1280, 1280), (2 * B, 64, 640, 320), (2 * B, 32, 1280, 640), (2 * B, 16, 2560, 1280)):
+    CONV = ((2 * B, 64, 320, 320), (B, 64, 320, 320), (2 * B, 32, 640, 640), (B, 32, 640, 640), (2 * B, 16, 1280, 1280),
+                          (B, 16, 1280, 1280), (2 * B, 8, 1280, 1280), (2 * B, 64, 640, 320), (2 * B, 32, 1280, 640), (2 * B, 16, 2560, 1280))
+    if os.environ.get("CONV_SHAPES"):   # "B,H,Ci,Co;..." -- tuning sweeps (AQL_SPLITS / AQL_TILE / AQL_W) on a few shapes
+        CONV = tuple(tuple(int(v) for v in t.split(",")) for t in os.environ["CONV_SHAPES"].split(";"))
+    for Bn, H, Ci, Co in CONV:
         xs = [rnd(Bn, Ci, H, H).contiguous(memory_format=torch.channels_last) for _ in range(3)]
 
+        _hot = {}
+
         def mkc(i, form):
+            if os.environ.get("HOT") and (form in _hot):
+                return _hot[form]
             x = xs[i % 3]
             w = rnd(Co, Ci, 3, 3) * 0.02
+            if os.environ.get("HOT") and i > 0:   # every launch reads the SAME weights (L2 / MALL resident): how much of the time is the cold panel?
+                return mkc(0, form)
             if form == "ours":
                 p = ops.PackedConv3x3(w, torch.zeros(Co, device=dev, dtype=torch.bfloat16), 1)
 
                 def f():
                     with torch.no_grad():
                         return ops.conv3x3(x, p)
+                _hot[form] = f
                 return f
             wc = w.contiguous(memory_format=torch.channels_last)
             return lambda: F.conv2d(x, wc, None, 1, 1)
@@ -116,7 +126,7 @@ if "conv" in what:
             print("ours failed:", repr(e)[:200])
             t_o = float("nan")
         try:
-            t_v = graph_time([mkc(i, "vendor") for i in range(6)])
+            t_v = float("nan") if os.environ.get("NO_VENDOR") else graph_time([mkc(i, "vendor") for i in range(6)])
         except Exception as e:  # noqa: BLE001
             print("vendor failed:", repr(e)[:200])
             t_v = float("nan")

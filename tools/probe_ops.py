@@ -21,7 +21,9 @@ def timeit(fn, n=10):
 # GroupNorm + SiLU
 for (B, C, H, W, silu, eps) in [(2, 320, 64, 64, 1, 1e-5), (2, 640, 16, 16, 0, 1e-6), (3, 2560, 8, 8, 1, 1e-5), (2, 32, 4, 4, 1, 1e-5), (2, 960, 32, 32, 1, 1e-5),
                                 # maps above 32x32: the row-slab form (ragged slabs, non-square, VAE-like widths)
-                                (3, 640, 64, 64, 1, 1e-5), (2, 960, 64, 64, 0, 1e-6), (1, 320, 72, 88, 1, 1e-5), (1, 128, 160, 96, 1, 1e-6)]:
+                                (3, 640, 64, 64, 1, 1e-5), (2, 960, 64, 64, 0, 1e-6), (1, 320, 72, 88, 1, 1e-5), (1, 128, 160, 96, 1, 1e-6),
+                                # whole-row statistics pass (gn_rowstats_kernel): 8 samples (64 slabs), 32x32 backward at 8 samples, ragged last slab
+                                (8, 320, 64, 64, 1, 1e-5), (8, 640, 32, 32, 1, 1e-5), (5, 960, 40, 52, 1, 1e-5)]:
     x = (rnd(B, C, H, W) * 2 + 0.5).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     g = rnd(C) * 0.5 + 1; b = rnd(C) * 0.1
     y = ops.groupnorm_silu(x, g, b, eps, silu)
@@ -60,7 +62,9 @@ def attn_ref(q, k, v, H):
     return o.transpose(1, 2).reshape(B, Nq, C)
 for (B, H, Nq, Nk, d) in [(2, 8, 256, 256, 40), (1, 8, 1024, 1024, 80), (2, 8, 64, 64, 160), (2, 8, 256, 77, 40), (1, 8, 100, 77, 160), (1, 2, 200, 300, 64), (1, 8, 4096, 4096, 40),
                            # rob-finetune samples 512..768 px (rob_enhance_finetune.py:1004-1005): up to 96x96 = 9216 tokens, non-square maps
-                           (1, 2, 9216, 9216, 40), (1, 2, 6336, 6336, 40), (1, 2, 6336, 77, 40), (1, 2, 1584, 1584, 80)]:
+                           (1, 2, 9216, 9216, 40), (1, 2, 6336, 6336, 40), (1, 2, 6336, 77, 40), (1, 2, 1584, 1584, 80),
+                           # text-state attention with the key side resident: several owner blocks per wavefront (4 at d = 40, 2 at d = 80), ragged Q ranges, few keys
+                           (8, 8, 4096, 77, 40), (8, 8, 2048, 77, 80), (3, 8, 1000, 77, 40), (2, 8, 300, 13, 80), (2, 8, 64, 80, 160)]:
     q = rnd(B, Nq, H * d).requires_grad_(True); k = rnd(B, Nk, H * d).requires_grad_(True); v = rnd(B, Nk, H * d).requires_grad_(True)
     o = ops.attention(q, k, v, H)
     qr, kr, vr = [t.detach().float().requires_grad_(True) for t in (q, k, v)]
