@@ -1275,8 +1275,9 @@ class MseFn(torch.autograd.Function):
     pass over the two bf16 tensors."""
 
     @staticmethod
-    def forward(ctx, pred, target):
+    def forward(ctx, pred, target, unit_grad=False):
         _req(pred, "mse")
+        ctx.unit_grad = unit_grad
         p = pred.contiguous() if pred.is_contiguous() else as_cl(pred)
         t = target.contiguous() if pred.is_contiguous() else as_cl(target)
         loss = torch.empty(1, dtype=torch.float32, device=pred.device)
@@ -1288,8 +1289,10 @@ class MseFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dpred,) = ctx.saved_tensors
-        return dpred * g.to(dpred.dtype), None
+        if ctx.unit_grad:   # the caller promises loss.backward() with the implicit seed of 1.0: no cast + multiply launches
+            return dpred, None, None
+        return dpred * g.to(dpred.dtype), None, None
 
 
-def mse_loss(pred, target):
-    return MseFn.apply(pred, target)
+def mse_loss(pred, target, unit_grad=False):
+    return MseFn.apply(pred, target, unit_grad)

@@ -28,6 +28,23 @@ _PROLOGUE = os.environ.get("AQL_PROLOGUE", "1") != "0"   # A/B hook: 0 = the gen
 VAE_SCALING = 0.18215
 
 
+def _feed(static, z, msg, eps, t, ctx):
+    """Fresh inputs -> the captured step's static buffers.  One multi-tensor copy per dtype (torch._foreach_copy_) instead of five
+    4-5 us launches in front of every replay; falls back to per-tensor copies where the foreach form is not available."""
+    dst, src = [], []
+    for k, v in (("z", z), ("msg", msg), ("eps", eps), ("t", t), ("ctx", ctx)):
+        if v is not static[k]:
+            dst.append(static[k])
+            src.append(v)
+    if not dst:
+        return
+    try:
+        torch._foreach_copy_(dst, src)
+    except (AttributeError, RuntimeError):
+        for d, v in zip(dst, src):
+            d.copy_(v)
+
+
 class PPFTTrainer:
     def __init__(self, unet, mapper, sec_encoder, rank, learning_rate=1e-4, adam_beta1=0.9, adam_beta2=0.999,
                  adam_weight_decay=1e-2, adam_epsilon=1e-8, max_grad_norm=1.0, lr_lambda=None, lora_state=None,
@@ -161,7 +178,7 @@ class PPFTTrainer:
                     clean = ops.clean_twin(pred)
                 finally:
                     ops.dual_end()
-                loss = ops.mse_loss(pred, clean)
+                loss = ops.mse_loss(pred, clean, unit_grad=True)   # loss.backward() seeds 1.0: d(pred) is used as the kernel wrote it
                 loss.backward()
                 preds.append(pred.detach())
                 cleans.append(clean)
@@ -402,9 +419,7 @@ class PPFTTrainer:
         self._graphs = (g_fb, g_opt, static, loss, captured)
 
         def run(z, msg, eps, t, ctx):
-            for k, v in (("z", z), ("msg", msg), ("eps", eps), ("t", t), ("ctx", ctx)):
-                if v is not static[k]:
-                    static[k].copy_(v)
+            _feed(static, z, msg, eps, t, ctx)
             g_fb.replay()
             self.exchange_gradients()
             g_opt.replay()
@@ -429,9 +444,7 @@ class PPFTTrainer:
         self._graphs = (g, static, loss, captured)
 
         def run(z, msg, eps, t, ctx):
-            for k, v in (("z", z), ("msg", msg), ("eps", eps), ("t", t), ("ctx", ctx)):
-                if v is not static[k]:
-                    static[k].copy_(v)
+            _feed(static, z, msg, eps, t, ctx)
             g.replay()
             self.global_step += 1
             self.lr_t.fill_(self.base_lr * self.lr_lambda(self.global_step))
@@ -469,9 +482,7 @@ class PPFTTrainer:
             else captured.run_bucket
 
         def run(z, msg, eps, t, ctx):
-            for k, v in (("z", z), ("msg", msg), ("eps", eps), ("t", t), ("ctx", ctx)):
-                if v is not static[k]:
-                    static[k].copy_(v)
+            _feed(static, z, msg, eps, t, ctx)
             g_fb.replay()
             self.exchange_bucketed(ranges, run_bucket)
             g_opt.replay()
