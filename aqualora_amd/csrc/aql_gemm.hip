@@ -151,7 +151,7 @@ static int env_int(const char* name, int dflt) {
 // Tile configurations.  ids 0-4: the transposing (token-reduction) kernels on the 32x32x16 MFMA; ids 5-10: the
 // pipelined buffer-load kernels on the 16x16x32 MFMA used by every bf16-output GEMM / conv.
 enum { P_128x160 = 5, P_64x160 = 6, P_32x160 = 7, P_64x64 = 8, P_128x32 = 9, P_128x128 = 10, P_W128x160 = 11, P_W64x160 = 12, P_W32x160 = 13,
-       P_W256x160 = 14 };
+       P_W256x160 = 14, P_W256x160B = 15 };   // 15: experiment, 256x160 on FOUR compute wavefronts of 128x80 (AQL_TILE=15 only)
 
 template <class LA, class LB, int EPI>
 void launch_cfg(int cfg, int pd, const GemmArgs<LA, LB>& g, hipStream_t stream) {
@@ -191,6 +191,9 @@ void launch_cfg(int cfg, int pd, const GemmArgs<LA, LB>& g, hipStream_t stream) 
       if (conv_row == 1 && cfg == P_W128x160 && g.M % 128 == 0 && aqlconvrow::try_conv_row<LA, EPI>(g, 128, stream)) return;
     }
     if (cfg == P_W256x160) return launch_gemm_w<256, 160, 64, 80, LA, LB, EPI, 3, 8>(g, stream);
+#ifdef AQL_BIGWAVE
+    if (cfg == P_W256x160B) return launch_gemm_w<256, 160, 128, 80, LA, LB, EPI, 3, 4>(g, stream);
+#endif
     if (cfg == P_W128x160) return launch_gemm_w<128, 160, 64, 80, LA, LB, EPI, 4>(g, stream);
     if (cfg == P_W64x160) return launch_gemm_w<64, 160, 32, 80, LA, LB, EPI, 5>(g, stream);
     if (cfg == P_W32x160) return launch_gemm_w<32, 160, 16, 80, LA, LB, EPI, 6>(g, stream);
@@ -259,7 +262,7 @@ inline void pick_tile(long M, int N, int kt_total, bool can_split, int* cfg, int
     static const int use_w256 = env_int("AQL_W256", 1);
     const int t256 = aql_cdiv(M, 256) * nt;
     if (use_w && use_w256 && kt_total >= 8 && t256 >= 240 && t256 <= 256) *cfg = P_W256x160, *tiles = t256;
-    if (force == P_W256x160) *cfg = force, *tiles = t256;
+    if (force == P_W256x160 || force == P_W256x160B) *cfg = force, *tiles = t256;
     if (force == P_W128x160) *cfg = force, *tiles = t128;
     if (force == P_W64x160) *cfg = force, *tiles = t64;
     if (force == P_W32x160) *cfg = force, *tiles = t32;

@@ -76,7 +76,10 @@ what = os.environ.get("WHAT", "gemm,conv,attn").split(",")
 
 if "gemm" in what:
     print("# plain GEMM Y = X W^T (bf16, fp32 accumulate), us per launch, HBM-cold weights")
-    for tag, M, N, K in gemm_shapes():
+    GS = gemm_shapes()
+    if os.environ.get("GEMM_SHAPES"):   # "M,N,K;..." -- tuning sweeps (AQL_TILE / AQL_W) on a few shapes
+        GS = [("fwd",) + tuple(int(v) for v in t.split(",")) for t in os.environ["GEMM_SHAPES"].split(";")]
+    for tag, M, N, K in GS:
         acts = [rnd(M, K) for _ in range(4)]
 
         def mk(i, form):
@@ -87,7 +90,7 @@ if "gemm" in what:
                 return lambda: ops.gemm_bf16(X, W, None, out=Y)
             return lambda: torch.mm(X, W.t(), out=Y)
         t_o = graph_time([mk(i, "ours") for i in range(NL)])
-        t_v = graph_time([mk(i, "vendor") for i in range(NL)])
+        t_v = float("nan") if os.environ.get("NO_VENDOR") else graph_time([mk(i, "vendor") for i in range(NL)])
         fl = 2.0 * M * K * N
         print(f"{tag} M{M:6d} N{N:5d} K{K:6d}: ours {t_o:7.1f} ({fl / t_o / 1e6:5.0f} TF/s)  hipBLASLt {t_v:7.1f} ({fl / t_v / 1e6:5.0f} TF/s)"
               f"  ours/vendor {t_o / t_v:5.2f}", flush=True)
