@@ -1080,6 +1080,51 @@ __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int
   } else {
     const int arow = (wm0 + (lane & 15)), brow = (wn0 + (lane & 15));
     const int ch0 = lane >> 4, ch1 = 4 + (lane >> 4);
+    if constexpr (FM >= 8) {
+      // 128-row wavefront tiles (experiment, -DAQL_BIGWAVE: 256 x 160 on FOUR compute wavefronts): 40 accumulator fragments = 160
+      // registers, so the A fragments cannot be held for a whole k-half (two halves x 8 fragments = 64 more registers: the
+      // double-buffered loop below spilled 78 VGPRs).  Here the B fragments of both k-halves stay resident (40 registers) and the
+      // A fragments stream through a ring of four: the read of fragment i+2 is issued in front of the five MFMAs of fragment i,
+      // crossing k-halves and, at the end of a tile, into the next stage (tile t+1 has landed before barrier(t), as for the loop below).
+      // Per 64-deep K step a wavefront reads 8 x 2 + 5 x 2 = 26 fragments for 80 MFMAs instead of 18 for 40.
+      // MEASURED (profiles/r03_bigwave_experiment.txt): parity-green, 223-233 VGPRs, no spill -- and within 1 % of the 12-wave 256 x 160
+      // kernel on every GEMM / conv shape tried.  Halving the fragment reads per MFMA changes nothing: the K loop of a 256 x 160 tile is
+      // bound by the ISSUE of its 53 LDS-DMA pieces per step (4 loader wavefronts x 13 pieces x ~110 cycles), not by the LDS array.
+      constexpr int NSUB = 2 * FM;            // (k-half, fragment) sub-steps per K tile
+      bf16x8_t fbk[2][FN], far[4];
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < FN; ++j) fbk[0][j] = *reinterpret_cast<const bf16x8_t*>(lds + A_BYTES + lds_off(brow + j * 16, ch0));
+      far[0] = *reinterpret_cast<const bf16x8_t*>(lds + lds_off(arow, ch0));
+      far[1] = *reinterpret_cast<const bf16x8_t*>(lds + lds_off(arow + 16, ch0));
+      int rd = 0;
+      for (int kt = kt_begin; kt < kt_end; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* sA = lds + rd * STAGE;
+        const char* sB = sA + A_BYTES;
+        rd = (rd + 1 == NSTG) ? 0 : rd + 1;
+        const char* nA = lds + rd * STAGE;
+        const char* nB = nA + A_BYTES;
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) {
+          const int kh = u / FM, i = u % FM;
+          // A fragment two sub-steps ahead: same tile (k-half 0 / 1) or fragments 0, 1 of the next tile's k-half 0
+          const int v = u + 2;
+          if (v < NSUB) far[v & 3] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(arow + (v % FM) * 16, (v / FM) ? ch1 : ch0));
+          else far[v & 3] = *reinterpret_cast<const bf16x8_t*>(nA + lds_off(arow + (v - NSUB) * 16, ch0));
+          // B fragments of the other k-half / the next tile, one per sub-step at the head of each half
+          if (kh == 0 && i < FN) fbk[1][i] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(brow + i * 16, ch1));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbk[kh][j], far[u & 3], acc[i][j], 0, 0, 0);
+          if (kh == 1 && i < FN) fbk[0][i] = *reinterpret_cast<const bf16x8_t*>(nB + lds_off(brow + i * 16, ch0));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
     bf16x8_t fa0[FM], fb0[FN], fa1[FM], fb1[FN];
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -1128,6 +1173,7 @@ __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    }   // FM < 8
   }
   // the trailing (zero-fill) DMAs still write LDS: retire them before the C tile reuses it
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
