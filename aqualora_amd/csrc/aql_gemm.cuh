@@ -432,12 +432,13 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, 
 // slot = tid&7) fetches source chunk slot ^ ((row >> 1) & 7) (the XOR swizzle is applied on the SOURCE side), i.e.
 // k element kc = ((tid&7) ^ ((tid>>4)&7)) * 8 of the tile.  begin() positions the stager on tile t_first of the
 // concatenated K range; every dma() stages the next tile and advances.  Tiles at or past t_end are zero-filled.
-template <int R, class L>
+// RPI = rows one piece instruction covers across the loader wavefronts: 8 rows per wavefront x 4 loaders = 32 (8 loaders: 64, experiment)
+template <int R, class L, int RPI = 32>
 struct DmaStager;
 
-template <int R>
-struct DmaStager<R, PlainLoader> {
-  static constexpr int NL = R / 32;
+template <int R, int RPI>
+struct DmaStager<R, PlainLoader, RPI> {
+  static constexpr int NL = (R + RPI - 1) / RPI;
   uint32_t voff[NL], voff1[NL];  // row byte offset + lane chunk offset (current segment / segment 1), or OOB_ROW
   __amdgpu_buffer_rsrc_t rs, rs1;
   uint32_t soff;                 // byte offset of the next tile inside the current segment
@@ -452,7 +453,7 @@ struct DmaStager<R, PlainLoader> {
     rs = in1 ? rs1 : make_rsrc(l0.base);
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const int lr = (tid >> 3) + 32 * i;
+      const int lr = (tid >> 3) + RPI * i;
       const int r = row0 + lr + ((l0.gsplit && lr >= l0.gsplit) ? l0.goff : 0);
       const int r1 = row0 + lr + ((l1.gsplit && lr >= l1.gsplit) ? l1.goff : 0);
       const uint32_t v0 = r < l0.rows ? (uint32_t)r * (uint32_t)(l0.ld * 2) + kc * 2 : OOB_ROW;
@@ -470,7 +471,9 @@ struct DmaStager<R, PlainLoader> {
   __device__ __forceinline__ void dma(char* stage, int wave) {
     const bool bad = kc >= krem;  // K tail of the segment / past the end of this split
 #pragma unroll
-    for (int i = 0; i < NL; ++i) dma16(rs, stage + (32 * i + 8 * wave) * 128, bad ? OOB_ROW : voff[i], soff);
+    for (int i = 0; i < NL; ++i)
+      if (R % RPI == 0 || RPI * i + 8 * wave < R)   // wave-uniform: a piece past the tile's rows would zero-fill the next stage
+        dma16(rs, stage + (RPI * i + 8 * wave) * 128, bad ? OOB_ROW : voff[i], soff);
     soff += BK * 2;
     krem -= BK;
     if (--to_switch == 0) {  // uniform: enter segment 1 (the LoRA rank segment)
@@ -486,9 +489,9 @@ struct DmaStager<R, PlainLoader> {
 // 3x3 gather loaders.  Fast path (channels % 64 == 0, no folded upsample / stride-2 adjoint): a K tile lies inside one
 // tap, so (kh, kw, c0) are scalars advanced per tile and a row's offset is rowbase + tapoff.  Anything else takes the
 // general per-lane path (conv_in with 8 channels, the 3 upsample convs, the 3 stride-2 backward convs).
-template <int R>
-struct DmaStager<R, ConvFwdLoader> {
-  static constexpr int NL = R / 32;
+template <int R, int RPI>
+struct DmaStager<R, ConvFwdLoader, RPI> {
+  static constexpr int NL = (R + RPI - 1) / RPI;
   int rb[NL], rh[NL], rw[NL];  // b*Hin, h0, w0 of the row's output pixel (h0 = -FAR for rows past M)
   uint32_t rowbase[NL];        // fast path: (((b*Hin + h0)*Win + w0)*Cin + kc)*2   (wraps for border rows; only used when valid)
   __amdgpu_buffer_rsrc_t rs;
@@ -504,7 +507,7 @@ struct DmaStager<R, ConvFwdLoader> {
     const int hw = l.Hout * l.Wout;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const int r = row0 + (tid >> 3) + 32 * i;
+      const int r = row0 + (tid >> 3) + RPI * i;
       const int b = r / hw, rem = r - b * hw, ho = rem / l.Wout;
       rb[i] = b * l.Hin;
       rh[i] = r < l.rows ? ho * l.stride - l.pad : -FAR;
@@ -525,7 +528,7 @@ struct DmaStager<R, ConvFwdLoader> {
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         const bool ok = (unsigned)(rh[i] + khe) < (unsigned)Hl && (unsigned)(rw[i] + kw) < (unsigned)Wl;
-        dma16(rs, stage + (32 * i + 8 * wave) * 128, ok ? rowbase[i] + tapoff : OOB_ROW, 0);
+        if (R % RPI == 0 || RPI * i + 8 * wave < R) dma16(rs, stage + (RPI * i + 8 * wave) * 128, ok ? rowbase[i] + tapoff : OOB_ROW, 0);
       }
       c0 += BK;
       if (c0 >= Cin) {
@@ -542,7 +545,7 @@ struct DmaStager<R, ConvFwdLoader> {
         const int hi = rh[i] + khl, wi = rw[i] + kwl;
         const bool ok = (unsigned)hi < (unsigned)Hl && (unsigned)wi < (unsigned)Wl;
         const uint32_t off = (uint32_t)(((rb[i] + (hi >> ups)) * Win + (wi >> ups)) * Cin + ci) * 2u;
-        dma16(rs, stage + (32 * i + 8 * wave) * 128, ok ? off : OOB_ROW, 0);
+        if (R % RPI == 0 || RPI * i + 8 * wave < R) dma16(rs, stage + (RPI * i + 8 * wave) * 128, ok ? off : OOB_ROW, 0);
       }
     }
     ++t;
@@ -550,9 +553,9 @@ struct DmaStager<R, ConvFwdLoader> {
   }
 };
 
-template <int R>
-struct DmaStager<R, ConvBwdLoader> {
-  static constexpr int NL = R / 32;
+template <int R, int RPI>
+struct DmaStager<R, ConvBwdLoader, RPI> {
+  static constexpr int NL = (R + RPI - 1) / RPI;
   int rb[NL], rh[NL], rw[NL];  // b*Hout, hi+1, wi+1 of the row's input pixel (hi+1 = -FAR for rows past M)
   uint32_t rowbase[NL];        // fast path: (((b*Hout + hi+1)*Wout + wi+1)*Cout + kc)*2
   __amdgpu_buffer_rsrc_t rs;
@@ -568,7 +571,7 @@ struct DmaStager<R, ConvBwdLoader> {
     const int hw = l.Hin * l.Win;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const int r = row0 + (tid >> 3) + 32 * i;
+      const int r = row0 + (tid >> 3) + RPI * i;
       const int b = r / hw, rem = r - b * hw, hi = rem / l.Win;
       rb[i] = b * l.Hout;
       rh[i] = r < l.rows ? hi + 1 : -FAR;
@@ -589,7 +592,7 @@ struct DmaStager<R, ConvBwdLoader> {
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         const bool ok = (unsigned)(rh[i] - khe) < (unsigned)Hout && (unsigned)(rw[i] - kw) < (unsigned)Wout;
-        dma16(rs, stage + (32 * i + 8 * wave) * 128, ok ? rowbase[i] + tapoff : OOB_ROW, 0);
+        if (R % RPI == 0 || RPI * i + 8 * wave < R) dma16(rs, stage + (RPI * i + 8 * wave) * 128, ok ? rowbase[i] + tapoff : OOB_ROW, 0);
       }
       c0 += BK;
       if (c0 >= Cout) {
@@ -608,7 +611,7 @@ struct DmaStager<R, ConvBwdLoader> {
         const int ho = th >> s2, wo = tw >> s2;
         const bool ok = par && th >= 0 && tw >= 0 && ho < Hout && wo < Wout;
         const uint32_t off = (uint32_t)(((rb[i] + ho) * Wout + wo) * Cout + co) * 2u;
-        dma16(rs, stage + (32 * i + 8 * wave) * 128, ok ? off : OOB_ROW, 0);
+        if (R % RPI == 0 || RPI * i + 8 * wave < R) dma16(rs, stage + (RPI * i + 8 * wave) * 128, ok ? off : OOB_ROW, 0);
       }
     }
     ++t;
@@ -972,13 +975,17 @@ inline void launch_gemm_d(const GemmArgs<LA, LB>& g, hipStream_t stream) {
 
 // NCW = compute wavefronts: 4 (8-wave workgroup) or 8 (12-wave workgroup, 256x160 tile: two compute wavefronts per SIMD keep the
 // matrix pipe fed across each other's fragment-read latency, and a weight tile is shared by twice the rows).
-template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG, int NCW = 4>
+// NLW = loader wavefronts: 4, or 8 (experiment, AQL_TILE=16 on a -DAQL_BIGWAVE build: the K loop is paced by the ISSUE of the LDS-DMA pieces,
+// ~110 cycles per piece per loader wavefront -- twice the issuers, half the pieces each)
+template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG, int NCW = 4, int NLW = 4>
 __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int block_x, const int block_z) {
   static_assert(EPI != EPI_ATOMIC && !LA::kTrans, "bf16 / slab epilogues only");
   constexpr int FM = WM / 16, FN = WN / 16;
   constexpr int WAVES_N = BN / WN;
-  constexpr int NT = (NCW + 4) * 64;   // threads per workgroup
-  static_assert((BM / WM) * (BN / WN) == NCW && (NCW == 4 || NCW == 8), "NCW compute wavefronts (+ 4 loader wavefronts) per workgroup");
+  constexpr int NT = (NCW + NLW) * 64;   // threads per workgroup
+  constexpr int RPI = 8 * NLW;           // rows per piece instruction across the loader wavefronts
+  static_assert((BM / WM) * (BN / WN) == NCW && (NCW == 4 || NCW == 8), "NCW compute wavefronts (+ NLW loader wavefronts) per workgroup");
+  static_assert(NLW == 4 || NLW == 8, "4 or 8 loader wavefronts");
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int C_PITCH = (BN + 8) * 2;  // bytes per row of the bf16 C tile staged in LDS
@@ -1017,7 +1024,11 @@ __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int
   const int kt_end = (int)(((long)kt_total * (block_z + 1)) / g.splits);
   const bool dual = kt1 > 0;
 
-  constexpr int NLD = BM / 32 + BN / 32;  // LDS-DMA instructions per loader thread per K tile
+  constexpr int NLD = (BM + RPI - 1) / RPI + (BN + RPI - 1) / RPI;  // LDS-DMA instructions per loader thread per K tile (the wavefronts whose rows start inside the tile)
+  constexpr int NLD_S = BM / RPI + BN / RPI;                       // ... of the wavefronts past a ragged tail (NLW = 8, BN = 160: 4 instead of 5)
+  // this loader wavefront issues the short count when its 8 rows of the last piece lie past BM / BN (wave-uniform)
+  const bool lw_short = loader && ((BM % RPI != 0 && (BM / RPI) * RPI + 8 * (wave - NCW) >= BM) || (BN % RPI != 0 && (BN / RPI) * RPI + 8 * (wave - NCW) >= BN));
+  static_assert(NLD == NLD_S || NLD == NLD_S + 1, "at most one ragged operand");
   uint2 biasr[FN];  // compute wavefronts: this lane's bias values, fetched before the K loop (epi_load_bias)
   if constexpr (EPI == EPI_BF16) {
     if (!loader) epi_load_bias<FN>(biasr, g.epi.bias, g.b0.base, n0, wn0, lane, g.N, gF, BN / 2);
@@ -1041,8 +1052,8 @@ __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int
   // live range.
   static_assert(NSTG >= 3, "the cross-tile prefetch needs tile t+1 resident while tile t-1's stage is refilled");
   if (loader) {
-    DmaStager<BM, LA> sa;  // row descriptors only: tiles go global -> LDS directly (no staging registers, no ds_write)
-    DmaStager<BN, LB> sb;
+    DmaStager<BM, LA, RPI> sa;  // row descriptors only: tiles go global -> LDS directly (no staging registers, no ds_write)
+    DmaStager<BN, LB, RPI> sb;
     sa.begin(g.a0, g.a1, dual, m0, ltid, kt_begin, kt_end, g.ktiles0);
     sb.begin(g.b0, g.b1, dual, n0, ltid, kt_begin, kt_end, g.ktiles0);
     auto issue = [&](int stage) {  // stages the NEXT tile of the K range (tiles are requested in order)
@@ -1052,7 +1063,8 @@ __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int
     };
 #pragma unroll
     for (int u = 0; u < NSTG - 1; ++u) issue(u);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * NLD) : "memory");  // first tile landed
+    if (NLD != NLD_S && lw_short) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * NLD_S) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * NLD) : "memory");  // first tile landed
     __builtin_amdgcn_s_barrier();
     int wr = NSTG - 1;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -1062,7 +1074,8 @@ __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int
         trace = reinterpret_cast<long*>(g.epi.Cf) + ((block_x ? 8 : 0) + wave) * 1024 + (kt - kt_begin) * 4;
       if (trace) trace[0] = clock64();
 #endif
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 3) * NLD) : "memory");  // tile kt+1 landed
+      if (NLD != NLD_S && lw_short) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 3) * NLD_S) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 3) * NLD) : "memory");  // tile kt+1 landed
 #ifdef AQL_TRACE_W
       if (trace) trace[1] = clock64();
 #endif
@@ -1218,18 +1231,18 @@ __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int
   }
 }
 
-template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG, int NCW = 4>
-__global__ __launch_bounds__((NCW + 4) * 64) void gemm_kernel_w(const GemmArgs<LA, LB> g) {
+template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG, int NCW = 4, int NLW = 4>
+__global__ __launch_bounds__((NCW + NLW) * 64) void gemm_kernel_w(const GemmArgs<LA, LB> g) {
   const int nblk = gridDim.x, bid = blockIdx.x;
   const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
   const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  gemm_body_w<BM, BN, WM, WN, LA, LB, EPI, NSTG, NCW>(g, logical, blockIdx.z);
+  gemm_body_w<BM, BN, WM, WN, LA, LB, EPI, NSTG, NCW, NLW>(g, logical, blockIdx.z);
 }
 
-template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG, int NCW = 4>
+template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG, int NCW = 4, int NLW = 4>
 inline void launch_gemm_w(const GemmArgs<LA, LB>& g, hipStream_t stream) {
   dim3 grid(aql_cdiv(g.M, BM) * aql_cdiv(g.N, BN), 1, g.splits);
-  hipLaunchKernelGGL((gemm_kernel_w<BM, BN, WM, WN, LA, LB, EPI, NSTG, NCW>), grid, dim3((NCW + 4) * 64), 0, stream, g);
+  hipLaunchKernelGGL((gemm_kernel_w<BM, BN, WM, WN, LA, LB, EPI, NSTG, NCW, NLW>), grid, dim3((NCW + NLW) * 64), 0, stream, g);
 }
 
 template <int BM, int BN, int WM, int WN, class LA, class LB, int EPI, int NSTG = 2>

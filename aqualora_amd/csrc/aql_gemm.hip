@@ -151,7 +151,7 @@ static int env_int(const char* name, int dflt) {
 // Tile configurations.  ids 0-4: the transposing (token-reduction) kernels on the 32x32x16 MFMA; ids 5-10: the
 // pipelined buffer-load kernels on the 16x16x32 MFMA used by every bf16-output GEMM / conv.
 enum { P_128x160 = 5, P_64x160 = 6, P_32x160 = 7, P_64x64 = 8, P_128x32 = 9, P_128x128 = 10, P_W128x160 = 11, P_W64x160 = 12, P_W32x160 = 13,
-       P_W256x160 = 14, P_W256x160B = 15 };   // 15: experiment, 256x160 on FOUR compute wavefronts of 128x80 (AQL_TILE=15 only)
+       P_W256x160 = 14, P_W256x160B = 15, P_W128x160L8 = 16 };   // experiments (-DAQL_BIGWAVE, AQL_TILE only): 15 = 256x160 on FOUR compute wavefronts of 128x80, 16 = 128x160 with EIGHT loader wavefronts
 
 template <class LA, class LB, int EPI>
 void launch_cfg(int cfg, int pd, const GemmArgs<LA, LB>& g, hipStream_t stream) {
@@ -193,6 +193,7 @@ void launch_cfg(int cfg, int pd, const GemmArgs<LA, LB>& g, hipStream_t stream) 
     if (cfg == P_W256x160) return launch_gemm_w<256, 160, 64, 80, LA, LB, EPI, 3, 8>(g, stream);
 #ifdef AQL_BIGWAVE
     if (cfg == P_W256x160B) return launch_gemm_w<256, 160, 128, 80, LA, LB, EPI, 3, 4>(g, stream);
+    if (cfg == P_W128x160L8) return launch_gemm_w<128, 160, 64, 80, LA, LB, EPI, 4, 4, 8>(g, stream);
 #endif
     if (cfg == P_W128x160) return launch_gemm_w<128, 160, 64, 80, LA, LB, EPI, 4>(g, stream);
     if (cfg == P_W64x160) return launch_gemm_w<64, 160, 32, 80, LA, LB, EPI, 5>(g, stream);
@@ -263,7 +264,7 @@ inline void pick_tile(long M, int N, int kt_total, bool can_split, int* cfg, int
     const int t256 = aql_cdiv(M, 256) * nt;
     if (use_w && use_w256 && kt_total >= 8 && t256 >= 240 && t256 <= 256) *cfg = P_W256x160, *tiles = t256;
     if (force == P_W256x160 || force == P_W256x160B) *cfg = force, *tiles = t256;
-    if (force == P_W128x160) *cfg = force, *tiles = t128;
+    if (force == P_W128x160 || force == P_W128x160L8) *cfg = force, *tiles = t128;
     if (force == P_W64x160) *cfg = force, *tiles = t64;
     if (force == P_W32x160) *cfg = force, *tiles = t32;
   } else if (N <= 32) {
@@ -296,7 +297,7 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
     return AQL_NOT_FUSED;  // the [80 value | 80 gate] tile layout exists for the 160-wide tiles only
   int splits = 1;
   if (ws != nullptr && o.C2 == nullptr) splits = pick_splits(tiles, kt_total, g.M, g.N, ws_bytes);
-  if ((cfg == P_W128x160 || cfg == P_W64x160 || cfg == P_W32x160) && splits > 1) {
+  if ((cfg == P_W128x160 || cfg == P_W128x160L8 || cfg == P_W64x160 || cfg == P_W32x160) && splits > 1) {
     // one workgroup per CU: aim at exactly one (or two) chip-wide rounds
     int s2 = 256 / tiles;
     if (s2 < 1) s2 = 1;
