@@ -222,7 +222,9 @@ class PPFTTrainer:
             else:
                 self.deferred.flush_ds()
             S.backward(self.ds_accum)
-        loss = torch.stack(losses).mean()
+        loss = losses[0] if len(losses) == 1 else torch.stack(losses).mean()   # one twin batch: no copy + mean launches
+        if len(preds) == 1:   # one twin batch: hand the tensors out as they are (torch.cat of one tensor is a copy launch each)
+            return loss, preds[0], cleans[0]
         return loss, torch.cat(preds), torch.cat(cleans)
 
     def _twin_prologue(self, z, msg, eps, t, ctx):
