@@ -54,9 +54,8 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 // erf(x) by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 -- two orders below fp32-in / bf16-out resolution of every
-// caller): one v_rcp, one v_exp and six FMAs instead of libm's branchy erff (~4x the VALU work).  The GEGLU activation
-// (scripts/lib/original_unet.py:721-729, F.gelu exact form) is VALU-bound inside a GEMM epilogue, where nothing overlaps it.
-// Used by the fused epilogue AND the stand-alone geglu kernels, so the two paths stay bit-identical to each other.
+// caller): one v_rcp, one v_exp and six FMAs instead of libm's branchy erff (~4x the VALU work).  Kept for reference builds
+// (-DAQL_ERF_7126); the GEGLU paths use the pair form below.
 __device__ __forceinline__ float aql_erf(float x) {
 #pragma clang fp contract(off)   // every fused multiply-add below is an explicit fmaf: the same bits in every kernel that inlines this
   const float ax = fabsf(x);
@@ -68,19 +67,64 @@ __device__ __forceinline__ float aql_erf(float x) {
   const float e = __expf(-ax * ax);
   return copysignf(fmaf(-p * t, e, 1.f), x);
 }
-__device__ __forceinline__ float aql_gelu(float g) {
+
+// Pair form for the GEGLU epilogues (scripts/lib/original_unet.py:721-729, F.gelu exact form), which are VALU-bound: ~10k cycles of
+// activation per 128 x 160 tile next to a 5-step K loop.  A&S 7.1.28: erf(x) = 1 - (1 + a1 x + ... + a6 x^6)^-16, |error| <= 3e-7,
+// ONE transcendental (v_rcp) per element instead of two (v_rcp + v_exp), and every other operation -- six FMAs, four squarings -- on
+// TWO elements per instruction (v_pk_fma_f32 / v_pk_mul_f32: the two bf16 halves of a 32-bit word).  Per element ~11 issue slots
+// instead of ~19.  Large |x|: the 16th power overflows to +inf, its reciprocal is 0, erf = +-1 (no NaN: inf * inf = inf).
+// Used by the fused epilogues AND the stand-alone geglu kernels, so the two paths stay bit-identical to each other (packed lanes are
+// independent IEEE operations: the pairing does not matter).
+typedef float aql_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ aql_f32x2_t aql_splat2(float v) { return aql_f32x2_t{v, v}; }
+__device__ __forceinline__ aql_f32x2_t aql_erf2(aql_f32x2_t x) {
 #pragma clang fp contract(off)
-  return 0.5f * g * (1.f + aql_erf(g * 0.70710678118654752f));
+  const aql_f32x2_t ax = __builtin_elementwise_abs(x);
+  aql_f32x2_t p = __builtin_elementwise_fma(ax, aql_splat2(0.0000430638f), aql_splat2(0.0002765672f));
+  p = __builtin_elementwise_fma(ax, p, aql_splat2(0.0001520143f));
+  p = __builtin_elementwise_fma(ax, p, aql_splat2(0.0092705272f));
+  p = __builtin_elementwise_fma(ax, p, aql_splat2(0.0422820123f));
+  p = __builtin_elementwise_fma(ax, p, aql_splat2(0.0705230784f));
+  p = __builtin_elementwise_fma(ax, p, aql_splat2(1.f));
+  p = p * p;
+  p = p * p;
+  p = p * p;
+  p = p * p;
+  const aql_f32x2_t r = aql_f32x2_t{__builtin_amdgcn_rcpf(p.x), __builtin_amdgcn_rcpf(p.y)};
+  const aql_f32x2_t e = aql_splat2(1.f) - r;
+  return aql_f32x2_t{copysignf(e.x, x.x), copysignf(e.y, x.y)};
 }
-// d(value * gelu(gate)) -> d(value), d(gate) (h = value, g = gate).  Shared by aql_geglu_bwd and the GEGLU-backward GEMM
+__device__ __forceinline__ aql_f32x2_t aql_gelu2(aql_f32x2_t g) {
+#pragma clang fp contract(off)
+#ifdef AQL_ERF_7126
+  return aql_f32x2_t{0.5f * g.x * (1.f + aql_erf(g.x * 0.70710678118654752f)), 0.5f * g.y * (1.f + aql_erf(g.y * 0.70710678118654752f))};
+#else
+  const aql_f32x2_t e = aql_erf2(g * aql_splat2(0.70710678118654752f));
+  return (aql_splat2(0.5f) * g) * (aql_splat2(1.f) + e);
+#endif
+}
+__device__ __forceinline__ float aql_gelu(float g) { return aql_gelu2(aql_splat2(g)).x; }
+// d(value * gelu(gate)) -> d(value), d(gate) (h = value, g = gate) on a pair.  Shared by aql_geglu_bwd and the GEGLU-backward GEMM
 // epilogue, which must agree bit for bit: with -ffp-contract=fast the compiler's choice of which a*b+c to fuse depended on the
 // code around the inlined body (one element of a 4096x2560 tile rounded differently after an unrelated epilogue change).
-__device__ __forceinline__ void aql_geglu_bwd1(float d, float h, float g, float& dh, float& dg) {
+__device__ __forceinline__ void aql_geglu_bwd2(aql_f32x2_t d, aql_f32x2_t h, aql_f32x2_t g, aql_f32x2_t& dh, aql_f32x2_t& dg) {
 #pragma clang fp contract(off)
-  const float cdf = 0.5f * (1.f + aql_erf(g * 0.70710678118654752f));
-  const float pdf = 0.3989422804014327f * __expf(-0.5f * g * g);
+#ifdef AQL_ERF_7126
+  const aql_f32x2_t e = aql_f32x2_t{aql_erf(g.x * 0.70710678118654752f), aql_erf(g.y * 0.70710678118654752f)};
+#else
+  const aql_f32x2_t e = aql_erf2(g * aql_splat2(0.70710678118654752f));
+#endif
+  const aql_f32x2_t cdf = aql_splat2(0.5f) * (aql_splat2(1.f) + e);
+  const aql_f32x2_t q = aql_splat2(-0.5f) * g * g;
+  const aql_f32x2_t pdf = aql_splat2(0.3989422804014327f) * aql_f32x2_t{__expf(q.x), __expf(q.y)};
   dh = d * g * cdf;
-  dg = d * h * fmaf(g, pdf, cdf);
+  dg = d * h * __builtin_elementwise_fma(g, pdf, cdf);
+}
+__device__ __forceinline__ void aql_geglu_bwd1(float d, float h, float g, float& dh, float& dg) {
+  aql_f32x2_t a, b;
+  aql_geglu_bwd2(aql_splat2(d), aql_splat2(h), aql_splat2(g), a, b);
+  dh = a.x;
+  dg = b.x;
 }
 
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }

@@ -35,7 +35,11 @@ __global__ __launch_bounds__(256) void geglu_fwd_kernel(const bf16_t* __restrict
     unpack8(*reinterpret_cast<const uint4*>(in + m * 2 * F + c), h);
     unpack8(*reinterpret_cast<const uint4*>(in + m * 2 * F + F + c), g);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = h[j] * aql_gelu(g[j]);
+    for (int j = 0; j < 8; j += 2) {
+      const aql_f32x2_t a = aql_f32x2_t{h[j], h[j + 1]} * aql_gelu2(aql_f32x2_t{g[j], g[j + 1]});
+      o[j] = a.x;
+      o[j + 1] = a.y;
+    }
     *reinterpret_cast<uint4*>(out + m * F + c) = pack8(o);
   }
 }
@@ -52,8 +56,11 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict
     unpack8(*reinterpret_cast<const uint4*>(in + m * 2 * F + F + c), g);
     unpack8(*reinterpret_cast<const uint4*>(dy + m * F + c), d);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      aql_geglu_bwd1(d[j], h[j], g[j], dh[j], dg[j]);
+    for (int j = 0; j < 8; j += 2) {
+      aql_f32x2_t a, b;
+      aql_geglu_bwd2(aql_f32x2_t{d[j], d[j + 1]}, aql_f32x2_t{h[j], h[j + 1]}, aql_f32x2_t{g[j], g[j + 1]}, a, b);
+      dh[j] = a.x, dh[j + 1] = a.y;
+      dg[j] = b.x, dg[j + 1] = b.y;
     }
     *reinterpret_cast<uint4*>(din + m * 2 * F + c) = pack8(dh);
     *reinterpret_cast<uint4*>(din + m * 2 * F + F + c) = pack8(dg);

@@ -621,6 +621,11 @@ struct DmaStager<R, ConvBwdLoader, RPI> {
 
 // ---- GEGLU epilogue helpers ---------------------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_erf(float g) { return aql_gelu(g); }
+// value * gelu(gate) on the two bf16 halves of a word, packed fp32 arithmetic (aql_gelu2)
+__device__ __forceinline__ uint32_t geglu_word(uint32_t v, uint32_t gt) {
+  const aql_f32x2_t a = aql_f32x2_t{bf16lo(v), bf16hi(v)} * aql_gelu2(aql_f32x2_t{bf16lo(gt), bf16hi(gt)});
+  return pack_bf16x2(a.x, a.y);
+}
 
 // bias index of tile-local column `col` (a multiple of 4): plain tiles n0 + col; GEGLU tiles [value | gate] halves
 __device__ __forceinline__ int epi_bias_col(int n0, int col, int F, int half) {
@@ -633,15 +638,11 @@ __device__ __forceinline__ void geglu_bwd8(const uint4& d, const uint4& hv, cons
   uint32_t ov[4], og[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    float rv[2], rg[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const float dd = q ? bf16hi(dw[e]) : bf16lo(dw[e]), h = q ? bf16hi(vw[e]) : bf16lo(vw[e]);
-      const float gt = q ? bf16hi(gw[e]) : bf16lo(gw[e]);
-      aql_geglu_bwd1(dd, h, gt, rv[q], rg[q]);
-    }
-    ov[e] = pack_bf16x2(rv[0], rv[1]);
-    og[e] = pack_bf16x2(rg[0], rg[1]);
+    aql_f32x2_t rv, rg;
+    aql_geglu_bwd2(aql_f32x2_t{bf16lo(dw[e]), bf16hi(dw[e])}, aql_f32x2_t{bf16lo(vw[e]), bf16hi(vw[e])},
+                   aql_f32x2_t{bf16lo(gw[e]), bf16hi(gw[e])}, rv, rg);
+    ov[e] = pack_bf16x2(rv.x, rv.y);
+    og[e] = pack_bf16x2(rg.x, rg.y);
   }
   dv = make_uint4(ov[0], ov[1], ov[2], ov[3]);
   dg = make_uint4(og[0], og[1], og[2], og[3]);
@@ -664,10 +665,10 @@ __device__ __forceinline__ void geglu_store(const char* lds, int m0, int n0, int
       *reinterpret_cast<uint4*>(ep.C + (long)m * ep.ldc + F + n) = gt;
     }
     uint4 o;
-    o.x = pack_bf16x2(bf16lo(v.x) * gelu_erf(bf16lo(gt.x)), bf16hi(v.x) * gelu_erf(bf16hi(gt.x)));
-    o.y = pack_bf16x2(bf16lo(v.y) * gelu_erf(bf16lo(gt.y)), bf16hi(v.y) * gelu_erf(bf16hi(gt.y)));
-    o.z = pack_bf16x2(bf16lo(v.z) * gelu_erf(bf16lo(gt.z)), bf16hi(v.z) * gelu_erf(bf16hi(gt.z)));
-    o.w = pack_bf16x2(bf16lo(v.w) * gelu_erf(bf16lo(gt.w)), bf16hi(v.w) * gelu_erf(bf16hi(gt.w)));
+    o.x = geglu_word(v.x, gt.x);
+    o.y = geglu_word(v.y, gt.y);
+    o.z = geglu_word(v.z, gt.z);
+    o.w = geglu_word(v.w, gt.w);
     *reinterpret_cast<uint4*>(ep.G + (long)m * ep.ldg + n) = o;
   }
 }
