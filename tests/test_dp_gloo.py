@@ -162,3 +162,22 @@ def test_bank_order_puts_the_up_path_first_and_the_text_projections_last():
     assert all(k.startswith("up_blocks.") for k in names[:n_lead]) and names[n_lead].startswith("mid_block.")
     body = names[:-n_kv]
     assert body == [k for k in reversed(keys) if not is_kv(k)]                 # gradient-ready order otherwise
+
+
+def test_step_input_feed_copies_into_the_static_buffers():
+    """ppft._feed: fresh step inputs -> the captured step's static buffers (one multi-tensor copy per dtype); an input that IS the static
+    buffer is left alone, dtypes are preserved, the buffers keep their addresses (a replayed graph reads them)."""
+    import torch
+    from aqualora_amd.ppft import _feed
+    static = {"z": torch.zeros(2, 4, 8, 8), "msg": torch.zeros(2, 48), "eps": torch.zeros(2, 4, 8, 8),
+              "t": torch.zeros(2, dtype=torch.int64), "ctx": torch.zeros(2, 77, 16, dtype=torch.bfloat16)}
+    ptrs = {k: v.data_ptr() for k, v in static.items()}
+    g = torch.Generator().manual_seed(0)
+    new = {"z": torch.randn(2, 4, 8, 8, generator=g), "msg": torch.randint(0, 2, (2, 48), generator=g).float(),
+           "eps": torch.randn(2, 4, 8, 8, generator=g), "t": torch.tensor([17, 933]), "ctx": torch.randn(2, 77, 16, generator=g).to(torch.bfloat16)}
+    _feed(static, **new)
+    for k in static:
+        assert static[k].data_ptr() == ptrs[k] and static[k].dtype == new[k].dtype and torch.equal(static[k], new[k]), k
+    before = static["eps"].clone()
+    _feed(static, new["z"] * 2, new["msg"], static["eps"], new["t"] + 1, new["ctx"])   # eps IS the static buffer: untouched
+    assert torch.equal(static["eps"], before) and torch.equal(static["z"], new["z"] * 2) and static["t"].tolist() == [18, 934]
