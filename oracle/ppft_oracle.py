@@ -397,6 +397,41 @@ def k_sample_oracle(eps_fn, x, ts, sig, sampler):
         elif sampler == "lms":
             hist = ([d] + hist)[:4]
             x = x + sum(lms_coeff_oracle(sig, len(hist), i, j) * hist[j] for j in range(len(hist)))
+        elif sampler == "kdpm2a":   # k-diffusion sample_dpm_2_ancestral, eta = 1; noise_fn rides on eps_fn.noise (test plumbing)
+            if sn == 0:
+                x = x - s * d
+            else:
+                up = min(sn, math.sqrt(sn * sn * (s * s - sn * sn) / (s * s)))
+                down = math.sqrt(sn * sn - up * up)
+                sm = math.sqrt(s * down)
+                x = x + (down - s) * eps_fn(x + (sm - s) * d, sm, None)
+                x = x + up * eps_fn.noise(i, x)
         else:
             raise ValueError(sampler)
+    return x
+
+
+def plms_oracle(eps_fn, x, n_steps, acp):
+    """Independent restatement of the PLMS sampler as diffusers' PNDMScheduler runs it for the SD-1.5 config (skip_prk_steps, leading
+    spacing with offset 1, final alpha = alphas_cumprod[0]): written as explicit phases instead of the scheduler's counter logic.
+    Phase 1 (Heun-like warm-up at the first timestep), then Adams-Bashforth of growing order 2, 3, 4 on the eps history."""
+    import math
+    ratio = 1000 // n_steps
+    grid = [1 + i * ratio for i in range(n_steps)][::-1]          # t_0 > t_1 > ... > t_{N-1} = 1
+
+    def transfer(x_, t, tp, e):
+        a_t = float(acp[t])
+        a_p = float(acp[tp]) if tp >= 0 else float(acp[0])
+        return math.sqrt(a_p / a_t) * x_ - (a_p - a_t) * e / (a_t * math.sqrt(1 - a_p) + math.sqrt(a_t * (1 - a_t) * a_p))
+    e0 = eps_fn(x, grid[0])
+    x1 = transfer(x, grid[0], grid[1], e0)
+    e1 = eps_fn(x1, grid[1])
+    x = transfer(x, grid[0], grid[1], 0.5 * (e0 + e1))              # corrected first step
+    hist = [e0]
+    coeffs = {2: (1.5, -0.5), 3: (23 / 12, -16 / 12, 5 / 12), 4: (55 / 24, -59 / 24, 37 / 24, -9 / 24)}
+    for k in range(1, n_steps):
+        hist = (hist + [eps_fn(x, grid[k])])[-4:]
+        c = coeffs[len(hist)]
+        e = sum(ci * hi for ci, hi in zip(c, hist[::-1]))
+        x = transfer(x, grid[k], grid[k] - ratio, e)
     return x

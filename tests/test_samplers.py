@@ -142,3 +142,79 @@ def test_k_sampler_hip_vs_oracle_tiny_unet():
         assert torch.isfinite(got).all()
         # bf16 U-Net inputs: an fp32 ulp between the host-side and device-side update flips input roundings (the DPM-Solver test's bound)
         assert float((got.cpu() - want).abs().max() / want.abs().max()) < 2e-2, sampler
+
+
+def test_pndm_plms_integrates_the_exact_noise_model_and_matches_the_restatement():
+    """``pndm`` (evaluation/utils_eval.py:91-92; PNDMScheduler with skip_prk_steps = PLMS).  (1) Under the exact noise model the true
+    noise is constant along the trajectory, every slope combination with weights summing to one equals it, and the transfer formula
+    is exact: the loop must land on alpha_0 x0 + sigma_0 eps to machine precision for any step count.  (2) With a nonlinear stand-in
+    model the scheduler-style counter loop equals the phase-by-phase restatement in oracle/ppft_oracle.py.  (3) The timestep list has
+    the warm-up repeat diffusers builds."""
+    from aqualora_amd.ksamplers import pndm_sample_core, pndm_timesteps
+    torch.manual_seed(0)
+    acp = O.alphas_cumprod().double()
+    assert pndm_timesteps(10) == ([901, 801, 801, 701, 601, 501, 401, 301, 201, 101, 1], 100)
+    ts50, r50 = pndm_timesteps(50)
+    assert len(ts50) == 51 and ts50[:3] == [981, 961, 961] and ts50[-1] == 1 and r50 == 20
+    x0 = torch.randn(2, 4, 8, 8, dtype=torch.float64)
+    eps = torch.randn_like(x0)
+    for steps in (10, 25, 50):
+        t0 = pndm_timesteps(steps)[0][0]
+        xT = acp[t0].sqrt() * x0 + (1 - acp[t0]).sqrt() * eps
+        got = pndm_sample_core(lambda x, t: (x - acp[t].sqrt() * x0) / (1 - acp[t]).sqrt(), xT, steps, acp)
+        assert float((got - (acp[0].sqrt() * x0 + (1 - acp[0]).sqrt() * eps)).abs().max()) < 1e-9
+        f = lambda x, t: torch.tanh(x * 0.7) * (1 + 0.001 * t)   # noqa: E731
+        a, b = pndm_sample_core(f, xT, steps, acp), O.plms_oracle(f, xT, steps, acp)
+        assert float((a - b).abs().max() / b.abs().max()) < 1e-9
+
+
+def test_kdpm2_ancestral_matches_the_restatement_and_keeps_the_noise_level():
+    """``kdpm2a`` (utils_eval.py:99-100): same trajectory as the independent restatement given the same per-step noise; sigma_down^2 +
+    sigma_up^2 = sigma_next^2 (the marginal noise level of an ancestral step); with zero fresh noise and the exact model the state
+    after a step is x0 + sigma_down * noise."""
+    from aqualora_amd.ksamplers import ancestral_step, k_sample_core, k_schedule
+    from aqualora_amd.watermark import sd15_alphas_cumprod
+    torch.manual_seed(1)
+    ts, sig = k_schedule(12)
+    ts_o, sig_o = O.k_sigmas_oracle(12, sd15_alphas_cumprod().double())
+    for i in range(12):
+        d, u = ancestral_step(float(sig[i]), float(sig[i + 1]))
+        assert abs(d * d + u * u - float(sig[i + 1]) ** 2) < 1e-12 * max(1.0, float(sig[i + 1]) ** 2) and 0 <= d <= float(sig[i + 1])
+    x0 = torch.randn(2, 4, 8, 8, dtype=torch.float64)
+    n0 = torch.randn_like(x0)
+    x = x0 + float(sig[0]) * n0
+    g = torch.Generator().manual_seed(2)
+    noises = [torch.randn(2, 4, 8, 8, dtype=torch.float64, generator=g) for _ in range(12)]
+    f = lambda x_, s, t: torch.tanh(x_ / (1 + s)) * (1 + 0.1 * s)   # noqa: E731
+    a = k_sample_core(f, x, ts, sig, "kdpm2a", noise_fn=lambda i, x_: noises[i])
+    f.noise = lambda i, x_: noises[i]
+    b = O.k_sample_oracle(f, x, ts_o, sig_o, "kdpm2a")
+    assert float((a - b).abs().max() / b.abs().max()) < 1e-9
+    one = k_sample_core(lambda x_, s, t: (x_ - x0) / s, x, ts[:1], sig[:2], "kdpm2a", noise_fn=lambda i, x_: torch.zeros_like(x_))
+    assert float((one - (x0 + ancestral_step(float(sig[0]), float(sig[1]))[0] * n0)).abs().max()) < 1e-9
+    with pytest.raises(ValueError):
+        k_sample_core(f, x, ts, sig, "kdpm2a")
+
+
+@pytest.mark.gpu
+def test_pndm_hip_vs_oracle_tiny_unet():
+    """PLMS on the HIP tiny U-Net against the oracle's phase-by-phase loop driving the same U-Net."""
+    from aqualora_amd.ksamplers import pndm_sample
+    from tests.common import T, TINY, tiny_unet
+    dev = "cuda"
+    unet = tiny_unet(dev, torch.bfloat16)
+    ctx = T("p.ctx", (1, 77, TINY["cross_attention_dim"]), device=dev)
+    unc = torch.zeros_like(ctx)
+    lat = T("p.lat", (1, 4, 16, 16), device=dev)
+    got = pndm_sample(unet, ctx, unc, lat, 6, 3.0)
+
+    def eps(x, t):
+        tt = torch.full((2,), int(t), dtype=torch.long, device=dev)
+        xin = x.to(dev).float().contiguous()
+        e = unet(torch.cat([xin, xin]), tt, torch.cat([unc, ctx]).to(torch.bfloat16),
+                 cross_attention_kwargs={"scale": None}).sample.float().cpu()
+        return e[:1] + 3.0 * (e[1:] - e[:1])
+    with torch.no_grad():
+        want = O.plms_oracle(eps, lat.cpu().float(), 6, O.alphas_cumprod().double())
+    assert torch.isfinite(got).all()
+    assert float((got.cpu() - want).abs().max() / want.abs().max()) < 2e-2
