@@ -118,6 +118,7 @@ SIGNATURES = {
     "aql_sdpa_bwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p,
                      c_p, c_p, c_sz, c_p],
     "aql_abi_version": [],
+    "aql_comm_available": [],
     "aql_comm_unique_id": [c_p],
     "aql_comm_init": [c_p, c_i, c_i, c_p],
     "aql_comm_size": [c_p],

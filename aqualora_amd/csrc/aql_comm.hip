@@ -11,11 +11,19 @@
 // Host code only -- the collectives' kernels are RCCL's (xGMI rings/trees); there is no device code of ours in this file.
 #include "aql_common.h"
 #include <dlfcn.h>
-#include <rccl/rccl.h>
-
-#define AQL_ABI_VERSION 3   // bump when an existing entry point changes its signature (include/aqualora_hip.h)
+#include "../../include/aqualora_abi.h"   // AQL_ABI_VERSION: the ONE definition (include/aqualora_hip.h includes the same file)
 
 extern "C" int aql_abi_version(void) { return AQL_ABI_VERSION; }
+
+// The handful of RCCL (NCCL API 2.x) types this file passes through, declared here so that the library builds without RCCL's
+// headers: RCCL is a run-time dependency only (dlopen below).  Values from the published nccl.h ABI, which RCCL keeps.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclUint8 = 1, ncclFloat32 = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclAvg = 4 } ncclRedOp_t;
+}
 
 namespace {
 
@@ -76,6 +84,11 @@ int rccl_status(ncclResult_t r, const char* what) {
 }
 
 }  // namespace
+
+// 1 when RCCL and every entry point used here resolve in this process, else 0 (reason in aql_last_error).  A count-like answer,
+// not a status: the host side lets all ranks agree on it BEFORE anyone enters the collective aql_comm_init, so that a rank whose
+// dlopen fails cannot leave the others blocked inside ncclCommInitRank.
+extern "C" int aql_comm_available(void) { return rccl_load() ? 1 : 0; }
 
 // 128 opaque bytes that identify one communicator; rank 0 creates them, the host side hands them to every rank (any side
 // channel: the launcher's TCP store, an MPI broadcast ...), then every rank calls aql_comm_init with the same bytes.

@@ -654,16 +654,72 @@ extern "C" int aql_lora_down(const bf16_t* X, long ldx, long M, int K, const bf1
   return aql_lora_ds(T, Tref, (int)(M / rows_per_sample), rows_per_sample, r, dS, stream);
 }
 
-// Deep-K / few-rows form of the rank-32 down product (M <= ~2048, K >= 2048: the backward-data pass of ff.net.0 at the 16x16 and
-// 8x8 levels contracts over 10240 features with 1024 / 256 rows).  The 16-row workgroups of lora_down_skinny_kernel are then
-// too few to fill the chip (64 / 16 workgroups: 26 us for 21 MB), so the K range is cut into `ks` pieces (grid.y): every
-// workgroup writes its fp32 partial [16][32] to `part` [ks][M][32], takes a ticket on the row block's counter, and the LAST
-// arrival adds the pieces in piece order (deterministic) and writes T / Ts.  The counters are zero before the launch and are
-// left zero by it.  Release / acquire fences around the ticket: the pieces come from other XCDs' L2s.
+// Split-K form of the rank-32 down product for few rows under a deep contraction (M <= ~2048, K >= 2048: the backward-data pass
+// of ff.net.0 at the 16x16 and 8x8 levels contracts over 10240 features with 1024 / 256 rows; the 16-row workgroups of
+// lora_down_skinny_kernel are then too few to fill the chip -- 64 / 16 workgroups: 26 us for 21 MB): the K range is cut into `ks`
+// pieces (grid.y), workgroup (row block, piece) reduces its K range and writes its fp32 partial [16][32] to `part` [ks][M][32]; the pieces are then added IN PIECE ORDER (deterministic) and
+// T / Ts written -- by a second launch (default: `lora_down_splitk_finalize_kernel`, ordered by the kernel boundary, no
+// inter-workgroup communication at all), or, TICKET = true (AQL_DOWN_TICKET=1, a tuning build of the same entry point), by the
+// last workgroup of the row block to take a ticket on `counters` (zero before the launch, left zero by it).
+//
+// The ticket form and the memory model.  Every exchanged word is written with a device-scope relaxed atomic store
+// (`global_store ... sc1`: written through to memory, not left dirty in the writing XCD's L2), read with a device-scope relaxed atomic
+// load (`global_load ... sc1`: not served from the reading XCD's L2), and the ticket is taken after `s_waitcnt vmcnt(0)`, i.e.
+// after the write-through stores have been acknowledged.  That is the code sequence LLVM's AMDGPU memory model itself emits for an
+// agent-scope release on gfx942 / gfx950 MINUS the `buffer_wbl2 sc1` that writes back every OTHER dirty line of the L2 (which is
+// what makes the fenced form cost 50-65 us here: 512 workgroups each flushing an L2 full of the previous kernels' outputs).  In
+// the HIP / C++ model the accesses are all atomic (no data race) but relaxed, so visibility of the pieces to the ticket holder
+// is a property of this hardware's sc1 path, not of the language: hence opt-in, guarded to the gfx94x / gfx950 ISAs below, and
+// stress-tested (tests/test_gpu_kernels.py: 2000 launches on rotating inputs over stale scratch, bit-compared with the
+// two-launch form).
+__device__ __forceinline__ void splitk_sum_rows(const float* __restrict__ part, int ks, long M, long rowblock, const bf16_t* __restrict__ S,
+                                                int rps, bf16_t* __restrict__ T, bf16_t* __restrict__ Ts, bool coherent) {
+  if (threadIdx.x < 128) {   // 16 rows x 8 groups of 4 rank columns
+    const int r16 = threadIdx.x >> 3, c = (threadIdx.x & 7) * 4;
+    const long m = rowblock * 16 + r16;
+    if (m < M) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int p0 = 0; p0 < ks; p0 += 8) {   // eight pieces in flight (each load is a round trip to memory), added in piece order
+        float u[8][4];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float* src = part + ((long)min(p0 + q, ks - 1) * M + m) * 32 + c;
+          if (coherent) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[q][e] = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            const float4 w = *reinterpret_cast<const float4*>(src);
+            u[q][0] = w.x, u[q][1] = w.y, u[q][2] = w.z, u[q][3] = w.w;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (p0 + q < ks) v.x += u[q][0], v.y += u[q][1], v.z += u[q][2], v.w += u[q][3];
+      }
+      const uint2 t = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+      *reinterpret_cast<uint2*>(T + m * 32 + c) = t;
+      const uint2 sv = *reinterpret_cast<const uint2*>(S + (m / rps) * 32 + c);
+      *reinterpret_cast<uint2*>(Ts + m * 32 + c) =
+          make_uint2(pack_bf16x2(bf16lo(t.x) * bf16lo(sv.x), bf16hi(t.x) * bf16hi(sv.x)),
+                     pack_bf16x2(bf16lo(t.y) * bf16lo(sv.y), bf16hi(t.y) * bf16hi(sv.y)));
+    }
+  }
+}
+
+__global__ __launch_bounds__(128) void lora_down_splitk_finalize_kernel(const float* __restrict__ part, int ks, long M,
+                                                                        const bf16_t* __restrict__ S, int rps, bf16_t* __restrict__ T,
+                                                                        bf16_t* __restrict__ Ts) {
+  splitk_sum_rows(part, ks, M, blockIdx.x, S, rps, T, Ts, false);
+}
+
+template <bool TICKET>
 __global__ __launch_bounds__(256) void lora_down_splitk_kernel(const bf16_t* __restrict__ X, long ldx, long M, int K, int kchunk,
                                                                const bf16_t* __restrict__ A, const bf16_t* __restrict__ S,
                                                                int rps, bf16_t* __restrict__ T, bf16_t* __restrict__ Ts,
                                                                float* __restrict__ part, int* __restrict__ counters) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+  static_assert(!TICKET, "the fence-free ticket form relies on the sc1 write-through / read-around path of gfx942 / gfx950");
+#endif
   constexpr int RF = 2;
   __shared__ f32x4_t red[4][RF][64];
   __shared__ int s_last;
@@ -715,15 +771,19 @@ __global__ __launch_bounds__(256) void lora_down_splitk_kernel(const bf16_t* __r
       const f32x4_t u = red[w][wave][lane];
       v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
     }
-    if (ok) {   // device-scope (sc1, write-through) stores: the piece is in memory, not dirty in this XCD's L2
+    if (ok) {
       float* dst = part + ((long)piece * M + row) * 32 + wave * 16 + g * 4;
+      if constexpr (TICKET) {   // device-scope (sc1, write-through) stores: the piece is in memory, not dirty in this XCD's L2
 #pragma unroll
-      for (int e = 0; e < 4; ++e) __hip_atomic_store(dst + e, v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int e = 0; e < 4; ++e) __hip_atomic_store(dst + e, v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+      }
     }
   }
-  // No fence: a device-scope release fence writes back the WHOLE L2 (buffer_wbl2) -- measured 50-65 us for this kernel with
-  // 512 workgroups doing it.  The pieces are the only data exchanged, they are written through (above) and read around the
-  // L2 (below); the wait makes every wavefront's stores complete before the workgroup's ticket is taken.
+  if constexpr (!TICKET) return;   // the finalize launch adds the pieces
+  // No fence (see the comment above the kernel): the pieces are the only data exchanged, they are written through (above) and
+  // read around the L2 (splitk_sum_rows, coherent); the wait makes every wavefront's stores complete before the ticket is taken.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -733,31 +793,7 @@ __global__ __launch_bounds__(256) void lora_down_splitk_kernel(const bf16_t* __r
   }
   __syncthreads();
   if (!s_last) return;
-  if (threadIdx.x < 128) {   // 16 rows x 8 groups of 4 rank columns
-    const int r16 = threadIdx.x >> 3, c = (threadIdx.x & 7) * 4;
-    const long m = (long)blockIdx.x * 16 + r16;
-    if (m < M) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int p0 = 0; p0 < ks; p0 += 8) {   // eight pieces in flight (each load is a round trip to memory), added in piece order
-        float u[8][4];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const float* src = part + ((long)min(p0 + q, ks - 1) * M + m) * 32 + c;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) u[q][e] = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-          if (p0 + q < ks) v.x += u[q][0], v.y += u[q][1], v.z += u[q][2], v.w += u[q][3];
-      }
-      const uint2 t = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
-      *reinterpret_cast<uint2*>(T + m * 32 + c) = t;
-      const uint2 sv = *reinterpret_cast<const uint2*>(S + (m / rps) * 32 + c);
-      *reinterpret_cast<uint2*>(Ts + m * 32 + c) =
-          make_uint2(pack_bf16x2(bf16lo(t.x) * bf16lo(sv.x), bf16hi(t.x) * bf16hi(sv.x)),
-                     pack_bf16x2(bf16lo(t.y) * bf16lo(sv.y), bf16hi(t.y) * bf16hi(sv.y)));
-    }
-  }
+  splitk_sum_rows(part, ks, M, blockIdx.x, S, rps, T, Ts, true);
 }
 
 // aql_lora_down for rank 32 with the K range split over workgroups when the row count alone cannot fill the chip; `part`
@@ -781,8 +817,17 @@ extern "C" int aql_lora_down_splitk(const bf16_t* X, long ldx, long M, int K, co
   if (ks <= 1) return aql_lora_down(X, ldx, M, K, Adown, r, S, rows_per_sample, T, Ts, nullptr, nullptr, stream);
   int kchunk = ((K / 32 + ks - 1) / ks) * 32;
   ks = (K + kchunk - 1) / kchunk;            // no empty pieces
-  hipLaunchKernelGGL(lora_down_splitk_kernel, dim3((unsigned)rb, (unsigned)ks), dim3(256), 0, stream, X, ldx, M, K, kchunk, Adown,
-                     S, rows_per_sample, T, Ts, part, counters);
+  const char* tk = getenv("AQL_DOWN_TICKET");   // tuning hook, read per call (tests flip it): one launch, last arrival adds
+  const bool ticket = tk != nullptr && tk[0] == '1';
+  if (ticket) {
+    hipLaunchKernelGGL(lora_down_splitk_kernel<true>, dim3((unsigned)rb, (unsigned)ks), dim3(256), 0, stream, X, ldx, M, K, kchunk,
+                       Adown, S, rows_per_sample, T, Ts, part, counters);
+  } else {
+    hipLaunchKernelGGL(lora_down_splitk_kernel<false>, dim3((unsigned)rb, (unsigned)ks), dim3(256), 0, stream, X, ldx, M, K, kchunk,
+                       Adown, S, rows_per_sample, T, Ts, part, counters);
+    hipLaunchKernelGGL(lora_down_splitk_finalize_kernel, dim3((unsigned)rb), dim3(128), 0, stream, part, ks, M, S, rows_per_sample,
+                       T, Ts);
+  }
   AQL_CHECK_LAUNCH("aql_lora_down_splitk");
   return AQL_OK;
 }

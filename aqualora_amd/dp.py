@@ -116,12 +116,18 @@ class AqlComm:
         else:
             self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         idbuf = ctypes.create_string_buffer(128)
+        err = ""
         if self.rank == 0:
-            L.call("aql_comm_unique_id", idbuf)
-        box = [bytes(idbuf.raw)]
+            try:
+                L.call("aql_comm_unique_id", idbuf)
+            except L.AqlError as e:   # must reach every rank: the others are about to wait in the broadcast below
+                err = str(e)
+        box = [bytes(idbuf.raw), err]
         if self.world > 1:
             src = dist.get_global_rank(group, 0) if group is not None else 0
             dist.broadcast_object_list(box, src=src, group=group)
+        if box[1]:
+            raise L.AqlError(f"aql_comm_unique_id failed on rank 0: {box[1]}")
         self._id = ctypes.create_string_buffer(box[0], 128)
         self.handle = ctypes.c_void_p()
         L.call("aql_comm_init", self._id, self.world, self.rank, ctypes.byref(self.handle))
@@ -211,11 +217,15 @@ class AqlComm:
 
 def make_comm(group=None):
     """The communicator of the captured / overlapped exchange, or (None, reason) when it is not to be used: no exchange active,
-    a non-RCCL backend (the gloo CPU tests), AQL_COMM=0, or a failed self-test."""
+    a non-RCCL backend (the gloo CPU tests), no AQL_COMM=1, or a failed self-test.
+
+    OPT-IN (AQL_COMM=1) since round 4: the captured, hook-driven exchange has only ever run on single-rank communicators (1-GPU
+    development boxes; the world-size-2 protocol test runs over gloo).  Until a run on >= 2 GPUs has compared its parameters and
+    gradients with the torch.distributed exchange, the default data-parallel path is the bucketed torch.distributed one."""
     if not exchange_active(group):
         return None, "no exchange (single rank)"
-    if os.environ.get("AQL_COMM", "1") == "0":
-        return None, "AQL_COMM=0"
+    if os.environ.get("AQL_COMM", "0") != "1":
+        return None, "AQL_COMM != 1 (the captured aql_comm_* exchange is opt-in until validated on >= 2 GPUs)"
     if dist.get_backend(group) != "nccl" or not torch.cuda.is_available():
         return None, f"backend {dist.get_backend(group)}"
     if group in _COMMS:                 # one communicator (and one self-test) per process group
@@ -227,23 +237,41 @@ def make_comm(group=None):
 _COMMS = {}
 
 
+def _agree(ok, group):
+    """MIN over ranks of a local yes / no, through the launcher's torch.distributed group."""
+    flag = torch.tensor([1.0 if ok else 0.0], device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return flag.item() >= 1.0
+
+
 def _make_comm(group):
     comm, ok, why = None, False, ""
+    # (1) every rank must be able to bind RCCL BEFORE anyone enters the collective ncclCommInitRank: a rank whose dlopen / dlsym
+    # fails would otherwise leave the others blocked inside it, out of reach of the agreement below.
+    from . import _lib as L
+    try:
+        have = L.call_raw("aql_comm_available") == 1
+        if not have:
+            why = "RCCL not loadable: " + L.load().aql_last_error().decode("utf-8", "replace")
+    except Exception as e:   # noqa: BLE001
+        have, why = False, f"{type(e).__name__}: {e}"
+    if not _agree(have, group):
+        return None, f"RCCL unavailable ({why or 'on another rank'})"
     try:
         comm = AqlComm(group)
         ok, why = comm.self_test()
     except Exception as e:   # noqa: BLE001
         why = f"aql_comm_init failed: {e}"
     # every rank must take the same decision: a rank that fell back alone would wait in a torch.distributed collective forever
-    flag = torch.tensor([1.0 if ok else 0.0], device="cuda")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if flag.item() < 1.0:
+    if not _agree(ok, group):
         if comm is not None:
             try:
-                comm.abort()
+                comm.abort()     # also takes a captured all-reduce that the self-test's deadline left in flight down with it
             except Exception:   # noqa: BLE001
                 pass
         return None, f"self-test failed ({why or 'on another rank'})"
+    import atexit
+    atexit.register(comm.destroy)    # ncclCommDestroy at interpreter exit (a trainer may also call comm.destroy() itself)
     return comm, "ok"
 
 

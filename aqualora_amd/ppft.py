@@ -62,10 +62,11 @@ class PPFTTrainer:
         self.bank = LoraBank(unet, extra_params=[mapper.bit_embeddings.weight])
         self.pg = process_group
         # Our own RCCL communicator (aql_comm_*, include/aqualora_hip.h): collectives on a stream of OUR choice, capturable
-        # into the step graph.  None on a single GPU, under a non-RCCL backend (gloo CPU tests), with AQL_COMM=0, or when its
+        # into the step graph.  None on a single GPU, under a non-RCCL backend (gloo CPU tests), without AQL_COMM=1 (opt-in), or when its
         # self-test fails on this box -- then the torch.distributed exchange below is used (`comm_note` says which and why).
         self.comm, self.comm_note = dp.make_comm(process_group)
-        self.overlap = self.comm is not None
+        # the overlapped exchange runs ONE backward pass per step: micro-batched steps use the bucketed torch.distributed exchange
+        self.overlap = self.comm is not None and max(1, micro_batches) == 1
         # DDP broadcasts rank 0's parameters when it wraps the trainable modules (accelerator.prepare,
         # ppft_train.py:905-912).  inject_lora draws N(0, 1/r) and MapperNet an orthogonal table from each process's own
         # RNG (the reference default is seed=None): without this sync every rank would train a different replica on
@@ -97,8 +98,6 @@ class PPFTTrainer:
         self.bucketed = (not self.overlap and dp.exchange_active(process_group)
                          and dp.bucket_count(4 * self.bank.n_lora) > 1)
         self.reducer = dp.BucketedAllreduce(process_group)
-        if self.overlap and max(1, micro_batches) != 1:
-            raise L.AqlError("the overlapped exchange runs one backward pass per step (micro_batches = 1)")
         # `split`: the weight-gradient GEMMs of the up path are launched from the backward hook on the mid-block output, so that
         # the all-reduce of their region (forked onto the side stream) runs under the mid / down backward.  The GEMMs themselves
         # stay on the main stream: on a side stream, concurrent with backward, they cost the step +0.53 ms (23.33 -> 23.86 ms, A/B
@@ -244,6 +243,15 @@ class PPFTTrainer:
             return None
         E = self.mapper.bit_embeddings.weight
         bits, r = E.shape
+        # raw pointers go to the kernel: everything it indexes must be on this device, dense, and of the width it assumes
+        # (acp[t[b]] and E[bit] are read unchecked) -- anything else takes the generic path, which validates / converts
+        if not (t.is_cuda and t.is_contiguous() and msg.is_cuda and msg.shape[0] == B and msg.shape[1] == bits and z.is_cuda
+                and eps.is_cuda and ctx.is_cuda and eps.shape == z.shape and E.is_cuda and E.is_contiguous()
+                and E.dtype == torch.float32):
+            return None
+        from .lora import _packed_conv3
+        if _packed_conv3(self.unet.conv_in).Cin != 8:     # the kernel writes the twin latents at conv_in's packed width of 8
+            return None
         dev = z.device
         HW = z.shape[2] * z.shape[3]
         dim = cfg.block_out_channels[0]

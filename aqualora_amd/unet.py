@@ -489,7 +489,9 @@ class UNet2DConditionModel(nn.Module):
         if not torch.is_tensor(timestep):
             timestep = torch.tensor([timestep], device=sample.device)
         timestep = timestep.reshape(-1).expand(sample.shape[0])
-        if not (sample.dtype == self.dtype and ops.is_cpad(sample, 8)):
+        # a channel-padded twin view (ops.register_cpad) passes through only at the width conv_in's packed weights expect --
+        # the same test Conv3x3Fn makes; any other layout is made channels-last here (and re-registered by make_twin's callers)
+        if not (sample.dtype == self.dtype and ops.is_cpad(sample, _packed_conv3(self.conv_in).Cin)):
             sample = ops.as_cl(sample.to(self.dtype))
         if _aql_t_emb is not None:
             t_emb = _aql_t_emb

@@ -380,6 +380,7 @@ int aql_lpips_layer_bwd(const bf16_t* f0, const bf16_t* f1, const float* w, int 
  * accelerator.backward (:1058); aql_comm_all_gather also serves the logged-loss gather (:1054).  Every collective is enqueued
  * on the CALLER's stream: it can sit on a forked side stream under the rest of backward and be captured into the step's
  * hipGraph.  RCCL is bound at run time (dlopen librccl.so.1: the instance PyTorch-ROCm already loaded, when there is one).
+ *   aql_comm_available   1 if RCCL resolves in this process (agreed across ranks before the collective init), else 0
  *   aql_comm_unique_id   rank 0: 128 opaque bytes, handed to every rank by the launcher's side channel
  *   aql_comm_init        collective: communicator of the current HIP device  ->  *comm
  *   aql_comm_size        number of ranks (or -1): a count, not a status
@@ -390,8 +391,9 @@ int aql_lpips_layer_bwd(const bf16_t* f0, const bf16_t* f1, const float* w, int 
  *   aql_comm_abort / aql_comm_destroy
  * aql_abi_version: AQL_ABI_VERSION of the built library; bumped when an existing entry point changes its signature
  * (round 2 inserted `lora_row0` into aql_lora_gemm_fused): a binding built against another version must refuse to load.   */
-#define AQL_ABI_VERSION 3
+#include "aqualora_abi.h" /* AQL_ABI_VERSION */
 int aql_abi_version(void);
+int aql_comm_available(void);
 int aql_comm_unique_id(void* id128);
 int aql_comm_init(const void* id128, int nranks, int rank, void** comm);
 int aql_comm_size(void* comm);

@@ -36,8 +36,8 @@ def main():
         batch = dict(z=inp["z"], msg=inp["msg"], eps=inp["eps"], t=inp["t"], ctx=inp["ctx"].to(torch.bfloat16))
         res = {}
         # plain: single-GPU form.  overlap_*: our RCCL communicator (aql_comm_*), collectives forked onto a side stream from the
-        # backward hook and captured into the ONE step graph.  bucketed_*: the torch.distributed form (AQL_COMM=0), bucket
-        # graphs with eager collectives between them -- the fallback when the communicator's self-test fails.
+        # backward hook and captured into the ONE step graph.  bucketed_*: the torch.distributed form (the default without AQL_COMM=1), bucket
+        # graphs with eager collectives between them -- also the fallback when the communicator's self-test fails.
         for mode in ("plain", "overlap_eager", "overlap_graph", "bucketed_eager", "bucketed_graph"):
             os.environ.pop("AQL_FORCE_ALLREDUCE", None)
             os.environ.pop("AQL_COMM", None)
@@ -45,8 +45,8 @@ def main():
             if mode != "plain":
                 os.environ["AQL_FORCE_ALLREDUCE"] = "1"
                 os.environ["AQL_BUCKETS"] = "3"     # the tiny bank is far below the size where bucketing switches on
-            if mode.startswith("bucketed"):
-                os.environ["AQL_COMM"] = "0"
+            if mode.startswith("overlap"):
+                os.environ["AQL_COMM"] = "1"        # opt-in (dp.make_comm): the captured aql_comm_* exchange
             tr = build(rank, inp)
             assert tr.bucketed == mode.startswith("bucketed"), (mode, tr.bucketed, tr.comm_note)
             assert tr.overlap == mode.startswith("overlap"), (mode, tr.overlap, tr.comm_note)

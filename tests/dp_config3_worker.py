@@ -3,7 +3,7 @@ end to end at FULL size through the data-parallel form of the step.  A single-ra
 the trainer into the form every rank of the 8-GPU recipe runs (train/README.md:34-48, ppft_train.py:1058): the wide-rank
 weight-gradient GEMMs are held back and cut into exchange buckets of the 543 MB gradient buffer -- by default the overlapped
 exchange through aql_comm_* (up-path buckets forked from the backward hook, the rest behind the last weight-gradient launch,
-captured into ONE step graph); with AQL_COMM=0 the torch.distributed fallback (8 bucket graphs, eager collectives).
+captured into ONE step graph); with AQL_COMM=0 the torch.distributed form (8 bucket graphs, eager collectives).
 
 Samples are independent, so ONE batch-8 twin step must equal the mean of eight batch-1 steps (the batch-1 step at rank 320 is
 pinned to the CPU oracle by test_full_size_ppft_gradients_vs_oracle[320]).  Shapes that only exist here: conv_row_kernel<32,8>,
@@ -125,6 +125,7 @@ if __name__ == "__main__":
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29549")
     os.environ["AQL_FORCE_ALLREDUCE"] = "1"
+    os.environ.setdefault("AQL_COMM", "1")     # the overlapped aql_comm_* exchange (opt-in); AQL_COMM=0 tests the fallback
     dist.init_process_group("nccl", rank=0, world_size=1)
     torch.cuda.set_device(0)
     try:

@@ -21,42 +21,69 @@ def main():
     from aqualora_amd.unet import lora_keys
     from aqualora_amd.watermark import MapperNet, SecretEncoder
     from tests.common import TINY_RANK, ppft_inputs, tiny_unet
-    torch.manual_seed(1000 + rank)             # every rank draws its OWN LoRA / mapper initialisation
-    unet = tiny_unet(dev, torch.bfloat16)
-    inject_lora(unet, TINY_RANK, lora_keys(unet))
-    with torch.no_grad():                       # diffusers initialises up = 0: make the branch live
-        for m in unet.modules():
-            if hasattr(m, "up") and hasattr(m, "down"):
-                m.up.weight.normal_(0, 0.05)
-    mapper = MapperNet(48, TINY_RANK)
-    first = torch.cat([p.detach().float().reshape(-1).to(dev) for p in unet.parameters() if p.requires_grad][:4])
-    gathered = [torch.zeros_like(first) for _ in range(world)]
-    dist.all_gather(gathered, first)
-    differs = not torch.equal(gathered[0], gathered[1])
-    tr = PPFTTrainer(unet, mapper, SecretEncoder(48, base_res=8, resolution=16), TINY_RANK, learning_rate=1e-3)
 
-    def same():
-        flat = tr.bank.flat.clone()
-        ref = flat.clone()
-        dist.broadcast(ref, src=0)
-        ok = torch.tensor([float(torch.equal(flat, ref))], device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        return bool(ok.item())
+    def run(comm):
+        """3 steps from rank-dependent initialisation and data under one exchange: comm = "0" the torch.distributed form (the
+        default), "1" the captured / hook-driven aql_comm_* exchange (opt-in until THIS comparison has passed on >= 2 GPUs)."""
+        os.environ["AQL_COMM"] = comm
+        os.environ["AQL_BUCKETS"] = "3"           # the tiny bank is far below the size where bucketing switches on
+        torch.manual_seed(1000 + rank)             # every rank draws its OWN LoRA / mapper initialisation
+        unet = tiny_unet(dev, torch.bfloat16)
+        inject_lora(unet, TINY_RANK, lora_keys(unet))
+        with torch.no_grad():                       # diffusers initialises up = 0: make the branch live
+            for m in unet.modules():
+                if hasattr(m, "up") and hasattr(m, "down"):
+                    m.up.weight.normal_(0, 0.05)
+        mapper = MapperNet(48, TINY_RANK)
+        first = torch.cat([p.detach().float().reshape(-1).to(dev) for p in unet.parameters() if p.requires_grad][:4])
+        gathered = [torch.zeros_like(first) for _ in range(world)]
+        dist.all_gather(gathered, first)
+        differs = not torch.equal(gathered[0], gathered[1])
+        tr = PPFTTrainer(unet, mapper, SecretEncoder(48, base_res=8, resolution=16), TINY_RANK, learning_rate=1e-3)
 
-    eq0 = same()
-    start = tr.bank.flat.clone()
-    for i in range(3):
-        inp = ppft_inputs(device=dev)
-        s = 7000 + 13 * rank + i                # rank-dependent data
-        tr.step(synth.normal("w.z", inp["z"].shape, 1.0, s, dev), synth.bits("w.msg", inp["msg"].shape, s, dev),
-                synth.normal("w.eps", inp["eps"].shape, 1.0, s, dev), synth.randint("w.t", inp["t"].shape, 1000, s, dev),
-                synth.normal("w.ctx", inp["ctx"].shape, 1.0, s, dev).to(torch.bfloat16))
-    torch.cuda.synchronize()
-    eq3 = same()
-    moved = bool((tr.bank.flat - start).abs().max().item() > 0)
+        def same():
+            flat = tr.bank.flat.clone()
+            ref = flat.clone()
+            dist.broadcast(ref, src=0)
+            ok = torch.tensor([float(torch.equal(flat, ref))], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            return bool(ok.item())
+
+        eq0 = same()
+        start = tr.bank.flat.clone()
+        grads = None
+        for i in range(3):
+            inp = ppft_inputs(device=dev)
+            s = 7000 + 13 * rank + i                # rank-dependent data
+            batch = (synth.normal("w.z", inp["z"].shape, 1.0, s, dev), synth.bits("w.msg", inp["msg"].shape, s, dev),
+                     synth.normal("w.eps", inp["eps"].shape, 1.0, s, dev), synth.randint("w.t", inp["t"].shape, 1000, s, dev),
+                     synth.normal("w.ctx", inp["ctx"].shape, 1.0, s, dev).to(torch.bfloat16))
+            if i == 0:      # the exchanged (mean) gradient of the first step, before the optimizer consumes it
+                if tr.split:
+                    tr.forward_backward(*batch)
+                elif tr.bucketed:
+                    tr.forward_backward(*batch, flush_dw=False)
+                    tr.exchange_bucketed(tr.plan_exchange(), tr.deferred.run_bucket)
+                    tr.deferred.reset()
+                else:
+                    tr.forward_backward(*batch)
+                    tr.exchange_gradients()
+                grads = tr.bank.grad[:tr.bank.numel].clone()
+                tr.bank.zero_grad()
+            tr.step(*batch)
+        torch.cuda.synchronize()
+        return dict(differs=differs, eq0=eq0, eq3=same(), moved=bool((tr.bank.flat - start).abs().max().item() > 0),
+                    overlap=bool(tr.overlap), note=tr.comm_note, flat=tr.bank.flat.clone(), grads=grads)
+
+    a, b = run("0"), run("1")
+    rel = lambda x, y: float((x - y).abs().max() / y.abs().max().clamp_min(1e-30))   # noqa: E731
     if rank == 0:
-        print(json.dumps({"world": world, "rccl_ranks_seen": int(one.item()), "init_differs_before_broadcast": differs,
-                          "params_equal_after_init": eq0, "params_equal_after_steps": eq3, "params_moved": moved}), flush=True)
+        print(json.dumps({"world": world, "rccl_ranks_seen": int(one.item()), "init_differs_before_broadcast": a["differs"],
+                          "params_equal_after_init": a["eq0"] and b["eq0"], "params_equal_after_steps": a["eq3"] and b["eq3"],
+                          "params_moved": a["moved"] and b["moved"], "overlap_used": b["overlap"], "overlap_note": b["note"],
+                          "default_is_overlap": a["overlap"],
+                          "aql_comm_vs_torch_dist_grad_relerr": rel(b["grads"], a["grads"]),
+                          "aql_comm_vs_torch_dist_param_relerr": rel(b["flat"], a["flat"])}), flush=True)
     dist.destroy_process_group()
 
 

@@ -32,7 +32,11 @@ def test_header_matches_binding_and_library():
         assert name in decls, f"{name} bound in _lib.py but missing from include/aqualora_hip.h"
     assert set(decls) - set(bound) <= {"aql_last_error", "aql_groupnorm_scratch_floats", "aql_bn_scratch_floats", "aql_prvl_scratch_floats"}
     # the version the header declares == the one the binding was written against == the one the built library reports
-    hdr = open(os.path.join(ROOT, "include", "aqualora_hip.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "aqualora_abi.h")).read()   # the one definition (included by aqualora_hip.h and aql_comm.hip)
+    import glob
+    defs = [f for f in glob.glob(os.path.join(ROOT, "include", "*.h")) + glob.glob(os.path.join(ROOT, "aqualora_amd", "csrc", "*.*"))
+            if f.endswith((".h", ".hip", ".cuh")) and re.search(r"#define\s+AQL_ABI_VERSION", open(f).read())]
+    assert [os.path.basename(f) for f in defs] == ["aqualora_abi.h"], defs
     ver = int(re.search(r"#define\s+AQL_ABI_VERSION\s+(\d+)", hdr).group(1))
     assert ver == _lib.ABI_VERSION == lib.aql_abi_version()
     # the SURVEY section 8(b) minimum set of the exchange is exported

@@ -74,7 +74,7 @@ def test_geglu_epilogue_equals_two_kernel_path():
 
 
 def test_lora_down_splitk_equals_one_piece_sum():
-    """aql_lora_down_splitk (deep K under few rows: K range cut over workgroups, last-arrival reduction by ticket) against fp32
+    """aql_lora_down_splitk (deep K under few rows: K range cut over workgroups, pieces added in piece order by the finalize launch) against fp32
     torch and against aql_lora_down on the backward-data shapes of ff.net.0 at the 16x16 / 8x8 levels, a ragged row count and a K
     that is not a multiple of the piece size; repeated launches reuse the self-resetting counters and give identical bits."""
     from aqualora_amd import _lib as L
@@ -107,6 +107,56 @@ def test_lora_down_splitk_equals_one_piece_sum():
         L.call("aql_lora_down", L.ptr(X), K, M, K, L.ptr(A), 32, L.ptr(S), M // 2, L.ptr(T1), L.ptr(Ts1), None, None, L.stream_ptr())
         # different summation order in fp32, then one bf16 rounding: equal up to a bf16 ulp at rounding boundaries
         assert float((T.float() - T1.float()).abs().max() / ref.abs().max()) < 8e-3, (M, K)
+
+
+def test_lora_down_splitk_ticket_form_stress():
+    """The opt-in one-launch form of aql_lora_down_splitk (AQL_DOWN_TICKET=1: partials exchanged between workgroups of different XCDs
+    through sc1 stores / loads and a relaxed ticket, no fence -- see the kernel's comment) against the default two-launch form
+    (ordered by the kernel boundary): 2000 launches on four rotating inputs over scratch that still holds the PREVIOUS input's
+    partials, with a bandwidth-hungry copy running beside them; a stale or torn piece would change bits.  Every output must equal
+    the two-launch form's bit for bit, and the counters must be left zero."""
+    import os
+    from aqualora_amd import _lib as L
+    torch.manual_seed(7)
+    cnt = torch.zeros(4096, dtype=torch.int32, device="cuda")
+    ws = torch.full((32 * 2048 * 32,), float("nan"), dtype=torch.float32, device="cuda")
+    big = torch.randn(64 << 20, device="cuda")
+    big2 = torch.empty_like(big)
+    side = torch.cuda.Stream()
+    old = os.environ.pop("AQL_DOWN_TICKET", None)
+    try:
+        for M, K in ((1024, 10240), (256, 10240)):
+            Xs = [torch.randn(M, K, device="cuda").to(torch.bfloat16) for _ in range(4)]
+            A = (torch.randn(32, K, device="cuda") / 32).to(torch.bfloat16)
+            S = torch.randn(2, 32, device="cuda").to(torch.bfloat16)
+
+            def run(X):
+                T = torch.full((M, 32), float("nan"), device="cuda", dtype=torch.bfloat16)
+                Ts = T.clone()
+                L.call("aql_lora_down_splitk", L.ptr(X), K, M, K, L.ptr(A), 32, L.ptr(S), M // 2, L.ptr(T), L.ptr(Ts), L.ptr(ws),
+                       ws.numel() * 4, L.ptr(cnt), cnt.numel() * 4, L.stream_ptr())
+                return T, Ts
+
+            os.environ.pop("AQL_DOWN_TICKET", None)
+            want = [run(X) for X in Xs]
+            assert all(torch.isfinite(t.float()).all() for pair in want for t in pair)
+            assert not torch.equal(want[0][0], want[1][0])
+            os.environ["AQL_DOWN_TICKET"] = "1"
+            bad = torch.zeros((), dtype=torch.int64, device="cuda")
+            for i in range(2000):
+                if i % 50 == 0:
+                    with torch.cuda.stream(side):
+                        big2.copy_(big)
+                T, Ts = run(Xs[i % 4])
+                bad += (T.view(torch.int16) != want[i % 4][0].view(torch.int16)).sum() + \
+                    (Ts.view(torch.int16) != want[i % 4][1].view(torch.int16)).sum()
+            torch.cuda.synchronize()
+            assert int(bad) == 0, (M, K, int(bad))
+            assert int(cnt.abs().max()) == 0
+    finally:
+        os.environ.pop("AQL_DOWN_TICKET", None)
+        if old is not None:
+            os.environ["AQL_DOWN_TICKET"] = old
 
 
 def test_lora_down_skinny_every_k_step_count():

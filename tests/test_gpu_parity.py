@@ -478,6 +478,11 @@ def test_two_rank_rccl_replicas_stay_identical():
     assert res["world"] == 2 and res["rccl_ranks_seen"] == 2
     assert res["init_differs_before_broadcast"] and res["params_equal_after_init"]
     assert res["params_equal_after_steps"] and res["params_moved"], res
+    # the validation the opt-in waits for (dp.make_comm): the captured aql_comm_* exchange against the torch.distributed one, from
+    # the same initialisation and data -- exchanged gradients and parameters after three steps (fp32 atomics: last-bit noise)
+    assert res["default_is_overlap"] is False
+    if res["overlap_used"]:
+        assert res["aql_comm_vs_torch_dist_grad_relerr"] < 1e-4 and res["aql_comm_vs_torch_dist_param_relerr"] < 2e-3, res
 
 
 def test_reference_rounding_mode_matches_autocast_restatement_per_element():
