@@ -79,14 +79,18 @@ def _cfg_scale(scale, B):
 
 
 @torch.no_grad()
-def ddim_sample(unet, ctx_cond, ctx_uncond, latents, num_inference_steps=50, guidance_scale=7.5, graph=True, scale=None):
+def ddim_sample(unet, ctx_cond, ctx_uncond, latents, num_inference_steps=50, guidance_scale=7.5, graph=True, scale=None,
+                stop_after=None):
     """latents: [B,4,h,w] fp32 ~ N(0,1) (init_noise_sigma = 1 for DDIM).  Returns the final fp32 latents.
     One HIP graph holds a full guided step (U-Net on batch 2B + the DDIM update); it is replayed once per timestep with
     the timestep and the four schedule coefficients in device scalars.  ``scale``: see `_cfg_scale` (a [B, r] tensor
-    samples through the un-fused watermark LoRA with one message per image, ppft_train.py:1153-1154)."""
+    samples through the un-fused watermark LoRA with one message per image, ppft_train.py:1153-1154).  ``stop_after`` = n returns
+    after the first n steps of the schedule (tests: one guided step at full size)."""
     dev = latents.device
     acp = sd15_alphas_cumprod(device="cpu").double()
     ts = ddim_timesteps(num_inference_steps)
+    if stop_after is not None:
+        ts = ts[:int(stop_after)]
     ratio = 1000 // num_inference_steps
     x = latents.float().contiguous().clone()
     B = x.shape[0]

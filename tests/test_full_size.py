@@ -1,0 +1,93 @@
+"""Full-size holes of the parity suite (round-3 review): the SD-1.5 VAE DECODER at 64x64x4 -> 512x512, one classifier-free-guided
+DDIM step of the fused-LoRA full-size U-Net (BASELINE config 4's inner loop), and the train-mode SecretDecoder at the config-5 shape
+(batch 16 at 512x512).  Each against the CPU oracle on the same by-name inputs; the oracle work is a few tens of seconds per test."""
+import os
+
+import pytest
+import torch
+
+from aqualora_amd import synth
+from tests.test_gpu_parity import DEV, decoder_training_step_parity, l2rel, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _threads():
+    torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
+
+
+def test_vae_full_size_decoder_vs_oracle():
+    """AutoencoderKL.decode at full width and full size (post_quant_conv, mid block with the 4096-token single-head attention, four up
+    blocks with the folded nearest-x2 upsamples, GroupNorm + SiLU + conv_out): 1x4x64x64 scaled latents -> 1x3x512x512."""
+    from aqualora_amd.vae import SD15_VAE, AutoencoderKL, synthetic_state_dict
+    from oracle.vae_oracle import VAEOracle
+    _threads()
+    sd = synthetic_state_dict(SD15_VAE)
+    vae = AutoencoderKL(sd, SD15_VAE, DEV)
+    z = synth.normal("vaefull.z", (1, 4, 64, 64), 0.18215 * 4.0, 13)
+    img = vae.decode(z.to(DEV))
+    assert img.shape == (1, 3, 512, 512) and torch.isfinite(img).all()
+    with torch.no_grad():
+        ref = VAEOracle(sd, SD15_VAE, bf16=True).decode(z)
+    assert relerr(img, ref) < 3e-2 and l2rel(img, ref) < 2e-2, (relerr(img, ref), l2rel(img, ref))
+    assert torch.equal(vae.decode(z.to(DEV)), img)       # deterministic
+
+
+def test_full_size_guided_ddim_step_of_the_fused_unet_vs_oracle():
+    """BASELINE config 4's inner loop at full size: the rank-32 watermark LoRA baked with a message (create_wm_lora.py:24-41) and
+    fused into W (utils_eval.py:81-82), then ONE captured guided step of `ddim_sample` (U-Net on the CFG batch of 2 + aql_ddim_step,
+    first timestep of the 50-step schedule, t = 981 -> 961, guidance 7.5) against the oracle U-Net on the same fused weights +
+    oracle.ddim_step.  At t = 981 the update is x' = a x + b eps_guided (a = 1.123, b = -0.123) and eps_guided = 7.5 eps_c - 6.5 eps_u amplifies the
+    U-Net's bf16 error 14x, so both the new latents and the implied guided epsilon are bounded."""
+    from aqualora_amd.checkpoint import lora_state_dict
+    from aqualora_amd.inference import create_watermark_lora, ddim_sample, fuse_lora
+    from aqualora_amd.lora import inject_lora
+    from aqualora_amd.unet import SD15, UNet2DConditionModel, init_synthetic, lora_keys
+    from aqualora_amd.watermark import MapperNet
+    from oracle import ppft_oracle as O
+    _threads()
+    rank, seed = 32, 2048
+    unet = UNet2DConditionModel(device=DEV, dtype=torch.bfloat16)
+    init_synthetic(unet, seed)
+    keys = lora_keys(unet)
+    inject_lora(unet, rank, keys)
+    with torch.no_grad():
+        for k in keys:
+            lay = unet.get_submodule(k).lora_layer
+            lay.down.weight.copy_(synth.normal(k + ".lora.down", lay.down.weight.shape, 1.0 / rank, seed, DEV))
+            lay.up.weight.copy_(synth.normal(k + ".lora.up", lay.up.weight.shape, 0.02, seed, DEV))
+    mapper = MapperNet(48, rank).to(DEV)
+    msg = synth.bits("g.msg", (1, 48), seed)
+    w_before = unet.get_submodule(keys[0]).weight.detach().clone()
+    _, baked = create_watermark_lora(lora_state_dict(unet, keys), mapper, msg)
+    fuse_lora(unet, baked, 1.0, keys)
+    assert not torch.equal(unet.get_submodule(keys[0]).weight, w_before)
+    sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items() if "lora_layer" not in k}
+    x = synth.normal("g.x", (1, 4, 64, 64), 1.0, seed)
+    ctx = synth.normal("g.ctx", (1, 77, 768), 1.0, seed)
+    unc = synth.normal("g.unc", (1, 77, 768), 1.0, seed)
+    got = ddim_sample(unet, ctx.to(DEV), unc.to(DEV), x.to(DEV), 50, 7.5, graph=True, stop_after=1).float().cpu()
+    eager = ddim_sample(unet, ctx.to(DEV), unc.to(DEV), x.to(DEV), 50, 7.5, graph=False, stop_after=1).float().cpu()
+    assert torch.equal(got, eager)                                     # captured step == eager step, bit for bit (forward only)
+    ref = O.UNetOracle(sd, dict(SD15), None, bf16=True)
+    t = torch.tensor([981])
+    with torch.no_grad():
+        eu, ec = ref.forward(x, t, unc, None), ref.forward(x, t, ctx, None)
+    want = O.ddim_step(x, eu, ec, 981, 961, 7.5)
+    acp = O.alphas_cumprod().double()
+    a, b = float((acp[961] / acp[981]).sqrt()), float((1 - acp[961]).sqrt() - (acp[961] * (1 - acp[981]) / acp[981]).sqrt())
+    eps_got, eps_want = (got - a * x) / b, (want - a * x) / b          # the implied guided epsilon
+    assert 1.0 < a < 1.2 and -0.2 < b < 0
+    e_x, e_eps = relerr(got, want), l2rel(eps_got, eps_want)
+    print(f"guided DDIM step at full size: a {a:.4f} b {b:.4f} latents max-rel {e_x:.3e}, guided eps l2rel {e_eps:.3e}")
+    assert e_x < 2.7e-2 and e_eps < 0.11, (e_x, e_eps)       # measured 1.35e-2 / 5.2e-2: bounds at 2x
+    assert l2rel(ec, eu) > 1e-3                                        # the two CFG halves do differ: guidance is exercised
+
+
+def test_secret_decoder_training_step_at_the_config5_shape():
+    """rob_enhance_finetune.py:1018-1036 at BASELINE config 5's per-GPU shape: batch 16 at 512x512 (BatchNorm reductions over
+    16x256x256 pixels, depthwise 5x5 backward at 112-192 channels) -- logits, loss, running statistics, the image gradient and >= 250
+    parameter gradients against torch autograd on the CPU restatement."""
+    _threads()
+    res = decoder_training_step_parity(16, 512, 512, grad_tol=2e-3, image_grad_tol=1e-3)   # measured 2.3e-4 / 1.7e-5
+    print("config-5 decoder step:", res)

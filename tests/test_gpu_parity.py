@@ -716,17 +716,21 @@ def test_secret_decoder_training_step_vs_oracle():
     """train()-mode EfficientNet-B1 (BatchNorm batch statistics, stochastic depth, dropout) forward, BCE loss and the
     full backward (all 301 parameter tensors + the input image) against torch autograd on the CPU restatement, with the
     random masks pinned; running statistics must move identically."""
+    decoder_training_step_parity(2, 96, 80)
+
+
+def decoder_training_step_parity(B, H, W, grad_tol=5e-2, image_grad_tol=2e-2):
     from aqualora_amd import decoder as D
     from oracle.decoder_oracle import secret_decoder_train
     torch.manual_seed(0)
-    B, bits = 2, 48
+    bits = 48
     dec = _synthetic_decoder(bits)
     sd = {k[len("model."):]: v.clone().float() for k, v in dec.state_dict().items()}
     params = {k: v.requires_grad_(True) for k, v in sd.items() if "running" not in k and "num_batches" not in k}
     nblk = 23
     sd_noise = [torch.bernoulli(torch.full((B,), 1.0 - 0.2 * i / nblk)) / (1.0 - 0.2 * i / nblk) for i in range(nblk)]
     drop = torch.bernoulli(torch.full((B, 1280), 0.8)) / 0.8
-    x = T("dect.x", (B, 3, 96, 80), 0.5).clamp(-1, 1)
+    x = T("dect.x", (B, 3, H, W), 0.5).clamp(-1, 1)
     msg = (T("dect.m", (B, bits), 1.0) > 0).long()
     target = torch.nn.functional.one_hot(msg, 2).float()
 
@@ -743,7 +747,7 @@ def test_secret_decoder_training_step_vs_oracle():
 
     assert relerr(got, want) < 2e-3, relerr(got, want)
     assert abs(loss_g.item() - loss_r.item()) < 1e-4 * max(1.0, abs(loss_r.item()))
-    assert l2rel(xg.grad, xr.grad) < 2e-2, l2rel(xg.grad, xr.grad)
+    assert l2rel(xg.grad, xr.grad) < image_grad_tol, l2rel(xg.grad, xr.grad)
     worst, n = 0.0, 0
     for name, p in dec.model.named_parameters():
         ref = params[name].grad
@@ -752,12 +756,13 @@ def test_secret_decoder_training_step_vs_oracle():
             e = l2rel(p.grad, ref)
             worst = max(worst, e)
             n += 1
-    assert n > 250 and worst < 5e-2, (n, worst)
+    assert n > 250 and worst < grad_tol, (n, worst)
     for name, b in dec.model.named_buffers():
         if "running" in name:
             assert relerr(b, sd[name]) < 1e-3, name
     dec.eval()                       # folded inference weights are rebuilt from the moved running statistics
     assert dec(x.to(DEV)).shape == (B, bits, 2)
+    return dict(logits=relerr(got, want), image_grad=l2rel(xg.grad, xr.grad), worst_param_grad=worst, n_grads=n)
 
 
 def test_distortion_maps_vs_torch():
