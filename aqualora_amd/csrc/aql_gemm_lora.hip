@@ -292,6 +292,279 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
 #endif
 }
 
+// EXPERIMENT, off by default (AQL_LORA_PERSIST / AQL_LORA_CFG=p128; measured equal or slower, see the launcher) --
+// persistent form of the 4-wave kernel for grids of several chip-wide rounds (ff.net.0 + GEGLU at the 64x64 level: 4096 tiles
+// of 128x160 = 8 rounds of two workgroups per CU).  A workgroup of the one-shot kernel spends 5-7k of its ~30k cycles before its
+// first MFMA (tile arithmetic, stager set-up, the first-touch latency of its first K tile: tools/trace_lora.py) and the same
+// again per round.  Here a workgroup walks the tiles  first, first + G, first + 2G ...  (G = grid size, round-major, each round
+// XCD-remapped like the one-shot grid), and in the LAST k-step of a tile -- where the one-shot kernel issues a zero-fill DMA
+// into the free ring stage -- it re-positions its stagers on the NEXT tile and issues that tile's first K tile instead, so
+// that it lands under the LoRA up step and the epilogue.  Two-stage ring (80 KB: two workgroups per CU); the bf16 C tile is
+// staged in two 64-row halves through the stage the last k-step used, the other stage holds the next tile's data.  Barriers in
+// the tail are raw `s_barrier`s behind `lgkmcnt(0)` only: `__syncthreads()` would drain the LDS-DMA in flight (`vmcnt(0)`).
+// Same arithmetic in the same order as lora_gemm_kernel: bit-identical outputs (tools/probe_lora_gemm.py, probe_geglu.py).
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(NTHREADS, 2) void lora_gemm_kernel_p(const GemmArgs<PlainLoader, PlainLoader> g, const PlainLoader la,
+                                                               const LoraParams lp, const int ntiles) {
+  constexpr int FM = WM / 16, FN = WN / 16;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * (BN / WN) == 4 && BM / WM == 2, "2 x 2 wavefronts: each C half belongs to one wavefront row");
+  constexpr int FT = LR / (16 * WAVES_N);
+  static_assert(FT >= 1, "at most two wavefronts along N");
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, L_BYTES = LR * 128;
+  constexpr int STAGE = A_BYTES + B_BYTES + L_BYTES;
+  constexpr int C_PITCH = (BN + 8) * 2;
+  constexpr int HB = BM / 2;                         // rows per C half
+  static_assert(HB * C_PITCH <= STAGE, "a C half fits one ring stage");
+  static_assert(2 * STAGE <= 80 * 1024, "two workgroups per CU");
+  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+#define AQL_LBAR() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int qq = G >> 3, rr = G & 7, xcd = bid & 7;
+  const int first = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);   // XCD-aware remap inside a round
+  if (first >= ntiles) return;
+  const int tid0 = threadIdx.x;
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+  const int gF = g.epi.geglu_F;
+  const int kt_end = g.ktiles0;
+  const EpiParams& ep = g.epi;
+
+  struct Tile { int m0, n0, grp; bool lora_on, t_writer; };
+  auto tile_of = [&](int t) {
+    Tile c;
+    int tile_m, tile_n;
+    if (g.m_fast) {
+      tile_n = t / tiles_m;
+      tile_m = t - tile_n * tiles_m;
+    } else {
+      tile_m = t / tiles_n;
+      tile_n = t - tile_m * tiles_n;
+    }
+    c.m0 = tile_m * BM;
+    c.n0 = tile_n * (gF ? BN / 2 : BN);
+    c.grp = 0;
+    if (lp.ngroups > 0)
+      while (c.grp + 1 < lp.ngroups && c.n0 >= lp.col_start[c.grp + 1]) ++c.grp;
+    c.t_writer = lp.ngroups > 0 ? (c.n0 == lp.col_start[c.grp]) : (tile_n == 0);
+    c.lora_on = c.m0 + BM > lp.row0;
+    return c;
+  };
+
+  DmaStager<BM, PlainLoader> sa;
+  DmaStager<BN, PlainLoader> sb;
+  DmaStager<LR, PlainLoader> sl;
+  auto position = [&](const Tile& c, int tid) {   // stagers on K tile 0 of tile c
+    PlainLoader lag = la;
+    lag.base += (long)c.grp * LR * la.ld;
+    if (!c.lora_on) lag.rows = 0;        // every row out of range: the A DMAs are zero fills without traffic
+    sa.begin(g.a0, g.a0, false, c.m0, tid, 0, kt_end, kt_end);
+    sb.begin(g.b0, g.b0, false, c.n0, tid, 0, kt_end, kt_end);
+    sl.begin(lag, lag, false, 0, tid, 0, kt_end, kt_end);
+  };
+  auto issue = [&](int stage, int wave) {
+    char* sA = lds + stage * STAGE;
+    sa.dma(sA, wave);
+    sb.dma(sA + A_BYTES, wave);
+    sl.dma(sA + A_BYTES + B_BYTES, wave);
+  };
+
+  int t = first;
+  Tile cur = tile_of(t);
+  position(cur, tid0);
+  issue(0, tid0 >> 6);
+  int rd = 0;   // ring stage that holds K tile 0 of the current tile
+
+  for (;;) {
+    // lane-derived values are re-derived per tile from a laundered thread id: hoisted out of the tile loop (LICM) the fragment /
+    // epilogue address registers of ALL phases stay live across the whole body -- 41 spilled VGPRs at two workgroups per CU
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+    const int wt0 = (wave % WAVES_N) * FT;
+    const int tn = t + G;
+    const bool has_next = tn < ntiles;
+    const Tile nxt = tile_of(has_next ? tn : t);
+    const int m0 = cur.m0, n0 = cur.n0;
+    const bool lora_on = cur.lora_on;
+    bf16_t* const Tg = lp.T + (long)cur.grp * g.M * LR;
+    bf16_t* const Tsg = lp.Ts + (long)cur.grp * g.M * LR;
+
+    f32x4_t acc[FM][FN], tacc[FM][FT];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tt = 0; tt < FT; ++tt) tacc[i][tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    // this tile's bias values, up-projection panel and scale rows are needed after the K loop: they are requested in the LAST
+    // k-step, in front of the next tile's DMA (loads retire in order: behind it they would wait for that HBM-cold tile), and
+    // land under that k-step's MFMAs -- held across the whole K loop they cost 30 VGPRs the 2-workgroup budget does not have
+    uint2 biasr[FN];
+    constexpr int NBP = (BN * 4 + NTHREADS - 1) / NTHREADS;
+    uint4 bup[NBP];
+    uint2 srow[FM][FT];
+    auto tail_loads = [&]() {
+      epi_load_bias<FN>(biasr, ep.bias, g.b0.base, n0, wn0, lane, g.N, gF, BN / 2);
+#pragma unroll
+      for (int u = 0; u < NBP; ++u) {
+        const int id = tid + u * NTHREADS, row = id >> 2, c = id & 3;
+        const int brow = epi_bias_col(n0, row, gF, BN / 2);
+        const bool ok = (id < BN * 4) & (brow < g.N) & lora_on;
+        bup[u] = epi_mask4(*reinterpret_cast<const uint4*>(lp.Bup + (ok ? (long)brow * LR + c * 8 : 0)), ok);
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const long m = (long)m0 + wm0 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int tt = 0; tt < FT; ++tt) {
+          const bool ok = (m < g.M) & lora_on;
+          srow[i][tt] = epi_mask2(*reinterpret_cast<const uint2*>(lp.S + (ok ? (long)((uint32_t)m / (uint32_t)lp.rps) * LR + (wt0 + tt) * 16 + (lane >> 4) * 4 : 0)), ok);
+        }
+      }
+    };
+
+    auto mainloop = [&](auto lora_tag) {
+      constexpr bool LORA = decltype(lora_tag)::value;
+      auto kstep = [&]() {
+        const char* sA = lds + rd * STAGE;
+        const char* sB = sA + A_BYTES;
+        const char* sL = sB + B_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+          bf16x8_t fa[FM], fb[FN], fl[FT];
+          const int chunk = ks * 4 + (lane >> 4);
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+            fa[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(wm0 + i * 16 + (lane & 15), chunk));
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            fb[j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(wn0 + j * 16 + (lane & 15), chunk));
+          if constexpr (LORA) {
+#pragma unroll
+            for (int tt = 0; tt < FT; ++tt)
+              fl[tt] = *reinterpret_cast<const bf16x8_t*>(sL + lds_off((wt0 + tt) * 16 + (lane & 15), chunk));
+          }
+#pragma unroll
+          for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            if constexpr (LORA) {
+#pragma unroll
+              for (int tt = 0; tt < FT; ++tt) tacc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[tt], fa[i], tacc[i][tt], 0, 0, 0);
+            }
+          }
+        }
+        rd ^= 1;
+      };
+      for (int kt = 0; kt + 1 < kt_end; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K tile kt has landed (and the previous tile's stores are out)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue(rd ^ 1, wave);
+        kstep();
+      }
+      // last k-step: the free stage takes the NEXT tile's first K tile
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      tail_loads();
+      if (has_next) {
+        position(nxt, tid);
+        issue(rd ^ 1, wave);
+      }
+      kstep();
+    };
+    if (lora_on) mainloop(std::true_type{});
+    else mainloop(std::false_type{});
+    // rd = the stage the next tile's first K tile is landing in; rd ^ 1 = the stage of the last k-step, free from here on
+    char* const scr = lds + (rd ^ 1) * STAGE;
+    AQL_LBAR();   // every wavefront has read its last fragments
+    if (lora_on) {
+      char* sA = scr;
+      char* sB = scr + A_BYTES;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int row = wm0 + i * 16 + (lane & 15);
+        const long m = (long)m0 + row;
+        const bool ok = m < g.M;
+#pragma unroll
+        for (int tt = 0; tt < FT; ++tt) {
+          const int r = (wt0 + tt) * 16 + (lane >> 4) * 4;
+          const uint2 tv = make_uint2(pack_bf16x2(tacc[i][tt][0], tacc[i][tt][1]), pack_bf16x2(tacc[i][tt][2], tacc[i][tt][3]));
+          const uint2 sv = srow[i][tt];
+          const uint2 ts = make_uint2(pack_bf16x2(bf16lo(tv.x) * bf16lo(sv.x), bf16hi(tv.x) * bf16hi(sv.x)),
+                                      pack_bf16x2(bf16lo(tv.y) * bf16lo(sv.y), bf16hi(tv.y) * bf16hi(sv.y)));
+          *reinterpret_cast<uint2*>(sA + lds_off(row, r >> 3) + (r & 7) * 2) = ts;
+          if (ok && cur.t_writer) {
+            *reinterpret_cast<uint2*>(Tg + m * LR + r) = tv;
+            *reinterpret_cast<uint2*>(Tsg + m * LR + r) = ts;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NBP; ++u) {
+        const int id = tid + u * NTHREADS, row = id >> 2, c = id & 3;
+        if (id < BN * 4) *reinterpret_cast<uint4*>(sB + lds_off(row, c)) = bup[u];
+      }
+      AQL_LBAR();
+      {
+        bf16x8_t fa[FM], fb[FN];
+        const int chunk = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+          fa[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(wm0 + i * 16 + (lane & 15), chunk));
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          fb[j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(wn0 + j * 16 + (lane & 15), chunk));
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      }
+      AQL_LBAR();
+    }
+    // ---- epilogue in two passes of 64 rows: in pass p every wavefront stages ITS fragment rows 2p, 2p+1 (32 rows), so that half
+    // of every wavefront's accumulators is dead before the first store pass needs its registers (a pass of one wavefront row
+    // would keep the other row's 80 accumulator registers alive under the store loop: 33 spilled VGPRs).  LDS rows 0..31 of a
+    // pass = tile rows 32p.., rows 32..63 = tile rows 64 + 32p..
+    static_assert(FM == 4, "two passes of two fragment rows");
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = 2 * h + ii;
+        const int row = (wm0 / WM) * 32 + ii * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int col = wn0 + j * 16 + (lane >> 4) * 4;
+          float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+          v0 += bf16lo(biasr[j].x);
+          v1 += bf16hi(biasr[j].x);
+          v2 += bf16lo(biasr[j].y);
+          v3 += bf16hi(biasr[j].y);
+          *reinterpret_cast<uint2*>(scr + row * C_PITCH + col * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+        }
+      }
+      AQL_LBAR();
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {   // the two 32-row blocks of this pass
+        const char* blk = scr + q * 32 * C_PITCH;
+        const int mq = m0 + q * WM + h * 32;
+        if (gF) geglu_store<32, BN, C_PITCH, NTHREADS>(blk, mq, n0, g.M, ep, tid);
+        else epi_store_tile<32, BN, C_PITCH, NTHREADS>(blk, mq, n0, g.M, g.N, ep, tid);
+      }
+      if (h == 0) AQL_LBAR();   // the second pass overwrites the staging rows (the K loop's first barrier closes the last one)
+    }
+    if (!has_next) break;
+    t = tn;
+    cur = nxt;
+  }
+#undef AQL_LBAR
+}
+
 // Wave-specialised form (as gemm_kernel_w in aql_gemm.cuh): 512 threads, wavefronts 4-7 only issue the LDS-DMA loads
 // (X tile, W tile and the 32 rows of A), wavefronts 0-3 only read fragments and issue MFMAs, with the fragments of the next
 // k-half fetched under the current MFMA batch.  Used when the grid is about one workgroup per CU and K >= 8 tiles; on the
@@ -543,6 +816,14 @@ void launch_w(const GemmArgs<PlainLoader, PlainLoader>& g, const PlainLoader& la
   hipLaunchKernelGGL((lora_gemm_kernel_w<BM, BN, WM, WN, NSTG>), grid, dim3(2 * NTHREADS), 0, stream, g, la, lp);
 }
 
+// persistent 4-wave kernel: `wgs` resident workgroups (two per CU) walk all tiles
+template <int BM, int BN, int WM, int WN>
+void launch_p(const GemmArgs<PlainLoader, PlainLoader>& g, const PlainLoader& la, const LoraParams& lp, int wgs, hipStream_t stream) {
+  const int ntiles = aql_cdiv(g.M, BM) * aql_cdiv(g.N, BN);
+  dim3 grid(ntiles < wgs ? ntiles : wgs);
+  hipLaunchKernelGGL((lora_gemm_kernel_p<BM, BN, WM, WN>), grid, dim3(NTHREADS), 0, stream, g, la, lp, ntiles);
+}
+
 template <int BM, int BN, int WM, int WN, int NSTG>
 void launch(const GemmArgs<PlainLoader, PlainLoader>& g, const PlainLoader& la, const LoraParams& lp, hipStream_t stream) {
   dim3 grid(aql_cdiv(g.M, BM) * aql_cdiv(g.N, BN));
@@ -624,7 +905,8 @@ static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long
       const int tiles = aql_cdiv(M, bm) * (N / 160);
       const bool shallow = cfg[strlen(cfg) - 1] == 's' || tiles > 288;
       bool ok = true;
-      if (cfg[0] == 'w' && bm == 128) launch_w<128, 160, 64, 80, 3>(g, la, lp, stream);
+      if (cfg[0] == 'p' && bm == 128) launch_p<128, 160, 64, 80>(g, la, lp, 512, stream);
+      else if (cfg[0] == 'w' && bm == 128) launch_w<128, 160, 64, 80, 3>(g, la, lp, stream);
       else if (cfg[0] == 'w' && bm == 64) launch_w<64, 160, 32, 80, 4>(g, la, lp, stream);
       else if (cfg[0] == 'w' && bm == 32) launch_w<32, 160, 16, 80, 5>(g, la, lp, stream);
       else if (cfg[0] == 'd' && bm == 128) { if (shallow) launch<128, 160, 64, 80, 2>(g, la, lp, stream); else launch<128, 160, 64, 80, 3>(g, la, lp, stream); }
@@ -667,7 +949,13 @@ static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long
       if (t64 < 240 && t32 >= 240 && t32 <= 512) { launch_w<32, 160, 16, 80, 5>(g, la, lp, stream); AQL_CHECK_LAUNCH("aql_lora_gemm_fused"); return AQL_OK; }
     }
     if (force_bm == 128 || (force_bm == 0 && t128 >= 448)) {
+      // AQL_LORA_PERSIST=n (default 0 = off): grids of >= n tiles on the persistent kernel, whose workgroups fetch their next
+      // tile's first K tile under the current tile's tail.  Measured round 4 (tools/probe_lora_persist.py, bit-identical on all 18
+      // forms): 0.98x on ff.net.0 + GEGLU at 32768 x 2560 x 320 and 1.03-1.17x (SLOWER) everywhere else -- with two workgroups
+      // per CU the dispatcher already starts a fresh workgroup's prologue under its neighbour's K loop (profiles/r04_lora_persistent.txt)
+      static const int persist_min = getenv("AQL_LORA_PERSIST") ? atoi(getenv("AQL_LORA_PERSIST")) : 0;
       if (t128 <= 288) launch<128, 160, 64, 80, 3>(g, la, lp, stream);
+      else if (persist_min > 0 && t128 >= persist_min) launch_p<128, 160, 64, 80>(g, la, lp, 512, stream);
       else launch<128, 160, 64, 80, 2>(g, la, lp, stream);
     } else if (force_bm == 64 || (force_bm == 0 && t64 >= 200)) {
       if (t64 <= 288) launch<64, 160, 32, 80, 5>(g, la, lp, stream);
