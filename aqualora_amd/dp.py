@@ -329,9 +329,114 @@ def broadcast_module_(module, group=None, src=0):
 
 def broadcast_buffers_(module, group=None, src=0):
     """DDP(broadcast_buffers=True): rank ``src``'s buffers (BatchNorm running statistics) overwrite everyone's before a
-    forward pass, so that the replicas stay identical."""
+    forward pass, so that the replicas stay identical.  The ~200 BatchNorm buffers of the SecretDecoder travel as ONE collective
+    per dtype (fp32 statistics; int64 `num_batches_tracked` counters): packed into a flat tensor, broadcast, scattered back with
+    one multi-tensor copy -- not one ~10 us collective per buffer."""
     if world_size(group) <= 1:
         return
+    by_dtype = {}
     for b in module.buffers():
         if b.numel():
-            dist.broadcast(b, src=src, group=group)
+            by_dtype.setdefault(b.dtype, []).append(b)
+    root = dist.get_global_rank(group, src) if group is not None else src
+    for bufs in by_dtype.values():
+        flat = torch.cat([b.detach().reshape(-1) for b in bufs])
+        dist.broadcast(flat, src=root, group=group)
+        outs, off = [], 0
+        for b in bufs:
+            outs.append(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+        with torch.no_grad():
+            try:
+                torch._foreach_copy_(bufs, outs)
+            except (AttributeError, RuntimeError):
+                for b, o in zip(bufs, outs):
+                    b.copy_(o)
+
+
+class ModuleGradExchange:
+    """DDP's grad-ready buckets for an ordinary trainable module (the SecretDecoder of rob_enhance_finetune.py:917-919,1037,
+    ~26 MB of fp32 gradients), overlapped with its backward pass.
+
+    Every parameter's ``.grad`` is a view into ONE flat fp32 buffer laid out in reverse parameter order -- the order in which
+    backward produces the gradients (classifier first, stem last) -- cut into ``n_buckets`` contiguous ranges at parameter
+    boundaries (for EfficientNet-B1 with 4 buckets: head + the last MBConv stages | ... | stem + the first stages).  A
+    post-accumulate-grad hook on every parameter counts its bucket down; the hook that completes a bucket hands its range to the
+    collective at once: ``aql_comm_all_reduce_f32`` on a forked side stream when the trainer has our RCCL communicator (``comm``),
+    else torch.distributed's asynchronous all-reduce -- either way it runs under the rest of backward.  ``finish()`` joins.
+    No ``torch.cat`` pack, no copy-back: the optimizer reads the averaged gradients where the collective left them.
+    ``zero_grad()`` zeroes the flat buffer and keeps the views (``optimizer.zero_grad()`` would drop them: set_to_none)."""
+
+    def __init__(self, module, group=None, comm=None, n_buckets=4):
+        self.group, self.comm = group, comm
+        self.params = [p for p in reversed(list(module.parameters())) if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.offsets, off = [], 0
+        for p in self.params:
+            if p.dtype != torch.float32:
+                raise ValueError("ModuleGradExchange: fp32 parameters only")
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.offsets.append(off)
+            off += p.numel()
+        # buckets: contiguous runs of parameters of about n / n_buckets elements each
+        self.bucket_of, self.ranges = [], []
+        target, lo, b = max(1, n // max(1, n_buckets)), 0, 0
+        for i, p in enumerate(self.params):
+            self.bucket_of.append(b)
+            end = self.offsets[i] + p.numel()
+            if end - lo >= target and b < n_buckets - 1 and i + 1 < len(self.params):
+                self.ranges.append((lo, end))
+                lo, b = end, b + 1
+        self.ranges.append((lo, n))
+        self.sizes = [sum(1 for q in self.bucket_of if q == k) for k in range(len(self.ranges))]
+        self.left = list(self.sizes)
+        self.reducer = BucketedAllreduce(group)
+        self.side = torch.cuda.Stream(device=dev) if (comm is not None and dev.type == "cuda") else None
+        self.launched = []
+        self._handles = [p.register_post_accumulate_grad_hook(lambda _p, _i=i: self._ready(_i)) for i, p in enumerate(self.params)]
+
+    def _ready(self, i):
+        k = self.bucket_of[i]
+        self.left[k] -= 1
+        if self.left[k] == 0:
+            self._launch(k)
+
+    def _launch(self, k):
+        lo, hi = self.ranges[k]
+        self.launched.append(k)
+        if not exchange_active(self.group):
+            return
+        if self.comm is not None:
+            main = torch.cuda.current_stream()
+            self.side.wait_stream(main)            # fork behind the kernels that produced this bucket's gradients
+            with torch.cuda.stream(self.side):
+                self.comm.all_reduce_(self.flat[lo:hi], average=True)
+        else:
+            self.reducer.launch(self.flat[lo:hi])
+
+    def finish(self):
+        """After backward: every bucket was launched from a hook (a parameter that received no gradient leaves its bucket
+        open: it is launched here); wait for the collectives."""
+        for k in range(len(self.ranges)):
+            if self.left[k] != 0 and k not in self.launched:
+                self._launch(k)
+        if self.comm is not None and self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+        self.reducer.finish()
+        order = list(self.launched)
+        self.left = list(self.sizes)
+        self.launched = []
+        return order
+
+    def zero_grad(self):
+        self.flat.zero_()
+        for p, off in zip(self.params, self.offsets):      # re-attach views an optimizer.zero_grad(set_to_none=True) dropped
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
+                p.grad = self.flat[off:off + p.numel()].view_as(p)
+
+    def close(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []

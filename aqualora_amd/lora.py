@@ -303,19 +303,50 @@ def patch_lora_forwards(unet):
 
 
 # ------------------------------------------------------------------------------------------ flat bank
-def bank_order(keys):
-    """-> (site indices in buffer order, number of leading sites that belong to the up path).  Pure host logic (CPU-tested):
-    reverse traversal order with the text-state projections attn2.to_k / to_v moved to the end (see LoraBank)."""
-    def is_kv(k):
-        return k.endswith(".attn2.to_k") or k.endswith(".attn2.to_v")
+def _is_kv(k):
+    return k.endswith(".attn2.to_k") or k.endswith(".attn2.to_v")
+
+
+def backward_stage(key):
+    """Which leg of backward completes a site's weight gradients: 0 = up path, 1 = mid block + down_blocks.3 / .2, 2 = down_blocks.1,
+    3 = down_blocks.0.  The U-Net fires a backward hook at the end of legs 0, 1 and 2 (unet.forward: gradients of the mid-block
+    output, of down_blocks.1's output, of down_blocks.0's output)."""
+    if key.startswith("up_blocks."):
+        return 0
+    if key.startswith("mid_block."):
+        return 1
+    if key.startswith("down_blocks."):
+        i = int(key.split(".")[1])
+        return 1 if i >= 2 else (2 if i == 1 else 3)
+    return 3
+
+
+N_STAGES = 4
+
+
+def bank_stages(keys, kv_last=True):
+    """-> (site indices in buffer order, [number of leading sites complete after backward leg 0, 1, 2]).  Pure host logic
+    (CPU-tested): reverse traversal order; ``kv_last`` moves the text-state projections attn2.to_k / to_v to the end of the buffer
+    (rank 32: all 32 of them are ONE grouped launch in front of the U-Net whose backward is the last node of the graph; at other
+    ranks they are ordinary sites of their block and stay in traversal order)."""
     rev = list(reversed(range(len(keys))))
-    order = [i for i in rev if not is_kv(keys[i])] + [i for i in rev if is_kv(keys[i])]
-    n_lead = 0
-    for i in order:
-        if not keys[i].startswith("up_blocks.") or is_kv(keys[i]):
-            break
-        n_lead += 1
-    return order, n_lead
+    if kv_last:
+        order = [i for i in rev if not _is_kv(keys[i])] + [i for i in rev if _is_kv(keys[i])]
+    else:
+        order = rev
+    ends, pos = [], 0
+    for stage in range(N_STAGES - 1):
+        while pos < len(order) and backward_stage(keys[order[pos]]) <= stage and not (kv_last and _is_kv(keys[order[pos]])):
+            pos += 1
+        ends.append(pos)
+    return order, ends
+
+
+def bank_order(keys):
+    """-> (site indices in buffer order, number of leading sites that belong to the up path): `bank_stages` with the text-state
+    projections last, first cut only."""
+    order, ends = bank_stages(keys, True)
+    return order, ends[0]
 
 
 class LoraBank:
@@ -325,22 +356,26 @@ class LoraBank:
     that finish first in backward (up_blocks.3 ...) sit at the front of the buffer: bucket i of the exchange is
     complete as soon as backward has passed its last site."""
 
-    def __init__(self, unet, keys=None, extra_params=()):
+    def __init__(self, unet, keys=None, extra_params=(), kv_last=None):
         keys = keys if keys is not None else load_unet_keys(unet)
         self.layers = [_walk(unet, k).lora_layer for k in keys]
+        if kv_last is None:    # the text-state projections are grouped in front of the U-Net (unet._ctx_kv) at rank 32 only
+            kv_last = all(int(l.rank) == 32 for l in self.layers)
         # Gradient-ready order: reverse traversal, EXCEPT the text-state projections attn2.to_k / to_v -- at rank 32 all 32 of
         # them are one grouped launch in front of the U-Net (unet._ctx_kv) whose backward is the LAST node of the graph, so
         # their gradients complete last wherever their block sits: they go to the end of the buffer.  The buffer then reads
         #   [ up_blocks sites | mid + down_blocks sites | text k|v sites | extra (mapper) ]
         # and the first region (`n_early` elements) is complete the moment backward leaves the up path: the overlapped
         # exchange all-reduces it under the mid / down backward (ppft.PPFTTrainer, DDP's early buckets at ppft_train.py:1058).
-        order, n_lead = bank_order(keys)
+        order, ends = bank_stages(keys, kv_last)
         plist = []
-        self.n_early = 0
+        self.cuts = [0] * len(ends)     # elements complete after backward leg 0, 1, 2 (lora.backward_stage)
         for j, i in enumerate(order):
             plist += [self.layers[i].down.weight, self.layers[i].up.weight]
-            if j < n_lead:
-                self.n_early += self.layers[i].down.weight.numel() + self.layers[i].up.weight.numel()
+            for q, e in enumerate(ends):
+                if j < e:
+                    self.cuts[q] += self.layers[i].down.weight.numel() + self.layers[i].up.weight.numel()
+        self.n_early = self.cuts[0]
         self.n_lora = sum(p.numel() for p in plist)
         plist += list(extra_params)
         self.params = plist

@@ -519,16 +519,22 @@ class DeferredDW:
 
 
 class SplitDeferred:
-    """Router in front of two DeferredDW tables for the overlapped data-parallel exchange: a weight gradient whose output
-    lies inside [lo_ptr, hi_ptr) -- the leading region of the flat gradient buffer, complete when backward leaves the up path
-    (lora.LoraBank) -- is queued on ``early``, everything else (and every dS reduction) on ``late``.  The trainer flushes and
-    all-reduces ``early`` from a hook in the middle of backward and ``late`` at its end."""
+    """Router in front of several DeferredDW tables for the overlapped data-parallel exchange: a weight gradient whose output
+    lies inside [bounds[i], bounds[i+1]) -- region i of the flat gradient buffer, complete when backward finishes leg i
+    (lora.LoraBank.cuts) -- is queued on ``tables[i]``; everything behind the last bound (and every dS reduction) on ``late``.
+    The trainer flushes and all-reduces table i from the U-Net's backward hook i and ``late`` at the end of backward."""
 
-    def __init__(self, early, late, lo_ptr, hi_ptr):
-        self.early, self.late, self.lo, self.hi = early, late, int(lo_ptr), int(hi_ptr)
+    def __init__(self, tables, late, bounds):
+        self.tables, self.late, self.bounds = list(tables), late, [int(b) for b in bounds]
+        assert len(self.bounds) == len(self.tables) + 1
 
     def add_tn(self, U, V, C, alpha=1.0):
-        tgt = self.early if self.lo <= C.data_ptr() < self.hi else self.late
+        p = C.data_ptr()
+        tgt = self.late
+        for i, t in enumerate(self.tables):
+            if self.bounds[i] <= p < self.bounds[i + 1]:
+                tgt = t
+                break
         return tgt.add_tn(U, V, C, alpha)
 
     def add_ds(self, dTs, T, dS, nb, rps, r):

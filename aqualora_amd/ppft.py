@@ -106,18 +106,29 @@ class PPFTTrainer:
         self.split = self.overlap or (not dp.exchange_active(process_group) and max(1, micro_batches) == 1
                                       and os.environ.get("AQL_EARLY_DW", "0") == "1")
         self.side = torch.cuda.Stream(device=dev) if self.split else None   # forked / joined inside the step (and its graph)
+        # backward legs that end with a hook-driven exchange (lora.backward_stage): 3 = up path | mid + down_blocks.3/.2 |
+        # down_blocks.1, leaving only down_blocks.0 (+ the grouped text-state projections at rank 32 + the mapper) for the end of
+        # backward: 8.8 MB of 54 MB at rank 32, 30 MB of 543 MB at rank 320.  AQL_LEGS=1 restores round 3's single hook.
+        self.n_legs = max(1, min(3, int(os.environ.get("AQL_LEGS", "3"))))
         self._new_deferred()
 
     def _new_deferred(self):
-        """Descriptor tables of the held-back weight-gradient GEMMs.  Overlapped exchange: two tables behind a router -- the
-        leading `n_early` elements of the flat gradient buffer (the up path) and the rest (ops.SplitDeferred)."""
+        """Descriptor tables of the held-back weight-gradient GEMMs.  Overlapped exchange: one table per backward leg behind a
+        router (ops.SplitDeferred) -- region i of the flat gradient buffer, [cuts[i-1], cuts[i]), is complete when backward
+        finishes leg i (lora.backward_stage: up path | mid + down_blocks.3/.2 | down_blocks.1) -- and the rest."""
         dev = self.bank.grad.device
         self.deferred = ops.DeferredDW(dev, defer_wide=self.bucketed)
-        self.deferred_early = self.router = None
+        self.deferred_legs, self.router = [], None
         if self.split:
-            self.deferred_early = ops.DeferredDW(dev)
+            cuts = [c for c in self.bank.cuts[:self.n_legs]]
+            self.leg_bounds = [0] + cuts                      # leg i owns [leg_bounds[i], leg_bounds[i + 1])
+            self.deferred_legs = [ops.DeferredDW(dev) for _ in cuts]
             base = self.bank.grad.data_ptr()
-            self.router = ops.SplitDeferred(self.deferred_early, self.deferred, base, base + 4 * self.bank.n_early)
+            self.router = ops.SplitDeferred(self.deferred_legs, self.deferred, [base + 4 * b for b in self.leg_bounds])
+
+    @property
+    def deferred_early(self):      # the up path's table (leg 0)
+        return self.deferred_legs[0] if self.deferred_legs else None
 
     # ---------------------------------------------------------------------------------------------
     def forward_backward(self, z, msg, eps, t, ctx, flush_dw=True):
@@ -148,8 +159,10 @@ class PPFTTrainer:
         preds, cleans, losses = [], [], []
         ops.DEFERRED = self.router if self.split else self.deferred  # weight-gradient GEMMs + dS reductions are collected ...
         if self.split:
-            self._early_done = False
-            self.unet._aql_up_path_done = self._early_exchange   # fires inside backward, when it leaves the up path
+            self._leg_done = [False] * len(self.deferred_legs)
+            self.leg_ranges = [[] for _ in self.deferred_legs]
+            # fire inside backward, when it finishes leg k (unet.forward registers them on the leg's boundary tensors)
+            self.unet._aql_bwd_hooks = [(lambda k=k: self._leg_exchange(k)) for k in range(len(self.deferred_legs))]
         try:
             if self.twin and micro == 1:
                 # ONE forward over a twin batch of 2B: clean samples (all-zero scale rows == the reference's clean pass,
@@ -208,7 +221,7 @@ class PPFTTrainer:
         finally:
             ops.DEFERRED = None
             if self.split:
-                self.unet._aql_up_path_done = None
+                self.unet._aql_bwd_hooks = None
         for tns in preds + cleans + losses:
             tns.record_stream(main)
         if self.split:
@@ -286,37 +299,50 @@ class PPFTTrainer:
             pos += n
         return pos == hi
 
-    def _early_exchange(self):
-        """Called from the backward hook on the mid-block output (unet._aql_up_path_done): every LoRA site of the up blocks
-        has queued its weight-gradient GEMMs, whose outputs are the leading `n_early` elements of the flat gradient buffer.
-        Launch them now and fork the side stream behind them: the all-reduce(mean) of that region runs under the mid / down
-        backward (DDP's first-ready buckets, ppft_train.py:1058).  Inside a capture this becomes a branch of the graph."""
-        if self._early_done:
+    def _leg_exchange(self, k):
+        """Called from the U-Net's backward hook k (unet._aql_bwd_hooks): backward has finished leg k, every LoRA site of that
+        leg has queued its weight-gradient GEMMs, whose outputs are region [leg_bounds[k], leg_bounds[k+1]) of the flat gradient
+        buffer.  Launch them now and fork the side stream behind them: the all-reduce(mean) of that region runs under the rest
+        of backward (DDP's grad-ready buckets, ppft_train.py:1058).  Inside a capture this becomes a branch of the graph."""
+        if self._leg_done[k]:
             return
-        self._early_done = True
-        b, e = self.bank, self.deferred_early
+        for j in range(k):             # hooks fire in leg order; a leg whose boundary tensor carried no gradient is flushed here
+            self._leg_exchange(j)
+        self._leg_done[k] = True
+        b, e = self.bank, self.deferred_legs[k]
+        lo0, hi0 = self.leg_bounds[k], self.leg_bounds[k + 1]
         if not e.items:
             return
-        if not self._tiles(e, 0, b.n_early):
-            raise L.AqlError("overlapped exchange: the up-path weight gradients do not tile the head of the gradient buffer")
-        ranges = e.plan(b.grad, dp.bucket_count(4 * b.n_early) if self.overlap else 1)
+        if not self._tiles(e, lo0, hi0):
+            raise L.AqlError(f"overlapped exchange: the weight gradients of backward leg {k} do not tile their region of the gradient buffer")
+        ranges = e.plan(b.grad, dp.bucket_count(4 * (hi0 - lo0)) if self.overlap else 1)
         main = torch.cuda.current_stream()
-        for k, (lo, hi) in enumerate(ranges):
-            e.run_bucket(k)                       # on the backward stream
+        for q, (lo, hi) in enumerate(ranges):
+            e.run_bucket(q)                       # on the backward stream
             if self.overlap:
-                self.side.wait_stream(main)       # fork: the collective of bucket k runs under what follows on `main`
+                self.side.wait_stream(main)       # fork: the collective of this bucket runs under what follows on `main`
                 with torch.cuda.stream(self.side):
                     self.comm.all_reduce_(b.grad[lo:hi], average=True)
-        self.early_ranges = ranges
+        self.leg_ranges[k] = ranges
+
+    def _early_exchange(self):
+        self._leg_exchange(0)
+
+    @property
+    def early_ranges(self):        # every bucket issued from a backward hook, in issue order
+        return [r for leg in self.leg_ranges for r in leg]
 
     def _late_exchange(self):
         """End of backward: the remaining weight gradients in buckets on the main stream, each bucket's all-reduce on the
         side stream under the next bucket's GEMMs; the mapper gradient (complete after S.backward) rides with the last one."""
         b, d = self.bank, self.deferred
         main = torch.cuda.current_stream()
-        if not self._early_done:      # no gradient reached the mid-block output (cannot happen on the PPFT path): do it now
-            self._early_exchange()
-        lo0 = b.n_early if self.deferred_early.items else 0
+        for k in range(len(self.deferred_legs)):      # a hook that never fired (cannot happen on the PPFT path): do it now
+            self._leg_exchange(k)
+        lo0 = 0
+        for k, e in enumerate(self.deferred_legs):    # the late region starts behind the last leg that queued anything
+            if e.items:
+                lo0 = self.leg_bounds[k + 1]
         if not self._tiles(d, lo0, b.n_lora):
             raise L.AqlError("overlapped exchange: the weight gradients do not tile the gradient buffer")
         ranges = d.plan(b.grad, dp.bucket_count(4 * (b.n_lora - lo0)) if self.overlap else 1)
@@ -329,7 +355,8 @@ class PPFTTrainer:
                     self.comm.all_reduce_(b.grad[lo:hi], average=True)
         main.wait_stream(self.side)
         self.late_ranges = ranges
-        self.deferred_early.reset()
+        for e in self.deferred_legs:
+            e.reset()
         d.reset()
 
     def exchange_gradients(self):
@@ -444,13 +471,13 @@ class PPFTTrainer:
         """The whole step as ONE HIP graph: forward + backward (+ the gradient exchange as a forked branch: the early buckets
         under the mid / down backward, the rest behind the last weight-gradient launch, all through aql_comm_* on the side
         stream) + clip + AdamW + re-cast.  Single GPU: the same graph without collectives."""
-        eager = (self.deferred, self.deferred_early, self.router)
+        eager = (self.deferred, self.deferred_legs, self.router)
         self._new_deferred()          # the captured memcpy nodes re-read these pinned tables at every replay
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             loss, _, _ = self.forward_backward(**static)
             self.optimizer_step()
-        captured = (self.deferred, self.deferred_early, self.router)
-        self.deferred, self.deferred_early, self.router = eager
+        captured = (self.deferred, self.deferred_legs, self.router)
+        self.deferred, self.deferred_legs, self.router = eager
         self._graphs = (g, static, loss, captured)
 
         def run(z, msg, eps, t, ctx):

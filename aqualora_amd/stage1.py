@@ -130,11 +130,17 @@ class Stage1Step:
                 "logits": reveal_output, "watermarked_image": watermarked_image}
 
 
-def prepare_rob_finetune(msgdecoder, process_group=None):
+def prepare_rob_finetune(msgdecoder, process_group=None, n_buckets=4):
     """What ``accelerator.prepare(msgdecoder)`` does in rob_enhance_finetune.py:917-919 besides moving the module: DDP's
-    construction-time broadcast of rank 0's parameters and buffers, so that every rank fine-tunes the same decoder."""
+    construction-time broadcast of rank 0's parameters and buffers, so that every rank fine-tunes the same decoder, and DDP's
+    grad-ready buckets: under torch.distributed the decoder gets a `dp.ModuleGradExchange` (flat gradient buffer, bucket
+    all-reduces launched from gradient hooks under the rest of backward -- through aql_comm_* when the trainer's RCCL
+    communicator is in use, AQL_COMM=1, else torch.distributed's asynchronous all-reduce), which `rob_finetune_step` drives."""
     from . import dp
     dp.broadcast_module_(msgdecoder, process_group)
+    if dp.exchange_active(process_group):
+        comm, _ = dp.make_comm(process_group)
+        msgdecoder._aql_exchange = dp.ModuleGradExchange(msgdecoder, process_group, comm, n_buckets)
     return msgdecoder
 
 
@@ -142,9 +148,11 @@ def rob_finetune_step(msgdecoder, optimizer, images01, secret_bits, distort=None
     """rob_enhance_finetune.py:1018-1036: generated images in [0,1] (no grad) -> distortion -> [-1,1] -> msgdecoder ->
     BCE against one-hot bits -> backward -> optimizer step.  Returns (loss, bit accuracy).  Under torch.distributed (one
     process per GPU, the reference wraps the decoder in DDP through accelerate) rank 0's BatchNorm buffers are broadcast
-    before the forward and the gradients are mean-all-reduced over RCCL in flat buckets before the optimizer step."""
+    before the forward (one collective per dtype) and the gradients are mean-all-reduced over RCCL: in buckets launched from
+    gradient hooks DURING backward when `prepare_rob_finetune` installed the exchange, else in flat buckets after it."""
     from . import dp
     dp.broadcast_buffers_(msgdecoder, process_group)
+    ex = getattr(msgdecoder, "_aql_exchange", None)
     x = images01.detach().float()
     if distort is not None:
         x = distort(x)
@@ -154,7 +162,12 @@ def rob_finetune_step(msgdecoder, optimizer, images01, secret_bits, distort=None
     acc = (decoded == secret_bits.long()).float().mean()
     loss = bce_with_logits(logits.float(), torch.nn.functional.one_hot(secret_bits.long(), num_classes=2).float())
     loss.backward()
-    dp.allreduce_module_grads_(msgdecoder.parameters(), process_group)
-    optimizer.step()
-    optimizer.zero_grad()
+    if ex is not None:
+        ex.finish()
+        optimizer.step()
+        ex.zero_grad()
+    else:
+        dp.allreduce_module_grads_(msgdecoder.parameters(), process_group)
+        optimizer.step()
+        optimizer.zero_grad()
     return loss.detach(), acc

@@ -509,15 +509,25 @@ class UNet2DConditionModel(nn.Module):
         try:
             h = self.conv_in(sample, scale)
             skips = (h,)
-            for blk in self.down_blocks:
+            # backward-leg hooks of the data-parallel trainer (ppft.PPFTTrainer, lora.backward_stage): hooks[0] fires when backward
+            # has left the up path (the gradient of the mid-block output is complete), hooks[1] after the mid block and
+            # down_blocks.3 / .2 (gradient of down_blocks.1's output: its skip-connection consumers in the up path and
+            # down_blocks.2 are all done), hooks[2] after down_blocks.1 (gradient of down_blocks.0's output)
+            hooks = getattr(self, "_aql_bwd_hooks", None)
+
+            def leg_done(tensor, k):
+                if hooks is not None and k < len(hooks) and hooks[k] is not None and tensor.requires_grad:
+                    tensor.register_hook(lambda g, _f=hooks[k]: (_f(), None)[1])
+
+            for bi, blk in enumerate(self.down_blocks):
                 h, outs = blk(h, temb_act, ctx, scale)
                 skips += outs
+                if bi == 0:
+                    leg_done(h, 2)
+                elif bi == 1:
+                    leg_done(h, 1)
             h = self.mid_block(h, temb_act, ctx, scale)
-            hook = getattr(self, "_aql_up_path_done", None)
-            if hook is not None and h.requires_grad:
-                # d(loss)/d(mid-block output) is complete exactly when backward has left the up path (every up block's
-                # backward precedes it, nothing of the mid / down blocks has run): the trainer's cue for the early exchange
-                h.register_hook(lambda g, _f=hook: (_f(), None)[1])
+            leg_done(h, 0)
             for blk in self.up_blocks:
                 n = len(blk.resnets)
                 h = blk(h, skips[-n:], temb_act, ctx, scale)

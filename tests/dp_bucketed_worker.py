@@ -60,6 +60,8 @@ def main():
             if mode == "overlap_graph":
                 out[f"r{rank}_overlap_ranges"] = [list(map(int, r)) for r in list(tr.early_ranges) + list(tr.late_ranges)]
                 out[f"r{rank}_n_early"], out[f"r{rank}_numel"] = int(tr.bank.n_early), int(tr.bank.numel)
+                out[f"r{rank}_cuts"] = [int(c) for c in tr.bank.cuts]
+                out[f"r{rank}_hook_buckets"] = len(tr.early_ranges)
                 out[f"r{rank}_overlap_graphs"] = int(getattr(run, "n_graphs", 0))
         lp, pp = res["plain"]
         for mode in ("overlap_eager", "overlap_graph", "bucketed_eager", "bucketed_graph"):
@@ -67,7 +69,57 @@ def main():
             out[f"r{rank}_{mode}_param_relerr"] = float((p - pp).abs().max() / pp.abs().max())
             out[f"r{rank}_{mode}_losses"] = l
         out[f"r{rank}_plain_losses"] = lp
+    out.update(robft_modes())
     print(json.dumps(out))
+
+
+def robft_modes():
+    """rob_enhance_finetune.py:1018-1036 on one GPU in its three exchange forms: no exchange; dp.ModuleGradExchange over
+    torch.distributed (bucket all-reduces launched from gradient hooks during backward); the same through aql_comm_* on a forked
+    side stream (AQL_COMM=1).  Two optimizer steps each from the same decoder, parameters compared with the plain form."""
+    from aqualora_amd import stage1 as S1, synth
+    from tests.test_gpu_parity import _synthetic_decoder
+    B = 4
+    img = (synth.normal("rob.dp.img", (B, 3, 128, 128), 0.25, 5, "cuda") + 0.5).clamp(0, 1)
+    bits = synth.bits("rob.dp.bits", (B, 48), 5, "cuda")
+    out, ref = {}, None
+    for mode in ("plain", "plain2", "dist", "comm"):     # plain2: the run-to-run spread of the decoder step itself (fp32 atomics)
+        os.environ.pop("AQL_FORCE_ALLREDUCE", None)
+        os.environ.pop("AQL_COMM", None)
+        if not mode.startswith("plain"):
+            os.environ["AQL_FORCE_ALLREDUCE"] = "1"
+        if mode == "comm":
+            os.environ["AQL_COMM"] = "1"
+        torch.manual_seed(11)       # the train-mode forward draws stochastic depth / dropout from torch's generator
+        dec = _synthetic_decoder(48).to("cuda").train()
+        S1.prepare_rob_finetune(dec, None, n_buckets=4)
+        ex = getattr(dec, "_aql_exchange", None)
+        opt = torch.optim.AdamW(dec.parameters(), lr=1e-3)
+        losses, orders = [], []
+        for _ in range(2):
+            if ex is not None:
+                real = ex.finish
+                ex.finish = lambda _r=real: (orders.append(_r()), orders[-1])[1]
+            loss, acc = S1.rob_finetune_step(dec, opt, img, bits, None, None)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        flat = torch.cat([p.detach().reshape(-1) for p in dec.parameters()])
+        if mode == "plain":
+            ref = flat
+            out["robft_plain_losses"] = losses
+            assert ex is None
+        elif mode == "plain2":
+            out["robft_plain_rerun_param_relerr"] = float((flat - ref).abs().max() / ref.abs().max())
+        else:
+            assert ex is not None and (ex.comm is not None) == (mode == "comm"), (mode, ex.comm)
+            out[f"robft_{mode}_param_relerr"] = float((flat - ref).abs().max() / ref.abs().max())
+            out[f"robft_{mode}_losses"] = losses
+            out[f"robft_{mode}_buckets"] = len(ex.ranges)
+            out[f"robft_{mode}_hook_launch_order"] = orders[-1]
+            out[f"robft_{mode}_bucket_mb"] = [round(4 * (hi - lo) / 2 ** 20, 2) for lo, hi in ex.ranges]
+    os.environ.pop("AQL_FORCE_ALLREDUCE", None)
+    os.environ.pop("AQL_COMM", None)
+    return out
 
 
 if __name__ == "__main__":

@@ -44,7 +44,8 @@ def main():
         mapper.bit_embeddings.weight.copy_(synth.normal("c3.E", (48, rank), 1.0, seed))
     tr = PPFTTrainer(unet, mapper, SecretEncoder(48), rank)
     out = {"bucketed": bool(tr.bucketed), "overlap": bool(tr.overlap), "comm": tr.comm_note, "twin": bool(tr.twin),
-           "n_lora": int(tr.bank.n_lora), "n_early": int(tr.bank.n_early), "numel": int(tr.bank.numel)}
+           "n_lora": int(tr.bank.n_lora), "n_early": int(tr.bank.n_early), "numel": int(tr.bank.numel),
+           "cuts": [int(c) for c in tr.bank.cuts], "n_legs": int(getattr(tr, "n_legs", 0))}
     z = synth.normal("c3.z", (B, 4, 64, 64), 1.0, seed).to(dev)
     wm = synth.normal("c3.wm", (B, 4, 64, 64), 0.05, seed).to(dev)
     eps = synth.normal("c3.eps", (B, 4, 64, 64), 1.0, seed).to(dev)
@@ -63,11 +64,13 @@ def main():
         tr.bank.zero_grad()
         if tr.overlap:
             kinds = set()
-            real_e, real_l = tr.deferred_early.plan, tr.deferred.plan
-            tr.deferred_early.plan = lambda *a: (kinds.update(it[1] for it in tr.deferred_early.items), real_e(*a))[1]
-            tr.deferred.plan = lambda *a: (kinds.update(it[1] for it in tr.deferred.items), real_l(*a))[1]
+            tables = list(tr.deferred_legs) + [tr.deferred]
+            real = [d.plan for d in tables]
+            for d, f in zip(tables, real):
+                d.plan = (lambda *a, _d=d, _f=f: (kinds.update(it[1] for it in _d.items), _f(*a))[1])
             loss, pred, clean = tr.forward_backward(z[sl], msg[sl], eps[sl], t[sl], ctx[sl])
-            tr.deferred_early.plan, tr.deferred.plan = real_e, real_l
+            for d, f in zip(tables, real):
+                d.plan = f
             return loss, pred, clean, list(tr.early_ranges) + list(tr.late_ranges), sorted(kinds)
         loss, pred, clean = tr.forward_backward(z[sl], msg[sl], eps[sl], t[sl], ctx[sl], flush_dw=False)
         kinds = sorted({it[1] for it in tr.deferred.items})

@@ -74,17 +74,59 @@ def _worker(rank, world, port, q):
     n_lora, n_early = sum(sizes), sum(sizes[:4])
     d = synth.normal("grad", (n,), 1.0, seed=100 + rank)[:n_lora + 100].clone()   # + a 100-element "mapper" tail
     want_d = want[:n_lora + 100]
-    early = ops.plan_buckets(offs[:4], sizes[:4], 2)
-    late = ops.plan_buckets(offs[4:], sizes[4:], 3)
-    ranges = [(lo, hi) for lo, hi, _ in early] + [(lo, hi) for lo, hi, _ in late]
+    # round 4: three backward legs (up path | mid + down_blocks.3/.2 | down_blocks.1) are planned and reduced from their own
+    # hooks, in leg order; what is left (down_blocks.0, text projections) + the mapper tail at the end of backward
+    legs = [(0, 4), (4, 6), (6, 7)]
+    ranges = []
+    for a_, b_ in legs:
+        ranges += [(lo, hi) for lo, hi, _ in ops.plan_buckets(offs[a_:b_], sizes[a_:b_], 2)]
+    ranges += [(lo, hi) for lo, hi, _ in ops.plan_buckets(offs[7:], sizes[7:], 3)]
     ranges[-1] = (ranges[-1][0], d.numel())
-    ok_tile = (ranges[0][0] == 0 and any(hi == n_early for _, hi in ranges)
+    cut_ends = [sum(sizes[:b_]) for _, b_ in legs]
+    ok_tile = (ranges[0][0] == 0 and all(any(hi == c for _, hi in ranges) for c in cut_ends) and cut_ends[0] == n_early
                and all(x[1] == y[0] for x, y in zip(ranges, ranges[1:])))
     red2 = dp.BucketedAllreduce()
     for lo, hi in ranges:
         red2.launch(d[lo:hi])
     red2.finish()
     ok_async = ok_async and ok_tile and torch.allclose(d, want_d, atol=1e-6)
+    # DDP's broadcast_buffers as ONE collective per dtype (fp32 statistics + int64 counters), and the hook-driven gradient
+    # exchange of an ordinary module (dp.ModuleGradExchange: the rob-finetune decoder): mean of the ranks' gradients, every bucket
+    # launched from a gradient hook during backward, the views survive zero_grad
+    torch.manual_seed(77 + rank)
+    net3 = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU(), torch.nn.Linear(16, 8),
+                               torch.nn.BatchNorm1d(8), torch.nn.Linear(8, 4))
+    net3[1].running_mean.fill_(float(rank + 1))
+    net3[4].num_batches_tracked.fill_(5 + rank)
+    dp.broadcast_module_(net3)                       # parameters: rank 0's
+    net3[1].running_mean.fill_(float(rank + 1))
+    net3[4].num_batches_tracked.fill_(5 + rank)
+    dp.broadcast_buffers_(net3)
+    ok_buf = float(net3[1].running_mean[3]) == 1.0 and int(net3[4].num_batches_tracked) == 5
+    ex = dp.ModuleGradExchange(net3, None, None, n_buckets=3)
+    xin = synth.normal("mge.x", (5, 6), 1.0, seed=300 + rank)
+    net3(xin).square().sum().backward()
+    launched = ex.finish()
+    mine = [p.grad.clone() for p in net3.parameters()]
+    gath = [[torch.zeros_like(g_) for _ in range(world)] for g_ in mine]
+    ok_mge = launched == list(range(len(ex.ranges))) and len(ex.ranges) >= 2
+    # reference: plain local gradients (no exchange), averaged by hand
+    ref3 = [p.detach().clone().requires_grad_(True) for p in net3.parameters()]
+    import copy
+    net4 = copy.deepcopy(net3)
+    for p_ in net4.parameters():
+        p_.grad = None
+    for m_ in net4.modules():       # the first forward above already moved the running statistics: same batch statistics either way
+        if isinstance(m_, torch.nn.BatchNorm1d):
+            m_.momentum = 0.0
+    net4(xin).square().sum().backward()
+    for g_, p_ in zip(mine, net4.parameters()):
+        loc = p_.grad.clone()
+        dist.all_reduce(loc)
+        ok_mge = ok_mge and torch.allclose(g_, loc / world, atol=1e-5, rtol=1e-5)
+    ex.zero_grad()
+    ok_mge = ok_mge and float(ex.flat.abs().sum()) == 0.0 and all(p_.grad is not None for p_ in net3.parameters())
+    ok_mod = ok_mod and ok_buf and ok_mge
     q.put((rank, torch.allclose(a, want, atol=1e-6), torch.equal(a, b) and ok_async and ok_mod,
            not torch.equal(gathered[0], gathered[1])))
     dist.destroy_process_group()
@@ -162,6 +204,50 @@ def test_bank_order_puts_the_up_path_first_and_the_text_projections_last():
     assert all(k.startswith("up_blocks.") for k in names[:n_lead]) and names[n_lead].startswith("mid_block.")
     body = names[:-n_kv]
     assert body == [k for k in reversed(keys) if not is_kv(k)]                 # gradient-ready order otherwise
+
+
+def test_bank_stages_cut_the_buffer_at_the_backward_legs():
+    """lora.bank_stages / LoraBank.cuts: the flat gradient buffer is [up path | mid + down_blocks.3/.2 | down_blocks.1 | rest];
+    at rank 32 the grouped text-state projections sit at the end, at other ranks they stay inside their block.  Sizes at the
+    SD-1.5 widths: what is left for the end of backward is 8.8 MB of 54 MB at rank 32 and 30 MB of 543 MB at rank 320."""
+    from aqualora_amd.lora import backward_stage, bank_stages
+    from aqualora_amd.unet import lora_keys
+    from tests.common import tiny_unet
+    keys = lora_keys(tiny_unet())
+    is_kv = lambda k: k.endswith(".attn2.to_k") or k.endswith(".attn2.to_v")   # noqa: E731
+    for kv_last in (True, False):
+        order, ends = bank_stages(keys, kv_last)
+        names = [keys[i] for i in order]
+        assert sorted(order) == list(range(len(keys))) and len(ends) == 3 and 0 < ends[0] < ends[1] < ends[2] < len(keys)
+        for q, e in enumerate(ends):
+            assert all(backward_stage(k) <= q for k in names[:e])
+            assert backward_stage(names[e]) > q or (kv_last and is_kv(names[e]))
+        if kv_last:
+            assert not any(is_kv(k) for k in names[:ends[2]])
+        else:
+            assert names == list(reversed(keys)) and any(is_kv(k) for k in names[:ends[0]])
+    assert [backward_stage(k) for k in ("up_blocks.1.attentions.0.proj_in", "mid_block.attentions.0.proj_out",
+                                        "down_blocks.2.attentions.1.proj_in", "down_blocks.1.attentions.0.proj_in",
+                                        "down_blocks.0.attentions.1.proj_in")] == [0, 1, 1, 2, 3]
+    # element counts at the SD-1.5 widths, from the per-site sizes of SURVEY Appendix A
+    C = {"down_blocks.0": 320, "down_blocks.1": 640, "down_blocks.2": 1280, "mid_block": 1280, "up_blocks.1": 1280,
+         "up_blocks.2": 640, "up_blocks.3": 320}
+
+    def site_elems(k, r):
+        c = C[".".join(k.split(".")[:2]) if not k.startswith("mid_block") else "mid_block"]
+        if is_kv(k):
+            return (768 + c) * r
+        if k.endswith("ff.net.0.proj"):
+            return 9 * c * r
+        if k.endswith("ff.net.2"):
+            return 5 * c * r
+        return 2 * c * r
+    for r, kv_last, bound in ((32, True, 16 << 20), (320, False, 64 << 20)):
+        order, ends = bank_stages(keys, kv_last)
+        total = sum(site_elems(k, r) for k in keys)
+        assert total == 423936 * r
+        late = sum(site_elems(keys[i], r) for i in order[ends[2]:])
+        assert 4 * (late + 48 * r) <= bound, (r, 4 * late)
 
 
 def test_step_input_feed_copies_into_the_static_buffers():
