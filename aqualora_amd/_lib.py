@@ -26,6 +26,9 @@ SIGNATURES = {
     "aql_gemm_bf16_ex": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_i, c_p, c_l, c_p, c_l,
                          c_l, c_p, c_sz, c_p],
     "aql_lora_gemm_fused": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p],
+    # A lda B ldb M N K | Bs sstride srows srow0 | bias residual ldr res_mod | C ldc G ldg geglu_F c_row0 | gb_h gb_ldh | ws ws_bytes stream
+    "aql_gemm_bf16_sw": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_l, c_l, c_p, c_p, c_l, c_l, c_p, c_l, c_p, c_l, c_i, c_l,
+                         c_p, c_l, c_p, c_sz, c_p],
     "aql_gemm_bf16_geglu": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_l, c_l, c_p],
     "aql_lora_gemm_fused_geglu": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_l,
                                   c_p],
@@ -72,6 +75,7 @@ SIGNATURES = {
     "aql_ds_desc_fill": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i],
     "aql_lora_ds_grouped": [c_p, c_i, c_i, c_p],
     "aql_lora_ds": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
+    "aql_wside_reduce": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_l, c_p, c_p],
     "aql_sumsq_f32": [c_p, c_l, c_p, c_p],
     "aql_clipnorm_adamw": [c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_p, c_f, c_f, c_f, c_f, c_p, c_p],
     "aql_jpeg_mask": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
@@ -183,11 +187,26 @@ def stream_ptr():
     return c_p(torch.cuda.current_stream().cuda_stream)
 
 
+_DEBUG_SYNC = bool(os.environ.get("AQL_DEBUG_SYNC"))   # debugging aid: synchronise after every entry point and name the one that faulted
+
+
+def _debug_sync(name):
+    import sys
+    print(f"[aql] {name}", file=sys.stderr, flush=True)
+    if not torch.cuda.is_current_stream_capturing():
+        torch.cuda.synchronize()
+
+
 def call(name, *args):
     lib = load()
     check(getattr(lib, name)(*args), name)
+    if _DEBUG_SYNC:
+        _debug_sync(name)
 
 
 def call_raw(name, *args):
     """For the *_desc_fill helpers, whose return value is a workgroup count rather than a status."""
-    return getattr(load(), name)(*args)
+    rc = getattr(load(), name)(*args)
+    if _DEBUG_SYNC and not name.endswith("_fill"):
+        _debug_sync(name)
+    return rc

@@ -617,6 +617,50 @@ extern "C" int aql_cast_transpose_batched(const void* desc, int n, int total_til
   AQL_CHECK_LAUNCH("aql_cast_transpose_batched");
   return AQL_OK;
 }
+// Weight-side form of the watermark-LoRA linear (ops.wside_backward; the reference's branch is utils/lora_modules.py:13-19): after
+// P[b][n][j] = sum_k dWe_b[n][k] A[j][k] the two r-wide gradients that remain are reductions over the samples / the output rows:
+//     dBup[n][j] += sum_b P[b][n][j] S[b][j]          dS[b][j] += sum_n Bup[n][j] P[b][n][j]
+// One workgroup per 16 rows n, one thread per rank column j (coalesced along j); dBup is owned (no atomics, deterministic), the
+// per-block partial of dS goes out as one fp32 atomic per (b, j) like the other dS reductions.
+__global__ __launch_bounds__(256) void wside_reduce_kernel(const bf16_t* __restrict__ P, const bf16_t* __restrict__ S,
+                                                           const bf16_t* __restrict__ Bup, int B, int N, int r,
+                                                           float* __restrict__ dB, long lddb, float* __restrict__ dS) {
+  constexpr int NR = 16;
+  const int n0 = blockIdx.x * NR;
+  for (int j = threadIdx.x; j < r; j += blockDim.x) {
+    float bup[NR], acc[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int n = n0 + i;
+      bup[i] = n < N ? bf16_to_f32(Bup[(long)n * r + j]) : 0.f;
+      acc[i] = 0.f;
+    }
+    for (int b = 0; b < B; ++b) {
+      const float s = bf16_to_f32(S[(long)b * r + j]);
+      const bf16_t* p = P + ((long)b * N + n0) * r + j;
+      float ds = 0.f;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const float v = (n0 + i < N) ? bf16_to_f32(p[(long)i * r]) : 0.f;
+        acc[i] = fmaf(v, s, acc[i]);
+        ds = fmaf(bup[i], v, ds);
+      }
+      atomicAdd(dS + (long)b * r + j, ds);
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+      if (n0 + i < N) dB[(long)(n0 + i) * lddb + j] += acc[i];
+  }
+}
+
+extern "C" int aql_wside_reduce(const bf16_t* P, const bf16_t* S, const bf16_t* Bup, int B, int N, int r, float* dBup, long lddb,
+                                float* dS, hipStream_t stream) {
+  AQL_CHECK_ARG(P && S && Bup && dBup && dS && B > 0 && N > 0 && r > 0 && lddb >= r, "aql_wside_reduce: bad args");
+  hipLaunchKernelGGL(wside_reduce_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, P, S, Bup, B, N, r, dBup, lddb, dS);
+  AQL_CHECK_LAUNCH("aql_wside_reduce");
+  return AQL_OK;
+}
+
 extern "C" int aql_lora_ds(const bf16_t* dTs, const bf16_t* T, int nb, int rows_per_sample, int r, float* dS,
                            hipStream_t stream) {
   AQL_CHECK_ARG(dTs && T && dS && r % 8 == 0 && r <= 1024, "aql_lora_ds: bad args (r=%d)", r);

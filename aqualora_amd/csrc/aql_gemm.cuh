@@ -10,6 +10,7 @@
 // with 4 consecutive output columns of one output row; LDS rows are 128 B (8 chunks of 16 B) with the chunk index
 // XOR-swizzled by (row >> 1) & 7 so that staging and ds_read_b128 fragment reads are bank-conflict free.
 #pragma once
+#include <type_traits>
 #include "aql_common.h"
 
 namespace aqlgemm {
@@ -39,7 +40,29 @@ struct PlainLoader {
   // weight tile holds 80 "value" rows [n0, n0+80) and the matching 80 "gate" rows [F+n0, F+n0+80).  0 = plain rows.
   int gsplit = 0, goff = 0;
   int row_lo = 0;  // rows below row_lo read as zeros (segment 1 of a twin batch: the clean half has no LoRA term)
+  // Per-sample operand (the weight side of a GEMM whose weights differ per sample: W + Bup.diag(S_b).A, aql_gemm_bf16_sw): the
+  // workgroup whose first output row is m0 reads sample s = m0 / srows - s0 of `sbase` (stride `sstride` elements) instead of
+  // `base` when s >= 0.  srows is a multiple of every tile height, so a tile never straddles two samples.  srows = 0: off.
+  const bf16_t* sbase = nullptr;
+  long sstride = 0;
+  int srows = 0, s0 = 0;
 };
+
+// the weight-side loader of the workgroup whose output tile starts at row m0 (see PlainLoader::sbase)
+template <class LB>
+__device__ __forceinline__ LB sample_operand(const LB& l, int m0) {
+  LB r = l;
+  if constexpr (std::is_same<LB, PlainLoader>::value) {
+    // block-uniform (m0 comes from the block index): kept in scalar registers through readfirstlane, the buffer descriptor built
+    // from the result must be wave-uniform
+    const int rows = l.srows > 0 ? l.srows : 1;
+    const int s = __builtin_amdgcn_readfirstlane(m0 / rows - l.s0);
+    const bool use = l.srows > 0 && s >= 0;
+    const long off = use ? (long)s * l.sstride : 0;
+    r.base = (use ? l.sbase : l.base) + off;
+  }
+  return r;
+}
 
 // Forward 3x3 conv, NHWC input [B,Hin,Win,Cin]; row r = (b,ho,wo); k = (kh*3+kw)*Cin + ci.
 // ups=1 reads the input through a nearest x2 upsample (diffusers Upsample2D) without materialising it.
@@ -82,6 +105,7 @@ struct EpiParams {
   const bf16_t* bias;      // [N] or null
   const bf16_t* residual;  // [M][ldr] or null
   long ldr;
+  int res_mod = 0;         // > 0: row m reads residual row m % res_mod (the same [res_mod][N] block under every sample of a stacked M)
   bf16_t* C2;              // second output (row-scaled) or null
   long ldc2;
   const bf16_t* rowscale;  // [nsamples][N]
@@ -757,7 +781,7 @@ __device__ __forceinline__ void epi_store_tile(const char* lds, int m0, int n0, 
       uint4 rs[U], hv[U], hg[U];
       if (has_res) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) rs[u] = *reinterpret_cast<const uint4*>(ep.residual + om[u] * ep.ldr + nn[u]);
+        for (int u = 0; u < U; ++u) rs[u] = *reinterpret_cast<const uint4*>(ep.residual + (ep.res_mod ? om[u] % ep.res_mod : om[u]) * ep.ldr + nn[u]);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -789,7 +813,7 @@ __device__ __forceinline__ void epi_store_tile(const char* lds, int m0, int n0, 
       }
       if (has_res) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) rs[u] = *reinterpret_cast<const uint4*>(ep.residual + om[u] * ep.ldr + nn[u]);
+        for (int u = 0; u < U; ++u) rs[u] = *reinterpret_cast<const uint4*>(ep.residual + (ep.res_mod ? om[u] % ep.res_mod : om[u]) * ep.ldr + nn[u]);
       }
       if (has_c2) {
 #pragma unroll
@@ -852,7 +876,7 @@ __device__ __forceinline__ void gemm_body_d(const GemmArgs<LA, LB>& g, const int
   DmaStager<BN, LB> sb;
   constexpr int NLD = BM / 32 + BN / 32;  // LDS-DMA instructions per thread per K tile
   sa.begin(g.a0, g.a1, dual, m0, tid, kt_begin, kt_end, g.ktiles0);
-  sb.begin(g.b0, g.b1, dual, n0, tid, kt_begin, kt_end, g.ktiles0);
+  sb.begin(sample_operand(g.b0, m0), g.b1, dual, n0, tid, kt_begin, kt_end, g.ktiles0);
 
   uint2 biasr[FN];  // fetched ahead of the ring fill (older than every DMA: the counted vmcnt waits below retire them first)
   if constexpr (EPI == EPI_BF16) epi_load_bias<FN>(biasr, g.epi.bias, g.b0.base, n0, wn0, lane, g.N, gF, BN / 2);
@@ -1056,7 +1080,7 @@ __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int
     DmaStager<BM, LA, RPI> sa;  // row descriptors only: tiles go global -> LDS directly (no staging registers, no ds_write)
     DmaStager<BN, LB, RPI> sb;
     sa.begin(g.a0, g.a1, dual, m0, ltid, kt_begin, kt_end, g.ktiles0);
-    sb.begin(g.b0, g.b1, dual, n0, ltid, kt_begin, kt_end, g.ktiles0);
+    sb.begin(sample_operand(g.b0, m0), g.b1, dual, n0, ltid, kt_begin, kt_end, g.ktiles0);
     auto issue = [&](int stage) {  // stages the NEXT tile of the K range (tiles are requested in order)
       char* sA = lds + stage * STAGE;
       sa.dma(sA, wave - NCW);

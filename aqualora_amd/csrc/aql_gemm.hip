@@ -130,6 +130,7 @@ struct OutSpec {
   int c_row0 = 0;
   const bf16_t* gb_h = nullptr;  // GEGLU-backward epilogue (EpiParams::gb_F = N): saved pre-activation [M][2N]
   long gb_ldh = 0;
+  int res_mod = 0;               // EpiParams::res_mod
 };
 
 inline int pick_splits(int tiles, int kt_total, long M, int N, size_t ws_bytes) {
@@ -311,7 +312,7 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
       if (s >= 1) splits = s;
     }
   }
-  if (o.gb_h != nullptr && splits > 1) return AQL_NOT_FUSED;   // the slab + finalize path has no GEGLU-backward epilogue
+  if ((o.gb_h != nullptr || o.res_mod > 0) && splits > 1) return AQL_NOT_FUSED;   // the slab + finalize path has neither epilogue
   g.splits = splits;
   // LDS-DMA staging everywhere (measured fastest on every shape, hot or cold operands); a grid of <= 1 workgroup per CU
   // cannot hide latency with occupancy, so it gets the deep stage ring instead
@@ -345,6 +346,7 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
   g.epi.ldg = o.ldg;
   g.epi.geglu_F = o.geglu_F;
   g.epi.c_row0 = o.c_row0;
+  g.epi.res_mod = o.res_mod;
   if (o.gb_h != nullptr) g.epi.gb_h = o.gb_h, g.epi.gb_ldh = o.gb_ldh, g.epi.gb_F = g.N;
   launch_cfg<LA, LB, EPI_BF16>(cfg, pd, g, stream);
   AQL_CHECK_LAUNCH(name);
@@ -490,6 +492,62 @@ extern "C" int aql_gemm_bf16_geglu(const bf16_t* A, long lda, const bf16_t* B, l
   OutSpec o{bias, nullptr, 0, 1, nullptr, 0, H, ldh, nullptr, 0, nullptr, G, ldg, F};
   o.c_row0 = (int)(lora_row0 < 0 ? 0 : (lora_row0 > M ? M : lora_row0));   // H is only needed where backward runs
   return run_bf16_gemm(g, o, nullptr, 0, stream, "aql_gemm_bf16_geglu");
+}
+
+// The general bf16 GEMM with PER-SAMPLE weights -- the weight-side form of the watermark-LoRA linear (utils/lora_modules.py:9-26,
+// 56-62): where the rank is not small against the channel count (r = 320 on the 320-channel level: BASELINE config 3) the
+// activation-side branch ((x.A^T) * S_b).Bup^T costs 6 M r (N + K) FLOPs per site and sample over forward, backward-data and the
+// weight gradients, the effective weight  We_b = W + Bup.diag(S_b).A  built once per sample costs 2 N K r and turns forward and
+// backward-data into plain GEMMs:
+//     C[m][:] = A[m][:] . Wsel(m)^T (+ bias) (+ residual)     Wsel(m) = B                               for m <  srow0
+//                                                                     = Bs + ((m - srow0) / srows) * sstride  otherwise
+// (twin batches: rows below srow0 are the clean pass and use the frozen W).  srows (rows per sample) must be a multiple of 256 so
+// that no tile straddles two samples; srow0 a multiple of srows.  The same entry BUILDS the per-sample weights: with A = the stacked
+// scaled up-matrices [(b, n)][r], B = A_down^T [K][r], residual = W [N][K] and res_mod = N it writes We [(b, n)][K] = W + (Bup*S_b).A.
+// geglu_F > 0: ff.net.0 -- B / Bs hold 2 geglu_F rows ([value | gate]), G [M][geglu_F] = value * gelu(gate), C (= H, may be null)
+// is written for rows >= c_row0.  gb_h != null: the GEGLU-backward epilogue of aql_gemm_bf16_geglu_bwd (C = DH [M][2N]).
+// Returns AQL_NOT_FUSED (100) where the GEGLU forms have no tile.
+extern "C" int aql_gemm_bf16_sw(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, int N, int K, const bf16_t* Bs,
+                                long sstride, long srows, long srow0, const bf16_t* bias, const bf16_t* residual, long ldr,
+                                long res_mod, bf16_t* C, long ldc, bf16_t* G, long ldg, int geglu_F, long c_row0,
+                                const bf16_t* gb_h, long gb_ldh, float* ws, size_t ws_bytes, hipStream_t stream) {
+  AQL_CHECK_ARG(A && B && (C || (geglu_F > 0 && G)), "aql_gemm_bf16_sw: null operand");
+  AQL_CHECK_ARG(M > 0 && N > 0 && K > 0 && M < (1L << 31) && N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+                    (C == nullptr || ldc % 8 == 0), "aql_gemm_bf16_sw: bad shape M=%ld N=%d K=%d", M, N, K);
+  AQL_CHECK_ARG(aligned16(A) && aligned16(B) && aligned16(C) && aligned16(Bs) && aligned16(G), "aql_gemm_bf16_sw: pointers must be 16-byte aligned");
+  AQL_CHECK_ARG(residual == nullptr || (ldr % 8 == 0 && aligned16(residual) && res_mod >= 0), "aql_gemm_bf16_sw: bad residual");
+  AQL_CHECK_ARG(Bs == nullptr || (srows > 0 && srows % 256 == 0 && srow0 >= 0 && srow0 % srows == 0 && sstride % 8 == 0),
+                "aql_gemm_bf16_sw: rows per sample (%ld) must be a multiple of 256, srow0 (%ld) a multiple of it", srows, srow0);
+  AQL_CHECK_ARG(geglu_F == 0 || (geglu_F > 0 && N == 2 * geglu_F && G != nullptr && ldg % 8 == 0 && residual == nullptr && gb_h == nullptr),
+                "aql_gemm_bf16_sw: GEGLU form needs N = 2 F, G and no residual");
+  AQL_CHECK_ARG(gb_h == nullptr || (gb_ldh % 8 == 0 && gb_ldh >= 2 * N && aligned16(gb_h) && bias == nullptr), "aql_gemm_bf16_sw: bad GEGLU-backward operand");
+  if (geglu_F > 0 && geglu_F % 80 != 0) return AQL_NOT_FUSED;
+  GemmArgs<PlainLoader, PlainLoader> g;
+  g.a0 = plain(A, lda, M, K);
+  g.b0 = plain(B, ldb, N, K);
+  if (geglu_F > 0) g.b0.gsplit = 80, g.b0.goff = geglu_F - 80;
+  if (Bs != nullptr) {
+    g.b0.sbase = Bs;
+    g.b0.sstride = sstride;
+    g.b0.srows = (int)srows;
+    g.b0.s0 = (int)(srow0 / srows);
+  }
+  g.ktiles0 = aql_cdiv(K, BK);
+  g.ktiles1 = 0;
+  g.a1 = g.a0;
+  g.b1 = g.b0;
+  g.M = (int)M;
+  g.N = N;
+  OutSpec o{bias, nullptr, 0, 1, residual, ldr, C, ldc, nullptr, 0, nullptr};
+  o.res_mod = (int)res_mod;
+  if (geglu_F > 0) {
+    o.G = G, o.ldg = ldg, o.geglu_F = geglu_F;
+    o.c_row0 = (int)(c_row0 < 0 ? 0 : (c_row0 > M ? M : c_row0));
+  }
+  if (gb_h != nullptr) o.gb_h = gb_h, o.gb_ldh = gb_ldh;
+  // split K only for the plain form (the slab path knows neither the GEGLU epilogues nor the residual modulo)
+  const bool plain_form = geglu_F == 0 && gb_h == nullptr && res_mod == 0;
+  return run_bf16_gemm(g, o, plain_form ? ws : nullptr, plain_form ? ws_bytes : 0, stream, "aql_gemm_bf16_sw");
 }
 
 // Skinny rank-r "down" GEMM for r <= 64: HBM-bound (reads X once), so no LDS staging of operands.  A workgroup owns

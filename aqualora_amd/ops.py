@@ -369,6 +369,7 @@ class DeferredDW:
     def __init__(self, device, max_sites=1024, defer_wide=True):
         self.device = device
         self.defer_wide = defer_wide   # kept for callers; wide problems are always grouped now
+        self.allow_post = False        # set by a trainer whose exchange form runs `flush` (single GPU): enables the weight-side LoRA form
         self.host, self.dev = {}, {}
         for k, (nbytes, _, _, _) in self.KINDS.items():
             self.host[k] = torch.zeros(2 * max_sites * nbytes, dtype=torch.uint8).pin_memory()
@@ -385,6 +386,7 @@ class DeferredDW:
         self.keep = []
         self.items = []    # (C, kind, nblk, direct args or None) in arrival order; kind "d" = launched on its own
         self.buckets = None
+        self.post = []     # weight-side LoRA sites: callables run between two grouped launches of `flush` (see wside_backward)
 
     @property
     def n_tn(self):
@@ -466,7 +468,29 @@ class DeferredDW:
         self.items = []
 
     def flush(self):
-        self.flush_tn()
+        """One grouped launch per table for everything queued; then the post-phase of the weight-side LoRA sites (they read the
+        per-sample dY^T X products of the first launch and queue their dA problems) and a second launch over the NEW descriptors
+        only.  The descriptor tables are append-only within a step: under graph capture the H2D copy nodes re-read the pinned host
+        tables at every replay, so a slot must never be rewritten between the two launches."""
+        mark = {"n": (0, 0), "w": (0, 0), "items": 0}
+
+        def launch_new():
+            for k in ("n", "w"):
+                first, base = mark[k]
+                if self.n[k] > first:
+                    self._launch(k, first, self.n[k] - first, base, self.blk[k] - base)
+                mark[k] = (self.n[k], self.blk[k])
+            for C, k, _, direct in self.items[mark["items"]:]:
+                if k == "d":
+                    gemm_tn_acc(direct[0], direct[1], C, direct[2])
+            mark["items"] = len(self.items)
+
+        launch_new()
+        if self.post:
+            post, self.post = self.post, []
+            for fn in post:
+                fn()
+            launch_new()
         self.flush_ds()
         self.reset()
 
@@ -625,6 +649,117 @@ def _geglu_fused(x2d, packed, site, S16, rps, T, Ts, G, H, row0=0):
     return "done"
 
 
+# ----------------------------------------------------------------------- weight-side form of the LoRA linear
+# OFF by default (AQL_WSIDE=1 enables it): measured round 4 on MI355X, BASELINE config 3 (rank 320, batch 8): 51.9 ms per step
+# against 49.4 ms for the activation-side branch (profiles/r04_weight_side_lora.txt).  The FLOPs it removes (5.0 -> 1.1 GFLOP per
+# square site and sample) are the EFFICIENT ones -- 32768-row GEMMs at 20-30 us each -- and what it adds are eight per-sample token
+# reductions plus ~8 small launches per site.  Parity with the activation-side branch: 2-5e-3 relative L2 on every output and gradient.
+_WSIDE = os.environ.get("AQL_WSIDE", "0") == "1"
+
+
+def gemm_sw(A, B, N, K, out, Bs=None, sstride=0, srows=0, srow0=0, bias=None, residual=None, res_mod=0, G=None, geglu_F=0,
+            c_row0=0, gb_h=None):
+    """aql_gemm_bf16_sw: out[m] = A[m] . Wsel(m)^T (+ bias) (+ residual[m % res_mod]) with per-sample weights behind row srow0
+    (see include/aqualora_hip.h).  Returns the raw status (100 = the GEGLU form has no tile for this shape)."""
+    M = A.shape[0]
+    ws = workspace(A.device)
+    return L.call_raw("aql_gemm_bf16_sw", L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), M, N, K, L.ptr(Bs), int(sstride), int(srows),
+                      int(srow0), L.ptr(bias), L.ptr(residual), 0 if residual is None else residual.stride(0), int(res_mod),
+                      L.ptr(out), 0 if out is None else out.stride(0), L.ptr(G), 0 if G is None else G.stride(0), int(geglu_F),
+                      int(c_row0), L.ptr(gb_h), 0 if gb_h is None else gb_h.stride(0), L.ptr(ws), ws.numel() * 4, L.stream_ptr())
+
+
+def wside_ok(packed, site, S16, rps, geglu=False):
+    """Does the weight-side form (per-sample effective weights We_b = W + Bup.diag(S_b).A) pay for this site?
+    Activation side: 6 rps r (N + K) FLOPs per sample over forward, backward-data and the two weight gradients.  Weight side:
+    8 N K r (We, We^T, and the two r-wide products that turn dWe into dA / dBup / dS) + 2 rps N K (dWe = dY^T X).  Taken when the
+    ratio exceeds 1.5 (rank 320 on the 320-channel level: 4.6x for the square projections, 2.6x for the feed-forward pair; the
+    640-channel level sits at 1.3x and below and stays on the activation side), at ranks above 32 (rank 32 has the one-launch
+    kernel), with whole 256-row tiles per sample, and only where the weight gradients are flushed in one piece (single GPU):
+    the bucketed / overlapped data-parallel exchanges plan their buckets over direct weight-gradient outputs."""
+    if not _WSIDE or site is None or S16 is None or site.rank <= 32 or rps % 256 != 0 or REF_ROUNDING:
+        return False
+    if geglu and (packed.N // 2) % 80 != 0:
+        return False
+    dfr = DEFERRED
+    if dfr is not None and not getattr(dfr, "allow_post", False):
+        return False
+    r, N, K = site.rank, packed.N, packed.K
+    if r % 8 or N % 8 or K % 8:
+        return False
+    return 6.0 * rps * r * (N + K) > 1.5 * (8.0 * N * K * r + 2.0 * rps * N * K)
+
+
+def wside_weights(packed, site, S16):
+    """(We [(b, n)][K], WeT [(b, k)][N]) bf16 for the B scale rows S16 [B, r]: two GEMMs over the rank, the frozen weight as the
+    residual under every sample (res_mod).  The scaled stacks Bup * S_b / A^T * S_b are broadcast multiplies (plumbing)."""
+    B, r = S16.shape
+    N, K = packed.N, packed.K
+    dev = S16.device
+    bs = (site.b16.unsqueeze(0) * S16.unsqueeze(1)).reshape(B * N, r)        # [(b, n)][r]: kept for backward (the dA problem)
+    We = torch.empty(B * N, K, dtype=torch.bfloat16, device=dev)
+    L.check(gemm_sw(bs, site.at16, K, r, We, residual=packed.w, res_mod=N), "aql_gemm_bf16_sw (We)")
+    ats = (site.at16.unsqueeze(0) * S16.unsqueeze(1)).reshape(B * K, r)      # [(b, k)][r]
+    WeT = torch.empty(B * K, N, dtype=torch.bfloat16, device=dev)
+    L.check(gemm_sw(ats, site.b16, N, r, WeT, residual=packed.wt, res_mod=K), "aql_gemm_bf16_sw (We^T)")
+    return We, WeT, bs
+
+
+def wside_backward(dy, x2d, WeT, bs, S16, packed, site, rps, ds_accum, want_dx, ret_ds, s_dtype, dx_prev, geglu_h=None):
+    """Backward of the weight-side form: dX = dY . We_b (plain GEMM with per-sample weights; for ff.net.2 with the GEGLU-backward
+    epilogue), dWe_b = dY_b^T X_b per sample (token-reduction problems on the trainer's grouped launch), then -- after that launch --
+        P[(b, n)][j] = sum_k dWe_b[n][k] A[j][k]                      one GEMM over K
+        dBup[n][j] += sum_b P[(b,n)][j] S_b[j]      dS_b[j] += sum_n Bup[n][j] P[(b,n)][j]        aql_wside_reduce
+        dA[j][k]   += sum_(b,n) (Bup[n][j] S_b[j]) dWe_b[n][k]        one token-reduction problem over (b, n); `bs` from forward
+    Returns (dX or None, dS in s_dtype or None)."""
+    M, N, K, r = dy.shape[0], packed.N, packed.K, site.rank
+    B = S16.shape[0]
+    dev = dy.device
+    dx = None
+    if want_dx:
+        if geglu_h is not None:       # ff.net.2: X = GEGLU(H); the epilogue turns d(activated) [M, K] into d(H) [M, 2K]
+            dh = torch.empty(M, 2 * K, dtype=torch.bfloat16, device=dev)
+            rc = gemm_sw(dy, packed.wt, K, N, dh, Bs=WeT, sstride=K * N, srows=rps, srow0=0, gb_h=geglu_h)
+            if rc != 100:
+                L.check(rc, "aql_gemm_bf16_sw (GEGLU backward)")
+                dx = dh
+        if dx is None:
+            dx = torch.empty(M, K, dtype=torch.bfloat16, device=dev)
+            L.check(gemm_sw(dy, packed.wt, K, N, dx, Bs=WeT, sstride=K * N, srows=rps, srow0=0, residual=dx_prev), "aql_gemm_bf16_sw (dX)")
+            if geglu_h is not None:
+                dh = torch.empty_like(geglu_h)
+                L.call("aql_geglu_bwd", L.ptr(geglu_h), L.ptr(dx), M, geglu_h.shape[1] // 2, L.ptr(dh), L.stream_ptr())
+                dx = dh
+    acc = ds_accum
+    want_ds = ret_ds or acc is not None
+    dS = torch.zeros(B, r, dtype=torch.float32, device=dev) if (acc is None) else None
+    ds_target = acc if acc is not None else dS
+    dfr = DEFERRED
+    immediate = dfr is None or not getattr(dfr, "allow_post", False) or (want_ds and acc is None)
+    Gw = torch.zeros(B, N, K, dtype=torch.float32, device=dev)               # dWe_b = dY_b^T X_b, rows (b, n)
+    for b in range(B):
+        u, v, c = dy[b * rps:(b + 1) * rps], x2d[b * rps:(b + 1) * rps], Gw[b]
+        if immediate or not dfr.add_tn(u, v, c):
+            gemm_tn_acc(u, v, c)
+    ga, gb = site.ga, site.gb
+
+    def post():
+        G16 = Gw.view(B * N, K).to(torch.bfloat16)
+        P = gemm_bf16(G16, site.a16)                                         # [(b, n)][r]
+        L.call("aql_wside_reduce", L.ptr(P), L.ptr(S16), L.ptr(site.b16), B, N, r, L.ptr(gb), gb.stride(0), L.ptr(ds_target),
+               L.stream_ptr())
+        if immediate or not dfr.add_tn(bs, G16, ga):
+            gemm_tn_acc(bs, G16, ga)
+
+    if immediate:
+        post()
+    else:
+        dfr.post.append(post)
+    if dS is not None:
+        dS = dS.to(s_dtype) if ret_ds else None
+    return dx, dS
+
+
 class LoraLinearFn(torch.autograd.Function):
     """Y = X.W^T + b [+ ((X.A^T) * S[sample]).Bup^T] [+ residual]   on token-major X [M,K].
 
@@ -653,6 +788,35 @@ class LoraLinearFn(torch.autograd.Function):
         ctx.s_dtype = S.dtype if S is not None else None
         ctx.geglu = geglu
         T = Ts = Tk = Tsk = S16k = None
+        ctx.wside = use_lora and wside_ok(packed, site, S16, rps, geglu)
+        if ctx.wside:
+            # weight-side form (rank 320 on the 320-channel level): per-sample effective weights, plain GEMMs, no T / Ts
+            ctx.ds_accum = getattr(S, "_aql_ds_accum", None)
+            We, WeT, bs = wside_weights(packed, site, S16)
+            row0 = M if twin else 0     # twin batch: rows [0, M) are the clean pass and use the frozen W
+            F = packed.N // 2
+            Mk = xk.shape[0]
+            if geglu:
+                assert residual is None
+                yk, y = _alloc((M, F), torch.bfloat16, dev, twin)
+                hk, h = _alloc((M, packed.N), torch.bfloat16, dev, twin) if want_h else (None, None)
+                rc = gemm_sw(xk, packed.w, packed.N, packed.K, hk, Bs=We, sstride=packed.N * packed.K, srows=rps, srow0=row0,
+                             bias=packed.bias, G=yk, geglu_F=F, c_row0=row0 if _TWIN_SKIP else 0)
+                if rc == 100:           # no 160-wide tile: plain GEMM into H, then the activation kernel
+                    if hk is None:
+                        hk, h = _alloc((M, packed.N), torch.bfloat16, dev, twin)
+                    L.check(gemm_sw(xk, packed.w, packed.N, packed.K, hk, Bs=We, sstride=packed.N * packed.K, srows=rps,
+                                    srow0=row0, bias=packed.bias), "aql_gemm_bf16_sw")
+                    L.call("aql_geglu_fwd", L.ptr(hk), Mk, F, L.ptr(yk), L.stream_ptr())
+                else:
+                    L.check(rc, "aql_gemm_bf16_sw (GEGLU)")
+                ctx.save_for_backward(x2d, WeT, bs, S16, h)
+                return y
+            yk, y = _alloc((M, packed.N), torch.bfloat16, dev, twin)
+            L.check(gemm_sw(xk, packed.w, packed.N, packed.K, yk, Bs=We, sstride=packed.N * packed.K, srows=rps, srow0=row0,
+                            bias=packed.bias, residual=resk), "aql_gemm_bf16_sw")
+            ctx.save_for_backward(x2d, WeT, bs, S16, None)
+            return y
         if use_lora:
             r = site.rank
             S16k = _need_full(S16, "the LoRA scale") if twin else S16
@@ -724,18 +888,20 @@ class LoraLinearFn(torch.autograd.Function):
         if ctx.use_lora:
             x2d, T, Ts, S16 = ctx.saved_tensors[:4]
             dx, dS = _lora_backward(dy, x2d, T, Ts, S16, packed, site, ctx.rps, ctx.ds_accum, ctx.needs_input_grad[0],
-                                    ctx.needs_input_grad[3], ctx.s_dtype, None)
+                                    ctx.needs_input_grad[3], ctx.s_dtype, None, wside=ctx.wside)
         else:
             dx = gemm_bf16(dy, packed.wt) if ctx.needs_input_grad[0] else None
         return dx, None, None, dS, None, None, (dy if ctx.has_res else None), None, None
 
 
-def _lora_backward(dy, x2d, T, Ts, S16, packed, site, rps, ds_accum, want_dx, ret_ds, s_dtype, dx_prev, geglu_h=None):
+def _lora_backward(dy, x2d, T, Ts, S16, packed, site, rps, ds_accum, want_dx, ret_ds, s_dtype, dx_prev, geglu_h=None, wside=False):
     """Backward of one LoRA linear  Y = X.W^T + ((X.A^T)*S).Bup^T :  dTs = dY.Bup, dT = dTs*S, dX = dY.W + dT.A (+ dx_prev, added
     in the GEMM epilogue), dS += rowsum(dTs*T) per sample, and the weight gradients dBup += dY^T.Ts, dA += dT^T.X (queued on the
     trainer's DeferredDW when there is one).  Returns (dX or None, dS in s_dtype or None).
     ``geglu_h`` (ff.net.2 only): X is GEGLU(H); the returned gradient is d(H) [M, 2F] -- the GEGLU backward runs in the epilogue
     of the same launch (aql_lora_gemm_fused_geglu_bwd), or as aql_geglu_bwd behind the unfused forms."""
+    if wside:   # weight-side form: T holds We^T [(b, k)][N], Ts the scaled up-matrices [(b, n)][r] (LoraLinearFn.forward)
+        return wside_backward(dy, x2d, T, Ts, S16, packed, site, rps, ds_accum, want_dx, ret_ds, s_dtype, dx_prev, geglu_h)
     M = dy.shape[0]
     r = site.rank
     dS = None
@@ -821,6 +987,7 @@ class FeedForwardFn(torch.autograd.Function):
         y = LoraLinearFn.forward(c2, g, packed2, site2, S, S16, rps, residual, False, True)
         ctx.p0, ctx.s0, ctx.p2, ctx.s2, ctx.rps = packed0, site0, packed2, site2, rps
         ctx.ds_accum, ctx.s_dtype, ctx.has_res = c0.ds_accum, S.dtype, residual is not None
+        ctx.w0, ctx.w2 = c0.wside, c2.wside
         _, T0, Ts0, _, h = c0.saved
         _, T2, Ts2, _, _ = c2.saved
         ctx.save_for_backward(x2d, T0, Ts0, S16, h, g, T2, Ts2)
@@ -832,9 +999,9 @@ class FeedForwardFn(torch.autograd.Function):
         dy = dy.contiguous()
         ret_ds = ctx.needs_input_grad[5]
         dh, dS2 = _lora_backward(dy, g, T2, Ts2, S16, ctx.p2, ctx.s2, ctx.rps, ctx.ds_accum, True, ret_ds, ctx.s_dtype, None,
-                                 geglu_h=h)
+                                 geglu_h=h, wside=ctx.w2)
         dx, dS0 = _lora_backward(dh, x2d, T0, Ts0, S16, ctx.p0, ctx.s0, ctx.rps, ctx.ds_accum, ctx.needs_input_grad[0], ret_ds,
-                                 ctx.s_dtype, None)
+                                 ctx.s_dtype, None, wside=ctx.w0)
         dS = None
         if dS0 is not None or dS2 is not None:
             dS = dS0 if dS2 is None else (dS2 if dS0 is None else dS0 + dS2)

@@ -118,6 +118,9 @@ class PPFTTrainer:
         finishes leg i (lora.backward_stage: up path | mid + down_blocks.3/.2 | down_blocks.1) -- and the rest."""
         dev = self.bank.grad.device
         self.deferred = ops.DeferredDW(dev, defer_wide=self.bucketed)
+        # the weight-side LoRA form (ops.wside_ok) folds per-sample dY^T X products into dA / dBup / dS between two grouped launches
+        # of `flush`: only the single-GPU form of the step flushes in one piece
+        self.deferred.allow_post = not (self.split or self.bucketed)
         self.deferred_legs, self.router = [], None
         if self.split:
             cuts = [c for c in self.bank.cuts[:self.n_legs]]
@@ -447,6 +450,7 @@ class PPFTTrainer:
         # DeferredDW so that a later eager step() cannot rewrite them
         eager_deferred = self.deferred
         self.deferred = ops.DeferredDW(eager_deferred.device, defer_wide=False)
+        self.deferred.allow_post = eager_deferred.allow_post
         with torch.cuda.graph(g_fb, capture_error_mode="thread_local"):
             loss, _, _ = self.forward_backward(**static)
         with torch.cuda.graph(g_opt, pool=g_fb.pool(), capture_error_mode="thread_local"):

@@ -42,6 +42,18 @@ int aql_gemm_bf16_ex(const bf16_t* A, long lda, const bf16_t* B, long ldb, long 
                      int rows_per_sample, const bf16_t* residual, long ldr, bf16_t* C, long ldc, long lora_row0, float* ws,
                      size_t ws_bytes, aql_stream_t stream);
 
+/* The same GEMM with PER-SAMPLE weights: the weight-side form of the watermark-LoRA linear (utils/lora_modules.py:9-26,56-62) for
+ * ranks that are not small against the channel count (rank 320 on 320 channels, BASELINE config 3):
+ *   C[m][:] = A[m][:] . Wsel(m)^T (+ bias) (+ residual[res_mod ? m % res_mod : m]),
+ *   Wsel(m) = B for m < srow0, else Bs + ((m - srow0) / srows) * sstride       (We_b = W + Bup.diag(S_b).A, built by this entry too:
+ *   A = stacked scaled up-matrices [(b,n)][r], B = A_down^T, residual = W with res_mod = N).  srows % 256 == 0.
+ * geglu_F > 0: the ff.net.0 form of aql_gemm_bf16_geglu (C = H may be null, written for rows >= c_row0); gb_h: the GEGLU-backward
+ * epilogue of aql_gemm_bf16_geglu_bwd.  Returns 100 where the GEGLU forms have no tile.                                          */
+int aql_gemm_bf16_sw(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, int N, int K, const bf16_t* Bs, long sstride,
+                     long srows, long srow0, const bf16_t* bias, const bf16_t* residual, long ldr, long res_mod, bf16_t* C,
+                     long ldc, bf16_t* G, long ldg, int geglu_F, long c_row0, const bf16_t* gb_h, long gb_ldh, float* ws,
+                     size_t ws_bytes, aql_stream_t stream);
+
 /* T = X.Adown^T ; Ts = T * S[m / rows_per_sample]   ==  down(x) @ diag_embed(scale)
  *   utils/lora_modules.py:13-17 (linear) and :33-36 (conv, scale[:, :, None, None]).                           */
 /* Backward reuse: with X = dY, Adown = up.weight^T it yields dTs and dT = dTs*S; passing Tref (the forward T) and dS
@@ -235,6 +247,11 @@ int aql_cast_transpose(const float* w, int rows, int cols, bf16_t* out, bf16_t* 
 int aql_cast_transpose_batched(const void* desc, int n, int total_tiles, aql_stream_t stream);
 /* dS[b,j] += sum_{m in sample b} dTs[m,j]*T[m,j]: gradient of the diagonal (autograd of diag_embed, :16-17)         */
 int aql_lora_ds(const bf16_t* dTs, const bf16_t* T, int nb, int rows_per_sample, int r, float* dS, aql_stream_t stream);
+/* Weight-side form of the LoRA linear (aql_gemm_bf16_sw): with P[b][n][j] = sum_k (dY_b^T X_b)[n][k] A[j][k] (bf16, [B][N][r]),
+ * dBup[n][j] += sum_b P[b][n][j] S[b][j]  and  dS[b][j] += sum_n Bup[n][j] P[b][n][j]  (the gradients of up.weight and of the
+ * diagonal in utils/lora_modules.py:13-19).  dS must tolerate fp32 atomics (zeroed by the caller once per step).                 */
+int aql_wside_reduce(const bf16_t* P, const bf16_t* S, const bf16_t* Bup, int B, int N, int r, float* dBup, long lddb, float* dS,
+                     aql_stream_t stream);
 /* grouped form (48-byte host descriptors, same protocol as aql_tn_desc_fill)                                         */
 int aql_ds_desc_fill(void* host_desc, const bf16_t* dTs, const bf16_t* T, int nb, int rows_per_sample, int r, float* dS,
                      int first_block);

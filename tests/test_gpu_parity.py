@@ -1070,6 +1070,19 @@ def test_fuse_lora_and_ddim_sampler():
     assert relerr(a, xr) < 1e-4
 
 
+def test_weight_side_lora_form_equals_the_activation_side_branch():
+    """The opt-in weight-side form of the LoRA linear (AQL_WSIDE=1: per-sample effective weights W + Bup.diag(S_b).A through
+    aql_gemm_bf16_sw, per-sample dY^T X, aql_wside_reduce) against the default activation-side branch on
+    the same inputs: outputs, dX, dS, dA, dBup of a square 320 -> 320 site and of the feed-forward pair (GEGLU forward and backward
+    epilogues with per-sample weights) at rank 320, 1024 and 4096 tokens per sample: relative L2 < 3e-2 (measured 2-5e-3: the bf16
+    rounding of the effective weight instead of the bf16 rounding of T).  tools/probe_wside.py prints the numbers."""
+    import os, subprocess, sys
+    from tests.conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probe_wside.py")], cwd=ROOT, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and "ALL PASS" in out.stdout and "FAIL" not in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_bench_under_torchrun_with_rccl_collective():
     """The N>1 launch path on one GPU: bench.py under torch.distributed.run with the gradient all-reduce forced through
     RCCL (AQL_FORCE_ALLREDUCE=1).  Regression test: RCCL's watchdog thread calls hipEventQuery while the step is being
