@@ -152,7 +152,7 @@ static int env_int(const char* name, int dflt) {
 // Tile configurations.  ids 0-4: the transposing (token-reduction) kernels on the 32x32x16 MFMA; ids 5-10: the
 // pipelined buffer-load kernels on the 16x16x32 MFMA used by every bf16-output GEMM / conv.
 enum { P_128x160 = 5, P_64x160 = 6, P_32x160 = 7, P_64x64 = 8, P_128x32 = 9, P_128x128 = 10, P_W128x160 = 11, P_W64x160 = 12, P_W32x160 = 13,
-       P_W256x160 = 14, P_W256x160B = 15, P_W128x160L8 = 16 };   // experiments (-DAQL_BIGWAVE, AQL_TILE only): 15 = 256x160 on FOUR compute wavefronts of 128x80, 16 = 128x160 with EIGHT loader wavefronts
+       P_W256x160 = 14, P_W256x160B = 15, P_W128x160L8 = 16, P_256x256 = 17 };   // 17 (AQL_TILE only, -DAQL_T256 build): 256x256 on FOUR wavefronts of 128x128, one per SIMD, no loader wavefronts   // experiments (-DAQL_BIGWAVE, AQL_TILE only): 15 = 256x160 on FOUR compute wavefronts of 128x80, 16 = 128x160 with EIGHT loader wavefronts
 
 template <class LA, class LB, int EPI>
 void launch_cfg(int cfg, int pd, const GemmArgs<LA, LB>& g, hipStream_t stream) {
@@ -191,6 +191,11 @@ void launch_cfg(int cfg, int pd, const GemmArgs<LA, LB>& g, hipStream_t stream) 
       if (conv_row && r256 && aqlconvrow::try_conv_row<LA, EPI>(g, 256, stream)) return;
       if (conv_row == 1 && cfg == P_W128x160 && g.M % 128 == 0 && aqlconvrow::try_conv_row<LA, EPI>(g, 128, stream)) return;
     }
+#ifdef AQL_T256
+    if constexpr (std::is_same<LA, PlainLoader>::value && std::is_same<LB, PlainLoader>::value && EPI == EPI_BF16) {
+      if (cfg == P_256x256) return launch_gemm_d<256, 256, 128, 128, LA, LB, EPI, 2>(g, stream);
+    }
+#endif
     if (cfg == P_W256x160) return launch_gemm_w<256, 160, 64, 80, LA, LB, EPI, 3, 8>(g, stream);
 #ifdef AQL_BIGWAVE
     if (cfg == P_W256x160B) return launch_gemm_w<256, 160, 128, 80, LA, LB, EPI, 3, 4>(g, stream);
@@ -276,6 +281,7 @@ inline void pick_tile(long M, int N, int kt_total, bool can_split, int* cfg, int
     else *cfg = P_64x64, *tiles = aql_cdiv(M, 64) * aql_cdiv(N, 64);
   }
   if (force == P_64x64) *cfg = P_64x64, *tiles = aql_cdiv(M, 64) * aql_cdiv(N, 64);
+  if (force == P_256x256) *cfg = P_256x256, *tiles = aql_cdiv(M, 256) * aql_cdiv(N, 256);
   *pd = force_pd ? force_pd : 0;  // 0: chosen from the grid size once the split count is known
 }
 
