@@ -110,6 +110,7 @@ SIGNATURES = {
     "aql_prvl_loss_bwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "aql_ddim_step": [c_p, c_p, c_p, c_f, c_p, c_l, c_p],
     "aql_dpmpp2m_step": [c_p, c_p, c_p, c_f, c_p, c_p, c_l, c_p],
+    "aql_sampler_step": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p],
     "aql_lpips_scale": [c_p, c_i, c_i, c_i, c_p, c_p],
     "aql_lpips_scale_bwd": [c_p, c_i, c_i, c_i, c_p, c_p],
     "aql_relu_bf16": [c_p, c_l, c_p, c_p],

@@ -739,6 +739,61 @@ extern "C" int aql_ddim_step(float* x, const bf16_t* eps_u, const bf16_t* eps_c,
   return AQL_OK;
 }
 
+// ---- one phase of a captured sampling loop (evaluation/utils_eval.py:83-102: the schedulers behind `sampler=`) -----------------------
+// Every deterministic sampler of the table -- Euler, Heun, KDPM2, LMS, PLMS, DPM-Solver++ single-step, UniPC (and the ancestral
+// KDPM2 with caller-supplied noise) -- advances by LINEAR combinations of a handful of buffers between two U-Net calls: the state x,
+// one auxiliary state (Heun's / KDPM2's trial point, PLMS's / DPM-Solver's saved sample, UniPC's last sample), up to four history
+// entries and the guided noise prediction e = eps_u + g (eps_c - eps_u) that just arrived.  This kernel is that combination with
+// everything that varies per phase in DEVICE memory, so that ONE HIP graph [U-Net on the CFG batch, this kernel (twice)] replays for
+// every phase of every sampler (aqualora_amd/ksamplers.py writes the per-phase numbers):
+//   coef[0] g   coef[1] c_x   coef[2] c_aux   coef[3] c_e   coef[4..7] c_h0..c_h3   coef[8] c_noise   coef[9] next_in_scale
+//   coef[10] p_src   coef[11] p_e      (the value pushed into the history: p_src * SRC + p_e * e, SRC = the state the model just saw)
+//   flag[0] dst (0 = x, 1 = aux)   flag[1] push (shift h3 <- h2 <- h1 <- h0, h0 <- pushed value, BEFORE the combination)
+//   flag[2] next_src (0 = x, 1 = aux: which state the next model call reads)   flag[3] bit 0: no model output in this call (e = 0),
+//   bit 1: aux <- x before the combination (save the sample)   flag[4] src (which state the model just saw: 0 = x, 1 = aux)
+//   dst <- c_x x + c_aux aux + c_e e + sum_k c_hk h_k + c_noise noise ;   uin[0..n) = uin[n..2n) = next_in_scale * (next source)
+namespace {
+__global__ __launch_bounds__(256) void sampler_step_kernel(float* __restrict__ x, float* __restrict__ aux, float* __restrict__ hist,
+                                                           const float* __restrict__ noise, const bf16_t* __restrict__ eps_u,
+                                                           const bf16_t* __restrict__ eps_c, float* __restrict__ uin,
+                                                           const float* __restrict__ coef, const int* __restrict__ flag, long n) {
+  const float g = coef[0], cx = coef[1], ca = coef[2], ce = coef[3], cn = coef[8], nscale = coef[9], psrc = coef[10], pe = coef[11];
+  const float ch0 = coef[4], ch1 = coef[5], ch2 = coef[6], ch3 = coef[7];
+  const int dst = flag[0], push = flag[1], nsrc = flag[2], mode = flag[3], src = flag[4];
+  const bool no_eval = mode & 1, save = mode & 2;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x) {
+    float xv = x[id], av = aux[id];
+    float e = 0.f;
+    if (!no_eval) {
+      const float eu = bf16_to_f32(eps_u[id]), ec = bf16_to_f32(eps_c[id]);
+      e = eu + g * (ec - eu);
+    }
+    float h0 = hist[id], h1 = hist[n + id], h2 = hist[2 * n + id], h3 = hist[3 * n + id];
+    if (push) {
+      h3 = h2, h2 = h1, h1 = h0;
+      h0 = psrc * (src ? av : xv) + pe * e;
+      hist[id] = h0, hist[n + id] = h1, hist[2 * n + id] = h2, hist[3 * n + id] = h3;
+    }
+    if (save) av = xv;
+    float v = cx * xv + ca * av + ce * e + ch0 * h0 + ch1 * h1 + ch2 * h2 + ch3 * h3;
+    if (cn != 0.f) v += cn * noise[id];
+    if (dst) av = v; else xv = v;
+    x[id] = xv;
+    aux[id] = av;
+    const float u = nscale * (nsrc ? av : xv);
+    uin[id] = u;
+    uin[n + id] = u;
+  }
+}
+}  // namespace
+extern "C" int aql_sampler_step(float* x, float* aux, float* hist, const float* noise, const bf16_t* eps_u, const bf16_t* eps_c,
+                                float* uin, const float* coef, const int* flag, long n, hipStream_t stream) {
+  AQL_CHECK_ARG(x && aux && hist && noise && eps_u && eps_c && uin && coef && flag && n > 0, "aql_sampler_step: bad args");
+  hipLaunchKernelGGL(sampler_step_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, aux, hist, noise, eps_u, eps_c, uin, coef, flag, n);
+  AQL_CHECK_LAUNCH("aql_sampler_step");
+  return AQL_OK;
+}
+
 // ---- row softmax for the VAE's single-head, 512-wide attention (diffusers AutoencoderKL mid-block Attention; the flash
 // kernels of aql_attn.hip stop at d = 160): P[m, :] = softmax(scale * S[m, :]) with S fp32 (from aql_gemm_nt_f32_accum)
 // and P bf16.  One workgroup per row; the row is read three times (max, sum, write) and stays in L2.

@@ -277,6 +277,13 @@ int aql_ddim_step(float* x, const bf16_t* eps_uncond, const bf16_t* eps_cond, fl
  * coef (device) = {alpha_t, sigma_t, a, b, c}                                                                         */
 int aql_dpmpp2m_step(float* x, const bf16_t* eps_u, const bf16_t* eps_c, float guidance, float* x0_prev,
                      const float* coef, long n, aql_stream_t stream);
+/* One phase of a captured sampling loop for the OTHER schedulers of evaluation/utils_eval.py:83-102 (Euler, Heun, KDPM2, KDPM2-
+ * ancestral, LMS, PLMS, DPM-Solver++ single-step, UniPC): every update between two U-Net calls is a linear combination of the state x,
+ * one auxiliary state, four history entries, caller-supplied noise and the guided prediction e = eps_u + g (eps_c - eps_u); coef
+ * (12 floats) and flag (5 ints) live in DEVICE memory so that one hipGraph replays for every phase (layout: csrc/aql_elem.hip).
+ * Also writes the next model input uin [2n] = next_in_scale * (x | aux), both halves of the guidance batch.                       */
+int aql_sampler_step(float* x, float* aux, float* hist, const float* noise, const bf16_t* eps_u, const bf16_t* eps_c, float* uin,
+                     const float* coef, const int* flag, long n, aql_stream_t stream);
 
 /* csrc/aql_distort.hip: deterministic image maps of noises.py:34-85 / noiser.py:46-71 (random parameters are drawn by the
  * host like the reference does); NCHW fp32, BC = batch*channels; backward=1 applies the adjoint.                        */

@@ -435,3 +435,99 @@ def plms_oracle(eps_fn, x, n_steps, acp):
         e = sum(ci * hi for ci, hi in zip(c, hist[::-1]))
         x = transfer(x, grid[k], grid[k] - ratio, e)
     return x
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DPM-Solver++ single-step (2S) and UniPC (evaluation/utils_eval.py:93-94,101-102), written the way the schedulers keep their state
+# (lists of data predictions and timesteps), independent of the coefficient programs of aqualora_amd/ksamplers.py.  UNPINNED
+# (diffusers absent): Lu et al. 2022 (arXiv:2211.01095) Alg. 1 for 2S with the midpoint rule; Zhao et al. 2023 (arXiv:2302.04867)
+# UniP / UniC with B(h) = e^h - 1 ("bh2"), data prediction, order 2, lower_order_final.  eps_fn(x, t) -> (guided) eps at integer t.
+def _dpm_grid(n_steps, acp):
+    import numpy as np
+    a = np.asarray(acp, dtype=np.float64)
+    ts = [int(v) for v in np.linspace(0, 999, n_steps + 1).round()[::-1][:-1]]
+    al, sg = np.sqrt(a), np.sqrt(1.0 - a)
+    return ts, al, sg, np.log(al / sg)
+
+
+def dpms_singlestep_oracle(eps_fn, x, n_steps, acp):
+    import math
+    ts, al, sg, lam = _dpm_grid(n_steps, acp)
+    orders = [1, 2] * (n_steps // 2) + ([1] if n_steps % 2 else [])
+    outs, saved = [], None
+    for k, s0 in enumerate(ts):
+        t = ts[k + 1] if k + 1 < n_steps else 0
+        m0 = (x - sg[s0] * eps_fn(x, s0)) / al[s0]
+        outs = (outs + [m0])[-2:]
+        if orders[k] == 1:
+            saved = x
+            h = lam[t] - lam[s0]
+            x = (sg[t] / sg[s0]) * saved - al[t] * math.expm1(-h) * m0
+        else:
+            s1 = ts[k - 1]
+            m1 = outs[-2]
+            h, h_0 = lam[t] - lam[s1], lam[s0] - lam[s1]
+            r0 = h_0 / h
+            D0, D1 = m1, (m0 - m1) / r0
+            x = (sg[t] / sg[s1]) * saved - al[t] * math.expm1(-h) * D0 - 0.5 * al[t] * math.expm1(-h) * D1
+    return x
+
+
+def unipc_oracle(eps_fn, x, n_steps, acp, solver_order=2, lower_order_final=True):
+    import math
+    import numpy as np
+    ts, al, sg, lam = _dpm_grid(n_steps, acp)
+
+    def bh(order, rks, hh):
+        h_phi_1 = math.expm1(hh)
+        h_phi_k = h_phi_1 / hh - 1.0
+        B_h = math.expm1(hh)
+        R, b, fact = [], [], 1
+        for i in range(1, order + 1):
+            R.append([rk ** (i - 1) for rk in rks])
+            b.append(h_phi_k * fact / B_h)
+            fact *= i + 1
+            h_phi_k = h_phi_k / hh - 1.0 / fact
+        return np.array(R), np.array(b), h_phi_1, B_h
+
+    outs, tlist = [], []
+    last_sample, this_order, lower = None, 1, 0
+    for k, s in enumerate(ts):
+        t_next = ts[k + 1] if k + 1 < n_steps else 0
+        m_t = (x - sg[s] * eps_fn(x, s)) / al[s]
+        if k > 0:    # UniC: correct the sample at s with the new prediction
+            s0, m0, order = tlist[-1], outs[-1], this_order
+            h = lam[s] - lam[s0]
+            rks, D1s = [], []
+            for i in range(1, order):
+                si, mi = tlist[-(i + 1)], outs[-(i + 1)]
+                rk = (lam[si] - lam[s0]) / h
+                rks.append(rk)
+                D1s.append((mi - m0) / rk)
+            rks.append(1.0)
+            R, b, h_phi_1, B_h = bh(order, rks, -h)
+            rhos = np.array([0.5]) if order == 1 else np.linalg.solve(R, b)
+            x_ = (sg[s] / sg[s0]) * last_sample - al[s] * h_phi_1 * m0
+            corr = sum(float(rhos[j]) * D1s[j] for j in range(len(D1s))) if D1s else 0.0
+            x = x_ - al[s] * B_h * (corr + float(rhos[-1]) * (m_t - m0))
+        outs, tlist = (outs + [m_t])[-solver_order:], (tlist + [s])[-solver_order:]
+        this_order = min(min(solver_order, n_steps - k) if lower_order_final else solver_order, lower + 1)
+        last_sample = x
+        # UniP: predict the sample at t_next
+        s0, m0 = tlist[-1], outs[-1]
+        h = lam[t_next] - lam[s0]
+        rks, D1s = [], []
+        for i in range(1, this_order):
+            si, mi = tlist[-(i + 1)], outs[-(i + 1)]
+            rk = (lam[si] - lam[s0]) / h
+            rks.append(rk)
+            D1s.append((mi - m0) / rk)
+        rks.append(1.0)
+        R, b, h_phi_1, B_h = bh(this_order, rks, -h)
+        x_ = (sg[t_next] / sg[s0]) * x - al[t_next] * h_phi_1 * m0
+        if D1s:
+            rhos_p = np.array([0.5]) if this_order == 2 else np.linalg.solve(R[:-1, :-1], b[:-1])
+            x_ = x_ - al[t_next] * B_h * sum(float(rhos_p[j]) * D1s[j] for j in range(len(D1s)))
+        x = x_
+        lower += 1
+    return x
