@@ -292,213 +292,9 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
 #endif
 }
 
-// Three workgroups per CU (AQL_LORA_CFG=s128 / AQL_LORA_S1): the same tile and arithmetic as lora_gemm_kernel<128,160,64,80,2> on a
-// ONE-stage ring (43 KB of LDS: the C tile) under a 168-VGPR budget.  A workgroup of the two-stage kernel is a dependent chain --
-// ring fill, K loop, LoRA up step, tile staging, GEGLU, stores -- and two co-resident chains leave every shared resource of the CU
-// under 40 % busy; this form trades the workgroup's own DMA / MFMA overlap (the tile is waited for in every
-// k-step) for a third independent chain.  The bias / Bup / scale-row loads sit in the last k-step (30 VGPRs that are not held
-// across the K loop).  Same arithmetic in the same order: bit-identical outputs (tools/probe_lora_persist.py).
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(NTHREADS, 3) void lora_gemm_kernel_s1(const GemmArgs<PlainLoader, PlainLoader> g, const PlainLoader la,
-                                                                   const LoraParams lp) {
-  constexpr int FM = WM / 16, FN = WN / 16;
-  constexpr int WAVES_N = BN / WN;
-  static_assert((BM / WM) * (BN / WN) == 4, "4 wavefronts per workgroup");
-  constexpr int FT = LR / (16 * WAVES_N);
-  static_assert(FT >= 1, "at most two wavefronts along N");
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, L_BYTES = LR * 128;
-  constexpr int STAGE = A_BYTES + B_BYTES + L_BYTES;
-  constexpr int C_PITCH = (BN + 8) * 2;
-  constexpr int LDS_BYTES = (STAGE > BM * C_PITCH) ? STAGE : BM * C_PITCH;
-  static_assert(3 * LDS_BYTES <= 160 * 1024, "three workgroups per CU");
-  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
-
-  const int nblk = gridDim.x, bid = blockIdx.x;
-  const int qq = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
-  const int block_x = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
-  const int wt0 = (wave % WAVES_N) * FT;
-  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
-  int tile_m, tile_n;
-  if (g.m_fast) {
-    tile_n = block_x / tiles_m;
-    tile_m = block_x - tile_n * tiles_m;
-  } else {
-    tile_m = block_x / tiles_n;
-    tile_n = block_x - tile_m * tiles_n;
-  }
-  const int gF = g.epi.geglu_F;
-  const int m0 = tile_m * BM, n0 = tile_n * (gF ? BN / 2 : BN);
-  const int kt_end = g.ktiles0;
-  int grp = 0;
-  if (lp.ngroups > 0)
-    while (grp + 1 < lp.ngroups && n0 >= lp.col_start[grp + 1]) ++grp;
-  const bool t_writer = lp.ngroups > 0 ? (n0 == lp.col_start[grp]) : (tile_n == 0);
-  bf16_t* const Tg = lp.T + (long)grp * g.M * LR;
-  bf16_t* const Tsg = lp.Ts + (long)grp * g.M * LR;
-  PlainLoader lag = la;
-  lag.base += (long)grp * LR * la.ld;
-  const bool lora_on = m0 + BM > lp.row0;
-  if (!lora_on) lag.rows = 0;
-
-  DmaStager<BM, PlainLoader> sa;
-  DmaStager<BN, PlainLoader> sb;
-  DmaStager<LR, PlainLoader> sl;
-  sa.begin(g.a0, g.a0, false, m0, tid, 0, kt_end, kt_end);
-  sb.begin(g.b0, g.b0, false, n0, tid, 0, kt_end, kt_end);
-  sl.begin(lag, lag, false, 0, tid, 0, kt_end, kt_end);
-
-  f32x4_t acc[FM][FN], tacc[FM][FT];
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-#pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < FT; ++t) tacc[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  }
-  uint2 biasr[FN];
-  constexpr int NBP = (BN * 4 + NTHREADS - 1) / NTHREADS;
-  uint4 bup[NBP];
-  uint2 srow[FM][FT];
-  auto tail_loads = [&]() {
-    epi_load_bias<FN>(biasr, g.epi.bias, g.b0.base, n0, wn0, lane, g.N, gF, BN / 2);
-#pragma unroll
-    for (int u = 0; u < NBP; ++u) {
-      const int id = tid + u * NTHREADS, row = id >> 2, c = id & 3;
-      const int brow = epi_bias_col(n0, row, gF, BN / 2);
-      const bool ok = (id < BN * 4) & (brow < g.N) & lora_on;
-      bup[u] = epi_mask4(*reinterpret_cast<const uint4*>(lp.Bup + (ok ? (long)brow * LR + c * 8 : 0)), ok);
-    }
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const long m = (long)m0 + wm0 + i * 16 + (lane & 15);
-#pragma unroll
-      for (int t = 0; t < FT; ++t) {
-        const bool ok = (m < g.M) & lora_on;
-        srow[i][t] = epi_mask2(*reinterpret_cast<const uint2*>(lp.S + (ok ? (long)((uint32_t)m / (uint32_t)lp.rps) * LR + (wt0 + t) * 16 + (lane >> 4) * 4 : 0)), ok);
-      }
-    }
-  };
-  auto issue = [&]() {
-    sa.dma(lds, wave);
-    sb.dma(lds + A_BYTES, wave);
-    sl.dma(lds + A_BYTES + B_BYTES, wave);
-  };
-  auto mainloop = [&](auto lora_tag) {
-    constexpr bool LORA = decltype(lora_tag)::value;
-    auto kstep = [&]() {
-      const char* sA = lds;
-      const char* sB = sA + A_BYTES;
-      const char* sL = sB + B_BYTES;
-#pragma unroll
-      for (int ks = 0; ks < BK / 32; ++ks) {
-        bf16x8_t fa[FM];
-        const int chunk = ks * 4 + (lane >> 4);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-          fa[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(wm0 + i * 16 + (lane & 15), chunk));
-        // one B fragment live at a time (the 168-VGPR budget): column block outermost
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          const bf16x8_t fb = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(wn0 + j * 16 + (lane & 15), chunk));
-#pragma unroll
-          for (int i = 0; i < FM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[i], acc[i][j], 0, 0, 0);
-        }
-        if constexpr (LORA) {
-#pragma unroll
-          for (int t = 0; t < FT; ++t) {
-            const bf16x8_t fl = *reinterpret_cast<const bf16x8_t*>(sL + lds_off((wt0 + t) * 16 + (lane & 15), chunk));
-#pragma unroll
-            for (int i = 0; i < FM; ++i) tacc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl, fa[i], tacc[i][t], 0, 0, 0);
-          }
-        }
-      }
-    };
-    for (int kt = 0; kt + 1 < kt_end; ++kt) {
-      issue();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      kstep();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();      // every wavefront has read the stage before the next tile lands in it
-      asm volatile("" ::: "memory");
-    }
-    issue();
-    tail_loads();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    kstep();
-  };
-  if (lora_on) mainloop(std::true_type{});
-  else mainloop(std::false_type{});
-  __syncthreads();
-  if (lora_on) {
-    char* sA = lds;
-    char* sB = lds + A_BYTES;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int row = wm0 + i * 16 + (lane & 15);
-      const long m = (long)m0 + row;
-      const bool ok = m < g.M;
-#pragma unroll
-      for (int t = 0; t < FT; ++t) {
-        const int r = (wt0 + t) * 16 + (lane >> 4) * 4;
-        const uint2 tv = make_uint2(pack_bf16x2(tacc[i][t][0], tacc[i][t][1]), pack_bf16x2(tacc[i][t][2], tacc[i][t][3]));
-        const uint2 sv = srow[i][t];
-        const uint2 ts = make_uint2(pack_bf16x2(bf16lo(tv.x) * bf16lo(sv.x), bf16hi(tv.x) * bf16hi(sv.x)),
-                                    pack_bf16x2(bf16lo(tv.y) * bf16lo(sv.y), bf16hi(tv.y) * bf16hi(sv.y)));
-        *reinterpret_cast<uint2*>(sA + lds_off(row, r >> 3) + (r & 7) * 2) = ts;
-        if (ok && t_writer) {
-          *reinterpret_cast<uint2*>(Tg + m * LR + r) = tv;
-          *reinterpret_cast<uint2*>(Tsg + m * LR + r) = ts;
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < NBP; ++u) {
-      const int id = tid + u * NTHREADS, row = id >> 2, c = id & 3;
-      if (id < BN * 4) *reinterpret_cast<uint4*>(sB + lds_off(row, c)) = bup[u];
-    }
-    __syncthreads();
-    {
-      bf16x8_t fa[FM], fb[FN];
-      const int chunk = lane >> 4;
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-        fa[i] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off(wm0 + i * 16 + (lane & 15), chunk));
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-        fb[j] = *reinterpret_cast<const bf16x8_t*>(sB + lds_off(wn0 + j * 16 + (lane & 15), chunk));
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  const EpiParams& ep = g.epi;
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int row = wm0 + i * 16 + (lane & 15);
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int col = wn0 + j * 16 + (lane >> 4) * 4;
-      float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-      v0 += bf16lo(biasr[j].x);
-      v1 += bf16hi(biasr[j].x);
-      v2 += bf16lo(biasr[j].y);
-      v3 += bf16hi(biasr[j].y);
-      *reinterpret_cast<uint2*>(lds + row * C_PITCH + col * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-    }
-  }
-  __syncthreads();
-  if (gF) geglu_store<BM, BN, C_PITCH, NTHREADS>(lds, m0, n0, g.M, ep, tid);
-  else epi_store_tile<BM, BN, C_PITCH, NTHREADS>(lds, m0, n0, g.M, g.N, ep, tid);
-}
-
+// (A one-stage, three-workgroups-per-CU form of the kernel above -- 43 KB of LDS, 168 VGPRs, the tile waited for in every k-step --
+// was built and measured in round 4: bit-identical, 1.05-1.2x SLOWER on 16 of 18 shapes, profiles/r04_lora_three_workgroups.txt; its
+// source is at commit 1d72eae.  A third dependent chain per CU does not make up for losing the workgroup's own DMA / MFMA overlap.)
 // EXPERIMENT, off by default (AQL_LORA_PERSIST / AQL_LORA_CFG=p128; measured equal or slower, see the launcher) --
 // persistent form of the 4-wave kernel for grids of several chip-wide rounds (ff.net.0 + GEGLU at the 64x64 level: 4096 tiles
 // of 128x160 = 8 rounds of two workgroups per CU).  A workgroup of the one-shot kernel spends 5-7k of its ~30k cycles before its
@@ -1023,12 +819,6 @@ void launch_w(const GemmArgs<PlainLoader, PlainLoader>& g, const PlainLoader& la
   hipLaunchKernelGGL((lora_gemm_kernel_w<BM, BN, WM, WN, NSTG>), grid, dim3(2 * NTHREADS), 0, stream, g, la, lp);
 }
 
-template <int BM, int BN, int WM, int WN>
-void launch_s1(const GemmArgs<PlainLoader, PlainLoader>& g, const PlainLoader& la, const LoraParams& lp, hipStream_t stream) {
-  dim3 grid(aql_cdiv(g.M, BM) * aql_cdiv(g.N, BN));
-  hipLaunchKernelGGL((lora_gemm_kernel_s1<BM, BN, WM, WN>), grid, dim3(NTHREADS), 0, stream, g, la, lp);
-}
-
 // persistent 4-wave kernel: `wgs` resident workgroups (two per CU) walk all tiles
 template <int BM, int BN, int WM, int WN>
 void launch_p(const GemmArgs<PlainLoader, PlainLoader>& g, const PlainLoader& la, const LoraParams& lp, int wgs, hipStream_t stream) {
@@ -1119,7 +909,6 @@ static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long
       const bool shallow = cfg[strlen(cfg) - 1] == 's' || tiles > 288;
       bool ok = true;
       if (cfg[0] == 'p' && bm == 128) launch_p<128, 160, 64, 80>(g, la, lp, 512, stream);
-      else if (cfg[0] == 's' && bm == 128) launch_s1<128, 160, 64, 80>(g, la, lp, stream);
       else if (cfg[0] == 'w' && bm == 128) launch_w<128, 160, 64, 80, 3>(g, la, lp, stream);
       else if (cfg[0] == 'w' && bm == 64) launch_w<64, 160, 32, 80, 4>(g, la, lp, stream);
       else if (cfg[0] == 'w' && bm == 32) launch_w<32, 160, 16, 80, 5>(g, la, lp, stream);

@@ -1,8 +1,11 @@
 """The samplers of evaluation/utils_eval.py:83-102 beyond DDIM / DPM-Solver++(2M) (those live in inference.py), on the HIP U-Net, as
 CAPTURED loops: ``euler`` (EulerDiscreteScheduler), ``heun`` (HeunDiscreteScheduler), ``kdpm2`` / ``kdpm2a`` (KDPM2[Ancestral]-
 DiscreteScheduler), ``lms`` (LMSDiscreteScheduler), ``pndm`` (PNDMScheduler with skip_prk_steps = PLMS), ``dpms_s``
-(DPMSolverSinglestepScheduler: DPM-Solver++(2S), midpoint) and ``unipc`` (UniPCMultistepScheduler: order 2, bh2, data prediction).
-``dpms_sde`` needs torchsde's Brownian tree to reproduce the reference's noise and is not built.  10 of the table's 11.
+(DPMSolverSinglestepScheduler: DPM-Solver++(2S), midpoint), ``unipc`` (UniPCMultistepScheduler: order 2, bh2, data prediction) and
+``dpms_sde`` (DPMSolverSDEScheduler: DPM-Solver++ SDE, midpoint ratio 1/2, eta = s_noise = 1).  With DDIM and DPM-Solver++(2M) that is
+all 11 of the table.  ``dpms_sde`` draws its noise as increments of ONE Brownian path over sigma (the second stage's interval
+contains the first's: its noise is the normalised sum of the first stage's increment and a fresh one) -- the process torchsde's
+BrownianTree realises; the reference's per-seed values of that tree are not reproducible without torchsde, the distribution is.
 
 Every one of these advances by LINEAR combinations of a few buffers between two U-Net calls.  A sampler is therefore a *program*: a
 list of phases, each ``(timestep, which state the model reads, coefficients)`` for the kernel ``aql_sampler_step``
@@ -29,7 +32,7 @@ from .inference import _cfg_scale, ddim_timesteps
 from .watermark import sd15_alphas_cumprod
 
 K_SAMPLERS = ("euler", "heun", "kdpm2", "lms", "kdpm2a")
-SAMPLERS = K_SAMPLERS + ("pndm", "dpms_s", "unipc")
+SAMPLERS = K_SAMPLERS + ("pndm", "dpms_s", "unipc", "dpms_sde")
 _C = dict(g=0, cx=1, ca=2, ce=3, h0=4, h1=5, h2=6, h3=7, cn=8, nscale=9, psrc=10, pe=11)
 
 
@@ -113,8 +116,9 @@ class Phase:
     """One model evaluation at timestep ``t`` on state ``src`` (0 = x, 1 = aux; the previous phase already wrote the scaled model
     input) followed by two kernel calls A, B.  ``next`` = (state, input scale) of the NEXT evaluation: carried by the last call."""
 
-    def __init__(self, t, src, A, B=None, nxt=(0, 1.0), noise=False):
+    def __init__(self, t, src, A, B=None, nxt=(0, 1.0), noise=False, noise_mix=(0.0, 1.0)):
         self.t, self.src, self.noise = float(t), int(src), bool(noise)
+        self.noise_mix = (float(noise_mix[0]), float(noise_mix[1]))   # noise buffer <- mix[0] * (its content) + mix[1] * (fresh N(0, 1))
         coefA, flagA = _call(src=src, **A)
         if B is None:
             B = dict(cx=1.0)                       # x <- x: a no-op that only writes the next model input
@@ -168,6 +172,35 @@ def k_program(sampler, num_inference_steps, lms_order=4):
             cs = {f"h{j}": lms_coefficient(sig, order, i, j) for j in range(order)}
             ph.append(Phase(t, 0, dict(push=1, cx=1.0, **cs), nxt=nx))
     return Program(sampler, math.sqrt(sig[0] ** 2 + 1.0), _inscale(sig[0]), ph)
+
+
+def dpms_sde_program(num_inference_steps):
+    """DPM-Solver++ SDE as DPMSolverSDEScheduler.step runs it (k-diffusion ``sample_dpmpp_sde`` with r = 1/2, where the combined data
+    prediction is the midpoint's alone): per step sigma -> sigma_next, in t = -log sigma,
+        stage 1  x_mid = x + (down1 - sigma) eps(x, sigma) + up1 n1          (down1, up1) = ancestral_step(sigma, sigma_mid),  sigma_mid = sqrt(sigma sigma_next)
+        stage 2  x'    = (down2 / sigma) x + (1 - down2 / sigma) D + up2 n2    D = x_mid - sigma_mid eps(x_mid, sigma_mid),  (down2, up2) = ancestral_step(sigma, sigma_next)
+    (stage 1 written in the scheduler's exponential form is the same Euler step: (down1/sigma) x - (down1/sigma - 1)(x - sigma eps)).
+    n1, n2 = normalised increments of one Brownian path W over [sigma_mid, sigma] and [sigma_next, sigma]:
+        n2 = (sqrt(a) n1 + sqrt(b) fresh) / sqrt(a + b),   a = sigma - sigma_mid,  b = sigma_mid - sigma_next.
+    The last step (sigma_next = 0) is a plain Euler step.  2N - 1 model evaluations."""
+    ts, sig = k_schedule(num_inference_steps)
+    sig = [float(v) for v in sig]
+    table = k_sigma_table()
+    ph = []
+    for i, t in enumerate(ts):
+        s, sn = sig[i], sig[i + 1]
+        nx = (0, _inscale(sn))
+        if sn == 0:
+            ph.append(Phase(t, 0, dict(cx=1.0, ce=sn - s), nxt=nx))
+            continue
+        sm = math.sqrt(s * sn)
+        d1, u1 = ancestral_step(s, sm)
+        d2, u2 = ancestral_step(s, sn)
+        a, b = s - sm, sm - sn
+        ph.append(Phase(t, 0, dict(dst=1, cx=1.0, ce=d1 - s, cn=u1), nxt=(1, _inscale(sm)), noise=True))
+        ph.append(Phase(sigma_to_t(sm, table), 1, dict(cx=d2 / s, ca=1.0 - d2 / s, ce=-(1.0 - d2 / s) * sm, cn=u2), nxt=nx, noise=True,
+                        noise_mix=(math.sqrt(a / (a + b)), math.sqrt(b / (a + b)))))
+    return Program("dpms_sde", math.sqrt(sig[0] ** 2 + 1.0), _inscale(sig[0]), ph)
 
 
 def _pndm_ab(t, t_prev, acp):
@@ -323,6 +356,8 @@ def program(sampler, num_inference_steps):
         return dpms_program(num_inference_steps)
     if sampler == "unipc":
         return unipc_program(num_inference_steps)
+    if sampler == "dpms_sde":
+        return dpms_sde_program(num_inference_steps)
     raise ValueError(f"sampler {sampler!r} is not one of {SAMPLERS}")
 
 
@@ -400,7 +435,11 @@ class SamplerMachine:
             if phase.noise:
                 if noise_fn is None:
                     raise ValueError(f"{prog.name} is an ancestral sampler: pass noise_fn(i, like)")
-                self.noise.copy_(noise_fn(i, self.x).reshape(-1))
+                fresh = noise_fn(i, self.x).reshape(-1)
+                if phase.noise_mix[0] == 0.0:
+                    self.noise.copy_(fresh)
+                else:            # the next increment of the same Brownian path (dpms_sde): keeps the previous phase's share
+                    self.noise.mul_(phase.noise_mix[0]).add_(fresh, alpha=phase.noise_mix[1])
             self._upload(phase)
             if self.graph is not None:
                 self.graph.replay()
@@ -414,11 +453,12 @@ def sample(unet, ctx_cond, ctx_uncond, latents, sampler="euler", num_inference_s
            generator=None, graph=True):
     """latents [B,4,h,w] fp32 ~ N(0,1) -> final fp32 latents, for any sampler of `SAMPLERS`.  One guided U-Net call (batch 2B) per
     model evaluation: ``num_inference_steps`` for euler / lms / dpms_s / unipc, one more for pndm, twice that minus one for heun /
-    kdpm2 / kdpm2a.  ``generator``: the per-image torch.Generator of the reference (kdpm2a draws its noise from it)."""
+    kdpm2 / kdpm2a / dpms_sde.  ``generator``: the per-image torch.Generator of the reference (kdpm2a and dpms_sde draw their
+    noise from it)."""
     prog = program(sampler, num_inference_steps)
     m = SamplerMachine(unet, ctx_cond, ctx_uncond, latents, guidance_scale, scale, graph)
     noise_fn = None
-    if sampler == "kdpm2a":
+    if sampler in ("kdpm2a", "dpms_sde"):
         noise_fn = lambda i, like: torch.randn(m.shape, generator=generator, device=like.device, dtype=torch.float32)   # noqa: E731
     return m.run(prog, noise_fn)
 

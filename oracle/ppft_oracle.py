@@ -411,6 +411,47 @@ def k_sample_oracle(eps_fn, x, ts, sig, sampler):
     return x
 
 
+def dpms_sde_oracle(eps_fn, x, ts, sig, brownian):
+    """DPM-Solver++ SDE (``dpms_sde`` of evaluation/utils_eval.py:95-96: diffusers' DPMSolverSDEScheduler, itself k-diffusion's
+    ``sample_dpmpp_sde`` with r = 1/2), written the way the scheduler words it -- in t = -log sigma with expm1, data predictions, and a
+    noise sampler called with (sigma_from, sigma_to) -- independently of the sigma-space coefficient program of
+    aqualora_amd/ksamplers.py.  UNPINNED (diffusers and torchsde absent): Lu et al. 2022 (arXiv:2211.01095) section 4 / k-diffusion.
+    eps_fn(x, sigma, t) -> eps;  brownian(sigma_from, sigma_to) -> (W(sigma_to) - W(sigma_from)) / sqrt(|sigma_to - sigma_from|) of ONE
+    Brownian path W (what BrownianTreeNoiseSampler returns; the overall sign convention is immaterial, the nesting is not)."""
+    import math
+
+    def t_fn(sigma):
+        return -math.log(sigma)
+
+    def sigma_fn(t):
+        return math.exp(-t)
+
+    def ancestral(sigma_from, sigma_to):
+        up = min(sigma_to, math.sqrt(sigma_to ** 2 * (sigma_from ** 2 - sigma_to ** 2) / sigma_from ** 2))
+        return math.sqrt(sigma_to ** 2 - up ** 2), up
+
+    for i in range(len(ts)):
+        s, sn = sig[i], sig[i + 1]
+        denoised = x - s * eps_fn(x, s, ts[i])
+        if sn == 0:
+            x = x + ((x - denoised) / s) * (sn - s)
+            continue
+        t, t_next = t_fn(s), t_fn(sn)
+        t_mid = t + 0.5 * (t_next - t)
+        # first stage: to the midpoint
+        down, up = ancestral(sigma_fn(t), sigma_fn(t_mid))
+        t_anc = t_fn(down)
+        x_mid = (sigma_fn(t_anc) / sigma_fn(t)) * x - math.expm1(t - t_anc) * denoised
+        x_mid = x_mid + brownian(sigma_fn(t), sigma_fn(t_mid)) * up
+        denoised_mid = x_mid - sigma_fn(t_mid) * eps_fn(x_mid, sigma_fn(t_mid), None)
+        # second stage: the whole step from the ORIGINAL sample with the midpoint's data prediction
+        down, up = ancestral(sigma_fn(t), sigma_fn(t_next))
+        t_anc = t_fn(down)
+        x = (sigma_fn(t_anc) / sigma_fn(t)) * x - math.expm1(t - t_anc) * denoised_mid
+        x = x + brownian(sigma_fn(t), sigma_fn(t_next)) * up
+    return x
+
+
 def plms_oracle(eps_fn, x, n_steps, acp):
     """Independent restatement of the PLMS sampler as diffusers' PNDMScheduler runs it for the SD-1.5 config (skip_prk_steps, leading
     spacing with offset 1, final alpha = alphas_cumprod[0]): written as explicit phases instead of the scheduler's counter logic.

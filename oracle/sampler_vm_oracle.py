@@ -33,8 +33,8 @@ def run(program, eps_fn, latents, noise_fn=None):
     st = dict(x=x, aux=torch.zeros_like(x), hist=torch.zeros((4,) + tuple(x.shape), dtype=torch.float64), noise=torch.zeros_like(x))
     uin = program.first_in_scale * x
     for i, ph in enumerate(program.phases):
-        if ph.noise:
-            st["noise"] = noise_fn(i, x).double()
+        if ph.noise:        # noise buffer <- mix[0] * its content + mix[1] * fresh (dpms_sde: increments of one Brownian path)
+            st["noise"] = ph.noise_mix[0] * st["noise"] + ph.noise_mix[1] * noise_fn(i, x).double()
         e = eps_fn(uin, ph.t).double()
         for coef, flag in ph.calls:
             uin = step(st, coef, flag, e)

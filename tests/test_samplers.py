@@ -198,6 +198,76 @@ def test_kdpm2_ancestral_matches_the_restatement_and_keeps_the_noise_level():
     assert float((one - (x0 + ancestral_step(float(sig[0]), float(sig[1]))[0] * n0)).abs().max()) < 1e-8
 
 
+def test_dpm_solver_sde_program_matches_the_restatement_on_one_brownian_path():
+    """``dpms_sde`` (utils_eval.py:95-96, DPMSolverSDEScheduler).  The scheduler asks ONE Brownian path W over sigma for the normalised
+    increments over [sigma_mid, sigma] (first stage) and [sigma_next, sigma] (second stage): nested intervals, correlated draws.  The
+    test realises W from independent normals on the elementary intervals of the grid {sigma_i, sigma_mid_i}; the scheduler-style
+    restatement (oracle/ppft_oracle.dpms_sde_oracle, in t = -log sigma with expm1) reads increments of it, the coefficient program
+    gets the elementary normals and mixes them itself (Phase.noise_mix).  (1) same trajectory to 1e-9 with a nonlinear model; (2)
+    the marginal noise level of both stages: down^2 + up^2 = target^2; (3) with zero noise and the exact model the state after one
+    step is x0 + sigma_down * n; (4) the mixing weights are the Brownian ones (squares sum to one, ratio = interval lengths)."""
+    from aqualora_amd.ksamplers import Program, ancestral_step, dpms_sde_program, k_schedule, program
+    from aqualora_amd.watermark import sd15_alphas_cumprod
+    from oracle import sampler_vm_oracle as VM
+    torch.manual_seed(3)
+    n = 12
+    ts, sig = k_schedule(n)
+    ts_o, sig_o = O.k_sigmas_oracle(n, sd15_alphas_cumprod().double())
+    prog = dpms_sde_program(n)
+    assert program("dpms_sde", n).name == "dpms_sde" and len(prog.phases) == 2 * n - 1
+    g = torch.Generator().manual_seed(4)
+    shape = (2, 4, 8, 8)
+    elem = {}                                     # (hi, lo) -> N(0, 1) of the elementary interval
+    for i in range(n - 1):
+        s, sn = float(sig[i]), float(sig[i + 1])
+        sm = math.sqrt(s * sn)
+        elem[(i, 0)] = (s, sm, torch.randn(shape, dtype=torch.float64, generator=g))
+        elem[(i, 1)] = (sm, sn, torch.randn(shape, dtype=torch.float64, generator=g))
+
+    def brownian(sigma_from, sigma_to):          # (W(to) - W(from)) / sqrt(|to - from|), W built from the elementary normals
+        hi, lo = max(sigma_from, sigma_to), min(sigma_from, sigma_to)
+        tot, length = 0.0, 0.0
+        for a, b, z in elem.values():
+            if a <= hi * (1 + 1e-12) and b >= lo * (1 - 1e-12):
+                tot = tot + math.sqrt(a - b) * z
+                length += a - b
+        assert abs(length - (hi - lo)) < 1e-9 * hi, "the interval is a union of elementary intervals of the grid"
+        return tot / math.sqrt(hi - lo)
+
+    phase_elem, k = {}, 0                         # noisy phase index -> its fresh elementary normal
+    for pi, ph in enumerate(prog.phases):
+        if ph.noise:
+            phase_elem[pi] = elem[(k // 2, k % 2)][2]
+            k += 1
+    assert k == 2 * (n - 1)
+    f = lambda x_, s: torch.tanh(x_ / (1 + s)) * (1 + 0.1 * s)   # noqa: E731
+    lat = torch.randn(shape, dtype=torch.float64)
+    a = VM.run(prog, _k_model_for_vm(f), lat, noise_fn=lambda i, x_: phase_elem[i])
+    b = O.dpms_sde_oracle(lambda x_, s, t: f(x_, s), lat * prog.init_scale, ts_o, sig_o, brownian)
+    assert float((a - b).abs().max() / b.abs().max()) < 1e-9
+    for i in range(n - 1):
+        s, sn = float(sig[i]), float(sig[i + 1])
+        sm = math.sqrt(s * sn)
+        for target in (sm, sn):
+            d, u = ancestral_step(s, target)
+            assert abs(d * d + u * u - target * target) < 1e-12 * max(1.0, target * target)
+        w0, w1 = prog.phases[2 * i + 1].noise_mix
+        assert abs(w0 * w0 + w1 * w1 - 1.0) < 1e-12 and abs(w0 * w0 / (w1 * w1) - (s - sm) / (sm - sn)) < 1e-9
+        assert prog.phases[2 * i].noise_mix == (0.0, 1.0)
+    x0 = torch.randn(shape, dtype=torch.float64)
+    n0 = lat * prog.init_scale / float(sig[0])
+    first = Program("first step", prog.init_scale, prog.first_in_scale, prog.phases[:2])
+    one = VM.run(first, _k_model_for_vm(lambda x_, s: (x_ - x0) / s), (x0 + float(sig[0]) * n0) / prog.init_scale,
+                 noise_fn=lambda i, x_: torch.zeros_like(x_))
+    assert float((one - (x0 + ancestral_step(float(sig[0]), float(sig[1]))[0] * n0)).abs().max()) < 1e-8
+    # the SDE keeps the marginal: exact model + unit noise -> the state after a step has variance sigma_next^2 around x0 (statistically)
+    big = (64, 4, 16, 16)
+    x0b, nb = torch.zeros(big, dtype=torch.float64), torch.randn(big, dtype=torch.float64)
+    one = VM.run(first, _k_model_for_vm(lambda x_, s: (x_ - x0b) / s), (x0b + float(sig[0]) * nb) / prog.init_scale,
+                 noise_fn=lambda i, x_: torch.randn(big, dtype=torch.float64))
+    assert abs(float(one.std()) / float(sig[1]) - 1.0) < 2e-2
+
+
 @pytest.mark.parametrize("sampler", ["dpms_s", "unipc"])
 def test_dpm_singlestep_and_unipc_programs(sampler):
     """``dpms_s`` (DPMSolverSinglestepScheduler) and ``unipc`` (UniPCMultistepScheduler) of evaluation/utils_eval.py:93-94,101-102 as
@@ -260,7 +330,7 @@ def test_dpm_singlestep_and_unipc_programs(sampler):
 def test_captured_sampler_machine_vs_oracle_tiny_unet():
     """Every sampler of ksamplers.SAMPLERS on the HIP tiny U-Net through the captured machine (one graph: U-Net on the guidance batch
     + aql_sampler_step twice, replayed per phase) against the oracle's DIRECT loops driving the same U-Net from the host; captured ==
-    eager bit for bit; kdpm2a with a fixed generator is reproducible."""
+    eager bit for bit; kdpm2a / dpms_sde with a fixed generator are reproducible."""
     from aqualora_amd import ksamplers as KS
     from tests.common import T, TINY, tiny_unet
     dev = "cuda"
@@ -296,6 +366,21 @@ def test_captured_sampler_machine_vs_oracle_tiny_unet():
                 want = O.plms_oracle(guided, lat.cpu().double(), steps, acp)
             elif sampler == "dpms_s":
                 want = O.dpms_singlestep_oracle(guided, lat.cpu().double(), steps, acp.numpy())
+            elif sampler == "dpms_sde":
+                ts, sig = KS.k_schedule(steps)
+                sig = [float(v) for v in sig]
+                g2, held = gen(), []
+
+                def brownian(sigma_from, sigma_to):   # the machine's draw order: [sigma_mid, sigma] then [sigma_next, sigma_mid] per step
+                    z = torch.randn((1, 4, 16, 16), generator=g2, device=dev, dtype=torch.float32).cpu().double()
+                    if not held:
+                        held.append((sigma_from - sigma_to, z))
+                        return z
+                    a, z0 = held.pop()
+                    b = (sigma_from - sigma_to) - a
+                    return (math.sqrt(a) * z0 + math.sqrt(b) * z) / math.sqrt(a + b)
+                want = O.dpms_sde_oracle(lambda x, s_, t: guided(x / math.sqrt(s_ * s_ + 1), KS.sigma_to_t(s_) if t is None else t),
+                                         lat.cpu().double() * math.sqrt(sig[0] ** 2 + 1), ts, sig, brownian)
             else:
                 want = O.unipc_oracle(guided, lat.cpu().double(), steps, acp.numpy())
         # bf16 U-Net inputs: an fp32 ulp between the host-side and device-side update flips input roundings (the DPM-Solver test's bound)
