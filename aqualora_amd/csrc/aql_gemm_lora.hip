@@ -20,6 +20,7 @@
 #include <type_traits>
 #include "aql_gemm.cuh"
 #include "aql_gemm_lora_kgroups.cuh"
+#include "aql_gemm_lora_t256.cuh"
 #include <stdlib.h>
 #include <string.h>
 
@@ -898,6 +899,32 @@ static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long
   lp.ngroups = ngroups;
   for (int i = 0; i <= ngroups && ngroups > 0; ++i) lp.col_start[i] = col_start[i];
   if (ngroups > 0 && N % 160 != 0) return AQL_NOT_FUSED;  // groups are cut at 160-column tile boundaries
+  // 256 x 256 persistent tile for the GEGLU form (aql_gemm_lora_t256.cuh): taken from two chip-wide rounds of tiles on (measured:
+  // 0.71-0.90x of the 128 x 160 kernel's time from 640 tiles up, 1.14-1.46x below 320: profiles/r04_t256_geglu.txt).
+  // AQL_LORA_T256=n moves the threshold (0 = never), AQL_LORA_CFG=t256 forces it on every shape it can run.
+  {
+    static const int t256_min_tiles = getenv("AQL_LORA_T256") ? atoi(getenv("AQL_LORA_T256")) : 512;
+    const char* cfg = getenv("AQL_LORA_CFG");
+    const bool forced = cfg && cfg[0] == 't';
+    const bool fits = geglu_F > 0 && geglu_F % 128 == 0 && gb_h == nullptr && ngroups == 0 && residual == nullptr && G != nullptr &&
+                      rows_per_sample >= 32 &&   // the tile's scale-row table holds 16 samples
+                      ldg % 8 == 0 && M * (ldy > ldx ? ldy : ldx) < (1L << 31) && 2L * geglu_F * ldw < (1L << 31);   // 32-bit buffer ranges
+    const long t256_tiles = (long)aql_cdiv((int)M, 256) * (geglu_F / 128);
+    if (fits && !(cfg && !forced) && (forced || (t256_min_tiles > 0 && t256_tiles >= t256_min_tiles))) {
+      aqlt256::Args a{};
+      a.X = X, a.W = W, a.Ad = Adown, a.S = S, a.Bup = Bup, a.bias = bias;
+      a.H = Y, a.G = G, a.T = T, a.Ts = Ts;
+      a.ldx = ldx, a.ldw = ldw, a.ldh = ldy, a.ldg = ldg;
+      a.M = (int)M, a.K = K, a.F = geglu_F, a.rps = rows_per_sample, a.row0 = lp.row0, a.c_row0 = lp.row0;
+      a.ntiles = (int)t256_tiles;
+#ifdef AQL_T256_TRACE
+      if (const char* tb = getenv("AQL_TRACE_BUF")) a.trace = reinterpret_cast<long long*>(strtoull(tb, nullptr, 0));
+#endif
+      aqlt256::launch(a, stream);
+      AQL_CHECK_LAUNCH("aql_lora_gemm_fused (256 x 256 tile)");
+      return AQL_OK;
+    }
+  }
   static const int deep_kt = getenv("AQL_DEEPKT") ? atoi(getenv("AQL_DEEPKT")) : 32;
   static const int force_bm = getenv("AQL_LORA_BM") ? atoi(getenv("AQL_LORA_BM")) : 0;  // tuning hook (160-wide tiles)
   // tuning hook (tools/tune_lora_cfg.py), re-read on every call: w128 / w64 / w32 = wave-specialised kernel with that tile

@@ -42,6 +42,18 @@ def test_gemm_family_parity_on_the_8_wave_128x160_kernel():
     assert text.count("PASS") >= 30
 
 
+def test_lora_geglu_256x256_persistent_tile_is_bit_identical():
+    """aql_gemm_lora_t256.cuh (the default of aql_lora_gemm_fused_geglu from 512 tiles on) forced on every GEGLU form it can run
+    (AQL_LORA_CFG=t256) against the 128 x 160 one-shot kernel: G / H / T / Ts equal bit for bit, ragged rows, K tails, twin row0."""
+    text = _run("probe_lora_persist.py", {"PROBE_ALT": "t256"})
+    assert text.count("PASS geglu") >= 13
+
+
+def test_geglu_epilogue_on_the_256x256_tile_vs_fp32():
+    text = _run("probe_geglu.py", {"AQL_LORA_CFG": "t256"})
+    assert text.count("PASS") >= 20
+
+
 def test_ops_parity():
     text = _run("probe_ops.py")
     assert text.count("PASS") >= 76   # incl. attention at 9216 / 6336 tokens (768 px and non-square rob-finetune samples)

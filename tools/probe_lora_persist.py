@@ -79,8 +79,11 @@ def run(kind, M, N, K, nb, row0=0, widths=None, time_it=False):
     call("d128s", True)
     call(ALT, True)
     a, b = outs["d128s"], outs[ALT]
-    # rows below row0 of T / Ts (and H of a twin GEGLU) are never written by either kernel: compare bit patterns (NaN == NaN)
-    same = all(torch.equal(x.view(torch.int16), y.view(torch.int16)) for x, y in zip(a, b))
+    # H rows below row0 of a twin GEGLU are never written by either kernel: compare bit patterns (NaN == NaN).  T / Ts are specified
+    # from row0 on only (tiles that straddle row0 write the rows below it, tiles entirely below it do not: depends on the tile height)
+    bits = lambda z: z.view(torch.int16)   # noqa: E731
+    same = bool(torch.equal(bits(a[0]), bits(b[0])) and torch.equal(bits(a[1]), bits(b[1])) and
+                torch.equal(bits(a[2][:, row0:]), bits(b[2][:, row0:])) and torch.equal(bits(a[3][:, row0:]), bits(b[3][:, row0:])))
     fin = torch.isfinite(b[1].float()).all() if kind.startswith("geglu") else torch.isfinite(b[0].float()).all() or row0 > 0
     msg = ""
     if time_it:
@@ -106,5 +109,13 @@ for kind, M, N, K, nb, row0, widths in [
         ("grouped", 32768, 960, 320, 8, 16384, (320, 320, 320)), ("grouped", 616, 5120, 768, 8, 308, (320, 320, 640, 640, 1280, 1280, 640)),
         ("grouped", 8192, 1920, 640, 8, 0, (640, 640, 640))]:
     run(kind, M, N, K, nb, row0, widths, time_it=timing)
+if ALT == "t256":
+    # the 256 x 256 GEGLU tile only: one tile, fewer rows than a tile, ragged rows, K tails (not a multiple of 64), row0 inside a tile,
+    # the smallest feature count, rows_per_sample below a tile (9 samples under one tile), no bias-free / H-free mixes, many rounds
+    # (the 128 x 160 kernel splits value | gate at 80-column tiles, this one at 128: F must be a multiple of 640 for both to run)
+    for kind, M, N, K, nb, row0 in [("geglu", 100, 1280, 64, 1, 0), ("geglu", 256, 1280, 320, 2, 128), ("geglu", 1000, 1280, 200, 5, 400),
+                                    ("geglu_noh", 777, 2560, 328, 7, 333), ("geglu", 2048, 2560, 72, 64, 1024), ("geglu", 5000, 3840, 640, 5, 0),
+                                    ("geglu", 65536, 2560, 320, 16, 32768), ("geglu_noh", 4096, 10240, 1280, 4, 0)]:
+        run(kind, M, N, K, nb, row0, None, time_it=timing)
 print("ALL PASS" if ok_all else "SOME FAILED")
 sys.exit(0 if ok_all else 1)
