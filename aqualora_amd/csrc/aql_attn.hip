@@ -1119,7 +1119,9 @@ int launch_fwd(const AttnArgs& a0, hipStream_t st) {
   static const int force = getenv("AQL_ATTN_NOF") ? atoi(getenv("AQL_ATTN_NOF")) : 0;  // tuning hook
   static const int ones = getenv("AQL_ATTN_ONES") ? atoi(getenv("AQL_ATTN_ONES")) : 1;  // tuning hook
   if constexpr (DH <= 64) {
-    if (force == 4 || (force == 0 && a.Nq >= 2048)) {
+    // 64 rows per wavefront only while that still gives two workgroups per CU (one guided image = 2 x 8 heads x 16 row blocks = 256
+    // workgroups of 256 rows: 97 us, against 93.5 us as 512 workgroups of 128 rows; a single sample 89 vs 62 us)
+    if (force == 4 || (force == 0 && a.Nq >= 2048 && (long)aql_cdiv(a.Nq, 256) * a.H * a.B >= 512)) {
       if (a.d < DV && ones) hipLaunchKernelGGL((attn_fwd_kernel<DH, DV, 4, true>), dim3(aql_cdiv(a.Nq, 256), a.H, a.B), dim3(256), 0, st, a);
       else hipLaunchKernelGGL((attn_fwd_kernel<DH, DV, 4, false>), dim3(aql_cdiv(a.Nq, 256), a.H, a.B), dim3(256), 0, st, a);
       return 0;

@@ -78,60 +78,156 @@ def _cfg_scale(scale, B):
     return torch.cat([s, s]).contiguous()
 
 
+def _weights_key(unet):
+    """Serial numbers of the packed weight copies the U-Net currently runs on (0 = not packed yet)."""
+    return tuple(getattr(getattr(m, "_aql_packed", None), "serial", 0) for m in unet.modules() if isinstance(m, (torch.nn.Linear, torch.nn.Conv2d)))
+
+
+class _GuidedLoop:
+    """One guided sampling step (U-Net on the 2B guidance batch + an update kernel) with everything that does not depend on the
+    latents taken out of it, as ONE HIP graph that advances its own step counter:
+
+      * the timestep head (sinusoid, time_embedding MLP, SiLU, the 22 time projections: 19 launches) is run once per schedule entry
+        BEFORE the loop (`UNet2DConditionModel.time_projection_rows`, same launches on the same shapes: same bits); a step gathers
+        its row with one index_select on the device-side step counter;
+      * attn2's k|v projections of the text states (16 launches per step) are computed once per prompt (`UNet.text_kv`);
+      * the schedule coefficients live in a device table; the graph ends with `step += 1`, so the host loop is `replay()` x T with
+        no host-to-device copy (and no host synchronisation) between steps.
+
+    Both hoists apply to the LoRA-free / fused-LoRA U-Net (``scale`` None: evaluation/utils_eval.py:81-82); with a per-message
+    scale tensor (un-fused watermark LoRA, rob_enhance_finetune.py:999-1012) the U-Net runs its complete forward every step.
+    A loop is kept on the U-Net and re-used by later calls with the same shapes / schedule / packed weights: the warm-up step and
+    the capture (~25 ms of host work) are paid once, not per image."""
+
+    def __init__(self, unet, B, lat_shape, ctx_shape, rows, guidance_scale, scale2, update, n_state=0):
+        dev = unet.device
+        self.unet, self.B, self.rows, self.update, self.g = unet, B, rows, update, float(guidance_scale)
+        self.x = torch.zeros(lat_shape, dtype=torch.float32, device=dev)
+        self.state = [torch.zeros_like(self.x) for _ in range(n_state)]
+        self.ctx = torch.zeros(ctx_shape, dtype=torch.bfloat16, device=dev)
+        self.step = torch.zeros(2 * B, dtype=torch.long, device=dev)
+        self.t_table = torch.tensor([int(r[0]) for r in rows], dtype=torch.long, device=dev)
+        self.coef = torch.tensor([list(r[1:]) for r in rows], dtype=torch.float32, device=dev)
+        self.scale2 = scale2
+        self.hoist = scale2 is None
+        self.table = None
+        self.graph = None
+        if self.hoist:
+            t1 = torch.zeros(1, dtype=torch.long, device=dev)
+            blocks = []
+            for r in rows:
+                t1.fill_(int(r[0]))
+                blocks.append(unet.time_projection_rows(t1, 2 * B, None)[:1])
+            self.table = torch.cat(blocks).contiguous()   # [T, sum cout]
+            self.kv = None
+
+    def load(self, latents, ctx):
+        self.x.copy_(latents)
+        self.ctx.copy_(ctx)
+        for s in self.state:
+            s.zero_()
+        self.step.zero_()
+        if self.hoist:
+            kv = self.unet.text_kv(self.ctx)
+            if self.kv is None:
+                self.kv = kv
+            else:   # the captured graph reads the first call's tensors: refresh them in place
+                for key, (k, v) in kv.items():
+                    self.kv[key][0].copy_(k)
+                    self.kv[key][1].copy_(v)
+            self.ctx._aql_kv_static = self.kv
+
+    def one_step(self):
+        B, x = self.B, self.x
+        cf = self.coef.index_select(0, self.step[:1])
+        if self.hoist:
+            tproj = self.table.index_select(0, self.step)
+            eps = self.unet(torch.cat([x, x]), self.t_table[:1], self.ctx, cross_attention_kwargs={"scale": None},
+                            _aql_tproj=tproj).sample
+        else:
+            t_dev = self.t_table.index_select(0, self.step)
+            eps = self.unet(torch.cat([x, x]), t_dev, self.ctx, cross_attention_kwargs={"scale": self.scale2}).sample
+        eps = eps.contiguous()  # NCHW-contiguous so that it lines up with x element for element
+        self.update(self, eps[:B], eps[B:], cf)
+        self.step.add_(1)
+
+    def run(self, graph=True):
+        if graph and self.graph is None:
+            keep = [self.x.clone()] + [s.clone() for s in self.state]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.one_step()
+            torch.cuda.current_stream().wait_stream(side)
+            for dst, src in zip([self.x] + self.state, keep):
+                dst.copy_(src)
+            self.step.zero_()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):  # see ppft.capture: RCCL's watchdog thread
+                self.one_step()
+            for dst, src in zip([self.x] + self.state, keep):
+                dst.copy_(src)
+            self.step.zero_()
+        for _ in self.rows:
+            if graph:
+                self.graph.replay()
+            else:
+                self.one_step()
+        return self.x.clone()
+
+
+def _loop_key(unet, kind, B, latents, ctx, rows, guidance_scale):
+    return (kind, B, tuple(latents.shape), tuple(ctx.shape), tuple(rows), float(guidance_scale), _weights_key(unet))
+
+
+def _run_guided(unet, kind, latents, ctx, rows, guidance_scale, scale2, update, n_state, graph):
+    """Run the cached loop for this (sampler, shapes, schedule, guidance, packed weights) or a fresh one, and keep a fresh captured
+    one on the U-Net (at most two).  Loops through an un-fused LoRA (scale tensor) are not kept: the LoRA weights they were captured
+    on are training state."""
+    B = latents.shape[0]
+    keep = graph and scale2 is None
+    cache = unet.__dict__.setdefault("_aql_loops", {})
+    loop = cache.get(_loop_key(unet, kind, B, latents, ctx, rows, guidance_scale)) if keep else None
+    fresh = loop is None
+    if fresh:
+        loop = _GuidedLoop(unet, B, latents.shape, ctx.shape, rows, guidance_scale, scale2, update, n_state)
+    loop.load(latents.float(), ctx)
+    out = loop.run(graph)
+    if fresh and keep:
+        for k in [k for k, v in cache.items() if k[:-1] == (kind, B, tuple(latents.shape), tuple(ctx.shape), tuple(rows), float(guidance_scale))]:
+            del cache[k]                                   # same loop on weight copies that no longer exist
+        while len(cache) >= 2:
+            cache.pop(next(iter(cache)))
+        # keyed AFTER the run: the warm-up step packs the weights it touches for the first time
+        cache[_loop_key(unet, kind, B, latents, ctx, rows, guidance_scale)] = loop
+    return out
+
+
+def _ddim_update(loop, eps_u, eps_c, cf):
+    L.call("aql_ddim_step", L.ptr(loop.x), L.ptr(eps_u), L.ptr(eps_c), loop.g, L.ptr(cf), loop.x.numel(), L.stream_ptr())
+
+
 @torch.no_grad()
 def ddim_sample(unet, ctx_cond, ctx_uncond, latents, num_inference_steps=50, guidance_scale=7.5, graph=True, scale=None,
                 stop_after=None):
     """latents: [B,4,h,w] fp32 ~ N(0,1) (init_noise_sigma = 1 for DDIM).  Returns the final fp32 latents.
-    One HIP graph holds a full guided step (U-Net on batch 2B + the DDIM update); it is replayed once per timestep with
-    the timestep and the four schedule coefficients in device scalars.  ``scale``: see `_cfg_scale` (a [B, r] tensor
-    samples through the un-fused watermark LoRA with one message per image, ppft_train.py:1153-1154).  ``stop_after`` = n returns
-    after the first n steps of the schedule (tests: one guided step at full size)."""
-    dev = latents.device
+    One HIP graph holds a full guided step (U-Net on batch 2B + the DDIM update + the step counter); it is replayed once per
+    timestep (`_GuidedLoop`).  ``scale``: see `_cfg_scale` (a [B, r] tensor samples through the un-fused watermark LoRA with one
+    message per image, ppft_train.py:1153-1154).  ``stop_after`` = n returns after the first n steps of the schedule (tests: one
+    guided step at full size)."""
     acp = sd15_alphas_cumprod(device="cpu").double()
     ts = ddim_timesteps(num_inference_steps)
     if stop_after is not None:
         ts = ts[:int(stop_after)]
     ratio = 1000 // num_inference_steps
-    x = latents.float().contiguous().clone()
-    B = x.shape[0]
-    ctx = torch.cat([ctx_uncond, ctx_cond]).to(torch.bfloat16).contiguous()
-    t_dev = torch.zeros(2 * B, dtype=torch.long, device=dev)
-    coef = torch.zeros(4, dtype=torch.float32, device=dev)
-    n = x.numel()
-    scale2 = _cfg_scale(scale, B)
-
-    def one_step():
-        eps = unet(torch.cat([x, x]), t_dev, ctx, cross_attention_kwargs={"scale": scale2}).sample
-        eps = eps.contiguous()  # NCHW-contiguous so that it lines up with x element for element
-        L.call("aql_ddim_step", L.ptr(x), L.ptr(eps[:B]), L.ptr(eps[B:]), float(guidance_scale), L.ptr(coef), n,
-               L.stream_ptr())
-
-    def set_step(t):
+    rows = []
+    for t in ts:
         a_t = acp[t]
         a_prev = acp[t - ratio] if t - ratio >= 0 else acp[0]
-        t_dev.fill_(t)
-        coef.copy_(torch.tensor([a_t.sqrt(), (1 - a_t).sqrt(), a_prev.sqrt(), (1 - a_prev).sqrt()], dtype=torch.float32))
-
-    g = None
-    if graph:
-        set_step(ts[0])
-        x_keep = x.clone()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            one_step()
-        torch.cuda.current_stream().wait_stream(side)
-        x.copy_(x_keep)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):  # see ppft.capture: RCCL's watchdog thread
-            one_step()
-    for t in ts:
-        set_step(t)
-        if g is not None:
-            g.replay()
-        else:
-            one_step()
-    return x
+        rows.append((int(t), float(a_t.sqrt()), float((1 - a_t).sqrt()), float(a_prev.sqrt()), float((1 - a_prev).sqrt())))
+    B = latents.shape[0]
+    ctx = torch.cat([ctx_uncond, ctx_cond]).to(torch.bfloat16).contiguous()
+    return _run_guided(unet, "ddim", latents, ctx, rows, guidance_scale, _cfg_scale(scale, B), _ddim_update, 0, graph)
 
 
 # ----------------------------------------------------------------------------------------- DPM-Solver++ (2M)
@@ -165,52 +261,20 @@ def dpmpp2m_schedule(num_inference_steps=20, num_train_timesteps=1000, acp=None)
     return out
 
 
+def _dpmpp2m_update(loop, eps_u, eps_c, cf):
+    L.call("aql_dpmpp2m_step", L.ptr(loop.x), L.ptr(eps_u), L.ptr(eps_c), loop.g, L.ptr(loop.state[0]), L.ptr(cf), loop.x.numel(),
+           L.stream_ptr())
+
+
 @torch.no_grad()
 def dpm_solver_sample(unet, ctx_cond, ctx_uncond, latents, num_inference_steps=20, guidance_scale=7.5, graph=True,
                       scale=None):
     """20-step DPM-Solver++(2M) sampling with classifier-free guidance, the generator in front of rob-finetune
     (rob_enhance_finetune.py:993-1015).  Same structure as `ddim_sample`: ONE HIP graph holds a guided step (U-Net on batch
-    2B + `aql_dpmpp2m_step`), replayed per timestep with the timestep and the five coefficients in device scalars.
+    2B + `aql_dpmpp2m_step`, previous data prediction in the loop's state buffer), replayed per timestep.
     ``scale`` = ``mapper(msg) * 1.03`` ([B, r]) samples through the UN-fused watermark LoRA so that every image of the batch
     carries its own message, as rob_enhance_finetune.py:999-1012 does; None = LoRA-free / fused U-Net."""
-    dev = latents.device
-    sched = dpmpp2m_schedule(num_inference_steps)
-    x = latents.float().contiguous().clone()
-    x0_prev = torch.zeros_like(x)
-    B = x.shape[0]
+    rows = [tuple(r) for r in dpmpp2m_schedule(num_inference_steps)]
+    B = latents.shape[0]
     ctx = torch.cat([ctx_uncond, ctx_cond]).to(torch.bfloat16).contiguous()
-    t_dev = torch.zeros(2 * B, dtype=torch.long, device=dev)
-    coef = torch.zeros(5, dtype=torch.float32, device=dev)
-    n = x.numel()
-    scale2 = _cfg_scale(scale, B)
-
-    def one_step():
-        eps = unet(torch.cat([x, x]), t_dev, ctx, cross_attention_kwargs={"scale": scale2}).sample.contiguous()
-        L.call("aql_dpmpp2m_step", L.ptr(x), L.ptr(eps[:B]), L.ptr(eps[B:]), float(guidance_scale), L.ptr(x0_prev), L.ptr(coef),
-               n, L.stream_ptr())
-
-    def set_step(row):
-        t_dev.fill_(row[0])
-        coef.copy_(torch.tensor(row[1:], dtype=torch.float32))
-
-    g = None
-    if graph:
-        set_step(sched[0])
-        x_keep = x.clone()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            one_step()
-        torch.cuda.current_stream().wait_stream(side)
-        x.copy_(x_keep)
-        x0_prev.zero_()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            one_step()
-    for row in sched:
-        set_step(row)
-        if g is not None:
-            g.replay()
-        else:
-            one_step()
-    return x
+    return _run_guided(unet, "dpmpp2m", latents, ctx, rows, guidance_scale, _cfg_scale(scale, B), _dpmpp2m_update, 1, graph)

@@ -388,6 +388,8 @@ class SamplerMachine:
         self.eps = None
         self.graph = None
         self.use_graph = graph
+        if self.scale2 is None:   # LoRA-free / fused U-Net: attn2's k|v of the text states once per prompt, not once per phase
+            self.ctx._aql_kv_static = unet.text_kv(self.ctx)
 
     def _kernel(self, k, eps):
         B = self.B

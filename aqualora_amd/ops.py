@@ -221,10 +221,21 @@ def nhwc_view(x):
 
 
 # --------------------------------------------------------------------------------------------- packing
+_PACK_SERIAL = [0]
+
+
+def next_pack_serial():
+    """Every packed (kernel-layout) weight copy gets a fresh number: a captured sampling loop names the copies it was captured
+    on (inference._weights_key) and is dropped when any of them has been replaced (fuse_lora, re-initialised weights)."""
+    _PACK_SERIAL[0] += 1
+    return _PACK_SERIAL[0]
+
+
 class PackedLinear:
     """bf16 kernel-layout copies of a frozen nn.Linear / 1x1 conv: W [N,K], W^T [K,N], bias [N]."""
 
     def __init__(self, weight, bias):
+        self.serial = next_pack_serial()
         w = weight.detach().reshape(weight.shape[0], -1)
         self.N, self.K = w.shape
         self.w = w.to(torch.bfloat16).contiguous()
@@ -236,6 +247,7 @@ class PackedConv3x3:
     """Wk [Cout, 9*Cin] (tap-major, channel-minor) for forward, Wt [Cin, 9*Cout] for backward-data."""
 
     def __init__(self, weight, bias, stride):
+        self.serial = next_pack_serial()
         Cout, Cin = weight.shape[0], weight.shape[1]
         self.Cin_real = Cin
         w = weight.detach().to(torch.bfloat16)

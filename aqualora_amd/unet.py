@@ -177,15 +177,20 @@ class Attention(nn.Module):
             qkv = ops.gemm_bf16(x2d, self._fused_weights(False)).view(B, N, 3 * C)
             q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         else:
-            Bc, Nc, Cc = ctx.shape
             q = self.to_q(x, None)
-            c2d = ctx.reshape(Bc * Nc, Cc)
-            if c2d.dtype != torch.bfloat16:
-                c2d = c2d.to(torch.bfloat16)
-            kv = ops.gemm_bf16(c2d.contiguous(), self._fused_weights(True)).view(Bc, Nc, 2 * C)
-            k, v = kv[..., :C], kv[..., C:]
+            cache = getattr(ctx, "_aql_kv_static", None)   # a sampling loop computed them once per prompt (UNet.text_kv)
+            k, v = cache[id(self)] if cache is not None and id(self) in cache else self._text_kv(ctx)
         o = ops.attention(q, k, v, self.heads)
         return self.to_out[0](o, None, residual=residual)
+
+    def _text_kv(self, ctx):
+        Bc, Nc, Cc = ctx.shape
+        C = self.to_q.out_features
+        c2d = ctx.reshape(Bc * Nc, Cc)
+        if c2d.dtype != torch.bfloat16:
+            c2d = c2d.to(torch.bfloat16)
+        kv = ops.gemm_bf16(c2d.contiguous(), self._fused_weights(True)).view(Bc, Nc, 2 * C)
+        return kv[..., :C], kv[..., C:]
 
     def _grouped_qkv(self, hidden_states, scale):
         """q|k|v of a self-attention as ONE grouped LoRA launch (they read the same tokens); None when the grouped form does
@@ -429,7 +434,36 @@ class UNet2DConditionModel(nn.Module):
             object.__setattr__(self, "_aql_temb_cat", cat)
         packed, offs = cat
         allp = ops.lora_linear(temb_act.contiguous(), packed)
-        return {key: allp[:, o:o + n] for key, o, n in offs}
+        return {key: allp[:, o:o + n] for key, o, n in offs}, allp
+
+    def _time_projection_views(self, allp):
+        """Per-ResNet column views of a [rows, sum cout] block of time projections (a row of `time_projection_rows`, gathered
+        per step by a sampling loop: `forward(..., _aql_tproj=...)`)."""
+        return {key: allp[:, o:o + n] for key, o, n in self._aql_temb_cat[1]}
+
+    @torch.no_grad()
+    def time_projection_rows(self, timestep, rows, scale=None):
+        """The timestep-only head of `forward` on its own: sinusoid -> time_embedding -> SiLU -> the 22 time_emb_proj as one
+        GEMM, for `rows` samples that share `timestep`; returns the [rows, sum cout] block.  A sampling loop calls this once
+        per step of its schedule BEFORE the loop (same launches on the same shapes as inside `forward`: same bits) and feeds
+        the row of the current step back through `_aql_tproj` -- 19 element-wise / tiny-GEMM launches leave every step."""
+        if not torch.is_tensor(timestep):
+            timestep = torch.tensor([timestep], device=self.device)
+        timestep = timestep.reshape(-1).expand(rows)
+        t_emb = get_timestep_embedding(timestep, self.config.block_out_channels[0]).to(self.dtype)
+        emb = self.time_embedding(t_emb, scale)
+        return self._all_time_projections(torch.nn.functional.silu(emb))[1]
+
+    @torch.no_grad()
+    def text_kv(self, ctx):
+        """attn2's k|v projections of the text states for the LoRA-free / fused-LoRA passes (`Attention._forward_nolora`): they do
+        not depend on the latents, so a sampling loop computes them ONCE per prompt (same GEMM as inside the block: same bits)
+        and attaches the dict to the text-state tensor as ``_aql_kv_static``; 16 launches leave every step."""
+        out = {}
+        for m in self.modules():
+            if isinstance(m, BasicTransformerBlock):
+                out[id(m.attn2)] = m.attn2._text_kv(ctx)
+        return out
 
     def _ctx_kv(self, ctx, scale):
         """attn2.to_k / to_v of ALL cross-attentions depend only on the text states: 32 small LoRA linears (616 x 768 -> C at
@@ -480,9 +514,11 @@ class UNet2DConditionModel(nn.Module):
         return self.conv_in.weight.device
 
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, cross_attention_kwargs=None,
-                return_dict=True, _aql_t_emb=None):
+                return_dict=True, _aql_t_emb=None, _aql_tproj=None):
         """``_aql_t_emb`` (internal): the sinusoidal timestep embedding of every row of the (twin) batch, already built by the
-        trainer's prologue kernel (ppft.PPFTTrainer._twin_prologue) -- the eight element-wise launches of the generic path are skipped."""
+        trainer's prologue kernel (ppft.PPFTTrainer._twin_prologue) -- the eight element-wise launches of the generic path are skipped.
+        ``_aql_tproj`` (internal): the [rows, sum cout] time projections of this step, computed before a sampling loop by
+        `time_projection_rows`; the whole timestep head is skipped."""
         scale = 1.0
         if cross_attention_kwargs is not None and "scale" in cross_attention_kwargs:
             scale = cross_attention_kwargs["scale"]
@@ -493,17 +529,20 @@ class UNet2DConditionModel(nn.Module):
         # the same test Conv3x3Fn makes; any other layout is made channels-last here (and re-registered by make_twin's callers)
         if not (sample.dtype == self.dtype and ops.is_cpad(sample, _packed_conv3(self.conv_in).Cin)):
             sample = ops.as_cl(sample.to(self.dtype))
-        if _aql_t_emb is not None:
-            t_emb = _aql_t_emb
+        if _aql_tproj is not None:
+            temb_act = self._time_projection_views(_aql_tproj)
         else:
-            if ops._full(sample) is not None:
-                # twin batch (ops._Dual): `sample` is the watermarked half of a 2B buffer whose first half is the clean pass; both
-                # halves share the timesteps, and the per-ResNet time projections are per-sample row biases covering all 2B rows
-                timestep = timestep.repeat(2)
-            t_emb = get_timestep_embedding(timestep, self.config.block_out_channels[0]).to(self.dtype)
-        emb = self.time_embedding(t_emb, scale)
-        temb_act = torch.nn.functional.silu(emb)  # every ResNet applies SiLU to temb first (original_unet.py:449)
-        temb_act = self._all_time_projections(temb_act)
+            if _aql_t_emb is not None:
+                t_emb = _aql_t_emb
+            else:
+                if ops._full(sample) is not None:
+                    # twin batch (ops._Dual): `sample` is the watermarked half of a 2B buffer whose first half is the clean pass; both
+                    # halves share the timesteps, and the per-ResNet time projections are per-sample row biases covering all 2B rows
+                    timestep = timestep.repeat(2)
+                t_emb = get_timestep_embedding(timestep, self.config.block_out_channels[0]).to(self.dtype)
+            emb = self.time_embedding(t_emb, scale)
+            temb_act = torch.nn.functional.silu(emb)  # every ResNet applies SiLU to temb first (original_unet.py:449)
+            temb_act = self._all_time_projections(temb_act)[0]
         ctx = encoder_hidden_states.to(self.dtype).contiguous()
         self._ctx_kv(ctx, scale)
         try:

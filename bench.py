@@ -139,7 +139,7 @@ def dominant_kernels(B, device):
         assert rc == 0, rc
     fl = 2.0 * M * K * 2 * F + (M // 2) * 2.0 * (K * 32 + 32 * 2 * F)
     alg = 2.0 * (M * K + 2 * F * K + M * F + (M // 2) * 2 * F + 2 * (M // 2) * 32)
-    entry("lora_gemm_kernel<128,160,64,80,2> (GEGLU epilogue) ff.net.0.proj 320->2x1280 + rank-32 LoRA + GEGLU, "
+    entry("lora_geglu256_kernel (256x256 persistent tile, GEGLU epilogue) ff.net.0.proj 320->2x1280 + rank-32 LoRA + GEGLU, "
           f"{2 * B} samples x 4096 tokens (twin forward)", time_kernel(geglu_call), fl, samples=2 * B, algorithmic_bytes=alg,
           pmc_key=f"lora_geglu 320->2x1280 M={M}")
     del X, W, H, G, T, Ts
@@ -411,7 +411,7 @@ def infer_record(device, B=1, runs=2, check_bits=True):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / runs
     tf = B * 50 * 2 * UNET_FWD_GFLOP / 1e3
-    rec = {"workload": f"BASELINE config 4: batch {B}, 50 DDIM steps (each captured step graph re-captured per call), CFG 7.5, "
+    rec = {"workload": f"BASELINE config 4: batch {B}, 50 DDIM steps (ONE captured step graph kept across calls; timestep head and text k|v outside the step), CFG 7.5, "
                        "VAE decode to 512x512, 48-bit extraction; synthetic weights",
            "value": B / dt, "unit": "images/sec", "ms_per_image": 1e3 * dt / B, "runs": runs,
            "sampling_only": {"images_per_sec": B / dt_s, "ms_per_image": 1e3 * dt_s / B},

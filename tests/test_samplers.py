@@ -83,6 +83,56 @@ def test_dpm_solver_hip_vs_oracle_tiny_unet():
     assert float((got.cpu() - want).abs().max() / want.abs().max()) < 2e-2
     assert float((got - got_eager).abs().max() / got_eager.abs().max()) < 1e-5
 
+@pytest.mark.gpu
+def test_guided_loop_hoists_are_bit_exact_and_the_captured_loop_is_reused():
+    """`inference._GuidedLoop` takes the timestep head and attn2's text k|v out of the step and keeps the captured step graph on
+    the U-Net.  (1) A 4-step DDIM run through it equals, BIT FOR BIT, a plain loop that calls the complete U-Net forward at every
+    step and `aql_ddim_step` with host-made coefficients.  (2) A second call with other latents and text states re-uses the SAME
+    captured graph and again equals the plain loop.  (3) Replacing a packed weight (what fuse_lora does) retires the loop."""
+    from aqualora_amd import _lib as L
+    from aqualora_amd.inference import ddim_sample, ddim_timesteps
+    from aqualora_amd.watermark import sd15_alphas_cumprod
+    from tests.common import T, TINY, tiny_unet
+    dev = "cuda"
+    unet = tiny_unet(dev, torch.bfloat16)
+    acp = sd15_alphas_cumprod(device="cpu").double()
+
+    def plain(ctx, unc, lat, steps, g):
+        x = lat.float().clone()
+        c2 = torch.cat([unc, ctx]).to(torch.bfloat16).contiguous()
+        ratio = 1000 // steps
+        with torch.no_grad():
+            for t in ddim_timesteps(steps):
+                a_t, a_p = acp[t], (acp[t - ratio] if t - ratio >= 0 else acp[0])
+                coef = torch.tensor([a_t.sqrt(), (1 - a_t).sqrt(), a_p.sqrt(), (1 - a_p).sqrt()], dtype=torch.float32, device=dev)
+                tt = torch.full((2 * lat.shape[0],), t, dtype=torch.long, device=dev)
+                eps = unet(torch.cat([x, x]), tt, c2, cross_attention_kwargs={"scale": None}).sample.contiguous()
+                B = lat.shape[0]
+                L.call("aql_ddim_step", L.ptr(x), L.ptr(eps[:B]), L.ptr(eps[B:]), 5.0, L.ptr(coef), x.numel(), L.stream_ptr())
+        return x
+
+    outs = []
+    for tag in ("a", "b"):
+        ctx = T(f"gl.ctx{tag}", (1, 77, TINY["cross_attention_dim"]), device=dev)
+        unc = T(f"gl.unc{tag}", (1, 77, TINY["cross_attention_dim"]), 0.1, device=dev)
+        lat = T(f"gl.lat{tag}", (1, 4, 16, 16), device=dev)
+        got = ddim_sample(unet, ctx, unc, lat, 4, 5.0, graph=True)
+        want = plain(ctx, unc, lat, 4, 5.0)
+        assert torch.isfinite(got).all()
+        assert torch.equal(got, want), float((got - want).abs().max())
+        assert torch.equal(ddim_sample(unet, ctx, unc, lat, 4, 5.0, graph=False), want)
+        outs.append(got)
+    assert not torch.equal(outs[0], outs[1])
+    loops = unet.__dict__["_aql_loops"]
+    assert len(loops) == 1 and next(iter(loops.values())).graph is not None     # one loop, captured once, used by both calls
+    first = next(iter(loops.values()))
+    lin = next(m for m in unet.modules() if hasattr(m, "_aql_packed"))
+    object.__delattr__(lin, "_aql_packed")                                      # the weight copy is replaced on the next forward
+    again = ddim_sample(unet, ctx, unc, lat, 4, 5.0, graph=True)
+    assert torch.equal(again, outs[1])
+    assert all(v is not first for v in unet.__dict__["_aql_loops"].values())
+
+
 def _k_model_for_vm(f):
     """A sigma-space model f(x, sigma) seen through the scaled input the U-Net gets: the program's phases carry the timestep, the
     sigma of a (possibly fractional) timestep is read back from the table the way k-diffusion's ``t_to_sigma`` does."""

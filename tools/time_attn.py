@@ -23,6 +23,8 @@ out = []
 SHAPES = ((4, 8, 4096, 40), (8, 8, 4096, 40), (4, 8, 1024, 80), (8, 8, 1024, 80))
 if os.environ.get("SMALL"):   # the low-resolution levels: 16x16 (d = 160) and 8x8
     SHAPES = ((4, 8, 256, 160), (8, 8, 256, 160), (4, 8, 64, 160), (8, 8, 64, 160), (4, 8, 1024, 80), (8, 8, 1024, 80))
+if os.environ.get("SHAPES"):   # SHAPES="2,8,4096,40;2,8,1024,80": B,H,N,d per shape (inference: CFG batch 2)
+    SHAPES = tuple(tuple(int(v) for v in sh.split(",")) for sh in os.environ["SHAPES"].split(";"))
 NK = int(os.environ.get("CTX", "0"))   # CTX=77: the text-state (cross-attention) shapes, forward at 8 samples, backward at 4
 if NK:
     SHAPES = ((8, 8, 4096, 40), (4, 8, 4096, 40), (8, 8, 1024, 80), (4, 8, 1024, 80), (8, 8, 256, 160), (4, 8, 256, 160), (8, 8, 64, 160), (4, 8, 64, 160))
