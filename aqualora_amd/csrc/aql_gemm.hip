@@ -10,6 +10,12 @@ using namespace aqlgemm;
 
 #define AQL_NOT_FUSED 100
 static thread_local char g_err[512] = "";
+namespace aqlt256 {   // aql_gemm_lora.hip (aql_gemm_lora_t256.cuh)
+int t256_geglu_two_segments(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, int F, int K, const bf16_t* A2, long lda2,
+                            const bf16_t* B2, long ldb2, int K2, const bf16_t* bias, bf16_t* H, long ldh, bf16_t* G, long ldg,
+                            long row0, hipStream_t stream);
+}
+
 extern "C" const char* aql_last_error(void) { return g_err; }
 void aql_set_error(const char* fmt, ...) {
   va_list ap;
@@ -470,6 +476,13 @@ extern "C" int aql_gemm_bf16_geglu(const bf16_t* A, long lda, const bf16_t* B, l
                     ldg % 8 == 0 && (H == nullptr || ldh % 8 == 0),
                 "aql_gemm_bf16_geglu: bad shape M=%ld F=%d K=%d", M, F, K);
   AQL_CHECK_ARG(aligned16(A) && aligned16(B) && aligned16(G) && aligned16(H), "aql_gemm_bf16_geglu: pointers must be 16-byte aligned");
+  if (A2 != nullptr)
+    AQL_CHECK_ARG(B2 && K2 > 0 && K2 % 8 == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0 && aligned16(A2) && aligned16(B2),
+                  "aql_gemm_bf16_geglu: bad second K segment");
+  {   // large grids: the 256 x 256 persistent tile (aql_gemm_lora_t256.cuh), bit-identical to the kernels below
+    const int rc = aqlt256::t256_geglu_two_segments(A, lda, B, ldb, M, F, K, A2, lda2, B2, ldb2, K2, bias, H, ldh, G, ldg, lora_row0, stream);
+    if (rc != AQL_NOT_FUSED) return rc;
+  }
   if (F % 80 != 0) return AQL_NOT_FUSED;
   GemmArgs<PlainLoader, PlainLoader> g;
   g.a0 = plain(A, lda, M, K);

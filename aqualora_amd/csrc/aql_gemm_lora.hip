@@ -17,6 +17,7 @@
 // Same LDS-DMA ring as gemm_body_d (aql_gemm.cuh): NSTG stages, one barrier per K tile, counted vmcnt waits.  No split-K
 // (T must be complete before the up-projection): deep-K / small-grid shapes return AQL_NOT_FUSED and the caller uses the
 // two-launch path.
+#include <algorithm>
 #include <type_traits>
 #include "aql_gemm.cuh"
 #include "aql_gemm_lora_kgroups.cuh"
@@ -845,6 +846,38 @@ inline PlainLoader plain(const bf16_t* p, long ld, long rows, int K) {
 
 }  // namespace
 
+// The picker of the 256 x 256 GEGLU tile, shared by the rank-32 one-launch form below and by aql_gemm_bf16_geglu (aql_gemm.hip: any
+// rank as a second K segment, or no LoRA at all): taken from two chip-wide rounds of tiles on (measured: 0.71-0.90x of the 128 x 160
+// kernel's time from 640 tiles up, 1.14-1.46x below 320: profiles/r04_t256_geglu.txt).  AQL_LORA_T256=n moves the threshold
+// (0 = never), AQL_LORA_CFG=t256 forces the tile on every shape it can run, any other AQL_LORA_CFG keeps it off.
+static bool t256_wanted(long M, int F, long ld_max, long ldw_max, long ldg) {
+  static const int min_tiles = getenv("AQL_LORA_T256") ? atoi(getenv("AQL_LORA_T256")) : 512;
+  const char* cfg = getenv("AQL_LORA_CFG");
+  const bool forced = cfg && cfg[0] == 't';
+  const bool fits = F > 0 && F % 128 == 0 && ldg % 8 == 0 && M * ld_max < (1L << 31) && 2L * F * ldw_max < (1L << 31);   // 32-bit buffer ranges
+  const long tiles = (long)aql_cdiv((int)M, 256) * (F / 128);
+  return fits && !(cfg && !forced) && (forced || (min_tiles > 0 && tiles >= min_tiles));
+}
+
+int aqlt256::t256_geglu_two_segments(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, int F, int K, const bf16_t* A2,
+                                     long lda2, const bf16_t* B2, long ldb2, int K2, const bf16_t* bias, bf16_t* H, long ldh, bf16_t* G,
+                                     long ldg, long row0, hipStream_t stream) {
+  const long ldm = std::max(std::max(lda, A2 ? lda2 : 0L), H ? ldh : 0L);
+  if (!t256_wanted(M, F, ldm, std::max(ldb, B2 ? ldb2 : 0L), ldg)) return AQL_NOT_FUSED;
+  aqlt256::Args a{};
+  a.X = A, a.W = B, a.bias = bias, a.H = H, a.G = G;
+  a.ldx = lda, a.ldw = ldb, a.ldh = ldh, a.ldg = ldg;
+  a.M = (int)M, a.K = K, a.F = F, a.rps = (int)M;
+  a.row0 = (int)(row0 < 0 ? 0 : (row0 > M ? M : row0));
+  a.c_row0 = a.row0;
+  a.ntiles = aql_cdiv((int)M, 256) * (F / 128);
+  a.seg2 = 1;
+  if (A2 != nullptr) a.X2 = A2, a.W2 = B2, a.ldx2 = lda2, a.ldw2 = ldb2, a.K2 = K2;
+  aqlt256::launch(a, stream);
+  AQL_CHECK_LAUNCH("aql_gemm_bf16_geglu (256 x 256 tile)");
+  return AQL_OK;
+}
+
 // Y[M,N] = X[M,K].W[N,K]^T + ((X.A[32,K]^T) * S[m / rps]).Bup[N,32]^T + bias + residual;  T, Ts [M,32] are written too.
 // Returns AQL_OK, an error, or AQL_NOT_FUSED (100) when the shape belongs on the two-launch path (deep K on a small grid:
 // split-K; N <= 32).
@@ -899,24 +932,17 @@ static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long
   lp.ngroups = ngroups;
   for (int i = 0; i <= ngroups && ngroups > 0; ++i) lp.col_start[i] = col_start[i];
   if (ngroups > 0 && N % 160 != 0) return AQL_NOT_FUSED;  // groups are cut at 160-column tile boundaries
-  // 256 x 256 persistent tile for the GEGLU form (aql_gemm_lora_t256.cuh): taken from two chip-wide rounds of tiles on (measured:
-  // 0.71-0.90x of the 128 x 160 kernel's time from 640 tiles up, 1.14-1.46x below 320: profiles/r04_t256_geglu.txt).
-  // AQL_LORA_T256=n moves the threshold (0 = never), AQL_LORA_CFG=t256 forces it on every shape it can run.
+  // 256 x 256 persistent tile for the GEGLU form (aql_gemm_lora_t256.cuh)
   {
-    static const int t256_min_tiles = getenv("AQL_LORA_T256") ? atoi(getenv("AQL_LORA_T256")) : 512;
-    const char* cfg = getenv("AQL_LORA_CFG");
-    const bool forced = cfg && cfg[0] == 't';
-    const bool fits = geglu_F > 0 && geglu_F % 128 == 0 && gb_h == nullptr && ngroups == 0 && residual == nullptr && G != nullptr &&
-                      rows_per_sample >= 32 &&   // the tile's scale-row table holds 16 samples
-                      ldg % 8 == 0 && M * (ldy > ldx ? ldy : ldx) < (1L << 31) && 2L * geglu_F * ldw < (1L << 31);   // 32-bit buffer ranges
-    const long t256_tiles = (long)aql_cdiv((int)M, 256) * (geglu_F / 128);
-    if (fits && !(cfg && !forced) && (forced || (t256_min_tiles > 0 && t256_tiles >= t256_min_tiles))) {
+    const bool fits = geglu_F > 0 && gb_h == nullptr && ngroups == 0 && residual == nullptr && G != nullptr &&
+                      rows_per_sample >= 32;   // the tile's scale-row table holds 16 samples
+    if (fits && t256_wanted(M, geglu_F, ldy > ldx ? ldy : ldx, ldw, ldg)) {
       aqlt256::Args a{};
       a.X = X, a.W = W, a.Ad = Adown, a.S = S, a.Bup = Bup, a.bias = bias;
       a.H = Y, a.G = G, a.T = T, a.Ts = Ts;
       a.ldx = ldx, a.ldw = ldw, a.ldh = ldy, a.ldg = ldg;
       a.M = (int)M, a.K = K, a.F = geglu_F, a.rps = rows_per_sample, a.row0 = lp.row0, a.c_row0 = lp.row0;
-      a.ntiles = (int)t256_tiles;
+      a.ntiles = aql_cdiv((int)M, 256) * (geglu_F / 128);
 #ifdef AQL_T256_TRACE
       if (const char* tb = getenv("AQL_TRACE_BUF")) a.trace = reinterpret_cast<long long*>(strtoull(tb, nullptr, 0));
 #endif

@@ -36,6 +36,11 @@ struct Args {
   long ldx, ldw, ldh, ldg;
   int M, K, F;
   int rps, row0, c_row0, ntiles;
+  // SEG2 kernels (any LoRA rank; aql_gemm_bf16_geglu): a second K segment  + X2[M, K2] . W2[2F, K2]^T  on rows >= row0 (X2 = the scaled
+  // LoRA down product Ts, W2 = Bup), no side product, no up step
+  const bf16_t *X2, *W2;
+  long ldx2, ldw2;
+  int K2, seg2;
   long long* trace;   // -DAQL_T256_TRACE builds only (tools/trace_t256.py)
 };
 
@@ -43,6 +48,7 @@ struct Args {
 __device__ __forceinline__ int seg_off(int row, int c) { return row * 256 + ((c ^ (row & 15)) << 4); }
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
+template <bool SEG2>
 __global__ __launch_bounds__(NTH, 2) void lora_geglu256_kernel(const Args a) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   int tid_ = threadIdx.x;
@@ -51,7 +57,7 @@ __global__ __launch_bounds__(NTH, 2) void lora_geglu256_kernel(const Args a) {
   const bool loader = wave < 4;
   const int tiles_n = a.F / 128, tiles_m = (a.M + TM - 1) / TM;
   const bool twin_mix = a.row0 > 0 && (tiles_m & 1) == 0 && a.row0 == (tiles_m >> 1) * TM;
-  const int KT = (a.K + BK - 1) / BK;
+  const int KT1 = (a.K + BK - 1) / BK, KT2 = SEG2 ? (a.K2 + BK - 1) / BK : 0;
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.X), 0, (uint32_t)a.M * (uint32_t)(a.ldx * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W), 0, (uint32_t)(2 * a.F) * (uint32_t)(a.ldw * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.Ad), 0, (uint32_t)LR_ * (uint32_t)(a.K * 2), 0x00020000);
@@ -63,13 +69,16 @@ __global__ __launch_bounds__(NTH, 2) void lora_geglu256_kernel(const Args a) {
   const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(a.G, 0, (uint32_t)a.M * (uint32_t)(a.ldg * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(a.H, 0, a.H ? (uint32_t)a.M * (uint32_t)(a.ldh * 2) : 0u, 0x00020000);
   const uint32_t stepX = 32u * (uint32_t)(a.ldx * 2), stepW = 32u * (uint32_t)(a.ldw * 2);
+  const __amdgpu_buffer_rsrc_t rsX2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.X2), 0, SEG2 ? (uint32_t)a.M * (uint32_t)(a.ldx2 * 2) : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W2), 0, SEG2 ? (uint32_t)(2 * a.F) * (uint32_t)(a.ldw2 * 2) : 0u, 0x00020000);
+  const uint32_t stepX2 = SEG2 ? 32u * (uint32_t)(a.ldx2 * 2) : 0u, stepW2 = SEG2 ? 32u * (uint32_t)(a.ldw2 * 2) : 0u;
   const int aBase = (wm * 128) * 128;
   const int bBaseV = ST_B + (wn * 32) * 128, bBaseG = ST_B + (128 + wn * 32) * 128;   // this wavefront's value / gate weight rows
   const int lBase = ST_L + ((wn & 1) * 16) * 128;                                     // its 16 rank rows of the LoRA-down tile
   const int tp = wn >> 1;                                                             // which 64-row half its T rows belong to
 
   // tile coordinates (all scalar)
-  struct Tile { int m0, f0; bool lora_on, t_writer, want_h; uint32_t rowX, rowWv, rowWg; };
+  struct Tile { int m0, f0, kt; bool lora_on, t_writer, want_h; uint32_t rowX, rowWv, rowWg; };
   auto tile_of = [&](int tl) __attribute__((always_inline)) {
     Tile c;
     int L = tl;
@@ -80,7 +89,8 @@ __global__ __launch_bounds__(NTH, 2) void lora_geglu256_kernel(const Args a) {
     // first, and a contiguous run of logical tiles per XCD would give XCDs 0-3 only cheap tiles.  Alternate the halves row tile by row tile.
     if (twin_mix) tile_m = (tile_m & 1) ? (tiles_m >> 1) + (tile_m >> 1) : (tile_m >> 1);
     c.m0 = tile_m * TM, c.f0 = tile_n * 128;
-    c.lora_on = c.m0 + TM > a.row0;
+    c.lora_on = !SEG2 && c.m0 + TM > a.row0;
+    c.kt = KT1 + (SEG2 && c.m0 + TM > a.row0 ? KT2 : 0);     // tiles of the clean half skip the second segment
     c.t_writer = tile_n == 0;
     c.want_h = a.H != nullptr && c.m0 + TM > a.c_row0;
     c.rowX = (uint32_t)c.m0 * (uint32_t)(a.ldx * 2);
@@ -93,7 +103,7 @@ __global__ __launch_bounds__(NTH, 2) void lora_geglu256_kernel(const Args a) {
 
   // loader lanes (rebuilt from a laundered thread id wherever they are used: hoisted out of the persistent loop the lane-derived
   // addresses cost ~20 VGPRs that nothing in the K loop can spare)
-  struct LoadLane { int kc; uint32_t vX, vW, vL; };
+  struct LoadLane { int kc, lrow; uint32_t vX, vW, vL, vX2, vW2; };
   auto load_lane = [&](int tid) __attribute__((always_inline)) {
     LoadLane q;
     const int lane = tid & 63;
@@ -105,21 +115,45 @@ __global__ __launch_bounds__(NTH, 2) void lora_geglu256_kernel(const Args a) {
     q.vX = (uint32_t)lrow * (uint32_t)(a.ldx * 2) + lchunk * 16;
     q.vW = (uint32_t)lrow * (uint32_t)(a.ldw * 2) + lchunk * 16;
     q.vL = (uint32_t)lrow * (uint32_t)(a.K * 2) + lchunk * 16;          // LoRA-down rows 8 w .. 8 w + 7
+    q.lrow = lrow;
+    q.vX2 = SEG2 ? (uint32_t)lrow * (uint32_t)(a.ldx2 * 2) + lchunk * 16 : 0u;
+    q.vW2 = SEG2 ? (uint32_t)lrow * (uint32_t)(a.ldw2 * 2) + lchunk * 16 : 0u;
     return q;
   };
   auto dma_x = [&](const LoadLane& q, const Tile& c, int half, int t, char* stage) __attribute__((always_inline)) {
+    if (SEG2 && t >= KT1) {      // second segment: rows below row0 (the clean half of a twin batch) contribute nothing
+      const int t2 = t - KT1;
+      const bool bad = q.kc >= a.K2 - t2 * BK;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool below = c.m0 + half * 128 + i * 32 + q.lrow < a.row0;
+        dma16(rsX2, stage + half * 16384 + (i * 4 + lw) * 1024,
+              (bad | below) ? OOB_ROW : q.vX2 + (uint32_t)c.m0 * (uint32_t)(a.ldx2 * 2) + (half * 4 + i) * stepX2, (uint32_t)t2 * (BK * 2));
+      }
+      return;
+    }
     const bool bad = q.kc >= a.K - t * BK;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       dma16(rsX, stage + half * 16384 + (i * 4 + lw) * 1024, bad ? OOB_ROW : q.vX + c.rowX + (half * 4 + i) * stepX, (uint32_t)t * (BK * 2));
   };
   auto dma_w = [&](const LoadLane& q, const Tile& c, int half, int t, char* stage) __attribute__((always_inline)) {
+    if (SEG2 && t >= KT1) {
+      const int t2 = t - KT1;
+      const bool bad = q.kc >= a.K2 - t2 * BK;
+      const uint32_t roww = (uint32_t)(half ? a.F + c.f0 : c.f0) * (uint32_t)(a.ldw2 * 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        dma16(rsW2, stage + ST_B + half * 16384 + (i * 4 + lw) * 1024, bad ? OOB_ROW : q.vW2 + roww + i * stepW2, (uint32_t)t2 * (BK * 2));
+      return;
+    }
     const bool bad = q.kc >= a.K - t * BK;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       dma16(rsW, stage + ST_B + half * 16384 + (i * 4 + lw) * 1024, bad ? OOB_ROW : q.vW + (half ? c.rowWg : c.rowWv) + i * stepW, (uint32_t)t * (BK * 2));
   };
   auto dma_l = [&](const LoadLane& q, const Tile& c, int t, char* stage) __attribute__((always_inline)) {
+    if constexpr (SEG2) return;
     const bool bad = (q.kc >= a.K - t * BK) | !c.lora_on;
     dma16(rsL, stage + ST_L + lw * 1024, bad ? OOB_ROW : q.vL, (uint32_t)t * (BK * 2));
   };
@@ -231,6 +265,7 @@ __global__ __launch_bounds__(NTH, 2) void lora_geglu256_kernel(const Args a) {
     // the side MFMAs inside the K tile cuts the compiler's ds_read / MFMA interleave)
     auto kloop = [&](auto tp_tag) __attribute__((always_inline)) {
       constexpr int TP = decltype(tp_tag)::value;
+      const int KT = c.kt;
       for (int t = 0; t < KT; ++t) {
         char* cur = region(t);
         char* nxt = region(t + 1);
@@ -259,13 +294,17 @@ __global__ __launch_bounds__(NTH, 2) void lora_geglu256_kernel(const Args a) {
         asm volatile("" ::: "memory");
       }
     };
-    if (!lora_on) kloop(std::integral_constant<int, -1>{});
-    else if (tp == 0) kloop(std::integral_constant<int, 0>{});
-    else kloop(std::integral_constant<int, 1>{});
+    if constexpr (SEG2) {
+      kloop(std::integral_constant<int, -1>{});
+    } else {
+      if (!lora_on) kloop(std::integral_constant<int, -1>{});
+      else if (tp == 0) kloop(std::integral_constant<int, 0>{});
+      else kloop(std::integral_constant<int, 1>{});
+    }
 
     T256_STAMP();   // 2 K loop done
     // ---- LoRA: T -> (T, Ts) bf16, Ts as an A image at the bottom of the LDS, one k-step against the Bup panel
-    if (lora_on) {
+    if (!SEG2 && lora_on) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = wm * 128 + tp * 64 + i * 16 + (lane & 15);
@@ -386,11 +425,19 @@ __global__ __launch_bounds__(NTH, 2) void lora_geglu256_kernel(const Args a) {
 inline void launch(const Args& a, hipStream_t stream) {
   static bool once = false;
   if (!once) {
-    (void)hipFuncSetAttribute((const void*)lora_geglu256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    (void)hipFuncSetAttribute((const void*)lora_geglu256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    (void)hipFuncSetAttribute((const void*)lora_geglu256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
     once = true;
   }
   const int grid = a.ntiles < 256 ? a.ntiles : 256;
-  hipLaunchKernelGGL(lora_geglu256_kernel, dim3(grid), dim3(NTH), LDS_TOTAL, stream, a);
+  if (a.seg2) hipLaunchKernelGGL(lora_geglu256_kernel<true>, dim3(grid), dim3(NTH), LDS_TOTAL, stream, a);
+  else hipLaunchKernelGGL(lora_geglu256_kernel<false>, dim3(grid), dim3(NTH), LDS_TOTAL, stream, a);
 }
+
+// aql_gemm_bf16_geglu's entry to the SEG2 kernel (defined in aql_gemm_lora.hip, the translation unit that instantiates the kernels):
+// AQL_OK when the 256 x 256 tile took the launch, AQL_NOT_FUSED when the shape stays on the 128 x 160 kernels.
+int t256_geglu_two_segments(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, int F, int K, const bf16_t* A2, long lda2,
+                            const bf16_t* B2, long ldb2, int K2, const bf16_t* bias, bf16_t* H, long ldh, bf16_t* G, long ldg,
+                            long row0, hipStream_t stream);
 
 }  // namespace aqlt256

@@ -49,6 +49,13 @@ def test_lora_geglu_256x256_persistent_tile_is_bit_identical():
     assert text.count("PASS geglu") >= 13
 
 
+def test_geglu_gemm_with_a_second_k_segment_on_the_256x256_tile_is_bit_identical():
+    """aql_gemm_bf16_geglu (rank != 32: the LoRA term as a second K segment on rows >= row0; or no LoRA) on the SEG2 form of the
+    256 x 256 tile against the 128 x 160 kernels: G / H equal bit for bit, NaN-poisoned Ts rows below row0 never read."""
+    text = _run("probe_t256_seg2.py")
+    assert text.count("PASS") >= 12
+
+
 def test_geglu_epilogue_on_the_256x256_tile_vs_fp32():
     text = _run("probe_geglu.py", {"AQL_LORA_CFG": "t256"})
     assert text.count("PASS") >= 20
