@@ -84,6 +84,8 @@ SIGNATURES = {
     "aql_dwconv_silu": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "aql_avgpool_nhwc": [c_p, c_i, c_i, c_i, c_p, c_p],
     "aql_se_gate": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p],
+    "aql_avgpool_nhwc_slabs": [c_p, c_i, c_i, c_i, c_i, c_p, c_p],
+    "aql_se_gate_slabs": [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     "aql_pwconv_f32": [c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_i, c_i, c_p, c_p],
     "aql_crop_resize_bilinear": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "aql_gauss_blur": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p],

@@ -124,14 +124,50 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ 
   }
 }
 
-// squeeze-excite gates: s = sigmoid(W2 . silu(W1 . pool + b1) + b2); one workgroup per sample
-__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ pool, const float* __restrict__ w1,
+// the same pool cut into S pixel slabs (grid.z): raw partial sums part[b][z][c], added in slab order by the consumer (se_fc_kernel).
+// One workgroup per (sample, 64-channel slab) reads 8 MB alone at the 256 x 256 level of a single image (0.5 ms per block, 12 of the
+// 16.5 ms of a batch-1 extraction); with the slabs the pool is a chip-wide pass.  Deterministic: fixed slab bounds, fixed order.
+__global__ __launch_bounds__(256) void avgpool_slabs_kernel(const float* __restrict__ x, int HW, int C, int S,
+                                                            float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int b = blockIdx.y, z = blockIdx.z, c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  const int per = (HW + S - 1) / S, p0 = z * per, p1 = min(HW, p0 + per);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    int p = p0 + sub;
+    for (; p + 12 < p1; p += 16) {      // four independent loads in flight per thread
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] += x[((long)b * HW + p + 4 * u) * C + c];
+    }
+    for (; p < p1; p += 4) acc[0] += x[((long)b * HW + p) * C + c];
+  }
+  red[sub][threadIdx.x & 63] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  __syncthreads();
+  if (sub == 0 && c < C) {
+    const int l = threadIdx.x;
+    part[((long)b * S + z) * C + c] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+  }
+}
+
+// squeeze-excite gates: s = sigmoid(W2 . silu(W1 . pool + b1) + b2); one workgroup per sample.  S > 0: `pool` holds S slab sums per
+// channel (avgpool_slabs_kernel), the mean is formed here first.
+__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ pool, int S, float inv_hw, const float* __restrict__ w1,
                                                     const float* __restrict__ b1, const float* __restrict__ w2,
                                                     const float* __restrict__ b2, int C, int Cs,
                                                     float* __restrict__ gate) {
   __shared__ float hid[512];
+  __shared__ float mean[2048];
   const int b = blockIdx.x;
   const float* p = pool + (long)b * C;
+  if (S > 0) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float a = 0.f;
+      for (int z = 0; z < S; ++z) a += pool[((long)b * S + z) * C + c];
+      mean[c] = a * inv_hw;
+    }
+    __syncthreads();
+    p = mean;
+  }
   for (int j = threadIdx.x; j < Cs; j += blockDim.x) {
     float a = b1[j];
     for (int c = 0; c < C; ++c) a += w1[(long)j * C + c] * p[c];
@@ -241,8 +277,24 @@ extern "C" int aql_avgpool_nhwc(const float* x, int B, int HW, int C, float* out
 extern "C" int aql_se_gate(const float* pool, const float* w1, const float* b1, const float* w2, const float* b2, int B,
                            int C, int Cs, float* gate, hipStream_t stream) {
   AQL_CHECK_ARG(pool && w1 && b1 && w2 && b2 && gate && Cs <= 512, "aql_se_gate: bad args");
-  hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), 0, stream, pool, w1, b1, w2, b2, C, Cs, gate);
+  hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), 0, stream, pool, 0, 1.f, w1, b1, w2, b2, C, Cs, gate);
   AQL_CHECK_LAUNCH("aql_se_gate");
+  return AQL_OK;
+}
+// The pool of a squeeze-excite block as S pixel slabs: part [B][S][C] raw sums (aql_avgpool_nhwc_slabs), consumed by
+// aql_se_gate_slabs, which forms the mean (sum over the slabs in order / HW) before the two small linears.  utils/models.py:84-96
+// through torchvision's MBConv SqueezeExcitation (AdaptiveAvgPool2d(1) -> fc1 -> SiLU -> fc2 -> Sigmoid).
+extern "C" int aql_avgpool_nhwc_slabs(const float* x, int B, int HW, int C, int S, float* part, hipStream_t stream) {
+  AQL_CHECK_ARG(x && part && B > 0 && HW > 0 && C > 0 && S > 0 && S <= HW && B < 65536 && S < 65536, "aql_avgpool_nhwc_slabs: bad args");
+  hipLaunchKernelGGL(avgpool_slabs_kernel, dim3((C + 63) / 64, B, S), dim3(256), 0, stream, x, HW, C, S, part);
+  AQL_CHECK_LAUNCH("aql_avgpool_nhwc_slabs");
+  return AQL_OK;
+}
+extern "C" int aql_se_gate_slabs(const float* part, int S, int HW, const float* w1, const float* b1, const float* w2, const float* b2,
+                                 int B, int C, int Cs, float* gate, hipStream_t stream) {
+  AQL_CHECK_ARG(part && w1 && b1 && w2 && b2 && gate && Cs <= 512 && C <= 2048 && S > 0 && HW > 0, "aql_se_gate_slabs: bad args");
+  hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), 0, stream, part, S, 1.f / (float)HW, w1, b1, w2, b2, C, Cs, gate);
+  AQL_CHECK_LAUNCH("aql_se_gate_slabs");
   return AQL_OK;
 }
 extern "C" int aql_pwconv_f32(const float* x, const float* w, const float* bias, const float* gate, int rows_per_sample,

@@ -208,11 +208,13 @@ class SecretDecoder(nn.Module):
             dw = torch.empty(B, Ho, Ho, cexp, device=dev)
             L.call("aql_dwconv_silu", L.ptr(h), L.ptr(d["dw"][0]), L.ptr(d["dw"][1]), B, Hc, Wc, cexp, k, s, L.ptr(dw), st)
             Hc = Wc = Ho
-            pool = torch.empty(B, cexp, device=dev)
-            L.call("aql_avgpool_nhwc", L.ptr(dw), B, Hc * Wc, cexp, L.ptr(pool), st)
+            # pool in pixel slabs (a chip-wide pass at any batch size), summed in slab order inside the gate kernel
+            S = max(1, min(128, (Hc * Wc) // 64, 2048 // (B * ((cexp + 63) // 64)) or 1))
+            part = torch.empty(B, S, cexp, device=dev)
+            L.call("aql_avgpool_nhwc_slabs", L.ptr(dw), B, Hc * Wc, cexp, S, L.ptr(part), st)
             gate = torch.empty(B, cexp, device=dev)
             w1, b1, w2, b2 = d["se"]
-            L.call("aql_se_gate", L.ptr(pool), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), B, cexp, w1.shape[0],
+            L.call("aql_se_gate_slabs", L.ptr(part), S, Hc * Wc, L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), B, cexp, w1.shape[0],
                    L.ptr(gate), st)
             out = torch.empty(B, Hc, Wc, cout, device=dev)
             L.call("aql_pwconv_f32", L.ptr(dw), L.ptr(d["proj"][0]), L.ptr(d["proj"][1]), L.ptr(gate), Hc * Wc,

@@ -324,6 +324,11 @@ int aql_se_gate(const float* pool, const float* w1, const float* b1, const float
                 int Cs, float* gate, aql_stream_t stream);
 int aql_pwconv_f32(const float* x, const float* w, const float* bias, const float* gate, int rows_per_sample,
                    const float* residual, long M, int N, int K, int act, float* y, aql_stream_t stream);
+/* the squeeze-excite pool as S pixel slabs (a chip-wide pass instead of one workgroup per sample and 64 channels): part [B][S][C]
+ * raw sums, added in slab order and divided by HW inside aql_se_gate_slabs (same reference lines as aql_avgpool_nhwc / aql_se_gate) */
+int aql_avgpool_nhwc_slabs(const float* x, int B, int HW, int C, int S, float* part, aql_stream_t stream);
+int aql_se_gate_slabs(const float* part, int S, int HW, const float* w1, const float* b1, const float* w2, const float* b2, int B,
+                      int C, int Cs, float* gate, aql_stream_t stream);
 
 /* wide-rank (r > 32) LoRA weight gradients (ppft_train.py:1058 backward through lora_modules.py:13-19): both operands
  * are transposed once (aql_transpose_bf16: dst[cols][rows] = src[rows][cols]^T) and C[M,N] += alpha * A[M,K].B[N,K]^T runs
