@@ -43,35 +43,79 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   f32x16_t acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  // 16-byte loads where an operand's unit stride is K and its rows are 16-byte aligned (the 1x1 convolutions: channel counts % 4 == 0)
+  const bool veca = sak == 1 && (sam & 3) == 0 && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  const bool vecb = sbk == 1 && (sbn & 3) == 0 && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
   for (long k0 = k_begin; k0 < k_end; k0 += 32) {
+    if (veca) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int id = tid + it * 256;
-      int r, c;
-      if (sak == 1) r = id >> 5, c = id & 31; else c = id >> 6, r = id & 63;
-      const long m = m0 + r, k = k0 + c;
-      sA[r][c] = (m < M && k < k_end) ? A[m * sam + k * sak] : 0.f;
-      if (sbk == 1) r = id >> 5, c = id & 31; else c = id >> 6, r = id & 63;
-      const long kb = k0 + c;
-      sB[r][c] = (n0 + r < N && kb < k_end) ? B[(long)(n0 + r) * sbn + kb * sbk] : 0.f;
+      for (int it = 0; it < 2; ++it) {
+        const int id = tid + it * 256, r = id >> 3, c = (id & 7) * 4;
+        const long m = m0 + r, k = k0 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < M && k + 3 < k_end) v = *reinterpret_cast<const float4*>(A + m * sam + k);
+        else if (m < M) {
+          if (k < k_end) v.x = A[m * sam + k];
+          if (k + 1 < k_end) v.y = A[m * sam + k + 1];
+          if (k + 2 < k_end) v.z = A[m * sam + k + 2];
+        }
+        sA[r][c] = v.x, sA[r][c + 1] = v.y, sA[r][c + 2] = v.z, sA[r][c + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int id = tid + it * 256;
+        int r, c;
+        if (sak == 1) r = id >> 5, c = id & 31; else c = id >> 6, r = id & 63;
+        const long m = m0 + r, k = k0 + c;
+        sA[r][c] = (m < M && k < k_end) ? A[m * sam + k * sak] : 0.f;
+      }
+    }
+    if (vecb) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int id = tid + it * 256, r = id >> 3, c = (id & 7) * 4;
+        const long k = k0 + c;
+        const bool in = n0 + r < N;
+        const float* bp = B + (long)(n0 + r) * sbn + k;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in && k + 3 < k_end) v = *reinterpret_cast<const float4*>(bp);
+        else if (in) {
+          if (k < k_end) v.x = bp[0];
+          if (k + 1 < k_end) v.y = bp[1];
+          if (k + 2 < k_end) v.z = bp[2];
+        }
+        sB[r][c] = v.x, sB[r][c + 1] = v.y, sB[r][c + 2] = v.z, sB[r][c + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int id = tid + it * 256;
+        int r, c;
+        if (sbk == 1) r = id >> 5, c = id & 31; else c = id >> 6, r = id & 63;
+        const long kb = k0 + c;
+        sB[r][c] = (n0 + r < N && kb < k_end) ? B[(long)(n0 + r) * sbn + kb * sbk] : 0.f;
+      }
     }
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < 32; kk += 2) {
-      const float a = sB[wn + (lane & 31)][kk + (lane >> 5)];   // MFMA operand A rows = output columns n
-      const float bq = sA[wm + (lane & 31)][kk + (lane >> 5)];  // MFMA operand B cols = output rows m
+      // D[i][j] += A[i][k] B[k][j] with i = output row m, j = output column n: a lane holds one column n = lane & 31 of 16 rows, so
+      // a store instruction writes two 128-byte row segments (the first form had the lanes along m: 64 rows x 4 bytes per store)
+      const float a = sA[wm + (lane & 31)][kk + (lane >> 5)];
+      const float bq = sB[wn + (lane & 31)][kk + (lane >> 5)];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
     }
     __syncthreads();
   }
-  const long m = m0 + wm + (lane & 31);
-  if (m >= M) return;
+  const int n = n0 + wn + (lane & 31);
+  if (n >= N) return;
+  const float bv = (bias != nullptr && blockIdx.z == 0) ? bias[n] : 0.f;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-    const int n = n0 + wn + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-    if (n >= N) continue;
-    float v = acc[e];
-    if (bias != nullptr && blockIdx.z == 0) v += bias[n];
+    const long m = m0 + wm + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+    if (m >= M) continue;
+    const float v = acc[e] + bv;
     if (splits > 1) atomicAdd(C + m * ldc + n, v);
     else C[m * ldc + n] = v;
   }
@@ -87,6 +131,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int BN_ROWS = 2048;  // rows per partial chunk
 
+// Lanes = 16 channel quads (16-byte loads) x 4 rows, 4 wavefronts = 16 rows per pass, four passes in flight per thread (the first
+// form -- one 4-byte load per lane and row, one row in flight per wavefront -- ran the 16 x 256 x 256-pixel maps of the rob-finetune
+// step at 0.8 TB/s: 26 of its 92 ms).  The four row lanes are folded with two xor-shuffles, the wavefronts through LDS, in a fixed order.
 template <bool BWD>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -94,33 +141,68 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
                                                          int act, long M, int C, float* __restrict__ p0,
                                                          float* __restrict__ p1) {
   __shared__ float r0[4][64], r1[4][64];
-  const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
-  const int c = blockIdx.y * 64 + cl;
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int q = lane & 15, rl = lane >> 4;
+  const int c = blockIdx.y * 64 + q * 4;
   const long m_begin = (long)blockIdx.x * BN_ROWS, m_end = min(M, m_begin + BN_ROWS);
-  float a0 = 0.f, a1 = 0.f;
+  float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
   if (c < C) {
-    float mu = 0.f, is = 0.f, g = 0.f, bt = 0.f;
-    if (BWD) mu = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
-    for (long m = m_begin + part; m < m_end; m += 4) {
-      const float xv = x[m * C + c];
-      if (!BWD) {
-        a0 += xv;
-        a1 += xv * xv;
-      } else {
-        const float xh = (xv - mu) * is;
-        float dz = dy[m * C + c];
-        if (act) dz *= dsilu_(g * xh + bt);
-        a0 += dz;
-        a1 += dz * xh;
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu, g = mu, bt = mu;
+    if (BWD) {
+      mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+      g = *reinterpret_cast<const float4*>(gamma + c), bt = *reinterpret_cast<const float4*>(beta + c);
+    }
+    auto add = [&](const float4& xv, const float4& dv) __attribute__((always_inline)) {
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+      const float ms[4] = {mu.x, mu.y, mu.z, mu.w}, ss[4] = {is.x, is.y, is.z, is.w};
+      const float gs[4] = {g.x, g.y, g.z, g.w}, bs[4] = {bt.x, bt.y, bt.z, bt.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (!BWD) {
+          a0[j] += xs[j];
+          a1[j] += xs[j] * xs[j];
+        } else {
+          const float xh = (xs[j] - ms[j]) * ss[j];
+          float dz = ds[j];
+          if (act) dz *= dsilu_(gs[j] * xh + bs[j]);
+          a0[j] += dz;
+          a1[j] += dz * xh;
+        }
       }
+    };
+    long m = m_begin + part * 4 + rl;
+    for (; m + 48 < m_end; m += 64) {
+      float4 xv[4], dv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xv[u] = *reinterpret_cast<const float4*>(x + (m + 16 * u) * C + c);
+        dv[u] = BWD ? *reinterpret_cast<const float4*>(dy + (m + 16 * u) * C + c) : xv[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) add(xv[u], dv[u]);
+    }
+    for (; m < m_end; m += 16) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + m * C + c);
+      const float4 dv = BWD ? *reinterpret_cast<const float4*>(dy + m * C + c) : xv;
+      add(xv, dv);
     }
   }
-  r0[part][cl] = a0;
-  r1[part][cl] = a1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    a0[j] += __shfl_xor(a0[j], 16);
+    a0[j] += __shfl_xor(a0[j], 32);
+    a1[j] += __shfl_xor(a1[j], 16);
+    a1[j] += __shfl_xor(a1[j], 32);
+  }
+  if (rl == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r0[part][q * 4 + j] = a0[j], r1[part][q * 4 + j] = a1[j];
+  }
   __syncthreads();
-  if (part == 0 && c < C) {
-    p0[(long)blockIdx.x * C + c] = (r0[0][cl] + r0[1][cl]) + (r0[2][cl] + r0[3][cl]);
-    p1[(long)blockIdx.x * C + c] = (r1[0][cl] + r1[1][cl]) + (r1[2][cl] + r1[3][cl]);
+  const int cl = threadIdx.x, cc = blockIdx.y * 64 + cl;
+  if (cl < 64 && cc < C) {
+    p0[(long)blockIdx.x * C + cc] = (r0[0][cl] + r0[1][cl]) + (r0[2][cl] + r0[3][cl]);
+    p1[(long)blockIdx.x * C + cc] = (r1[0][cl] + r1[1][cl]) + (r1[2][cl] + r1[3][cl]);
   }
 }
 
@@ -249,46 +331,67 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ src, 
   }
 }
 
-// dw[tap][c] += sum_{b,yo,xo} dy[b,yo,xo,c] * x[b, yo*s+kh-pad, xo*s+kw-pad, c]; a workgroup = 64 channels x 4 lanes over a
-// chunk of output pixels.  One pass over the pixels with all K*K tap sums in registers (dy read once per pixel), then one
-// atomicAdd per (workgroup, tap, channel).
+// dw[tap][c] += sum_{b,yo,xo} dy[b,yo,xo,c] * x[b, yo*s+kh-pad, xo*s+kw-pad, c].  A workgroup = 64 channels x `rows` output rows:
+// lanes = 16 channel quads (16-byte loads) x 4 pixels, 4 wavefronts = 16 consecutive output pixels of one row per pass; all K*K tap
+// sums of a lane's 4 channels in registers (dy read once per pixel, the K*K input reads hit L1: neighbouring pixels share them), no
+// division per pixel (the row is the loop, not a flat pixel index).  The first form (4-byte loads, one pixel per wavefront and
+// pass, three integer divisions per pixel) took 22 of the 92 ms of the rob-finetune step.  One atomicAdd per (workgroup, tap, channel).
 template <int K>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B,
-                                                       int H, int W, int C, int stride, int chunk,
+                                                       int H, int W, int C, int stride, int rows,
                                                        float* __restrict__ dw) {
   __shared__ float red[4][64];
   constexpr int pad = K / 2;
   const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
-  const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
-  const int c = blockIdx.y * 64 + cl;
-  const long P = (long)B * Ho * Wo;
-  const long p_begin = (long)blockIdx.x * chunk, p_end = min(P, p_begin + chunk);
-  float acc[K * K];
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int q = lane & 15, pl = lane >> 4;
+  const int c = blockIdx.y * 64 + q * 4;
+  const long R = (long)B * Ho;
+  const long r_begin = (long)blockIdx.x * rows, r_end = min(R, r_begin + rows);
+  float4 acc[K * K];
 #pragma unroll
-  for (int t = 0; t < K * K; ++t) acc[t] = 0.f;
+  for (int t = 0; t < K * K; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < C)
-    for (long p = p_begin + part; p < p_end; p += 4) {
-      const int xo = (int)(p % Wo), yo = (int)((p / Wo) % Ho);
-      const long b = p / ((long)Wo * Ho);
-      const float g = dy[p * C + c];
-      const int y0 = yo * stride - pad, x0 = xo * stride - pad;
+    for (long r = r_begin; r < r_end; ++r) {
+      const int yo = (int)(r % Ho);
+      const long b = r / Ho;
+      const int y0 = yo * stride - pad;
+      const float* dyr = dy + r * Wo * (long)C + c;
+      const float* xb = x + b * H * (long)W * C + c;
+      for (int xo = part * 4 + pl; xo < Wo; xo += 16) {
+        const float4 g = *reinterpret_cast<const float4*>(dyr + (long)xo * C);
+        const int x0 = xo * stride - pad;
 #pragma unroll
-      for (int kh = 0; kh < K; ++kh) {
-        const int yi = y0 + kh;
-        if (yi < 0 || yi >= H) continue;
+        for (int kh = 0; kh < K; ++kh) {
+          const int yi = y0 + kh;
+          if (yi < 0 || yi >= H) continue;
+          const float* xr = xb + (long)yi * W * C;
 #pragma unroll
-        for (int kw = 0; kw < K; ++kw) {
-          const int xi = x0 + kw;
-          if (xi < 0 || xi >= W) continue;
-          acc[kh * K + kw] += g * x[((b * H + yi) * W + xi) * C + c];
+          for (int kw = 0; kw < K; ++kw) {
+            const int xi = x0 + kw;
+            if (xi < 0 || xi >= W) continue;
+            const float4 v = *reinterpret_cast<const float4*>(xr + (long)xi * C);
+            float4& a = acc[kh * K + kw];
+            a.x += g.x * v.x, a.y += g.y * v.y, a.z += g.z * v.z, a.w += g.w * v.w;
+          }
         }
       }
     }
 #pragma unroll
   for (int t = 0; t < K * K; ++t) {
-    red[part][cl] = acc[t];
+    float v[4] = {acc[t].x, acc[t].y, acc[t].z, acc[t].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] += __shfl_xor(v[j], 16);
+      v[j] += __shfl_xor(v[j], 32);
+    }
+    if (pl == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[part][q * 4 + j] = v[j];
+    }
     __syncthreads();
-    if (part == 0 && c < C) atomicAdd(dw + (long)t * C + c, (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
+    const int cl = threadIdx.x, cc = blockIdx.y * 64 + cl;
+    if (cl < 64 && cc < C) atomicAdd(dw + (long)t * C + cc, (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
     __syncthreads();
   }
 }
@@ -593,11 +696,13 @@ extern "C" int aql_dwconv_train(const float* src, const float* src2, const float
                        stride, dst);
   } else {
     (void)hipMemsetAsync(dst, 0, (size_t)k * k * C * sizeof(float), stream);
-    const long P = (long)B * Ho * Wo;
-    const int chunk = 1024;
-    const dim3 grid((unsigned)((P + chunk - 1) / chunk), (C + 63) / 64);
-    if (k == 3) hipLaunchKernelGGL(dw_wgrad_kernel<3>, grid, dim3(256), 0, stream, src, src2, B, H, W, C, stride, chunk, dst);
-    else hipLaunchKernelGGL(dw_wgrad_kernel<5>, grid, dim3(256), 0, stream, src, src2, B, H, W, C, stride, chunk, dst);
+    const long R = (long)B * Ho;
+    int rows = 1024 / Wo;                        // ~1024 output pixels per workgroup, whole rows
+    if (rows < 1) rows = 1;
+    while (rows > 1 && (R + rows - 1) / rows * ((C + 63) / 64) < 1024) rows >>= 1;   // small maps: enough workgroups for the chip
+    const dim3 grid((unsigned)((R + rows - 1) / rows), (C + 63) / 64);
+    if (k == 3) hipLaunchKernelGGL(dw_wgrad_kernel<3>, grid, dim3(256), 0, stream, src, src2, B, H, W, C, stride, rows, dst);
+    else hipLaunchKernelGGL(dw_wgrad_kernel<5>, grid, dim3(256), 0, stream, src, src2, B, H, W, C, stride, rows, dst);
   }
   AQL_CHECK_LAUNCH("aql_dwconv_train");
   return AQL_OK;
