@@ -29,15 +29,18 @@ inline int grid_for(long n, int cap = 8192) {
 //   data      dX[M,Ci] = dY[M,Co] . W[Co,Ci]      A=dY (Co,1)  B=W (1,Ci)
 //   weight    dW[Co,Ci] = dY^T . X   (K = M)      A=dY (1,Co)  B=X (1,Ci)
 // ------------------------------------------------------------------------------------------------------------------
+// TM x TN output tile: 64 x 64 (2 x 2 wavefronts of 32 x 32) or, for N <= 32, 128 x 32 (4 x 1: no wavefront multiplies padding columns)
+template <int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long sam, long sak,
                                                        const float* __restrict__ B, long sbn, long sbk,
                                                        const float* __restrict__ bias, float* __restrict__ C, long ldc,
                                                        long M, int N, long K, int splits) {
-  __shared__ float sA[64][33], sB[64][33];
+  __shared__ float sA[TM][33], sB[TN][33];
+  constexpr int WAVES_N = TN / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long m0 = (long)blockIdx.x * 64;
-  const int n0 = blockIdx.y * 64;
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const long m0 = (long)blockIdx.x * TM;
+  const int n0 = blockIdx.y * TN;
+  const int wm = (wave / WAVES_N) * 32, wn = (wave % WAVES_N) * 32;
   const long kt = (K + 31) / 32;
   const long k_begin = (kt * blockIdx.z / splits) * 32, k_end = min(K, (kt * (blockIdx.z + 1) / splits) * 32);
   f32x16_t acc;
@@ -46,10 +49,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   // 16-byte loads where an operand's unit stride is K and its rows are 16-byte aligned (the 1x1 convolutions: channel counts % 4 == 0)
   const bool veca = sak == 1 && (sam & 3) == 0 && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
   const bool vecb = sbk == 1 && (sbn & 3) == 0 && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  const bool vecat = sam == 1 && sak != 1 && (sak & 3) == 0 && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  const bool vecbt = sbn == 1 && sbk != 1 && (sbk & 3) == 0 && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
   for (long k0 = k_begin; k0 < k_end; k0 += 32) {
     if (veca) {
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
+      for (int it = 0; it < TM / 32; ++it) {
         const int id = tid + it * 256, r = id >> 3, c = (id & 7) * 4;
         const long m = m0 + r, k = k0 + c;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -61,19 +66,36 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         }
         sA[r][c] = v.x, sA[r][c + 1] = v.y, sA[r][c + 2] = v.z, sA[r][c + 3] = v.w;
       }
+    } else if (vecat) {     // unit stride along m (weight gradients: A = dY^T): 4 consecutive rows per lane
+#pragma unroll
+      for (int it = 0; it < TM / 32; ++it) {
+        const int id = tid + it * 256, r = (id % (TM / 4)) * 4, c = id / (TM / 4);
+        const long m = m0 + r, k = k0 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < k_end) {
+          const float* ap = A + m + k * sak;
+          if (m + 3 < M) v = *reinterpret_cast<const float4*>(ap);
+          else {
+            if (m < M) v.x = ap[0];
+            if (m + 1 < M) v.y = ap[1];
+            if (m + 2 < M) v.z = ap[2];
+          }
+        }
+        sA[r][c] = v.x, sA[r + 1][c] = v.y, sA[r + 2][c] = v.z, sA[r + 3][c] = v.w;
+      }
     } else {
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
+      for (int it = 0; it < TM / 8; ++it) {
         const int id = tid + it * 256;
         int r, c;
-        if (sak == 1) r = id >> 5, c = id & 31; else c = id >> 6, r = id & 63;
+        if (sak == 1) r = id >> 5, c = id & 31; else c = id / TM, r = id % TM;
         const long m = m0 + r, k = k0 + c;
         sA[r][c] = (m < M && k < k_end) ? A[m * sam + k * sak] : 0.f;
       }
     }
     if (vecb) {
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
+      for (int it = 0; it < TN / 32; ++it) {
         const int id = tid + it * 256, r = id >> 3, c = (id & 7) * 4;
         const long k = k0 + c;
         const bool in = n0 + r < N;
@@ -87,12 +109,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         }
         sB[r][c] = v.x, sB[r][c + 1] = v.y, sB[r][c + 2] = v.z, sB[r][c + 3] = v.w;
       }
+    } else if (vecbt) {
+#pragma unroll
+      for (int it = 0; it < TN / 32; ++it) {
+        const int id = tid + it * 256, r = (id % (TN / 4)) * 4, c = id / (TN / 4);
+        const long k = k0 + c;
+        const int nn = n0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < k_end) {
+          const float* bp = B + nn + k * sbk;
+          if (nn + 3 < N) v = *reinterpret_cast<const float4*>(bp);
+          else {
+            if (nn < N) v.x = bp[0];
+            if (nn + 1 < N) v.y = bp[1];
+            if (nn + 2 < N) v.z = bp[2];
+          }
+        }
+        sB[r][c] = v.x, sB[r + 1][c] = v.y, sB[r + 2][c] = v.z, sB[r + 3][c] = v.w;
+      }
     } else {
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
+      for (int it = 0; it < TN / 8; ++it) {
         const int id = tid + it * 256;
         int r, c;
-        if (sbk == 1) r = id >> 5, c = id & 31; else c = id >> 6, r = id & 63;
+        if (sbk == 1) r = id >> 5, c = id & 31; else c = id / TN, r = id % TN;
         const long kb = k0 + c;
         sB[r][c] = (n0 + r < N && kb < k_end) ? B[(long)(n0 + r) * sbn + kb * sbk] : 0.f;
       }
@@ -206,14 +246,36 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
+// Column sums of the two partial tables in double precision: a workgroup = 64 channels x 4 chunk lanes (chunk i goes to lane i % 4),
+// the four lanes are added in a fixed order.  (One thread per channel walking all 512 chunks took 18 us per launch, 138 launches per step.)
+__device__ __forceinline__ void bn_column_sums(const float* __restrict__ p0, const float* __restrict__ p1, int nchunk, int C, int c,
+                                               int part, double (&red)[2][4][64], double& s, double& q) {
+  double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
+  if (c < C) {
+    int i = part;
+    for (; i + 4 < nchunk; i += 8) {
+      s0 += p0[(long)i * C + c], q0 += p1[(long)i * C + c];
+      s1 += p0[(long)(i + 4) * C + c], q1 += p1[(long)(i + 4) * C + c];
+    }
+    for (; i < nchunk; i += 4) s0 += p0[(long)i * C + c], q0 += p1[(long)i * C + c];
+  }
+  const int cl = threadIdx.x & 63;
+  red[0][part][cl] = s0 + s1;
+  red[1][part][cl] = q0 + q1;
+  __syncthreads();
+  s = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+  q = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+}
+
 __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
                                                               int nchunk, long M, int C, float eps, float momentum,
                                                               float* __restrict__ mean, float* __restrict__ invstd,
                                                               float* __restrict__ run_mean, float* __restrict__ run_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int i = 0; i < nchunk; ++i) s += p0[(long)i * C + c], q += p1[(long)i * C + c];
+  __shared__ double red[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  double s, q;
+  bn_column_sums(p0, p1, nchunk, C, c, part, red, s, q);
+  if (part != 0 || c >= C) return;
   const double mu = s / (double)M;
   double var = q / (double)M - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -229,10 +291,11 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __res
 __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
                                                               int nchunk, int C, float* __restrict__ dbeta,
                                                               float* __restrict__ dgamma) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int i = 0; i < nchunk; ++i) s += p0[(long)i * C + c], q += p1[(long)i * C + c];
+  __shared__ double red[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  double s, q;
+  bn_column_sums(p0, p1, nchunk, C, c, part, red, s, q);
+  if (part != 0 || c >= C) return;
   dbeta[c] = (float)s;
   dgamma[c] = (float)q;
 }
@@ -471,18 +534,21 @@ __global__ __launch_bounds__(256) void stem_bwd_data_kernel(const float* __restr
 // one pass with the 27 tap sums in registers
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B,
                                                          int H, int W, int Cout, int chunk, float* __restrict__ dw) {
-  __shared__ float red[4][64];
+  __shared__ float red[8][64];
   const int Ho = H / 2, Wo = W / 2;
-  const int co = threadIdx.x & 63, part = threadIdx.x >> 6;
+  // Cout <= 32 (EfficientNet-B1: 32): 8 pixels per pass, every lane busy
+  const int cw = Cout <= 32 ? 32 : 64, nparts = 256 / cw;
+  const int co = threadIdx.x % cw, part = threadIdx.x / cw;
   const long P = (long)B * Ho * Wo;
   const long p_begin = (long)blockIdx.x * chunk, p_end = min(P, p_begin + chunk);
   float acc[27];
 #pragma unroll
   for (int t = 0; t < 27; ++t) acc[t] = 0.f;
-  if (co < Cout)
-    for (long p = p_begin + part; p < p_end; p += 4) {
-      const int xo = (int)(p % Wo), yo = (int)((p / Wo) % Ho);
-      const long b = p / ((long)Wo * Ho);
+  if (co < Cout) {
+    long p = p_begin + part;
+    int xo = (int)(p % Wo), yo = (int)((p / Wo) % Ho);
+    long b = p / ((long)Wo * Ho);
+    for (; p < p_end; p += nparts) {
       const float g = dy[p * Cout + co];
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
@@ -497,12 +563,22 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
           for (int ci = 0; ci < 3; ++ci) acc[(kh * 3 + kw) * 3 + ci] += g * px[ci];
         }
       }
+      xo += nparts;                      // next pixel of this lane without a division (nparts <= Wo)
+      if (xo >= Wo) {
+        xo -= Wo;
+        if (++yo == Ho) yo = 0, ++b;
+      }
     }
+  }
 #pragma unroll
   for (int t = 0; t < 27; ++t) {
     red[part][co] = acc[t];
     __syncthreads();
-    if (part == 0 && co < Cout) atomicAdd(dw + (long)t * Cout + co, (red[0][co] + red[1][co]) + (red[2][co] + red[3][co]));
+    if (part == 0 && co < Cout) {
+      float v = 0.f;
+      for (int q = 0; q < nparts; ++q) v += red[q][co];
+      atomicAdd(dw + (long)t * Cout + co, v);
+    }
     __syncthreads();
   }
 }
@@ -545,6 +621,54 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
     const float v = ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) * scale;
     if (nsplit > 1) atomicAdd(out + (long)b * C + c, v);
     else out[(long)b * C + c] = v;
+  }
+}
+
+// the same reduction on 16-byte loads (C % 4 == 0): lanes = 16 channel quads x 4 rows, 16 rows per pass, four passes in flight
+__global__ __launch_bounds__(256) void chan_reduce4_kernel(const float* __restrict__ a, const float* __restrict__ bmul,
+                                                           long HW, int C, float scale, int nsplit,
+                                                           float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6, q = lane & 15, rl = lane >> 4;
+  const int b = blockIdx.y, c = blockIdx.x * 64 + q * 4;
+  const long per = (HW + nsplit - 1) / nsplit;
+  const long p0 = (long)blockIdx.z * per, p1 = min(HW, p0 + per);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    const float* ab = a + (long)b * HW * C + c;
+    const float* mb = bmul ? bmul + (long)b * HW * C + c : nullptr;
+    auto add = [&](const float4& v, const float4& w) __attribute__((always_inline)) {
+      acc[0] += v.x * w.x, acc[1] += v.y * w.y, acc[2] += v.z * w.z, acc[3] += v.w * w.w;
+    };
+    const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+    long p = p0 + part * 4 + rl;
+    for (; p + 48 < p1; p += 64) {
+      float4 v[4], w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = *reinterpret_cast<const float4*>(ab + (p + 16 * u) * C);
+        w[u] = mb ? *reinterpret_cast<const float4*>(mb + (p + 16 * u) * C) : one;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) add(v[u], w[u]);
+    }
+    for (; p < p1; p += 16) add(*reinterpret_cast<const float4*>(ab + p * C), mb ? *reinterpret_cast<const float4*>(mb + p * C) : one);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    acc[j] += __shfl_xor(acc[j], 16);
+    acc[j] += __shfl_xor(acc[j], 32);
+  }
+  if (rl == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[part][q * 4 + j] = acc[j];
+  }
+  __syncthreads();
+  const int l = threadIdx.x, cc = blockIdx.x * 64 + l;
+  if (l < 64 && cc < C) {
+    const float v = ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) * scale;
+    if (nsplit > 1) atomicAdd(out + (long)b * C + cc, v);
+    else out[(long)b * C + cc] = v;
   }
 }
 
@@ -623,21 +747,29 @@ extern "C" int aql_gemm_f32(const float* A, long sam, long sak, const float* B, 
                             float* C, long ldc, long M, int N, long K, hipStream_t stream) {
   AQL_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && (sam == 1 || sak == 1) && (sbn == 1 || sbk == 1),
                 "aql_gemm_f32: bad args (one stride of each operand must be 1)");
-  const long tiles = ((M + 63) / 64) * ((N + 63) / 64);
+  const int tn = (N <= 32 && M >= 128) ? 32 : 64;      // narrow outputs: 128 x 32 tiles
+  const long tiles = tn == 32 ? (M + 127) / 128 : ((M + 63) / 64) * ((N + 63) / 64);
   int splits = 1;
-  if (tiles < 256 && K >= 2048) {
-    splits = (int)((512 + tiles - 1) / tiles);
+  // Few output tiles under a long contraction (weight gradients: K = pixels; squeeze-excite linears: one tile): cut K so that the
+  // chip holds ~8 workgroups per CU -- a workgroup has ONE K tile in flight (load, barrier, 16 MFMAs, barrier), the overlap comes
+  // from co-resident workgroups.  (The first rule, <= 256 splits from K = 2048 on, ran the 1M-pixel weight gradients at 0.26 TB/s.)
+  if (tiles < 512 && K >= 512) {
+    splits = (int)((2048 + tiles - 1) / tiles);
     const long kt = (K + 31) / 32;
-    if (splits > kt / 8) splits = (int)(kt / 8);
-    if (splits > 256) splits = 256;
+    if (splits > kt / 4) splits = (int)(kt / 4);
+    if (splits > 4096) splits = 4096;
     if (splits < 1) splits = 1;
   }
   if (splits > 1) {
     if (ldc == N) (void)hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), stream);
     else (void)hipMemset2DAsync(C, ldc * sizeof(float), 0, N * sizeof(float), M, stream);
   }
-  hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)((M + 63) / 64), (N + 63) / 64, splits), dim3(256), 0, stream, A, sam,
-                     sak, B, sbn, sbk, bias, C, ldc, M, N, K, splits);
+  if (tn == 32)
+    hipLaunchKernelGGL((gemm_f32_kernel<128, 32>), dim3((unsigned)((M + 127) / 128), 1, splits), dim3(256), 0, stream, A, sam, sak, B,
+                       sbn, sbk, bias, C, ldc, M, N, K, splits);
+  else
+    hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), dim3((unsigned)((M + 63) / 64), (N + 63) / 64, splits), dim3(256), 0, stream, A, sam,
+                       sak, B, sbn, sbk, bias, C, ldc, M, N, K, splits);
   AQL_CHECK_LAUNCH("aql_gemm_f32");
   return AQL_OK;
 }
@@ -654,7 +786,7 @@ extern "C" int aql_bn_train_fwd(const float* x, const float* gamma, const float*
   float* p1 = scratch + (long)nchunk * C;
   hipLaunchKernelGGL(bn_partial_kernel<false>, dim3(nchunk, (C + 63) / 64), dim3(256), 0, stream, x, nullptr, nullptr,
                      nullptr, nullptr, nullptr, 0, M, C, p0, p1);
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, p0, p1, nchunk, M, C, eps,
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, p0, p1, nchunk, M, C, eps,
                      momentum, mean, invstd, run_mean, run_var);
   hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(grid_for(M * (C / 4))), dim3(256), 0, stream, x, nullptr, mean, invstd,
                      gamma, beta, nullptr, nullptr, act, M, C, y);
@@ -672,7 +804,7 @@ extern "C" int aql_bn_train_bwd(const float* x, const float* dy, const float* ga
   float* p1 = scratch + (long)nchunk * C;
   hipLaunchKernelGGL(bn_partial_kernel<true>, dim3(nchunk, (C + 63) / 64), dim3(256), 0, stream, x, dy, mean, invstd,
                      gamma, beta, act, M, C, p0, p1);
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, p0, p1, nchunk, C, dbeta,
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, p0, p1, nchunk, C, dbeta,
                      dgamma);
   hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(grid_for(M * (C / 4))), dim3(256), 0, stream, x, dy, mean, invstd, gamma,
                      beta, dbeta, dgamma, act, M, C, dx);
@@ -722,7 +854,7 @@ extern "C" int aql_stem_train(const float* src, const float* src2, const float* 
                        dst);
   } else {
     (void)hipMemsetAsync(dst, 0, (size_t)27 * Cout * sizeof(float), stream);
-    const int chunk = 2048;
+    const int chunk = 256;     // 4096 workgroups at 16 x 256 x 256 output pixels (512 of 2048 pixels each ran 1.2 ms: two per CU)
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)((P + chunk - 1) / chunk)), dim3(256), 0, stream, src, src2, B, H,
                        W, Cout, chunk, dst);
   }
@@ -745,12 +877,14 @@ extern "C" int aql_chan_reduce(const float* a, const float* bmul, int B, long HW
   AQL_CHECK_ARG(a && out, "aql_chan_reduce: bad args");
   int nsplit = 1;
   const long blocks = (long)((C + 63) / 64) * B;
-  if (blocks < 1024 && HW >= 2048) {
-    nsplit = (int)min((long)(2048 / blocks > 0 ? 2048 / blocks : 1), HW / 512);
+  if (blocks < 1024 && HW >= 512) {     // ~2048 workgroups, at least 128 rows each
+    nsplit = (int)min((long)(2048 / blocks > 0 ? 2048 / blocks : 1), HW / 128);
     if (nsplit < 1) nsplit = 1;
   }
   if (nsplit > 1) (void)hipMemsetAsync(out, 0, (size_t)B * C * sizeof(float), stream);
-  hipLaunchKernelGGL(chan_reduce_kernel, dim3((C + 63) / 64, B, nsplit), dim3(256), 0, stream, a, bmul, HW, C, scale, nsplit,
+  const bool vec = C % 4 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0 && (bmul == nullptr || (reinterpret_cast<uintptr_t>(bmul) & 15) == 0);
+  if (vec) hipLaunchKernelGGL(chan_reduce4_kernel, dim3((C + 63) / 64, B, nsplit), dim3(256), 0, stream, a, bmul, HW, C, scale, nsplit, out);
+  else hipLaunchKernelGGL(chan_reduce_kernel, dim3((C + 63) / 64, B, nsplit), dim3(256), 0, stream, a, bmul, HW, C, scale, nsplit,
                      out);
   AQL_CHECK_LAUNCH("aql_chan_reduce");
   return AQL_OK;
