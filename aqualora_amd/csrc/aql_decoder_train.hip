@@ -30,8 +30,11 @@ inline int grid_for(long n, int cap = 8192) {
 //   weight    dW[Co,Ci] = dY^T . X   (K = M)      A=dY (1,Co)  B=X (1,Ci)
 // ------------------------------------------------------------------------------------------------------------------
 // TM x TN output tile: 64 x 64 (2 x 2 wavefronts of 32 x 32) or, for N <= 32, 128 x 32 (4 x 1: no wavefront multiplies padding columns)
-template <int TM, int TN>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long sam, long sak,
+// LA / LB: how an operand tile is fetched -- 1 = 16-byte loads along K, 2 = 16-byte loads along m / n (transposed operand), 0 = 4-byte
+// loads (any strides).  Compile-time so that an instantiation carries ONE loader per operand (all four inline cost 176 VGPRs: two
+// workgroups per CU for a kernel whose only latency hiding is co-resident workgroups).
+template <int TM, int TN, int LA, int LB>
+__global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restrict__ A, long sam, long sak,
                                                        const float* __restrict__ B, long sbn, long sbk,
                                                        const float* __restrict__ bias, float* __restrict__ C, long ldc,
                                                        long M, int N, long K, int splits) {
@@ -47,12 +50,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   // 16-byte loads where an operand's unit stride is K and its rows are 16-byte aligned (the 1x1 convolutions: channel counts % 4 == 0)
-  const bool veca = sak == 1 && (sam & 3) == 0 && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
-  const bool vecb = sbk == 1 && (sbn & 3) == 0 && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
-  const bool vecat = sam == 1 && sak != 1 && (sak & 3) == 0 && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
-  const bool vecbt = sbn == 1 && sbk != 1 && (sbk & 3) == 0 && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
   for (long k0 = k_begin; k0 < k_end; k0 += 32) {
-    if (veca) {
+    if constexpr (LA == 1) {
 #pragma unroll
       for (int it = 0; it < TM / 32; ++it) {
         const int id = tid + it * 256, r = id >> 3, c = (id & 7) * 4;
@@ -66,7 +65,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         }
         sA[r][c] = v.x, sA[r][c + 1] = v.y, sA[r][c + 2] = v.z, sA[r][c + 3] = v.w;
       }
-    } else if (vecat) {     // unit stride along m (weight gradients: A = dY^T): 4 consecutive rows per lane
+    } else if constexpr (LA == 2) {     // unit stride along m (weight gradients: A = dY^T): 4 consecutive rows per lane
 #pragma unroll
       for (int it = 0; it < TM / 32; ++it) {
         const int id = tid + it * 256, r = (id % (TM / 4)) * 4, c = id / (TM / 4);
@@ -93,7 +92,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         sA[r][c] = (m < M && k < k_end) ? A[m * sam + k * sak] : 0.f;
       }
     }
-    if (vecb) {
+    if constexpr (LB == 1) {
 #pragma unroll
       for (int it = 0; it < TN / 32; ++it) {
         const int id = tid + it * 256, r = id >> 3, c = (id & 7) * 4;
@@ -109,7 +108,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         }
         sB[r][c] = v.x, sB[r][c + 1] = v.y, sB[r][c + 2] = v.z, sB[r][c + 3] = v.w;
       }
-    } else if (vecbt) {
+    } else if constexpr (LB == 2) {
 #pragma unroll
       for (int it = 0; it < TN / 32; ++it) {
         const int id = tid + it * 256, r = (id % (TN / 4)) * 4, c = id / (TN / 4);
@@ -764,12 +763,22 @@ extern "C" int aql_gemm_f32(const float* A, long sam, long sak, const float* B, 
     if (ldc == N) (void)hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), stream);
     else (void)hipMemset2DAsync(C, ldc * sizeof(float), 0, N * sizeof(float), M, stream);
   }
-  if (tn == 32)
-    hipLaunchKernelGGL((gemm_f32_kernel<128, 32>), dim3((unsigned)((M + 127) / 128), 1, splits), dim3(256), 0, stream, A, sam, sak, B,
-                       sbn, sbk, bias, C, ldc, M, N, K, splits);
-  else
-    hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), dim3((unsigned)((M + 63) / 64), (N + 63) / 64, splits), dim3(256), 0, stream, A, sam,
-                       sak, B, sbn, sbk, bias, C, ldc, M, N, K, splits);
+  // 16-byte loads where an operand's unit stride and its row pitch allow them (the 1x1 convolutions: channel counts % 4 == 0)
+  const bool al_a = (reinterpret_cast<uintptr_t>(A) & 15) == 0, al_b = (reinterpret_cast<uintptr_t>(B) & 15) == 0;
+  const int la = (sak == 1 && (sam & 3) == 0 && al_a) ? 1 : (sam == 1 && sak != 1 && (sak & 3) == 0 && al_a) ? 2 : 0;
+  const int lb = (sbk == 1 && (sbn & 3) == 0 && al_b) ? 1 : (sbn == 1 && sbk != 1 && (sbk & 3) == 0 && al_b) ? 2 : 0;
+  const dim3 grid = tn == 32 ? dim3((unsigned)((M + 127) / 128), 1, splits) : dim3((unsigned)((M + 63) / 64), (N + 63) / 64, splits);
+#define AQL_GEMM_F32_GO(TMv, TNv, LAv, LBv) \
+  hipLaunchKernelGGL((gemm_f32_kernel<TMv, TNv, LAv, LBv>), grid, dim3(256), 0, stream, A, sam, sak, B, sbn, sbk, bias, C, ldc, M, N, K, splits)
+#define AQL_GEMM_F32_LB(TMv, TNv, LAv) \
+  do { if (lb == 1) AQL_GEMM_F32_GO(TMv, TNv, LAv, 1); else if (lb == 2) AQL_GEMM_F32_GO(TMv, TNv, LAv, 2); else AQL_GEMM_F32_GO(TMv, TNv, LAv, 0); } while (0)
+#define AQL_GEMM_F32_LA(TMv, TNv) \
+  do { if (la == 1) AQL_GEMM_F32_LB(TMv, TNv, 1); else if (la == 2) AQL_GEMM_F32_LB(TMv, TNv, 2); else AQL_GEMM_F32_LB(TMv, TNv, 0); } while (0)
+  if (tn == 32) AQL_GEMM_F32_LA(128, 32);
+  else AQL_GEMM_F32_LA(64, 64);
+#undef AQL_GEMM_F32_LA
+#undef AQL_GEMM_F32_LB
+#undef AQL_GEMM_F32_GO
   AQL_CHECK_LAUNCH("aql_gemm_f32");
   return AQL_OK;
 }
