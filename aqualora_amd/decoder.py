@@ -122,6 +122,12 @@ class SecretDecoder(nn.Module):
         self._packed = None  # folded inference weights go stale as soon as the parameters may move
         return super().train(mode)
 
+    def __getstate__(self):
+        """copy.deepcopy / pickle: the folded weights and their captured graphs are derived state (a HIP graph cannot be copied)."""
+        state = dict(self.__dict__)
+        state["_packed"] = None
+        return state
+
     # ---------------------------------------------------------------------------------------- forward
     def forward(self, x, sd_noise=None, drop_mask=None):
         if not x.is_cuda:

@@ -505,6 +505,12 @@ class UNet2DConditionModel(nn.Module):
         outs = ops.lora_linear_grouped(x2d, wc[1], packs, sites, S, S16, N)
         ctx._aql_kv = {id(a): (outs[2 * i].view(B, N, -1), outs[2 * i + 1].view(B, N, -1)) for i, a in enumerate(attns)}
 
+    def __getstate__(self):
+        """copy.deepcopy / pickle: captured sampling loops (inference._GuidedLoop) are derived state; a HIP graph cannot be copied."""
+        state = dict(self.__dict__)
+        state.pop("_aql_loops", None)
+        return state
+
     @property
     def dtype(self):
         return self.conv_in.weight.dtype

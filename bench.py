@@ -509,7 +509,10 @@ def robft_bench(args, device):
                             "(EfficientNet-B1, train mode) forward / backward / AdamW on given 512x512 images, batch 16, fp32",
                 "value": B / dt, "unit": "images/sec", "ms_per_step": 1e3 * dt, "steps": args.steps, "dtype": "f32", "batch": B,
                 "achieved_tflops_fp32": gf / dt / 1e3, "loss": float(loss), "bit_acc_of_step": float(acc),
-                "finite": bool(torch.isfinite(loss))}
+                "finite": bool(torch.isfinite(loss)),
+                **({"generator": f"per-image messages, 20-step DPM-Solver++ sampling (CFG 7.5) through the un-fused rank-{args.rank} "
+                                 f"watermark LoRA at {args.robft_res}x{args.robft_res} + VAE decode in front of the step "
+                                 "(rob_enhance_finetune.py:997-1021): the WHOLE iteration"} if gen is not None else {})}
     print(json.dumps({"metric": "rob-finetune decoder step images/sec at 512x512 (EfficientNet-B1 train mode, fp32)",
                       "value": B / dt, "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "ms_per_step": 1e3 * dt,
                       "dtype": "f32", "higher_is_better": True, "data": "synthetic", "batch": B,
@@ -728,6 +731,12 @@ def main():
             ra = copy.copy(args)
             ra.as_record, ra.steps, ra.warmup, ra.robft_sample = True, 10, 3, False
             line["config5"] = robft_bench(ra, device)
+            # ... and the whole iteration of the reference's loop at BASELINE's rank 320: the 20-step sampling of the batch's 16 images
+            # through the un-fused LoRA + VAE decode in front of the decoder step (the sampling is ~97 % of it)
+            rb = copy.copy(args)
+            rb.as_record, rb.steps, rb.warmup, rb.robft_sample, rb.robft_res, rb.rank = True, 2, 1, True, "512", 320
+            whole = robft_bench(rb, device)
+            line["config5"]["whole_iteration"] = {k: whole[k] for k in ("value", "unit", "ms_per_step", "steps", "generator", "finite")}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tr, args.rank)
         print(json.dumps(line), flush=True)

@@ -70,3 +70,24 @@ def test_decoder_parameters_equal_the_published_efficientnet_b1_inventory():
     for n in bn:
         base = n[:-len("weight")]
         assert {base + "running_mean", base + "running_var", base + "num_batches_tracked"} <= set(bufs)
+
+
+def test_captured_graphs_are_not_part_of_a_module_copy():
+    """copy.deepcopy / pickle of the decoder or the U-Net must not trip over the derived GPU state they keep (folded weights with
+    their HIP graphs, captured sampling loops): `__getstate__` drops it and the copy rebuilds it on first use."""
+    import copy
+
+    import torch
+    from aqualora_amd.decoder import SecretDecoder
+    from tests.common import tiny_unet
+
+    class NoCopy:
+        def __deepcopy__(self, memo):
+            raise TypeError("a HIP graph cannot be copied")
+
+    dec = SecretDecoder(8)
+    dec._packed = {"graphs": NoCopy()}
+    assert copy.deepcopy(dec)._packed is None and dec._packed is not None
+    unet = tiny_unet("cpu", torch.float32)
+    unet.__dict__["_aql_loops"] = {"loop": NoCopy()}
+    assert "_aql_loops" not in copy.deepcopy(unet).__dict__ and "_aql_loops" in unet.__dict__
