@@ -56,6 +56,13 @@ def test_geglu_gemm_with_a_second_k_segment_on_the_256x256_tile_is_bit_identical
     assert text.count("PASS") >= 12
 
 
+def test_persistent_256x256_kernel_repeats_bit_for_bit():
+    """tools/stress_t256.py: the same launch 150 times on NaN-poisoned outputs, every result equal to the first (a missed barrier or
+    vmcnt wait of the hand-phased pipeline would show up as a difference)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_t256.py"), "150"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "ALL PASS" in out.stdout, (out.stdout + out.stderr)[-1500:]
+
+
 def test_geglu_epilogue_on_the_256x256_tile_vs_fp32():
     text = _run("probe_geglu.py", {"AQL_LORA_CFG": "t256"})
     assert text.count("PASS") >= 20
