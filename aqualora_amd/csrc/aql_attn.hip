@@ -403,27 +403,62 @@ __device__ __forceinline__ void attn_block(int& bx, int& h, int& b) {
 // product also yields the softmax denominator sum_j p_ij in accumulator column d -- the 16 packed adds, the two permlane
 // reductions and the running-sum update per row block and tile disappear from the VALU stream, and the denominator is the
 // sum of exactly the bf16 probabilities that multiply V.
-template <int DH, int DV, int NOF, bool ONES>
-__global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const AttnArgs a) {
+// FOLD (round 4, needs ONES): the loop keeps NO running maximum.  The shift of a row is fixed by the FIRST tile (its row maximum) and
+// never updated: later scores above it give probabilities above 1, which fp32 / bf16 carry as well as values below 1, and the
+// accumulator rescale disappears with the update.  What a running maximum guards against is overflow -- a score ~2^127 above the
+// first tile's maximum -- and that is detected at the end (non-finite or zero denominator / output): the workgroup then re-runs the
+// classic pass (tools/probe_ops.py forces it; never seen on the U-Net's data).  Unlike the thresholded rescale tried in round 3,
+// nothing here depends on a data-dependent decision after tile 0.
+//   FOLD = 1 (default):  p = exp2(fma(s, c, -m c)) on PAIRS (v_pk_fma_f32) -- the arithmetic of the classic loop, same precision;
+//                        per streamed element  pk_fma/2 + exp2 + cvt/2  instead of  max3/2 + fma + exp2 + cvt/2 + rescale.
+//   FOLD = 2 (opt-in, AQL_ATTN_FOLD=2; needs a spare K column, d < DH): the shift rides in the S-product -- Q is scaled by
+//                        scale * log2(e) once (bf16), the first padding column of the K tile is 1.0 and the same column of a Q row
+//                        carries -M_row, an INTEGER (exact in bf16; an integer shift scales probabilities, denominator and O by the
+//                        same exact power of two, so the normalised output does not depend on which integer it is).  No FMA at all
+//                        (278 -> 219 us at 8 x 8 x 4096^2 x 40), but the second bf16 rounding of q c costs ~0.0002 |s| log2 units
+//                        in the scores: errors double on typical data and reach 1.7e-2 at |s| ~ 100 (profiles/r04_attention_fold.txt).
+template <int DH, int DV, int NOF, bool ONES, int FOLD>
+__device__ __forceinline__ bool attn_fwd_pass(const AttnArgs& a, char* sK, char* sV, int IMG_, int bx, int h, int b,
+                                              f32x4_t (&o)[DV / 16][NOF], float (&inv)[NOF], float (&lse)[NOF]) {
   constexpr bool DMA = DH > AQL_ATTN_DMA_ABOVE;                      // one workgroup per CU: LDS-DMA into two images, one barrier per tile
   constexpr int IMG = TILE * RowPitch<DH>::value;
-  __shared__ __attribute__((aligned(1024))) char sK[(DMA ? 2 : 1) * IMG];
-  __shared__ __attribute__((aligned(1024))) char sV[(DMA ? 2 : 1) * IMG];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int bx, h, b;
-  attn_block(bx, h, b);
   const int q0 = bx * (64 * NOF) + wave * (16 * NOF);
   const bf16_t* qp = a.q + (long)b * a.Nq * a.ldq + h * a.d;
   const bf16_t* kp = a.k + (long)b * a.Nk * a.ldk + h * a.d;
   const bf16_t* vp = a.v + (long)b * a.Nk * a.ldv + h * a.d;
   bf16x8_t qf[NOF][DH / 32];
   load_owner<DH>(qf, qp, a.ldq, q0, a.Nq, a.d, lane);
-  f32x4_t o[DV / 16][NOF];
+  const float c = a.scale * LOG2E;
+  uint4 cm[DH / 32];   // FOLD = 2: halfword mask of the shift column in this lane's Q fragments
+  if constexpr (FOLD == 2) {
+#pragma unroll
+    for (int fr = 0; fr < NOF; ++fr)
+#pragma unroll
+      for (int ks = 0; ks < DH / 32; ++ks) {
+        uint4 v = *reinterpret_cast<uint4*>(&qf[fr][ks]);
+        v.x = pack_bf16x2(bf16lo(v.x) * c, bf16hi(v.x) * c);
+        v.y = pack_bf16x2(bf16lo(v.y) * c, bf16hi(v.y) * c);
+        v.z = pack_bf16x2(bf16lo(v.z) * c, bf16hi(v.z) * c);
+        v.w = pack_bf16x2(bf16lo(v.w) * c, bf16hi(v.w) * c);
+        qf[fr][ks] = *reinterpret_cast<bf16x8_t*>(&v);
+      }
+    const int e = a.d & 7;
+    const uint32_t hw = (e & 1) ? 0xffff0000u : 0x0000ffffu;
+#pragma unroll
+    for (int ks = 0; ks < DH / 32; ++ks) {
+      const bool mine = (ks == (a.d >> 5)) & ((lane >> 4) == ((a.d & 31) >> 3));
+      const uint32_t mk = mine ? hw : 0u;
+      cm[ks] = make_uint4((e >> 1) == 0 ? mk : 0u, (e >> 1) == 1 ? mk : 0u, (e >> 1) == 2 ? mk : 0u, (e >> 1) == 3 ? mk : 0u);
+    }
+  }
   zero_acc(o);
   float m[NOF], l[NOF];
 #pragma unroll
-  for (int of = 0; of < NOF; ++of) m[of] = -INFINITY, l[of] = 0.f;
-  const float c = a.scale * LOG2E;
+  for (int of = 0; of < NOF; ++of) m[of] = FOLD ? 0.f : -INFINITY, l[of] = 0.f;
+  float mc[NOF];       // FOLD = 1: the row's fixed shift m * c
+#pragma unroll
+  for (int of = 0; of < NOF; ++of) mc[of] = 0.f;
   Stager<DH> stK, stV;
   DmaTile<DH> dmK, dmV;
   if constexpr (DMA) {
@@ -439,12 +474,14 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const
     stK.fetch();
     stV.fetch();
   }
-  if constexpr (ONES) {
+  if constexpr (ONES || FOLD == 2) {
     __syncthreads();  // the padding chunks were zeroed by other threads
     if (tid < TILE) {
 #pragma unroll
-      for (int i = 0; i < (DMA ? 2 : 1); ++i)
-        *reinterpret_cast<bf16_t*>(sV + i * IMG + tile_off<DH>(tid, a.d >> 3) + (a.d & 7) * 2) = (bf16_t)0x3F80;  // 1.0
+      for (int i = 0; i < (DMA ? 2 : 1); ++i) {
+        if constexpr (ONES) *reinterpret_cast<bf16_t*>(sV + i * IMG + tile_off<DH>(tid, a.d >> 3) + (a.d & 7) * 2) = (bf16_t)0x3F80;  // 1.0
+        if constexpr (FOLD == 2) *reinterpret_cast<bf16_t*>(sK + i * IMG + tile_off<DH>(tid, a.d >> 3) + (a.d & 7) * 2) = (bf16_t)0x3F80;
+      }
     }
   }
   if constexpr (DMA) {
@@ -486,35 +523,99 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const
             for (int of = 0; of < NOF; ++of) s[sf][of][e] = -INFINITY;
           }
     }
+    if constexpr (FOLD == 1) {
+      if (kt == 0) {   // the shift: the first tile's row maximum, fixed from here on
 #pragma unroll
-    for (int of = 0; of < NOF; ++of) {
-      float mx = -INFINITY;
+        for (int of = 0; of < NOF; ++of) {
+          float mx = -INFINITY;
 #pragma unroll
-      for (int sf = 0; sf < 4; ++sf)
+          for (int sf = 0; sf < 4; ++sf)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[sf][of][e]);
-      mx = group4_max(mx);
-      // (Deferring the rescale until the maximum grows by 2^8 -- guide T13 -- measured -2...4 % on this kernel, but makes the
-      // bf16 rounding of P depend on a threshold decision: a 1e-7 input perturbation then moves outputs by a bf16 ulp
-      // everywhere instead of nowhere, which the sampler-vs-restatement test (1e-4 over 5 guided steps) rightly rejects.)
-      const float mn = fmaxf(m[of], mx);
-      const float alpha = __builtin_amdgcn_exp2f((m[of] - mn) * c);
-      m[of] = mn;
-      const float mnc = mn * c;
-      float rs = 0.f;
-#pragma unroll
-      for (int sf = 0; sf < 4; ++sf)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sf][of][e], c, -mnc));  // one FMA + one v_exp_f32
-          s[sf][of][e] = p;
-          if constexpr (!ONES) rs += p;
+            for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[sf][of][e]);
+          m[of] = group4_max(mx);
+          mc[of] = m[of] * c;
         }
-      if constexpr (!ONES) l[of] = l[of] * alpha + group4_sum(rs);
+      }
 #pragma unroll
-      for (int df = 0; df < DV / 16; ++df)
+      for (int of = 0; of < NOF; ++of) {
+        const aql_f32x2_t c2 = aql_splat2(c), nm2 = aql_splat2(-mc[of]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[df][of][e] *= alpha;
+        for (int sf = 0; sf < 4; ++sf) {
+          const aql_f32x2_t x0 = __builtin_elementwise_fma(aql_f32x2_t{s[sf][of][0], s[sf][of][1]}, c2, nm2);
+          const aql_f32x2_t x1 = __builtin_elementwise_fma(aql_f32x2_t{s[sf][of][2], s[sf][of][3]}, c2, nm2);
+          s[sf][of][0] = __builtin_amdgcn_exp2f(x0.x);
+          s[sf][of][1] = __builtin_amdgcn_exp2f(x0.y);
+          s[sf][of][2] = __builtin_amdgcn_exp2f(x1.x);
+          s[sf][of][3] = __builtin_amdgcn_exp2f(x1.y);
+        }
+      }
+    } else if constexpr (FOLD == 2) {
+      if (kt == 0) {   // the shift: integer ceiling of the first tile's row maximum (bf16), applied here by hand and from now on by the MFMA
+#pragma unroll
+        for (int of = 0; of < NOF; ++of) {
+          float mx = -INFINITY;
+#pragma unroll
+          for (int sf = 0; sf < 4; ++sf)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[sf][of][e]);
+          mx = group4_max(mx);
+          const uint32_t mb = pack_bf16x2(ceilf(mx), 0.f) & 0xffffu;
+          const float mf = bf16lo(mb);
+          m[of] = mf;
+          const uint32_t neg = (mb ^ 0x8000u) * 0x00010001u;   // -M in both halfwords
+#pragma unroll
+          for (int ks = 0; ks < DH / 32; ++ks) {
+            uint4 v = *reinterpret_cast<uint4*>(&qf[of][ks]);
+            v.x = (v.x & ~cm[ks].x) | (neg & cm[ks].x);
+            v.y = (v.y & ~cm[ks].y) | (neg & cm[ks].y);
+            v.z = (v.z & ~cm[ks].z) | (neg & cm[ks].z);
+            v.w = (v.w & ~cm[ks].w) | (neg & cm[ks].w);
+            qf[of][ks] = *reinterpret_cast<bf16x8_t*>(&v);
+          }
+#pragma unroll
+          for (int sf = 0; sf < 4; ++sf)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[sf][of][e] = __builtin_amdgcn_exp2f(s[sf][of][e] - mf);
+        }
+      } else {
+#pragma unroll
+        for (int of = 0; of < NOF; ++of)
+#pragma unroll
+          for (int sf = 0; sf < 4; ++sf)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[sf][of][e] = __builtin_amdgcn_exp2f(s[sf][of][e]);
+      }
+    } else {
+#pragma unroll
+      for (int of = 0; of < NOF; ++of) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int sf = 0; sf < 4; ++sf)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[sf][of][e]);
+        mx = group4_max(mx);
+        // (Deferring the rescale until the maximum grows by 2^8 -- guide T13 -- measured -2...4 % on this kernel, but makes the
+        // bf16 rounding of P depend on a threshold decision: a 1e-7 input perturbation then moves outputs by a bf16 ulp
+        // everywhere instead of nowhere, which the sampler-vs-restatement test (1e-4 over 5 guided steps) rightly rejects.)
+        const float mn = fmaxf(m[of], mx);
+        const float alpha = __builtin_amdgcn_exp2f((m[of] - mn) * c);
+        m[of] = mn;
+        const float mnc = mn * c;
+        float rs = 0.f;
+#pragma unroll
+        for (int sf = 0; sf < 4; ++sf)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sf][of][e], c, -mnc));  // one FMA + one v_exp_f32
+            s[sf][of][e] = p;
+            if constexpr (!ONES) rs += p;
+          }
+        if constexpr (!ONES) l[of] = l[of] * alpha + group4_sum(rs);
+#pragma unroll
+        for (int df = 0; df < DV / 16; ++df)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[df][of][e] *= alpha;
+      }
     }
     bf16x8_t pb[2][NOF];
     pack_p(pb, s);
@@ -538,15 +639,47 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const
       l[of] = group4_sum(v);
     }
   }
-  float inv[NOF];
+  bool ok = true;
 #pragma unroll
-  for (int of = 0; of < NOF; ++of) inv[of] = 1.f / l[of];
+  for (int of = 0; of < NOF; ++of) {
+    inv[of] = 1.f / l[of];
+    if constexpr (FOLD != 0) {
+      lse[of] = (FOLD == 2 ? m[of] * 0.6931471805599453f : m[of] * a.scale) + logf(l[of]);
+      float big = 0.f;
+#pragma unroll
+      for (int df = 0; df < DV / 16; ++df)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) big = fmaxf(big, fabsf(o[df][of][e]));
+      ok &= (l[of] > 0.f) & (l[of] < INFINITY) & (big < INFINITY);    // NaN fails every comparison
+    } else {
+      lse[of] = m[of] * a.scale + logf(l[of]);
+    }
+  }
+  return ok;
+}
+
+template <int DH, int DV, int NOF, bool ONES, int FOLD = 0>
+__global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const AttnArgs a) {
+  constexpr bool DMA = DH > AQL_ATTN_DMA_ABOVE;
+  constexpr int IMG = TILE * RowPitch<DH>::value;
+  __shared__ __attribute__((aligned(1024))) char sK[(DMA ? 2 : 1) * IMG];
+  __shared__ __attribute__((aligned(1024))) char sV[(DMA ? 2 : 1) * IMG];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int bx, h, b;
+  attn_block(bx, h, b);
+  const int q0 = bx * (64 * NOF) + wave * (16 * NOF);
+  f32x4_t o[DV / 16][NOF];
+  float inv[NOF], lse[NOF];
+  bool ok = attn_fwd_pass<DH, DV, NOF, ONES, FOLD>(a, sK, sV, IMG, bx, h, b, o, inv, lse);
+  if constexpr (FOLD != 0) {
+    if (__syncthreads_or(!ok)) attn_fwd_pass<DH, DV, NOF, ONES, 0>(a, sK, sV, IMG, bx, h, b, o, inv, lse);   // overflow: the classic pass
+  }
   store_t<DV>(o, a.out + (long)b * a.Nq * a.ldo + h * a.d, a.ldo, q0, a.Nq, a.d, inv, lane);
   if ((lane >> 4) == 0) {
 #pragma unroll
     for (int of = 0; of < NOF; ++of) {
       const int row = q0 + of * 16 + (lane & 15);
-      if (row < a.Nq) a.lse[((long)b * a.H + h) * a.Nq + row] = m[of] * a.scale + logf(l[of]);
+      if (row < a.Nq) a.lse[((long)b * a.H + h) * a.Nq + row] = lse[of];
     }
   }
 }
@@ -646,6 +779,8 @@ __global__ __launch_bounds__(256, (DH <= AQL_ATTN_DQ_OCC2_UPTO ? 2 : 1)) void at
     zero_acc(dp);
     s_product<DH>(s, tK, qf, lane);
     s_product<DH>(dp, tV, dof, lane);
+    // (the same arithmetic on pairs -- v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 -- measured SLOWER here and in dK/dV at d = 40:
+    // 433 -> 447 us backward at 4 x 8 x 4096^2 x 40; the pair registers cost more moves than the packed issue saves)
 #pragma unroll
     for (int sf = 0; sf < 4; ++sf)
 #pragma unroll
@@ -1118,6 +1253,31 @@ int launch_fwd(const AttnArgs& a0, hipStream_t st) {
   const AttnArgs& a = a0;
   static const int force = getenv("AQL_ATTN_NOF") ? atoi(getenv("AQL_ATTN_NOF")) : 0;  // tuning hook
   static const int ones = getenv("AQL_ATTN_ONES") ? atoi(getenv("AQL_ATTN_ONES")) : 1;  // tuning hook
+  static const int fold = getenv("AQL_ATTN_FOLD") ? atoi(getenv("AQL_ATTN_FOLD")) : 1;  // A/B hook: 0 = the running-maximum loop, 2 = the shift in the MFMA
+  if constexpr (DH <= 96) {
+    if (fold && ones && a.d < DV) {   // the denominator rides in the P.V product: the loop needs no row statistics after its first tile
+      const bool big = DH <= 64 && (force == 4 || (force == 0 && a.Nq >= 2048 && (long)aql_cdiv(a.Nq, 256) * a.H * a.B >= 512));
+      const dim3 g4(aql_cdiv(a.Nq, 256), a.H, a.B), g2(aql_cdiv(a.Nq, 128), a.H, a.B);
+      if (fold == 2 && a.d < DH) {
+        if constexpr (DH <= 64) {
+          if (big) {
+            hipLaunchKernelGGL((attn_fwd_kernel<DH, DV, 4, true, 2>), g4, dim3(256), 0, st, a);
+            return 0;
+          }
+        }
+        hipLaunchKernelGGL((attn_fwd_kernel<DH, DV, 2, true, 2>), g2, dim3(256), 0, st, a);
+        return 0;
+      }
+      if constexpr (DH <= 64 && DV <= 48) {   // (64 rows per wavefront at DV = 64 would spill two registers: no head of the U-Net needs it)
+        if (big) {
+          hipLaunchKernelGGL((attn_fwd_kernel<DH, DV, 4, true, 1>), g4, dim3(256), 0, st, a);
+          return 0;
+        }
+      }
+      hipLaunchKernelGGL((attn_fwd_kernel<DH, DV, 2, true, 1>), g2, dim3(256), 0, st, a);
+      return 0;
+    }
+  }
   if constexpr (DH <= 64) {
     // 64 rows per wavefront only while that still gives two workgroups per CU (one guided image = 2 x 8 heads x 16 row blocks = 256
     // workgroups of 256 rows: 97 us, against 93.5 us as 512 workgroups of 128 rows; a single sample 89 vs 62 us)

@@ -70,7 +70,7 @@ def test_geglu_epilogue_on_the_256x256_tile_vs_fp32():
 
 def test_ops_parity():
     text = _run("probe_ops.py")
-    assert text.count("PASS") >= 76   # incl. attention at 9216 / 6336 tokens (768 px and non-square rob-finetune samples)
+    assert text.count("PASS") >= 93   # incl. the shift-in-the-MFMA forward under late spikes (fast path and overflow fallback), attention at 9216 / 6336 tokens (768 px and non-square rob-finetune samples)
 
 
 def test_transpose_read_weight_gradient_gemm():

@@ -76,6 +76,25 @@ for (B, H, Nq, Nk, d) in [(2, 8, 256, 256, 40), (1, 8, 1024, 1024, 80), (2, 8, 6
 q = rnd(1, 256, 320); k = rnd(1, 256, 320); v = rnd(1, 256, 320)
 k[0, 200, :40] = q[0, 5, :40] * 20
 report("attn fwd spike", relerr(ops.attention(q, k, v, 8), attn_ref(q.float(), k.float(), v.float(), 8)), 1.5e-2)
+# the shift-in-the-MFMA forward (round 4): a late key far above the first tile's maximum.  x3 stays on the fast path (probabilities up
+# to ~2^25 against the first tile's integer shift), x20 overflows fp32 and must take the classic pass; both through backward (lse),
+# at d = 40 (register-staged tiles) and d = 80 (LDS-DMA tiles), and a row block whose scores all sit far below zero
+for d, H, mult in ((40, 8, 3.0), (40, 8, 20.0), (80, 4, 3.0), (80, 4, 20.0)):
+    q = rnd(2, 512, H * d).requires_grad_(True); k = rnd(2, 512, H * d); v = rnd(2, 512, H * d).requires_grad_(True)
+    with torch.no_grad():
+        k[0, 300, :d] = q[0, 5, :d] * mult
+        k[1, 70, d:2 * d] = q[1, 400, d:2 * d] * mult
+        q[1, 100:164] -= 0    # placeholder rows: plain
+    k = k.requires_grad_(True)
+    o = ops.attention(q, k, v, H)
+    qr, kr, vr = [t.detach().float().requires_grad_(True) for t in (q, k, v)]
+    orf = attn_ref(qr, kr, vr, H)
+    report(f"attn fwd late spike x{mult:g} d{d}", relerr(o, orf), 1.5e-2)
+    do = rnd(2, 512, H * d); o.backward(do); orf.backward(do.float())
+    report("attn dq", relerr(q.grad, qr.grad), 2e-2); report("attn dk", relerr(k.grad, kr.grad), 2e-2); report("attn dv", relerr(v.grad, vr.grad), 2e-2)
+q = rnd(1, 256, 320); k = rnd(1, 256, 320); v = rnd(1, 256, 320)
+q[0, :, :40] = 6.0; k[0, :, :40] = -6.0 + 0.1 * torch.randn(256, 40, device=dev).to(k.dtype)     # head 0: every score ~ -1440 * scale
+report("attn fwd all scores far below zero", relerr(ops.attention(q, k, v, 8), attn_ref(q.float(), k.float(), v.float(), 8)), 1.5e-2)
 # fused LoRA linear fwd/bwd
 class Site: pass
 for (B, N, K, Nout, r) in [(2, 256, 320, 320, 32), (2, 77, 768, 640, 8), (2, 64, 1280, 10240, 32), (1, 1024, 320, 320, 320),
