@@ -688,7 +688,11 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const
 #ifndef AQL_ATTN_DQ_OCC2_UPTO
 #define AQL_ATTN_DQ_OCC2_UPTO 96   // head sizes up to this are compiled for two workgroups per CU (d = 80: 284 -> 250 registers, no spill; 80.1 -> 78.5 us backward at 4 x 1024 x 8 x 80)
 #endif
-template <int DH, int DV>
+// DFOLD (round 4; needs two spare head columns, d < DH): `dP - delta` comes out of the dP product.  delta is constant along a query row,
+// so -delta rides as a (hi, lo) bf16 pair in the first two padding columns of the row's dO fragment against two columns of 1.0 in the
+// streamed V tile: the fp32 accumulation adds it exactly, delta is represented to 2^-17, and one of the five VALU operations per
+// element leaves the loop.
+template <int DH, int DV, bool DFOLD = false>
 __global__ __launch_bounds__(256, (DH <= AQL_ATTN_DQ_OCC2_UPTO ? 2 : 1)) void attn_dq_kernel(const AttnArgs a) {
   constexpr bool DMA = DH > AQL_ATTN_DMA_ABOVE;   // see attn_fwd_kernel / DmaTile
   constexpr int IMG = TILE * RowPitch<DH>::value;
@@ -731,6 +735,21 @@ __global__ __launch_bounds__(256, (DH <= AQL_ATTN_DQ_OCC2_UPTO ? 2 : 1)) void at
     lse2[of] = ok ? a.lse[((long)b * a.H + h) * a.Nq + row] * LOG2E : INFINITY;
     if (ok && (lane >> 4) == 0) a.delta[((long)b * a.H + h) * a.Nq + row] = dl[of];
   }
+  if constexpr (DFOLD) {   // columns d, d + 1 of the row's dO fragment: (-delta_hi, -delta_lo); d % 8 == 0: word 0 of chunk d / 8
+#pragma unroll
+    for (int of = 0; of < 2; ++of) {
+      const uint32_t hi = pack_bf16x2(dl[of], 0.f) & 0xffffu;
+      const uint32_t lo = pack_bf16x2(dl[of] - bf16lo(hi), 0.f) & 0xffffu;
+      const uint32_t word = (hi ^ 0x8000u) | ((lo ^ 0x8000u) << 16);
+#pragma unroll
+      for (int ks = 0; ks < DH / 32; ++ks)
+        if (ks == (a.d >> 5) && (lane >> 4) == ((a.d & 31) >> 3)) {
+          uint4 v = *reinterpret_cast<uint4*>(&dof[of][ks]);
+          v.x = word;
+          dof[of][ks] = *reinterpret_cast<bf16x8_t*>(&v);
+        }
+    }
+  }
   f32x4_t dq[DV / 16][2];
   zero_acc(dq);
   const float c = a.scale * LOG2E;
@@ -741,6 +760,13 @@ __global__ __launch_bounds__(256, (DH <= AQL_ATTN_DQ_OCC2_UPTO ? 2 : 1)) void at
     dmV.init(vp, a.ldv, a.Nk, a.d, wave, lane);
     DmaTile<DH>::pad(sK, 2, a.d, tid);
     DmaTile<DH>::pad(sV, 2, a.d, tid);
+    if constexpr (DFOLD) {
+      __syncthreads();   // the padding chunks were zeroed by other threads
+      if (tid < TILE) {
+        *reinterpret_cast<uint32_t*>(sV + tile_off<DH>(tid, a.d >> 3)) = 0x3F803F80u;         // 1.0 | 1.0
+        *reinterpret_cast<uint32_t*>(sV + IMG + tile_off<DH>(tid, a.d >> 3)) = 0x3F803F80u;
+      }
+    }
     dmK.issue(sK, 0);
     dmV.issue(sV, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -748,6 +774,10 @@ __global__ __launch_bounds__(256, (DH <= AQL_ATTN_DQ_OCC2_UPTO ? 2 : 1)) void at
   } else {
     stK.init(sK, kp, a.ldk, 0, a.Nk, a.d, tid);
     stV.init(sV, vp, a.ldv, 0, a.Nk, a.d, tid);
+    if constexpr (DFOLD) {
+      __syncthreads();   // the padding chunks were zeroed by other threads; they are never overwritten afterwards
+      if (tid < TILE) *reinterpret_cast<uint32_t*>(sV + tile_off<DH>(tid, a.d >> 3)) = 0x3F803F80u;
+    }
     stK.fetch();
     stV.fetch();
   }
@@ -788,7 +818,7 @@ __global__ __launch_bounds__(256, (DH <= AQL_ATTN_DQ_OCC2_UPTO ? 2 : 1)) void at
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sf][of][e], c, -lse2[of]));
-          s[sf][of][e] = p * (dp[sf][of][e] - dl[of]);
+          s[sf][of][e] = DFOLD ? p * dp[sf][of][e] : p * (dp[sf][of][e] - dl[of]);
         }
     if (kt + TILE > a.Nk) {  // last, partial tile: its padding rows repeat the last key row -> drop them
 #pragma unroll
@@ -812,7 +842,9 @@ __global__ __launch_bounds__(256, (DH <= AQL_ATTN_DQ_OCC2_UPTO ? 2 : 1)) void at
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <int DH, int DV>
+// DFOLD: as in attn_dq_kernel, mirrored -- here the dO rows are the streamed side: (-delta_hi, -delta_lo) of a row go into the two
+// padding columns of its row in the dO tile (written with the tile's row statistics), the owner V fragments carry 1.0 there.
+template <int DH, int DV, bool DFOLD = false>
 __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dkv_kernel(const AttnArgs a) {
   constexpr bool DMA = DH > AQL_ATTN_DMA_ABOVE;   // see attn_fwd_kernel / DmaTile
   constexpr int IMG = TILE * RowPitch<DH>::value, NIMG = DMA ? 2 : 1;
@@ -837,6 +869,17 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dkv_kernel(const
   bf16x8_t kf[2][DH / 32], vf[2][DH / 32];
   load_owner<DH>(kf, kp, a.ldk, k0, a.Nk, a.d, lane);
   load_owner<DH>(vf, vp, a.ldv, k0, a.Nk, a.d, lane);
+  if constexpr (DFOLD) {
+#pragma unroll
+    for (int of = 0; of < 2; ++of)
+#pragma unroll
+      for (int ks = 0; ks < DH / 32; ++ks)
+        if (ks == (a.d >> 5) && (lane >> 4) == ((a.d & 31) >> 3)) {
+          uint4 v = *reinterpret_cast<uint4*>(&vf[of][ks]);
+          v.x = 0x3F803F80u;   // columns d, d + 1 = 1.0
+          vf[of][ks] = *reinterpret_cast<bf16x8_t*>(&v);
+        }
+  }
   f32x4_t dk[DV / 16][2], dv[DV / 16][2];
   zero_acc(dk);
   zero_acc(dv);
@@ -857,7 +900,13 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dkv_kernel(const
     if (tid < TILE) {
       const bool ok = (qt + tid) < a.Nq;   // rows past the end: p = exp2(s - inf) = 0
       sLse[img * TILE + tid] = ok ? lse_r * LOG2E : INFINITY;
-      sDelta[img * TILE + tid] = ok ? delta_r : 0.f;
+      if constexpr (DFOLD) {
+        const uint32_t hi = pack_bf16x2(delta_r, 0.f) & 0xffffu;
+        const uint32_t lo = pack_bf16x2(delta_r - bf16lo(hi), 0.f) & 0xffffu;
+        *reinterpret_cast<uint32_t*>(sdO + img * IMG + tile_off<DH>(tid, a.d >> 3)) = ok ? ((hi ^ 0x8000u) | ((lo ^ 0x8000u) << 16)) : 0u;
+      } else {
+        sDelta[img * TILE + tid] = ok ? delta_r : 0.f;
+      }
     }
   };
   if constexpr (DMA) {
@@ -865,6 +914,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dkv_kernel(const
     dmO.init(dop, a.ldo, a.Nq, a.d, wave, lane);
     DmaTile<DH>::pad(sQ, 2, a.d, tid);
     DmaTile<DH>::pad(sdO, 2, a.d, tid);
+    if constexpr (DFOLD) __syncthreads();   // put_stats writes into padding chunks that other threads have just zeroed
     if (qt_lo < qt_hi) {
       dmQ.issue(sQ, qt_lo);
       dmO.issue(sdO, qt_lo);
@@ -917,7 +967,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dkv_kernel(const
 #pragma unroll
     for (int sf = 0; sf < 4; ++sf) {
       const float4 ls = *reinterpret_cast<const float4*>(&sLse[cur * TILE + sf * 16 + (lane >> 4) * 4]);
-      const float4 de = *reinterpret_cast<const float4*>(&sDelta[cur * TILE + sf * 16 + (lane >> 4) * 4]);
+      const float4 de = DFOLD ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(&sDelta[cur * TILE + sf * 16 + (lane >> 4) * 4]);
       const float lsv[4] = {ls.x, ls.y, ls.z, ls.w};
       const float dev[4] = {de.x, de.y, de.z, de.w};
 #pragma unroll
@@ -926,7 +976,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dkv_kernel(const
         for (int e = 0; e < 4; ++e) {
           const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sf][of][e], c, -lsv[e]));
           s[sf][of][e] = p;
-          ds[sf][of][e] = p * (dp[sf][of][e] - dev[e]);
+          ds[sf][of][e] = DFOLD ? p * dp[sf][of][e] : p * (dp[sf][of][e] - dev[e]);
         }
     }
     bf16x8_t pb[2][2];
@@ -1298,14 +1348,22 @@ int launch_fwd(const AttnArgs& a0, hipStream_t st) {
 }
 template <int DH, int DV>
 int launch_bwd(const AttnArgs& a, hipStream_t st) {
+  static const int dfold_on = getenv("AQL_ATTN_DFOLD") ? atoi(getenv("AQL_ATTN_DFOLD")) : 1;   // A/B hook: 0 = subtract delta per element
+  const bool dfold = DH <= 96 && dfold_on && a.d < DH;   // two spare head columns (d % 8 == 0)
   if (ctx_on(a)) {
     AttnArgs c = a;
     c.qsplit = ctx_blocks(a, CtxNB<DH>::bwd);
     hipLaunchKernelGGL((attn_ctx_dq_kernel<DH, DV>), dim3(aql_cdiv(a.Nq, 4 * OWN * c.qsplit), a.H, a.B), dim3(256), 0, st, c);
+  } else if (dfold) {
+    if constexpr (DH <= 96) hipLaunchKernelGGL((attn_dq_kernel<DH, DV, true>), dim3(aql_cdiv(a.Nq, 4 * OWN), a.H, a.B), dim3(256), 0, st, a);
   } else {
     hipLaunchKernelGGL((attn_dq_kernel<DH, DV>), dim3(aql_cdiv(a.Nq, 4 * OWN), a.H, a.B), dim3(256), 0, st, a);
   }
-  hipLaunchKernelGGL((attn_dkv_kernel<DH, DV>), dim3(aql_cdiv(a.Nk, 4 * OWN), a.H, a.B * a.qsplit), dim3(256), 0, st, a);
+  if (dfold) {
+    if constexpr (DH <= 96) hipLaunchKernelGGL((attn_dkv_kernel<DH, DV, true>), dim3(aql_cdiv(a.Nk, 4 * OWN), a.H, a.B * a.qsplit), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((attn_dkv_kernel<DH, DV>), dim3(aql_cdiv(a.Nk, 4 * OWN), a.H, a.B * a.qsplit), dim3(256), 0, st, a);
+  }
   if (a.qsplit > 1) {
     const long n = 2L * a.B * a.H * a.Nk * (a.d / 4);
     hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
