@@ -409,7 +409,7 @@ __device__ __forceinline__ void attn_block(int& bx, int& h, int& b) {
 // first tile's maximum -- and that is detected at the end (non-finite or zero denominator / output): the workgroup then re-runs the
 // classic pass (tools/probe_ops.py forces it; never seen on the U-Net's data).  Unlike the thresholded rescale tried in round 3,
 // nothing here depends on a data-dependent decision after tile 0.
-//   FOLD = 1 (default):  p = exp2(fma(s, c, -m c)) on PAIRS (v_pk_fma_f32) -- the arithmetic of the classic loop, same precision;
+//   FOLD = 1 (default):  p = exp2(fma(s, c, -m c)) on pairs (v_pk_fma_f32; measured equal to the scalar FMA: fp32 FMA already issues 32 lanes per clock) -- the arithmetic of the classic loop, same precision;
 //                        per streamed element  pk_fma/2 + exp2 + cvt/2  instead of  max3/2 + fma + exp2 + cvt/2 + rescale.
 //   FOLD = 2 (opt-in, AQL_ATTN_FOLD=2; needs a spare K column, d < DH): the shift rides in the S-product -- Q is scaled by
 //                        scale * log2(e) once (bf16), the first padding column of the K tile is 1.0 and the same column of a Q row
