@@ -57,9 +57,15 @@ struct RowCfg {
   static constexpr int ABUF = A_INSTR * 32 * 128;
 };
 
-template <int RW, int TROWS, bool FLIP, bool SLAB>
+// BN = output columns per tile: 160 (the U-Net: every channel count is a multiple of 160) or 128 (the VAE: 128 / 256 / 512 channels;
+// on 160-wide tiles a fifth of the MFMAs and weight loads would be padding).  Everything below derives from it.
+// WI = image width when a tile is a PART of an image row (WI = 512 on RW = 256-pixel tiles, TROWS = 1): the tile's two halo columns are
+// then the neighbouring half's pixels, not padding.
+template <int RW, int TROWS, bool FLIP, bool SLAB, int BN = 160, int WI = RW>
 __global__ __launch_bounds__((RowCfg<RW, TROWS, FLIP>::THREADS)) void conv_row_kernel(const RowArgs g) {
+  static_assert(WI == RW || (TROWS == 1 && WI % RW == 0), "a partial-row tile is one image row high");
   using CFG = RowCfg<RW, TROWS, FLIP>;
+  constexpr int CR_BN = BN, CR_WN = BN / 2, WST = BN * 128, NW = BN / 32;   // shadow the 160-wide defaults of the namespace
   constexpr int CR_BM = CFG::BM, NCW = CFG::NCW, CR_THREADS = CFG::THREADS, APX = CFG::APX, A_INSTR = CFG::A_INSTR, ABUF = CFG::ABUF;
   constexpr int P1 = CFG::P1;
   constexpr int FM = CR_WM / 16, FN = CR_WN / 16;
@@ -111,7 +117,7 @@ __global__ __launch_bounds__((RowCfg<RW, TROWS, FLIP>::THREADS)) void conv_row_k
   if (loader) {
     const int lw = wave - NCW;
     const int ltid = tid - NCW * 64;
-    const int b = m0 / (H * RW), h0 = (m0 - b * H * RW) / RW;
+    const int b = m0 / (H * WI), h0 = (m0 - b * H * WI) / WI, x0 = m0 - (b * H + h0) * WI;   // x0 = 0 unless WI > RW
     __amdgpu_buffer_rsrc_t rsx = make_rsrc(g.x), rsw = make_rsrc(g.w.base);
     // A tile: instruction j stages pixel rows 32 j .. 32 j + 31; this lane: row 32 j + (ltid >> 3), 16-byte slot ltid & 7
     uint32_t abase[A_INSTR];
@@ -121,9 +127,9 @@ __global__ __launch_bounds__((RowCfg<RW, TROWS, FLIP>::THREADS)) void conv_row_k
       const int p = 32 * j + (ltid >> 3);
       const int r = p / (RW + 2), wc = p - r * (RW + 2) - 1;
       const int kc = ((ltid & 7) ^ a_swz(p)) * 8;
-      const bool okc = (p < APX) & (wc >= 0) & (wc < RW);
+      const bool okc = (p < APX) & (x0 + wc >= 0) & (x0 + wc < WI);
       arh[j] = okc ? h0 + r - 1 : -(1 << 20);
-      abase[j] = (uint32_t)((((long)b * H + (h0 + r - 1)) * RW + wc) * Cin + kc) * 2u;
+      abase[j] = (uint32_t)((((long)b * H + (h0 + r - 1)) * WI + x0 + wc) * Cin + kc) * 2u;
     }
     uint32_t wv[CR_BN / 32];
 #pragma unroll
@@ -135,7 +141,7 @@ __global__ __launch_bounds__((RowCfg<RW, TROWS, FLIP>::THREADS)) void conv_row_k
     auto issueA = [&](int gi, int lo, int hi) {   // group gi = kh * nslab + c; instructions [lo, hi)
       const int kh = gi / nslab, c = gi - kh * nslab;
       const int khe = FLIP ? 2 - kh : kh;          // image-row offset of the tap, plus one
-      const uint32_t add = (uint32_t)((khe * RW * Cin + c * 64) * 2);
+      const uint32_t add = (uint32_t)((khe * WI * Cin + c * 64) * 2);
       char* dst = abuf + (gi & 1) * ABUF;
       const bool live = gi < NG;
 #pragma unroll
@@ -278,11 +284,11 @@ __global__ __launch_bounds__((RowCfg<RW, TROWS, FLIP>::THREADS)) void conv_row_k
   epi_store_tile<CR_BM, CR_BN, C_PITCH, CR_THREADS>(lds, m0, n0, g.M, g.N, ep, tid);
 }
 
-template <int RW, int TROWS, bool FLIP, bool SLAB>
+template <int RW, int TROWS, bool FLIP, bool SLAB, int BN = 160, int WI = RW>
 inline void launch_conv_row(const RowArgs& a, hipStream_t stream) {
   using CFG = RowCfg<RW, TROWS, FLIP>;
-  dim3 grid((a.M / CFG::BM) * aql_cdiv(a.N, CR_BN), 1, a.splits);
-  hipLaunchKernelGGL((conv_row_kernel<RW, TROWS, FLIP, SLAB>), grid, dim3(CFG::THREADS), 0, stream, a);
+  dim3 grid((a.M / CFG::BM) * aql_cdiv(a.N, BN), 1, a.splits);
+  hipLaunchKernelGGL((conv_row_kernel<RW, TROWS, FLIP, SLAB, BN, WI>), grid, dim3(CFG::THREADS), 0, stream, a);
 }
 
 // bm = 256 or 128 (the tile height the picker chose).  Returns false when the convolution does not fit a row tile.
@@ -305,7 +311,14 @@ inline bool try_conv_row(const GemmArgs<LA, PlainLoader>& g, int bm, hipStream_t
   static const int row32x8 = getenv("AQL_CONV_ROW_32X8") ? atoi(getenv("AQL_CONV_ROW_32X8")) : 1;   // A/B hook
   RowArgs a;
   a.x = l.base, a.H = H, a.C = C, a.w = g.b0, a.M = g.M, a.N = g.N, a.m_fast = g.m_fast, a.splits = g.splits, a.epi = g.epi;
-  if (bm == 256 && W == 64 && H % 4 == 0) launch_conv_row<64, 4, FLIP, SLAB>(a, stream);
+  const bool n128 = g.N % 128 == 0 && g.N % 160 != 0;    // the VAE's channel counts
+  if (bm == 256 && W == 512 && n128) launch_conv_row<256, 1, FLIP, SLAB, 128, 512>(a, stream);   // the VAE's 512-pixel rows as two half-row tiles
+  else if (bm == 256 && W == 256 && n128) launch_conv_row<256, 1, FLIP, SLAB, 128>(a, stream);    // the VAE's 256- and 128-pixel-wide maps
+  else if (bm == 256 && W == 256) launch_conv_row<256, 1, FLIP, SLAB>(a, stream);
+  else if (bm == 256 && W == 128 && H % 2 == 0 && n128) launch_conv_row<128, 2, FLIP, SLAB, 128>(a, stream);
+  else if (bm == 256 && W == 128 && H % 2 == 0) launch_conv_row<128, 2, FLIP, SLAB>(a, stream);
+  else if (bm == 256 && W == 64 && H % 4 == 0 && n128) launch_conv_row<64, 4, FLIP, SLAB, 128>(a, stream);
+  else if (bm == 256 && W == 64 && H % 4 == 0) launch_conv_row<64, 4, FLIP, SLAB>(a, stream);
   else if (bm == 256 && W == 32 && H % 8 == 0 && row32x8) launch_conv_row<32, 8, FLIP, SLAB>(a, stream);
   else if (bm == 128 && W == 64 && H % 2 == 0) launch_conv_row<64, 2, FLIP, SLAB>(a, stream);
   else if (bm == 128 && W == 32 && H % 4 == 0) launch_conv_row<32, 4, FLIP, SLAB>(a, stream);

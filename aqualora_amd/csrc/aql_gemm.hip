@@ -194,7 +194,10 @@ void launch_cfg(int cfg, int pd, const GemmArgs<LA, LB>& g, hipStream_t stream) 
       const int t256 = (g.M / 256) * aql_cdiv(g.N, 160);
       const bool r256 = cfg == P_W256x160 || (std::is_same<LA, ConvFwdLoader>::value && g.M % 256 == 0 && t256 % 256 == 0 &&
                                               t256 / 256 <= conv_row_rounds);
-      if (conv_row && r256 && aqlconvrow::try_conv_row<LA, EPI>(g, 256, stream)) return;
+      // the VAE's wide maps (128 / 256 pixels per row, 128-multiples of channels): many rounds of 256-pixel row tiles (AQL_CONV_ROW_WIDE=0: off)
+      static const int conv_row_wide = env_int("AQL_CONV_ROW_WIDE", 1);
+      const bool wide = conv_row_wide && g.splits == 1 && g.M % 256 == 0 && (g.a0.Win == 128 || g.a0.Win == 256 || (g.a0.Win == 512 && g.N % 128 == 0 && g.N % 160 != 0)) && g.M / 256 >= 256;
+      if (conv_row && (r256 || wide) && aqlconvrow::try_conv_row<LA, EPI>(g, 256, stream)) return;
       if (conv_row == 1 && cfg == P_W128x160 && g.M % 128 == 0 && aqlconvrow::try_conv_row<LA, EPI>(g, 128, stream)) return;
     }
 #ifdef AQL_T256
