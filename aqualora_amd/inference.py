@@ -80,7 +80,9 @@ def _cfg_scale(scale, B):
 
 def _weights_key(unet):
     """Serial numbers of the packed weight copies the U-Net currently runs on (0 = not packed yet)."""
-    return tuple(getattr(getattr(m, "_aql_packed", None), "serial", 0) for m in unet.modules() if isinstance(m, (torch.nn.Linear, torch.nn.Conv2d)))
+    cat = getattr(unet, "_aql_temb_cat", None)      # the 22 time projections as one packed GEMM (UNet._all_time_projections)
+    return (getattr(cat[0], "serial", 0) if cat else 0,) + tuple(
+        getattr(getattr(m, "_aql_packed", None), "serial", 0) for m in unet.modules() if isinstance(m, (torch.nn.Linear, torch.nn.Conv2d)))
 
 
 class _GuidedLoop:
