@@ -73,6 +73,14 @@ def test_ops_parity():
     assert text.count("PASS") >= 93   # incl. the shift-in-the-MFMA forward under late spikes (fast path and overflow fallback), attention at 9216 / 6336 tokens (768 px and non-square rob-finetune samples)
 
 
+@pytest.mark.parametrize("env", [{"AQL_ATTN_FOLD": "0", "AQL_ATTN_DFOLD": "0"}, {"AQL_ATTN_FOLD": "2"}])
+def test_ops_parity_on_the_other_attention_loops(env):
+    """The running-maximum forward (also the overflow fallback of the default loop) with the per-element `dP - delta` backward, and
+    the opt-in forward with the shift inside the S-product: the same sweep as test_ops_parity."""
+    text = _run("probe_ops.py", env)
+    assert text.count("PASS") >= 93
+
+
 def test_transpose_read_weight_gradient_gemm():
     """aql_gemm_tn_tr_f32 (wide 128x128 and rank <= 32 128x32 tiles, swapped / transposed output, ragged M, P, Q, strided
     operands) against fp32 torch."""

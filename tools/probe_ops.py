@@ -89,9 +89,13 @@ for d, H, mult in ((40, 8, 3.0), (40, 8, 20.0), (80, 4, 3.0), (80, 4, 20.0)):
     o = ops.attention(q, k, v, H)
     qr, kr, vr = [t.detach().float().requires_grad_(True) for t in (q, k, v)]
     orf = attn_ref(qr, kr, vr, H)
-    report(f"attn fwd late spike x{mult:g} d{d}", relerr(o, orf), 1.5e-2)
+    # AQL_ATTN_FOLD=2 (opt-in: the shift inside the S-product) pays a second bf16 rounding of q * scale: ~0.0002 |s| log2 units,
+    # visible only at |s| ~ 100 (profiles/r04_attention_fold.txt) -- its bounds under the x20 spike are wider
+    loose = os.environ.get("AQL_ATTN_FOLD") == "2" and mult >= 20
+    report(f"attn fwd late spike x{mult:g} d{d}", relerr(o, orf), 3e-2 if loose else 1.5e-2)
     do = rnd(2, 512, H * d); o.backward(do); orf.backward(do.float())
-    report("attn dq", relerr(q.grad, qr.grad), 2e-2); report("attn dk", relerr(k.grad, kr.grad), 2e-2); report("attn dv", relerr(v.grad, vr.grad), 2e-2)
+    gt = 8e-2 if loose else 2e-2
+    report("attn dq", relerr(q.grad, qr.grad), gt); report("attn dk", relerr(k.grad, kr.grad), gt); report("attn dv", relerr(v.grad, vr.grad), gt)
 q = rnd(1, 256, 320); k = rnd(1, 256, 320); v = rnd(1, 256, 320)
 q[0, :, :40] = 6.0; k[0, :, :40] = -6.0 + 0.1 * torch.randn(256, 40, device=dev).to(k.dtype)     # head 0: every score ~ -1440 * scale
 report("attn fwd all scores far below zero", relerr(ops.attention(q, k, v, 8), attn_ref(q.float(), k.float(), v.float(), 8)), 1.5e-2)
