@@ -88,6 +88,13 @@ def conv_case(Bn, H, W, Cin, Cout, stride, ups):
 conv_case(2, 16, 16, 64, 128, 1, 0)
 conv_case(2, 16, 12, 32, 64, 2, 0)
 conv_case(1, 8, 8, 64, 64, 1, 1)
+# the VAE's maps on row tiles (round 4): 128- / 256-pixel rows, 512-pixel rows as two half-row tiles (real halo columns), 128-wide column
+# tiles, forward and backward-data; batch > 1 so that tile rows cross image boundaries; a non-square map
+# (the picker takes them from 256 row tiles on: >= 65536 output pixels)
+conv_case(4, 128, 128, 64, 128, 1, 0)
+conv_case(2, 128, 256, 128, 256, 1, 0)
+conv_case(2, 64, 512, 128, 128, 1, 0)
+conv_case(4, 128, 128, 128, 320, 1, 0)
 conv_case(2, 8, 8, 1280, 1280, 1, 0)
 conv_case(1, 64, 64, 8, 320, 1, 0)
 # 64-pixel-wide stride-1 maps with Cin % 64 == 0: the row-tile kernel (aql_conv_row.cuh) whenever the 256x160 tile is chosen -- forced
