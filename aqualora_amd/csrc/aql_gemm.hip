@@ -257,9 +257,11 @@ inline void pick_tile(long M, int N, int kt_total, bool can_split, int* cfg, int
   if (N % 160 == 0) {
     const int nt = N / 160;
     const int t128 = aql_cdiv(M, 128) * nt, t64 = aql_cdiv(M, 64) * nt, t32 = aql_cdiv(M, 32) * nt;
+    // (round 4, tools/cmp_vendor.py GEMM_SHAPES sweep on the guided-sampling shapes: 512 x 3840 x 1280 runs 19.5 us on 192 tiles of
+    // 64 x 160 against 29.0 on 384 of 32 x 160; 512 x 1280 x 1280 13.2 us on 160 tiles of 64 x 64 against 16.3 on 128 of 32 x 160)
     if (t128 >= 448 || (deep && t64 < 448)) *cfg = P_128x160, *tiles = t128;
-    else if (t64 >= 200) *cfg = P_64x160, *tiles = t64;
-    else if (t32 >= 128) *cfg = P_32x160, *tiles = t32;
+    else if (t64 >= 160) *cfg = P_64x160, *tiles = t64;
+    else if (t32 >= 192) *cfg = P_32x160, *tiles = t32;
     else *cfg = P_64x64, *tiles = aql_cdiv(M, 64) * aql_cdiv(N, 64);
     // wave-specialised kernels (one 8-wave workgroup per CU): they win when the grid is a whole number of chip-wide
     // rounds and K is long enough to amortise the un-overlapped prologue / epilogue (measured, tools/tune_gemm.py)
@@ -268,7 +270,7 @@ inline void pick_tile(long M, int N, int kt_total, bool can_split, int* cfg, int
       if (t128 >= 240 && t128 <= 768) *cfg = P_W128x160, *tiles = t128;
       else if (deep && t128 < 240 && use_w != 3) *cfg = P_W128x160, *tiles = t128;  // split K up to one chip-wide round
       else if (t128 < 240 && t64 >= 240 && t64 <= 512) *cfg = P_W64x160, *tiles = t64;
-      else if (t64 < 240 && t32 >= 240 && t32 <= 512) *cfg = P_W32x160, *tiles = t32;
+      else if (t64 < 160 && t32 >= 240 && t32 <= 512) *cfg = P_W32x160, *tiles = t32;
     }
     if (force >= P_128x160 && force <= P_32x160) {
       *cfg = force;
