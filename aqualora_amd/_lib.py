@@ -54,6 +54,8 @@ SIGNATURES = {
     "aql_groupnorm_silu_bwd": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p],
     "aql_layernorm_fwd": [c_p, c_l, c_i, c_p, c_p, c_f, c_p, c_p, c_p],
     "aql_layernorm_bwd": [c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p],
+    # X ldx M rps row0 S nstage | W ldw bias Adown Bup T Ts res ldr out ldo keep ln gamma beta eps stats nout ldn nout_row0 | stream
+    "aql_lora_chain_fwd": [c_p, c_l, c_l, c_i, c_l, c_p, c_i] + [c_p] * 20 + [c_p],
     "aql_geglu_fwd": [c_p, c_l, c_i, c_p, c_p],
     "aql_geglu_bwd": [c_p, c_p, c_l, c_i, c_p, c_p],
     "aql_upsample2x_bwd": [c_p, c_i, c_i, c_i, c_i, c_p, c_p],

@@ -600,6 +600,26 @@ def _lora_gemm_fused(x2d, w, a16, S16, rps, b16, bias, residual, T, Ts, y=None, 
     return y
 
 
+def chain_fwd(x, ldx, M, rps, row0, S16, stages):
+    """aql_lora_chain_fwd: a row-resident chain of 320 -> 320 LoRA linears (csrc/aql_chain.hip).  ``stages``: list of dicts with the
+    keys  W ldw bias Ad Bup T Ts res ldr out ldo keep ln gamma beta eps stats nout ldn nout_row0  (tensors or None; missing = None / 0)."""
+    import ctypes
+    n = len(stages)
+    vp, lp_, ip, fp = ctypes.c_void_p * n, ctypes.c_long * n, ctypes.c_int * n, ctypes.c_float * n
+
+    def ptrs(key):
+        return vp(*[(None if st.get(key) is None else st[key].data_ptr()) for st in stages])
+
+    def longs(key):
+        return lp_(*[int(st.get(key) or 0) for st in stages])
+
+    L.call("aql_lora_chain_fwd", L.ptr(x), int(ldx), int(M), int(rps), int(row0), L.ptr(S16), n,
+           ptrs("W"), longs("ldw"), ptrs("bias"), ptrs("Ad"), ptrs("Bup"), ptrs("T"), ptrs("Ts"), ptrs("res"), longs("ldr"),
+           ptrs("out"), longs("ldo"), ip(*[int(st.get("keep") or 0) for st in stages]), ip(*[int(st.get("ln") or 0) for st in stages]),
+           ptrs("gamma"), ptrs("beta"), fp(*[float(st.get("eps") or 0.0) for st in stages]), ptrs("stats"), ptrs("nout"),
+           longs("ldn"), longs("nout_row0"), L.stream_ptr())
+
+
 _DOWN_COUNTERS = {}
 
 
@@ -1104,46 +1124,54 @@ class GroupedLoraFn(torch.autograd.Function):
                 DEFERRED.add_tn(dy, Ts[g], site.gb)
                 DEFERRED.add_tn(dT[g], x2d, site.ga)
             return None, None, None, None, None, None, None
-        G = len(dys)
-        if (ctx.needs_input_grad[0] and 2 <= G <= 3 and all(dy is not None for dy in dys) and ctx.ds_accum is not None
-                and DEFERRED is not None and _KGROUPS):   # (dS goes to the trainer's accumulator, as in the branch above)
-            # q | k | v backward-data as ONE launch: dX = sum_g (dY_g.W_g + ((dY_g.Bup_g) * S).A_g), accumulators in registers
-            import ctypes
-            M, Kin = x2d.shape
-            dys = [dy.contiguous() for dy in dys]
-            dTs = torch.empty(G, M, 32, dtype=torch.bfloat16, device=x2d.device)
-            dT = torch.empty_like(dTs)
-            dx = torch.empty(M, Kin, dtype=torch.bfloat16, device=x2d.device)
-            vp, lp_, ip = ctypes.c_void_p * G, ctypes.c_long * G, ctypes.c_int * G
-            rc = L.call_raw("aql_lora_gemm_fused_kgroups", G, vp(*[dy.data_ptr() for dy in dys]), lp_(*[dy.stride(0) for dy in dys]),
-                            vp(*[p.wt.data_ptr() for p in ctx.packs]), lp_(*[p.wt.stride(0) for p in ctx.packs]),
-                            ip(*[dy.shape[1] for dy in dys]), vp(*[s_.bt16.data_ptr() for s_ in ctx.sites]),
-                            vp(*[s_.at16.data_ptr() for s_ in ctx.sites]), M, Kin, L.ptr(S16), ctx.rps, None, 0, L.ptr(dx), Kin,
-                            vp(*[dTs[g].data_ptr() for g in range(G)]), vp(*[dT[g].data_ptr() for g in range(G)]), L.stream_ptr())
-            if rc != 100:
-                L.check(rc, "aql_lora_gemm_fused_kgroups")
-                nb = S16.shape[0]
-                for g, dy in enumerate(dys):
-                    site = ctx.sites[g]
-                    if not DEFERRED.add_ds(dTs[g], T[g], ctx.ds_accum, nb, ctx.rps, 32):
-                        L.call("aql_lora_ds", L.ptr(dTs[g]), L.ptr(T[g]), nb, ctx.rps, 32, L.ptr(ctx.ds_accum), L.stream_ptr())
-                    if not DEFERRED.add_tn(dy, Ts[g], site.gb):
-                        gemm_tn_acc(dy, Ts[g], site.gb)
-                    if not DEFERRED.add_tn(dT[g], x2d, site.ga):
-                        gemm_tn_acc(dT[g], x2d, site.ga)
-                return dx, None, None, None, None, None, None
-            dx = None
-        for g, dy in enumerate(dys):
-            if dy is None:
-                continue
-            dy = dy.contiguous()
-            dx_g, dS = _lora_backward(dy, x2d, T[g], Ts[g], S16, ctx.packs[g], ctx.sites[g], ctx.rps, ctx.ds_accum,
-                                      ctx.needs_input_grad[0], ctx.needs_input_grad[4], ctx.s_dtype, dx)
-            if dx_g is not None:
-                dx = dx_g
-            if dS is not None:
-                dS_sum = dS if dS_sum is None else dS_sum + dS
-        return dx, None, None, None, dS_sum, None, None
+        dx, dS = _grouped_backward(dys, x2d, T, Ts, S16, ctx.packs, ctx.sites, ctx.rps, ctx.ds_accum, ctx.needs_input_grad[0],
+                                   ctx.needs_input_grad[4], ctx.s_dtype)
+        return dx, None, None, None, dS, None, None
+
+
+def _grouped_backward(dys, x2d, T, Ts, S16, packs, sites, rps, ds_accum, want_dx, ret_ds, s_dtype):
+    """Backward of G LoRA linears that share their input x2d (q | k | v): dX = sum_g dX_g, weight gradients queued.  T / Ts are indexable
+    by group.  -> (dX or None, dS or None)."""
+    dx, dS_sum = None, None
+    G = len(dys)
+    if (want_dx and 2 <= G <= 3 and all(dy is not None for dy in dys) and ds_accum is not None
+            and DEFERRED is not None and _KGROUPS):   # (dS goes to the trainer's accumulator)
+        # q | k | v backward-data as ONE launch: dX = sum_g (dY_g.W_g + ((dY_g.Bup_g) * S).A_g), accumulators in registers
+        import ctypes
+        M, Kin = x2d.shape
+        dys = [dy.contiguous() for dy in dys]
+        dTs = torch.empty(G, M, 32, dtype=torch.bfloat16, device=x2d.device)
+        dT = torch.empty_like(dTs)
+        dx = torch.empty(M, Kin, dtype=torch.bfloat16, device=x2d.device)
+        vp, lp_, ip = ctypes.c_void_p * G, ctypes.c_long * G, ctypes.c_int * G
+        rc = L.call_raw("aql_lora_gemm_fused_kgroups", G, vp(*[dy.data_ptr() for dy in dys]), lp_(*[dy.stride(0) for dy in dys]),
+                        vp(*[p.wt.data_ptr() for p in packs]), lp_(*[p.wt.stride(0) for p in packs]),
+                        ip(*[dy.shape[1] for dy in dys]), vp(*[s_.bt16.data_ptr() for s_ in sites]),
+                        vp(*[s_.at16.data_ptr() for s_ in sites]), M, Kin, L.ptr(S16), rps, None, 0, L.ptr(dx), Kin,
+                        vp(*[dTs[g].data_ptr() for g in range(G)]), vp(*[dT[g].data_ptr() for g in range(G)]), L.stream_ptr())
+        if rc != 100:
+            L.check(rc, "aql_lora_gemm_fused_kgroups")
+            nb = S16.shape[0]
+            for g, dy in enumerate(dys):
+                site = sites[g]
+                if not DEFERRED.add_ds(dTs[g], T[g], ds_accum, nb, rps, 32):
+                    L.call("aql_lora_ds", L.ptr(dTs[g]), L.ptr(T[g]), nb, rps, 32, L.ptr(ds_accum), L.stream_ptr())
+                if not DEFERRED.add_tn(dy, Ts[g], site.gb):
+                    gemm_tn_acc(dy, Ts[g], site.gb)
+                if not DEFERRED.add_tn(dT[g], x2d, site.ga):
+                    gemm_tn_acc(dT[g], x2d, site.ga)
+            return dx, None
+        dx = None
+    for g, dy in enumerate(dys):
+        if dy is None:
+            continue
+        dy = dy.contiguous()
+        dx_g, dS = _lora_backward(dy, x2d, T[g], Ts[g], S16, packs[g], sites[g], rps, ds_accum, want_dx, ret_ds, s_dtype, dx)
+        if dx_g is not None:
+            dx = dx_g
+        if dS is not None:
+            dS_sum = dS if dS_sum is None else dS_sum + dS
+    return dx, dS_sum
 
 
 def grouped_lora_ok(x2d, packs, sites, S16):
@@ -1166,6 +1194,161 @@ def lora_linear(x2d, packed, site=None, S=None, S16=None, rps=1, residual=None, 
     S16: its bf16 copy read by the kernels.  ``geglu``: see LoraLinearFn."""
     want_h = torch.is_grad_enabled() and (x2d.requires_grad or (S is not None and torch.is_tensor(S) and S.requires_grad))
     return LoraLinearFn.apply(x2d, packed, site, S, S16, rps, residual, geglu, want_h)
+
+
+# ------------------------------------------------------------------------- row-resident chains (csrc/aql_chain.hip)
+CHAIN = os.environ.get("AQL_CHAIN", "1") != "0"   # A/B hook: 0 = every linear / LayerNorm of the transformer block as its own launch
+CHAIN_MIN_TILES = int(os.environ.get("AQL_CHAIN_MIN_TILES", "128"))   # below this many 128-row tiles the chip is mostly idle: unfused
+
+
+class ChainStage:
+    """One linear of a chain (static description).  ``keep``: the output tile stays in LDS as the next stage's input, after
+    ``+ residual`` (use_res) and LayerNorm (ln = module with weight / bias / eps); emit_out / emit_n: the (pre-LayerNorm) output / the
+    normalised rows are results of the chain (tensors autograd sees), not only saved state."""
+    __slots__ = ("packed", "site", "keep", "use_res", "ln", "emit_out", "emit_n")
+
+    def __init__(self, packed, site, keep, use_res=False, ln=None, emit_out=True, emit_n=False):
+        self.packed, self.site, self.keep, self.use_res, self.ln, self.emit_out, self.emit_n = packed, site, keep, use_res, ln, emit_out, emit_n
+
+
+def chain_ok(x2d, stages, S16, rps):
+    """The chain kernel takes these linears: 320 -> 320, rank-32 LoRA with bf16 scale rows, whole 128-row tiles, enough of them."""
+    if not CHAIN or REF_ROUNDING or S16 is None or x2d.dtype != torch.bfloat16 or x2d.dim() != 2 or x2d.stride(1) != 1:
+        return False
+    M = x2d.shape[0] * (2 if _full(x2d) is not None else 1)
+    if x2d.shape[1] != 320 or M % 128 or rps % 128 or M // 128 < CHAIN_MIN_TILES or (M * x2d.stride(0) * 2) >= (1 << 30):
+        return False
+    for st in stages:
+        if st.packed.N != 320 or st.packed.K != 320 or st.site is None or st.site.rank != 32:
+            return False
+    return os.environ.get("AQL_LORA_FUSED", "1") != "0"
+
+
+class ChainFn(torch.autograd.Function):
+    """A chain of 320 -> 320 LoRA linears with the row-local operations between them (bias, residual add, LayerNorm) as ONE launch
+    (aql_lora_chain_fwd): attn.to_out + residual -> LayerNorm -> next projection(s) of BasicTransformerBlock.forward and
+    proj_in -> norm1 -> to_q | to_k | to_v (scripts/lib/original_unet.py:786-806, 856-861; utils/lora_modules.py:9-26, 56-62).
+    Forward: bit-identical to LoraLinearFn / LayerNormFn / GroupedLoraFn in sequence.  Backward: exactly their backward launches, in
+    their order (the saved tensors are the same ones).  Outputs: per stage, in order, the emitted `out` then the emitted `n`."""
+
+    @staticmethod
+    def forward(ctx, x2d, res, S, S16, rps, stages):
+        _req(x2d, "lora chain")
+        M, C = x2d.shape
+        dev = x2d.device
+        xk = _full(x2d)
+        twin = xk is not None
+        if not twin:
+            xk = x2d
+        resk = None
+        if res is not None:
+            resk = _need_full(res, "the residual") if twin else res
+        S16k = _need_full(S16, "the LoRA scale") if twin else S16
+        row0 = M if (twin and _TWIN_SKIP) else 0
+        kst, outs, saved = [], [], [x2d, S16]
+        meta = []
+        for st in stages:
+            Tk, T = _alloc((M, 32), torch.bfloat16, dev, twin)
+            Tsk, Ts = _alloc((M, 32), torch.bfloat16, dev, twin)
+            d = dict(W=st.packed.w, ldw=st.packed.w.stride(0), bias=st.packed.bias, Ad=st.site.a16, Bup=st.site.b16, T=Tk, Ts=Tsk,
+                     keep=int(st.keep))
+            ok = o = nk = n = stk = stt = None
+            if st.emit_out or st.ln is not None or not st.keep:
+                ok, o = _alloc((M, C), torch.bfloat16, dev, twin)
+                d.update(out=ok, ldo=C)
+            if st.use_res:
+                d.update(res=resk, ldr=resk.stride(0))
+            if st.ln is not None:
+                nk, n = _alloc((M, C), torch.bfloat16, dev, twin)
+                stk, stt = _alloc((M, 2), torch.float32, dev, twin)
+                d.update(ln=1, gamma=st.ln.weight, beta=st.ln.bias, eps=float(st.ln.eps), stats=stk, nout=nk, ldn=C,
+                         nout_row0=0 if st.emit_n else row0)
+            kst.append(d)
+            if st.emit_out:
+                outs.append(o)
+            if st.emit_n:
+                outs.append(n)
+            meta.append((len(saved), o is not None, n is not None))
+            saved += [T, Ts] + ([o] if o is not None else []) + ([n, stt] if n is not None else [])
+        chain_fwd(xk, xk.stride(0), xk.shape[0], rps, row0, S16k, kst)
+        ctx.stages, ctx.meta, ctx.rps = stages, meta, rps
+        ctx.ds_accum = getattr(S, "_aql_ds_accum", None)
+        ctx.s_dtype = S.dtype
+        ctx.save_for_backward(*saved)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        sv = ctx.saved_tensors
+        x2d, S16 = sv[0], sv[1]
+        stages, rps = ctx.stages, ctx.rps
+        ret_ds = ctx.needs_input_grad[2]
+        # gradients of the emitted outputs, per stage
+        gi = iter(grads)
+        d_out, d_n = [], []
+        for st in stages:
+            d_out.append(next(gi) if st.emit_out else None)
+            d_n.append(next(gi) if st.emit_n else None)
+        # the tensors each stage saved, and the input each stage read (x2d, or the tile the previous keep stage left)
+        T, Ts, O, N, ST, X = [], [], [], [], [], []
+        cur = x2d
+        for st, (p, has_o, has_n) in zip(stages, ctx.meta):
+            T.append(sv[p])
+            Ts.append(sv[p + 1])
+            q = p + 2
+            O.append(sv[q] if has_o else None)
+            q += 1 if has_o else 0
+            N.append(sv[q] if has_n else None)
+            ST.append(sv[q + 1] if has_n else None)
+            X.append(cur)
+            if st.keep:
+                cur = N[-1] if has_n else O[-1]
+        dR, d_res, dS_sum = None, None, None
+
+        def add(a, b):
+            return b if a is None else (a if b is None else a + b)
+
+        g = len(stages) - 1
+        while g >= 0:
+            st = stages[g]
+            if not st.keep:
+                lo_ = g
+                while lo_ > 0 and not stages[lo_ - 1].keep:
+                    lo_ -= 1
+                run = list(range(lo_, g + 1))
+                want_dx = lo_ > 0 or ctx.needs_input_grad[0]
+                dx, dS = _grouped_backward([d_out[k] for k in run], X[lo_], [T[k] for k in run], [Ts[k] for k in run], S16,
+                                           [stages[k].packed for k in run], [stages[k].site for k in run], rps, ctx.ds_accum,
+                                           want_dx, ret_ds, ctx.s_dtype)
+                dR = add(dR, dx)
+                dS_sum = add(dS_sum, dS)
+                g = lo_ - 1
+                continue
+            dn = add(dR, d_n[g])
+            if st.ln is not None:
+                hs = O[g]
+                dres = None if d_out[g] is None else d_out[g].contiguous()
+                if dn is None:
+                    dhs = dres
+                else:
+                    dhs = torch.empty_like(hs)
+                    L.call("aql_layernorm_bwd", L.ptr(hs), L.ptr(dn.contiguous()), hs.shape[0], hs.shape[1], L.ptr(st.ln.weight),
+                           L.ptr(ST[g]), L.ptr(dres), L.ptr(dhs), L.stream_ptr())
+            else:
+                dhs = add(dn, d_out[g])
+            if st.use_res:
+                d_res = dhs
+            want_dx = g > 0 or ctx.needs_input_grad[0]
+            dx, dS = _lora_backward(dhs.contiguous(), X[g], T[g], Ts[g], S16, st.packed, st.site, rps, ctx.ds_accum, want_dx, ret_ds,
+                                    ctx.s_dtype, None)
+            dR = dx
+            dS_sum = add(dS_sum, dS)
+            g -= 1
+        return dR, d_res, dS_sum, None, None, None
+
+
+def lora_chain(x2d, res, S, S16, rps, stages):
+    return ChainFn.apply(x2d, res, S, S16, rps, tuple(stages))
 
 
 # --------------------------------------------------------------------------------------------- conv 3x3

@@ -313,10 +313,59 @@ class Transformer2DModel(nn.Module):
     def forward(self, x, ctx, scale=1.0):
         B, C, H, W = x.shape
         n, x = self.norm.forward_res(x)
+        y = self._forward_chains(n, x, ctx, scale)
+        if y is not None:
+            return y
         h = self.proj_in(n, scale)
         tokens = ops.nhwc_view(h).reshape(B, H * W, C)
         for blk in self.transformer_blocks:
             tokens = blk(tokens, ctx, scale)
+        h = tokens.view(B, H, W, C).permute(0, 3, 1, 2)
+        return self.proj_out(h, scale, residual=x)
+
+    def _forward_chains(self, n, x, ctx, scale):
+        """The 320-channel level with the rank-32 watermark LoRA on every linear (training, twin or plain batch): the linears with
+        K = N = 320 and the row-local operations between them run as row-resident chains (ops.ChainFn, csrc/aql_chain.hip) --
+            proj_in -> norm1 -> to_q | to_k | to_v      |  attn1.to_out + residual -> norm2 -> attn2.to_q
+            attn2.to_out + residual -> norm3            |  (feed-forward and proj_out: the existing launches)
+        13 launches of the block become 8; every tensor has the bits of the per-launch path (tests/test_gpu_kernels.py).  Returns
+        None when the chain form does not apply (other widths, ranks, float scale, no LoRA, small batches: ops.chain_ok)."""
+        if (not ops.CHAIN or len(self.transformer_blocks) != 1 or not torch.is_tensor(scale) or scale.dim() != 2 or scale.shape[1] != 32
+                or n.dtype != torch.bfloat16 or n.shape[1] != 320):
+            return None
+        blk = self.transformer_blocks[0]
+        a1, a2 = blk.attn1, blk.attn2
+        hosts = (self.proj_in, a1.to_q, a1.to_k, a1.to_v, a1.to_out[0], a2.to_q, a2.to_out[0])
+        if any(m.lora_layer is None or _has_alpha(m) for m in hosts) or any(m.bias is not None for m in (a1.to_q, a1.to_k, a1.to_v, a2.to_q)):
+            return None
+        kv = getattr(ctx, "_aql_kv", None)   # k | v of all cross-attentions, computed in front of the U-Net (UNet._ctx_kv)
+        if kv is None or id(a2) not in kv:
+            return None
+        from .lora import _scale16, _site_of
+        B, C, H, W = n.shape
+        N = H * W
+        n = ops.as_cl(n)
+        x2d = ops.nhwc_view(n).reshape(B * N, C)
+        pk = {m: _packed_linear(m) for m in hosts}
+        st = {m: _site_of(m.lora_layer) for m in hosts}
+        S = _scale16(scale, B, 32, x2d.device)
+        S16 = getattr(S, "_aql_s16", None)
+        if S16 is None:
+            S16 = S.detach().to(torch.bfloat16).contiguous()
+            S._aql_s16 = S16
+        CS = ops.ChainStage
+        d_stages = [CS(pk[self.proj_in], st[self.proj_in], True, ln=blk.norm1)] + \
+                   [CS(pk[m], st[m], False) for m in (a1.to_q, a1.to_k, a1.to_v)]
+        if not ops.chain_ok(x2d, d_stages, S16, N):
+            return None
+        h0, q, k, v = ops.lora_chain(x2d, None, S, S16, N, d_stages)
+        o1 = ops.attention(q.view(B, N, C), k.view(B, N, C), v.view(B, N, C), a1.heads).reshape(B * N, C)
+        h1, q2 = ops.lora_chain(o1, h0, S, S16, N, [CS(pk[a1.to_out[0]], st[a1.to_out[0]], True, use_res=True, ln=blk.norm2),
+                                                    CS(pk[a2.to_q], st[a2.to_q], False)])
+        k2, v2 = kv[id(a2)]
+        o2 = ops.attention(q2.view(B, N, C), k2, v2, a2.heads).reshape(B * N, C)
+        h2, n3 = ops.lora_chain(o2, h1, S, S16, N, [CS(pk[a2.to_out[0]], st[a2.to_out[0]], True, use_res=True, ln=blk.norm3, emit_n=True)])
+        tokens = blk.ff(n3.view(B, N, C), scale, residual=h2.view(B, N, C))
         h = tokens.view(B, H, W, C).permute(0, 3, 1, 2)
         return self.proj_out(h, scale, residual=x)
 

@@ -183,6 +183,25 @@ int aql_layernorm_fwd(const bf16_t* x, long M, int C, const bf16_t* gamma, const
                       float* stats, aql_stream_t stream);
 int aql_layernorm_bwd(const bf16_t* x, const bf16_t* dy, long M, int C, const bf16_t* gamma, const float* stats,
                       const bf16_t* dres, bf16_t* dx, aql_stream_t stream);
+/* Row-resident CHAIN of the transformer block at the 320-channel level (round 5): up to 4 rank-32 LoRA linears 320 -> 320 whose
+ * inputs and outputs never leave the CU between two of them -- one workgroup owns 128 token rows, the 128 x 320 activation tile
+ * stays in LDS as the A panel of the next linear, weights stream through an LDS-DMA ring.  Replaces, bit for bit, the launch
+ * sequences   attn.to_out (+ residual) -> LayerNorm -> next projection(s)   of BasicTransformerBlock.forward
+ * (scripts/lib/original_unet.py:786-806 with utils/lora_modules.py:9-26, 56-62 on every linear) and
+ * proj_in -> norm1 -> to_q | to_k | to_v (original_unet.py:856-861, 786-790):
+ *   stage g:  Y = X.W_g^T + ((X.Adown_g^T) * S[m / rps]).Bup_g^T + bias_g          X = the tile in LDS ([M, 320] input for g = 0)
+ *     keep_g = 1:  X <- bf16(Y) + res_g (bf16 add);  out_g <- X (if given);  ln_g = 1:  X <- LayerNorm(X; gamma_g, beta_g, eps_g),
+ *                  stats_g[m] = (mean, rstd),  nout_g <- X for rows >= nout_row0_g
+ *     keep_g = 0:  out_g <- bf16(Y)                                              (X unchanged: q | k | v read the same tile)
+ * Every per-stage argument is a HOST array of nstage entries (null entries where a stage has no such operand; Adown_g = null:
+ * no LoRA on that linear).  M % 128 == 0, rows_per_sample % 128 == 0, lora_row0 % 128 == 0 (rows below lora_row0 -- the clean half
+ * of a twin batch, ppft_train.py:1026-1029 -- carry no LoRA term and write no T / Ts); at most one LayerNorm per chain.        */
+int aql_lora_chain_fwd(const bf16_t* X, long ldx, long M, int rows_per_sample, long lora_row0, const bf16_t* S, int nstage,
+                       const void* const* W, const long* ldw, const void* const* bias, const void* const* Adown,
+                       const void* const* Bup, void* const* T, void* const* Ts, const void* const* res, const long* ldr,
+                       void* const* out, const long* ldo, const int* keep, const int* ln, const void* const* gamma,
+                       const void* const* beta, const float* eps, void* const* stats, void* const* nout, const long* ldn,
+                       const long* nout_row0, aql_stream_t stream);
 
 /* ---- attention (csrc/aql_attn.hip) ---- F.scaled_dot_product_attention via diffusers AttnProcessor2_0 / twin
  * original_unet.py:688-704.  q/k/v/o: [B,N,H*d] with row strides ld*; lse,delta: [B,H,Nq] fp32.                   */
