@@ -20,9 +20,14 @@ extern "C" int aql_abi_version(void) { return AQL_ABI_VERSION; }
 extern "C" {
 typedef struct ncclComm* ncclComm_t;
 typedef struct { char internal[128]; } ncclUniqueId;
-typedef enum { ncclSuccess = 0 } ncclResult_t;
-typedef enum { ncclUint8 = 1, ncclFloat32 = 7 } ncclDataType_t;
-typedef enum { ncclSum = 0, ncclAvg = 4 } ncclRedOp_t;
+// plain ints, not one-enumerator enums: RCCL returns codes (and takes datatype / op values) outside a mirrored enum's value range, and
+// a C++ compiler may assume a value of an enum type lies within it
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+enum : int { ncclSuccess = 0 };
+enum : int { ncclUint8 = 1, ncclFloat32 = 7 };
+enum : int { ncclSum = 0, ncclAvg = 4 };
 }
 
 namespace {

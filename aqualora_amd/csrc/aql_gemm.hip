@@ -298,9 +298,23 @@ inline void pick_tile(long M, int N, int kt_total, bool can_split, int* cfg, int
 
 // Dispatch one bf16-output GEMM over the tile configurations; split-K slabs + finalize when the grid cannot fill
 // 256 CUs, K is deep and the caller supplied a workspace.
+// bytes an operand spans from its base pointer: the kernels read operands through buffer descriptors of BUF_BYTES (1 GiB) whose
+// out-of-range offsets zero-fill -- an operand reaching past that would silently read zeros (the VAE's 256-channel 512 x 512 map at
+// batch 16 is 2.1 GiB), so the entry points refuse it and the Python wrappers go through such maps in sample / row chunks
+inline long loader_span(const PlainLoader& l) { return (long)l.rows * l.ld * 2; }
+inline long loader_span(const ConvFwdLoader& l) { return (long)l.B * l.Hin * l.Win * l.Cin * 2; }
+inline long loader_span(const ConvBwdLoader& l) { return (long)l.B * l.Hout * l.Wout * l.Cout * 2; }
+
 template <class LA, class LB>
 int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_bytes, hipStream_t stream,
                   const char* name) {
+  {
+    const long sa = loader_span(g.a0), sb = loader_span(g.b0);
+    const long sa1 = g.ktiles1 > 0 ? loader_span(g.a1) : 0, sb1 = g.ktiles1 > 0 ? loader_span(g.b1) : 0;
+    AQL_CHECK_ARG(sa < (long)BUF_BYTES && sb < (long)BUF_BYTES && sa1 < (long)BUF_BYTES && sb1 < (long)BUF_BYTES,
+                  "%s: an operand spans %ld bytes, the buffer descriptors cover %u (split the batch / the rows: ops.span_chunks)", name,
+                  sa > sb ? sa : sb, BUF_BYTES);
+  }
   g.epi = EpiParams{};
   g.epi.rows_per_sample = o.rows_per_sample > 0 ? o.rows_per_sample : 1;
   const int kt_total = g.ktiles0 + g.ktiles1;

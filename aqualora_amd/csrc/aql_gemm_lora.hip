@@ -887,6 +887,8 @@ static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long
                                 bf16_t* Ts, bf16_t* G, long ldg, int geglu_F, int ngroups, const int* col_start, long row0,
                                 hipStream_t stream, const bf16_t* gb_h = nullptr, long gb_ldh = 0) {
   AQL_CHECK_ARG(X && W && Adown && S && Bup && (Y || geglu_F) && T && Ts, "aql_lora_gemm_fused: null operand");
+  AQL_CHECK_ARG(M * ldx * 2 < (long)BUF_BYTES && (long)N * ldw * 2 < (long)BUF_BYTES,
+                "aql_lora_gemm_fused: an operand spans >= 1 GiB, the buffer descriptors cover %u bytes (split the rows)", BUF_BYTES);
   AQL_CHECK_ARG(M > 0 && M < (1L << 31) && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 &&
                     ldy % 8 == 0 && rows_per_sample > 0 && (residual == nullptr || ldr % 8 == 0),
                 "aql_lora_gemm_fused: bad shape M=%ld N=%d K=%d", M, N, K);

@@ -398,6 +398,14 @@ class ModuleGradExchange:
         self._handles = [p.register_post_accumulate_grad_hook(lambda _p, _i=i: self._ready(_i)) for i, p in enumerate(self.params)]
 
     def _ready(self, i):
+        # the hooks reduce the FLAT buffer: a parameter whose .grad is no longer a view of it (optimizer.zero_grad(set_to_none=True)
+        # or module.zero_grad() between prepare and the step) would be stepped on its local, un-averaged gradient while the
+        # collective averages zeros -- replicas would diverge silently.  Catch it here: copy the stray gradient in and re-attach.
+        p, off = self.params[i], self.offsets[i]
+        if p.grad is not None and p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
+            view = self.flat[off:off + p.numel()].view_as(p)
+            view.copy_(p.grad)
+            p.grad = view
         k = self.bucket_of[i]
         self.left[k] -= 1
         if self.left[k] == 0:
@@ -419,7 +427,7 @@ class ModuleGradExchange:
     def finish(self):
         """After backward: every bucket was launched from a hook (a parameter that received no gradient leaves its bucket
         open: it is launched here); wait for the collectives."""
-        for k in range(len(self.ranges)):
+        for k in range(len(self.ranges)):      # ascending bucket index on every rank: the collective order cannot differ across ranks
             if self.left[k] != 0 and k not in self.launched:
                 self._launch(k)
         if self.comm is not None and self.side is not None:

@@ -268,6 +268,19 @@ class PackedConv3x3:
 
 
 # ------------------------------------------------------------------------------------- low-level calls
+DESC_SPAN = 1 << 30   # the kernels' buffer descriptors cover 1 GiB from an operand's base (csrc/aql_gemm.cuh BUF_BYTES): larger
+# activations are processed in row / sample chunks, each with its own descriptor base.  The C entry points refuse larger spans.
+
+
+def span_chunks(n, bytes_per_unit, align=1):
+    """[(first, count)] covering n units (rows / samples) so that each chunk's operand span stays below DESC_SPAN."""
+    per = max(1, (DESC_SPAN - 1) // max(1, bytes_per_unit))
+    if per >= n:
+        return [(0, n)]
+    per = max(align, per // align * align)
+    return [(i, min(per, n - i)) for i in range(0, n, per)]
+
+
 def gemm_bf16(A, B, bias=None, A2=None, B2=None, rowbias=None, rps=1, residual=None, out=None, lora_row0=0):
     """C[M,N] = A[M,K].B[N,K]^T (+A2.B2^T) + bias + rowbias[m//rps] + residual, bf16 with fp32 accumulation.
     lora_row0: rows below it have no A2.B2^T term (the clean half of a twin batch)."""
@@ -275,11 +288,18 @@ def gemm_bf16(A, B, bias=None, A2=None, B2=None, rowbias=None, rps=1, residual=N
     N = B.shape[0]
     C = out if out is not None else torch.empty(M, N, dtype=torch.bfloat16, device=A.device)
     ws = workspace(A.device)
-    L.call("aql_gemm_bf16_ex", L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), M, N, K,
-           L.ptr(A2), 0 if A2 is None else A2.stride(0), L.ptr(B2), 0 if B2 is None else B2.stride(0),
-           0 if A2 is None else A2.shape[1], L.ptr(bias), L.ptr(rowbias), rps,
-           L.ptr(residual), 0 if residual is None else residual.stride(0), L.ptr(C), C.stride(0), int(lora_row0),
-           L.ptr(ws), ws.numel() * 4, L.stream_ptr())
+    chunks = span_chunks(M, max(A.stride(0), C.stride(0)) * 2, rps if rowbias is not None else 1)
+    for r0, n in chunks:
+        sl = slice(r0, r0 + n)
+        Ac, Cc = A[sl], C[sl]
+        A2c = None if A2 is None else A2[sl]
+        rc = None if residual is None else residual[sl]
+        rb = None if rowbias is None else rowbias[r0 // rps:]
+        L.call("aql_gemm_bf16_ex", L.ptr(Ac), A.stride(0), L.ptr(B), B.stride(0), n, N, K,
+               L.ptr(A2c), 0 if A2 is None else A2.stride(0), L.ptr(B2), 0 if B2 is None else B2.stride(0),
+               0 if A2 is None else A2.shape[1], L.ptr(bias), L.ptr(rb), rps,
+               L.ptr(rc), 0 if residual is None else residual.stride(0), L.ptr(Cc), C.stride(0), max(0, int(lora_row0) - r0),
+               L.ptr(ws), ws.numel() * 4, L.stream_ptr())
     return C
 
 
@@ -1383,9 +1403,12 @@ class Conv3x3Fn(torch.autograd.Function):
         resk = res if (res is None or not twin) else _need_full(res, "the conv residual")
         if twin and rowbias is not None and rowbias.shape[0] != Bk:
             raise L.AqlError("twin batch: the per-sample row bias must cover both halves")
-        L.call("aql_conv3x3_fwd", L.ptr(xk), Bk, H, W, packed.Cin, L.ptr(packed.wk), L.ptr(packed.bias), packed.Cout,
-               packed.stride, int(upsample), L.ptr(rowbias), 0 if rowbias is None else rowbias.stride(0), L.ptr(resk),
-               L.ptr(yk), L.ptr(ws), ws.numel() * 4, L.stream_ptr())
+        # maps above 1 GiB (the VAE's 256-channel 512 x 512 level at batch 16: 2.1 GiB) go through the kernel in sample chunks
+        for b0, nb in span_chunks(Bk, max(H * W * packed.Cin, Ho * Wo * packed.Cout) * 2):
+            L.call("aql_conv3x3_fwd", L.ptr(xk[b0:b0 + nb]), nb, H, W, packed.Cin, L.ptr(packed.wk), L.ptr(packed.bias), packed.Cout,
+                   packed.stride, int(upsample), L.ptr(None if rowbias is None else rowbias[b0:]),
+                   0 if rowbias is None else rowbias.stride(0), L.ptr(None if resk is None else resk[b0:b0 + nb]),
+                   L.ptr(yk[b0:b0 + nb]), L.ptr(ws), ws.numel() * 4, L.stream_ptr())
         ctx.packed, ctx.upsample, ctx.in_shape, ctx.c_in = packed, upsample, (B, H, W), C
         ctx.has_rb, ctx.has_res = rowbias is not None, residual is not None
         if packed.Cout_real != packed.Cout:
@@ -1406,8 +1429,9 @@ class Conv3x3Fn(torch.autograd.Function):
             Hl, Wl = (H * 2, W * 2) if ctx.upsample else (H, W)
             ws = workspace(dy.device)
             du = torch.empty((B, packed.Cin, Hl, Wl), dtype=torch.bfloat16, device=dy.device, memory_format=CL)
-            L.call("aql_conv3x3_bwd_data", L.ptr(dy), B, Hl, Wl, packed.Cin, L.ptr(packed.wt), packed.Cout,
-                   packed.stride, L.ptr(du), L.ptr(ws), ws.numel() * 4, L.stream_ptr())
+            for b0, nb in span_chunks(B, max(Hl * Wl * packed.Cin, dy.shape[2] * dy.shape[3] * packed.Cout) * 2):
+                L.call("aql_conv3x3_bwd_data", L.ptr(dy[b0:b0 + nb]), nb, Hl, Wl, packed.Cin, L.ptr(packed.wt), packed.Cout,
+                       packed.stride, L.ptr(du[b0:b0 + nb]), L.ptr(ws), ws.numel() * 4, L.stream_ptr())
             if ctx.upsample:
                 dx = torch.empty((B, packed.Cin, H, W), dtype=torch.bfloat16, device=dy.device, memory_format=CL)
                 L.call("aql_upsample2x_bwd", L.ptr(du), B, H, W, packed.Cin, L.ptr(dx), L.stream_ptr())

@@ -199,8 +199,10 @@ class AutoencoderKL:
         Ho, Wo = (Hl + 2 - 3) // pk.stride + 1, (Wl + 2 - 3) // pk.stride + 1
         y = torch.empty((B, pk.Cout, Ho, Wo), dtype=torch.bfloat16, device=x.device, memory_format=CL)
         ws = ops.workspace(x.device)
-        L.call("aql_conv3x3_fwd_pad", L.ptr(x), B, H, W, pk.Cin, L.ptr(pk.wk), L.ptr(pk.bias), pk.Cout, pk.stride,
-               int(upsample), pad_lo, None, 0, L.ptr(residual), L.ptr(y), L.ptr(ws), ws.numel() * 4, L.stream_ptr())
+        for b0, nb in ops.span_chunks(B, max(H * W * pk.Cin, Ho * Wo * pk.Cout) * 2):   # 1 GiB buffer descriptors: sample chunks
+            L.call("aql_conv3x3_fwd_pad", L.ptr(x[b0:b0 + nb]), nb, H, W, pk.Cin, L.ptr(pk.wk), L.ptr(pk.bias), pk.Cout, pk.stride,
+                   int(upsample), pad_lo, None, 0, L.ptr(None if residual is None else residual[b0:b0 + nb]), L.ptr(y[b0:b0 + nb]),
+                   L.ptr(ws), ws.numel() * 4, L.stream_ptr())
         return y[:, :pk.Cout_real] if pk.Cout_real != pk.Cout else y
 
     def _norm(self, x, key, silu):

@@ -301,9 +301,16 @@ def ddim_step(x, eps_u, eps_c, t, t_prev, guidance, acp=None):
     return (a_p.sqrt() * x0 + (1 - a_p).sqrt() * eps).float()
 
 
+def leading_timesteps(n, T=1000, steps_offset=1):
+    """diffusers' timestep_spacing="leading": k * (T // (n + 1)) for k = n .. 1, plus steps_offset -- the grid DPMSolverMultistepScheduler
+    and UniPCMultistepScheduler build from the SD-1.5 scheduler config (recalled; UNPINNED)."""
+    ratio = T // (n + 1)
+    return [k * ratio + steps_offset for k in range(n, 0, -1)]
+
+
 def dpmpp2m_steps(num_inference_steps, num_train_timesteps=1000, acp=None):
     """Own restatement of the DPM-Solver++(2M) trajectory (independent of aqualora_amd.inference.dpmpp2m_schedule): timesteps =
-    round(linspace(0, T-1, n+1))[::-1][:-1] (diffusers' "linspace" spacing), data-prediction multistep update of Lu et al. 2022
+    `leading_timesteps` (diffusers' "leading" spacing with steps_offset 1, as the SD-1.5 scheduler config sets it), data-prediction multistep update of Lu et al. 2022
     (arXiv:2211.01095, Alg. 2) in half-log-SNR lambda = log(alpha / sigma):
         h = lambda_next - lambda_t;  x_next = (sigma_next / sigma_t) x - alpha_next (e^{-h} - 1) D,
         D = x0_t (first step; last step too when n < 15: diffusers' lower_order_final) else x0_t + (x0_t - x0_prev) / (2 r0),
@@ -313,7 +320,7 @@ def dpmpp2m_steps(num_inference_steps, num_train_timesteps=1000, acp=None):
     import math
     import numpy as np
     acp = (alphas_cumprod() if acp is None else acp).double().numpy()
-    ts = [int(v) for v in np.linspace(0, num_train_timesteps - 1, num_inference_steps + 1).round()[::-1][:-1]]
+    ts = leading_timesteps(num_inference_steps, num_train_timesteps)
     lam = lambda t: 0.5 * math.log(acp[t] / (1.0 - acp[t]))  # noqa: E731
     return ts, lam, acp
 
@@ -483,10 +490,10 @@ def plms_oracle(eps_fn, x, n_steps, acp):
 # (lists of data predictions and timesteps), independent of the coefficient programs of aqualora_amd/ksamplers.py.  UNPINNED
 # (diffusers absent): Lu et al. 2022 (arXiv:2211.01095) Alg. 1 for 2S with the midpoint rule; Zhao et al. 2023 (arXiv:2302.04867)
 # UniP / UniC with B(h) = e^h - 1 ("bh2"), data prediction, order 2, lower_order_final.  eps_fn(x, t) -> (guided) eps at integer t.
-def _dpm_grid(n_steps, acp):
+def _dpm_grid(n_steps, acp, leading=False):
     import numpy as np
     a = np.asarray(acp, dtype=np.float64)
-    ts = [int(v) for v in np.linspace(0, 999, n_steps + 1).round()[::-1][:-1]]
+    ts = leading_timesteps(n_steps) if leading else [int(v) for v in np.linspace(0, 999, n_steps + 1).round()[::-1][:-1]]
     al, sg = np.sqrt(a), np.sqrt(1.0 - a)
     return ts, al, sg, np.log(al / sg)
 
@@ -517,7 +524,7 @@ def dpms_singlestep_oracle(eps_fn, x, n_steps, acp):
 def unipc_oracle(eps_fn, x, n_steps, acp, solver_order=2, lower_order_final=True):
     import math
     import numpy as np
-    ts, al, sg, lam = _dpm_grid(n_steps, acp)
+    ts, al, sg, lam = _dpm_grid(n_steps, acp, leading=True)   # UniPC honours the config's timestep_spacing; the single-step class cannot
 
     def bh(order, rks, hh):
         h_phi_1 = math.expm1(hh)

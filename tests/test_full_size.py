@@ -33,6 +33,32 @@ def test_vae_full_size_decoder_vs_oracle():
     assert torch.equal(vae.decode(z.to(DEV)), img)       # deterministic
 
 
+def test_vae_decode_of_16_images_reads_every_sample_through_1gib_descriptors():
+    """Config 5's generator decodes 16 x 512 x 512 in one call (rob_enhance_finetune.py:1016): the 256-channel 512 x 512 input of
+    up_blocks.3 is 2.1 GiB, past the 1 GiB the kernels' buffer descriptors cover -- before round 5 samples 8..15 of such a map read as
+    zeros, silently.  Now the entry points refuse a span >= 1 GiB and the wrappers go through the map in sample chunks
+    (ops.span_chunks): the batch-16 decode must equal the per-sample decodes."""
+    from aqualora_amd import _lib as L
+    from aqualora_amd import ops
+    from aqualora_amd.vae import SD15_VAE, AutoencoderKL, synthetic_state_dict
+    vae = AutoencoderKL(synthetic_state_dict(SD15_VAE), SD15_VAE, DEV)
+    z = synth.normal("vae16.z", (16, 4, 64, 64), 0.18215 * 4.0, 17).to(DEV)
+    img = vae.decode(z)
+    assert img.shape == (16, 3, 512, 512) and torch.isfinite(img).all()
+    for i in (0, 7, 8, 15):
+        one = vae.decode(z[i:i + 1])
+        e = l2rel(img[i:i + 1], one)
+        assert e < 1e-2, (i, e)          # other tiles at the other batch size: bf16 rounding only (a zero-filled map gives ~1)
+    # the C entry point itself refuses what a descriptor cannot cover
+    x = torch.zeros((9, 256, 512, 512), dtype=torch.bfloat16, device=DEV).contiguous(memory_format=torch.channels_last)
+    pk = vae.p["decoder.up_blocks.3.resnets.0.conv1"]
+    y = torch.empty((9, pk.Cout, 512, 512), dtype=torch.bfloat16, device=DEV).contiguous(memory_format=torch.channels_last)
+    ws = ops.workspace(x.device)
+    rc = L.call_raw("aql_conv3x3_fwd", L.ptr(x), 9, 512, 512, pk.Cin, L.ptr(pk.wk), L.ptr(pk.bias), pk.Cout, 1, 0, None, 0, None,
+                    L.ptr(y), L.ptr(ws), ws.numel() * 4, L.stream_ptr())
+    assert rc == 1 and b"spans" in L.load().aql_last_error()
+
+
 def test_full_size_guided_ddim_step_of_the_fused_unet_vs_oracle():
     """BASELINE config 4's inner loop at full size: the rank-32 watermark LoRA baked with a message (create_wm_lora.py:24-41) and
     fused into W (utils_eval.py:81-82), then ONE captured guided step of `ddim_sample` (U-Net on the CFG batch of 2 + aql_ddim_step,

@@ -18,8 +18,8 @@ def test_dpmpp2m_schedule_matches_independent_restatement():
     for steps in (20, 10, 50):
         sched = dpmpp2m_schedule(steps)
         ts = [r[0] for r in sched]
-        want_ts = list(np.linspace(0, 999, steps + 1).round()[::-1][:-1].astype(int))
-        assert ts == want_ts and ts[0] == 999 and len(ts) == steps
+        want_ts = [k * (1000 // (steps + 1)) + 1 for k in range(steps, 0, -1)]     # "leading" spacing + steps_offset 1 (SD-1.5 config)
+        assert ts == want_ts and len(ts) == steps and (steps != 50 or (ts[0], ts[-1]) == (951, 20))
         lam = lambda t: 0.5 * math.log(acp[t] / (1 - acp[t]))  # noqa: E731
         for i, (t, al, sg, a, b, c) in enumerate(sched):
             nxt = ts[i + 1] if i + 1 < steps else 0
@@ -337,8 +337,8 @@ def test_dpm_singlestep_and_unipc_programs(sampler):
     eps = torch.randn_like(x0)
     for steps in (5, 6, 20):
         prog = program(sampler, steps)
-        ts = dpm_timesteps(steps)
-        assert [int(p.t) for p in prog.phases] == ts and ts[0] == 999 and len(ts) == steps
+        ts = dpm_timesteps(steps, spacing="leading" if sampler == "unipc" else "linspace")
+        assert [int(p.t) for p in prog.phases] == ts and ts[0] == (999 if sampler == "dpms_s" else (1000 // (steps + 1)) * steps + 1) and len(ts) == steps
         f = lambda x, t: torch.tanh(x * 0.7) * (1 + 0.001 * t)   # noqa: E731
         xT = torch.randn_like(x0)
         a, b = VM.run(prog, f, xT), ref(f, xT, steps, acp.numpy())
@@ -355,11 +355,14 @@ def test_dpm_singlestep_and_unipc_programs(sampler):
         t = int(t)
         return sg[t] * (x - al[t] * mu) / (al[t] ** 2 * sd ** 2 + sg[t] ** 2)
     xT = torch.randn(4, 4, 8, 8, dtype=torch.float64)
-    exact = al[0] * mu + (xT - al[999] * mu) * ((al[0] ** 2 * sd ** 2 + sg[0] ** 2) / (al[999] ** 2 * sd ** 2 + sg[999] ** 2)).sqrt()
+    grid = lambda steps: dpm_timesteps(steps, spacing="leading" if sampler == "unipc" else "linspace")   # noqa: E731
+
+    def exact_from(tT):            # closed-form probability-flow solution from the sampler's own first timestep
+        return al[0] * mu + (xT - al[tT] * mu) * ((al[0] ** 2 * sd ** 2 + sg[0] ** 2) / (al[tT] ** 2 * sd ** 2 + sg[tT] ** 2)).sqrt()
     lam = torch.log(al / sg)
 
     def first_order(steps):        # DPM-Solver++(1) (== DDIM) on the same grid: the yardstick
-        ts, x = dpm_timesteps(steps), xT.clone()
+        ts, x = grid(steps), xT.clone()
         for k, s_ in enumerate(ts):
             t_ = ts[k + 1] if k + 1 < steps else 0
             m = (x - sg[s_] * eps_gauss(x, s_)) / al[s_]
@@ -367,6 +370,7 @@ def test_dpm_singlestep_and_unipc_programs(sampler):
         return x
     errs, errs1 = [], []
     for steps in (20, 40, 80):
+        exact = exact_from(grid(steps)[0])
         errs.append(float((VM.run(program(sampler, steps), eps_gauss, xT) - exact).abs().max()))
         errs1.append(float((first_order(steps) - exact).abs().max()))
     # measured (round 4): first order 0.174 / 0.094 / 0.049 (ratio 1.85-1.91); dpms_s 0.068 / 0.026 / 0.0058 (2.6, 4.5);
