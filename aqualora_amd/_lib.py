@@ -156,8 +156,11 @@ def load():
         # a source-only checkout: compile the HIP library in-tree (this is a build, not a fallback -- if hipcc is
         # missing or the build fails we still stop below)
         import subprocess
-        subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j8"], check=False, stdout=subprocess.DEVNULL,
-                       stderr=subprocess.DEVNULL)
+        res = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j8"], check=False, capture_output=True, text=True)
+        if res.returncode != 0 or not os.path.exists(LIB_PATH):   # a failed build must say WHY, not surface as "not found"
+            tail = "\n".join((res.stdout + res.stderr).splitlines()[-25:])
+            raise AqlError(f"building {LIB_PATH} failed (make exit code {res.returncode}); there is no fallback path.  Last lines of "
+                           f"the build log:\n{tail}")
     if not os.path.exists(LIB_PATH):
         raise AqlError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -1308,6 +1308,7 @@ int launch_fwd(const AttnArgs& a0, hipStream_t st) {
     if (fold && ones && a.d < DV) {   // the denominator rides in the P.V product: the loop needs no row statistics after its first tile
       const bool big = DH <= 64 && (force == 4 || (force == 0 && a.Nq >= 2048 && (long)aql_cdiv(a.Nq, 256) * a.H * a.B >= 512));
       const dim3 g4(aql_cdiv(a.Nq, 256), a.H, a.B), g2(aql_cdiv(a.Nq, 128), a.H, a.B);
+#ifdef AQL_EXPERIMENTS   // AQL_ATTN_FOLD=2 (the shift inside the S-product: 210 vs 231 us, twice the rounding error; profiles/r04_attention_fold.txt)
       if (fold == 2 && a.d < DH) {
         if constexpr (DH <= 64) {
           if (big) {
@@ -1318,6 +1319,7 @@ int launch_fwd(const AttnArgs& a0, hipStream_t st) {
         hipLaunchKernelGGL((attn_fwd_kernel<DH, DV, 2, true, 2>), g2, dim3(256), 0, st, a);
         return 0;
       }
+#endif
       if constexpr (DH <= 64 && DV <= 48) {   // (64 rows per wavefront at DV = 64 would spill two registers: no head of the U-Net needs it)
         if (big) {
           hipLaunchKernelGGL((attn_fwd_kernel<DH, DV, 4, true, 1>), g4, dim3(256), 0, st, a);

@@ -321,7 +321,9 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
   // adjacent tiles share the LARGER operand: the weight panel when it outweighs the activations (deep 3x3 convs at
   // 8x8 / 16x16 / 32x32), else the activation rows
   g.m_fast = ((long)g.N * kt_total > (long)g.M * (kt_total < 9 ? kt_total : kt_total / 9 + 1)) ? 1 : 0;
+#ifdef AQL_EXPERIMENTS
   if (const char* e = getenv("AQL_MFAST")) g.m_fast = atoi(e);
+#endif
   int tiles = 0, cfg = 0, pd = 1;
   pick_tile(g.M, g.N, kt_total, ws != nullptr && o.C2 == nullptr, &cfg, &tiles, &pd);
   if (o.geglu_F > 0 && !(cfg == P_128x160 || cfg == P_64x160 || cfg == P_32x160 || cfg == P_W128x160 || cfg == P_W64x160 ||
@@ -336,6 +338,7 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
     while (s2 > 1 && (kt_total / s2 < 8 || (size_t)s2 * (size_t)g.M * (size_t)g.N * 4u > ws_bytes)) --s2;
     splits = s2;
   }
+#ifdef AQL_EXPERIMENTS
   if (ws != nullptr && o.C2 == nullptr) {   // tuning hook (tools/experiments/time_conv8.py), re-read on every call
     if (const char* e = getenv("AQL_SPLITS")) {
       int s = atoi(e);
@@ -343,6 +346,7 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
       if (s >= 1) splits = s;
     }
   }
+#endif
   if ((o.gb_h != nullptr || o.res_mod > 0) && splits > 1) return AQL_NOT_FUSED;   // the slab + finalize path has neither epilogue
   g.splits = splits;
   // LDS-DMA staging everywhere (measured fastest on every shape, hot or cold operands); a grid of <= 1 workgroup per CU

@@ -297,6 +297,7 @@ __global__ __launch_bounds__(NTHREADS) void lora_gemm_kernel(const GemmArgs<Plai
 // (A one-stage, three-workgroups-per-CU form of the kernel above -- 43 KB of LDS, 168 VGPRs, the tile waited for in every k-step --
 // was built and measured in round 4: bit-identical, 1.05-1.2x SLOWER on 16 of 18 shapes, profiles/r04_lora_three_workgroups.txt; its
 // source is at commit 1d72eae.  A third dependent chain per CU does not make up for losing the workgroup's own DMA / MFMA overlap.)
+#ifdef AQL_EXPERIMENTS   // shelved in round 4 (measured equal or slower); tools/build_alt.sh -DAQL_EXPERIMENTS builds it for A/B runs
 // EXPERIMENT, off by default (AQL_LORA_PERSIST / AQL_LORA_CFG=p128; measured equal or slower, see the launcher) --
 // persistent form of the 4-wave kernel for grids of several chip-wide rounds (ff.net.0 + GEGLU at the 64x64 level: 4096 tiles
 // of 128x160 = 8 rounds of two workgroups per CU).  A workgroup of the one-shot kernel spends 5-7k of its ~30k cycles before its
@@ -569,6 +570,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lora_gemm_kernel_p(const GemmArgs
   }
 #undef AQL_LBAR
 }
+#endif   // AQL_EXPERIMENTS
 
 // Wave-specialised form (as gemm_kernel_w in aql_gemm.cuh): 512 threads, wavefronts 4-7 only issue the LDS-DMA loads
 // (X tile, W tile and the 32 rows of A), wavefronts 0-3 only read fragments and issue MFMAs, with the fragments of the next
@@ -821,6 +823,7 @@ void launch_w(const GemmArgs<PlainLoader, PlainLoader>& g, const PlainLoader& la
   hipLaunchKernelGGL((lora_gemm_kernel_w<BM, BN, WM, WN, NSTG>), grid, dim3(2 * NTHREADS), 0, stream, g, la, lp);
 }
 
+#ifdef AQL_EXPERIMENTS
 // persistent 4-wave kernel: `wgs` resident workgroups (two per CU) walk all tiles
 template <int BM, int BN, int WM, int WN>
 void launch_p(const GemmArgs<PlainLoader, PlainLoader>& g, const PlainLoader& la, const LoraParams& lp, int wgs, hipStream_t stream) {
@@ -828,6 +831,7 @@ void launch_p(const GemmArgs<PlainLoader, PlainLoader>& g, const PlainLoader& la
   dim3 grid(ntiles < wgs ? ntiles : wgs);
   hipLaunchKernelGGL((lora_gemm_kernel_p<BM, BN, WM, WN>), grid, dim3(NTHREADS), 0, stream, g, la, lp, ntiles);
 }
+#endif
 
 template <int BM, int BN, int WM, int WN, int NSTG>
 void launch(const GemmArgs<PlainLoader, PlainLoader>& g, const PlainLoader& la, const LoraParams& lp, hipStream_t stream) {
@@ -963,8 +967,11 @@ static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long
       const int tiles = aql_cdiv(M, bm) * (N / 160);
       const bool shallow = cfg[strlen(cfg) - 1] == 's' || tiles > 288;
       bool ok = true;
+#ifdef AQL_EXPERIMENTS
       if (cfg[0] == 'p' && bm == 128) launch_p<128, 160, 64, 80>(g, la, lp, 512, stream);
-      else if (cfg[0] == 'w' && bm == 128) launch_w<128, 160, 64, 80, 3>(g, la, lp, stream);
+      else
+#endif
+      if (cfg[0] == 'w' && bm == 128) launch_w<128, 160, 64, 80, 3>(g, la, lp, stream);
       else if (cfg[0] == 'w' && bm == 64) launch_w<64, 160, 32, 80, 4>(g, la, lp, stream);
       else if (cfg[0] == 'w' && bm == 32) launch_w<32, 160, 16, 80, 5>(g, la, lp, stream);
       else if (cfg[0] == 'd' && bm == 128) { if (shallow) launch<128, 160, 64, 80, 2>(g, la, lp, stream); else launch<128, 160, 64, 80, 3>(g, la, lp, stream); }
@@ -1011,9 +1018,11 @@ static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long
       // tile's first K tile under the current tile's tail.  Measured round 4 (tools/probe_lora_persist.py, bit-identical on all 18
       // forms): 0.98x on ff.net.0 + GEGLU at 32768 x 2560 x 320 and 1.03-1.17x (SLOWER) everywhere else -- with two workgroups
       // per CU the dispatcher already starts a fresh workgroup's prologue under its neighbour's K loop (profiles/r04_lora_persistent.txt)
-      static const int persist_min = getenv("AQL_LORA_PERSIST") ? atoi(getenv("AQL_LORA_PERSIST")) : 0;
       if (t128 <= 288) launch<128, 160, 64, 80, 3>(g, la, lp, stream);
-      else if (persist_min > 0 && t128 >= persist_min) launch_p<128, 160, 64, 80>(g, la, lp, 512, stream);
+#ifdef AQL_EXPERIMENTS
+      else if (getenv("AQL_LORA_PERSIST") && atoi(getenv("AQL_LORA_PERSIST")) > 0 && t128 >= atoi(getenv("AQL_LORA_PERSIST")))
+        launch_p<128, 160, 64, 80>(g, la, lp, 512, stream);
+#endif
       else launch<128, 160, 64, 80, 2>(g, la, lp, stream);
     } else if (force_bm == 64 || (force_bm == 0 && t64 >= 200)) {
       if (t64 <= 288) launch<64, 160, 32, 80, 5>(g, la, lp, stream);

@@ -206,6 +206,52 @@ def profile_staleness():
     return {"kernel_sources_changed_since_profile": changed, "static_sections_current": not changed}
 
 
+def exchange_record(tr, device, world, iters=10):
+    """The gradient exchange ALONE, per rank (HIP events on the launch stream around the collective; the payload is the flat fp32
+    gradient buffer of the trainer): what the step's exchange costs when nothing hides it, and the bus bandwidth it implies for a ring
+    all-reduce, 2 (N - 1) / N x bytes / time.  Both forms are timed when both exist: the bucketed torch.distributed all-reduce (the
+    default) and aql_comm_all_reduce_f32 on the caller's stream (AQL_COMM=1).  With ONE rank RCCL does no transfer: the numbers
+    are the collective's launch floor, not a bandwidth."""
+    from aqualora_amd import dp
+    flat = tr.bank.grad[:tr.bank.numel]
+    nbytes = flat.numel() * 4
+    keep = flat.clone()
+    out = {"payload_bytes": nbytes, "ranks": world, "iters": iters}
+
+    def time_it(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        per_rank = [None] * world
+        if world > 1:
+            dist.all_gather_object(per_rank, ms)
+        else:
+            per_rank = [ms]
+        worst = max(per_rank)
+        return {"exchange_ms_per_rank": per_rank, "exchange_ms": worst,
+                "bus_GBps": (2.0 * (world - 1) / world * nbytes / (worst * 1e-3) / 1e9) if world > 1 else None}
+
+    if dp.exchange_active(tr.pg):
+        out["torch_distributed_allreduce"] = time_it(lambda: dp.allreduce_mean_(flat, tr.pg))
+        comm = tr.comm
+        if comm is not None:
+            out["aql_comm_allreduce"] = time_it(lambda: comm.all_reduce_(flat, average=True))
+        else:
+            out["aql_comm_allreduce"] = None
+            out["aql_comm_note"] = tr.comm_note
+    else:
+        out["note"] = "no exchange active (single process without AQL_FORCE_ALLREDUCE)"
+    flat.copy_(keep)
+    return out
+
+
 def config3_record(device, rank_id, steps=10, warmup=3):
     """BASELINE config 3 per GPU (rank 320, batch 8; train/README.md:34-48) on this GPU, as a sub-record of the default line:
     the same captured step, HIP-event median over `steps` replays with a fresh batch each."""
@@ -452,6 +498,7 @@ def robft_bench(args, device):
     bits = synth.bits("rob.bits", (B, 48), 1).to(device)
     distort = NZ.RobNoiser([0.6, 0.1, 0.15, 0.05, 0.1])
     gen = None
+    drawn = []
     if args.robft_sample:
         # the whole iteration of rob_enhance_finetune.py:997-1036: a fresh random message per image -> S = mapper(m) * 1.03,
         # concatenated for the two CFG halves (:999-1002) -> 20-step DPM-Solver++ sampling (CFG 7.5) through the UN-fused
@@ -480,6 +527,7 @@ def robft_bench(args, device):
         rng = random.Random(2048)
         sizes = [512, 576, 640, 704, 768] if args.robft_res == "random" else [int(args.robft_res)]
         it = [0]
+        drawn = []
 
         def gen():
             it[0] += 1
@@ -487,6 +535,7 @@ def robft_bench(args, device):
             with torch.no_grad():
                 S = mapper(bits.float()).to(torch.bfloat16) * 1.03
             h, w = rng.choice(sizes) // 8, rng.choice(sizes) // 8
+            drawn.append((h * 8, w * 8))
             lat = synth.normal(f"rob.lat{it[0]}", (B, 4, h, w), 1.0, 1, device)
             z = dpm_solver_sample(unet, ctx, torch.zeros_like(ctx), lat, 20, 7.5, scale=S)
             img = (vae.decode(z.clamp(-4, 4) * 0.18215) / 2 + 0.5).clamp(0, 1)
@@ -510,6 +559,14 @@ def robft_bench(args, device):
                 "value": B / dt, "unit": "images/sec", "ms_per_step": 1e3 * dt, "steps": args.steps, "dtype": "f32", "batch": B,
                 "achieved_tflops_fp32": gf / dt / 1e3, "loss": float(loss), "bit_acc_of_step": float(acc),
                 "finite": bool(torch.isfinite(loss)),
+                **({} if gen is not None else {"roofline": (lambda nb: {
+                    "bound": "hbm", "achieved": nb / dt / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nb / dt / 1e9 / 8000.0,
+                    "traffic": None, "bytes_per_step": nb,
+                    "model": "algorithmic bytes of the decoder step counted op by op, fp32, no fusion between ops "
+                             "(aqualora_amd.decoder.train_step_algorithmic_bytes: forward + backward-data + backward-weight of the "
+                             "EfficientNet-B1 maps); the distortion layer and AdamW (26 MB of state) are not counted"})(
+                                 __import__("aqualora_amd.decoder", fromlist=["x"]).train_step_algorithmic_bytes(B, 512))}),
+                **({"resolutions_drawn": drawn} if gen is not None else {}),
                 **({"generator": f"per-image messages, 20-step DPM-Solver++ sampling (CFG 7.5) through the un-fused rank-{args.rank} "
                                  f"watermark LoRA at {args.robft_res}x{args.robft_res} + VAE decode in front of the step "
                                  "(rob_enhance_finetune.py:997-1021): the WHOLE iteration"} if gen is not None else {})}
@@ -645,6 +702,7 @@ def main():
     images = args.batch * world * args.steps
     value = images / dt
     loss_v = float(loss)
+    exch = exchange_record(tr, device, world) if launched else None   # collective: every rank calls it
 
     if rank_id == 0:
         tf_img = step_tflop_per_image(args.rank)
@@ -653,7 +711,7 @@ def main():
             "metric": "PPFT train-step images/sec at 512x512", "value": value, "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "ms_per_step_hip_event_median": per_step[len(per_step) // 2], "ms_per_step_hip_event_min": per_step[0],
-            "rccl_ranks_seen": rccl_ranks_seen,
+            "rccl_ranks_seen": rccl_ranks_seen, "exchange_alone": exch,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"SD1.5 PPFT LoRA rank={args.rank}, 48-bit msg, 512x512 (64x64x4 latents in), "
                                    f"batch={args.batch}/GPU, " + ("pixel-in (frozen VAE encode inside the step" + (", CLIP text encoder inside" if args.text_in else ", CLIP outside") + ")"
@@ -734,9 +792,12 @@ def main():
             # ... and the whole iteration of the reference's loop at BASELINE's rank 320: the 20-step sampling of the batch's 16 images
             # through the un-fused LoRA + VAE decode in front of the decoder step (the sampling is ~97 % of it)
             rb = copy.copy(args)
-            rb.as_record, rb.steps, rb.warmup, rb.robft_sample, rb.robft_res, rb.rank = True, 2, 1, True, "512", 320
+            # ... at the reference's resolutions: height and width drawn per step from {512, 576, 640, 704, 768} (:1004-1005), so the
+            # timed steps include the capture of the sampling loop for every (height, width) pair seen for the first time
+            rb.as_record, rb.steps, rb.warmup, rb.robft_sample, rb.robft_res, rb.rank = True, 2, 1, True, "random", 320
             whole = robft_bench(rb, device)
-            line["config5"]["whole_iteration"] = {k: whole[k] for k in ("value", "unit", "ms_per_step", "steps", "generator", "finite")}
+            line["config5"]["whole_iteration"] = {k: whole[k] for k in ("value", "unit", "ms_per_step", "steps", "generator", "finite",
+                                                                         "resolutions_drawn")}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tr, args.rank)
         print(json.dumps(line), flush=True)

@@ -59,6 +59,99 @@ def test_vae_decode_of_16_images_reads_every_sample_through_1gib_descriptors():
     assert rc == 1 and b"spans" in L.load().aql_last_error()
 
 
+def test_full_size_unet_on_a_96x80_latent_vs_oracle():
+    """Config 5's generator samples at heights / widths drawn from {512..768} (rob_enhance_finetune.py:1004-1005): the FULL-SIZE U-Net
+    with the un-fused rank-320 watermark LoRA on a non-square 96 x 80 latent (768 x 640 pixels; 7680 / 1920 / 480 / 120 tokens per
+    level, maps whose widths no row-tile kernel was written for) against the bf16-mirroring CPU oracle, clean and watermarked."""
+    from aqualora_amd.lora import inject_lora
+    from aqualora_amd.unet import SD15, UNet2DConditionModel, init_synthetic, lora_keys
+    from oracle import ppft_oracle as O
+    _threads()
+    rank, seed = 320, 2048
+    unet = UNet2DConditionModel(device=DEV, dtype=torch.bfloat16)
+    init_synthetic(unet, seed)
+    keys = lora_keys(unet)
+    sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
+    inject_lora(unet, rank, keys)
+    lw = {}
+    with torch.no_grad():
+        for k in keys:
+            lay = unet.get_submodule(k).lora_layer
+            lay.down.weight.copy_(synth.normal(k + ".lora.down", lay.down.weight.shape, 1.0 / rank, seed, DEV))
+            lay.up.weight.copy_(synth.normal(k + ".lora.up", lay.up.weight.shape, 0.02, seed, DEV))
+            lw[k] = (lay.down.weight.detach().float().cpu(), lay.up.weight.detach().float().cpu())
+    x = synth.normal("ns.z", (1, 4, 96, 80), 1.0, seed)
+    ctx = synth.normal("ns.ctx", (1, 77, 768), 1.0, seed)
+    t = torch.tensor([700])
+    S = (1.0 + 0.5 * synth.normal("ns.S", (1, rank), 1.0, seed)) * 1.03
+    ref = O.UNetOracle(sd, dict(SD15), lw, bf16=True)
+    with torch.no_grad():
+        clean_o = ref.forward(x, t, ctx, None)
+        pred_o = ref.forward(x, t, ctx, S)
+        xb, cb = x.to(DEV), ctx.to(DEV).to(torch.bfloat16)
+        clean = unet(xb, t.to(DEV), cb, cross_attention_kwargs={"scale": None}).sample
+        pred = unet(xb, t.to(DEV), cb, cross_attention_kwargs={"scale": S.to(DEV)}).sample
+        pred2 = unet(xb, t.to(DEV), cb, cross_attention_kwargs={"scale": S.to(DEV)}).sample
+    assert pred.shape == (1, 4, 96, 80) and torch.equal(pred, pred2)
+    print(f"96x80 latent: clean {relerr(clean, clean_o):.3e} / {l2rel(clean, clean_o):.3e}, pred {relerr(pred, pred_o):.3e} / {l2rel(pred, pred_o):.3e}")
+    assert relerr(clean, clean_o) < 4e-2 and relerr(pred, pred_o) < 4e-2, (relerr(clean, clean_o), relerr(pred, pred_o))
+    assert l2rel(clean, clean_o) < 2e-2 and l2rel(pred, pred_o) < 2e-2
+    assert relerr(pred_o, clean_o) > 1e-3
+
+
+def test_stage1_step_assembled_at_config1_size_vs_oracle():
+    """BASELINE config 1 (latent_wm_pretrain.py:164-221) at its REAL sizes as ONE step on HIP: batch 2 of 64 x 64 x 4 latents ->
+    SecretEncoder(48 bits, base 32 -> 64) -> full-size frozen VAE decode (with its HIP backward) -> 2 x 3 x 512 x 512 -> EfficientNet-B1
+    in train mode -> BCE + LPIPS(VGG16) x 5 + PRVL x 1.5 (the late-phase loss, :207-209) -> backward into the encoder.  Against
+    oracle/roundtrip_oracle.py (the same forward in fp32 autograd on the CPU: message loss, BatchNorm running statistics after the
+    step); the encoder's gradient must be finite and non-zero through every term.  Every piece was tested at full size alone and the
+    assembled step at toy size (tests/test_roundtrip.py); this is where they meet."""
+    from aqualora_amd import noise as NZ, stage1 as S1
+    from aqualora_amd.lpips import LPIPS, synthetic_state_dict as lpips_sd
+    from aqualora_amd.vae import SD15_VAE, AutoencoderKL, synthetic_state_dict
+    from aqualora_amd.watermark import SecretEncoder
+    from oracle import roundtrip_oracle as RO
+    from tests import roundtrip as R
+    _threads()
+    B, bits, seed = 2, 48, 31
+    cfg = dict(R.default_cfg(), bits=bits, stage1_batch=B, stage1_fixinit=0)
+    vae_sd = synthetic_state_dict(SD15_VAE)
+    vae = AutoencoderKL(vae_sd, SD15_VAE, DEV)
+    st = dict(lin_w=synth.normal("c1.lin.w", (32 * 32, bits), bits ** -0.5, seed), lin_b=torch.zeros(32 * 32),
+              conv_w=synth.normal("c1.conv.w", (4, 4, 3, 3), 0.5, seed), conv_b=torch.zeros(4))
+    enc = SecretEncoder(bits, base_res=32, resolution=64)
+    with torch.no_grad():
+        enc.secret_scaler[0].weight.copy_(st["lin_w"])
+        enc.secret_scaler[0].bias.copy_(st["lin_b"])
+        enc.secret_scaler[5].weight.copy_(st["conv_w"])
+        enc.secret_scaler[5].bias.copy_(st["conv_b"])
+    enc = enc.to(DEV)
+    dec0 = R.make_decoder(cfg, "cpu")
+    dec = R.make_decoder(cfg, DEV).train()
+    pool = synth.normal("c1.pool", (8, 4, 64, 64), 0.18215 * 4.0, seed)      # scaled latents; stage1_batch divides by the VAE scaling
+    b = R.stage1_batch(0, pool.to(DEV), cfg, tag="c1.s1")
+    dd = R._DecoderWithDraws(dec)
+    dd.draws = dict(sd_noise=b["sd_noise"], drop_mask=b["drop_mask"])
+    step = S1.Stage1Step(enc, dd, lambda z: vae.decode_grad(z, scaled=False), NZ.Noiser(["Identity"], [1.0]), lpips_fn=LPIPS(lpips_sd(), DEV))
+    step.warmup = False
+    out = step.losses(b["lat"], b["msg"], epochs_done=11, combine=dict(cornerfy_aug=False), noiser_choice=[1.0])
+    assert all(torch.isfinite(out[k]).all() for k in ("loss", "msgloss", "lpips_loss")) and float(out["lpips_loss"]) > 0
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    for m in (enc.secret_scaler[0], enc.secret_scaler[5]):
+        g = m.weight.grad
+        assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
+    got = float(out["msgloss"].detach())
+    bc = {k: ([t.cpu() for t in v] if isinstance(v, list) else v.cpu()) for k, v in b.items()}
+    want, _, dec_o = RO.stage1_steps({k: v.cpu() for k, v in vae_sd.items()}, SD15_VAE, st, dec0.state_dict(), [bc], bits, 32, 64)
+    print(f"config-1 stage-1 step at full size: msgloss {got:.5f} (oracle {want[0]:.5f}), lpips {float(out['lpips_loss']):.4f}")
+    assert abs(got - want[0]) < 2e-2 * want[0], (got, want)
+    rm = dec.state_dict()["model.features.0.1.running_mean"].float().cpu()
+    rv = dec.state_dict()["model.features.0.1.running_var"].float().cpu()
+    assert float((rm - dec_o["features.0.1.running_mean"]).abs().max()) < 0.03 * float(dec_o["features.0.1.running_mean"].abs().max())
+    assert float((rv - dec_o["features.0.1.running_var"]).abs().max()) < 0.03 * float(dec_o["features.0.1.running_var"].abs().max())
+
+
 def test_full_size_guided_ddim_step_of_the_fused_unet_vs_oracle():
     """BASELINE config 4's inner loop at full size: the rank-32 watermark LoRA baked with a message (create_wm_lora.py:24-41) and
     fused into W (utils_eval.py:81-82), then ONE captured guided step of `ddim_sample` (U-Net on the CFG batch of 2 + aql_ddim_step,

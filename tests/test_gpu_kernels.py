@@ -73,10 +73,11 @@ def test_ops_parity():
     assert text.count("PASS") >= 93   # incl. the shift-in-the-MFMA forward under late spikes (fast path and overflow fallback), attention at 9216 / 6336 tokens (768 px and non-square rob-finetune samples)
 
 
-@pytest.mark.parametrize("env", [{"AQL_ATTN_FOLD": "0", "AQL_ATTN_DFOLD": "0"}, {"AQL_ATTN_FOLD": "2"}])
+@pytest.mark.parametrize("env", [{"AQL_ATTN_FOLD": "0", "AQL_ATTN_DFOLD": "0"}])
 def test_ops_parity_on_the_other_attention_loops(env):
-    """The running-maximum forward (also the overflow fallback of the default loop) with the per-element `dP - delta` backward, and
-    the opt-in forward with the shift inside the S-product: the same sweep as test_ops_parity."""
+    """The running-maximum forward (also the overflow fallback of the default loop) with the per-element `dP - delta` backward: the
+    same sweep as test_ops_parity.  (The shelved forward with the shift inside the S-product, AQL_ATTN_FOLD=2, left the product build
+    in round 5: it exists in -DAQL_EXPERIMENTS builds only, tools/build_alt.sh.)"""
     text = _run("probe_ops.py", env)
     assert text.count("PASS") >= 93
 
