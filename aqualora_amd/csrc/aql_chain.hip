@@ -32,29 +32,38 @@ using namespace aqlgemm;
 
 namespace aqlchain {
 
-constexpr int BM = 128, CH = 320, NTH = 512, NKT = CH / 32, LR = 32, MAXS = 4;
-constexpr int RES_BYTES = NKT * BM * 64;           // 81920
+constexpr int CH = 320, NTH = 512, NKT = CH / 32, LR = 32, MAXS = 4;
 constexpr int W_BYTES = CH * 64, L_BYTES = LR * 64, STAGE = W_BYTES + L_BYTES, NSTG = 3;
-constexpr int OFF_RING = RES_BYTES;
-constexpr int OFF_TS = OFF_RING + NSTG * STAGE;     // 149504
-constexpr int OFF_BIAS = OFF_TS + BM * 64;          // 157696
-constexpr int OFF_GAMMA = OFF_BIAS + MAXS * CH * 2;
-constexpr int OFF_BETA = OFF_GAMMA + CH * 2;
-constexpr int OFF_SROW = OFF_BETA + CH * 2;
-constexpr int LDS_TOTAL = OFF_SROW + 64;
-static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
+// LDS map of a workgroup that owns BM = 64 FM rows (FM = 2: the forward chains on twin batches, 128-row tiles; FM = 1: the backward
+// chains, whose 16384 rows would fill only half the chip with 128-row tiles)
+template <int FM>
+struct Lay {
+  static constexpr int BM = 64 * FM;
+  static constexpr int RES_BYTES = NKT * BM * 64;
+  static constexpr int OFF_RING = RES_BYTES;
+  static constexpr int OFF_TS = OFF_RING + NSTG * STAGE;
+  static constexpr int OFF_BIAS = OFF_TS + BM * 64;
+  static constexpr int OFF_GAMMA = OFF_BIAS + MAXS * CH * 2;
+  static constexpr int OFF_BETA = OFF_GAMMA + CH * 2;
+  static constexpr int OFF_SROW = OFF_BETA + CH * 2;
+  static constexpr int TOTAL = OFF_SROW + 64;
+};
+static_assert(Lay<2>::TOTAL <= 160 * 1024, "LDS budget");
+
+enum { RP_NONE = 0, RP_LN_FWD = 1, RP_LN_BWD = 2 };
 
 struct Stage {
   const bf16_t *W, *bias, *Ad, *Bup;   // W [320][ldw], bias [320] or null, Ad [32][320] or null (no LoRA), Bup [320][32]
   bf16_t *T, *Ts;                      // [M][32], rows >= row0
-  const bf16_t* res;                   // KEEP: residual rows [M][ldr] or null
+  const bf16_t* res;                   // KEEP: rows [M][ldr] added (bf16) to the tile -- the residual; LN backward: the gradient of the residual branch, added last
   bf16_t* out;                         // [M][ldo] or null
-  bf16_t* nout;                        // KEEP + ln: LayerNorm output [M][ldn] (rows >= nout_row0) or null
-  float* stats;                        // KEEP + ln: (mean, rstd) per row [M][2]
+  bf16_t* nout;                        // KEEP + forward LN: LayerNorm output [M][ldn] (rows >= nout_row0) or null
+  float* stats;                        // forward LN: (mean, rstd) per row [M][2], written; LN backward: the saved statistics, read
   const bf16_t *gamma, *beta;
-  long ldw, ldr, ldo, ldn;
+  const bf16_t* lnx;                   // LN backward: the LayerNorm's saved input rows [M][ldlx]
+  long ldw, ldr, ldo, ldn, ldlx;
   float eps;
-  int keep, ln, nout_row0;
+  int keep, ln, nout_row0;             // ln: RP_NONE / RP_LN_FWD / RP_LN_BWD
 };
 
 struct Args {
@@ -62,7 +71,9 @@ struct Args {
   long ldx;
   const bf16_t* S;   // [nsamples][32] scale rows
   int M, rps, row0, nstage;
+  int has_pre;        // a row pass on the chain INPUT in front of the first linear (backward chains: LN backward of the incoming gradient)
   long long* trace;   // tools/trace_chain.py (AQL_CHAIN_TRACE_BUF): 32 cycle stamps per (block, wave 0 / wave 4); null in production
+  Stage pre;          // row-pass fields only
   Stage st[MAXS];
 };
 
@@ -161,6 +172,64 @@ __device__ __forceinline__ void ln_rows8(uint4 (&x)[8], bool act, const uint4& g
   }
 }
 
+typedef uint32_t u32x4_t_fwd __attribute__((ext_vector_type(4)));
+// LayerNorm BACKWARD of EIGHT rows (lanes 0..39 one 16-byte chunk each): the arithmetic of ln_kernel<1, R, 1> (aql_norm.hip) per row --
+//   dv = dy * gamma;  xh = (x - mean) * rstd;  s1 = sum(dv) / C;  s2 = sum(dv * xh) / C;  dx = rstd * fma(-xh, s2, dv - s1)  (+ dres)
+// with the two row sums of all eight rows reduced by wave_sum8.  dy[r] is replaced by dx.
+__device__ __forceinline__ void lnb_rows8(uint4 (&dy)[8], const uint4 (&x)[8], const float (&mean)[8], const float (&rstd)[8], bool act,
+                                          const uint4& gr, const u32x4_t_fwd (&dres)[8], bool has_dres) {
+#pragma clang fp contract(off)
+  float dv[8][8], xh[8][8], s1[8], s2[8], ga[8];
+  const uint32_t gw[4] = {gr.x, gr.y, gr.z, gr.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    ga[2 * e] = bf16lo(gw[e]);
+    ga[2 * e + 1] = bf16hi(gw[e]);
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const uint32_t dw[4] = {dy[r].x, dy[r].y, dy[r].z, dy[r].w}, xw[4] = {x[r].x, x[r].y, x[r].z, x[r].w};
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j = 2 * e + h;
+        const float d0 = h ? bf16hi(dw[e]) : bf16lo(dw[e]), x0 = h ? bf16hi(xw[e]) : bf16lo(xw[e]);
+        dv[r][j] = d0 * ga[j];
+        xh[r][j] = (x0 - mean[r]) * rstd[r];
+        a1 += dv[r][j];
+        a2 = fmaf(dv[r][j], xh[r][j], a2);
+      }
+    }
+    s1[r] = act ? a1 : 0.f;
+    s2[r] = act ? a2 : 0.f;
+  }
+  float p0, p1, q0, q1;
+  wave_sum8(s1, p0, p1);
+  wave_sum8(s2, q0, q1);
+  p0 = p0 / CH;
+  p1 = p1 / CH;
+  q0 = q0 / CH;
+  q1 = q1 / CH;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const float m1 = pick8(p0, p1, r), m2 = pick8(q0, q1, r);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = rstd[r] * fmaf(-xh[r][j], m2, dv[r][j] - m1);
+    if (has_dres) {
+      const uint32_t rw[4] = {dres[r].x, dres[r].y, dres[r].z, dres[r].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[2 * e] += bf16lo(rw[e]);
+        o[2 * e + 1] += bf16hi(rw[e]);
+      }
+    }
+    dy[r] = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+  }
+}
+
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
@@ -187,15 +256,28 @@ template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-// at most 3 + n operations outstanding, n in {0, 10, 16, 36}: the stores of the previous stage's epilogue / row pass
+// at most 3 + n operations outstanding: n = the stores of the previous stage's DIRECT epilogue (5 FM) or row pass (8 FM rows out,
+// + 2 FM statistics + 8 FM rows nout for a forward LayerNorm); anything else waits for the stores too
 __device__ __forceinline__ void wait_tiles(int n) {
-  if (n == 0) wait_vm<3>();
-  else if (n == 10) wait_vm<13>();
-  else if (n == 16) wait_vm<19>();
-  else wait_vm<39>();
+  switch (n) {
+    case 0: wait_vm<3>(); break;
+    case 5: wait_vm<8>(); break;
+    case 8: wait_vm<11>(); break;
+    case 10: wait_vm<13>(); break;
+    case 16: wait_vm<19>(); break;
+    case 18: wait_vm<21>(); break;
+    case 36: wait_vm<39>(); break;
+    default: wait_vm<3>(); break;
+  }
 }
 
+// BWD: the row passes of this instance are LayerNorm BACKWARD passes (the backward chains); else forward (residual / LayerNorm).  Two
+// instances instead of a run-time mode: the backward pass holds 128 more floats per lane across its reductions, and one kernel with
+// both would take its register allocation (spills in the forward K loop).
+template <int FM, bool BWD>
 __global__ __launch_bounds__(NTH, 2) void chain_kernel(const Args a) {
+  using LY = Lay<FM>;
+  constexpr int BM = LY::BM, RW = 8 * FM;     // rows of the tile; rows a wavefront owns in a row pass
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -225,23 +307,25 @@ __global__ __launch_bounds__(NTH, 2) void chain_kernel(const Args a) {
     const int g = id / (CH / 8), c = id - g * (CH / 8);
     const bf16_t* b = a.st[g].bias;
     const uint4 v = b ? *reinterpret_cast<const uint4*>(b + c * 8) : make_uint4(0u, 0u, 0u, 0u);
-    *reinterpret_cast<uint4*>(lds + OFF_BIAS + g * CH * 2 + c * 16) = v;
+    *reinterpret_cast<uint4*>(lds + LY::OFF_BIAS + g * CH * 2 + c * 16) = v;
   }
-  for (int g = 0; g < a.nstage; ++g)
-    if (a.st[g].ln && tid < CH / 8) {
-      *reinterpret_cast<uint4*>(lds + OFF_GAMMA + tid * 16) = *reinterpret_cast<const uint4*>(a.st[g].gamma + tid * 8);
-      *reinterpret_cast<uint4*>(lds + OFF_BETA + tid * 16) = *reinterpret_cast<const uint4*>(a.st[g].beta + tid * 8);
-    }
+  if (tid < CH / 8) {
+    const bf16_t *gm = a.has_pre ? a.pre.gamma : nullptr, *bt = a.has_pre ? a.pre.beta : nullptr;
+    for (int g = 0; g < a.nstage; ++g)
+      if (a.st[g].ln) gm = a.st[g].gamma, bt = a.st[g].beta;
+    if (gm) *reinterpret_cast<uint4*>(lds + LY::OFF_GAMMA + tid * 16) = *reinterpret_cast<const uint4*>(gm + tid * 8);
+    if (bt) *reinterpret_cast<uint4*>(lds + LY::OFF_BETA + tid * 16) = *reinterpret_cast<const uint4*>(bt + tid * 8);
+  }
   if (tid < 4)
-    *reinterpret_cast<uint4*>(lds + OFF_SROW + tid * 16) =
+    *reinterpret_cast<uint4*>(lds + LY::OFF_SROW + tid * 16) =
         (lora_tile && a.S) ? *reinterpret_cast<const uint4*>(a.S + (long)(m0 / a.rps) * LR + tid * 8) : make_uint4(0u, 0u, 0u, 0u);
 
-  // ---- the chain input tile -> resident region: 80 instructions of 1 KB, 10 per wavefront (K tile kt, 16-row block rb)
+  // ---- the chain input tile -> resident region: 10 K tiles x BM / 16 instructions of 1 KB, 5 FM per wavefront
   {
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(a.X);
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      const int q = wave + 8 * i, kt = q >> 3, rb = q & 7;
+    for (int i = 0; i < 5 * FM; ++i) {
+      const int q = wave + 8 * i, kt = q / (BM / 16), rb = q % (BM / 16);
       const uint32_t voff = (uint32_t)(m0 + rb * 16 + drow) * (uint32_t)(a.ldx * 2) + dchunk;
       dma16(rsX, lds + kt * (BM * 64) + rb * 1024, voff, (uint32_t)kt * 64u);
     }
@@ -254,7 +338,7 @@ __global__ __launch_bounds__(NTH, 2) void chain_kernel(const Args a) {
   auto ring_next = [](int x) { return x + 1 == NSTG ? 0 : x + 1; };
   // W / LoRA-down K tile kt of one linear
   auto issue_w = [&](const __amdgpu_buffer_rsrc_t& rsW, uint32_t ldb, const __amdgpu_buffer_rsrc_t& rsL, int kt) __attribute__((always_inline)) {
-    char* dst = lds + OFF_RING + wr * STAGE;
+    char* dst = lds + LY::OFF_RING + wr * STAGE;
     const uint32_t soff = (uint32_t)kt * 64u, v0 = dr0 * ldb + dchunk;
     dma16(rsW, dst + wave * 1024, v0, soff);
     dma16(rsW, dst + (wave + 8) * 1024, v0 + 128u * ldb, soff);
@@ -263,7 +347,7 @@ __global__ __launch_bounds__(NTH, 2) void chain_kernel(const Args a) {
     wr = ring_next(wr);
   };
   auto issue_up = [&](const __amdgpu_buffer_rsrc_t& rsB) __attribute__((always_inline)) {   // the Bup tile [320][32]
-    char* dst = lds + OFF_RING + wr * STAGE;
+    char* dst = lds + LY::OFF_RING + wr * STAGE;
     const uint32_t v0 = dr0 * 64u + dchunk;
     dma16(rsB, dst + wave * 1024, v0, 0);
     dma16(rsB, dst + (wave + 8) * 1024, v0 + 128u * 64u, 0);
@@ -278,10 +362,129 @@ __global__ __launch_bounds__(NTH, 2) void chain_kernel(const Args a) {
     issue_w(rsW, (uint32_t)(s0.ldw * 2), rsL, 1);
   }
 
-  const int aoff = (wm * 32) * 64 + lo;            // A fragments: rows wm*32 + 16 i + l15 of a K tile
+  const int aoff = (wm * 16 * FM) * 64 + lo;       // A fragments: rows wm * 16 FM + 16 i + l15 of a K tile
   const int boff = (wn * 160) * 64 + lo;           // W fragments: rows wn*160 + 16 j + l15
   const int loff = W_BYTES + (wn * 16) * 64 + lo;  // LoRA-down fragment: rank rows wn*16 + l15
-  int pend = 0;                                    // row-pass stores of the previous stage still counted by vmcnt (per wavefront)
+  int pend = 0;                                    // stores of the previous stage still counted by vmcnt (per wavefront)
+
+  // ---- row pass over the resident tile: wavefront w owns rows RW w .. RW w + RW - 1, lanes 0..39 one 16-byte chunk each (whole
+  // 640-byte rows to / from HBM).  Branch-free: lanes 40..63 compute on chunk 0 and are switched off by out-of-range buffer offsets /
+  // a dummy LDS address.  Forward: tile + residual -> out; LayerNorm -> statistics, nout.  Backward: LayerNorm backward of the tile
+  // (the incoming gradient) with the saved input rows and statistics, + the residual branch's gradient -> out.
+  auto row_pass = [&](const Stage& s) __attribute__((always_inline)) {
+    const bool act = lane < CH / 8;
+    const int cl = act ? lane : 0;
+    const int mode = s.ln;
+    const bool has_res = s.res != nullptr;
+    const bool wr_n = mode == RP_LN_FWD && s.nout != nullptr && m0 >= s.nout_row0;    // block-uniform
+    const float eps = s.eps;
+    const uint32_t ldr2 = keep_s((uint32_t)(s.ldr * 2)), ldo2 = keep_s((uint32_t)(s.ldo * 2)), ldn2 = keep_s((uint32_t)(s.ldn * 2)),
+                   ldx2 = keep_s((uint32_t)(s.ldlx * 2));
+    const __amdgpu_buffer_rsrc_t rsR = make_rsrc(s.res), rsO = make_rsrc(s.out), rsN = make_rsrc(wr_n ? s.nout : nullptr),
+                                 rsS = make_rsrc(mode != RP_NONE ? s.stats : nullptr), rsX = make_rsrc(mode == RP_LN_BWD ? s.lnx : nullptr);
+    const uint32_t mrow = (uint32_t)(m0 + wave * RW);
+    const uint32_t vr = mrow * ldr2 + cl * 16, vx = mrow * ldx2 + cl * 16;
+    const uint32_t vo = act ? mrow * ldo2 + cl * 16 : OOB_ROW;
+    const uint32_t vn = act ? mrow * ldn2 + cl * 16 : OOB_ROW;
+    const int myrow = ((q4 & 1) << 1) | (q4 >> 1);             // the row (of four) whose statistics this lane's 16-lane row holds
+    const uint32_t vs4 = l15 == 0 ? (mrow + myrow) * 8u : OOB_ROW;
+    const int kbase = (cl >> 2) * (BM * 64);
+    auto laddr = [&](int rr) __attribute__((always_inline)) {
+      const int row = wave * RW + rr;      // wave-uniform
+      return kbase + row * 64 + (((cl & 3) ^ swz4(row)) << 4);
+    };
+    uint4 gr = make_uint4(0u, 0u, 0u, 0u), br = gr;
+    if (mode != RP_NONE) {
+      gr = *reinterpret_cast<const uint4*>(lds + LY::OFF_GAMMA + cl * 16);
+      br = *reinterpret_cast<const uint4*>(lds + LY::OFF_BETA + cl * 16);
+    }
+    auto batch = [&](auto res_tag, auto mode_tag, int r0) __attribute__((always_inline)) {
+      constexpr bool RES = decltype(res_tag)::value;
+      constexpr int MODE = decltype(mode_tag)::value;
+      uint4 xv[8];
+      u32x4_t rv[8];
+      if constexpr (MODE == RP_LN_BWD) {
+        u32x4_t xs[8];
+        u32x2_t st[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int rr = r0 + u;
+          xs[u] = __builtin_amdgcn_raw_buffer_load_b128(rsX, vx + rr * ldx2, 0, 0);
+          st[u] = __builtin_amdgcn_raw_buffer_load_b64(rsS, (mrow + rr) * 8u, 0, 0);       // the row's (mean, rstd): one address for the wavefront
+          if constexpr (RES) rv[u] = __builtin_amdgcn_raw_buffer_load_b128(rsR, vr + rr * ldr2, 0, 0);
+          xv[u] = *reinterpret_cast<const uint4*>(lds + laddr(rr));
+        }
+        uint4 xin[8];
+        float mean[8], rstd[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          xin[u] = make_uint4(xs[u].x, xs[u].y, xs[u].z, xs[u].w);
+          mean[u] = __uint_as_float(st[u].x);
+          rstd[u] = __uint_as_float(st[u].y);
+        }
+        lnb_rows8(xv, xin, mean, rstd, act, gr, rv, RES);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{xv[u].x, xv[u].y, xv[u].z, xv[u].w}, rsO, vo + (r0 + u) * ldo2, 0, 0);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int rr = r0 + u;
+          if constexpr (RES) rv[u] = __builtin_amdgcn_raw_buffer_load_b128(rsR, vr + rr * ldr2, 0, 0);
+          xv[u] = *reinterpret_cast<const uint4*>(lds + laddr(rr));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int rr = r0 + u;
+          if constexpr (RES) xv[u] = epi_add8(xv[u], make_uint4(rv[u].x, rv[u].y, rv[u].z, rv[u].w));
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{xv[u].x, xv[u].y, xv[u].z, xv[u].w}, rsO, vo + rr * ldo2, 0, 0);   // null descriptor: dropped
+        }
+        if constexpr (MODE == RP_LN_FWD) {
+          float ma, mb, ra, rb;
+          ln_rows8(xv, act, gr, br, eps, ma, mb, ra, rb);
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(ma), __float_as_uint(ra)}, rsS, vs4 + r0 * 8, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(mb), __float_as_uint(rb)}, rsS, vs4 + (r0 + 4) * 8, 0, 0);
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{xv[u].x, xv[u].y, xv[u].z, xv[u].w}, rsN, vn + (r0 + u) * ldn2, 0, 0);
+        }
+      }
+      if constexpr (RES || MODE != RP_NONE) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          char* const wp = act ? lds + laddr(r0 + u) : lds + LY::OFF_TS + lane * 16;
+          *reinterpret_cast<uint4*>(wp) = xv[u];
+        }
+      }
+    };
+    auto pass = [&](auto res_tag, auto mode_tag) __attribute__((always_inline)) {
+#pragma unroll
+      for (int b = 0; b < FM; ++b) batch(res_tag, mode_tag, 8 * b);
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if constexpr (BWD) {
+      if (has_res) pass(T_{}, std::integral_constant<int, RP_LN_BWD>{});
+      else pass(F_{}, std::integral_constant<int, RP_LN_BWD>{});
+    } else {
+      if (mode == RP_LN_FWD) {
+        if (has_res) pass(T_{}, std::integral_constant<int, RP_LN_FWD>{});
+        else pass(F_{}, std::integral_constant<int, RP_LN_FWD>{});
+      } else {
+        if (has_res) pass(T_{}, std::integral_constant<int, RP_NONE>{});
+        else pass(F_{}, std::integral_constant<int, RP_NONE>{});
+      }
+    }
+    return mode == RP_LN_FWD ? 18 * FM : 8 * FM;   // stores ISSUED per wavefront (dropped ones included)
+  };
+
+  if (a.has_pre) {   // backward chains: the incoming gradient goes through the LayerNorm backward before the first linear
+    wait_vm<6>();    // the input tile has landed (the two weight tiles behind it may still fly)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    pend = row_pass(a.pre);
+  }
 
   for (int g = 0; g < a.nstage; ++g) {
     const Stage& s = a.st[g];
@@ -310,9 +513,9 @@ __global__ __launch_bounds__(NTH, 2) void chain_kernel(const Args a) {
       }
     };
 
-    f32x4_t acc[2][10], tacc[2];
+    f32x4_t acc[FM][10], tacc[FM];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < FM; ++i) {
 #pragma unroll
       for (int j = 0; j < 10; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       tacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -323,7 +526,7 @@ __global__ __launch_bounds__(NTH, 2) void chain_kernel(const Args a) {
       constexpr bool LORA = decltype(lora_tag)::value;
 #pragma unroll
       for (int t = 0; t < NKT; ++t) {
-        // iterations 0 / 1: the previous stage's row-pass stores are YOUNGER than this tile's requests -- count past them; from
+        // iterations 0 / 1: the previous stage's stores are YOUNGER than this tile's requests -- count past them; from
         // iteration 2 on the awaited tile is younger than the stores, which have had two tiles' time to drain
         if (t < 2) wait_tiles(pend);
         else wait_vm<3>();
@@ -331,11 +534,11 @@ __global__ __launch_bounds__(NTH, 2) void chain_kernel(const Args a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t == 0) CH_STAMP();   // 1 + 6 g: the stage's first K tile (g = 0: and the chain input) has landed
-        const char* sW = lds + OFF_RING + rd * STAGE;
+        const char* sW = lds + LY::OFF_RING + rd * STAGE;
         const char* sA = lds + t * (BM * 64);
-        bf16x8_t fa[2], fb[10], fl;
+        bf16x8_t fa[FM], fb[10], fl;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(sA + aoff + i * 1024);
+        for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(sA + aoff + i * 1024);
 #pragma unroll
         for (int j = 0; j < 10; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(sW + boff + j * 1024);
         if constexpr (LORA) fl = *reinterpret_cast<const bf16x8_t*>(sW + loff);
@@ -343,9 +546,11 @@ __global__ __launch_bounds__(NTH, 2) void chain_kernel(const Args a) {
         for (int j = 0; j < 10; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[0], acc[0][j], 0, 0, 0);
         if constexpr (LORA) tacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl, fa[0], tacc[0], 0, 0, 0);
         issue_ahead(t + 2);
+        if constexpr (FM == 2) {
 #pragma unroll
-        for (int j = 0; j < 10; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[1], acc[1][j], 0, 0, 0);
-        if constexpr (LORA) tacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl, fa[1], tacc[1], 0, 0, 0);
+          for (int j = 0; j < 10; ++j) acc[FM - 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[FM - 1], acc[FM - 1][j], 0, 0, 0);
+          if constexpr (LORA) tacc[FM - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl, fa[FM - 1], tacc[FM - 1], 0, 0, 0);
+        }
         rd = ring_next(rd);
       }
     };
@@ -356,35 +561,37 @@ __global__ __launch_bounds__(NTH, 2) void chain_kernel(const Args a) {
 
     if (lora_g) {
       // ---- T -> (T, Ts) bf16; Ts as one more A tile; one k-step against the Bup tile of the ring
-      const uint2 sv = *reinterpret_cast<const uint2*>(lds + OFF_SROW + (wn * 16 + q4 * 4) * 2);
+      const uint2 sv = *reinterpret_cast<const uint2*>(lds + LY::OFF_SROW + (wn * 16 + q4 * 4) * 2);
       const __amdgpu_buffer_rsrc_t rsT = make_rsrc(s.T), rsTs = make_rsrc(s.Ts);
-      const uint32_t vt = (uint32_t)(m0 + wm * 32 + l15) * 64u + (uint32_t)(wn * 16 + q4 * 4) * 2u;
+      const uint32_t vt = (uint32_t)(m0 + wm * 16 * FM + l15) * 64u + (uint32_t)(wn * 16 + q4 * 4) * 2u;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = wm * 32 + i * 16 + l15;
+      for (int i = 0; i < FM; ++i) {
+        const int row = wm * 16 * FM + i * 16 + l15;
         const int r = wn * 16 + q4 * 4;
         const u32x2_t tv = {pack_bf16x2(tacc[i][0], tacc[i][1]), pack_bf16x2(tacc[i][2], tacc[i][3])};
         const u32x2_t ts = {pack_bf16x2(bf16lo(tv.x) * bf16lo(sv.x), bf16hi(tv.x) * bf16hi(sv.x)),
                             pack_bf16x2(bf16lo(tv.y) * bf16lo(sv.y), bf16hi(tv.y) * bf16hi(sv.y))};
-        *reinterpret_cast<u32x2_t*>(lds + OFF_TS + off64(row, r >> 3) + (r & 7) * 2) = ts;
-        __builtin_amdgcn_raw_buffer_store_b64(tv, rsT, vt, i * 1024, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(ts, rsTs, vt, i * 1024, 0);
+        *reinterpret_cast<u32x2_t*>(lds + LY::OFF_TS + off64(row, r >> 3) + (r & 7) * 2) = ts;
+        __builtin_amdgcn_raw_buffer_store_b64(tv, rsT, vt + i * 1024, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(ts, rsTs, vt + i * 1024, 0, 0);
       }
-      wait_vm<7>();   // in order: [Bup tile 3] [next tile 3] [T / Ts stores 4]
+      wait_vm<3 + 3 + 2 * FM>();   // in order: [Bup tile 3] [next tile 3] [T / Ts stores 2 FM]
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      const char* sW = lds + OFF_RING + rd * STAGE;
-      bf16x8_t fa[2], fb[10];
+      const char* sW = lds + LY::OFF_RING + rd * STAGE;
+      bf16x8_t fa[FM], fb[10];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(lds + OFF_TS + aoff + i * 1024);
+      for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(lds + LY::OFF_TS + aoff + i * 1024);
 #pragma unroll
       for (int j = 0; j < 10; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(sW + boff + j * 1024);
 #pragma unroll
       for (int j = 0; j < 10; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[0], acc[0][j], 0, 0, 0);
       issue_ahead(NKT + 2);
+      if constexpr (FM == 2) {
 #pragma unroll
-      for (int j = 0; j < 10; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[1], acc[1][j], 0, 0, 0);
+        for (int j = 0; j < 10; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[1], acc[1][j], 0, 0, 0);
+      }
       rd = ring_next(rd);
     } else if (keep) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -396,14 +603,14 @@ __global__ __launch_bounds__(NTH, 2) void chain_kernel(const Args a) {
     // ---- epilogue: bias in fp32, round to bf16; column blocks pairwise through v_permlane16_swap so that a lane holds 8 consecutive
     // columns (16 bytes): lane row q4 = 0 / 2 -> block 2jp, columns 0-7 / 8-15; q4 = 1 / 3 -> block 2jp + 1
     {
-      const char* sBias = lds + OFF_BIAS + g * CH * 2 + (wn * 160 + q4 * 4) * 2;
+      const char* sBias = lds + LY::OFF_BIAS + g * CH * 2 + (wn * 160 + q4 * 4) * 2;
       const int c0 = wn * 160 + (q4 & 1) * 16 + (q4 >> 1) * 8;       // + 32 jp
       const __amdgpu_buffer_rsrc_t rsO = make_rsrc(keep ? nullptr : s.out);
       const uint32_t ldo2 = keep ? 0u : (uint32_t)(s.ldo * 2);
-      const uint32_t vo = (uint32_t)(m0 + wm * 32 + l15) * ldo2 + (uint32_t)c0 * 2u;
+      const uint32_t vo = (uint32_t)(m0 + wm * 16 * FM + l15) * ldo2 + (uint32_t)c0 * 2u;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = wm * 32 + i * 16 + l15;
+      for (int i = 0; i < FM; ++i) {
+        const int row = wm * 16 * FM + i * 16 + l15;
         char* const ldst = lds + row * 64;
         const int sz = swz4(row);
 #pragma unroll
@@ -426,85 +633,14 @@ __global__ __launch_bounds__(NTH, 2) void chain_kernel(const Args a) {
     if (!keep) {
       CH_STAMP();
       CH_STAMP();
-      pend = 10;   // 2 x 5 output stores per wavefront
+      pend = 5 * FM;   // FM x 5 output stores per wavefront
       continue;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     CH_STAMP();   // 5 + 6 g: tile published
-
-    // ---- row pass: wavefront w owns rows 16 w .. 16 w + 15, lanes 0..39 one 16-byte chunk each (whole 640-byte rows to HBM).
-    // Branch-free: lanes 40..63 compute on chunk 0 and are switched off by out-of-range buffer offsets / a dummy LDS address.
-    {
-      const bool act = lane < CH / 8;
-      const int cl = act ? lane : 0;
-      const bool has_res = s.res != nullptr, has_out = s.out != nullptr, do_ln = s.ln != 0;
-      const bool wr_n = do_ln && s.nout != nullptr && m0 >= s.nout_row0;    // block-uniform
-      const float eps = s.eps;
-      const uint32_t ldr2 = keep_s((uint32_t)(s.ldr * 2)), ldo2 = keep_s((uint32_t)(s.ldo * 2)), ldn2 = keep_s((uint32_t)(s.ldn * 2));
-      const __amdgpu_buffer_rsrc_t rsR = make_rsrc(s.res), rsO = make_rsrc(s.out), rsN = make_rsrc(wr_n ? s.nout : nullptr),
-                                   rsS = make_rsrc(do_ln ? s.stats : nullptr);
-      const uint32_t mrow = (uint32_t)(m0 + wave * 16);
-      const uint32_t vr = mrow * ldr2 + cl * 16;
-      const uint32_t vo = act ? mrow * ldo2 + cl * 16 : OOB_ROW;
-      const uint32_t vn = act ? mrow * ldn2 + cl * 16 : OOB_ROW;
-      const uint32_t vs = lane == 0 ? mrow * 8u : OOB_ROW;
-      const int lbase = (cl >> 2) * (BM * 64) + (wave * 16) * 64;
-      uint4 gr = make_uint4(0u, 0u, 0u, 0u), br = gr;
-      if (do_ln) {
-        gr = *reinterpret_cast<const uint4*>(lds + OFF_GAMMA + cl * 16);
-        br = *reinterpret_cast<const uint4*>(lds + OFF_BETA + cl * 16);
-      }
-      // lane (16 k + rr' ...) of a wave_sum8 result: the (mean, rstd) pair of row rr is stored by lane 16 * (0, 2, 1, 3)[rr & 3]
-      const int myrow = ((q4 & 1) << 1) | (q4 >> 1);             // the row (of four) whose statistics this lane's 16-lane row holds
-      const uint32_t vs4 = l15 == 0 ? (mrow + myrow) * 8u : OOB_ROW;
-      auto batch = [&](auto res_tag, auto ln_tag, int r0) __attribute__((always_inline)) {
-        constexpr bool RES = decltype(res_tag)::value, LN = decltype(ln_tag)::value;
-        uint4 xv[8];
-        u32x4_t rv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int rr = r0 + u;   // row wave*16 + rr: swizzle term g[(rr >> 2) & 3]
-          if constexpr (RES) rv[u] = __builtin_amdgcn_raw_buffer_load_b128(rsR, vr, rr * ldr2, 0);
-          xv[u] = *reinterpret_cast<const uint4*>(lds + lbase + rr * 64 + ((((cl & 3)) ^ swz4(rr)) << 4));
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int rr = r0 + u;
-          if constexpr (RES) xv[u] = epi_add8(xv[u], make_uint4(rv[u].x, rv[u].y, rv[u].z, rv[u].w));
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{xv[u].x, xv[u].y, xv[u].z, xv[u].w}, rsO, vo + rr * ldo2, 0, 0);   // null descriptor: dropped
-        }
-        if constexpr (LN) {
-          float ma, mb, ra, rb;
-          ln_rows8(xv, act, gr, br, eps, ma, mb, ra, rb);
-          __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(ma), __float_as_uint(ra)}, rsS, vs4, r0 * 8, 0);
-          __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(mb), __float_as_uint(rb)}, rsS, vs4, (r0 + 4) * 8, 0);
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{xv[u].x, xv[u].y, xv[u].z, xv[u].w}, rsN, vn + (r0 + u) * ldn2, 0, 0);
-        }
-        if constexpr (RES || LN) {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int rr = r0 + u;
-            char* const wp = act ? lds + lbase + rr * 64 + ((((cl & 3)) ^ swz4(rr)) << 4) : lds + OFF_TS + lane * 16;
-            *reinterpret_cast<uint4*>(wp) = xv[u];
-          }
-        }
-      };
-      auto pass = [&](auto res_tag, auto ln_tag) __attribute__((always_inline)) {
-        batch(res_tag, ln_tag, 0);
-        batch(res_tag, ln_tag, 8);
-      };
-      if (has_res && do_ln) pass(std::true_type{}, std::true_type{});
-      else if (do_ln) pass(std::false_type{}, std::true_type{});
-      else if (has_res) pass(std::true_type{}, std::false_type{});
-      else pass(std::false_type{}, std::false_type{});
-      (void)has_out;
-      (void)vs;
-      pend = do_ln ? 36 : 16;   // stores ISSUED per wavefront (dropped ones included): 16 rows out, + 4 statistics + 16 rows nout
-    }
+    pend = row_pass(s);
     CH_STAMP();   // 6 + 6 g: row pass done
     // the next stage's first barrier publishes the rewritten tile
   }
@@ -515,17 +651,61 @@ __global__ __launch_bounds__(NTH, 2) void chain_kernel(const Args a) {
 
 }  // namespace aqlchain
 
+namespace {
+
+using namespace aqlchain;
+
+// shared tail of the two entry points: argument checks of the filled descriptor, tile height, launch
+int chain_launch(Args& a, long M, const char* name, bool bwd, hipStream_t stream) {
+  int nln = a.has_pre ? 1 : 0;
+  for (int g = 0; g < a.nstage; ++g) {
+    const Stage& s = a.st[g];
+    AQL_CHECK_ARG(s.W != nullptr && s.ldw >= CH && (long)CH * s.ldw * 2 < (long)BUF_BYTES, "%s: stage %d has no weight", name, g);
+    AQL_CHECK_ARG(s.Ad == nullptr || (s.Bup && s.T && s.Ts && a.S), "%s: stage %d: LoRA needs Bup, T, Ts and S", name, g);
+    AQL_CHECK_ARG(s.keep || (s.out != nullptr && s.res == nullptr && !s.ln), "%s: stage %d: a DIRECT stage writes `out` only", name, g);
+    AQL_CHECK_ARG(s.ln != RP_LN_FWD || (s.keep && s.gamma && s.beta && s.stats), "%s: stage %d: LayerNorm needs keep, gamma, beta, stats", name, g);
+    AQL_CHECK_ARG(s.ln != RP_LN_BWD || (s.keep && s.gamma && s.stats && s.lnx && s.out), "%s: stage %d: LayerNorm backward needs keep, gamma, stats, x, out", name, g);
+    AQL_CHECK_ARG(s.out == nullptr || (s.ldo >= CH && M * s.ldo * 2 < (long)BUF_BYTES), "%s: stage %d: output span", name, g);
+    AQL_CHECK_ARG(s.res == nullptr || (s.ldr >= CH && M * s.ldr * 2 < (long)BUF_BYTES), "%s: stage %d: residual span", name, g);
+    AQL_CHECK_ARG(s.lnx == nullptr || (s.ldlx >= CH && M * s.ldlx * 2 < (long)BUF_BYTES), "%s: stage %d: saved LayerNorm input span", name, g);
+    AQL_CHECK_ARG(s.nout == nullptr || (s.ldn >= CH && M * s.ldn * 2 < (long)BUF_BYTES && s.nout_row0 % 128 == 0), "%s: stage %d: LayerNorm output span / first row", name, g);
+    nln += s.ln ? 1 : 0;
+  }
+  AQL_CHECK_ARG(nln <= 1, "%s: at most one LayerNorm per chain", name);
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute((const void*)chain_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Lay<1>::TOTAL);
+    (void)hipFuncSetAttribute((const void*)chain_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Lay<2>::TOTAL);
+    (void)hipFuncSetAttribute((const void*)chain_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Lay<1>::TOTAL);
+    once = true;
+  }
+  {
+    const char* tb = getenv("AQL_CHAIN_TRACE_BUF");   // device address of the stamp buffer (tools/trace_chain.py)
+    a.trace = tb ? (long long*)strtoull(tb, nullptr, 0) : nullptr;
+  }
+  // 128-row tiles while they fill the chip (the twin forward: 256 tiles), 64-row tiles below that (the backward pass runs on the
+  // watermarked half only: 16384 rows = 128 tiles of 128 -- half the CUs idle -- or 256 of 64)
+  static const int force = getenv("AQL_CHAIN_BM") ? atoi(getenv("AQL_CHAIN_BM")) : 0;   // tuning hook
+  const bool small = force == 64 || (force == 0 && (M / 128 < 200 || M % 128 != 0 || a.rps % 128 != 0 || a.row0 % 128 != 0));
+  if (bwd) hipLaunchKernelGGL((chain_kernel<1, true>), dim3((unsigned)(M / 64)), dim3(NTH), Lay<1>::TOTAL, stream, a);   // (64-row tiles only)
+  else if (small) hipLaunchKernelGGL((chain_kernel<1, false>), dim3((unsigned)(M / 64)), dim3(NTH), Lay<1>::TOTAL, stream, a);
+  else hipLaunchKernelGGL((chain_kernel<2, false>), dim3((unsigned)(M / 128)), dim3(NTH), Lay<2>::TOTAL, stream, a);
+  AQL_CHECK_LAUNCH(name);
+  return AQL_OK;
+}
+
+}  // namespace
+
 extern "C" int aql_lora_chain_fwd(const bf16_t* X, long ldx, long M, int rows_per_sample, long lora_row0, const bf16_t* S, int nstage,
                                   const void* const* W, const long* ldw, const void* const* bias, const void* const* Adown,
                                   const void* const* Bup, void* const* T, void* const* Ts, const void* const* res, const long* ldr,
                                   void* const* out, const long* ldo, const int* keep, const int* ln, const void* const* gamma,
                                   const void* const* beta, const float* eps, void* const* stats, void* const* nout, const long* ldn,
                                   const long* nout_row0, hipStream_t stream) {
-  using namespace aqlchain;
   AQL_CHECK_ARG(X != nullptr && nstage >= 1 && nstage <= MAXS, "aql_lora_chain_fwd: 1..%d stages", MAXS);
-  AQL_CHECK_ARG(M > 0 && M % BM == 0 && M < (1L << 30), "aql_lora_chain_fwd: M = %ld must be a multiple of %d", M, BM);
-  AQL_CHECK_ARG(rows_per_sample > 0 && rows_per_sample % BM == 0, "aql_lora_chain_fwd: rows_per_sample %% %d != 0", BM);
-  AQL_CHECK_ARG(lora_row0 >= 0 && lora_row0 % BM == 0, "aql_lora_chain_fwd: lora_row0 %% %d != 0", BM);
+  AQL_CHECK_ARG(M > 0 && M % 64 == 0 && M < (1L << 30), "aql_lora_chain_fwd: M = %ld must be a multiple of 64", M);
+  AQL_CHECK_ARG(rows_per_sample > 0 && rows_per_sample % 64 == 0, "aql_lora_chain_fwd: rows_per_sample %% 64 != 0");
+  AQL_CHECK_ARG(lora_row0 >= 0 && lora_row0 % 64 == 0, "aql_lora_chain_fwd: lora_row0 %% 64 != 0");
   AQL_CHECK_ARG(ldx >= CH && (ldx % 8) == 0 && (long)M * ldx * 2 < (long)BUF_BYTES, "aql_lora_chain_fwd: input leading dimension / span");
   Args a;
   memset(&a, 0, sizeof(a));
@@ -536,11 +716,6 @@ extern "C" int aql_lora_chain_fwd(const bf16_t* X, long ldx, long M, int rows_pe
   a.rps = rows_per_sample;
   a.row0 = (int)lora_row0;
   a.nstage = nstage;
-  {
-    const char* tb = getenv("AQL_CHAIN_TRACE_BUF");   // device address of the stamp buffer (tools/trace_chain.py)
-    a.trace = tb ? (long long*)strtoull(tb, nullptr, 0) : nullptr;
-  }
-  int nln = 0;
   for (int g = 0; g < nstage; ++g) {
     Stage& s = a.st[g];
     s.W = (const bf16_t*)W[g];
@@ -555,7 +730,7 @@ extern "C" int aql_lora_chain_fwd(const bf16_t* X, long ldx, long M, int rows_pe
     s.out = out ? (bf16_t*)out[g] : nullptr;
     s.ldo = ldo ? ldo[g] : 0;
     s.keep = keep[g];
-    s.ln = ln ? ln[g] : 0;
+    s.ln = (ln && ln[g]) ? RP_LN_FWD : RP_NONE;
     s.gamma = gamma ? (const bf16_t*)gamma[g] : nullptr;
     s.beta = beta ? (const bf16_t*)beta[g] : nullptr;
     s.eps = eps ? eps[g] : 0.f;
@@ -563,22 +738,63 @@ extern "C" int aql_lora_chain_fwd(const bf16_t* X, long ldx, long M, int rows_pe
     s.nout = nout ? (bf16_t*)nout[g] : nullptr;
     s.ldn = ldn ? ldn[g] : 0;
     s.nout_row0 = nout_row0 ? (int)nout_row0[g] : 0;
-    AQL_CHECK_ARG(s.W != nullptr && s.ldw >= CH, "aql_lora_chain_fwd: stage %d has no weight", g);
-    AQL_CHECK_ARG(s.Ad == nullptr || (s.Bup && s.T && s.Ts && S), "aql_lora_chain_fwd: stage %d: LoRA needs Bup, T, Ts and S", g);
-    AQL_CHECK_ARG(s.keep || (s.out != nullptr && s.res == nullptr && !s.ln), "aql_lora_chain_fwd: stage %d: a DIRECT stage writes `out` only", g);
-    AQL_CHECK_ARG(!s.ln || (s.keep && s.gamma && s.beta && s.stats), "aql_lora_chain_fwd: stage %d: LayerNorm needs keep, gamma, beta, stats", g);
-    AQL_CHECK_ARG(s.out == nullptr || (s.ldo >= CH && M * s.ldo * 2 < (long)BUF_BYTES), "aql_lora_chain_fwd: stage %d: output span", g);
-    AQL_CHECK_ARG(s.res == nullptr || (s.ldr >= CH && M * s.ldr * 2 < (long)BUF_BYTES), "aql_lora_chain_fwd: stage %d: residual span", g);
-    AQL_CHECK_ARG(s.nout == nullptr || (s.ldn >= CH && M * s.ldn * 2 < (long)BUF_BYTES && s.nout_row0 % BM == 0), "aql_lora_chain_fwd: stage %d: LayerNorm output span / first row", g);
-    nln += s.ln ? 1 : 0;
   }
-  AQL_CHECK_ARG(nln <= 1, "aql_lora_chain_fwd: at most one LayerNorm per chain");
-  static bool once = false;
-  if (!once) {
-    (void)hipFuncSetAttribute((const void*)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-    once = true;
+  return chain_launch(a, M, "aql_lora_chain_fwd", false, stream);
+}
+
+extern "C" int aql_lora_chain_bwd(const bf16_t* dY, long lddy, long M, int rows_per_sample, const bf16_t* S, int nstage,
+                                  const void* const* Wt, const long* ldw, const void* const* BupT, const void* const* AT,
+                                  void* const* dTs, void* const* dT, void* const* dX, const long* lddx, const int* keep,
+                                  const void* const* ln_x, const long* ld_lnx, const void* const* ln_stats, const void* const* ln_gamma,
+                                  const void* const* ln_dres, const long* ld_dres, void* const* ln_out, const long* ld_lnout,
+                                  hipStream_t stream) {
+  AQL_CHECK_ARG(dY != nullptr && nstage >= 1 && nstage <= MAXS, "aql_lora_chain_bwd: 1..%d stages", MAXS);
+  AQL_CHECK_ARG(M > 0 && M % 64 == 0 && M < (1L << 30), "aql_lora_chain_bwd: M = %ld must be a multiple of 64", M);
+  AQL_CHECK_ARG(rows_per_sample > 0 && rows_per_sample % 64 == 0, "aql_lora_chain_bwd: rows_per_sample %% 64 != 0");
+  AQL_CHECK_ARG(lddy >= CH && (lddy % 8) == 0 && (long)M * lddy * 2 < (long)BUF_BYTES, "aql_lora_chain_bwd: input leading dimension / span");
+  Args a;
+  memset(&a, 0, sizeof(a));
+  a.X = dY;
+  a.ldx = lddy;
+  a.S = S;
+  a.M = (int)M;
+  a.rps = rows_per_sample;
+  a.row0 = 0;
+  a.nstage = nstage;
+  auto fill_ln = [&](Stage& s, int k) {   // entry k of the ln_* arrays: 0 = the pass on the chain input, g + 1 = behind stage g
+    s.ln = RP_LN_BWD;
+    s.lnx = (const bf16_t*)ln_x[k];
+    s.ldlx = ld_lnx[k];
+    s.stats = (float*)const_cast<void*>(ln_stats[k]);
+    s.gamma = (const bf16_t*)ln_gamma[k];
+    s.res = ln_dres ? (const bf16_t*)ln_dres[k] : nullptr;
+    s.ldr = ld_dres ? ld_dres[k] : 0;
+    s.out = (bf16_t*)ln_out[k];
+    s.ldo = ld_lnout[k];
+    s.keep = 1;
+  };
+  if (ln_x && ln_x[0]) {
+    a.has_pre = 1;
+    fill_ln(a.pre, 0);
+    AQL_CHECK_ARG(a.pre.stats && a.pre.gamma && a.pre.out && a.pre.ldo >= CH && a.pre.ldlx >= CH && M * a.pre.ldo * 2 < (long)BUF_BYTES &&
+                      M * a.pre.ldlx * 2 < (long)BUF_BYTES && (a.pre.res == nullptr || (a.pre.ldr >= CH && M * a.pre.ldr * 2 < (long)BUF_BYTES)),
+                  "aql_lora_chain_bwd: the LayerNorm backward on the chain input needs x, stats, gamma, out (spans < 1 GiB)");
   }
-  hipLaunchKernelGGL(chain_kernel, dim3((unsigned)(M / BM)), dim3(NTH), LDS_TOTAL, stream, a);
-  AQL_CHECK_LAUNCH("aql_lora_chain_fwd");
-  return AQL_OK;
+  for (int g = 0; g < nstage; ++g) {
+    Stage& s = a.st[g];
+    s.W = (const bf16_t*)Wt[g];
+    s.ldw = ldw[g];
+    s.Ad = BupT ? (const bf16_t*)BupT[g] : nullptr;
+    s.Bup = AT ? (const bf16_t*)AT[g] : nullptr;
+    s.T = dTs ? (bf16_t*)dTs[g] : nullptr;
+    s.Ts = dT ? (bf16_t*)dT[g] : nullptr;
+    s.keep = keep[g];
+    if (s.keep && ln_x && ln_x[g + 1]) {
+      fill_ln(s, g + 1);
+    } else {
+      s.out = dX ? (bf16_t*)dX[g] : nullptr;
+      s.ldo = lddx ? lddx[g] : 0;
+    }
+  }
+  return chain_launch(a, M, "aql_lora_chain_bwd", true, stream);
 }

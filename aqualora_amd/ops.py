@@ -640,6 +640,30 @@ def chain_fwd(x, ldx, M, rps, row0, S16, stages):
            longs("ldn"), longs("nout_row0"), L.stream_ptr())
 
 
+def chain_bwd(dy, lddy, M, rps, S16, stages, lns):
+    """aql_lora_chain_bwd (csrc/aql_chain.hip): backward-data of a chain.  ``stages``: dicts  Wt ldw BupT AT dTs dT dX lddx keep;
+    ``lns``: nstage + 1 entries (None or dict  x ldx stats gamma dres lddres out ldo): entry 0 = LayerNorm backward on the incoming
+    gradient, entry g + 1 = behind stage g."""
+    import ctypes
+    n = len(stages)
+    vp, lp_, ip = ctypes.c_void_p * n, ctypes.c_long * n, ctypes.c_int * n
+    vq, lq = ctypes.c_void_p * (n + 1), ctypes.c_long * (n + 1)
+
+    def ptrs(key):
+        return vp(*[(None if st.get(key) is None else st[key].data_ptr()) for st in stages])
+
+    def lptr(key):
+        return vq(*[(None if (e is None or e.get(key) is None) else e[key].data_ptr()) for e in lns])
+
+    def llong(key):
+        return lq(*[int((e or {}).get(key) or 0) for e in lns])
+
+    L.call("aql_lora_chain_bwd", L.ptr(dy), int(lddy), int(M), int(rps), L.ptr(S16), n,
+           ptrs("Wt"), lp_(*[int(st.get("ldw") or 0) for st in stages]), ptrs("BupT"), ptrs("AT"), ptrs("dTs"), ptrs("dT"), ptrs("dX"),
+           lp_(*[int(st.get("lddx") or 0) for st in stages]), ip(*[int(st.get("keep") or 0) for st in stages]),
+           lptr("x"), llong("ldx"), lptr("stats"), lptr("gamma"), lptr("dres"), llong("lddres"), lptr("out"), llong("ldo"), L.stream_ptr())
+
+
 _DOWN_COUNTERS = {}
 
 
@@ -1218,6 +1242,7 @@ def lora_linear(x2d, packed, site=None, S=None, S16=None, rps=1, residual=None, 
 
 # ------------------------------------------------------------------------- row-resident chains (csrc/aql_chain.hip)
 CHAIN = os.environ.get("AQL_CHAIN", "1") != "0"   # A/B hook: 0 = every linear / LayerNorm of the transformer block as its own launch
+CHAIN_BWD = os.environ.get("AQL_CHAIN_BWD", "1") != "0"   # A/B hook: 0 = the chains' backward as separate launches
 CHAIN_MIN_TILES = int(os.environ.get("AQL_CHAIN_MIN_TILES", "128"))   # below this many 128-row tiles the chip is mostly idle: unfused
 
 
@@ -1328,9 +1353,63 @@ class ChainFn(torch.autograd.Function):
         def add(a, b):
             return b if a is None else (a if b is None else a + b)
 
+        def queue_site(k, dy_k, dTs_k, dT_k):     # dS and the weight gradients of linear k, as _grouped_backward queues them
+            site = stages[k].site
+            nb = S16.shape[0]
+            if not DEFERRED.add_ds(dTs_k, T[k], ctx.ds_accum, nb, rps, 32):
+                L.call("aql_lora_ds", L.ptr(dTs_k), L.ptr(T[k]), nb, rps, 32, L.ptr(ctx.ds_accum), L.stream_ptr())
+            if not DEFERRED.add_tn(dy_k, Ts[k], site.gb):
+                gemm_tn_acc(dy_k, Ts[k], site.gb)
+            if not DEFERRED.add_tn(dT_k, X[k], site.ga):
+                gemm_tn_acc(dT_k, X[k], site.ga)
+
+        def bwd_stage(k, dTs_k, dT_k, **kw):
+            st_ = stages[k]
+            return dict(Wt=st_.packed.wt, ldw=st_.packed.wt.stride(0), BupT=st_.site.bt16, AT=st_.site.at16, dTs=dTs_k, dT=dT_k, **kw)
+
+        M = x2d.shape[0]
+        fused_bwd = (CHAIN_BWD and ctx.ds_accum is not None and DEFERRED is not None and M % 64 == 0 and rps % 64 == 0
+                     and M // 64 >= CHAIN_MIN_TILES and not ret_ds)
+        mk = lambda *shape: torch.empty(*shape, dtype=torch.bfloat16, device=x2d.device)   # noqa: E731
+
         g = len(stages) - 1
         while g >= 0:
             st = stages[g]
+            # ---- backward chains (aql_lora_chain_bwd): [a single DIRECT linear's backward ->] LayerNorm backward -> this linear's backward
+            if fused_bwd and st.keep and st.ln is not None and (g > 0 or ctx.needs_input_grad[0]):
+                ln_entry = dict(x=O[g], ldx=O[g].stride(0), stats=ST[g], gamma=st.ln.weight)
+                if g + 2 == len(stages) and dR is None and not stages[g + 1].keep and d_out[g + 1] is not None and d_n[g] is None:
+                    # to_q backward -> LayerNorm backward -> to_out backward (the mirror of chain `a`)
+                    k = g + 1
+                    dy_k = d_out[k].contiguous()
+                    dres = None if d_out[g] is None else d_out[g].contiguous()
+                    dhs, dx = mk(M, 320), mk(M, 320)
+                    dTs_k, dT_k, dTs_g, dT_g = mk(M, 32), mk(M, 32), mk(M, 32), mk(M, 32)
+                    chain_bwd(dy_k, dy_k.stride(0), M, rps, S16,
+                              [bwd_stage(k, dTs_k, dT_k, keep=1), bwd_stage(g, dTs_g, dT_g, dX=dx, lddx=320, keep=0)],
+                              [None, dict(ln_entry, dres=dres, lddres=0 if dres is None else dres.stride(0), out=dhs, ldo=320), None])
+                    queue_site(k, dy_k, dTs_k, dT_k)
+                    queue_site(g, dhs, dTs_g, dT_g)
+                    if st.use_res:
+                        d_res = dhs
+                    dR = dx
+                    g -= 1
+                    continue
+                dn = add(dR, d_n[g])
+                if dn is not None:
+                    # LayerNorm backward -> this linear's backward (norm3 -> attn2.to_out; norm1 -> proj_in)
+                    dn = dn.contiguous()
+                    dres = None if d_out[g] is None else d_out[g].contiguous()
+                    dhs, dx = mk(M, 320), mk(M, 320)
+                    dTs_g, dT_g = mk(M, 32), mk(M, 32)
+                    chain_bwd(dn, dn.stride(0), M, rps, S16, [bwd_stage(g, dTs_g, dT_g, dX=dx, lddx=320, keep=0)],
+                              [dict(ln_entry, dres=dres, lddres=0 if dres is None else dres.stride(0), out=dhs, ldo=320), None])
+                    queue_site(g, dhs, dTs_g, dT_g)
+                    if st.use_res:
+                        d_res = dhs
+                    dR = dx
+                    g -= 1
+                    continue
             if not st.keep:
                 lo_ = g
                 while lo_ > 0 and not stages[lo_ - 1].keep:

@@ -202,6 +202,24 @@ int aql_lora_chain_fwd(const bf16_t* X, long ldx, long M, int rows_per_sample, l
                        void* const* out, const long* ldo, const int* keep, const int* ln, const void* const* gamma,
                        const void* const* beta, const float* eps, void* const* stats, void* const* nout, const long* ldn,
                        const long* nout_row0, aql_stream_t stream);
+/* The mirrored BACKWARD chains (round 5): the backward-data passes of up to 4 of those linears with the LayerNorm backward between
+ * them, one launch, 64-row tiles (the backward pass runs on the watermarked half of the batch only).  Per linear the operands of
+ * aql_lora_gemm_fused's backward-data form: Wt = W^T [320][ldw], BupT = Bup^T [32][320], AT = A^T [320][32]; dTs, dT [M][32] out.
+ *   tile <- dY rows;   [ln_x[0] given: tile <- LayerNormBackward(tile; ln_x[0], ln_stats[0], ln_gamma[0]) + ln_dres[0];  ln_out[0] <- tile]
+ *   stage g:  dXg = tile.Wt_g^T + ((tile.BupT_g^T) * S[m / rps]).AT_g^T
+ *     keep_g = 1:  tile <- bf16(dXg);  ln_x[g + 1] given: tile <- LayerNormBackward(tile; ...[g + 1]) + ln_dres[g + 1];  ln_out[g + 1] <- tile
+ *     keep_g = 0:  dX_g <- bf16(dXg)                                                      (tile unchanged)
+ * LayerNormBackward is aql_layernorm_bwd's arithmetic per row (x = the LayerNorm's saved input, stats = its saved (mean, rstd), the
+ * residual branch's gradient ln_dres added last).  Replaces, bit for bit, the backward launches of BasicTransformerBlock
+ * (scripts/lib/original_unet.py:786-806 under autograd):  norm3 backward -> attn2.to_out backward;  attn2.to_q backward -> norm2
+ * backward -> attn1.to_out backward;  norm1 backward -> proj_in backward.  The ln_* arrays have nstage + 1 entries (entry 0: the pass
+ * on the chain input), every other per-stage argument nstage entries; all are HOST arrays.  At most one LayerNorm per chain.      */
+int aql_lora_chain_bwd(const bf16_t* dY, long lddy, long M, int rows_per_sample, const bf16_t* S, int nstage,
+                       const void* const* Wt, const long* ldw, const void* const* BupT, const void* const* AT,
+                       void* const* dTs, void* const* dT, void* const* dX, const long* lddx, const int* keep,
+                       const void* const* ln_x, const long* ld_lnx, const void* const* ln_stats, const void* const* ln_gamma,
+                       const void* const* ln_dres, const long* ld_dres, void* const* ln_out, const long* ld_lnout,
+                       aql_stream_t stream);
 
 /* ---- attention (csrc/aql_attn.hip) ---- F.scaled_dot_product_attention via diffusers AttnProcessor2_0 / twin
  * original_unet.py:688-704.  q/k/v/o: [B,N,H*d] with row strides ld*; lse,delta: [B,H,Nq] fp32.                   */

@@ -381,7 +381,7 @@ def test_full_size_batch4_twin_step_equals_the_mean_of_four_batch1_steps():
     loss4b, pred4b, _ = tr.forward_backward(z, msg, eps, t, ctx)
     g4b = tr.bank.grad[:n]
     assert torch.equal(pred4b, pred4)                                             # the forward pass is bit-identical ...
-    assert abs(loss4b.item() - loss4.item()) < 1e-6 * loss4.item()                # ... the MSE reduction uses fp32 atomics too
+    assert abs(loss4b.item() - loss4.item()) < 5e-6 * loss4.item()                # ... the MSE reduction uses fp32 atomics too (one run in ~20 exceeded 1e-6)
     spread_l2 = l2rel(g4b, g4)
     spread_max = ((g4b - g4).abs().max() / g4.abs().max()).item()
     print(f"atomic accumulation spread between two identical steps: l2rel {spread_l2:.2e}, max |diff| / max |g| {spread_max:.2e}")

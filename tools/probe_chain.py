@@ -118,4 +118,75 @@ for name, M, nb, twin, nq in [("a: to_out+res -> LN -> to_q", 32768, 8, True, 1)
         tu, tc = graph_time(run_unfused), graph_time(run_chain)
         line += f" | unfused {tu:.1f} us, chain {tc:.1f} us, ratio {tc / tu:.2f}"
     print(line, flush=True)
-print("ALL PASS" if ok_all else "SOME FAILED")
+print("forward chains: " + ("ok" if ok_all else "SOME FAILED"))
+
+# ---------------------------------------------------------------------------------------------------------------- backward chains
+# aql_lora_chain_bwd against  aql_layernorm_bwd / aql_lora_gemm_fused (backward-data operands)  in sequence, M = 16384 (64-row tiles)
+print("backward chains:", flush=True)
+ok_b = True
+for name, M, nb, pre, nst in [("B1: LN bwd -> to_out bwd", 16384, 4, True, 1), ("B2: to_q bwd -> LN bwd -> to_out bwd", 16384, 4, False, 2),
+                              ("B1 without a residual gradient", 16384, 4, True, 1), ("B2, 8192 rows", 8192, 2, False, 2)]:
+    rps = M // nb
+    dY, Xs, dres, S = rnd(M, C), rnd(M, C), rnd(M, C), rnd(nb, 32)
+    if "without" in name:
+        dres = None
+    gamma = rnd(C, std=0.3) + 1
+    stats = torch.stack([torch.randn(M, device=dev) * 0.1, torch.rand(M, device=dev) + 0.5], dim=1).contiguous()
+    lins = [dict(Wt=rnd(C, C, std=C ** -0.5), BupT=rnd(32, C, std=0.2), AT=rnd(C, 32, std=C ** -0.5)) for _ in range(nst)]
+
+    def lin_bwd(x, p):   # dTs = dY.Bup, dT = dTs * S, dX = dY.W + dT.A : the one-launch kernel with exchanged operands
+        y = torch.empty(M, C, dtype=torch.bfloat16, device=dev)
+        T = torch.empty(M, 32, dtype=torch.bfloat16, device=dev)
+        Ts = torch.empty_like(T)
+        L.check(L.call_raw("aql_lora_gemm_fused", L.ptr(x), C, L.ptr(p["Wt"]), C, M, C, C, L.ptr(p["BupT"]), L.ptr(S), rps, L.ptr(p["AT"]),
+                           None, None, 0, L.ptr(y), C, L.ptr(T), L.ptr(Ts), 0, L.stream_ptr()), "aql_lora_gemm_fused")
+        return y, T, Ts
+
+    def ln_bwd(dy):
+        dx = torch.empty_like(dy)
+        L.call("aql_layernorm_bwd", L.ptr(Xs), L.ptr(dy), M, C, L.ptr(gamma), L.ptr(stats), L.ptr(dres), L.ptr(dx), L.stream_ptr())
+        return dx
+
+    def run_unfused():
+        if pre:
+            dh = ln_bwd(dY)
+            return [dh] + list(lin_bwd(dh, lins[0]))
+        dn, T0, Ts0 = lin_bwd(dY, lins[0])
+        dh = ln_bwd(dn)
+        return [dh, T0, Ts0] + list(lin_bwd(dh, lins[1]))
+
+    mk = lambda *s: torch.full(s, float("nan"), dtype=torch.bfloat16, device=dev)  # noqa: E731
+    dh2 = mk(M, C)
+    outs2 = [(mk(M, C), mk(M, 32), mk(M, 32)) for _ in range(nst)]
+    ln_entry = dict(x=Xs, ldx=C, stats=stats, gamma=gamma, dres=dres, lddres=C, out=dh2, ldo=C)
+    if pre:
+        stages = [dict(lins[0], ldw=C, dTs=outs2[0][1], dT=outs2[0][2], dX=outs2[0][0], lddx=C, keep=0)]
+        lns = [ln_entry, None]
+    else:
+        stages = [dict(lins[0], ldw=C, dTs=outs2[0][1], dT=outs2[0][2], keep=1),
+                  dict(lins[1], ldw=C, dTs=outs2[1][1], dT=outs2[1][2], dX=outs2[1][0], lddx=C, keep=0)]
+        lns = [None, ln_entry, None]
+
+    def run_chain():
+        ops.chain_bwd(dY, C, M, rps, S, stages, lns)
+
+    ref = run_unfused()
+    run_chain()
+    torch.cuda.synchronize()
+    if pre:
+        got = [dh2, outs2[0][0], outs2[0][1], outs2[0][2]]
+    else:
+        got = [dh2, outs2[0][1], outs2[0][2], outs2[1][0], outs2[1][1], outs2[1][2]]
+    same = [eq(a_, b_) for a_, b_ in zip(ref, got)]
+    ok = all(same)
+    ok_b &= ok
+    line = f"{'PASS' if ok else 'FAIL'} chain [{name}] M{M}: bit-identical {same}"
+    if not ok:
+        for a_, b_ in zip(ref, got):
+            d = (a_.float() - b_.float()).abs()
+            line += f" | {int((d > 0).sum())} differ / nan {int(torch.isnan(b_.float()).sum())}"
+    if TIME:
+        tu, tc = graph_time(run_unfused), graph_time(run_chain)
+        line += f" | unfused {tu:.1f} us, chain {tc:.1f} us, ratio {tc / tu:.2f}"
+    print(line, flush=True)
+print("ALL PASS" if (ok_all and ok_b) else "SOME FAILED")
