@@ -1257,14 +1257,19 @@ class ChainStage:
 
 
 def chain_ok(x2d, stages, S16, rps):
-    """The chain kernel takes these linears: 320 -> 320, rank-32 LoRA with bf16 scale rows, whole 128-row tiles, enough of them."""
-    if not CHAIN or REF_ROUNDING or S16 is None or x2d.dtype != torch.bfloat16 or x2d.dim() != 2 or x2d.stride(1) != 1:
+    """The chain kernel takes these linears: 320 -> 320, all with the rank-32 LoRA (bf16 scale rows) or all without (the fused-weight /
+    clean passes: S16 None), whole 64-row tiles, enough of them to fill half the chip."""
+    if not CHAIN or REF_ROUNDING or x2d.dtype != torch.bfloat16 or x2d.dim() != 2 or x2d.stride(1) != 1:
         return False
     M = x2d.shape[0] * (2 if _full(x2d) is not None else 1)
-    if x2d.shape[1] != 320 or M % 128 or rps % 128 or M // 128 < CHAIN_MIN_TILES or (M * x2d.stride(0) * 2) >= (1 << 30):
+    if x2d.shape[1] != 320 or M % 64 or rps % 64 or M // 64 < CHAIN_MIN_TILES or (M * x2d.stride(0) * 2) >= (1 << 30):
+        return False
+    if S16 is None and M // 64 < 2 * CHAIN_MIN_TILES:
+        # LoRA-free passes at CFG batch 2 (8192 rows = 128 tiles of 64, half the chip): measured 5.56 vs 5.54 ms per guided forward
+        # against the per-launch path, whose q | k | v is ONE 960-wide GEMM on 768 tiles (tools/time_infer_forward.py) -- not taken
         return False
     for st in stages:
-        if st.packed.N != 320 or st.packed.K != 320 or st.site is None or st.site.rank != 32:
+        if st.packed.N != 320 or st.packed.K != 320 or (S16 is None) != (st.site is None) or (st.site is not None and st.site.rank != 32):
             return False
     return os.environ.get("AQL_LORA_FUSED", "1") != "0"
 
@@ -1288,15 +1293,18 @@ class ChainFn(torch.autograd.Function):
         resk = None
         if res is not None:
             resk = _need_full(res, "the residual") if twin else res
-        S16k = _need_full(S16, "the LoRA scale") if twin else S16
+        lora = S16 is not None
+        S16k = (_need_full(S16, "the LoRA scale") if twin else S16) if lora else None
         row0 = M if (twin and _TWIN_SKIP) else 0
         kst, outs, saved = [], [], [x2d, S16]
         meta = []
         for st in stages:
-            Tk, T = _alloc((M, 32), torch.bfloat16, dev, twin)
-            Tsk, Ts = _alloc((M, 32), torch.bfloat16, dev, twin)
-            d = dict(W=st.packed.w, ldw=st.packed.w.stride(0), bias=st.packed.bias, Ad=st.site.a16, Bup=st.site.b16, T=Tk, Ts=Tsk,
-                     keep=int(st.keep))
+            d = dict(W=st.packed.w, ldw=st.packed.w.stride(0), bias=st.packed.bias, keep=int(st.keep))
+            T = Ts = None
+            if lora:
+                Tk, T = _alloc((M, 32), torch.bfloat16, dev, twin)
+                Tsk, Ts = _alloc((M, 32), torch.bfloat16, dev, twin)
+                d.update(Ad=st.site.a16, Bup=st.site.b16, T=Tk, Ts=Tsk)
             ok = o = nk = n = stk = stt = None
             if st.emit_out or st.ln is not None or not st.keep:
                 ok, o = _alloc((M, C), torch.bfloat16, dev, twin)
@@ -1316,6 +1324,8 @@ class ChainFn(torch.autograd.Function):
             meta.append((len(saved), o is not None, n is not None))
             saved += [T, Ts] + ([o] if o is not None else []) + ([n, stt] if n is not None else [])
         chain_fwd(xk, xk.stride(0), xk.shape[0], rps, row0, S16k, kst)
+        if not lora:   # the LoRA-free chains run under no_grad only (the clean pass / sampling with fused weights): nothing to save
+            return tuple(outs)
         ctx.stages, ctx.meta, ctx.rps = stages, meta, rps
         ctx.ds_accum = getattr(S, "_aql_ds_accum", None)
         ctx.s_dtype = S.dtype
@@ -1369,7 +1379,7 @@ class ChainFn(torch.autograd.Function):
 
         M = x2d.shape[0]
         fused_bwd = (CHAIN_BWD and ctx.ds_accum is not None and DEFERRED is not None and M % 64 == 0 and rps % 64 == 0
-                     and M // 64 >= CHAIN_MIN_TILES and not ret_ds)
+                     and M // 64 >= CHAIN_MIN_TILES)      # (dS goes to the trainer's accumulator, as in _grouped_backward's one-launch branch)
         mk = lambda *shape: torch.empty(*shape, dtype=torch.bfloat16, device=x2d.device)   # noqa: E731
 
         g = len(stages) - 1

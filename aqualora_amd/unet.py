@@ -330,29 +330,39 @@ class Transformer2DModel(nn.Module):
             attn2.to_out + residual -> norm3            |  (feed-forward and proj_out: the existing launches)
         13 launches of the block become 8; every tensor has the bits of the per-launch path (tests/test_gpu_kernels.py).  Returns
         None when the chain form does not apply (other widths, ranks, float scale, no LoRA, small batches: ops.chain_ok)."""
-        if (not ops.CHAIN or len(self.transformer_blocks) != 1 or not torch.is_tensor(scale) or scale.dim() != 2 or scale.shape[1] != 32
-                or n.dtype != torch.bfloat16 or n.shape[1] != 320):
+        nolora = scale is None and not torch.is_grad_enabled()     # the clean pass alone / sampling with the LoRA fused into W
+        if not ops.CHAIN or len(self.transformer_blocks) != 1 or n.dtype != torch.bfloat16 or n.shape[1] != 320:
+            return None
+        if not nolora and (not torch.is_tensor(scale) or scale.dim() != 2 or scale.shape[1] != 32):
             return None
         blk = self.transformer_blocks[0]
         a1, a2 = blk.attn1, blk.attn2
         hosts = (self.proj_in, a1.to_q, a1.to_k, a1.to_v, a1.to_out[0], a2.to_q, a2.to_out[0])
-        if any(m.lora_layer is None or _has_alpha(m) for m in hosts) or any(m.bias is not None for m in (a1.to_q, a1.to_k, a1.to_v, a2.to_q)):
+        if any(m.bias is not None for m in (a1.to_q, a1.to_k, a1.to_v, a2.to_q)):
             return None
-        kv = getattr(ctx, "_aql_kv", None)   # k | v of all cross-attentions, computed in front of the U-Net (UNet._ctx_kv)
-        if kv is None or id(a2) not in kv:
+        if not nolora and any(m.lora_layer is None or _has_alpha(m) for m in hosts):
             return None
-        from .lora import _scale16, _site_of
         B, C, H, W = n.shape
         N = H * W
+        if nolora:
+            kvs = getattr(ctx, "_aql_kv_static", None)      # a sampling loop computed them once per prompt (UNet.text_kv)
+            kv = None if kvs is None or id(a2) not in kvs else kvs
+        else:
+            kv = getattr(ctx, "_aql_kv", None)   # k | v of all cross-attentions, computed in front of the U-Net (UNet._ctx_kv)
+            if kv is None or id(a2) not in kv:
+                return None
+        from .lora import _scale16, _site_of
         n = ops.as_cl(n)
         x2d = ops.nhwc_view(n).reshape(B * N, C)
         pk = {m: _packed_linear(m) for m in hosts}
-        st = {m: _site_of(m.lora_layer) for m in hosts}
-        S = _scale16(scale, B, 32, x2d.device)
-        S16 = getattr(S, "_aql_s16", None)
-        if S16 is None:
-            S16 = S.detach().to(torch.bfloat16).contiguous()
-            S._aql_s16 = S16
+        st = {m: (None if nolora else _site_of(m.lora_layer)) for m in hosts}
+        S = S16 = None
+        if not nolora:
+            S = _scale16(scale, B, 32, x2d.device)
+            S16 = getattr(S, "_aql_s16", None)
+            if S16 is None:
+                S16 = S.detach().to(torch.bfloat16).contiguous()
+                S._aql_s16 = S16
         CS = ops.ChainStage
         d_stages = [CS(pk[self.proj_in], st[self.proj_in], True, ln=blk.norm1)] + \
                    [CS(pk[m], st[m], False) for m in (a1.to_q, a1.to_k, a1.to_v)]
@@ -362,7 +372,7 @@ class Transformer2DModel(nn.Module):
         o1 = ops.attention(q.view(B, N, C), k.view(B, N, C), v.view(B, N, C), a1.heads).reshape(B * N, C)
         h1, q2 = ops.lora_chain(o1, h0, S, S16, N, [CS(pk[a1.to_out[0]], st[a1.to_out[0]], True, use_res=True, ln=blk.norm2),
                                                     CS(pk[a2.to_q], st[a2.to_q], False)])
-        k2, v2 = kv[id(a2)]
+        k2, v2 = kv[id(a2)] if kv is not None else a2._text_kv(ctx)
         o2 = ops.attention(q2.view(B, N, C), k2, v2, a2.heads).reshape(B * N, C)
         h2, n3 = ops.lora_chain(o2, h1, S, S16, N, [CS(pk[a2.to_out[0]], st[a2.to_out[0]], True, use_res=True, ln=blk.norm3, emit_n=True)])
         tokens = blk.ff(n3.view(B, N, C), scale, residual=h2.view(B, N, C))

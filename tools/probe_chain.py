@@ -17,14 +17,18 @@ TIME = len(sys.argv) > 1 and sys.argv[1] == "time"
 ok_all = True
 
 
-def lin(bias=True):
-    return dict(W=rnd(C, C, std=C ** -0.5), bias=rnd(C, std=0.1) if bias else None, Ad=rnd(32, C, std=C ** -0.5), Bup=rnd(C, 32, std=0.2))
+def lin(bias=True, lora=True):
+    return dict(W=rnd(C, C, std=C ** -0.5), bias=rnd(C, std=0.1) if bias else None, Ad=rnd(32, C, std=C ** -0.5) if lora else None,
+                Bup=rnd(C, 32, std=0.2) if lora else None)
 
 
 def unfused_linear(x, p, S, rps, row0, res, M):
     y = torch.empty(M, C, dtype=torch.bfloat16, device=dev)
     T = torch.full((M, 32), float("nan"), dtype=torch.bfloat16, device=dev)
     Ts = torch.full((M, 32), float("nan"), dtype=torch.bfloat16, device=dev)
+    if p["Ad"] is None:     # the LoRA-free linear of the clean / inference passes
+        ops.gemm_bf16(x, p["W"], p["bias"], residual=res, out=y)
+        return y, T, Ts
     rc = L.call_raw("aql_lora_gemm_fused", L.ptr(x), C, L.ptr(p["W"]), C, M, C, C, L.ptr(p["Ad"]), L.ptr(S), rps, L.ptr(p["Bup"]),
                     L.ptr(p["bias"]), L.ptr(res), 0 if res is None else C, L.ptr(y), C, L.ptr(T), L.ptr(Ts), row0, L.stream_ptr())
     L.check(rc, "aql_lora_gemm_fused")
@@ -62,15 +66,17 @@ def eq(a, b, row0=0):
 
 for name, M, nb, twin, nq in [("a: to_out+res -> LN -> to_q", 32768, 8, True, 1), ("d: proj_in -> LN -> q|k|v", 32768, 8, True, 3),
                               ("a, no twin", 16384, 4, False, 1), ("b': to_out+res -> LN", 32768, 8, True, 0),
-                              ("a, 2 rounds", 65536, 16, True, 1)]:
+                              ("a, 2 rounds", 65536, 16, True, 1), ("a, batch-1 twin (64-row tiles)", 8192, 2, True, 1),
+                              ("d, no LoRA, CFG batch 2 (64-row tiles)", 8192, 2, False, 3), ("a, no LoRA, CFG batch 2", 8192, 2, False, 1)]:
     rps = M // nb
     row0 = M // 2 if twin else 0
+    nolora = "no LoRA" in name
     X, R = rnd(M, C), rnd(M, C)
     S = rnd(nb, 32)
     if twin:
         S[: nb // 2] = 0
-    p0 = lin()
-    qs = [lin(bias=False) for _ in range(nq)]
+    p0 = lin(lora=not nolora)
+    qs = [lin(bias=False, lora=not nolora) for _ in range(nq)]
     gamma, beta = rnd(C, std=0.3) + 1, rnd(C, std=0.1)
 
     def run_unfused():
@@ -96,12 +102,14 @@ for name, M, nb, twin, nq in [("a: to_out+res -> LN -> to_q", 32768, 8, True, 1)
     hs, T0, Ts0, n, st, outs = run_unfused()
     run_chain()
     torch.cuda.synchronize()
-    checks = {"hs": eq(hs, hs2), "T0": eq(T0, T2[0], row0), "Ts0": eq(Ts0, Ts2[0], row0), "ln": eq(n, n2, row0 if nq else 0),
-              "stats": torch.equal(st, st2)}
+    checks = {"hs": eq(hs, hs2), "ln": eq(n, n2, row0 if nq else 0), "stats": torch.equal(st, st2)}
+    if not nolora:
+        checks.update(T0=eq(T0, T2[0], row0), Ts0=eq(Ts0, Ts2[0], row0))
     for i, (y, T, Ts) in enumerate(outs):
         checks[f"q{i}"] = eq(y, q2[i])
-        checks[f"T{i + 1}"] = eq(T, T2[i + 1], row0)
-        checks[f"Ts{i + 1}"] = eq(Ts, Ts2[i + 1], row0)
+        if not nolora:
+            checks[f"T{i + 1}"] = eq(T, T2[i + 1], row0)
+            checks[f"Ts{i + 1}"] = eq(Ts, Ts2[i + 1], row0)
     ok = all(checks.values())
     ok_all &= ok
     bad = [k for k, v in checks.items() if not v]
