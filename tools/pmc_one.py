@@ -1,5 +1,5 @@
 """One GEMM / conv shape, a handful of launches: the workload for rocprofv3 --pmc passes (tools/pmc_run.sh).
-usage: pmc_one.py gemm M N K | conv B H Cin Cout | lora M N K | geglu M F K | attn B S heads | tntr M P Q"""
+usage: pmc_one.py gemm M N K | conv B H Cin Cout | lora M N K | geglu M F K | attn B S heads | tntr M P Q | chain M"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -42,6 +42,19 @@ elif kind == "attn":   # self-attention forward + backward, head dim 40
             o = ops.attention(q, k, v, heads)
             o.backward(do)
         return f
+elif kind == "chain":   # the row-resident chain  attn.to_out + residual -> LayerNorm -> to_q  on a twin batch (csrc/aql_chain.hip)
+    from aqualora_amd import ops
+    M, = a
+    C = 320
+    def mk():
+        X, R = rnd(M, C), rnd(M, C)
+        S = torch.cat([torch.zeros(4, 32, device=dev), torch.randn(4, 32, device=dev)]).to(torch.bfloat16)
+        lin = lambda bias: dict(W=rnd(C, C), bias=rnd(C) if bias else None, Ad=rnd(32, C), Bup=rnd(C, 32), ldw=C)
+        e = lambda *sh: torch.empty(*sh, dtype=torch.bfloat16, device=dev)
+        st = [dict(lin(True), T=e(M, 32), Ts=e(M, 32), res=R, ldr=C, out=e(M, C), ldo=C, keep=1, ln=1, gamma=rnd(C), beta=rnd(C), eps=1e-5,
+                   stats=torch.empty(M, 2, device=dev), nout=e(M, C), ldn=C, nout_row0=M // 2),
+              dict(lin(False), T=e(M, 32), Ts=e(M, 32), out=e(M, C), ldo=C, keep=0)]
+        return lambda: ops.chain_fwd(X, C, M, M // 8, M // 2, S, st)
 elif kind == "tntr":
     from aqualora_amd import ops
     M, P, Q = a
