@@ -271,13 +271,128 @@ __device__ __forceinline__ void wait_tiles(int n) {
   }
 }
 
+// ---- row pass over the resident tile: wavefront w owns rows RW w .. RW w + RW - 1, lanes 0..39 one 16-byte chunk each (whole
+// 640-byte rows to / from HBM).  Branch-free: lanes 40..63 compute on chunk 0 and are switched off by out-of-range buffer offsets /
+// a dummy LDS address.  Forward: tile + residual -> out; LayerNorm -> statistics, nout.  Backward: LayerNorm backward of the tile
+// (the incoming gradient) with the saved input rows and statistics, + the residual branch's gradient -> out.
+// BM = rows of the tile, RW = rows per wavefront, OFF_G / OFF_B = gamma / beta images in LDS, OFF_DUMMY = 1 KB the inactive lanes may scribble on.
+template <int FM, bool BWD, int OFF_G, int OFF_B, int OFF_DUMMY>
+__device__ __forceinline__ int row_pass_fn(char* lds, const Stage& s, int m0, int wave, int lane) {
+  constexpr int BM = 64 * FM, RW = 8 * FM;
+  const int l15 = lane & 15, q4 = lane >> 4;
+    const bool act = lane < CH / 8;
+    const int cl = act ? lane : 0;
+    const int mode = s.ln;
+    const bool has_res = s.res != nullptr;
+    const bool wr_n = mode == RP_LN_FWD && s.nout != nullptr && m0 >= s.nout_row0;    // block-uniform
+    const float eps = s.eps;
+    const uint32_t ldr2 = keep_s((uint32_t)(s.ldr * 2)), ldo2 = keep_s((uint32_t)(s.ldo * 2)), ldn2 = keep_s((uint32_t)(s.ldn * 2)),
+                   ldx2 = keep_s((uint32_t)(s.ldlx * 2));
+    const __amdgpu_buffer_rsrc_t rsR = make_rsrc(s.res), rsO = make_rsrc(s.out), rsN = make_rsrc(wr_n ? s.nout : nullptr),
+                                 rsS = make_rsrc(mode != RP_NONE ? s.stats : nullptr), rsX = make_rsrc(mode == RP_LN_BWD ? s.lnx : nullptr);
+    const uint32_t mrow = (uint32_t)(m0 + wave * RW);
+    const uint32_t vr = mrow * ldr2 + cl * 16, vx = mrow * ldx2 + cl * 16;
+    const uint32_t vo = act ? mrow * ldo2 + cl * 16 : OOB_ROW;
+    const uint32_t vn = act ? mrow * ldn2 + cl * 16 : OOB_ROW;
+    const int myrow = ((q4 & 1) << 1) | (q4 >> 1);             // the row (of four) whose statistics this lane's 16-lane row holds
+    const uint32_t vs4 = l15 == 0 ? (mrow + myrow) * 8u : OOB_ROW;
+    const int kbase = (cl >> 2) * (BM * 64);
+    auto laddr = [&](int rr) __attribute__((always_inline)) {
+      const int row = wave * RW + rr;      // wave-uniform
+      return kbase + row * 64 + (((cl & 3) ^ swz4(row)) << 4);
+    };
+    uint4 gr = make_uint4(0u, 0u, 0u, 0u), br = gr;
+    if (mode != RP_NONE) {
+      gr = *reinterpret_cast<const uint4*>(lds + OFF_G + cl * 16);
+      br = *reinterpret_cast<const uint4*>(lds + OFF_B + cl * 16);
+    }
+    auto batch = [&](auto res_tag, auto mode_tag, int r0) __attribute__((always_inline)) {
+      constexpr bool RES = decltype(res_tag)::value;
+      constexpr int MODE = decltype(mode_tag)::value;
+      uint4 xv[8];
+      u32x4_t rv[8];
+      if constexpr (MODE == RP_LN_BWD) {
+        u32x4_t xs[8];
+        u32x2_t st[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int rr = r0 + u;
+          xs[u] = __builtin_amdgcn_raw_buffer_load_b128(rsX, vx + rr * ldx2, 0, 0);
+          st[u] = __builtin_amdgcn_raw_buffer_load_b64(rsS, (mrow + rr) * 8u, 0, 0);       // the row's (mean, rstd): one address for the wavefront
+          if constexpr (RES) rv[u] = __builtin_amdgcn_raw_buffer_load_b128(rsR, vr + rr * ldr2, 0, 0);
+          xv[u] = *reinterpret_cast<const uint4*>(lds + laddr(rr));
+        }
+        uint4 xin[8];
+        float mean[8], rstd[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          xin[u] = make_uint4(xs[u].x, xs[u].y, xs[u].z, xs[u].w);
+          mean[u] = __uint_as_float(st[u].x);
+          rstd[u] = __uint_as_float(st[u].y);
+        }
+        lnb_rows8(xv, xin, mean, rstd, act, gr, rv, RES);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{xv[u].x, xv[u].y, xv[u].z, xv[u].w}, rsO, vo + (r0 + u) * ldo2, 0, 0);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int rr = r0 + u;
+          if constexpr (RES) rv[u] = __builtin_amdgcn_raw_buffer_load_b128(rsR, vr + rr * ldr2, 0, 0);
+          xv[u] = *reinterpret_cast<const uint4*>(lds + laddr(rr));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int rr = r0 + u;
+          if constexpr (RES) xv[u] = epi_add8(xv[u], make_uint4(rv[u].x, rv[u].y, rv[u].z, rv[u].w));
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{xv[u].x, xv[u].y, xv[u].z, xv[u].w}, rsO, vo + rr * ldo2, 0, 0);   // null descriptor: dropped
+        }
+        if constexpr (MODE == RP_LN_FWD) {
+          float ma, mb, ra, rb;
+          ln_rows8(xv, act, gr, br, eps, ma, mb, ra, rb);
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(ma), __float_as_uint(ra)}, rsS, vs4 + r0 * 8, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(mb), __float_as_uint(rb)}, rsS, vs4 + (r0 + 4) * 8, 0, 0);
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{xv[u].x, xv[u].y, xv[u].z, xv[u].w}, rsN, vn + (r0 + u) * ldn2, 0, 0);
+        }
+      }
+      if constexpr (RES || MODE != RP_NONE) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          char* const wp = act ? lds + laddr(r0 + u) : lds + OFF_DUMMY + lane * 16;
+          *reinterpret_cast<uint4*>(wp) = xv[u];
+        }
+      }
+    };
+    auto pass = [&](auto res_tag, auto mode_tag) __attribute__((always_inline)) {
+#pragma unroll
+      for (int b = 0; b < FM; ++b) batch(res_tag, mode_tag, 8 * b);
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if constexpr (BWD) {
+      if (has_res) pass(T_{}, std::integral_constant<int, RP_LN_BWD>{});
+      else pass(F_{}, std::integral_constant<int, RP_LN_BWD>{});
+    } else {
+      if (mode == RP_LN_FWD) {
+        if (has_res) pass(T_{}, std::integral_constant<int, RP_LN_FWD>{});
+        else pass(F_{}, std::integral_constant<int, RP_LN_FWD>{});
+      } else {
+        if (has_res) pass(T_{}, std::integral_constant<int, RP_NONE>{});
+        else pass(F_{}, std::integral_constant<int, RP_NONE>{});
+      }
+    }
+  return mode == RP_LN_FWD ? 18 * FM : 8 * FM;   // stores ISSUED per wavefront (dropped ones included)
+}
+
 // BWD: the row passes of this instance are LayerNorm BACKWARD passes (the backward chains); else forward (residual / LayerNorm).  Two
 // instances instead of a run-time mode: the backward pass holds 128 more floats per lane across its reductions, and one kernel with
 // both would take its register allocation (spills in the forward K loop).
 template <int FM, bool BWD>
 __global__ __launch_bounds__(NTH, 2) void chain_kernel(const Args a) {
   using LY = Lay<FM>;
-  constexpr int BM = LY::BM, RW = 8 * FM;     // rows of the tile; rows a wavefront owns in a row pass
+  constexpr int BM = LY::BM;                  // rows of the tile
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -367,115 +482,8 @@ __global__ __launch_bounds__(NTH, 2) void chain_kernel(const Args a) {
   const int loff = W_BYTES + (wn * 16) * 64 + lo;  // LoRA-down fragment: rank rows wn*16 + l15
   int pend = 0;                                    // stores of the previous stage still counted by vmcnt (per wavefront)
 
-  // ---- row pass over the resident tile: wavefront w owns rows RW w .. RW w + RW - 1, lanes 0..39 one 16-byte chunk each (whole
-  // 640-byte rows to / from HBM).  Branch-free: lanes 40..63 compute on chunk 0 and are switched off by out-of-range buffer offsets /
-  // a dummy LDS address.  Forward: tile + residual -> out; LayerNorm -> statistics, nout.  Backward: LayerNorm backward of the tile
-  // (the incoming gradient) with the saved input rows and statistics, + the residual branch's gradient -> out.
   auto row_pass = [&](const Stage& s) __attribute__((always_inline)) {
-    const bool act = lane < CH / 8;
-    const int cl = act ? lane : 0;
-    const int mode = s.ln;
-    const bool has_res = s.res != nullptr;
-    const bool wr_n = mode == RP_LN_FWD && s.nout != nullptr && m0 >= s.nout_row0;    // block-uniform
-    const float eps = s.eps;
-    const uint32_t ldr2 = keep_s((uint32_t)(s.ldr * 2)), ldo2 = keep_s((uint32_t)(s.ldo * 2)), ldn2 = keep_s((uint32_t)(s.ldn * 2)),
-                   ldx2 = keep_s((uint32_t)(s.ldlx * 2));
-    const __amdgpu_buffer_rsrc_t rsR = make_rsrc(s.res), rsO = make_rsrc(s.out), rsN = make_rsrc(wr_n ? s.nout : nullptr),
-                                 rsS = make_rsrc(mode != RP_NONE ? s.stats : nullptr), rsX = make_rsrc(mode == RP_LN_BWD ? s.lnx : nullptr);
-    const uint32_t mrow = (uint32_t)(m0 + wave * RW);
-    const uint32_t vr = mrow * ldr2 + cl * 16, vx = mrow * ldx2 + cl * 16;
-    const uint32_t vo = act ? mrow * ldo2 + cl * 16 : OOB_ROW;
-    const uint32_t vn = act ? mrow * ldn2 + cl * 16 : OOB_ROW;
-    const int myrow = ((q4 & 1) << 1) | (q4 >> 1);             // the row (of four) whose statistics this lane's 16-lane row holds
-    const uint32_t vs4 = l15 == 0 ? (mrow + myrow) * 8u : OOB_ROW;
-    const int kbase = (cl >> 2) * (BM * 64);
-    auto laddr = [&](int rr) __attribute__((always_inline)) {
-      const int row = wave * RW + rr;      // wave-uniform
-      return kbase + row * 64 + (((cl & 3) ^ swz4(row)) << 4);
-    };
-    uint4 gr = make_uint4(0u, 0u, 0u, 0u), br = gr;
-    if (mode != RP_NONE) {
-      gr = *reinterpret_cast<const uint4*>(lds + LY::OFF_GAMMA + cl * 16);
-      br = *reinterpret_cast<const uint4*>(lds + LY::OFF_BETA + cl * 16);
-    }
-    auto batch = [&](auto res_tag, auto mode_tag, int r0) __attribute__((always_inline)) {
-      constexpr bool RES = decltype(res_tag)::value;
-      constexpr int MODE = decltype(mode_tag)::value;
-      uint4 xv[8];
-      u32x4_t rv[8];
-      if constexpr (MODE == RP_LN_BWD) {
-        u32x4_t xs[8];
-        u32x2_t st[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int rr = r0 + u;
-          xs[u] = __builtin_amdgcn_raw_buffer_load_b128(rsX, vx + rr * ldx2, 0, 0);
-          st[u] = __builtin_amdgcn_raw_buffer_load_b64(rsS, (mrow + rr) * 8u, 0, 0);       // the row's (mean, rstd): one address for the wavefront
-          if constexpr (RES) rv[u] = __builtin_amdgcn_raw_buffer_load_b128(rsR, vr + rr * ldr2, 0, 0);
-          xv[u] = *reinterpret_cast<const uint4*>(lds + laddr(rr));
-        }
-        uint4 xin[8];
-        float mean[8], rstd[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          xin[u] = make_uint4(xs[u].x, xs[u].y, xs[u].z, xs[u].w);
-          mean[u] = __uint_as_float(st[u].x);
-          rstd[u] = __uint_as_float(st[u].y);
-        }
-        lnb_rows8(xv, xin, mean, rstd, act, gr, rv, RES);
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{xv[u].x, xv[u].y, xv[u].z, xv[u].w}, rsO, vo + (r0 + u) * ldo2, 0, 0);
-      } else {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int rr = r0 + u;
-          if constexpr (RES) rv[u] = __builtin_amdgcn_raw_buffer_load_b128(rsR, vr + rr * ldr2, 0, 0);
-          xv[u] = *reinterpret_cast<const uint4*>(lds + laddr(rr));
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int rr = r0 + u;
-          if constexpr (RES) xv[u] = epi_add8(xv[u], make_uint4(rv[u].x, rv[u].y, rv[u].z, rv[u].w));
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{xv[u].x, xv[u].y, xv[u].z, xv[u].w}, rsO, vo + rr * ldo2, 0, 0);   // null descriptor: dropped
-        }
-        if constexpr (MODE == RP_LN_FWD) {
-          float ma, mb, ra, rb;
-          ln_rows8(xv, act, gr, br, eps, ma, mb, ra, rb);
-          __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(ma), __float_as_uint(ra)}, rsS, vs4 + r0 * 8, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(mb), __float_as_uint(rb)}, rsS, vs4 + (r0 + 4) * 8, 0, 0);
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{xv[u].x, xv[u].y, xv[u].z, xv[u].w}, rsN, vn + (r0 + u) * ldn2, 0, 0);
-        }
-      }
-      if constexpr (RES || MODE != RP_NONE) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          char* const wp = act ? lds + laddr(r0 + u) : lds + LY::OFF_TS + lane * 16;
-          *reinterpret_cast<uint4*>(wp) = xv[u];
-        }
-      }
-    };
-    auto pass = [&](auto res_tag, auto mode_tag) __attribute__((always_inline)) {
-#pragma unroll
-      for (int b = 0; b < FM; ++b) batch(res_tag, mode_tag, 8 * b);
-    };
-    using T_ = std::true_type;
-    using F_ = std::false_type;
-    if constexpr (BWD) {
-      if (has_res) pass(T_{}, std::integral_constant<int, RP_LN_BWD>{});
-      else pass(F_{}, std::integral_constant<int, RP_LN_BWD>{});
-    } else {
-      if (mode == RP_LN_FWD) {
-        if (has_res) pass(T_{}, std::integral_constant<int, RP_LN_FWD>{});
-        else pass(F_{}, std::integral_constant<int, RP_LN_FWD>{});
-      } else {
-        if (has_res) pass(T_{}, std::integral_constant<int, RP_NONE>{});
-        else pass(F_{}, std::integral_constant<int, RP_NONE>{});
-      }
-    }
-    return mode == RP_LN_FWD ? 18 * FM : 8 * FM;   // stores ISSUED per wavefront (dropped ones included)
+    return row_pass_fn<FM, BWD, LY::OFF_GAMMA, LY::OFF_BETA, LY::OFF_TS>(lds, s, m0, wave, lane);
   };
 
   if (a.has_pre) {   // backward chains: the incoming gradient goes through the LayerNorm backward before the first linear
