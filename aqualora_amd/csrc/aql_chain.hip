@@ -271,6 +271,23 @@ __device__ __forceinline__ void wait_tiles(int n) {
   }
 }
 
+// at most n operations outstanding (n from the small set the wide kernel's ring depths and store counts produce)
+__device__ __forceinline__ void wait_le(int n) {
+  switch (n) {
+    case 3: wait_vm<3>(); break;
+    case 8: wait_vm<8>(); break;
+    case 9: wait_vm<9>(); break;
+    case 11: wait_vm<11>(); break;
+    case 13: wait_vm<13>(); break;
+    case 14: wait_vm<14>(); break;
+    case 17: wait_vm<17>(); break;
+    case 19: wait_vm<19>(); break;
+    case 21: wait_vm<21>(); break;
+    case 27: wait_vm<27>(); break;
+    default: wait_vm<3>(); break;
+  }
+}
+
 // ---- row pass over the resident tile: wavefront w owns rows RW w .. RW w + RW - 1, lanes 0..39 one 16-byte chunk each (whole
 // 640-byte rows to / from HBM).  Branch-free: lanes 40..63 compute on chunk 0 and are switched off by out-of-range buffer offsets /
 // a dummy LDS address.  Forward: tile + residual -> out; LayerNorm -> statistics, nout.  Backward: LayerNorm backward of the tile
@@ -657,6 +674,243 @@ __global__ __launch_bounds__(NTH, 2) void chain_kernel(const Args a) {
 #undef CH_STAMP
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// RANK-320 chains (BASELINE config 3: train/README.md:34-48 trains at rank 320).  The rank-32 kernel lets the down product ride in the K
+// loop; at rank 320 the down product T = X.A^T is a 320 x 320 GEMM of its own and Ts = T * S is a second FULL-WIDTH A panel.  With 64-row
+// tiles both panels fit the LDS next to the weight ring (40 + 40 + 60 KB), so the whole LoRA linear runs inside the chain:
+//     pass T:    acc = X.A^T                      -> T (bf16), Ts = T * S[sample]  -> HBM (backward) and the Ts panel in LDS
+//     pass main: acc = X.W^T + Ts.Bup^T + bias    -> the epilogues of the rank-32 kernel (DIRECT / KEEP + row pass)
+// i.e. 30 weight tiles of 320 x 32 per stage instead of 11 (10 on tiles of the clean half).  Same roundings in the same places as
+// aql_lora_down (T, Ts through the row-scaled second output) + the two-K-segment aql_gemm_bf16: bit-identical (tools/probe_chain.py).
+struct LayW {
+  static constexpr int BM = 64;
+  static constexpr int OFF_TSW = NKT * BM * 64;             // 40960: the Ts panel, 10 K tiles x 64 rows x 64 B
+  static constexpr int OFF_RING = 2 * OFF_TSW;              // 3 stages of 320 x 64 B
+  static constexpr int OFF_DUMMY = OFF_RING + NSTG * W_BYTES;   // 2 KB nobody reads: wavefronts 4-7's third DMA, inactive lanes of the row pass
+  static constexpr int OFF_BIAS = OFF_DUMMY + 2048;
+  static constexpr int OFF_GAMMA = OFF_BIAS + MAXS * CH * 2;
+  static constexpr int OFF_BETA = OFF_GAMMA + CH * 2;
+  static constexpr int OFF_SROW = OFF_BETA + CH * 2;        // the tile's scale row: 320 bf16
+  static constexpr int TOTAL = OFF_SROW + CH * 2;
+};
+static_assert(LayW::TOTAL <= 160 * 1024, "LDS budget");
+
+__global__ __launch_bounds__(NTH, 2) void chain_wide_kernel(const Args a) {
+  using LY = LayW;
+  constexpr int BM = LY::BM;
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;     // wavefront grid 2 (M) x 4 (N): 32 rows x 80 columns each -- 7 fragment reads per 10 MFMAs
+  const int tiles_m = a.M / BM;
+  int tile_m = blockIdx.x;
+  if (a.row0 > 0 && a.row0 < a.M) {            // twin batch: the LoRA tiles (3x the work) first, the clean tiles fill in behind them
+    const int t0 = a.row0 / BM;
+    tile_m = tile_m < tiles_m - t0 ? t0 + tile_m : tile_m - (tiles_m - t0);
+  }
+  const int m0 = tile_m * BM;
+  const bool lora_tile = m0 + BM > a.row0;   // block-uniform
+  int mark_ = 0;
+  long long* const trc = (a.trace != nullptr && lane == 0 && (wave == 0 || wave == 4)) ? a.trace + ((long)blockIdx.x * 2 + (wave >> 2)) * 32 : nullptr;
+#define CW_STAMP() do { if (trc != nullptr && mark_ < 32) trc[mark_] = __builtin_readcyclecounter(); ++mark_; } while (0)
+  CW_STAMP();   // 0 start (tools/trace_chain.py wide)
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int lo = l15 * 64 + ((q4 ^ swz4(l15)) << 4);
+  const int drow = lane >> 2;
+  const uint32_t dchunk = (uint32_t)(((lane & 3) ^ swz4(drow)) << 4);
+  const uint32_t dr0 = (uint32_t)(wave * 16 + drow);
+
+  for (int id = tid; id < a.nstage * (CH / 8); id += NTH) {
+    const int g = id / (CH / 8), c = id - g * (CH / 8);
+    const bf16_t* b = a.st[g].bias;
+    const uint4 v = b ? *reinterpret_cast<const uint4*>(b + c * 8) : make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4*>(lds + LY::OFF_BIAS + g * CH * 2 + c * 16) = v;
+  }
+  if (tid < CH / 8) {
+    const bf16_t *gm = nullptr, *bt = nullptr;
+    for (int g = 0; g < a.nstage; ++g)
+      if (a.st[g].ln) gm = a.st[g].gamma, bt = a.st[g].beta;
+    if (gm) *reinterpret_cast<uint4*>(lds + LY::OFF_GAMMA + tid * 16) = *reinterpret_cast<const uint4*>(gm + tid * 8);
+    if (bt) *reinterpret_cast<uint4*>(lds + LY::OFF_BETA + tid * 16) = *reinterpret_cast<const uint4*>(bt + tid * 8);
+    *reinterpret_cast<uint4*>(lds + LY::OFF_SROW + tid * 16) =
+        (lora_tile && a.S) ? *reinterpret_cast<const uint4*>(a.S + (long)(m0 / a.rps) * CH + tid * 8) : make_uint4(0u, 0u, 0u, 0u);
+  }
+  {
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(a.X);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int q = wave + 8 * i, kt = q / (BM / 16), rb = q % (BM / 16);
+      const uint32_t voff = (uint32_t)(m0 + rb * 16 + drow) * (uint32_t)(a.ldx * 2) + dchunk;
+      dma16(rsX, lds + kt * (BM * 64) + rb * 1024, voff, (uint32_t)kt * 64u);
+    }
+  }
+
+  auto tile_body = [&](auto ns_tag) __attribute__((always_inline)) {
+    // ---- weight-tile stream: segments of 10 tiles [320 rows][32 k]; a stage with LoRA on a LoRA tile has three (A_down, W, Bup), else
+    // one (W).  The ISSUE cursor runs two tiles ahead of the consuming loops, across segments and stages.
+    // Ring: 3 slots behind the two panels on a LoRA tile; a clean tile never builds a Ts panel and takes its 40 KB as two more slots
+    // (5 slots, 4 tiles in flight: the K loop is bound by the latency of the L2 -> LDS requests in flight, not by their bandwidth)
+    constexpr int NS = decltype(ns_tag)::value, PD = NS - 1;
+    constexpr int RING0 = NS == NSTG ? LY::OFF_RING : LY::OFF_TSW;
+    int wr = 0, rd = 0;
+    auto ring_next = [](int x) { return x + 1 == NS ? 0 : x + 1; };
+    int ig = 0, ij = 0, it_ = 0;                 // issue cursor: stage, segment, tile
+    const bf16_t* ip = nullptr;                  // its segment's matrix and row pitch in bytes
+    uint32_t ildb = 0;
+    auto nseg_of = [&](int g) { return (lora_tile && a.st[g].Ad != nullptr) ? 3 : 1; };
+    auto seg_load = [&]() __attribute__((always_inline)) {
+      if (ig < a.nstage) {
+        const Stage& s = a.st[ig];
+        const bool wide = lora_tile && s.Ad != nullptr;
+        const int kind = wide ? ij : 1;          // 0 = A_down, 1 = W, 2 = Bup
+        ip = keep_p(kind == 0 ? s.Ad : kind == 1 ? s.W : s.Bup);
+        ildb = keep_s(kind == 1 ? (uint32_t)(s.ldw * 2) : (uint32_t)(CH * 2));
+      } else {
+        ip = nullptr;
+        ildb = 0;
+      }
+    };
+    auto issue = [&]() __attribute__((always_inline)) {
+      char* dst = lds + RING0 + wr * W_BYTES;
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(ip);      // past the end of the chain: a null descriptor zero-fills without traffic
+      const uint32_t soff = (uint32_t)it_ * 64u, v0 = dr0 * ildb + dchunk;
+      dma16(rs, dst + wave * 1024, v0, soff);
+      dma16(rs, dst + (wave + 8) * 1024, v0 + 128u * ildb, soff);
+      if (wave < 4) dma16(rs, dst + (wave + 16) * 1024, v0 + 256u * ildb, soff);
+      else dma16(make_rsrc(nullptr), lds + LY::OFF_DUMMY + (wave & 1) * 1024, OOB_ROW, 0);    // keeps the per-wavefront count at 3
+      wr = ring_next(wr);
+      if (++it_ == NKT) {
+        it_ = 0;
+        if (ig < a.nstage && ++ij == nseg_of(ig)) {
+          ij = 0;
+          ++ig;
+        }
+        seg_load();
+      }
+    };
+    seg_load();
+  #pragma unroll
+    for (int i = 0; i < PD; ++i) issue();
+
+    const int aoff = (wm * 32) * 64 + lo;
+    const int boff = (wn * 80) * 64 + lo;
+    int pend = 0;
+    f32x4_t acc[2][5];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+  #pragma unroll
+      for (int i = 0; i < 2; ++i)
+  #pragma unroll
+        for (int j = 0; j < 5; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    };
+    // one segment: acc += A_panel . B^T over 10 K tiles; A_panel = the resident tile or the Ts panel
+    auto segment = [&](int a_base) __attribute__((always_inline)) {
+  #pragma unroll
+      for (int t = 0; t < NKT; ++t) {
+        if (t < PD) wait_le(3 * (PD - 1) + pend);      // the previous stage's stores are younger than the tiles in flight: count past them
+        else wait_vm<3 * (PD - 1)>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* sW = lds + RING0 + rd * W_BYTES;
+        const bf16x8_t fa0 = *reinterpret_cast<const bf16x8_t*>(lds + a_base + t * (BM * 64) + aoff);
+        const bf16x8_t fa1 = *reinterpret_cast<const bf16x8_t*>(lds + a_base + t * (BM * 64) + aoff + 1024);
+        bf16x8_t fb[5];
+  #pragma unroll
+        for (int j = 0; j < 5; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(sW + boff + j * 1024);
+  #pragma unroll
+        for (int j = 0; j < 5; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa0, acc[0][j], 0, 0, 0);
+        issue();
+  #pragma unroll
+        for (int j = 0; j < 5; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa1, acc[1][j], 0, 0, 0);
+        rd = ring_next(rd);
+      }
+      pend = 0;
+    };
+    // accumulators (+ bias image or nothing) -> bf16; the two ROW fragments of a column block are paired through v_permlane16_swap so
+    // that a lane holds 8 consecutive columns (16 bytes) of one row: lane rows q4 = 0 / 2 -> row fragment 0, columns 0-7 / 8-15 of the
+    // block, q4 = 1 / 3 -> row fragment 1.  `sink(cc, v)` gets the chunk of columns cc .. cc + 7 of row `row`
+    const int row = wm * 32 + (q4 & 1) * 16 + l15;
+    const int c0 = wn * 80 + (q4 >> 1) * 8;      // + 16 j
+    auto emit = [&](const char* sBias, auto&& sink) __attribute__((always_inline)) {
+  #pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        uint2 bA = make_uint2(0u, 0u);
+        if (sBias != nullptr) bA = *reinterpret_cast<const uint2*>(sBias + j * 32);
+        const f32x4_t& xa = acc[0][j];
+        const f32x4_t& xb = acc[1][j];
+        uint32_t x0 = pack_bf16x2(xa[0] + bf16lo(bA.x), xa[1] + bf16hi(bA.x)), x1 = pack_bf16x2(xa[2] + bf16lo(bA.y), xa[3] + bf16hi(bA.y));
+        uint32_t y0 = pack_bf16x2(xb[0] + bf16lo(bA.x), xb[1] + bf16hi(bA.x)), y1 = pack_bf16x2(xb[2] + bf16lo(bA.y), xb[3] + bf16hi(bA.y));
+        const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+        sink(c0 + 16 * j, u32x4_t{s0[0], s1[0], s0[1], s1[1]});
+      }
+    };
+    const int sz = swz4(row);
+    auto lds_chunk = [&](int base, int cc) __attribute__((always_inline)) {
+      return lds + base + (cc >> 5) * (BM * 64) + row * 64 + ((((cc >> 3) & 3) ^ sz) << 4);
+    };
+
+    for (int g = 0; g < a.nstage; ++g) {
+      const Stage& s = a.st[g];
+      const bool wide = lora_tile && s.Ad != nullptr;
+      const int keep = (int)keep_s((uint32_t)s.keep);
+      if (wide) {
+        // ---- pass T: T = X.A^T, Ts = T * S -> HBM and the Ts panel
+        zero_acc();
+        segment(0);
+        CW_STAMP();   // 1 + 6 g: pass T issued
+        const __amdgpu_buffer_rsrc_t rsT = make_rsrc(s.T), rsTs = make_rsrc(s.Ts);
+        const uint32_t vt = (uint32_t)(m0 + row) * (uint32_t)(CH * 2);
+        emit(nullptr, [&](int cc, const u32x4_t& tv) __attribute__((always_inline)) {
+          const uint4 sv = *reinterpret_cast<const uint4*>(lds + LY::OFF_SROW + cc * 2);
+          const uint4 ts = epi_mul8(make_uint4(tv.x, tv.y, tv.z, tv.w), sv);
+          *reinterpret_cast<uint4*>(lds_chunk(LY::OFF_TSW, cc)) = ts;
+          __builtin_amdgcn_raw_buffer_store_b128(tv, rsT, vt + cc * 2, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{ts.x, ts.y, ts.z, ts.w}, rsTs, vt + cc * 2, 0, 0);
+        });
+        pend = 10;    // T and Ts: 2 x 5 stores, younger than the two tiles in flight
+        CW_STAMP();   // 2 + 6 g: T / Ts out
+      } else {
+        CW_STAMP();
+        CW_STAMP();
+      }
+      // ---- pass main: X.W^T (+ Ts.Bup^T); its first barrier publishes the Ts panel
+      zero_acc();
+      segment(0);
+      CW_STAMP();   // 3 + 6 g: X.W^T issued
+      if (wide) segment(LY::OFF_TSW);
+      CW_STAMP();   // 4 + 6 g: Ts.Bup^T issued
+      if (keep) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // every wavefront has read its last resident K tile: the epilogue may overwrite it
+        asm volatile("" ::: "memory");
+      }
+      const char* sBias = lds + LY::OFF_BIAS + g * CH * 2 + (wn * 80 + q4 * 4) * 2;
+      if (keep) {
+        emit(sBias, [&](int cc, const u32x4_t& v) __attribute__((always_inline)) { *reinterpret_cast<u32x4_t*>(lds_chunk(0, cc)) = v; });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        CW_STAMP();   // 5 + 6 g: epilogue, tile published
+        pend = row_pass_fn<1, false, LY::OFF_GAMMA, LY::OFF_BETA, LY::OFF_DUMMY>(lds, s, m0, wave, lane);
+        CW_STAMP();   // 6 + 6 g: row pass
+      } else {
+        const __amdgpu_buffer_rsrc_t rsO = make_rsrc(s.out);
+        const uint32_t vo = (uint32_t)(m0 + row) * (uint32_t)(s.ldo * 2);
+        emit(sBias, [&](int cc, const u32x4_t& v) __attribute__((always_inline)) { __builtin_amdgcn_raw_buffer_store_b128(v, rsO, vo + cc * 2, 0, 0); });
+        pend = 5;
+        CW_STAMP();
+        CW_STAMP();
+      }
+    }
+  };
+  if (lora_tile) tile_body(std::integral_constant<int, NSTG>{});
+  else tile_body(std::integral_constant<int, 5>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing zero-fill DMAs still target the LDS
+  CW_STAMP();   // drained
+#undef CW_STAMP
+}
+
 }  // namespace aqlchain
 
 namespace {
@@ -664,7 +918,7 @@ namespace {
 using namespace aqlchain;
 
 // shared tail of the two entry points: argument checks of the filled descriptor, tile height, launch
-int chain_launch(Args& a, long M, const char* name, bool bwd, hipStream_t stream) {
+int chain_launch(Args& a, long M, const char* name, bool bwd, hipStream_t stream, bool wide = false) {
   int nln = a.has_pre ? 1 : 0;
   for (int g = 0; g < a.nstage; ++g) {
     const Stage& s = a.st[g];
@@ -685,6 +939,7 @@ int chain_launch(Args& a, long M, const char* name, bool bwd, hipStream_t stream
     (void)hipFuncSetAttribute((const void*)chain_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Lay<1>::TOTAL);
     (void)hipFuncSetAttribute((const void*)chain_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Lay<2>::TOTAL);
     (void)hipFuncSetAttribute((const void*)chain_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Lay<1>::TOTAL);
+    (void)hipFuncSetAttribute((const void*)chain_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LayW::TOTAL);
     once = true;
   }
   {
@@ -695,7 +950,8 @@ int chain_launch(Args& a, long M, const char* name, bool bwd, hipStream_t stream
   // watermarked half only: 16384 rows = 128 tiles of 128 -- half the CUs idle -- or 256 of 64)
   static const int force = getenv("AQL_CHAIN_BM") ? atoi(getenv("AQL_CHAIN_BM")) : 0;   // tuning hook
   const bool small = force == 64 || (force == 0 && (M / 128 < 200 || M % 128 != 0 || a.rps % 128 != 0 || a.row0 % 128 != 0));
-  if (bwd) hipLaunchKernelGGL((chain_kernel<1, true>), dim3((unsigned)(M / 64)), dim3(NTH), Lay<1>::TOTAL, stream, a);   // (64-row tiles only)
+  if (wide) hipLaunchKernelGGL(chain_wide_kernel, dim3((unsigned)(M / 64)), dim3(NTH), LayW::TOTAL, stream, a);   // rank 320: 64-row tiles
+  else if (bwd) hipLaunchKernelGGL((chain_kernel<1, true>), dim3((unsigned)(M / 64)), dim3(NTH), Lay<1>::TOTAL, stream, a);   // (64-row tiles only)
   else if (small) hipLaunchKernelGGL((chain_kernel<1, false>), dim3((unsigned)(M / 64)), dim3(NTH), Lay<1>::TOTAL, stream, a);
   else hipLaunchKernelGGL((chain_kernel<2, false>), dim3((unsigned)(M / 128)), dim3(NTH), Lay<2>::TOTAL, stream, a);
   AQL_CHECK_LAUNCH(name);
@@ -704,12 +960,12 @@ int chain_launch(Args& a, long M, const char* name, bool bwd, hipStream_t stream
 
 }  // namespace
 
-extern "C" int aql_lora_chain_fwd(const bf16_t* X, long ldx, long M, int rows_per_sample, long lora_row0, const bf16_t* S, int nstage,
-                                  const void* const* W, const long* ldw, const void* const* bias, const void* const* Adown,
-                                  const void* const* Bup, void* const* T, void* const* Ts, const void* const* res, const long* ldr,
-                                  void* const* out, const long* ldo, const int* keep, const int* ln, const void* const* gamma,
-                                  const void* const* beta, const float* eps, void* const* stats, void* const* nout, const long* ldn,
-                                  const long* nout_row0, hipStream_t stream) {
+static int chain_fwd_common(bool wide, const bf16_t* X, long ldx, long M, int rows_per_sample, long lora_row0, const bf16_t* S, int nstage,
+                            const void* const* W, const long* ldw, const void* const* bias, const void* const* Adown,
+                            const void* const* Bup, void* const* T, void* const* Ts, const void* const* res, const long* ldr,
+                            void* const* out, const long* ldo, const int* keep, const int* ln, const void* const* gamma,
+                            const void* const* beta, const float* eps, void* const* stats, void* const* nout, const long* ldn,
+                            const long* nout_row0, hipStream_t stream) {
   AQL_CHECK_ARG(X != nullptr && nstage >= 1 && nstage <= MAXS, "aql_lora_chain_fwd: 1..%d stages", MAXS);
   AQL_CHECK_ARG(M > 0 && M % 64 == 0 && M < (1L << 30), "aql_lora_chain_fwd: M = %ld must be a multiple of 64", M);
   AQL_CHECK_ARG(rows_per_sample > 0 && rows_per_sample % 64 == 0, "aql_lora_chain_fwd: rows_per_sample %% 64 != 0");
@@ -747,7 +1003,29 @@ extern "C" int aql_lora_chain_fwd(const bf16_t* X, long ldx, long M, int rows_pe
     s.ldn = ldn ? ldn[g] : 0;
     s.nout_row0 = nout_row0 ? (int)nout_row0[g] : 0;
   }
-  return chain_launch(a, M, "aql_lora_chain_fwd", false, stream);
+  return chain_launch(a, M, wide ? "aql_lora_chain_fwd_r320" : "aql_lora_chain_fwd", false, stream, wide);
+}
+
+extern "C" int aql_lora_chain_fwd(const bf16_t* X, long ldx, long M, int rows_per_sample, long lora_row0, const bf16_t* S, int nstage,
+                                  const void* const* W, const long* ldw, const void* const* bias, const void* const* Adown,
+                                  const void* const* Bup, void* const* T, void* const* Ts, const void* const* res, const long* ldr,
+                                  void* const* out, const long* ldo, const int* keep, const int* ln, const void* const* gamma,
+                                  const void* const* beta, const float* eps, void* const* stats, void* const* nout, const long* ldn,
+                                  const long* nout_row0, hipStream_t stream) {
+  return chain_fwd_common(false, X, ldx, M, rows_per_sample, lora_row0, S, nstage, W, ldw, bias, Adown, Bup, T, Ts, res, ldr, out, ldo, keep,
+                          ln, gamma, beta, eps, stats, nout, ldn, nout_row0, stream);
+}
+
+// The rank-320 form (chain_wide_kernel): same arguments; Adown[g] is [320][320] (rank x K), Bup[g] [320][320] (N x rank), T[g] / Ts[g]
+// [M][320], S [M / rows_per_sample][320].
+extern "C" int aql_lora_chain_fwd_r320(const bf16_t* X, long ldx, long M, int rows_per_sample, long lora_row0, const bf16_t* S, int nstage,
+                                       const void* const* W, const long* ldw, const void* const* bias, const void* const* Adown,
+                                       const void* const* Bup, void* const* T, void* const* Ts, const void* const* res, const long* ldr,
+                                       void* const* out, const long* ldo, const int* keep, const int* ln, const void* const* gamma,
+                                       const void* const* beta, const float* eps, void* const* stats, void* const* nout, const long* ldn,
+                                       const long* nout_row0, hipStream_t stream) {
+  return chain_fwd_common(true, X, ldx, M, rows_per_sample, lora_row0, S, nstage, W, ldw, bias, Adown, Bup, T, Ts, res, ldr, out, ldo, keep,
+                          ln, gamma, beta, eps, stats, nout, ldn, nout_row0, stream);
 }
 
 extern "C" int aql_lora_chain_bwd(const bf16_t* dY, long lddy, long M, int rows_per_sample, const bf16_t* S, int nstage,

@@ -620,9 +620,10 @@ def _lora_gemm_fused(x2d, w, a16, S16, rps, b16, bias, residual, T, Ts, y=None, 
     return y
 
 
-def chain_fwd(x, ldx, M, rps, row0, S16, stages):
-    """aql_lora_chain_fwd: a row-resident chain of 320 -> 320 LoRA linears (csrc/aql_chain.hip).  ``stages``: list of dicts with the
-    keys  W ldw bias Ad Bup T Ts res ldr out ldo keep ln gamma beta eps stats nout ldn nout_row0  (tensors or None; missing = None / 0)."""
+def chain_fwd(x, ldx, M, rps, row0, S16, stages, rank=32):
+    """aql_lora_chain_fwd (rank 32; rank 320: aql_lora_chain_fwd_r320): a row-resident chain of 320 -> 320 LoRA linears
+    (csrc/aql_chain.hip).  ``stages``: list of dicts with the keys  W ldw bias Ad Bup T Ts res ldr out ldo keep ln gamma beta eps
+    stats nout ldn nout_row0  (tensors or None; missing = None / 0)."""
     import ctypes
     n = len(stages)
     vp, lp_, ip, fp = ctypes.c_void_p * n, ctypes.c_long * n, ctypes.c_int * n, ctypes.c_float * n
@@ -633,7 +634,7 @@ def chain_fwd(x, ldx, M, rps, row0, S16, stages):
     def longs(key):
         return lp_(*[int(st.get(key) or 0) for st in stages])
 
-    L.call("aql_lora_chain_fwd", L.ptr(x), int(ldx), int(M), int(rps), int(row0), L.ptr(S16), n,
+    L.call("aql_lora_chain_fwd_r320" if rank == 320 else "aql_lora_chain_fwd", L.ptr(x), int(ldx), int(M), int(rps), int(row0), L.ptr(S16), n,
            ptrs("W"), longs("ldw"), ptrs("bias"), ptrs("Ad"), ptrs("Bup"), ptrs("T"), ptrs("Ts"), ptrs("res"), longs("ldr"),
            ptrs("out"), longs("ldo"), ip(*[int(st.get("keep") or 0) for st in stages]), ip(*[int(st.get("ln") or 0) for st in stages]),
            ptrs("gamma"), ptrs("beta"), fp(*[float(st.get("eps") or 0.0) for st in stages]), ptrs("stats"), ptrs("nout"),
@@ -1179,7 +1180,7 @@ def _grouped_backward(dys, x2d, T, Ts, S16, packs, sites, rps, ds_accum, want_dx
     dx, dS_sum = None, None
     G = len(dys)
     if (want_dx and 2 <= G <= 3 and all(dy is not None for dy in dys) and ds_accum is not None
-            and DEFERRED is not None and _KGROUPS):   # (dS goes to the trainer's accumulator)
+            and DEFERRED is not None and _KGROUPS and all(s_.rank == 32 for s_ in sites)):   # (dS goes to the trainer's accumulator)
         # q | k | v backward-data as ONE launch: dX = sum_g (dY_g.W_g + ((dY_g.Bup_g) * S).A_g), accumulators in registers
         import ctypes
         M, Kin = x2d.shape
@@ -1243,6 +1244,7 @@ def lora_linear(x2d, packed, site=None, S=None, S16=None, rps=1, residual=None, 
 # ------------------------------------------------------------------------- row-resident chains (csrc/aql_chain.hip)
 CHAIN = os.environ.get("AQL_CHAIN", "1") != "0"   # A/B hook: 0 = every linear / LayerNorm of the transformer block as its own launch
 CHAIN_BWD = os.environ.get("AQL_CHAIN_BWD", "1") != "0"   # A/B hook: 0 = the chains' backward as separate launches
+CHAIN_R320 = os.environ.get("AQL_CHAIN_R320", "1") != "0"   # A/B hook: 0 = rank-320 linears as aql_lora_down + aql_gemm_bf16 launches
 CHAIN_MIN_TILES = int(os.environ.get("AQL_CHAIN_MIN_TILES", "128"))   # below this many 128-row tiles the chip is mostly idle: unfused
 
 
@@ -1257,8 +1259,8 @@ class ChainStage:
 
 
 def chain_ok(x2d, stages, S16, rps):
-    """The chain kernel takes these linears: 320 -> 320, all with the rank-32 LoRA (bf16 scale rows) or all without (the fused-weight /
-    clean passes: S16 None), whole 64-row tiles, enough of them to fill half the chip."""
+    """The chain kernel takes these linears: 320 -> 320, all with the rank-32 (or all with the rank-320) LoRA (bf16 scale rows) or all
+    without (the fused-weight / clean passes: S16 None), whole 64-row tiles, enough of them to fill half the chip."""
     if not CHAIN or REF_ROUNDING or x2d.dtype != torch.bfloat16 or x2d.dim() != 2 or x2d.stride(1) != 1:
         return False
     M = x2d.shape[0] * (2 if _full(x2d) is not None else 1)
@@ -1268,9 +1270,14 @@ def chain_ok(x2d, stages, S16, rps):
         # LoRA-free passes at CFG batch 2 (8192 rows = 128 tiles of 64, half the chip): measured 5.56 vs 5.54 ms per guided forward
         # against the per-launch path, whose q | k | v is ONE 960-wide GEMM on 768 tiles (tools/time_infer_forward.py) -- not taken
         return False
+    rank = None if S16 is None else S16.shape[1]
+    if rank not in (None, 32, 320) or (rank == 320 and (not CHAIN_R320 or M // 64 < 2 * CHAIN_MIN_TILES)):
+        return False       # (rank 320: one 150 KB workgroup per CU on 64-row tiles)
     for st in stages:
-        if st.packed.N != 320 or st.packed.K != 320 or (S16 is None) != (st.site is None) or (st.site is not None and st.site.rank != 32):
+        if st.packed.N != 320 or st.packed.K != 320 or (S16 is None) != (st.site is None) or (st.site is not None and st.site.rank != rank):
             return False
+        if rank == 320 and wside_ok(st.packed, st.site, S16, rps):
+            return False   # the opt-in weight-side form owns these sites
     return os.environ.get("AQL_LORA_FUSED", "1") != "0"
 
 
@@ -1294,6 +1301,7 @@ class ChainFn(torch.autograd.Function):
         if res is not None:
             resk = _need_full(res, "the residual") if twin else res
         lora = S16 is not None
+        rank = S16.shape[1] if lora else 32
         S16k = (_need_full(S16, "the LoRA scale") if twin else S16) if lora else None
         row0 = M if (twin and _TWIN_SKIP) else 0
         kst, outs, saved = [], [], [x2d, S16]
@@ -1302,8 +1310,8 @@ class ChainFn(torch.autograd.Function):
             d = dict(W=st.packed.w, ldw=st.packed.w.stride(0), bias=st.packed.bias, keep=int(st.keep))
             T = Ts = None
             if lora:
-                Tk, T = _alloc((M, 32), torch.bfloat16, dev, twin)
-                Tsk, Ts = _alloc((M, 32), torch.bfloat16, dev, twin)
+                Tk, T = _alloc((M, rank), torch.bfloat16, dev, twin)
+                Tsk, Ts = _alloc((M, rank), torch.bfloat16, dev, twin)
                 d.update(Ad=st.site.a16, Bup=st.site.b16, T=Tk, Ts=Tsk)
             ok = o = nk = n = stk = stt = None
             if st.emit_out or st.ln is not None or not st.keep:
@@ -1323,7 +1331,7 @@ class ChainFn(torch.autograd.Function):
                 outs.append(n)
             meta.append((len(saved), o is not None, n is not None))
             saved += [T, Ts] + ([o] if o is not None else []) + ([n, stt] if n is not None else [])
-        chain_fwd(xk, xk.stride(0), xk.shape[0], rps, row0, S16k, kst)
+        chain_fwd(xk, xk.stride(0), xk.shape[0], rps, row0, S16k, kst, rank)
         if not lora:   # the LoRA-free chains run under no_grad only (the clean pass / sampling with fused weights): nothing to save
             return tuple(outs)
         ctx.stages, ctx.meta, ctx.rps = stages, meta, rps
@@ -1379,7 +1387,7 @@ class ChainFn(torch.autograd.Function):
 
         M = x2d.shape[0]
         fused_bwd = (CHAIN_BWD and ctx.ds_accum is not None and DEFERRED is not None and M % 64 == 0 and rps % 64 == 0
-                     and M // 64 >= CHAIN_MIN_TILES)      # (dS goes to the trainer's accumulator, as in _grouped_backward's one-launch branch)
+                     and M // 64 >= CHAIN_MIN_TILES and S16.shape[1] == 32)      # (dS goes to the trainer's accumulator, as in _grouped_backward's one-launch branch)
         mk = lambda *shape: torch.empty(*shape, dtype=torch.bfloat16, device=x2d.device)   # noqa: E731
 
         g = len(stages) - 1

@@ -324,7 +324,7 @@ class Transformer2DModel(nn.Module):
         return self.proj_out(h, scale, residual=x)
 
     def _forward_chains(self, n, x, ctx, scale):
-        """The 320-channel level with the rank-32 watermark LoRA on every linear (training, twin or plain batch): the linears with
+        """The 320-channel level with the rank-32 / rank-320 watermark LoRA on every linear (training, twin or plain batch): the linears with
         K = N = 320 and the row-local operations between them run as row-resident chains (ops.ChainFn, csrc/aql_chain.hip) --
             proj_in -> norm1 -> to_q | to_k | to_v      |  attn1.to_out + residual -> norm2 -> attn2.to_q
             attn2.to_out + residual -> norm3            |  (feed-forward and proj_out: the existing launches)
@@ -333,7 +333,7 @@ class Transformer2DModel(nn.Module):
         nolora = scale is None and not torch.is_grad_enabled()     # the clean pass alone / sampling with the LoRA fused into W
         if not ops.CHAIN or len(self.transformer_blocks) != 1 or n.dtype != torch.bfloat16 or n.shape[1] != 320:
             return None
-        if not nolora and (not torch.is_tensor(scale) or scale.dim() != 2 or scale.shape[1] != 32):
+        if not nolora and (not torch.is_tensor(scale) or scale.dim() != 2 or scale.shape[1] not in (32, 320)):
             return None
         blk = self.transformer_blocks[0]
         a1, a2 = blk.attn1, blk.attn2
@@ -349,7 +349,7 @@ class Transformer2DModel(nn.Module):
             kv = None if kvs is None or id(a2) not in kvs else kvs
         else:
             kv = getattr(ctx, "_aql_kv", None)   # k | v of all cross-attentions, computed in front of the U-Net (UNet._ctx_kv)
-            if kv is None or id(a2) not in kv:
+            if kv is not None and id(a2) not in kv:
                 return None
         from .lora import _scale16, _site_of
         n = ops.as_cl(n)
@@ -358,7 +358,7 @@ class Transformer2DModel(nn.Module):
         st = {m: (None if nolora else _site_of(m.lora_layer)) for m in hosts}
         S = S16 = None
         if not nolora:
-            S = _scale16(scale, B, 32, x2d.device)
+            S = _scale16(scale, B, scale.shape[1], x2d.device)
             S16 = getattr(S, "_aql_s16", None)
             if S16 is None:
                 S16 = S.detach().to(torch.bfloat16).contiguous()
@@ -372,7 +372,12 @@ class Transformer2DModel(nn.Module):
         o1 = ops.attention(q.view(B, N, C), k.view(B, N, C), v.view(B, N, C), a1.heads).reshape(B * N, C)
         h1, q2 = ops.lora_chain(o1, h0, S, S16, N, [CS(pk[a1.to_out[0]], st[a1.to_out[0]], True, use_res=True, ln=blk.norm2),
                                                     CS(pk[a2.to_q], st[a2.to_q], False)])
-        k2, v2 = kv[id(a2)] if kv is not None else a2._text_kv(ctx)
+        if kv is not None:
+            k2, v2 = kv[id(a2)]
+        elif nolora:
+            k2, v2 = a2._text_kv(ctx)
+        else:                                   # (rank 320: no grouped k | v launch in front of the U-Net)
+            k2, v2 = a2.to_k(ctx, scale), a2.to_v(ctx, scale)
         o2 = ops.attention(q2.view(B, N, C), k2, v2, a2.heads).reshape(B * N, C)
         h2, n3 = ops.lora_chain(o2, h1, S, S16, N, [CS(pk[a2.to_out[0]], st[a2.to_out[0]], True, use_res=True, ln=blk.norm3, emit_n=True)])
         tokens = blk.ff(n3.view(B, N, C), scale, residual=h2.view(B, N, C))

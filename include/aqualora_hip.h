@@ -202,6 +202,16 @@ int aql_lora_chain_fwd(const bf16_t* X, long ldx, long M, int rows_per_sample, l
                        void* const* out, const long* ldo, const int* keep, const int* ln, const void* const* gamma,
                        const void* const* beta, const float* eps, void* const* stats, void* const* nout, const long* ldn,
                        const long* nout_row0, aql_stream_t stream);
+/* The same chain at LoRA rank 320 (BASELINE config 3, train/README.md:34-48): Adown_g [320][320] (rank x K), Bup_g [320][320]
+ * (N x rank), T_g / Ts_g [M][320], S [M / rps][320].  One workgroup owns 64 token rows; per LoRA linear the down product
+ * T = X.Adown^T runs as a pass of its own, (T, Ts = T * S) go to HBM for backward and Ts stays in LDS as the second A panel of the
+ * main pass X.W^T + Ts.Bup^T.  Bit for bit aql_lora_down + the two-K-segment aql_gemm_bf16.  M, rows_per_sample, lora_row0: % 64.  */
+int aql_lora_chain_fwd_r320(const bf16_t* X, long ldx, long M, int rows_per_sample, long lora_row0, const bf16_t* S, int nstage,
+                            const void* const* W, const long* ldw, const void* const* bias, const void* const* Adown,
+                            const void* const* Bup, void* const* T, void* const* Ts, const void* const* res, const long* ldr,
+                            void* const* out, const long* ldo, const int* keep, const int* ln, const void* const* gamma,
+                            const void* const* beta, const float* eps, void* const* stats, void* const* nout, const long* ldn,
+                            const long* nout_row0, aql_stream_t stream);
 /* The mirrored BACKWARD chains (round 5): the backward-data passes of up to 4 of those linears with the LayerNorm backward between
  * them, one launch, 64-row tiles (the backward pass runs on the watermarked half of the batch only).  Per linear the operands of
  * aql_lora_gemm_fused's backward-data form: Wt = W^T [320][ldw], BupT = Bup^T [32][320], AT = A^T [320][32]; dTs, dT [M][32] out.

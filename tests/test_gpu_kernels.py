@@ -237,9 +237,10 @@ def test_row_resident_chain_kernel_repeats_bit_for_bit_under_memory_load():
     assert out.returncode == 0 and len(lines) == 3 and all("mismatching outputs: 0 " in l for l in lines), text[-2000:]
 
 
-def test_transformer_block_through_chains_equals_the_per_launch_block():
+@pytest.mark.parametrize("rank", [32, 320])
+def test_transformer_block_through_chains_equals_the_per_launch_block(rank):
     """unet.Transformer2DModel at 320 channels on a twin batch of 8 x 64 x 64: with ops.CHAIN the three chains (ops.ChainFn) replace nine
-    launches.  Forward output bit-identical; the input gradient and every LoRA weight gradient as close as two runs of the per-launch
+    launches (rank 320, BASELINE config 3: sixteen -- aql_lora_chain_fwd_r320 also holds the down products).  Forward output bit-identical; the input gradient and every LoRA weight gradient as close as two runs of the per-launch
     path are to each other (the weight-gradient GEMMs accumulate with fp32 atomics)."""
     from aqualora_amd import ops, synth
     from aqualora_amd.lora import inject_lora
@@ -257,16 +258,16 @@ def test_transformer_block_through_chains_equals_the_per_launch_block():
     for p_ in tm.parameters():
         p_.requires_grad_(False)
     keys = [n_ for n_, m in tm.named_modules() if hasattr(m, "lora_layer") and (n_.startswith("proj") or "attn" in n_ or "ff" in n_)]
-    inject_lora(tm, 32, keys)
+    inject_lora(tm, rank, keys)
     with torch.no_grad():
         for k in keys:
             lay = tm.get_submodule(k).lora_layer
-            lay.down.weight.copy_(synth.normal(k + ".d", lay.down.weight.shape, 1.0 / 32, 7, dev))
+            lay.down.weight.copy_(synth.normal(k + ".d", lay.down.weight.shape, 1.0 / rank, 7, dev))
             lay.up.weight.copy_(synth.normal(k + ".u", lay.up.weight.shape, 0.05, 7, dev))
     lparams = [p_ for k in keys for p_ in (tm.get_submodule(k).lora_layer.down.weight, tm.get_submodule(k).lora_layer.up.weight)]
     x0 = synth.normal("x", (2 * B, C, H, H), 1.0, 7, dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     ctx0 = synth.normal("ctx", (2 * B, 77, 768), 1.0, 7, dev).to(torch.bfloat16)
-    S0 = torch.cat([torch.zeros(B, 32, device=dev), synth.normal("S", (B, 32), 1.0, 7, dev)])
+    S0 = torch.cat([torch.zeros(B, rank, device=dev), synth.normal("S", (B, rank), 1.0, 7, dev)])
     dy = synth.normal("dy", (B, C, H, H), 1.0, 7, dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
 
     def run(chain):

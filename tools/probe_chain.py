@@ -197,4 +197,85 @@ for name, M, nb, pre, nst in [("B1: LN bwd -> to_out bwd", 16384, 4, True, 1), (
         tu, tc = graph_time(run_unfused), graph_time(run_chain)
         line += f" | unfused {tu:.1f} us, chain {tc:.1f} us, ratio {tc / tu:.2f}"
     print(line, flush=True)
-print("ALL PASS" if (ok_all and ok_b) else "SOME FAILED")
+
+# ---------------------------------------------------------------------------------------------------------------- rank-320 chains
+# aql_lora_chain_fwd_r320 against  aql_lora_down (LoRA rows only) + aql_gemm_bf16 with the second K segment [Ts | Bup]  (+ residual) ->
+# aql_layernorm_fwd -> ...  on the twin batch of BASELINE config 3 (batch 8: 65536 rows) and smaller ones
+print("rank-320 chains:", flush=True)
+ok_w = True
+R3 = 320
+
+
+def lin3(bias=True):
+    return dict(W=rnd(C, C, std=C ** -0.5), bias=rnd(C, std=0.1) if bias else None, Ad=rnd(R3, C, std=C ** -0.5), Bup=rnd(C, R3, std=0.05))
+
+
+def unfused3(x, p, S, rps, row0, res, M):
+    y = torch.empty(M, C, dtype=torch.bfloat16, device=dev)
+    T = torch.full((M, R3), float("nan"), dtype=torch.bfloat16, device=dev)
+    Ts = torch.full((M, R3), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.lora_down(x[row0:], C, M - row0, C, p["Ad"], R3, S[row0 // rps:], rps, T[row0:], Ts[row0:])
+    ops.gemm_bf16(x, p["W"], p["bias"], A2=Ts, B2=p["Bup"], residual=res, out=y, lora_row0=row0)
+    return y, T, Ts
+
+
+for name, M, nb, twin, nq in [("a: to_out+res -> LN -> to_q", 65536, 16, True, 1), ("d: proj_in -> LN -> q|k|v", 65536, 16, True, 3),
+                              ("b': to_out+res -> LN", 65536, 16, True, 0), ("a, no twin", 32768, 8, False, 1),
+                              ("d, batch 4 twin", 32768, 8, True, 3)]:
+    rps = M // nb
+    row0 = M // 2 if twin else 0
+    X, R = rnd(M, C), rnd(M, C)
+    S = rnd(nb, R3)
+    if twin:
+        S[: nb // 2] = 0
+    p0 = lin3()
+    qs = [lin3(bias=False) for _ in range(nq)]
+    gamma, beta = rnd(C, std=0.3) + 1, rnd(C, std=0.1)
+
+    def run_unfused():
+        hs, T0, Ts0 = unfused3(X, p0, S, rps, row0, R, M)
+        n, st = unfused_ln(hs, gamma, beta, M)
+        outs = [unfused3(n, q, S, rps, row0, None, M) for q in qs]
+        return hs, T0, Ts0, n, st, outs
+
+    hs2 = torch.empty(M, C, dtype=torch.bfloat16, device=dev)
+    n2 = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=dev)
+    st2 = torch.empty(M, 2, dtype=torch.float32, device=dev)
+    T2 = [torch.full((M, R3), float("nan"), dtype=torch.bfloat16, device=dev) for _ in range(nq + 1)]
+    Ts2 = [torch.full((M, R3), float("nan"), dtype=torch.bfloat16, device=dev) for _ in range(nq + 1)]
+    q2 = [torch.empty(M, C, dtype=torch.bfloat16, device=dev) for _ in range(nq)]
+    stages = [dict(p0, ldw=C, T=T2[0], Ts=Ts2[0], res=R, ldr=C, out=hs2, ldo=C, keep=1, ln=1, gamma=gamma, beta=beta, eps=1e-5,
+                   stats=st2, nout=n2, ldn=C, nout_row0=(row0 if nq else 0))]
+    for i, q in enumerate(qs):
+        stages.append(dict(q, ldw=C, T=T2[i + 1], Ts=Ts2[i + 1], out=q2[i], ldo=C, keep=0))
+
+    def run_chain():
+        ops.chain_fwd(X, C, M, rps, row0, S, stages, rank=R3)
+
+    hs, T0, Ts0, n, st, outs = run_unfused()
+    run_chain()
+    torch.cuda.synchronize()
+    checks = {"hs": eq(hs, hs2), "ln": eq(n, n2, row0 if nq else 0), "stats": torch.equal(st, st2), "T0": eq(T0, T2[0], row0),
+              "Ts0": eq(Ts0, Ts2[0], row0)}
+    for i, (y, T, Ts) in enumerate(outs):
+        checks[f"q{i}"] = eq(y, q2[i])
+        checks[f"T{i + 1}"] = eq(T, T2[i + 1], row0)
+        checks[f"Ts{i + 1}"] = eq(Ts, Ts2[i + 1], row0)
+    ok = all(checks.values())
+    ok_w &= ok
+    bad = [k for k, v in checks.items() if not v]
+    extra = ""
+    if not ok:
+        for k, (u, c) in {"hs": (hs, hs2), "ln": (n, n2), "T0": (T0[row0:], T2[0][row0:]), "Ts0": (Ts0[row0:], Ts2[0][row0:])}.items():
+            d = (u.float() - c.float()).abs()
+            extra += f" | {k}: {int((d > 0).sum())} differ, max {float(d.nan_to_num(9e9).max()):.3e}"
+        for i, (y, _, _) in enumerate(outs):
+            d = (y.float() - q2[i].float()).abs()
+            extra += f" | q{i}: {int((d > 0).sum())} differ, max {float(d.nan_to_num(9e9).max()):.3e}"
+    line = f"{'PASS' if ok else 'FAIL'} chain r320 [{name}] M{M}: bit-identical {ok} {bad}{extra}"
+    if TIME:
+        tu, tc = graph_time(run_unfused), graph_time(run_chain)
+        line += f" | unfused {tu:.1f} us, chain {tc:.1f} us, ratio {tc / tu:.2f}"
+    print(line, flush=True)
+
+print("ALL PASS" if (ok_all and ok_b and ok_w) else "SOME FAILED")
