@@ -105,7 +105,7 @@ def time_kernel(fn, iters=20):
 def dominant_kernels(B, device):
     """HIP-event timings (torch's current stream == the launch stream of the C-ABI calls) of the heaviest launch of each
     kernel family, at the shapes the step runs them.  kernels[0] is the heaviest launch of the TIME-dominant family (the
-    one-launch LoRA linears: 34 % of the step, profiles/r04_families_config2.json): ff.net.0.proj + rank-32 LoRA + GEGLU on the twin
+    one-launch LoRA linears: 34 % of the step, profiles/r05_families_config2.json): ff.net.0.proj + rank-32 LoRA + GEGLU on the twin
     batch of the 64x64 level.  The forward runs both U-Net passes as ONE twin batch of 2B samples (ops._Dual), so forward
     launches see 2B samples; rows of the clean half skip the LoRA branch (lora_row0)."""
     from aqualora_amd import _lib as L
@@ -194,7 +194,7 @@ def profile_staleness():
     """Which kernel sources changed since the committed profiles (families, PMC traffic, MfmaUtil) were taken: those sections of the
     line are read from files, not measured in this run, and describe an older library when this list is not empty."""
     import hashlib
-    meta = load_profile_json("r04_meta.json")
+    meta = load_profile_json("r05_meta.json")
     if meta is None:
         return {"profile_meta": "missing"}
     changed = []
@@ -729,8 +729,8 @@ def main():
         # `roofline` = the heaviest launch of the TIME-dominant kernel family (the one-launch LoRA linears, `families` below),
         # timed live with HIP events on the launch stream.  `traffic` = HBM bytes per launch of the same kernel and shape from
         # the rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 2x FETCH correction, tools/pmc_traffic.sh),
-        # read from the committed profiles/r04_pmc_traffic.json -- NOT measured in this run; null without a committed pass.
-        pmc = load_profile_json("r04_pmc_traffic.json") or {}
+        # read from the committed profiles/r05_pmc_traffic.json -- NOT measured in this run; null without a committed pass.
+        pmc = load_profile_json("r05_pmc_traffic.json") or {}
         ent = pmc.get(dom.get("pmc_key", ""))
         traffic = None if ent is None else ent["traffic_bytes"]
         line["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_tflops"],
@@ -738,7 +738,7 @@ def main():
                             "traffic": traffic, "traffic_unit": f"bytes/launch (algorithmic: {dom['algorithmic_bytes']:.4g})",
                             "traffic_source": None if traffic is None else
                             "static, not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel + shape, "
-                            "profiles/r04_pmc_traffic.json",
+                            "profiles/r05_pmc_traffic.json",
                             "flops_per_launch": dom["flops"], "ms_per_launch": dom["ms"], "timing": dom["timing"],
                             "selected_by": "largest ms/step family of the committed kernel trace (families), heaviest launch of it",
                             "hbm_view": {"achieved_GBps": dom["algorithmic_bytes"] / dom["ms"] / 1e6, "peak_GBps": 8000.0,
@@ -747,9 +747,9 @@ def main():
             e = pmc.get(k.get("pmc_key", ""))
             if e is not None:
                 k["traffic_bytes_static"] = e["traffic_bytes"]
-        fam = load_profile_json(f"r04_families_config{args.config}.json")
+        fam = load_profile_json(f"r05_families_config{args.config}.json")
         if fam is not None:
-            line["families"] = {"source": f"static, not measured in this run: profiles/r04_families_config{args.config}.json "
+            line["families"] = {"source": f"static, not measured in this run: profiles/r05_families_config{args.config}.json "
                                           "(tools/prof_families.py over a rocprofv3 --kernel-trace of this command)",
                                 "ms_per_step_profiled": fam.get("ms_per_step"), "launches_per_step": fam.get("launches_per_step"),
                                 "rows": fam.get("families")}
@@ -759,9 +759,9 @@ def main():
         line["kernels"] = ks
         line["static_profile_sections"] = dict(profile_staleness(), sections=["roofline.traffic", "families", "mfma_util_pmc",
                                                                              "kernels[].traffic_bytes_static"])
-        mu = load_profile_json("r04_pmc_mfma_util.json")
+        mu = load_profile_json("r05_pmc_mfma_util.json")
         if mu is not None:   # rocprofv3 MfmaUtil (matrix-pipe busy fraction) of the attention / conv / LoRA kernels: static evidence
-            line["mfma_util_pmc"] = {"source": "static, not measured in this run: profiles/r04_pmc_mfma_util.json (rocprofv3 --pmc pass)",
+            line["mfma_util_pmc"] = {"source": "static, not measured in this run: profiles/r05_pmc_mfma_util.json (rocprofv3 --pmc pass)",
                                      "kernels": {k: v["mfma_util"] for k, v in mu["kernels"].items()},
                                      "attention_64x64_time_weighted": mu.get("attention_64x64_time_weighted")}
         if world == 1 and not args.no_extras and not (args.pixel_in or args.text_in):

@@ -8,7 +8,7 @@ for i in range(1, n + 1):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for row in csv.DictReader(open(files[0])):
         k = re.sub(r"\(.*", "", row["Kernel_Name"].replace("(anonymous namespace)::", ""))
-        if not any(t in k for t in ("gemm_kernel", "geglu256_kernel", "conv_row_kernel", "attn_", "gemm_tn_tr")): continue
+        if not any(t in k for t in ("gemm_kernel", "geglu256_kernel", "conv_row_kernel", "attn_", "gemm_tn_tr", "chain_kernel", "chain_wide_kernel")): continue
         agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, cs in agg.items():
         print(f"pass {i}: {k[:90]}")

@@ -22,7 +22,7 @@ FAMILIES = [   # first match wins
     ("attention", r"attn_"),
     ("conv3x3", r"conv_row_kernel|ConvFwdLoader|ConvBwdLoader"),
     ("weight_grad", r"gemm_tn|lora_ds"),
-    ("linear", r"lora_gemm_kernel|lora_geglu256_kernel|lora_down|gemm_kernel|chain_kernel"),   # (the chain kernels carry their LayerNorms: round 5)
+    ("linear", r"lora_gemm_kernel|lora_geglu256_kernel|lora_down|gemm_kernel|chain_kernel|chain_wide_kernel"),   # (the chain kernels carry their LayerNorms: round 5)
     ("groupnorm", r"gn_"),
     ("layernorm", r"ln_kernel"),
     ("splitk_finalize", r"splitk_finalize"),
