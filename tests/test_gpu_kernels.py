@@ -311,3 +311,44 @@ def test_transformer_block_through_chains_equals_the_per_launch_block(rank):
     # upstream of the q | k | v sum the gradients inherit its bf16-level difference (proj_in, norm1); everything else sees equal inputs
     assert g_a.abs().max() > 0 and diff < 5e-3, (spread, diff)
     assert ((ds_a - ds_c).abs().max() / ds_a.abs().max()).item() < 5e-3
+
+
+@pytest.mark.parametrize("B,N", [(4, 4096), (1, 2048)])   # 256-row (NOF = 4) and 128-row (NOF = 2) workgroups of attn_fwd_kernel
+def test_attention_overflow_fallback_forward_and_backward_vs_fp32(B, N):
+    """The default self-attention forward fixes the softmax shift from the FIRST key tile and re-runs a workgroup with the
+    running-maximum pass when a later score overflows it (csrc/aql_attn.hip, FOLD = 1).  Here the LAST key scores ~150 (natural log
+    units) above everything in the first tile for every second query row, so the fallback runs in every workgroup while half of each
+    workgroup's rows would have been fine: O, and dq / dk / dv through the saved lse, against an fp32 softmax attention."""
+    from aqualora_amd import ops
+    torch.manual_seed(5)
+    dev, H, d = "cuda", 8, 40
+    C = H * d
+    q = torch.randn(B, N, H, d, device=dev)
+    k = torch.randn(B, N, H, d, device=dev)
+    v = torch.randn(B, N, H, d, device=dev)
+    u = torch.ones(d, device=dev) / d ** 0.5
+    q[:, ::2] += 4.0 * d ** 0.5 * u          # q.u = 4 sqrt(d) + noise on the even rows
+    k[:, -1] = 40.0 * u                      # => score (q.k) / sqrt(d) ~ 160 on those rows, ~0 on the odd ones
+    q16, k16, v16 = (t.reshape(B, N, C).to(torch.bfloat16).requires_grad_(True) for t in (q, k, v))
+    do = torch.randn(B, N, C, device=dev).to(torch.bfloat16)
+    o = ops.attention(q16, k16, v16, H)
+    o.backward(do)
+    assert torch.isfinite(o).all() and all(torch.isfinite(t.grad).all() for t in (q16, k16, v16))
+    # fp32 reference on the bf16-rounded inputs, a few heads at a time
+    qf, kf, vf = (t.detach().float().view(B, N, H, d).permute(0, 2, 1, 3).requires_grad_(True) for t in (q16, k16, v16))
+    dof = do.float().view(B, N, H, d).permute(0, 2, 1, 3)
+    outs = []
+    for b in range(B):
+        s = torch.einsum("hqd,hkd->hqk", qf[b], kf[b]) * d ** -0.5
+        ob = torch.einsum("hqk,hkd->hqd", torch.softmax(s, dim=-1), vf[b])
+        ob.backward(dof[b])
+        outs.append(ob.detach())
+        del s, ob
+    of = torch.stack(outs).permute(0, 2, 1, 3).reshape(B, N, C)
+    err = lambda a, b_: ((a.float() - b_).abs().max() / b_.abs().max()).item()   # noqa: E731
+    e_o = err(o, of)
+    e_q = err(q16.grad, qf.grad.permute(0, 2, 1, 3).reshape(B, N, C))
+    e_k = err(k16.grad, kf.grad.permute(0, 2, 1, 3).reshape(B, N, C))
+    e_v = err(v16.grad, vf.grad.permute(0, 2, 1, 3).reshape(B, N, C))
+    print(f"attention under a late spike, B {B} N {N}: o {e_o:.2e} dq {e_q:.2e} dk {e_k:.2e} dv {e_v:.2e}")
+    assert e_o < 8e-3 and e_q < 1.5e-2 and e_k < 1.5e-2 and e_v < 1.5e-2, (e_o, e_q, e_k, e_v)
