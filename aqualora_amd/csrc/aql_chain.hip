@@ -72,7 +72,7 @@ struct Args {
   const bf16_t* S;   // [nsamples][32] scale rows
   int M, rps, row0, nstage;
   int has_pre;        // a row pass on the chain INPUT in front of the first linear (backward chains: LN backward of the incoming gradient)
-  long long* trace;   // tools/trace_chain.py (AQL_CHAIN_TRACE_BUF): 32 cycle stamps per (block, wave 0 / wave 4); null in production
+  long long* trace;   // -DAQL_CHAIN_TRACE builds (tools/trace_chain.py): 32 cycle stamps per (block, wave 0 / wave 4); null otherwise
   Stage pre;          // row-pass fields only
   Stage st[MAXS];
 };
@@ -423,7 +423,11 @@ __global__ __launch_bounds__(NTH, 2) void chain_kernel(const Args a) {
   const bool lora_tile = m0 + BM > a.row0;   // block-uniform
   int mark_ = 0;
   long long* const trc = (a.trace != nullptr && lane == 0 && (wave == 0 || wave == 4)) ? a.trace + ((long)blockIdx.x * 2 + (wave >> 2)) * 32 : nullptr;
+#ifdef AQL_CHAIN_TRACE   // tools/trace_chain.py on a trace build (tools/build_alt.sh trace aql_chain.hip -DAQL_CHAIN_TRACE=1)
 #define CH_STAMP() do { if (trc != nullptr && mark_ < 32) trc[mark_] = __builtin_readcyclecounter(); ++mark_; } while (0)
+#else
+#define CH_STAMP() do { (void)trc; (void)mark_; } while (0)
+#endif
   CH_STAMP();   // 0 start
 
   // ---- lane constants
@@ -712,7 +716,11 @@ __global__ __launch_bounds__(NTH, 2) void chain_wide_kernel(const Args a) {
   const bool lora_tile = m0 + BM > a.row0;   // block-uniform
   int mark_ = 0;
   long long* const trc = (a.trace != nullptr && lane == 0 && (wave == 0 || wave == 4)) ? a.trace + ((long)blockIdx.x * 2 + (wave >> 2)) * 32 : nullptr;
+#ifdef AQL_CHAIN_TRACE
 #define CW_STAMP() do { if (trc != nullptr && mark_ < 32) trc[mark_] = __builtin_readcyclecounter(); ++mark_; } while (0)
+#else
+#define CW_STAMP() do { (void)trc; (void)mark_; } while (0)
+#endif
   CW_STAMP();   // 0 start (tools/trace_chain.py wide)
   const int l15 = lane & 15, q4 = lane >> 4;
   const int lo = l15 * 64 + ((q4 ^ swz4(l15)) << 4);
@@ -942,10 +950,14 @@ int chain_launch(Args& a, long M, const char* name, bool bwd, hipStream_t stream
     (void)hipFuncSetAttribute((const void*)chain_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LayW::TOTAL);
     once = true;
   }
+#ifdef AQL_CHAIN_TRACE
   {
-    const char* tb = getenv("AQL_CHAIN_TRACE_BUF");   // device address of the stamp buffer (tools/trace_chain.py)
+    const char* tb = getenv("AQL_CHAIN_TRACE_BUF");   // device address of the stamp buffer (tools/trace_chain.py, trace builds only)
     a.trace = tb ? (long long*)strtoull(tb, nullptr, 0) : nullptr;
   }
+#else
+  a.trace = nullptr;
+#endif
   // 128-row tiles while they fill the chip (the twin forward: 256 tiles), 64-row tiles below that (the backward pass runs on the
   // watermarked half only: 16384 rows = 128 tiles of 128 -- half the CUs idle -- or 256 of 64)
   static const int force = getenv("AQL_CHAIN_BM") ? atoi(getenv("AQL_CHAIN_BM")) : 0;   // tuning hook

@@ -1,5 +1,7 @@
 """Phase timeline of one workgroup of the row-resident chain kernel (aql_lora_chain_fwd): cycle stamps of wavefronts 0 and 4 of
-every block, written when AQL_CHAIN_TRACE_BUF names a device buffer.  Prints the median over blocks of each phase's length."""
+every block, written when AQL_CHAIN_TRACE_BUF names a device buffer.  Prints the median over blocks of each phase's length.
+Needs a trace build of the library (the product build has no stamps):
+    tools/build_alt.sh trace aql_chain.hip -DAQL_CHAIN_TRACE=1  &&  AQL_LIB=altlib/trace.so python tools/trace_chain.py 1 [wide]"""
 import os
 import sys
 
