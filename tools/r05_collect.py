@@ -1,0 +1,69 @@
+"""Copies the summaries tools/r05_refresh.sh left in gpurun_out/r05/ into profiles/r05_* and rebuilds the JSON files bench.py reads
+(r05_pmc_traffic.json, r05_pmc_mfma_util.json, r05_meta.json).  Run in the build container after the gpurun call."""
+import hashlib
+import json
+import os
+import re
+import shutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R, P = os.path.join(ROOT, "gpurun_out", "r05"), os.path.join(ROOT, "profiles")
+for src, dst in (("insitu_r05final_summary.txt", "r05_kernel_trace_graph_step.txt"), ("insitu_r05final_shapes.txt", "r05_kernel_trace_by_shape.txt"),
+                 ("insitu_r05final_sequence.txt", "r05_step_sequence.txt"), ("insitu_r05final_c3_summary.txt", "r05_kernel_trace_config3.txt"),
+                 ("insitu_r05final_families.json", "r05_families_config2.json"), ("insitu_r05final_c3_families.json", "r05_families_config3.json"),
+                 ("robft_r05_stats.txt", "r05_robft_stats.txt"), ("extract_b1_stats.txt", "r05_extract_b1_stats.txt"),
+                 ("extract_b16_stats.txt", "r05_extract_b16_stats.txt"), ("prof_vae.txt", "r05_vae_stats.txt"),
+                 ("infer_r05_stats.txt", "r05_infer_stats.txt"), ("pmc_mfma_util.txt", "r05_pmc_mfma_util.txt")):
+    shutil.copy(os.path.join(R, src), os.path.join(P, dst))
+
+
+def rd(name):
+    t = open(os.path.join(R, name)).read()
+    return float(re.search(r"FETCH_SIZE\s+([\d.]+)", t).group(1)), float(re.search(r"WRITE_SIZE\s+([\d.]+)", t).group(1))
+
+
+tr = json.load(open(os.path.join(P, "r05_pmc_traffic.json")))
+for key, name in (("lora_geglu 320->2x1280 M=32768", "pmct_geglu.txt"), ("conv3x3 320->320 @64x64 B=8", "pmct_conv8.txt"),
+                  ("chain a: to_out+res -> LN -> to_q, M=32768 (twin)", "pmct_chain.txt")):
+    f, w = rd(name)
+    tr[key].update(FETCH_SIZE_KiB=f, WRITE_SIZE_KiB=w, traffic_bytes=int((2 * f + w) * 1024))
+json.dump(tr, open(os.path.join(P, "r05_pmc_traffic.json"), "w"), indent=1)
+
+rows, cur = {}, None
+for line in open(os.path.join(P, "r05_pmc_mfma_util.txt")):
+    m = re.match(r"== pmc_one.py (.*)", line)
+    if m:
+        cur = m[1].strip()
+        continue
+    m = re.match(r"(\S.*?)\s+(\d+)\s+(\d+)\s+([\d.]+)\s+(\d+)\s+([\d.]+)\s+(\d+)\s+([\d.]+)\s*$", line)
+    if m and cur:
+        rows.setdefault(cur, {})[m[1].strip()] = (float(m[4]), round(float(m[8]) / 100, 3))
+mu = json.load(open(os.path.join(P, "r05_pmc_mfma_util.json")))
+K = mu["kernels"]
+
+
+def put(prefix, vals):
+    key = next(k for k in K if k.startswith(prefix))
+    K[key]["us"] = [v[0] for v in vals]
+    K[key]["mfma_util"] = [v[1] for v in vals]
+
+
+for kern, prefix in (("attn_fwd_kernel<64, 48, 4, true, 1>", "attn_fwd_kernel"), ("attn_dq_kernel<64, 48, true>", "attn_dq_kernel"),
+                     ("attn_dkv_kernel<64, 48, true>", "attn_dkv_kernel")):
+    put(prefix, [rows["attn 4 4096 8"][kern], rows["attn 8 4096 8"][kern]])
+put("conv_row_kernel", [rows["conv 8 64 320 320"]["aqlconvrow::conv_row_kernel<64, 4, false, false, 160, 64>"]])
+put("lora_geglu256_kernel", [rows["geglu 32768 1280 320"]["aqlt256::lora_geglu256_kernel<false>"]])
+put("lora_gemm_kernel", [rows["lora 32768 320 320"]["lora_gemm_kernel<128, 160, 64, 80, 2>"]])
+put("chain_kernel", [rows["chain 32768"]["aqlchain::chain_kernel<2, false>"]])
+f, q, kv = (K[next(k for k in K if k.startswith(p))] for p in ("attn_fwd_kernel", "attn_dq_kernel", "attn_dkv_kernel"))
+num = f["mfma_util"][1] * f["us"][1] + q["mfma_util"][0] * q["us"][0] + kv["mfma_util"][0] * kv["us"][0]
+mu["attention_64x64_time_weighted"] = round(num / (f["us"][1] + q["us"][0] + kv["us"][0]), 3)
+json.dump(mu, open(os.path.join(P, "r05_pmc_mfma_util.json"), "w"), indent=1)
+
+meta = json.load(open(os.path.join(P, "r05_meta.json")))
+meta["files"] = {f: hashlib.sha256(open(os.path.join(ROOT, "aqualora_amd", "csrc", f), "rb").read()).hexdigest()[:16] for f in meta["files"]}
+json.dump(meta, open(os.path.join(P, "r05_meta.json"), "w"), indent=1)
+fam = json.load(open(os.path.join(P, "r05_families_config2.json")))
+print("config 2:", fam["ms_per_step"], fam["kernel_busy_ms_per_step"], fam["launches_per_step"])
+fam = json.load(open(os.path.join(P, "r05_families_config3.json")))
+print("config 3:", fam["ms_per_step"], fam["kernel_busy_ms_per_step"], fam["launches_per_step"])
