@@ -279,7 +279,11 @@ inline void pick_tile(long M, int N, int kt_total, bool can_split, int* cfg, int
     // 12-wave workgroups on 256x160 tiles: ONE chip-wide round (AQL_W256=0 disables)
     static const int use_w256 = env_int("AQL_W256", 1);
     const int t256 = aql_cdiv(M, 256) * nt;
-    if (use_w && use_w256 && kt_total >= 8 && t256 >= 240 && t256 <= 256) *cfg = P_W256x160, *tiles = t256;
+    // (round 5: also 176-239 tiles under a short K -- q | k | v at the 16 x 16 / 32 x 32 levels, 2048 x 3840 x 1280 and 4096 x 1920 x 640:
+    // 192 tiles in ONE round on three quarters of the chip, 34.2 / 22.4 us against 41.5 / 24.8 on one and a half rounds of 128 x 160;
+    // at K >= 2560 the same grid loses, 88 against 63 us)
+    if (use_w && use_w256 && kt_total >= 8 && ((t256 >= 240 && t256 <= 256) || (t256 >= 176 && t256 < 240 && kt_total <= 20)))
+      *cfg = P_W256x160, *tiles = t256;
     if (force == P_W256x160 || force == P_W256x160B) *cfg = force, *tiles = t256;
     if (force == P_W128x160 || force == P_W128x160L8) *cfg = force, *tiles = t128;
     if (force == P_W64x160) *cfg = force, *tiles = t64;

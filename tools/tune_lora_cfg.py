@@ -56,6 +56,7 @@ def shapes():
             out.append((tag, M, C, C, False))           # attention / 1x1 projections
             out.append((tag, M, C, 4 * C, False))       # ff.net.2 (fwd) / ff.net.0 backward has K = 8C
             if tag == "twin-fwd":
+                out.append((tag + "-qkv", M, 3 * C, C, False))    # q | k | v (the grouped launch has this shape)
                 out.append((tag + "-geglu", M, 8 * C, C, True))   # ff.net.0 + GEGLU
             else:
                 out.append((tag, M, C, 8 * C, False))   # d(ff.net.0): N = C, K = 8C
@@ -63,7 +64,10 @@ def shapes():
     return out
 
 
+ONLY = os.environ.get("ONLY")     # e.g. ONLY=qkv: shapes whose tag contains the string
 for tag, M, N, K, geglu in shapes():
+    if ONLY and ONLY not in tag:
+        continue
     def mk():
         X, W, A, Bup, S = rnd(M, K), rnd(N, K), rnd(32, K), rnd(N, 32), rnd(2 * B, 32)
         T, Ts = torch.empty(M, 32, dtype=torch.bfloat16, device=dev), torch.empty(M, 32, dtype=torch.bfloat16, device=dev)
