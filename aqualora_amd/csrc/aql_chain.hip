@@ -757,7 +757,8 @@ __global__ __launch_bounds__(NTH, 2) void chain_wide_kernel(const Args a) {
     // ---- weight-tile stream: segments of 10 tiles [320 rows][32 k]; a stage with LoRA on a LoRA tile has three (A_down, W, Bup), else
     // one (W).  The ISSUE cursor runs two tiles ahead of the consuming loops, across segments and stages.
     // Ring: 3 slots behind the two panels on a LoRA tile; a clean tile never builds a Ts panel and takes its 40 KB as two more slots
-    // (5 slots, 4 tiles in flight: the K loop is bound by the latency of the L2 -> LDS requests in flight, not by their bandwidth)
+    // (5 slots, 4 tiles in flight -- measured neutral: the launch is made of its HBM traffic and of epilogue / row-pass phases that do
+    // not overlap the K loops, profiles/r05_chain_r320.txt; kept because it is free)
     constexpr int NS = decltype(ns_tag)::value, PD = NS - 1;
     constexpr int RING0 = NS == NSTG ? LY::OFF_RING : LY::OFF_TSW;
     int wr = 0, rd = 0;
