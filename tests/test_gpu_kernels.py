@@ -237,6 +237,15 @@ def test_row_resident_chain_kernel_repeats_bit_for_bit_under_memory_load():
     assert out.returncode == 0 and len(lines) == 3 and all("mismatching outputs: 0 " in l for l in lines), text[-2000:]
 
 
+def test_rank320_chain_kernel_repeats_bit_for_bit_under_memory_load():
+    """The same stress on the rank-320 kernel (aql_lora_chain_fwd_r320, config 3's 65536-row twin batch): 4 launches back to back behind
+    a bandwidth-bound kernel, 10 times per chain form."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_chain2.py"), "10", "wide"], capture_output=True, text=True, timeout=900)
+    text = out.stdout + out.stderr
+    lines = [l for l in text.splitlines() if "mismatching outputs" in l]
+    assert out.returncode == 0 and len(lines) == 3 and all("mismatching outputs: 0 " in l for l in lines), text[-2000:]
+
+
 @pytest.mark.parametrize("rank", [32, 320])
 def test_transformer_block_through_chains_equals_the_per_launch_block(rank):
     """unet.Transformer2DModel at 320 channels on a twin batch of 8 x 64 x 64: with ops.CHAIN the three chains (ops.ChainFn) replace nine
