@@ -55,8 +55,8 @@ SIGNATURES = {
     "aql_layernorm_fwd": [c_p, c_l, c_i, c_p, c_p, c_f, c_p, c_p, c_p],
     "aql_layernorm_bwd": [c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p],
     # X ldx M rps row0 S nstage | W ldw bias Adown Bup T Ts res ldr out ldo keep ln gamma beta eps stats nout ldn nout_row0 | stream
-    "aql_lora_chain_fwd": [c_p, c_l, c_l, c_i, c_l, c_p, c_i] + [c_p] * 20 + [c_p],
-    "aql_lora_chain_fwd_r320": [c_p, c_l, c_l, c_i, c_l, c_p, c_i] + [c_p] * 20 + [c_p],
+    "aql_lora_chain_fwd": [c_p, c_l, c_l, c_i, c_l, c_p, c_i] + [c_p] * 21 + [c_p],
+    "aql_lora_chain_fwd_r320": [c_p, c_l, c_l, c_i, c_l, c_p, c_i] + [c_p] * 21 + [c_p],
     # dY lddy M rps S nstage | Wt ldw BupT AT dTs dT dX lddx keep | ln_x ld_lnx ln_stats ln_gamma ln_dres ld_dres ln_out ld_lnout | stream
     "aql_lora_chain_bwd": [c_p, c_l, c_l, c_i, c_p, c_i] + [c_p] * 17 + [c_p],
     "aql_geglu_fwd": [c_p, c_l, c_i, c_p, c_p],
@@ -129,6 +129,9 @@ SIGNATURES = {
     "aql_sdpa_fwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p, c_p],
     "aql_sdpa_bwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p,
                      c_p, c_p, c_sz, c_p],
+    "aql_sdpa_fwd_qpre": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p, c_p],
+    "aql_sdpa_bwd_qpre": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p,
+                          c_p, c_p, c_sz, c_p],
     "aql_abi_version": [],
     "aql_comm_available": [],
     "aql_comm_unique_id": [c_p],
@@ -141,7 +144,7 @@ SIGNATURES = {
     "aql_comm_abort": [c_p],
     "aql_comm_destroy": [c_p],
 }
-ABI_VERSION = 3   # == AQL_ABI_VERSION of include/aqualora_hip.h this table was written against
+ABI_VERSION = 4   # == AQL_ABI_VERSION of include/aqualora_hip.h this table was written against
 
 _lib = None
 

@@ -373,6 +373,12 @@ struct AttnArgs {
   long ldq, ldk, ldv, ldo;
   int B, H, Nq, Nk, d;
   float scale;
+  // exponent and natural-log factors of a raw score q.k:  p = exp2(s * cexp - ...), lse = max * cnat + log(sum).  (scale log2(e), scale) --
+  // or (1, ln 2) when q arrives PRE-MULTIPLIED by scale log2(e) from its producer's epilogue (qpre: aql_sdpa_*_qpre; one bf16 rounding of
+  // q c instead of q, so the no-FMA forward loop, FOLD = 2, keeps the precision of the default one).  dQ is the gradient of the UNSCALED
+  // q in both cases (multiplier `scale`); dK = cnat dS^T q.
+  float cexp, cnat;
+  int qpre;
   int qsplit;    // dK/dV only: the streamed Q range is cut into qsplit pieces (grid.z = B * qsplit) ...
   float* part;   // ... whose fp32 partial results [2][qsplit][B][H][Nk][d] are summed by attn_dkv_reduce_kernel
 };
@@ -429,7 +435,7 @@ __device__ __forceinline__ bool attn_fwd_pass(const AttnArgs& a, char* sK, char*
   const bf16_t* vp = a.v + (long)b * a.Nk * a.ldv + h * a.d;
   bf16x8_t qf[NOF][DH / 32];
   load_owner<DH>(qf, qp, a.ldq, q0, a.Nq, a.d, lane);
-  const float c = a.scale * LOG2E;
+  const float c = a.cexp;
   uint4 cm[DH / 32];   // FOLD = 2: halfword mask of the shift column in this lane's Q fragments
   if constexpr (FOLD == 2) {
 #pragma unroll
@@ -644,7 +650,7 @@ __device__ __forceinline__ bool attn_fwd_pass(const AttnArgs& a, char* sK, char*
   for (int of = 0; of < NOF; ++of) {
     inv[of] = 1.f / l[of];
     if constexpr (FOLD != 0) {
-      lse[of] = (FOLD == 2 ? m[of] * 0.6931471805599453f : m[of] * a.scale) + logf(l[of]);
+      lse[of] = (FOLD == 2 ? m[of] * 0.6931471805599453f : m[of] * a.cnat) + logf(l[of]);
       float big = 0.f;
 #pragma unroll
       for (int df = 0; df < DV / 16; ++df)
@@ -652,7 +658,7 @@ __device__ __forceinline__ bool attn_fwd_pass(const AttnArgs& a, char* sK, char*
         for (int e = 0; e < 4; ++e) big = fmaxf(big, fabsf(o[df][of][e]));
       ok &= (l[of] > 0.f) & (l[of] < INFINITY) & (big < INFINITY);    // NaN fails every comparison
     } else {
-      lse[of] = m[of] * a.scale + logf(l[of]);
+      lse[of] = m[of] * a.cnat + logf(l[of]);
     }
   }
   return ok;
@@ -752,7 +758,7 @@ __global__ __launch_bounds__(256, (DH <= AQL_ATTN_DQ_OCC2_UPTO ? 2 : 1)) void at
   }
   f32x4_t dq[DV / 16][2];
   zero_acc(dq);
-  const float c = a.scale * LOG2E;
+  const float c = a.cexp;
   Stager<DH> stK, stV;
   DmaTile<DH> dmK, dmV;
   if constexpr (DMA) {
@@ -883,7 +889,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dkv_kernel(const
   f32x4_t dk[DV / 16][2], dv[DV / 16][2];
   zero_acc(dk);
   zero_acc(dv);
-  const float c = a.scale * LOG2E;
+  const float c = a.cexp;
   Stager<DH> stQ, stO;
   DmaTile<DH> dmQ, dmO;
   const float* lse_row = a.lse + ((long)b * a.H + h) * a.Nq;
@@ -998,7 +1004,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dkv_kernel(const
     store_t_f32<DV>(dv, pk + slab, a.d, k0, a.Nk, a.d, lane);
     return;
   }
-  const float mk[2] = {a.scale, a.scale}, mv[2] = {1.f, 1.f};
+  const float mk[2] = {a.cnat, a.cnat}, mv[2] = {1.f, 1.f};
   store_t<DV>(dk, a.dk + (long)b * a.Nk * ldo_kv + h * a.d, ldo_kv, k0, a.Nk, a.d, mk, lane);
   store_t<DV>(dv, a.dv + (long)b * a.Nk * ldo_kv + h * a.d, ldo_kv, k0, a.Nk, a.d, mv, lane);
 }
@@ -1023,7 +1029,7 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const AttnArgs a) 
       const float4 t = *reinterpret_cast<const float4*>(p + sp * sstride);
       acc.x += t.x, acc.y += t.y, acc.z += t.z, acc.w += t.w;
     }
-    const float mul = which ? 1.f : a.scale;
+    const float mul = which ? 1.f : a.cnat;
     bf16_t* out = (which ? a.dv : a.dk) + ((long)b * a.Nk + row) * ((long)a.H * a.d) + h * a.d + c;
     *reinterpret_cast<uint2*>(out) = make_uint2(pack_bf16x2(acc.x * mul, acc.y * mul), pack_bf16x2(acc.z * mul, acc.w * mul));
   }
@@ -1150,7 +1156,7 @@ __global__ __launch_bounds__(256, (DH <= 96 ? 2 : 1)) void attn_ctx_fwd_kernel(c
   ctx_stage<DH>(sK, a.k + (long)b * a.Nk * a.ldk + h * a.d, a.ldk, a.Nk, a.d, tid);
   ctx_stage<DH>(sV, a.v + (long)b * a.Nk * a.ldv + h * a.d, a.ldv, a.Nk, a.d, tid);
   __syncthreads();
-  const float c = a.scale * LOG2E;
+  const float c = a.cexp;
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int q0 = wg_q0 + (i * 4 + wave) * OWN;
@@ -1181,7 +1187,7 @@ __global__ __launch_bounds__(256, (DH <= 96 ? 2 : 1)) void attn_ctx_fwd_kernel(c
         }
       rs = group4_sum(rs);
       inv[of] = 1.f / rs;
-      lsev[of] = mx * a.scale + logf(rs);
+      lsev[of] = mx * a.cnat + logf(rs);
     }
     bf16x8_t pb[3][2];
     ctx_pack_p(pb, s);
@@ -1226,7 +1232,7 @@ __global__ __launch_bounds__(256, (DH <= 96 ? 2 : 1)) void attn_ctx_dq_kernel(co
   ctx_stage<DH>(sK, a.k + (long)b * a.Nk * a.ldk + h * a.d, a.ldk, a.Nk, a.d, tid);
   ctx_stage<DH>(sV, a.v + (long)b * a.Nk * a.ldv + h * a.d, a.ldv, a.Nk, a.d, tid);
   __syncthreads();
-  const float c = a.scale * LOG2E;
+  const float c = a.cexp;
   const long ld_dq = (long)a.H * a.d;
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
@@ -1308,6 +1314,14 @@ int launch_fwd(const AttnArgs& a0, hipStream_t st) {
     if (fold && ones && a.d < DV) {   // the denominator rides in the P.V product: the loop needs no row statistics after its first tile
       const bool big = DH <= 64 && (force == 4 || (force == 0 && a.Nq >= 2048 && (long)aql_cdiv(a.Nq, 256) * a.H * a.B >= 512));
       const dim3 g4(aql_cdiv(a.Nq, 256), a.H, a.B), g2(aql_cdiv(a.Nq, 128), a.H, a.B);
+      // q pre-multiplied by scale log2(e) (aql_sdpa_fwd_qpre): the loop whose shift rides in the S-product, at the default loop's precision
+      if constexpr (DH <= 64 && DV <= 48) {
+        if (a.qpre && a.d < DH) {
+          if (big) hipLaunchKernelGGL((attn_fwd_kernel<DH, DV, 4, true, 2>), g4, dim3(256), 0, st, a);
+          else hipLaunchKernelGGL((attn_fwd_kernel<DH, DV, 2, true, 2>), g2, dim3(256), 0, st, a);
+          return 0;
+        }
+      }
 #ifdef AQL_EXPERIMENTS   // AQL_ATTN_FOLD=2 (the shift inside the S-product: 210 vs 231 us, twice the rounding error; profiles/r04_attention_fold.txt)
       if (fold == 2 && a.d < DH) {
         if constexpr (DH <= 64) {
@@ -1375,9 +1389,9 @@ int launch_bwd(const AttnArgs& a, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int aql_sdpa_fwd(const bf16_t* q, long ldq, const bf16_t* k, long ldk, const bf16_t* v, long ldv, int B,
-                            int H, int Nq, int Nk, int d, float scale, bf16_t* o, long ldo, float* lse,
-                            hipStream_t stream) {
+static int sdpa_fwd_impl(int qpre, const bf16_t* q, long ldq, const bf16_t* k, long ldk, const bf16_t* v, long ldv, int B,
+                         int H, int Nq, int Nk, int d, float scale, bf16_t* o, long ldo, float* lse,
+                         hipStream_t stream) {
   AQL_CHECK_ARG(q && k && v && o && lse, "aql_sdpa_fwd: null operand");
   AQL_CHECK_ARG(d % 8 == 0 && d <= 160 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && Nk > 0,
                 "aql_sdpa_fwd: unsupported head dim %d or strides", d);
@@ -1385,6 +1399,7 @@ extern "C" int aql_sdpa_fwd(const bf16_t* q, long ldq, const bf16_t* k, long ldk
   a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d; a.scale = scale;
+  a.qpre = qpre; a.cexp = qpre ? 1.f : scale * LOG2E; a.cnat = qpre ? 0.6931471805599453f : scale;
   if (d <= 48) launch_fwd<64, 48>(a, stream);
   else if (d <= 64) launch_fwd<64, 64>(a, stream);
   else if (d <= 96) launch_fwd<96, 96>(a, stream);
@@ -1394,7 +1409,21 @@ extern "C" int aql_sdpa_fwd(const bf16_t* q, long ldq, const bf16_t* k, long ldk
   return AQL_OK;
 }
 
-extern "C" int aql_sdpa_bwd(const bf16_t* q, long ldq, const bf16_t* k, long ldk, const bf16_t* v, long ldv,
+extern "C" int aql_sdpa_fwd(const bf16_t* q, long ldq, const bf16_t* k, long ldk, const bf16_t* v, long ldv, int B,
+                            int H, int Nq, int Nk, int d, float scale, bf16_t* o, long ldo, float* lse,
+                            hipStream_t stream) {
+  return sdpa_fwd_impl(0, q, ldq, k, ldk, v, ldv, B, H, Nq, Nk, d, scale, o, ldo, lse, stream);
+}
+
+// q is PRE-MULTIPLIED by scale * log2(e) (rounded to bf16 once, in the epilogue of the launch that produced it: aql_lora_chain_fwd's
+// `oscale`); everything else as aql_sdpa_fwd, and lse is the same natural-log quantity.
+extern "C" int aql_sdpa_fwd_qpre(const bf16_t* q, long ldq, const bf16_t* k, long ldk, const bf16_t* v, long ldv, int B,
+                                 int H, int Nq, int Nk, int d, float scale, bf16_t* o, long ldo, float* lse,
+                                 hipStream_t stream) {
+  return sdpa_fwd_impl(1, q, ldq, k, ldk, v, ldv, B, H, Nq, Nk, d, scale, o, ldo, lse, stream);
+}
+
+static int sdpa_bwd_impl(int qpre, const bf16_t* q, long ldq, const bf16_t* k, long ldk, const bf16_t* v, long ldv,
                             const bf16_t* o, const bf16_t* dout, long ldo, const float* lse, float* delta, int B, int H,
                             int Nq, int Nk, int d, float scale, bf16_t* dq, bf16_t* dk, bf16_t* dv, float* ws,
                             size_t ws_bytes, hipStream_t stream) {
@@ -1406,6 +1435,7 @@ extern "C" int aql_sdpa_bwd(const bf16_t* q, long ldq, const bf16_t* k, long ldk
   a.dq = dq; a.dk = dk; a.dv = dv;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d; a.scale = scale;
+  a.qpre = qpre; a.cexp = qpre ? 1.f : scale * LOG2E; a.cnat = qpre ? 0.6931471805599453f : scale;
   // split the streamed Q range when the key side alone cannot fill the chip (cross-attention: Nk = 77)
   a.qsplit = 1;
   a.part = ws;
@@ -1424,4 +1454,20 @@ extern "C" int aql_sdpa_bwd(const bf16_t* q, long ldq, const bf16_t* k, long ldk
   else launch_bwd<160, 160>(a, stream);
   AQL_CHECK_LAUNCH("aql_sdpa_bwd");
   return AQL_OK;
+}
+
+extern "C" int aql_sdpa_bwd(const bf16_t* q, long ldq, const bf16_t* k, long ldk, const bf16_t* v, long ldv,
+                            const bf16_t* o, const bf16_t* dout, long ldo, const float* lse, float* delta, int B, int H,
+                            int Nq, int Nk, int d, float scale, bf16_t* dq, bf16_t* dk, bf16_t* dv, float* ws,
+                            size_t ws_bytes, hipStream_t stream) {
+  return sdpa_bwd_impl(0, q, ldq, k, ldk, v, ldv, o, dout, ldo, lse, delta, B, H, Nq, Nk, d, scale, dq, dk, dv, ws, ws_bytes, stream);
+}
+
+// Backward of aql_sdpa_fwd_qpre: q is the pre-multiplied tensor the forward saw; dq is the gradient of the UNSCALED q (what the
+// producing linear's backward expects), dk / dv as always.
+extern "C" int aql_sdpa_bwd_qpre(const bf16_t* q, long ldq, const bf16_t* k, long ldk, const bf16_t* v, long ldv,
+                                 const bf16_t* o, const bf16_t* dout, long ldo, const float* lse, float* delta, int B, int H,
+                                 int Nq, int Nk, int d, float scale, bf16_t* dq, bf16_t* dk, bf16_t* dv, float* ws,
+                                 size_t ws_bytes, hipStream_t stream) {
+  return sdpa_bwd_impl(1, q, ldq, k, ldk, v, ldv, o, dout, ldo, lse, delta, B, H, Nq, Nk, d, scale, dq, dk, dv, ws, ws_bytes, stream);
 }

@@ -63,6 +63,7 @@ struct Stage {
   const bf16_t* lnx;                   // LN backward: the LayerNorm's saved input rows [M][ldlx]
   long ldw, ldr, ldo, ldn, ldlx;
   float eps;
+  float oscale;       // DIRECT stages: out = bf16((acc + bias) * oscale) -- 1, or scale log2(e) on attn1.to_q (aql_sdpa_*_qpre reads q pre-multiplied)
   int keep, ln, nout_row0;             // ln: RP_NONE / RP_LN_FWD / RP_LN_BWD
 };
 
@@ -633,6 +634,7 @@ __global__ __launch_bounds__(NTH, 2) void chain_kernel(const Args a) {
     // columns (16 bytes): lane row q4 = 0 / 2 -> block 2jp, columns 0-7 / 8-15; q4 = 1 / 3 -> block 2jp + 1
     {
       const char* sBias = lds + LY::OFF_BIAS + g * CH * 2 + (wn * 160 + q4 * 4) * 2;
+      const float os = keep ? 1.f : s.oscale;                        // (x * 1.0f is exact: every other stage keeps its bits)
       const int c0 = wn * 160 + (q4 & 1) * 16 + (q4 >> 1) * 8;       // + 32 jp
       const __amdgpu_buffer_rsrc_t rsO = make_rsrc(keep ? nullptr : s.out);
       const uint32_t ldo2 = keep ? 0u : (uint32_t)(s.ldo * 2);
@@ -647,8 +649,8 @@ __global__ __launch_bounds__(NTH, 2) void chain_kernel(const Args a) {
           const uint2 bA = *reinterpret_cast<const uint2*>(sBias + jp * 64), bB = *reinterpret_cast<const uint2*>(sBias + jp * 64 + 32);
           const f32x4_t& xa = acc[i][2 * jp];
           const f32x4_t& xb = acc[i][2 * jp + 1];
-          uint32_t x0 = pack_bf16x2(xa[0] + bf16lo(bA.x), xa[1] + bf16hi(bA.x)), x1 = pack_bf16x2(xa[2] + bf16lo(bA.y), xa[3] + bf16hi(bA.y));
-          uint32_t y0 = pack_bf16x2(xb[0] + bf16lo(bB.x), xb[1] + bf16hi(bB.x)), y1 = pack_bf16x2(xb[2] + bf16lo(bB.y), xb[3] + bf16hi(bB.y));
+          uint32_t x0 = pack_bf16x2((xa[0] + bf16lo(bA.x)) * os, (xa[1] + bf16hi(bA.x)) * os), x1 = pack_bf16x2((xa[2] + bf16lo(bA.y)) * os, (xa[3] + bf16hi(bA.y)) * os);
+          uint32_t y0 = pack_bf16x2((xb[0] + bf16lo(bB.x)) * os, (xb[1] + bf16hi(bB.x)) * os), y1 = pack_bf16x2((xb[2] + bf16lo(bB.y)) * os, (xb[3] + bf16hi(bB.y)) * os);
           const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
           const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
           const u32x4_t v = {s0[0], s1[0], s0[1], s1[1]};
@@ -840,15 +842,15 @@ __global__ __launch_bounds__(NTH, 2) void chain_wide_kernel(const Args a) {
     // block, q4 = 1 / 3 -> row fragment 1.  `sink(cc, v)` gets the chunk of columns cc .. cc + 7 of row `row`
     const int row = wm * 32 + (q4 & 1) * 16 + l15;
     const int c0 = wn * 80 + (q4 >> 1) * 8;      // + 16 j
-    auto emit = [&](const char* sBias, auto&& sink) __attribute__((always_inline)) {
+    auto emit = [&](const char* sBias, const float os, auto&& sink) __attribute__((always_inline)) {
   #pragma unroll
       for (int j = 0; j < 5; ++j) {
         uint2 bA = make_uint2(0u, 0u);
         if (sBias != nullptr) bA = *reinterpret_cast<const uint2*>(sBias + j * 32);
         const f32x4_t& xa = acc[0][j];
         const f32x4_t& xb = acc[1][j];
-        uint32_t x0 = pack_bf16x2(xa[0] + bf16lo(bA.x), xa[1] + bf16hi(bA.x)), x1 = pack_bf16x2(xa[2] + bf16lo(bA.y), xa[3] + bf16hi(bA.y));
-        uint32_t y0 = pack_bf16x2(xb[0] + bf16lo(bA.x), xb[1] + bf16hi(bA.x)), y1 = pack_bf16x2(xb[2] + bf16lo(bA.y), xb[3] + bf16hi(bA.y));
+        uint32_t x0 = pack_bf16x2((xa[0] + bf16lo(bA.x)) * os, (xa[1] + bf16hi(bA.x)) * os), x1 = pack_bf16x2((xa[2] + bf16lo(bA.y)) * os, (xa[3] + bf16hi(bA.y)) * os);
+        uint32_t y0 = pack_bf16x2((xb[0] + bf16lo(bA.x)) * os, (xb[1] + bf16hi(bA.x)) * os), y1 = pack_bf16x2((xb[2] + bf16lo(bA.y)) * os, (xb[3] + bf16hi(bA.y)) * os);
         const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
         const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
         sink(c0 + 16 * j, u32x4_t{s0[0], s1[0], s0[1], s1[1]});
@@ -870,7 +872,7 @@ __global__ __launch_bounds__(NTH, 2) void chain_wide_kernel(const Args a) {
         CW_STAMP();   // 1 + 6 g: pass T issued
         const __amdgpu_buffer_rsrc_t rsT = make_rsrc(s.T), rsTs = make_rsrc(s.Ts);
         const uint32_t vt = (uint32_t)(m0 + row) * (uint32_t)(CH * 2);
-        emit(nullptr, [&](int cc, const u32x4_t& tv) __attribute__((always_inline)) {
+        emit(nullptr, 1.f, [&](int cc, const u32x4_t& tv) __attribute__((always_inline)) {
           const uint4 sv = *reinterpret_cast<const uint4*>(lds + LY::OFF_SROW + cc * 2);
           const uint4 ts = epi_mul8(make_uint4(tv.x, tv.y, tv.z, tv.w), sv);
           *reinterpret_cast<uint4*>(lds_chunk(LY::OFF_TSW, cc)) = ts;
@@ -896,7 +898,7 @@ __global__ __launch_bounds__(NTH, 2) void chain_wide_kernel(const Args a) {
       }
       const char* sBias = lds + LY::OFF_BIAS + g * CH * 2 + (wn * 80 + q4 * 4) * 2;
       if (keep) {
-        emit(sBias, [&](int cc, const u32x4_t& v) __attribute__((always_inline)) { *reinterpret_cast<u32x4_t*>(lds_chunk(0, cc)) = v; });
+        emit(sBias, 1.f, [&](int cc, const u32x4_t& v) __attribute__((always_inline)) { *reinterpret_cast<u32x4_t*>(lds_chunk(0, cc)) = v; });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -906,7 +908,7 @@ __global__ __launch_bounds__(NTH, 2) void chain_wide_kernel(const Args a) {
       } else {
         const __amdgpu_buffer_rsrc_t rsO = make_rsrc(s.out);
         const uint32_t vo = (uint32_t)(m0 + row) * (uint32_t)(s.ldo * 2);
-        emit(sBias, [&](int cc, const u32x4_t& v) __attribute__((always_inline)) { __builtin_amdgcn_raw_buffer_store_b128(v, rsO, vo + cc * 2, 0, 0); });
+        emit(sBias, s.oscale, [&](int cc, const u32x4_t& v) __attribute__((always_inline)) { __builtin_amdgcn_raw_buffer_store_b128(v, rsO, vo + cc * 2, 0, 0); });
         pend = 5;
         CW_STAMP();
         CW_STAMP();
@@ -978,7 +980,7 @@ static int chain_fwd_common(bool wide, const bf16_t* X, long ldx, long M, int ro
                             const void* const* Bup, void* const* T, void* const* Ts, const void* const* res, const long* ldr,
                             void* const* out, const long* ldo, const int* keep, const int* ln, const void* const* gamma,
                             const void* const* beta, const float* eps, void* const* stats, void* const* nout, const long* ldn,
-                            const long* nout_row0, hipStream_t stream) {
+                            const long* nout_row0, const float* oscale, hipStream_t stream) {
   AQL_CHECK_ARG(X != nullptr && nstage >= 1 && nstage <= MAXS, "aql_lora_chain_fwd: 1..%d stages", MAXS);
   AQL_CHECK_ARG(M > 0 && M % 64 == 0 && M < (1L << 30), "aql_lora_chain_fwd: M = %ld must be a multiple of 64", M);
   AQL_CHECK_ARG(rows_per_sample > 0 && rows_per_sample % 64 == 0, "aql_lora_chain_fwd: rows_per_sample %% 64 != 0");
@@ -1011,6 +1013,7 @@ static int chain_fwd_common(bool wide, const bf16_t* X, long ldx, long M, int ro
     s.gamma = gamma ? (const bf16_t*)gamma[g] : nullptr;
     s.beta = beta ? (const bf16_t*)beta[g] : nullptr;
     s.eps = eps ? eps[g] : 0.f;
+    s.oscale = oscale ? oscale[g] : 1.f;
     s.stats = stats ? (float*)stats[g] : nullptr;
     s.nout = nout ? (bf16_t*)nout[g] : nullptr;
     s.ldn = ldn ? ldn[g] : 0;
@@ -1024,9 +1027,9 @@ extern "C" int aql_lora_chain_fwd(const bf16_t* X, long ldx, long M, int rows_pe
                                   const void* const* Bup, void* const* T, void* const* Ts, const void* const* res, const long* ldr,
                                   void* const* out, const long* ldo, const int* keep, const int* ln, const void* const* gamma,
                                   const void* const* beta, const float* eps, void* const* stats, void* const* nout, const long* ldn,
-                                  const long* nout_row0, hipStream_t stream) {
+                                  const long* nout_row0, const float* oscale, hipStream_t stream) {
   return chain_fwd_common(false, X, ldx, M, rows_per_sample, lora_row0, S, nstage, W, ldw, bias, Adown, Bup, T, Ts, res, ldr, out, ldo, keep,
-                          ln, gamma, beta, eps, stats, nout, ldn, nout_row0, stream);
+                          ln, gamma, beta, eps, stats, nout, ldn, nout_row0, oscale, stream);
 }
 
 // The rank-320 form (chain_wide_kernel): same arguments; Adown[g] is [320][320] (rank x K), Bup[g] [320][320] (N x rank), T[g] / Ts[g]
@@ -1036,9 +1039,9 @@ extern "C" int aql_lora_chain_fwd_r320(const bf16_t* X, long ldx, long M, int ro
                                        const void* const* Bup, void* const* T, void* const* Ts, const void* const* res, const long* ldr,
                                        void* const* out, const long* ldo, const int* keep, const int* ln, const void* const* gamma,
                                        const void* const* beta, const float* eps, void* const* stats, void* const* nout, const long* ldn,
-                                       const long* nout_row0, hipStream_t stream) {
+                                       const long* nout_row0, const float* oscale, hipStream_t stream) {
   return chain_fwd_common(true, X, ldx, M, rows_per_sample, lora_row0, S, nstage, W, ldw, bias, Adown, Bup, T, Ts, res, ldr, out, ldo, keep,
-                          ln, gamma, beta, eps, stats, nout, ldn, nout_row0, stream);
+                          ln, gamma, beta, eps, stats, nout, ldn, nout_row0, oscale, stream);
 }
 
 extern "C" int aql_lora_chain_bwd(const bf16_t* dY, long lddy, long M, int rows_per_sample, const bf16_t* S, int nstage,
@@ -1083,6 +1086,7 @@ extern "C" int aql_lora_chain_bwd(const bf16_t* dY, long lddy, long M, int rows_
     Stage& s = a.st[g];
     s.W = (const bf16_t*)Wt[g];
     s.ldw = ldw[g];
+    s.oscale = 1.f;
     s.Ad = BupT ? (const bf16_t*)BupT[g] : nullptr;
     s.Bup = AT ? (const bf16_t*)AT[g] : nullptr;
     s.T = dTs ? (bf16_t*)dTs[g] : nullptr;

@@ -623,7 +623,7 @@ def _lora_gemm_fused(x2d, w, a16, S16, rps, b16, bias, residual, T, Ts, y=None, 
 def chain_fwd(x, ldx, M, rps, row0, S16, stages, rank=32):
     """aql_lora_chain_fwd (rank 32; rank 320: aql_lora_chain_fwd_r320): a row-resident chain of 320 -> 320 LoRA linears
     (csrc/aql_chain.hip).  ``stages``: list of dicts with the keys  W ldw bias Ad Bup T Ts res ldr out ldo keep ln gamma beta eps
-    stats nout ldn nout_row0  (tensors or None; missing = None / 0)."""
+    stats nout ldn nout_row0 oscale  (tensors or None; missing = None / 0; oscale: missing = 1)."""
     import ctypes
     n = len(stages)
     vp, lp_, ip, fp = ctypes.c_void_p * n, ctypes.c_long * n, ctypes.c_int * n, ctypes.c_float * n
@@ -638,7 +638,7 @@ def chain_fwd(x, ldx, M, rps, row0, S16, stages, rank=32):
            ptrs("W"), longs("ldw"), ptrs("bias"), ptrs("Ad"), ptrs("Bup"), ptrs("T"), ptrs("Ts"), ptrs("res"), longs("ldr"),
            ptrs("out"), longs("ldo"), ip(*[int(st.get("keep") or 0) for st in stages]), ip(*[int(st.get("ln") or 0) for st in stages]),
            ptrs("gamma"), ptrs("beta"), fp(*[float(st.get("eps") or 0.0) for st in stages]), ptrs("stats"), ptrs("nout"),
-           longs("ldn"), longs("nout_row0"), L.stream_ptr())
+           longs("ldn"), longs("nout_row0"), fp(*[float(st.get("oscale") or 1.0) for st in stages]), L.stream_ptr())
 
 
 def chain_bwd(dy, lddy, M, rps, S16, stages, lns):
@@ -1252,10 +1252,13 @@ class ChainStage:
     """One linear of a chain (static description).  ``keep``: the output tile stays in LDS as the next stage's input, after
     ``+ residual`` (use_res) and LayerNorm (ln = module with weight / bias / eps); emit_out / emit_n: the (pre-LayerNorm) output / the
     normalised rows are results of the chain (tensors autograd sees), not only saved state."""
-    __slots__ = ("packed", "site", "keep", "use_res", "ln", "emit_out", "emit_n")
+    __slots__ = ("packed", "site", "keep", "use_res", "ln", "emit_out", "emit_n", "oscale")
 
-    def __init__(self, packed, site, keep, use_res=False, ln=None, emit_out=True, emit_n=False):
+    def __init__(self, packed, site, keep, use_res=False, ln=None, emit_out=True, emit_n=False, oscale=1.0):
         self.packed, self.site, self.keep, self.use_res, self.ln, self.emit_out, self.emit_n = packed, site, keep, use_res, ln, emit_out, emit_n
+        # a DIRECT (keep = False) stage writes  out = bf16((x.W^T + LoRA + bias) * oscale):  attn1.to_q hands the attention kernels
+        # q * (d^-1/2 log2 e) (attention(..., q_prescaled=True)); its backward still receives the gradient of the UNSCALED q
+        self.oscale = float(oscale)
 
 
 def chain_ok(x2d, stages, S16, rps):
@@ -1307,7 +1310,7 @@ class ChainFn(torch.autograd.Function):
         kst, outs, saved = [], [], [x2d, S16]
         meta = []
         for st in stages:
-            d = dict(W=st.packed.w, ldw=st.packed.w.stride(0), bias=st.packed.bias, keep=int(st.keep))
+            d = dict(W=st.packed.w, ldw=st.packed.w.stride(0), bias=st.packed.bias, keep=int(st.keep), oscale=st.oscale)
             T = Ts = None
             if lora:
                 Tk, T = _alloc((M, rank), torch.bfloat16, dev, twin)
@@ -1716,7 +1719,7 @@ class AttentionFn(torch.autograd.Function):
     """softmax(Q K^T / sqrt(d)) V over heads packed along the channel axis: q [B,Nq,H*d], k/v [B,Nk,H*d]."""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads):
+    def forward(ctx, q, k, v, heads, q_prescaled=False):
         _req(q, "attention")
         B, Nq, C = q.shape
         Nk = k.shape[1]
@@ -1729,10 +1732,11 @@ class AttentionFn(torch.autograd.Function):
             qk, kk, vk = q, k, v
         ok, o = _alloc((B, Nq, C), q.dtype, q.device, twin)   # q may be a strided view of a packed q|k|v GEMM output
         lsek, lse = _alloc((B, heads, Nq), torch.float32, q.device, twin)
-        L.call("aql_sdpa_fwd", L.ptr(qk), qk.stride(1), L.ptr(kk), kk.stride(1), L.ptr(vk), vk.stride(1), qk.shape[0], heads, Nq,
-               Nk, d, float(d ** -0.5), L.ptr(ok), ok.stride(1), L.ptr(lsek), L.stream_ptr())
+        # q_prescaled: q was multiplied by d^-1/2 log2(e) by its producer (ChainStage.oscale) -- aql_sdpa_*_qpre
+        L.call("aql_sdpa_fwd_qpre" if q_prescaled else "aql_sdpa_fwd", L.ptr(qk), qk.stride(1), L.ptr(kk), kk.stride(1), L.ptr(vk), vk.stride(1),
+               qk.shape[0], heads, Nq, Nk, d, float(d ** -0.5), L.ptr(ok), ok.stride(1), L.ptr(lsek), L.stream_ptr())
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.heads = heads
+        ctx.heads, ctx.qpre = heads, bool(q_prescaled)
         return o
 
     @staticmethod
@@ -1748,14 +1752,17 @@ class AttentionFn(torch.autograd.Function):
         delta = torch.empty(B, heads, Nq, dtype=torch.float32, device=q.device)
         ws = workspace(q.device)
         ws = workspace(q.device)   # split-Q partials of dK/dV when Nk is short (cross-attention)
-        L.call("aql_sdpa_bwd", L.ptr(q), q.stride(1), L.ptr(k), k.stride(1), L.ptr(v), v.stride(1), L.ptr(o),
+        L.call("aql_sdpa_bwd_qpre" if ctx.qpre else "aql_sdpa_bwd", L.ptr(q), q.stride(1), L.ptr(k), k.stride(1), L.ptr(v), v.stride(1), L.ptr(o),
                L.ptr(do), o.stride(1), L.ptr(lse), L.ptr(delta), B, heads, Nq, Nk, d, float(d ** -0.5),
                L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(ws), ws.numel() * 4, L.stream_ptr())
-        return dq, dk, dv, None
+        return dq, dk, dv, None, None
 
 
-def attention(q, k, v, heads):
-    return AttentionFn.apply(q, k, v, heads)
+QPRE = os.environ.get("AQL_QPRE", "1") != "0"   # A/B hook: 0 = attn1.to_q of the chains unscaled, attention on aql_sdpa_fwd / _bwd
+
+
+def attention(q, k, v, heads, q_prescaled=False):
+    return AttentionFn.apply(q, k, v, heads, q_prescaled)
 
 
 # ------------------------------------------------------------------------------------------- loss

@@ -364,12 +364,17 @@ class Transformer2DModel(nn.Module):
                 S16 = S.detach().to(torch.bfloat16).contiguous()
                 S._aql_s16 = S16
         CS = ops.ChainStage
-        d_stages = [CS(pk[self.proj_in], st[self.proj_in], True, ln=blk.norm1)] + \
-                   [CS(pk[m], st[m], False) for m in (a1.to_q, a1.to_k, a1.to_v)]
+        # attn1.to_q leaves the chain multiplied by d^-1/2 log2(e) (one bf16 rounding, as the unscaled q has): the self-attention forward
+        # then carries its softmax shift inside the S-product (aql_sdpa_fwd_qpre).  Head sizes with a spare column only (d = 40 here).
+        d_head = C // a1.heads
+        qpre = ops.QPRE and d_head < 64 and d_head % 8 == 0
+        qs = (d_head ** -0.5) * 1.4426950408889634 if qpre else 1.0
+        d_stages = [CS(pk[self.proj_in], st[self.proj_in], True, ln=blk.norm1), CS(pk[a1.to_q], st[a1.to_q], False, oscale=qs)] + \
+                   [CS(pk[m], st[m], False) for m in (a1.to_k, a1.to_v)]
         if not ops.chain_ok(x2d, d_stages, S16, N):
             return None
         h0, q, k, v = ops.lora_chain(x2d, None, S, S16, N, d_stages)
-        o1 = ops.attention(q.view(B, N, C), k.view(B, N, C), v.view(B, N, C), a1.heads).reshape(B * N, C)
+        o1 = ops.attention(q.view(B, N, C), k.view(B, N, C), v.view(B, N, C), a1.heads, q_prescaled=qpre).reshape(B * N, C)
         h1, q2 = ops.lora_chain(o1, h0, S, S16, N, [CS(pk[a1.to_out[0]], st[a1.to_out[0]], True, use_res=True, ln=blk.norm2),
                                                     CS(pk[a2.to_q], st[a2.to_q], False)])
         if kv is not None:

@@ -2,5 +2,5 @@
  * aql_abi_version().  Bump when an EXISTING entry point changes its signature; new entry points do not need a bump. */
 #ifndef AQUALORA_ABI_H
 #define AQUALORA_ABI_H
-#define AQL_ABI_VERSION 3
+#define AQL_ABI_VERSION 4
 #endif

@@ -192,7 +192,8 @@ int aql_layernorm_bwd(const bf16_t* x, const bf16_t* dy, long M, int C, const bf
  *   stage g:  Y = X.W_g^T + ((X.Adown_g^T) * S[m / rps]).Bup_g^T + bias_g          X = the tile in LDS ([M, 320] input for g = 0)
  *     keep_g = 1:  X <- bf16(Y) + res_g (bf16 add);  out_g <- X (if given);  ln_g = 1:  X <- LayerNorm(X; gamma_g, beta_g, eps_g),
  *                  stats_g[m] = (mean, rstd),  nout_g <- X for rows >= nout_row0_g
- *     keep_g = 0:  out_g <- bf16(Y)                                              (X unchanged: q | k | v read the same tile)
+ *     keep_g = 0:  out_g <- bf16(Y * oscale_g)                                   (X unchanged: q | k | v read the same tile;
+ *                  oscale (host array or null = all 1): scale log2(e) on attn1.to_q, whose consumer is then aql_sdpa_fwd_qpre)
  * Every per-stage argument is a HOST array of nstage entries (null entries where a stage has no such operand; Adown_g = null:
  * no LoRA on that linear).  M % 128 == 0, rows_per_sample % 128 == 0, lora_row0 % 128 == 0 (rows below lora_row0 -- the clean half
  * of a twin batch, ppft_train.py:1026-1029 -- carry no LoRA term and write no T / Ts); at most one LayerNorm per chain.        */
@@ -201,7 +202,7 @@ int aql_lora_chain_fwd(const bf16_t* X, long ldx, long M, int rows_per_sample, l
                        const void* const* Bup, void* const* T, void* const* Ts, const void* const* res, const long* ldr,
                        void* const* out, const long* ldo, const int* keep, const int* ln, const void* const* gamma,
                        const void* const* beta, const float* eps, void* const* stats, void* const* nout, const long* ldn,
-                       const long* nout_row0, aql_stream_t stream);
+                       const long* nout_row0, const float* oscale, aql_stream_t stream);
 /* The same chain at LoRA rank 320 (BASELINE config 3, train/README.md:34-48): Adown_g [320][320] (rank x K), Bup_g [320][320]
  * (N x rank), T_g / Ts_g [M][320], S [M / rps][320].  One workgroup owns 64 token rows; per LoRA linear the down product
  * T = X.Adown^T runs as a pass of its own, (T, Ts = T * S) go to HBM for backward and Ts stays in LDS as the second A panel of the
@@ -211,7 +212,7 @@ int aql_lora_chain_fwd_r320(const bf16_t* X, long ldx, long M, int rows_per_samp
                             const void* const* Bup, void* const* T, void* const* Ts, const void* const* res, const long* ldr,
                             void* const* out, const long* ldo, const int* keep, const int* ln, const void* const* gamma,
                             const void* const* beta, const float* eps, void* const* stats, void* const* nout, const long* ldn,
-                            const long* nout_row0, aql_stream_t stream);
+                            const long* nout_row0, const float* oscale, aql_stream_t stream);
 /* The mirrored BACKWARD chains (round 5): the backward-data passes of up to 4 of those linears with the LayerNorm backward between
  * them, one launch, 64-row tiles (the backward pass runs on the watermarked half of the batch only).  Per linear the operands of
  * aql_lora_gemm_fused's backward-data form: Wt = W^T [320][ldw], BupT = Bup^T [32][320], AT = A^T [320][32]; dTs, dT [M][32] out.
@@ -238,6 +239,16 @@ int aql_sdpa_fwd(const bf16_t* q, long ldq, const bf16_t* k, long ldk, const bf1
 int aql_sdpa_bwd(const bf16_t* q, long ldq, const bf16_t* k, long ldk, const bf16_t* v, long ldv, const bf16_t* o,
                  const bf16_t* dout, long ldo, const float* lse, float* delta, int B, int H, int Nq, int Nk, int d,
                  float scale, bf16_t* dq, bf16_t* dk, bf16_t* dv, float* ws, size_t ws_bytes, aql_stream_t stream);
+/* The same attention with q PRE-MULTIPLIED by scale * log2(e) in the epilogue of the launch that produced it (one bf16 rounding of
+ * q c instead of q: aql_lora_chain_fwd's `oscale` on attn1.to_q, scripts/lib/original_unet.py:688-704): the forward loop then carries
+ * its softmax shift inside the S-product (no multiply-add per score) at the precision of aql_sdpa_fwd.  `scale` is still passed
+ * (dQ is the gradient of the UNSCALED q: what the producing linear's backward expects); lse is the same natural-log quantity.     */
+int aql_sdpa_fwd_qpre(const bf16_t* q, long ldq, const bf16_t* k, long ldk, const bf16_t* v, long ldv, int B, int H, int Nq,
+                      int Nk, int d, float scale, bf16_t* o, long ldo, float* lse, aql_stream_t stream);
+int aql_sdpa_bwd_qpre(const bf16_t* q, long ldq, const bf16_t* k, long ldk, const bf16_t* v, long ldv, const bf16_t* o,
+                      const bf16_t* dout, long ldo, const float* lse, float* delta, int B, int H, int Nq, int Nk, int d,
+                      float scale, bf16_t* dq, bf16_t* dk, bf16_t* dv, float* ws, size_t ws_bytes, aql_stream_t stream);
+
 /* ws (optional, caller-owned, per stream): fp32 scratch for split-Q partials of dK/dV when Nk is too short to fill the
  * chip (cross-attention, Nk = 77); 2*splits*B*H*Nk*d floats are used, NULL disables the split.                    */
 

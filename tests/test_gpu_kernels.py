@@ -279,8 +279,8 @@ def test_transformer_block_through_chains_equals_the_per_launch_block(rank):
     S0 = torch.cat([torch.zeros(B, rank, device=dev), synth.normal("S", (B, rank), 1.0, 7, dev)])
     dy = synth.normal("dy", (B, C, H, H), 1.0, 7, dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
 
-    def run(chain):
-        ops.CHAIN = chain
+    def run(chain, qpre=False):
+        ops.CHAIN, ops.QPRE = chain, qpre
         for p_ in lparams:
             p_.grad = None
         ops.dual_begin()
@@ -303,7 +303,7 @@ def test_transformer_block_through_chains_equals_the_per_launch_block(rank):
             return yk, x.grad.detach().clone(), torch.cat([p_.grad.reshape(-1).float() for p_ in lparams]), S.grad.detach().clone()
         finally:
             ops.dual_end()
-            ops.CHAIN = True
+            ops.CHAIN, ops.QPRE = True, True
 
     y_a, dx_a, g_a, ds_a = run(False)
     y_b, dx_b, g_b, ds_b = run(False)
@@ -320,6 +320,14 @@ def test_transformer_block_through_chains_equals_the_per_launch_block(rank):
     # upstream of the q | k | v sum the gradients inherit its bf16-level difference (proj_in, norm1); everything else sees equal inputs
     assert g_a.abs().max() > 0 and diff < 5e-3, (spread, diff)
     assert ((ds_a - ds_c).abs().max() / ds_a.abs().max()).item() < 5e-3
+    # the default form of the chains: attn1.to_q leaves the chain multiplied by d^-1/2 log2(e) and the self-attention runs on
+    # aql_sdpa_fwd_qpre / _bwd_qpre (the softmax shift inside the S-product) -- q is ROUNDED at another point, so not the same bits
+    y_d, dx_d, g_d, ds_d = run(True, qpre=True)
+    e_y = ((y_a.float() - y_d.float()).norm() / y_a.float().norm()).item()
+    e_dx = ((dx_a.float() - dx_d.float()).norm() / dx_a.float().norm()).item()
+    diff = ((g_a - g_d).abs().max() / g_a.abs().max()).item()
+    print(f"pre-scaled q: y l2rel {e_y:.2e}, dx l2rel {e_dx:.2e}, weight gradients max-rel {diff:.2e}")
+    assert e_y < 8e-3 and e_dx < 1e-2 and diff < 1.5e-2 and ((ds_a - ds_d).abs().max() / ds_a.abs().max()).item() < 1e-2
 
 
 @pytest.mark.parametrize("B,N", [(4, 4096), (1, 2048)])   # 256-row (NOF = 4) and 128-row (NOF = 2) workgroups of attn_fwd_kernel
