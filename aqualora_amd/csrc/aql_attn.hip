@@ -698,7 +698,11 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_fwd_kernel(const
 // so -delta rides as a (hi, lo) bf16 pair in the first two padding columns of the row's dO fragment against two columns of 1.0 in the
 // streamed V tile: the fp32 accumulation adds it exactly, delta is represented to 2^-17, and one of the five VALU operations per
 // element leaves the loop.
-template <int DH, int DV, bool DFOLD = false>
+// LFOLD (round 5; q pre-multiplied by scale log2(e), aql_sdpa_bwd_qpre; same two spare columns, of Q and K this time): the row's
+// -lse log2(e) rides as a (hi, lo) bf16 pair in the padding columns of its q fragment against two columns of 1.0 in the streamed K tile, so
+// the S-product already is the exponent: p = exp2(s), the multiply-add per score leaves the loop (bound measured beforehand: -6.5 % of
+// the two backward kernels at d = 40, profiles/r05_attention_shift_fma_bound.txt).  lse is represented to 2^-17.
+template <int DH, int DV, bool DFOLD = false, bool LFOLD = false>
 __global__ __launch_bounds__(256, (DH <= AQL_ATTN_DQ_OCC2_UPTO ? 2 : 1)) void attn_dq_kernel(const AttnArgs a) {
   constexpr bool DMA = DH > AQL_ATTN_DMA_ABOVE;   // see attn_fwd_kernel / DmaTile
   constexpr int IMG = TILE * RowPitch<DH>::value;
@@ -738,8 +742,23 @@ __global__ __launch_bounds__(256, (DH <= AQL_ATTN_DQ_OCC2_UPTO ? 2 : 1)) void at
   for (int of = 0; of < 2; ++of) {
     const int row = q0 + of * 16 + (lane & 15);
     const bool ok = row < a.Nq;
-    lse2[of] = ok ? a.lse[((long)b * a.H + h) * a.Nq + row] * LOG2E : INFINITY;
+    lse2[of] = ok ? a.lse[((long)b * a.H + h) * a.Nq + row] * LOG2E : (LFOLD ? 1e30f : INFINITY);   // (rows past the end: p = 0)
     if (ok && (lane >> 4) == 0) a.delta[((long)b * a.H + h) * a.Nq + row] = dl[of];
+  }
+  if constexpr (LFOLD) {   // columns d, d + 1 of the row's q fragment: (-lse2_hi, -lse2_lo)
+#pragma unroll
+    for (int of = 0; of < 2; ++of) {
+      const uint32_t hi = pack_bf16x2(lse2[of], 0.f) & 0xffffu;
+      const uint32_t lo = pack_bf16x2(lse2[of] - bf16lo(hi), 0.f) & 0xffffu;
+      const uint32_t word = (hi ^ 0x8000u) | ((lo ^ 0x8000u) << 16);
+#pragma unroll
+      for (int ks = 0; ks < DH / 32; ++ks)
+        if (ks == (a.d >> 5) && (lane >> 4) == ((a.d & 31) >> 3)) {
+          uint4 v = *reinterpret_cast<uint4*>(&qf[of][ks]);
+          v.x = word;
+          qf[of][ks] = *reinterpret_cast<bf16x8_t*>(&v);
+        }
+    }
   }
   if constexpr (DFOLD) {   // columns d, d + 1 of the row's dO fragment: (-delta_hi, -delta_lo); d % 8 == 0: word 0 of chunk d / 8
 #pragma unroll
@@ -766,11 +785,17 @@ __global__ __launch_bounds__(256, (DH <= AQL_ATTN_DQ_OCC2_UPTO ? 2 : 1)) void at
     dmV.init(vp, a.ldv, a.Nk, a.d, wave, lane);
     DmaTile<DH>::pad(sK, 2, a.d, tid);
     DmaTile<DH>::pad(sV, 2, a.d, tid);
-    if constexpr (DFOLD) {
+    if constexpr (DFOLD || LFOLD) {
       __syncthreads();   // the padding chunks were zeroed by other threads
       if (tid < TILE) {
-        *reinterpret_cast<uint32_t*>(sV + tile_off<DH>(tid, a.d >> 3)) = 0x3F803F80u;         // 1.0 | 1.0
-        *reinterpret_cast<uint32_t*>(sV + IMG + tile_off<DH>(tid, a.d >> 3)) = 0x3F803F80u;
+        if constexpr (DFOLD) {
+          *reinterpret_cast<uint32_t*>(sV + tile_off<DH>(tid, a.d >> 3)) = 0x3F803F80u;         // 1.0 | 1.0
+          *reinterpret_cast<uint32_t*>(sV + IMG + tile_off<DH>(tid, a.d >> 3)) = 0x3F803F80u;
+        }
+        if constexpr (LFOLD) {
+          *reinterpret_cast<uint32_t*>(sK + tile_off<DH>(tid, a.d >> 3)) = 0x3F803F80u;
+          *reinterpret_cast<uint32_t*>(sK + IMG + tile_off<DH>(tid, a.d >> 3)) = 0x3F803F80u;
+        }
       }
     }
     dmK.issue(sK, 0);
@@ -780,9 +805,12 @@ __global__ __launch_bounds__(256, (DH <= AQL_ATTN_DQ_OCC2_UPTO ? 2 : 1)) void at
   } else {
     stK.init(sK, kp, a.ldk, 0, a.Nk, a.d, tid);
     stV.init(sV, vp, a.ldv, 0, a.Nk, a.d, tid);
-    if constexpr (DFOLD) {
+    if constexpr (DFOLD || LFOLD) {
       __syncthreads();   // the padding chunks were zeroed by other threads; they are never overwritten afterwards
-      if (tid < TILE) *reinterpret_cast<uint32_t*>(sV + tile_off<DH>(tid, a.d >> 3)) = 0x3F803F80u;
+      if (tid < TILE) {
+        if constexpr (DFOLD) *reinterpret_cast<uint32_t*>(sV + tile_off<DH>(tid, a.d >> 3)) = 0x3F803F80u;
+        if constexpr (LFOLD) *reinterpret_cast<uint32_t*>(sK + tile_off<DH>(tid, a.d >> 3)) = 0x3F803F80u;
+      }
     }
     stK.fetch();
     stV.fetch();
@@ -823,7 +851,7 @@ __global__ __launch_bounds__(256, (DH <= AQL_ATTN_DQ_OCC2_UPTO ? 2 : 1)) void at
       for (int of = 0; of < 2; ++of)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sf][of][e], c, -lse2[of]));
+          const float p = LFOLD ? __builtin_amdgcn_exp2f(s[sf][of][e]) : __builtin_amdgcn_exp2f(__builtin_fmaf(s[sf][of][e], c, -lse2[of]));
           s[sf][of][e] = DFOLD ? p * dp[sf][of][e] : p * (dp[sf][of][e] - dl[of]);
         }
     if (kt + TILE > a.Nk) {  // last, partial tile: its padding rows repeat the last key row -> drop them
@@ -850,7 +878,8 @@ __global__ __launch_bounds__(256, (DH <= AQL_ATTN_DQ_OCC2_UPTO ? 2 : 1)) void at
 // ------------------------------------------------------------------------------------------------ dK, dV
 // DFOLD: as in attn_dq_kernel, mirrored -- here the dO rows are the streamed side: (-delta_hi, -delta_lo) of a row go into the two
 // padding columns of its row in the dO tile (written with the tile's row statistics), the owner V fragments carry 1.0 there.
-template <int DH, int DV, bool DFOLD = false>
+// LFOLD: mirrored as well -- (-lse2_hi, -lse2_lo) of a row go into the padding columns of its row in the Q tile, the owner K fragments carry 1.0.
+template <int DH, int DV, bool DFOLD = false, bool LFOLD = false>
 __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dkv_kernel(const AttnArgs a) {
   constexpr bool DMA = DH > AQL_ATTN_DMA_ABOVE;   // see attn_fwd_kernel / DmaTile
   constexpr int IMG = TILE * RowPitch<DH>::value, NIMG = DMA ? 2 : 1;
@@ -886,6 +915,17 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dkv_kernel(const
           vf[of][ks] = *reinterpret_cast<bf16x8_t*>(&v);
         }
   }
+  if constexpr (LFOLD) {
+#pragma unroll
+    for (int of = 0; of < 2; ++of)
+#pragma unroll
+      for (int ks = 0; ks < DH / 32; ++ks)
+        if (ks == (a.d >> 5) && (lane >> 4) == ((a.d & 31) >> 3)) {
+          uint4 v = *reinterpret_cast<uint4*>(&kf[of][ks]);
+          v.x = 0x3F803F80u;
+          kf[of][ks] = *reinterpret_cast<bf16x8_t*>(&v);
+        }
+  }
   f32x4_t dk[DV / 16][2], dv[DV / 16][2];
   zero_acc(dk);
   zero_acc(dv);
@@ -906,6 +946,12 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dkv_kernel(const
     if (tid < TILE) {
       const bool ok = (qt + tid) < a.Nq;   // rows past the end: p = exp2(s - inf) = 0
       sLse[img * TILE + tid] = ok ? lse_r * LOG2E : INFINITY;
+      if constexpr (LFOLD) {
+        const float l2 = ok ? lse_r * LOG2E : 1e30f;
+        const uint32_t hi = pack_bf16x2(l2, 0.f) & 0xffffu;
+        const uint32_t lo = pack_bf16x2(l2 - bf16lo(hi), 0.f) & 0xffffu;
+        *reinterpret_cast<uint32_t*>(sQ + img * IMG + tile_off<DH>(tid, a.d >> 3)) = (hi ^ 0x8000u) | ((lo ^ 0x8000u) << 16);
+      }
       if constexpr (DFOLD) {
         const uint32_t hi = pack_bf16x2(delta_r, 0.f) & 0xffffu;
         const uint32_t lo = pack_bf16x2(delta_r - bf16lo(hi), 0.f) & 0xffffu;
@@ -920,7 +966,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dkv_kernel(const
     dmO.init(dop, a.ldo, a.Nq, a.d, wave, lane);
     DmaTile<DH>::pad(sQ, 2, a.d, tid);
     DmaTile<DH>::pad(sdO, 2, a.d, tid);
-    if constexpr (DFOLD) __syncthreads();   // put_stats writes into padding chunks that other threads have just zeroed
+    if constexpr (DFOLD || LFOLD) __syncthreads();   // put_stats writes into padding chunks that other threads have just zeroed
     if (qt_lo < qt_hi) {
       dmQ.issue(sQ, qt_lo);
       dmO.issue(sdO, qt_lo);
@@ -980,7 +1026,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dkv_kernel(const
       for (int of = 0; of < 2; ++of)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sf][of][e], c, -lsv[e]));
+          const float p = LFOLD ? __builtin_amdgcn_exp2f(s[sf][of][e]) : __builtin_amdgcn_exp2f(__builtin_fmaf(s[sf][of][e], c, -lsv[e]));
           s[sf][of][e] = p;
           ds[sf][of][e] = DFOLD ? p * dp[sf][of][e] : p * (dp[sf][of][e] - dev[e]);
         }
@@ -1366,17 +1412,29 @@ template <int DH, int DV>
 int launch_bwd(const AttnArgs& a, hipStream_t st) {
   static const int dfold_on = getenv("AQL_ATTN_DFOLD") ? atoi(getenv("AQL_ATTN_DFOLD")) : 1;   // A/B hook: 0 = subtract delta per element
   const bool dfold = DH <= 96 && dfold_on && a.d < DH;   // two spare head columns (d % 8 == 0)
+  static const int lfold_on = getenv("AQL_ATTN_LFOLD") ? atoi(getenv("AQL_ATTN_LFOLD")) : 1;   // A/B hook: 0 = exp2(fma(s, 1, -lse)) on a pre-scaled q
+  const bool lfold = dfold && lfold_on && a.qpre && DH <= 64 && DV <= 48 && !ctx_on(a);
   if (ctx_on(a)) {
     AttnArgs c = a;
     c.qsplit = ctx_blocks(a, CtxNB<DH>::bwd);
     hipLaunchKernelGGL((attn_ctx_dq_kernel<DH, DV>), dim3(aql_cdiv(a.Nq, 4 * OWN * c.qsplit), a.H, a.B), dim3(256), 0, st, c);
   } else if (dfold) {
-    if constexpr (DH <= 96) hipLaunchKernelGGL((attn_dq_kernel<DH, DV, true>), dim3(aql_cdiv(a.Nq, 4 * OWN), a.H, a.B), dim3(256), 0, st, a);
+    if constexpr (DH <= 64 && DV <= 48) {
+      if (lfold) hipLaunchKernelGGL((attn_dq_kernel<DH, DV, true, true>), dim3(aql_cdiv(a.Nq, 4 * OWN), a.H, a.B), dim3(256), 0, st, a);
+    }
+    if constexpr (DH <= 96) {
+      if (!lfold) hipLaunchKernelGGL((attn_dq_kernel<DH, DV, true>), dim3(aql_cdiv(a.Nq, 4 * OWN), a.H, a.B), dim3(256), 0, st, a);
+    }
   } else {
     hipLaunchKernelGGL((attn_dq_kernel<DH, DV>), dim3(aql_cdiv(a.Nq, 4 * OWN), a.H, a.B), dim3(256), 0, st, a);
   }
   if (dfold) {
-    if constexpr (DH <= 96) hipLaunchKernelGGL((attn_dkv_kernel<DH, DV, true>), dim3(aql_cdiv(a.Nk, 4 * OWN), a.H, a.B * a.qsplit), dim3(256), 0, st, a);
+    if constexpr (DH <= 64 && DV <= 48) {
+      if (lfold) hipLaunchKernelGGL((attn_dkv_kernel<DH, DV, true, true>), dim3(aql_cdiv(a.Nk, 4 * OWN), a.H, a.B * a.qsplit), dim3(256), 0, st, a);
+    }
+    if constexpr (DH <= 96) {
+      if (!lfold) hipLaunchKernelGGL((attn_dkv_kernel<DH, DV, true>), dim3(aql_cdiv(a.Nk, 4 * OWN), a.H, a.B * a.qsplit), dim3(256), 0, st, a);
+    }
   } else {
     hipLaunchKernelGGL((attn_dkv_kernel<DH, DV>), dim3(aql_cdiv(a.Nk, 4 * OWN), a.H, a.B * a.qsplit), dim3(256), 0, st, a);
   }

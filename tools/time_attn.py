@@ -1,4 +1,5 @@
-"""HIP-graph timing of the self-attention kernels alone (forward; with BWD=1 also dQ and dK/dV) on the U-Net's two large
+"""(QPRE=1: the entries that take a q pre-multiplied by d^-1/2 log2(e), aql_sdpa_fwd_qpre / _bwd_qpre.)
+HIP-graph timing of the self-attention kernels alone (forward; with BWD=1 also dQ and dK/dV) on the U-Net's two large
 shapes, twin (8 samples) and batch-4.  AQL_LIB selects an ablation build, AQL_ATTN32=0 the 16x16x32 kernels."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -35,8 +36,9 @@ for B, H, N, d in SHAPES:
     o = torch.empty_like(q); lse = torch.empty(B, H, N, device="cuda"); delta = torch.empty_like(lse)
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     ws = torch.empty(16 << 20, device="cuda"); sc = float(d ** -0.5); st = L.stream_ptr
-    fwd = lambda: L.call("aql_sdpa_fwd", L.ptr(q), C, L.ptr(k), C, L.ptr(v), C, B, H, N, NK or N, d, sc, L.ptr(o), C, L.ptr(lse), st())
-    bwd = lambda: L.call("aql_sdpa_bwd", L.ptr(q), C, L.ptr(k), C, L.ptr(v), C, L.ptr(o), L.ptr(do), C, L.ptr(lse), L.ptr(delta), B, H, N, NK or N,
+    SFX = "_qpre" if os.environ.get("QPRE") == "1" else ""
+    fwd = lambda: L.call("aql_sdpa_fwd" + SFX, L.ptr(q), C, L.ptr(k), C, L.ptr(v), C, B, H, N, NK or N, d, sc, L.ptr(o), C, L.ptr(lse), st())
+    bwd = lambda: L.call("aql_sdpa_bwd" + SFX, L.ptr(q), C, L.ptr(k), C, L.ptr(v), C, L.ptr(o), L.ptr(do), C, L.ptr(lse), L.ptr(delta), B, H, N, NK or N,
                          d, sc, L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(ws), ws.numel() * 4, st())
     tf = graph_time(fwd)
     fl = 4.0 * B * H * N * (NK or N) * d
