@@ -82,6 +82,15 @@ def test_ops_parity_on_the_other_attention_loops(env):
     assert text.count("PASS") >= 93
 
 
+def test_self_attention_on_a_prescaled_q_vs_fp32():
+    """aql_sdpa_fwd_qpre / aql_sdpa_bwd_qpre (q multiplied by d^-1/2 log2(e) by its producer; the softmax shift inside the S-product in
+    all three passes) against an fp32 softmax attention on the operands the kernels see: 256- and 128-row workgroups, a late key 3x and
+    20x above the first tile's scores (fast path / overflow fallback), ragged N -- o, dq (gradient of the UNSCALED q), dk, dv
+    (tools/probe_attn_qpre.py); the LFOLD-off backward (AQL_ATTN_LFOLD=0) through the same sweep."""
+    assert _run("probe_attn_qpre.py").count("PASS attention qpre") == 6
+    assert _run("probe_attn_qpre.py", {"AQL_ATTN_LFOLD": "0"}).count("PASS attention qpre") == 6
+
+
 def test_transpose_read_weight_gradient_gemm():
     """aql_gemm_tn_tr_f32 (wide 128x128 and rank <= 32 128x32 tiles, swapped / transposed output, ragged M, P, Q, strided
     operands) against fp32 torch."""
