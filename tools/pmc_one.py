@@ -1,5 +1,5 @@
 """One GEMM / conv shape, a handful of launches: the workload for rocprofv3 --pmc passes (tools/pmc_run.sh).
-usage: pmc_one.py gemm M N K | conv B H Cin Cout | lora M N K | geglu M F K | attn B S heads | tntr M P Q | chain M"""
+usage: pmc_one.py gemm M N K | conv B H Cin Cout | lora M N K | geglu M F K | attn B S heads | attnq B S heads | tntr M P Q | chain M"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -32,14 +32,14 @@ elif kind == "geglu":   # ff.net.0.proj + rank-32 LoRA + GEGLU on a twin batch: 
         T = torch.empty(M, 32, dtype=torch.bfloat16, device=dev); Ts = torch.empty_like(T)
         return lambda: L.call("aql_lora_gemm_fused_geglu", L.ptr(X), K, L.ptr(W), K, M, F, K, L.ptr(A), L.ptr(S), M // 8, L.ptr(Bup),
                               L.ptr(bias), L.ptr(H), 2 * F, L.ptr(G), F, L.ptr(T), L.ptr(Ts), M // 2, L.stream_ptr())
-elif kind == "attn":   # self-attention forward + backward, head dim 40
+elif kind in ("attn", "attnq"):   # self-attention forward + backward, head dim 40 (attnq: q pre-multiplied by d^-1/2 log2 e, the step's form)
     from aqualora_amd import ops
     Bn, S, heads = a
     def mk():
         q, k, v = (rnd(Bn, S, heads * 40).requires_grad_(True) for _ in range(3))
         do = rnd(Bn, S, heads * 40)
         def f():
-            o = ops.attention(q, k, v, heads)
+            o = ops.attention(q, k, v, heads, q_prescaled=(kind == "attnq"))
             o.backward(do)
         return f
 elif kind == "chain":   # the row-resident chain  attn.to_out + residual -> LayerNorm -> to_q  on a twin batch (csrc/aql_chain.hip)

@@ -48,14 +48,24 @@ def put(prefix, vals):
     K[key]["mfma_util"] = [v[1] for v in vals]
 
 
-for kern, prefix in (("attn_fwd_kernel<64, 48, 4, true, 1>", "attn_fwd_kernel"), ("attn_dq_kernel<64, 48, true>", "attn_dq_kernel"),
-                     ("attn_dkv_kernel<64, 48, true>", "attn_dkv_kernel")):
-    put(prefix, [rows["attn 4 4096 8"][kern], rows["attn 8 4096 8"][kern]])
+def one(section, start):   # the kernel of a section whose name starts with `start` (template argument lists grow over the rounds)
+    return next(v for k, v in rows[section].items() if k.startswith(start))
+
+
+for prefix in ("attn_fwd_kernel", "attn_dq_kernel", "attn_dkv_kernel"):
+    put(prefix, [one("attn 4 4096 8", prefix + "<64, 48"), one("attn 8 4096 8", prefix + "<64, 48")])
 put("conv_row_kernel", [rows["conv 8 64 320 320"]["aqlconvrow::conv_row_kernel<64, 4, false, false, 160, 64>"]])
 put("lora_geglu256_kernel", [rows["geglu 32768 1280 320"]["aqlt256::lora_geglu256_kernel<false>"]])
 put("lora_gemm_kernel", [rows["lora 32768 320 320"]["lora_gemm_kernel<128, 160, 64, 80, 2>"]])
 put("chain_kernel", [rows["chain 32768"]["aqlchain::chain_kernel<2, false>"]])
-f, q, kv = (K[next(k for k in K if k.startswith(p))] for p in ("attn_fwd_kernel", "attn_dq_kernel", "attn_dkv_kernel"))
+for prefix, kern in (("qpre: attn_fwd_kernel", "attn_fwd_kernel"), ("qpre: attn_dq_kernel", "attn_dq_kernel"), ("qpre: attn_dkv_kernel", "attn_dkv_kernel")):
+    key = next((k for k in K if k.startswith(prefix)), None)
+    if key is None:
+        key = prefix + "<64,48,...> on a pre-scaled q (aql_sdpa_*_qpre: the step's form at the 64 x 64 level), 4 / 8 samples"
+        K[key] = {}
+    vals = [one("attnq 4 4096 8", kern + "<64, 48"), one("attnq 8 4096 8", kern + "<64, 48")]
+    K[key]["us"], K[key]["mfma_util"] = [v[0] for v in vals], [v[1] for v in vals]
+f, q, kv = (K[next(k for k in K if k.startswith(p))] for p in ("qpre: attn_fwd_kernel", "qpre: attn_dq_kernel", "qpre: attn_dkv_kernel"))
 num = f["mfma_util"][1] * f["us"][1] + q["mfma_util"][0] * q["us"][0] + kv["mfma_util"][0] * kv["us"][0]
 mu["attention_64x64_time_weighted"] = round(num / (f["us"][1] + q["us"][0] + kv["us"][0]), 3)
 json.dump(mu, open(os.path.join(P, "r05_pmc_mfma_util.json"), "w"), indent=1)
