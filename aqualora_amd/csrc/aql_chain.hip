@@ -931,6 +931,7 @@ using namespace aqlchain;
 // shared tail of the two entry points: argument checks of the filled descriptor, tile height, launch
 int chain_launch(Args& a, long M, const char* name, bool bwd, hipStream_t stream, bool wide = false) {
   int nln = a.has_pre ? 1 : 0;
+  bool nout_odd = false;   // a LayerNorm output that starts on an odd 64-row tile: 64-row tiles (the row pass decides per tile)
   for (int g = 0; g < a.nstage; ++g) {
     const Stage& s = a.st[g];
     AQL_CHECK_ARG(s.W != nullptr && s.ldw >= CH && (long)CH * s.ldw * 2 < (long)BUF_BYTES, "%s: stage %d has no weight", name, g);
@@ -941,7 +942,8 @@ int chain_launch(Args& a, long M, const char* name, bool bwd, hipStream_t stream
     AQL_CHECK_ARG(s.out == nullptr || (s.ldo >= CH && M * s.ldo * 2 < (long)BUF_BYTES), "%s: stage %d: output span", name, g);
     AQL_CHECK_ARG(s.res == nullptr || (s.ldr >= CH && M * s.ldr * 2 < (long)BUF_BYTES), "%s: stage %d: residual span", name, g);
     AQL_CHECK_ARG(s.lnx == nullptr || (s.ldlx >= CH && M * s.ldlx * 2 < (long)BUF_BYTES), "%s: stage %d: saved LayerNorm input span", name, g);
-    AQL_CHECK_ARG(s.nout == nullptr || (s.ldn >= CH && M * s.ldn * 2 < (long)BUF_BYTES && s.nout_row0 % 128 == 0), "%s: stage %d: LayerNorm output span / first row", name, g);
+    AQL_CHECK_ARG(s.nout == nullptr || (s.ldn >= CH && M * s.ldn * 2 < (long)BUF_BYTES && s.nout_row0 % 64 == 0), "%s: stage %d: LayerNorm output span / first row (multiple of 64)", name, g);
+    nout_odd = nout_odd || (s.nout != nullptr && s.nout_row0 % 128 != 0);
     nln += s.ln ? 1 : 0;
   }
   AQL_CHECK_ARG(nln <= 1, "%s: at most one LayerNorm per chain", name);
@@ -964,7 +966,7 @@ int chain_launch(Args& a, long M, const char* name, bool bwd, hipStream_t stream
   // 128-row tiles while they fill the chip (the twin forward: 256 tiles), 64-row tiles below that (the backward pass runs on the
   // watermarked half only: 16384 rows = 128 tiles of 128 -- half the CUs idle -- or 256 of 64)
   static const int force = getenv("AQL_CHAIN_BM") ? atoi(getenv("AQL_CHAIN_BM")) : 0;   // tuning hook
-  const bool small = force == 64 || (force == 0 && (M / 128 < 200 || M % 128 != 0 || a.rps % 128 != 0 || a.row0 % 128 != 0));
+  const bool small = force == 64 || (force == 0 && (M / 128 < 200 || M % 128 != 0 || a.rps % 128 != 0 || a.row0 % 128 != 0 || nout_odd));
   if (wide) hipLaunchKernelGGL(chain_wide_kernel, dim3((unsigned)(M / 64)), dim3(NTH), LayW::TOTAL, stream, a);   // rank 320: 64-row tiles
   else if (bwd) hipLaunchKernelGGL((chain_kernel<1, true>), dim3((unsigned)(M / 64)), dim3(NTH), Lay<1>::TOTAL, stream, a);   // (64-row tiles only)
   else if (small) hipLaunchKernelGGL((chain_kernel<1, false>), dim3((unsigned)(M / 64)), dim3(NTH), Lay<1>::TOTAL, stream, a);

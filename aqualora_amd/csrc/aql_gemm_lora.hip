@@ -1015,7 +1015,7 @@ static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long
     }
     // (round 5: 320-447 tiles of 128 rows are all resident at two workgroups per CU -- ONE round -- where the 64-row choice below
     // ran one and a half: q | k | v at the 16 x 16 level on the twin batch, 2048 x 3840 x 1280, 56.3 -> 37.2 us, tools/tune_lora_cfg.py)
-    if (force_bm == 128 || (force_bm == 0 && (t128 >= 448 || t128 >= 320))) {
+    if (force_bm == 128 || (force_bm == 0 && t128 >= 320)) {
       // AQL_LORA_PERSIST=n (default 0 = off): grids of >= n tiles on the persistent kernel, whose workgroups fetch their next
       // tile's first K tile under the current tile's tail.  Measured round 4 (tools/probe_lora_persist.py, bit-identical on all 18
       // forms): 0.98x on ff.net.0 + GEGLU at 32768 x 2560 x 320 and 1.03-1.17x (SLOWER) everywhere else -- with two workgroups

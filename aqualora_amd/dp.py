@@ -170,7 +170,7 @@ class AqlComm:
         development boxes; a communicator that fails or stalls here is aborted and the torch.distributed exchange is used)."""
         import time
         dev = torch.device("cuda", torch.cuda.current_device())
-        buf = torch.ones(4096, dtype=torch.float32, device=dev)
+        buf = torch.ones(1 << 20, dtype=torch.float32, device=dev)   # 4 MB: beyond RCCL's single-channel / low-latency protocol sizes
         side = torch.cuda.Stream(device=dev)
         cap = torch.cuda.Stream(device=dev)
         cap.wait_stream(torch.cuda.current_stream())
@@ -217,20 +217,27 @@ class AqlComm:
 
 def make_comm(group=None):
     """The communicator of the captured / overlapped exchange, or (None, reason) when it is not to be used: no exchange active,
-    a non-RCCL backend (the gloo CPU tests), no AQL_COMM=1, or a failed self-test.
+    a non-RCCL backend (the gloo CPU tests), AQL_COMM=0, or a failed self-test.
 
-    OPT-IN (AQL_COMM=1) since round 4: the captured, hook-driven exchange has only ever run on single-rank communicators (1-GPU
-    development boxes; the world-size-2 protocol test runs over gloo).  Until a run on >= 2 GPUs has compared its parameters and
-    gradients with the torch.distributed exchange, the default data-parallel path is the bucketed torch.distributed one."""
+    DEFAULT since round 6 (north_star: "RCCL all-reduce ... overlapped with backward"; the reference's DDP reducer fires from
+    backward, ppft_train.py:905-912,1058): every data-parallel run takes the captured, hook-driven aql_comm_* exchange when the
+    start-up self-test passes on ALL ranks -- RCCL loadable, ncclCommInitRank, communicator size == world size, and a captured,
+    forked all-reduce of 4 MB replayed twice against its closed form under a deadline (AqlComm.self_test).  Any failure makes every
+    rank fall back TOGETHER to the torch.distributed exchange, with the reason on stderr and in `comm_note` (bench.py prints it).
+    AQL_COMM=0 selects the torch.distributed exchange outright."""
     if not exchange_active(group):
         return None, "no exchange (single rank)"
-    if os.environ.get("AQL_COMM", "0") != "1":
-        return None, "AQL_COMM != 1 (the captured aql_comm_* exchange is opt-in until validated on >= 2 GPUs)"
+    if os.environ.get("AQL_COMM", "1") == "0":
+        return None, "AQL_COMM=0 (torch.distributed exchange requested)"
     if dist.get_backend(group) != "nccl" or not torch.cuda.is_available():
         return None, f"backend {dist.get_backend(group)}"
     if group in _COMMS:                 # one communicator (and one self-test) per process group
         return _COMMS[group]
     _COMMS[group] = res = _make_comm(group)
+    if res[0] is None:
+        import sys
+        print(f"[aqualora_amd.dp] rank {dist.get_rank(group)}: captured aql_comm_* exchange NOT in use -- {res[1]}; falling back to "
+              "the torch.distributed exchange (not overlapped at rank 32)", file=sys.stderr, flush=True)
     return res
 
 

@@ -236,7 +236,7 @@ def ddim_sample(unet, ctx_cond, ctx_uncond, latents, num_inference_steps=50, gui
 def dpmpp2m_schedule(num_inference_steps=20, num_train_timesteps=1000, acp=None):
     """Timesteps and update coefficients of diffusers 0.24 ``DPMSolverMultistepScheduler`` as the reference configures it
     (train/rob_enhance_finetune.py:993 ``from_config`` of the SD-1.5 scheduler: dpmsolver++, order 2, midpoint, epsilon
-    prediction, the config's "leading" spacing with steps_offset 1 (20 steps: 949, 902, ..., 48), last sigma = sigma(alphas_cumprod[0]); 20 steps at :1012).  Recalled from the published
+    prediction, the config's "leading" spacing with steps_offset 1 (20 steps: 941, 894, ..., 48), last sigma = sigma(alphas_cumprod[0]); 20 steps at :1012).  Recalled from the published
     algorithm -- diffusers is not on disk (UNPINNED).  Returns [(t, alpha_t, sigma_t, a, b, c)] for
         x0 = (x - sigma_t eps) / alpha_t ;  x <- a x + b x0 + c x0_prev
     with c = 0 on the first (first-order) step; for fewer than 15 steps the final step is first-order too."""

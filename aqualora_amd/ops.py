@@ -288,7 +288,12 @@ def gemm_bf16(A, B, bias=None, A2=None, B2=None, rowbias=None, rps=1, residual=N
     N = B.shape[0]
     C = out if out is not None else torch.empty(M, N, dtype=torch.bfloat16, device=A.device)
     ws = workspace(A.device)
-    chunks = span_chunks(M, max(A.stride(0), C.stride(0)) * 2, rps if rowbias is not None else 1)
+    ld = max(A.stride(0), C.stride(0), 0 if A2 is None else A2.stride(0), 0 if residual is None else residual.stride(0))
+    align = rps if rowbias is not None else 1
+    if align * ld * 2 >= DESC_SPAN:
+        raise L.AqlError(f"gemm_bf16: one sample ({align} rows of {ld} elements) spans more than the 1 GiB an operand descriptor "
+                         "covers; a row bias needs whole samples per launch (unsupported shape)")
+    chunks = span_chunks(M, ld * 2, align)
     for r0, n in chunks:
         sl = slice(r0, r0 + n)
         Ac, Cc = A[sl], C[sl]
@@ -1284,6 +1289,14 @@ def chain_ok(x2d, stages, S16, rps):
     return os.environ.get("AQL_LORA_FUSED", "1") != "0"
 
 
+def chain_input_ok(t, x2d):
+    """A later chain of a block reads an attention output: it must have the geometry chain_ok accepted for the block's input x2d
+    (bf16 rows of 320, unit column stride, under 1 GiB, a twin view exactly when x2d is one)."""
+    return (t.dtype == torch.bfloat16 and t.dim() == 2 and t.shape == x2d.shape and t.stride(1) == 1
+            and (_full(t) is not None) == (_full(x2d) is not None)
+            and t.shape[0] * (2 if _full(t) is not None else 1) * t.stride(0) * 2 < (1 << 30))
+
+
 class ChainFn(torch.autograd.Function):
     """A chain of 320 -> 320 LoRA linears with the row-local operations between them (bias, residual add, LayerNorm) as ONE launch
     (aql_lora_chain_fwd): attn.to_out + residual -> LayerNorm -> next projection(s) of BasicTransformerBlock.forward and
@@ -1396,26 +1409,31 @@ class ChainFn(torch.autograd.Function):
         g = len(stages) - 1
         while g >= 0:
             st = stages[g]
-            # ---- backward chains (aql_lora_chain_bwd): [a single DIRECT linear's backward ->] LayerNorm backward -> this linear's backward
+            # ---- backward chains (aql_lora_chain_bwd)
+            if (fused_bwd and not st.keep and g >= 1 and g + 1 == len(stages) and dR is None and d_out[g] is not None
+                    and stages[g - 1].keep and stages[g - 1].ln is not None and d_n[g - 1] is None
+                    and (g - 1 > 0 or ctx.needs_input_grad[0])):
+                # the trailing DIRECT linear's backward -> LayerNorm backward -> the keep linear's backward as ONE launch
+                # (attn2.to_q backward -> norm2 backward -> attn1.to_out backward: the mirror of chain `a`)
+                k, g = g, g - 1
+                st = stages[g]
+                ln_entry = dict(x=O[g], ldx=O[g].stride(0), stats=ST[g], gamma=st.ln.weight)
+                dy_k = d_out[k].contiguous()
+                dres = None if d_out[g] is None else d_out[g].contiguous()
+                dhs, dx = mk(M, 320), mk(M, 320)
+                dTs_k, dT_k, dTs_g, dT_g = mk(M, 32), mk(M, 32), mk(M, 32), mk(M, 32)
+                chain_bwd(dy_k, dy_k.stride(0), M, rps, S16,
+                          [bwd_stage(k, dTs_k, dT_k, keep=1), bwd_stage(g, dTs_g, dT_g, dX=dx, lddx=320, keep=0)],
+                          [None, dict(ln_entry, dres=dres, lddres=0 if dres is None else dres.stride(0), out=dhs, ldo=320), None])
+                queue_site(k, dy_k, dTs_k, dT_k)
+                queue_site(g, dhs, dTs_g, dT_g)
+                if st.use_res:
+                    d_res = dhs
+                dR = dx
+                g -= 1
+                continue
             if fused_bwd and st.keep and st.ln is not None and (g > 0 or ctx.needs_input_grad[0]):
                 ln_entry = dict(x=O[g], ldx=O[g].stride(0), stats=ST[g], gamma=st.ln.weight)
-                if g + 2 == len(stages) and dR is None and not stages[g + 1].keep and d_out[g + 1] is not None and d_n[g] is None:
-                    # to_q backward -> LayerNorm backward -> to_out backward (the mirror of chain `a`)
-                    k = g + 1
-                    dy_k = d_out[k].contiguous()
-                    dres = None if d_out[g] is None else d_out[g].contiguous()
-                    dhs, dx = mk(M, 320), mk(M, 320)
-                    dTs_k, dT_k, dTs_g, dT_g = mk(M, 32), mk(M, 32), mk(M, 32), mk(M, 32)
-                    chain_bwd(dy_k, dy_k.stride(0), M, rps, S16,
-                              [bwd_stage(k, dTs_k, dT_k, keep=1), bwd_stage(g, dTs_g, dT_g, dX=dx, lddx=320, keep=0)],
-                              [None, dict(ln_entry, dres=dres, lddres=0 if dres is None else dres.stride(0), out=dhs, ldo=320), None])
-                    queue_site(k, dy_k, dTs_k, dT_k)
-                    queue_site(g, dhs, dTs_g, dT_g)
-                    if st.use_res:
-                        d_res = dhs
-                    dR = dx
-                    g -= 1
-                    continue
                 dn = add(dR, d_n[g])
                 if dn is not None:
                     # LayerNorm backward -> this linear's backward (norm3 -> attn2.to_out; norm1 -> proj_in)

@@ -371,12 +371,17 @@ class Transformer2DModel(nn.Module):
         qs = (d_head ** -0.5) * 1.4426950408889634 if qpre else 1.0
         d_stages = [CS(pk[self.proj_in], st[self.proj_in], True, ln=blk.norm1), CS(pk[a1.to_q], st[a1.to_q], False, oscale=qs)] + \
                    [CS(pk[m], st[m], False) for m in (a1.to_k, a1.to_v)]
-        if not ops.chain_ok(x2d, d_stages, S16, N):
+        a_stages = [CS(pk[a1.to_out[0]], st[a1.to_out[0]], True, use_res=True, ln=blk.norm2), CS(pk[a2.to_q], st[a2.to_q], False)]
+        c_stages = [CS(pk[a2.to_out[0]], st[a2.to_out[0]], True, use_res=True, ln=blk.norm3, emit_n=True)]
+        # all seven hosts are gated BEFORE the first chain is launched (shape, rank, the opt-in weight-side form): the later chains read
+        # o1 / o2, which have x2d's geometry (twin views of [2B N, C] buffers, row stride C)
+        if not ops.chain_ok(x2d, d_stages + a_stages + c_stages, S16, N):
             return None
         h0, q, k, v = ops.lora_chain(x2d, None, S, S16, N, d_stages)
         o1 = ops.attention(q.view(B, N, C), k.view(B, N, C), v.view(B, N, C), a1.heads, q_prescaled=qpre).reshape(B * N, C)
-        h1, q2 = ops.lora_chain(o1, h0, S, S16, N, [CS(pk[a1.to_out[0]], st[a1.to_out[0]], True, use_res=True, ln=blk.norm2),
-                                                    CS(pk[a2.to_q], st[a2.to_q], False)])
+        if not ops.chain_input_ok(o1, x2d):
+            raise ops.L.AqlError("Transformer2DModel chains: the self-attention output lost the twin geometry of its input")
+        h1, q2 = ops.lora_chain(o1, h0, S, S16, N, a_stages)
         if kv is not None:
             k2, v2 = kv[id(a2)]
         elif nolora:
@@ -384,7 +389,9 @@ class Transformer2DModel(nn.Module):
         else:                                   # (rank 320: no grouped k | v launch in front of the U-Net)
             k2, v2 = a2.to_k(ctx, scale), a2.to_v(ctx, scale)
         o2 = ops.attention(q2.view(B, N, C), k2, v2, a2.heads).reshape(B * N, C)
-        h2, n3 = ops.lora_chain(o2, h1, S, S16, N, [CS(pk[a2.to_out[0]], st[a2.to_out[0]], True, use_res=True, ln=blk.norm3, emit_n=True)])
+        if not ops.chain_input_ok(o2, x2d):
+            raise ops.L.AqlError("Transformer2DModel chains: the text-state attention output lost the twin geometry of its input")
+        h2, n3 = ops.lora_chain(o2, h1, S, S16, N, c_stages)
         tokens = blk.ff(n3.view(B, N, C), scale, residual=h2.view(B, N, C))
         h = tokens.view(B, H, W, C).permute(0, 3, 1, 2)
         return self.proj_out(h, scale, residual=x)

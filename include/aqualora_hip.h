@@ -195,8 +195,9 @@ int aql_layernorm_bwd(const bf16_t* x, const bf16_t* dy, long M, int C, const bf
  *     keep_g = 0:  out_g <- bf16(Y * oscale_g)                                   (X unchanged: q | k | v read the same tile;
  *                  oscale (host array or null = all 1): scale log2(e) on attn1.to_q, whose consumer is then aql_sdpa_fwd_qpre)
  * Every per-stage argument is a HOST array of nstage entries (null entries where a stage has no such operand; Adown_g = null:
- * no LoRA on that linear).  M % 128 == 0, rows_per_sample % 128 == 0, lora_row0 % 128 == 0 (rows below lora_row0 -- the clean half
- * of a twin batch, ppft_train.py:1026-1029 -- carry no LoRA term and write no T / Ts); at most one LayerNorm per chain.        */
+ * no LoRA on that linear).  M, rows_per_sample, lora_row0, nout_row0: multiples of 64 (128-row tiles run when all are multiples
+ * of 128 and fill the chip, 64-row tiles otherwise; rows below lora_row0 -- the clean half of a twin batch,
+ * ppft_train.py:1026-1029 -- carry no LoRA term and write no T / Ts); at most one LayerNorm per chain.                         */
 int aql_lora_chain_fwd(const bf16_t* X, long ldx, long M, int rows_per_sample, long lora_row0, const bf16_t* S, int nstage,
                        const void* const* W, const long* ldw, const void* const* bias, const void* const* Adown,
                        const void* const* Bup, void* const* T, void* const* Ts, const void* const* res, const long* ldr,

@@ -45,8 +45,8 @@ def main():
             if mode != "plain":
                 os.environ["AQL_FORCE_ALLREDUCE"] = "1"
                 os.environ["AQL_BUCKETS"] = "3"     # the tiny bank is far below the size where bucketing switches on
-            if mode.startswith("overlap"):
-                os.environ["AQL_COMM"] = "1"        # opt-in (dp.make_comm): the captured aql_comm_* exchange
+            if mode != "plain":                     # the captured aql_comm_* exchange (the default) or, AQL_COMM=0, torch.distributed
+                os.environ["AQL_COMM"] = "1" if mode.startswith("overlap") else "0"
             tr = build(rank, inp)
             assert tr.bucketed == mode.startswith("bucketed"), (mode, tr.bucketed, tr.comm_note)
             assert tr.overlap == mode.startswith("overlap"), (mode, tr.overlap, tr.comm_note)
@@ -88,8 +88,8 @@ def robft_modes():
         os.environ.pop("AQL_COMM", None)
         if not mode.startswith("plain"):
             os.environ["AQL_FORCE_ALLREDUCE"] = "1"
-        if mode == "comm":
-            os.environ["AQL_COMM"] = "1"
+        if not mode.startswith("plain"):
+            os.environ["AQL_COMM"] = "1" if mode == "comm" else "0"
         torch.manual_seed(11)       # the train-mode forward draws stochastic depth / dropout from torch's generator
         dec = _synthetic_decoder(48).to("cuda").train()
         S1.prepare_rob_finetune(dec, None, n_buckets=4)

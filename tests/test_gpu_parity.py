@@ -448,6 +448,31 @@ def test_full_size_batch8_rank320_twin_step_equals_mean_of_batch1_steps():
     assert rec["graph_vs_eager_param_relerr"] < 2e-3, rec
 
 
+@pytest.mark.parametrize("rank,batch", [(32, 4), (320, 8)])
+def test_default_captured_exchange_equals_unexchanged_step(rank, batch):
+    """BASELINE configs 2 and 3 at full size: with nothing but a process group present (AQL_COMM unset) the trainer takes the
+    captured, hook-driven aql_comm_* exchange (ONE step graph, three legs under backward; ppft_train.py:905-912,1058) -- and on a
+    single-rank communicator, where the mean is the identity, that step equals the un-exchanged single-GPU step: first loss bit for
+    bit, gradients and parameters up to the order of the weight-gradient launches' fp32 atomics (tests/dp_identity_worker.py)."""
+    import json, os, subprocess, sys
+    from tests.conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29551")
+    for k in ("AQL_COMM", "AQL_FORCE_ALLREDUCE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "tests.dp_identity_worker", str(rank), str(batch)], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    print(rec)
+    assert rec["exchange_overlap"] and rec["exchange_n_graphs"] == 1 and rec["exchange_comm_note"] == "ok", rec
+    assert not rec["plain_overlap"], rec
+    rg = rec["exchange_ranges"]
+    assert rg[0][0] == 0 and rg[-1][1] == rec["numel"] and all(a[1] == b[0] for a, b in zip(rg, rg[1:])), rg
+    assert rec["finite"] and rec["first_loss_bit_equal"], rec
+    assert rec["grad_relerr"] < 1e-4 and rec["param_relerr"] < 2e-3, rec     # (AdamW's first steps are lr * sign(g): see the bucketed test)
+    assert abs(rec["plain_losses"][1] - rec["exchange_losses"][1]) < 2e-2 * abs(rec["plain_losses"][1]), rec
+
+
 def test_secret_decoder_vs_torchvision_live():
     """SURVEY.md section 8(c) option 2: when the box's own Python has torchvision, pin the decoder to the real
     ``efficientnet_b1`` (utils/models.py:84-96).  torchvision is absent from the build image, so this normally skips."""
