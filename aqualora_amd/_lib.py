@@ -47,6 +47,13 @@ SIGNATURES = {
     "aql_causal_attn_small": [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p],
     "aql_softmax_rows_bwd": [c_p, c_p, c_l, c_l, c_i, c_f, c_p, c_p],
     "aql_conv3x3_bwd_data": [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_sz, c_p],
+    "aql_gemm_bf16_grouped": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_p, c_p, c_l, c_p, c_l, c_p, c_l,
+                              c_p, c_i, c_l, c_p, c_sz, c_p],
+    "aql_conv3x3_fwd_defer": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_sz, c_p, c_p],
+    "aql_conv3x3_bwd_data_defer": [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_sz, c_p, c_p],
+    "aql_splitk_finalize": [c_p, c_i, c_l, c_i, c_p, c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_p],
+    "aql_groupnorm_silu_fwd_slabs": [c_p, c_i, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_f, c_i, c_p, c_p, c_p],
+    "aql_groupnorm_silu_bwd_slabs": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p],
     "aql_gemm_tn_f32": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_f, c_p, c_l, c_p],
     "aql_gemm_tn_tr_f32": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_f, c_p, c_l, c_p],
     "aql_gemm_tn_tr_grouped": [c_p, c_i, c_i, c_i, c_i, c_p],
@@ -129,6 +136,8 @@ SIGNATURES = {
     "aql_sdpa_fwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p, c_p],
     "aql_sdpa_bwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p,
                      c_p, c_p, c_sz, c_p],
+    "aql_sdpa_bwd_ex": [c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p,
+                        c_p, c_l, c_l, c_p, c_sz, c_p],
     "aql_sdpa_fwd_qpre": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p, c_p],
     "aql_sdpa_bwd_qpre": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p,
                           c_p, c_p, c_sz, c_p],

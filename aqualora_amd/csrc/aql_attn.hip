@@ -371,6 +371,7 @@ struct AttnArgs {
   float* lse;
   float* delta;
   long ldq, ldk, ldv, ldo;
+  long ldgq, ldgkv;   // backward: row stride of dq and of dk / dv (0 = dense, H * d; aql_sdpa_bwd_ex: column blocks of a wider buffer)
   int B, H, Nq, Nk, d;
   float scale;
   // exponent and natural-log factors of a raw score q.k:  p = exp2(s * cexp - ...), lse = max * cnat + log(sum).  (scale log2(e), scale) --
@@ -871,7 +872,7 @@ __global__ __launch_bounds__(256, (DH <= AQL_ATTN_DQ_OCC2_UPTO ? 2 : 1)) void at
     }
   }
   const float mq[2] = {a.scale, a.scale};
-  const long ld_dq = (long)a.H * a.d;  // dQ is written dense ([B][Nq][H*d]) whatever the row stride of q (q may be a column view)
+  const long ld_dq = a.ldgq > 0 ? a.ldgq : (long)a.H * a.d;  // dQ is written dense ([B][Nq][H*d]) whatever the row stride of q (q may be a column view), unless ldg says otherwise
   store_t<DV>(dq, a.dq + (long)b * a.Nq * ld_dq + h * a.d, ld_dq, q0, a.Nq, a.d, mq, lane);
 }
 
@@ -1042,7 +1043,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_dkv_kernel(const
       cur ^= 1;
     }
   }
-  const long ldo_kv = (long)a.H * a.d;
+  const long ldo_kv = a.ldgkv > 0 ? a.ldgkv : (long)a.H * a.d;
   if (a.qsplit > 1) {
     const long slab = (long)a.qsplit * a.B * a.H * a.Nk * a.d;
     float* pk = a.part + (((long)split * a.B + b) * a.H + h) * a.Nk * a.d;
@@ -1076,7 +1077,7 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const AttnArgs a) 
       acc.x += t.x, acc.y += t.y, acc.z += t.z, acc.w += t.w;
     }
     const float mul = which ? 1.f : a.cnat;
-    bf16_t* out = (which ? a.dv : a.dk) + ((long)b * a.Nk + row) * ((long)a.H * a.d) + h * a.d + c;
+    bf16_t* out = (which ? a.dv : a.dk) + ((long)b * a.Nk + row) * (a.ldgkv > 0 ? a.ldgkv : (long)a.H * a.d) + h * a.d + c;
     *reinterpret_cast<uint2*>(out) = make_uint2(pack_bf16x2(acc.x * mul, acc.y * mul), pack_bf16x2(acc.z * mul, acc.w * mul));
   }
 }
@@ -1279,7 +1280,7 @@ __global__ __launch_bounds__(256, (DH <= 96 ? 2 : 1)) void attn_ctx_dq_kernel(co
   ctx_stage<DH>(sV, a.v + (long)b * a.Nk * a.ldv + h * a.d, a.ldv, a.Nk, a.d, tid);
   __syncthreads();
   const float c = a.cexp;
-  const long ld_dq = (long)a.H * a.d;
+  const long ld_dq = a.ldgq > 0 ? a.ldgq : (long)a.H * a.d;
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int q0 = wg_q0 + (i * 4 + wave) * OWN;
@@ -1484,14 +1485,17 @@ extern "C" int aql_sdpa_fwd_qpre(const bf16_t* q, long ldq, const bf16_t* k, lon
 static int sdpa_bwd_impl(int qpre, const bf16_t* q, long ldq, const bf16_t* k, long ldk, const bf16_t* v, long ldv,
                             const bf16_t* o, const bf16_t* dout, long ldo, const float* lse, float* delta, int B, int H,
                             int Nq, int Nk, int d, float scale, bf16_t* dq, bf16_t* dk, bf16_t* dv, float* ws,
-                            size_t ws_bytes, hipStream_t stream) {
+                            size_t ws_bytes, hipStream_t stream, long ldgq = 0, long ldgkv = 0) {
   AQL_CHECK_ARG(q && k && v && o && dout && lse && delta && dq && dk && dv, "aql_sdpa_bwd: null operand");
+  AQL_CHECK_ARG((ldgq == 0 || (ldgq % 8 == 0 && ldgq >= (long)H * d)) && (ldgkv == 0 || (ldgkv % 8 == 0 && ldgkv >= (long)H * d)),
+                "aql_sdpa_bwd: gradient row strides %ld / %ld", ldgq, ldgkv);
   AQL_CHECK_ARG(d % 8 == 0 && d <= 160 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && Nk > 0,
                 "aql_sdpa_bwd: unsupported head dim %d or strides", d);
   AttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.o = o; a.dout = dout; a.lse = const_cast<float*>(lse); a.delta = delta;
   a.dq = dq; a.dk = dk; a.dv = dv;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+  a.ldgq = ldgq; a.ldgkv = ldgkv;
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d; a.scale = scale;
   a.qpre = qpre; a.cexp = qpre ? 1.f : scale * LOG2E; a.cnat = qpre ? 0.6931471805599453f : scale;
   // split the streamed Q range when the key side alone cannot fill the chip (cross-attention: Nk = 77)
@@ -1528,4 +1532,16 @@ extern "C" int aql_sdpa_bwd_qpre(const bf16_t* q, long ldq, const bf16_t* k, lon
                                  int Nq, int Nk, int d, float scale, bf16_t* dq, bf16_t* dk, bf16_t* dv, float* ws,
                                  size_t ws_bytes, hipStream_t stream) {
   return sdpa_bwd_impl(1, q, ldq, k, ldk, v, ldv, o, dout, ldo, lse, delta, B, H, Nq, Nk, d, scale, dq, dk, dv, ws, ws_bytes, stream);
+}
+
+// aql_sdpa_bwd / aql_sdpa_bwd_qpre (qpre = 0 / 1) whose gradients are written with row strides of ldg_q (dq) and ldg_kv (dk, dv)
+// elements (0 = dense): dq | dk | dv as the column blocks of ONE [B][N][3 H d] buffer (self-attention), or dk | dv as the column blocks of
+// one [B][Nk][2 H d] buffer (text-state attention) -- the activation-side operand of the grouped backward of the projections
+// (aql_gemm_bf16_grouped), with no gather copy in between.
+extern "C" int aql_sdpa_bwd_ex(int qpre, const bf16_t* q, long ldq, const bf16_t* k, long ldk, const bf16_t* v, long ldv,
+                               const bf16_t* o, const bf16_t* dout, long ldo, const float* lse, float* delta, int B, int H, int Nq,
+                               int Nk, int d, float scale, bf16_t* dq, bf16_t* dk, bf16_t* dv, long ldg_q, long ldg_kv, float* ws,
+                               size_t ws_bytes, hipStream_t stream) {
+  return sdpa_bwd_impl(qpre ? 1 : 0, q, ldq, k, ldk, v, ldv, o, dout, ldo, lse, delta, B, H, Nq, Nk, d, scale, dq, dk, dv, ws, ws_bytes,
+                       stream, ldg_q, ldg_kv);
 }

@@ -336,7 +336,7 @@ struct CastDesc {
   bf16_t* out;
   bf16_t* outT;
   int rows, cols;
-  int first_tile, pad;
+  int first_tile, pad;   // pad: leading dimension of outT, 0 = rows (dense)
 };
 __global__ __launch_bounds__(256) void cast_transpose_batched_kernel(const CastDesc* __restrict__ desc, int n) {
   __shared__ float tile[32][33];
@@ -350,6 +350,7 @@ __global__ __launch_bounds__(256) void cast_transpose_batched_kernel(const CastD
   const int tx_tiles = (d.cols + 31) / 32;
   const int bx = (t % tx_tiles) * 32, by = (t / tx_tiles) * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long ldt = d.pad > 0 ? d.pad : d.rows;   // leading dimension of the transposed copy (column blocks of a wider matrix: LoraBank)
   for (int i = ty; i < 32; i += 8) {
     const int r = by + i, c = bx + tx;
     float v = 0.f;
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(256) void cast_transpose_batched_kernel(const CastD
   __syncthreads();
   for (int i = ty; i < 32; i += 8) {
     const int c = bx + i, r = by + tx;
-    if (r < d.rows && c < d.cols) d.outT[(long)c * d.rows + r] = f32_to_bf16(tile[tx][i]);
+    if (r < d.rows && c < d.cols) d.outT[(long)c * ldt + r] = f32_to_bf16(tile[tx][i]);
   }
 }
 

@@ -148,8 +148,24 @@ struct GemmArgs {
   int seg1_row0 = 0;  // output tiles that end at or below this row skip K segment 1 (twin batch: clean rows carry no LoRA term)
   int splits;  // grid.z; k tiles of the concatenated K range are divided evenly
   int m_fast;  // tile order: 0 = N tiles of one M tile adjacent (activation reuse), 1 = M tiles adjacent (weight reuse)
+  // Column groups (round 6; 0 = off): output columns [g grp_n, (g + 1) grp_n) read the activation-side operand of segment 0 / 1 at a
+  // column offset of g grp_a0 / g grp_a1 elements -- block-diagonal products as ONE GEMM: q | k | v of a rank-r LoRA read their own
+  // slice of the stacked Ts [M, 3r] (segment 1), the three backward "down" products their own slice of [dQ | dK | dV] (segment 0).
+  // grp_n is a multiple of every tile width the picker may choose for N (entry points check: multiples of 320).
+  int grp_n = 0, grp_a0 = 0, grp_a1 = 0;
   EpiParams epi;
 };
+
+// the activation-side loader of the workgroup whose output tile starts at column n0 (GemmArgs::grp_n)
+template <class LA>
+__device__ __forceinline__ LA group_operand(const LA& l, int n0, int grp_n, int off) {
+  LA r = l;
+  if constexpr (std::is_same<LA, PlainLoader>::value) {
+    const int gidx = __builtin_amdgcn_readfirstlane(grp_n > 0 ? n0 / grp_n : 0);   // block-uniform
+    r.base = l.base + (long)gidx * off;
+  }
+  return r;
+}
 
 // --------------------------------------------------------------------------------------------
 // staging helpers
@@ -875,7 +891,7 @@ __device__ __forceinline__ void gemm_body_d(const GemmArgs<LA, LB>& g, const int
   DmaStager<BM, LA> sa;  // row descriptors only: tiles go global -> LDS directly (no staging registers, no ds_write)
   DmaStager<BN, LB> sb;
   constexpr int NLD = BM / 32 + BN / 32;  // LDS-DMA instructions per thread per K tile
-  sa.begin(g.a0, g.a1, dual, m0, tid, kt_begin, kt_end, g.ktiles0);
+  sa.begin(group_operand(g.a0, n0, g.grp_n, g.grp_a0), group_operand(g.a1, n0, g.grp_n, g.grp_a1), dual, m0, tid, kt_begin, kt_end, g.ktiles0);
   sb.begin(sample_operand(g.b0, m0), g.b1, dual, n0, tid, kt_begin, kt_end, g.ktiles0);
 
   uint2 biasr[FN];  // fetched ahead of the ring fill (older than every DMA: the counted vmcnt waits below retire them first)
@@ -1079,7 +1095,7 @@ __device__ __forceinline__ void gemm_body_w(const GemmArgs<LA, LB>& g, const int
   if (loader) {
     DmaStager<BM, LA, RPI> sa;  // row descriptors only: tiles go global -> LDS directly (no staging registers, no ds_write)
     DmaStager<BN, LB, RPI> sb;
-    sa.begin(g.a0, g.a1, dual, m0, ltid, kt_begin, kt_end, g.ktiles0);
+    sa.begin(group_operand(g.a0, n0, g.grp_n, g.grp_a0), group_operand(g.a1, n0, g.grp_n, g.grp_a1), dual, m0, ltid, kt_begin, kt_end, g.ktiles0);
     sb.begin(sample_operand(g.b0, m0), g.b1, dual, n0, ltid, kt_begin, kt_end, g.ktiles0);
     auto issue = [&](int stage) {  // stages the NEXT tile of the K range (tiles are requested in order)
       char* sA = lds + stage * STAGE;

@@ -137,6 +137,8 @@ struct OutSpec {
   const bf16_t* gb_h = nullptr;  // GEGLU-backward epilogue (EpiParams::gb_F = N): saved pre-activation [M][2N]
   long gb_ldh = 0;
   int res_mod = 0;               // EpiParams::res_mod
+  int* defer_splits = nullptr;   // not null: a split-K launch leaves its fp32 slabs UNFINISHED in ws and reports the split count here
+                                 // (1 = the output is complete); the caller's next launch consumes the slabs (aql_groupnorm_silu_*_slabs)
 };
 
 inline int pick_splits(int tiles, int kt_total, long M, int N, size_t ws_bytes) {
@@ -361,6 +363,10 @@ int run_bf16_gemm(GemmArgs<LA, LB> g, const OutSpec& o, float* ws, size_t ws_byt
     g.epi.ldcf = g.N;
     launch_cfg<LA, LB, EPI_SLAB>(cfg, pd, g, stream);
     AQL_CHECK_LAUNCH(name);
+    if (o.defer_splits != nullptr) {   // the finalize is the consumer's first pass
+      *o.defer_splits = splits;
+      return AQL_OK;
+    }
     const long nchunk = (long)g.M * (g.N / 4);
     int blocks = (int)((nchunk + 255) / 256);
     if (blocks > 2048) blocks = 2048;
@@ -451,6 +457,60 @@ extern "C" int aql_gemm_bf16_ex(const bf16_t* A, long lda, const bf16_t* B, long
   g.N = N;
   OutSpec o{bias, rowbias, 0, rows_per_sample, residual, ldr, C, ldc, nullptr, 0, nullptr};
   return run_bf16_gemm(g, o, ws, ws_bytes, stream, "aql_gemm_bf16");
+}
+
+// Column-grouped form of aql_gemm_bf16_ex (round 6): output columns [g grp_n, (g + 1) grp_n) read A at a column offset of g grp_a
+// elements and A2 at g grp_a2 (0 = the same columns for every group); B / B2 rows are the output columns as always.  Block-diagonal
+// products as ONE launch -- the rank-320 LoRA of q | k | v (BASELINE config 3; utils/lora_modules.py:9-26 on three linears that
+// read the same tokens, scripts/lib/original_unet.py:688-704):
+//   forward    [q | k | v] = X.[Wq; Wk; Wv]^T + Ts_g.Bup_g^T        A2 = [Ts_q | Ts_k | Ts_v] (grp_a2 = r), B2 = [Bup_q; Bup_k; Bup_v]
+//   backward   [dTs_q | dTs_k | dTs_v] = dY_g.Bup_g                 A = [dQ | dK | dV] (grp_a = C), B = [Bup_q^T; Bup_k^T; Bup_v^T]
+// Optional second output C2 = C * rowscale[m / rows_per_sample][n] (the per-message scale: Ts = T * S; then no split K).
+// grp_n: a multiple of 320 (every tile width the picker chooses divides it) that divides N; N a multiple of 160.
+extern "C" int aql_gemm_bf16_grouped(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, int N, int K, const bf16_t* A2,
+                                     long lda2, const bf16_t* B2, long ldb2, int K2, int grp_n, int grp_a, int grp_a2,
+                                     const bf16_t* bias, const bf16_t* residual, long ldr, bf16_t* C, long ldc, bf16_t* C2, long ldc2,
+                                     const bf16_t* rowscale, int rows_per_sample, long lora_row0, float* ws, size_t ws_bytes,
+                                     hipStream_t stream) {
+  AQL_CHECK_ARG(A && B && C, "aql_gemm_bf16_grouped: null operand");
+  AQL_CHECK_ARG(M > 0 && N > 0 && K > 0 && M < (1L << 31), "aql_gemm_bf16_grouped: bad shape M=%ld N=%d K=%d", M, N, K);
+  AQL_CHECK_ARG(N % 160 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0,
+                "aql_gemm_bf16_grouped: N must be a multiple of 160, K and the leading dimensions of 8 (N=%d K=%d)", N, K);
+  AQL_CHECK_ARG(grp_n > 0 && grp_n % 320 == 0 && N % grp_n == 0 && grp_a >= 0 && grp_a2 >= 0 && grp_a % 8 == 0 && grp_a2 % 8 == 0,
+                "aql_gemm_bf16_grouped: grp_n = %d must be a multiple of 320 that divides N = %d; offsets multiples of 8", grp_n, N);
+  AQL_CHECK_ARG(aligned16(A) && aligned16(B) && aligned16(C), "aql_gemm_bf16_grouped: pointers must be 16-byte aligned");
+  AQL_CHECK_ARG(residual == nullptr || (ldr % 8 == 0 && aligned16(residual)), "aql_gemm_bf16_grouped: bad residual");
+  AQL_CHECK_ARG(C2 == nullptr || (rowscale != nullptr && ldc2 % 8 == 0 && aligned16(C2) && rows_per_sample > 0),
+                "aql_gemm_bf16_grouped: the second output needs rowscale [M / rows_per_sample][N]");
+  const int ng = N / grp_n;
+  AQL_CHECK_ARG(lda >= (long)(ng - 1) * grp_a + K, "aql_gemm_bf16_grouped: A rows hold %ld elements, the groups read %ld", lda,
+                (long)(ng - 1) * grp_a + K);
+  GemmArgs<PlainLoader, PlainLoader> g;
+  g.a0 = plain(A, lda, M, K);
+  g.b0 = plain(B, ldb, N, K);
+  g.ktiles0 = aql_cdiv(K, BK);
+  g.ktiles1 = 0;
+  g.a1 = g.a0;
+  g.b1 = g.b0;
+  if (A2 != nullptr) {
+    AQL_CHECK_ARG(B2 && K2 > 0 && K2 % 8 == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0 && aligned16(A2) && aligned16(B2) &&
+                      lda2 >= (long)(ng - 1) * grp_a2 + K2,
+                  "aql_gemm_bf16_grouped: bad second K segment");
+    g.a1 = plain(A2, lda2, M, K2);
+    g.b1 = plain(B2, ldb2, N, K2);
+    g.ktiles1 = aql_cdiv(K2, BK);
+    if (lora_row0 > 0) {
+      g.seg1_row0 = (int)(lora_row0 > M ? M : lora_row0);
+      g.a1.row_lo = g.seg1_row0;
+    }
+  }
+  g.M = (int)M;
+  g.N = N;
+  g.grp_n = grp_n;
+  g.grp_a0 = grp_a;
+  g.grp_a1 = grp_a2;
+  OutSpec o{bias, nullptr, 0, rows_per_sample > 0 ? rows_per_sample : 1, residual, ldr, C, ldc, C2, ldc2, rowscale};
+  return run_bf16_gemm(g, o, C2 == nullptr ? ws : nullptr, C2 == nullptr ? ws_bytes : 0, stream, "aql_gemm_bf16_grouped");
 }
 
 // Backward-data of ff.net.2 in the two-launch LoRA form (any rank) fused with the backward of the GEGLU in front of it
@@ -966,9 +1026,47 @@ extern "C" int aql_conv3x3_fwd(const bf16_t* X, int B, int Hin, int Win, int Cin
 
 // pad_lo = 1: torch padding=1.  pad_lo = 0 (stride 2 only): zero padding on the bottom/right edge only, i.e.
 // F.pad(x, (0,1,0,1)) + Conv2d(padding=0) -- the Downsample2D of diffusers' AutoencoderKL encoder.
+static int conv3x3_fwd_impl(const bf16_t* X, int B, int Hin, int Win, int Cin, const bf16_t* Wk, const bf16_t* bias,
+                            int Cout, int stride, int upsample, int pad_lo, const bf16_t* rowbias, long rowbias_ld,
+                            const bf16_t* residual, bf16_t* Y, float* ws, size_t ws_bytes, int* defer_splits, hipStream_t stream);
+
 extern "C" int aql_conv3x3_fwd_pad(const bf16_t* X, int B, int Hin, int Win, int Cin, const bf16_t* Wk, const bf16_t* bias,
                                    int Cout, int stride, int upsample, int pad_lo, const bf16_t* rowbias, long rowbias_ld,
                                    const bf16_t* residual, bf16_t* Y, float* ws, size_t ws_bytes, hipStream_t stream) {
+  return conv3x3_fwd_impl(X, B, Hin, Win, Cin, Wk, bias, Cout, stride, upsample, pad_lo, rowbias, rowbias_ld, residual, Y, ws, ws_bytes,
+                          nullptr, stream);
+}
+
+// aql_conv3x3_fwd whose split-K finalize launch is left to the consumer (round 6): *splits_out = 1: Y is complete;
+// *splits_out = s > 1: ws holds s fp32 partial slabs [s][B*Hout*Wout][Cout] and Y is NOT written -- finish with
+// aql_groupnorm_silu_fwd_slabs (the GroupNorm behind the convolution, ResnetBlock2D.forward, original_unet.py:423-453) or aql_splitk_finalize.
+extern "C" int aql_conv3x3_fwd_defer(const bf16_t* X, int B, int Hin, int Win, int Cin, const bf16_t* Wk, const bf16_t* bias,
+                                     int Cout, int stride, int upsample, const bf16_t* rowbias, long rowbias_ld,
+                                     const bf16_t* residual, bf16_t* Y, float* ws, size_t ws_bytes, int* splits_out,
+                                     hipStream_t stream) {
+  AQL_CHECK_ARG(splits_out != nullptr, "aql_conv3x3_fwd_defer: splits_out is null");
+  *splits_out = 1;
+  return conv3x3_fwd_impl(X, B, Hin, Win, Cin, Wk, bias, Cout, stride, upsample, 1, rowbias, rowbias_ld, residual, Y, ws, ws_bytes,
+                          splits_out, stream);
+}
+
+// The finalize launch of a split-K GEMM on its own: C = bf16(sum_z slabs[z] + bias) + rowbias[m / rows_per_sample] + residual.
+extern "C" int aql_splitk_finalize(const float* slabs, int splits, long M, int N, const bf16_t* bias, const bf16_t* rowbias,
+                                   long rowbias_ld, int rows_per_sample, const bf16_t* residual, long ldr, bf16_t* C, long ldc,
+                                   hipStream_t stream) {
+  AQL_CHECK_ARG(slabs && C && splits >= 1 && M > 0 && N > 0 && N % 4 == 0 && ldc >= N, "aql_splitk_finalize: bad arguments");
+  const long nchunk = M * (N / 4);
+  int blocks = (int)((nchunk + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, stream, slabs, splits, M, N, bias, rowbias,
+                     rowbias_ld > 0 ? rowbias_ld : (long)N, rows_per_sample > 0 ? rows_per_sample : 1, residual, ldr, C, ldc);
+  AQL_CHECK_LAUNCH("aql_splitk_finalize");
+  return AQL_OK;
+}
+
+static int conv3x3_fwd_impl(const bf16_t* X, int B, int Hin, int Win, int Cin, const bf16_t* Wk, const bf16_t* bias,
+                            int Cout, int stride, int upsample, int pad_lo, const bf16_t* rowbias, long rowbias_ld,
+                            const bf16_t* residual, bf16_t* Y, float* ws, size_t ws_bytes, int* defer_splits, hipStream_t stream) {
   AQL_CHECK_ARG(X && Wk && Y, "aql_conv3x3_fwd: null operand");
   AQL_CHECK_ARG(pad_lo == 1 || (pad_lo == 0 && stride == 2 && Hin % 2 == 0 && Win % 2 == 0),
                 "aql_conv3x3_fwd: pad_lo=0 needs stride 2 and even H, W");
@@ -999,12 +1097,30 @@ extern "C" int aql_conv3x3_fwd_pad(const bf16_t* X, int B, int Hin, int Win, int
   g.M = l.rows;
   g.N = Cout;
   OutSpec o{bias, rowbias, rowbias_ld, l.Hout * l.Wout, residual, Cout, Y, Cout, nullptr, 0, nullptr};
+  o.defer_splits = defer_splits;
   return run_bf16_gemm(g, o, ws, ws_bytes, stream, "aql_conv3x3_fwd");
 }
 
 // dX[b,hi,wi,ci] = sum_{kh,kw,co} dY[b,ho,wo,co] * Wt[ci][(kh*3+kw)*Cout+co],  hi = ho*stride + kh - 1.
+static int conv3x3_bwd_data_impl(const bf16_t* dY, int B, int Hin, int Win, int Cin, const bf16_t* Wt, int Cout, int stride, bf16_t* dX,
+                                 float* ws, size_t ws_bytes, int* defer_splits, hipStream_t stream);
+
 extern "C" int aql_conv3x3_bwd_data(const bf16_t* dY, int B, int Hin, int Win, int Cin, const bf16_t* Wt, int Cout,
                                     int stride, bf16_t* dX, float* ws, size_t ws_bytes, hipStream_t stream) {
+  return conv3x3_bwd_data_impl(dY, B, Hin, Win, Cin, Wt, Cout, stride, dX, ws, ws_bytes, nullptr, stream);
+}
+
+// aql_conv3x3_bwd_data with the split-K finalize left to the consumer (see aql_conv3x3_fwd_defer): the GroupNorm backward in front of
+// the convolution's input (aql_groupnorm_silu_bwd_slabs), or aql_splitk_finalize.
+extern "C" int aql_conv3x3_bwd_data_defer(const bf16_t* dY, int B, int Hin, int Win, int Cin, const bf16_t* Wt, int Cout,
+                                          int stride, bf16_t* dX, float* ws, size_t ws_bytes, int* splits_out, hipStream_t stream) {
+  AQL_CHECK_ARG(splits_out != nullptr, "aql_conv3x3_bwd_data_defer: splits_out is null");
+  *splits_out = 1;
+  return conv3x3_bwd_data_impl(dY, B, Hin, Win, Cin, Wt, Cout, stride, dX, ws, ws_bytes, splits_out, stream);
+}
+
+static int conv3x3_bwd_data_impl(const bf16_t* dY, int B, int Hin, int Win, int Cin, const bf16_t* Wt, int Cout, int stride, bf16_t* dX,
+                                 float* ws, size_t ws_bytes, int* defer_splits, hipStream_t stream) {
   AQL_CHECK_ARG(dY && Wt && dX, "aql_conv3x3_bwd_data: null operand");
   AQL_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0 && (stride == 1 || stride == 2), "aql_conv3x3_bwd_data: bad shape");
   ConvBwdLoader l;
@@ -1028,6 +1144,7 @@ extern "C" int aql_conv3x3_bwd_data(const bf16_t* dY, int B, int Hin, int Win, i
   g.M = l.rows;
   g.N = Cin;
   OutSpec o{nullptr, nullptr, 0, 1, nullptr, 0, dX, Cin, nullptr, 0, nullptr};
+  o.defer_splits = defer_splits;
   return run_bf16_gemm(g, o, ws, ws_bytes, stream, "aql_conv3x3_bwd_data");
 }
 

@@ -423,13 +423,31 @@ constexpr int GNF_U = 8;  // pixels in flight per thread
 // workgroups and two launches: PHASE 1 writes each piece's raw sums to `part` [B][32][nsplit][2], PHASE 2 adds the pieces in
 // a fixed order (every workgroup redundantly: nsplit <= 8 pairs), then normalises its own piece -- one chip-wide drain
 // instead of two, no slab scratch traffic, and the pieces of a group stay on one XCD.
-template <int MODE, int PHASE>
+// SRC = 1 (round 6, PHASE 0 only): the tensor a split-K GEMM / conv produced is still its fp32 partial slabs [splits][B*HW][C] -- the
+// GroupNorm's first pass sums them and applies the GEMM's bf16 epilogue (bias, per-sample row bias, residual: the arithmetic of
+// splitk_finalize_kernel, operation for operation), i.e. the finalize launch between a split-K convolution and the GroupNorm behind it
+// disappears.  MODE 0: the finished tensor is x; the pass also WRITES it (`xout`: backward and residual branches read it) and the
+// second pass reads back what the same thread stored.  MODE 1: the finished tensor is dy (a backward-data convolution's output,
+// no epilogue terms); it is consumed here and never reaches HBM -- both passes sum the slabs.
+struct GnSlabSrc {
+  const float* slabs;
+  int splits;
+  long slab_stride;          // B * HW * C floats
+  const bf16_t* bias;        // [C] or null
+  const bf16_t* rowbias;     // [B][rowbias_ld] or null
+  long rowbias_ld;
+  const bf16_t* residual;    // [B][HW][C] or null
+  bf16_t* xout;              // MODE 0: the finished tensor [B][HW][C]
+};
+
+template <int MODE, int PHASE, int SRC = 0>
 __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                                const bf16_t* __restrict__ gamma,
                                                                const bf16_t* __restrict__ beta, float* __restrict__ stats,
                                                                int HW, int C, float eps, int silu,
                                                                const bf16_t* __restrict__ dres, bf16_t* __restrict__ out,
-                                                               int nsplit, float* __restrict__ part) {
+                                                               int nsplit, float* __restrict__ part, const GnSlabSrc ss) {
+  static_assert(SRC == 0 || PHASE == 0, "the slab source exists for the one-launch form only");
   __shared__ float red[2][GNF_THREADS / 64];
   __shared__ float bc[2];
   const int bid = blockIdx.x;
@@ -463,17 +481,95 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const bf16_t* __r
     }
     return d * ga;
   };
+  // SRC = 1: the channel pair of GNF_U pixels out of the split-K slabs, finished as splitk_finalize_kernel finishes it (fp32 sum over
+  // the splits in order, + bias in fp32, ONE rounding to bf16, then the row bias and the residual as bf16 adds)
+  // Memory-level parallelism: a thread owns only ~5-10 channel pairs of its (sample, group), each the sum of up to 16 slabs -- the pass
+  // is pure latency unless many loads fly at once.  Per step: the SAME GNF_ZC splits of GNF_U / 2 pixels (16 eight-byte loads in flight),
+  // splits past the end clamped to the last one and masked out of the sum; sums are taken in split order, as the finalize kernel takes them.
+  constexpr int GNF_ZC = 4, GNF_US = GNF_U / 2;
+  auto from_slabs = [&](int p, int p_end, uint32_t (&w)[GNF_U]) {
+    uint32_t rbw = 0u;
+    float bi0 = 0.f, bi1 = 0.f;
+    if (MODE == 0) {
+      if (ss.bias != nullptr) {
+        const uint32_t t = *reinterpret_cast<const uint32_t*>(ss.bias + ch);
+        bi0 = bf16lo(t), bi1 = bf16hi(t);
+      }
+      if (ss.rowbias != nullptr) rbw = *reinterpret_cast<const uint32_t*>(ss.rowbias + (long)b * ss.rowbias_ld + ch);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {        // two halves of the GNF_U pixels
+      if (p + h * GNF_US * pstep >= p_end) {   // (thread-uniform over u: nothing of this half is live)
+#pragma unroll
+        for (int u = 0; u < GNF_US; ++u) w[h * GNF_US + u] = 0u;
+        continue;
+      }
+      float2 acc[GNF_US];
+      long po[GNF_US];
+#pragma unroll
+      for (int u = 0; u < GNF_US; ++u) {
+        acc[u] = make_float2(0.f, 0.f);
+        po[u] = base + (long)min(p + (h * GNF_US + u) * pstep, p_end - 1) * C;
+      }
+      uint32_t rsw[GNF_US];
+      if (MODE == 0 && ss.residual != nullptr) {
+#pragma unroll
+        for (int u = 0; u < GNF_US; ++u) rsw[u] = *reinterpret_cast<const uint32_t*>(ss.residual + po[u]);
+      }
+      for (int z0 = 0; z0 < ss.splits; z0 += GNF_ZC) {
+        float2 t[GNF_ZC][GNF_US];
+#pragma unroll
+        for (int zc = 0; zc < GNF_ZC; ++zc) {
+          const float* sl = ss.slabs + (long)min(z0 + zc, ss.splits - 1) * ss.slab_stride;
+#pragma unroll
+          for (int u = 0; u < GNF_US; ++u) t[zc][u] = *reinterpret_cast<const float2*>(sl + po[u]);
+        }
+#pragma unroll
+        for (int zc = 0; zc < GNF_ZC; ++zc) {
+          if (z0 + zc < ss.splits) {
+#pragma unroll
+            for (int u = 0; u < GNF_US; ++u) acc[u].x += t[zc][u].x, acc[u].y += t[zc][u].y;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < GNF_US; ++u) {
+        uint32_t v = pack_bf16x2(acc[u].x + bi0, acc[u].y + bi1);
+        if (MODE == 0 && ss.rowbias != nullptr) v = pack_bf16x2(bf16lo(v) + bf16lo(rbw), bf16hi(v) + bf16hi(rbw));
+        if (MODE == 0 && ss.residual != nullptr) v = pack_bf16x2(bf16lo(v) + bf16lo(rsw[u]), bf16hi(v) + bf16hi(rsw[u]));
+        w[h * GNF_US + u] = v;
+      }
+    }
+  };
   // ---- pass 1.  GNF_U pixels per thread are loaded before any is used: a thread has only HW*D/1020 (~20) dwords to
   // fetch per pass, so the pass is latency-bound unless they are all in flight
   float s1 = 0.f, s2 = 0.f;
+  // SRC = 1: when a thread's whole share is ONE step of GNF_U pixels (maps up to ~16 x 16 at 1280 channels, 32 x 32 at 320), the finished
+  // values stay in registers for the second pass -- no second sum over the slabs, no read-back of the tensor just written
+  const bool single = SRC == 1 && (p_hi - p_lo) <= pstep * GNF_U;
+  uint32_t keep_x[GNF_U], keep_d[GNF_U];
   if (live && PHASE != 2) {
     for (int p = p_lo + p0; p < p_hi; p += pstep * GNF_U) {
       uint32_t xw[GNF_U], dwv[GNF_U];
+      if (SRC == 1 && MODE == 0) {
+        from_slabs(p, p_hi, xw);
+#pragma unroll
+        for (int u = 0; u < GNF_U; ++u)
+          if (p + u * pstep < p_hi) *reinterpret_cast<uint32_t*>(ss.xout + base + (long)(p + u * pstep) * C) = xw[u];
+      }
+      if (SRC == 1 && MODE == 1) from_slabs(p, p_hi, dwv);
 #pragma unroll
       for (int u = 0; u < GNF_U; ++u) {
         const int pp = min(p + u * pstep, p_hi - 1);
-        xw[u] = *reinterpret_cast<const uint32_t*>(x + base + (long)pp * C);
-        if (MODE == 1) dwv[u] = *reinterpret_cast<const uint32_t*>(dy + base + (long)pp * C);
+        if (!(SRC == 1 && MODE == 0)) xw[u] = *reinterpret_cast<const uint32_t*>(x + base + (long)pp * C);
+        if (MODE == 1 && SRC == 0) dwv[u] = *reinterpret_cast<const uint32_t*>(dy + base + (long)pp * C);
+      }
+      if (SRC == 1) {
+#pragma unroll
+        for (int u = 0; u < GNF_U; ++u) {
+          keep_x[u] = xw[u];
+          if (MODE == 1) keep_d[u] = dwv[u];
+        }
       }
 #pragma unroll
       for (int u = 0; u < GNF_U; ++u) {
@@ -531,12 +627,20 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const bf16_t* __r
   if (!live) return;
   for (int p = p_lo + p0; p < p_hi; p += pstep * GNF_U) {
     uint32_t xw[GNF_U], dwv[GNF_U], rw[GNF_U];
+    if (SRC == 1 && MODE == 1 && !single) from_slabs(p, p_hi, dwv);
+    // (SRC = 1, MODE 0: x == ss.xout, written by THIS thread in pass 1 -- same pixel / channel-pair mapping in both passes)
+    const bf16_t* xs = (SRC == 1 && MODE == 0) ? ss.xout : x;
 #pragma unroll
     for (int u = 0; u < GNF_U; ++u) {
       const long o = base + (long)min(p + u * pstep, p_hi - 1) * C;
-      xw[u] = *reinterpret_cast<const uint32_t*>(x + o);
+      if (SRC == 1 && single) {
+        xw[u] = keep_x[u];
+        if (MODE == 1) dwv[u] = keep_d[u];
+      } else {
+        xw[u] = *reinterpret_cast<const uint32_t*>(xs + o);
+      }
       if (MODE == 1) {
-        dwv[u] = *reinterpret_cast<const uint32_t*>(dy + o);
+        if (SRC == 0) dwv[u] = *reinterpret_cast<const uint32_t*>(dy + o);
         rw[u] = dres != nullptr ? *reinterpret_cast<const uint32_t*>(dres + o) : 0u;
       }
     }
@@ -795,7 +899,7 @@ extern "C" int aql_groupnorm_silu_fwd(const bf16_t* x, int B, int HW, int C, con
   AQL_CHECK_ARG(C % (8 * 1) == 0 && C % G == 0 && C / 8 <= 1024, "aql_groupnorm_silu_fwd: bad C=%d", C);
   if (gn_use_fused(C, HW)) {
     hipLaunchKernelGGL((gn_fused_kernel<0, 0>), dim3(B * G), dim3(GNF_THREADS), 0, stream, x, nullptr, gamma, beta, stats, HW,
-                       C, eps, silu, nullptr, y, 1, nullptr);
+                       C, eps, silu, nullptr, y, 1, nullptr, GnSlabSrc{});
     AQL_CHECK_LAUNCH("aql_groupnorm_silu_fwd");
     return AQL_OK;
   }
@@ -814,13 +918,13 @@ extern "C" int aql_groupnorm_silu_fwd(const bf16_t* x, int B, int HW, int C, con
   }
   if (const int ns = gn_split(C, HW)) {
     hipLaunchKernelGGL((gn_fused_kernel<0, 1>), dim3(B * G * ns), dim3(GNF_THREADS), 0, stream, x, nullptr, gamma, beta, stats,
-                       HW, C, eps, silu, nullptr, y, ns, scratch);
+                       HW, C, eps, silu, nullptr, y, ns, scratch, GnSlabSrc{});
     if (a2_ok)   // coalesced second pass that sums the piece statistics itself
       hipLaunchKernelGGL(gn_apply2_kernel<0>, dim3(nslab, B), dim3(threads), 0, stream, x, nullptr, gamma, beta, nullptr, nullptr,
                          scratch, ns, 0, 1.f / ((float)HW * (C / G)), eps, stats, HW, C, rps, silu, nullptr, y);
     else
       hipLaunchKernelGGL((gn_fused_kernel<0, 2>), dim3(B * G * ns), dim3(GNF_THREADS), 0, stream, x, nullptr, gamma, beta, stats,
-                         HW, C, eps, silu, nullptr, y, ns, scratch);
+                         HW, C, eps, silu, nullptr, y, ns, scratch, GnSlabSrc{});
     AQL_CHECK_LAUNCH("aql_groupnorm_silu_fwd");
     return AQL_OK;
   }
@@ -850,7 +954,7 @@ extern "C" int aql_groupnorm_silu_bwd(const bf16_t* x, const bf16_t* dy, int B, 
   AQL_CHECK_ARG(C % 8 == 0 && C % G == 0 && C / 8 <= 1024, "aql_groupnorm_silu_bwd: bad C=%d", C);
   if (gn_use_fused(C, HW, true)) {
     hipLaunchKernelGGL((gn_fused_kernel<1, 0>), dim3(B * G), dim3(GNF_THREADS), 0, stream, x, dy, gamma, beta,
-                       const_cast<float*>(stats), HW, C, 0.f, silu, dres, dx, 1, nullptr);
+                       const_cast<float*>(stats), HW, C, 0.f, silu, dres, dx, 1, nullptr, GnSlabSrc{});
     AQL_CHECK_LAUNCH("aql_groupnorm_silu_bwd");
     return AQL_OK;
   }
@@ -876,7 +980,7 @@ extern "C" int aql_groupnorm_silu_bwd(const bf16_t* x, const bf16_t* dy, int B, 
   }
   if (const int ns = ns_b) {
     hipLaunchKernelGGL((gn_fused_kernel<1, 1>), dim3(B * G * ns), dim3(GNF_THREADS), 0, stream, x, dy, gamma, beta,
-                       const_cast<float*>(stats), HW, C, 0.f, silu, nullptr, dx, ns, scratch);
+                       const_cast<float*>(stats), HW, C, 0.f, silu, nullptr, dx, ns, scratch, GnSlabSrc{});
     hipLaunchKernelGGL(gn_apply2_kernel<1>, dim3(nslab, B), dim3(threads), 0, stream, x, dy, gamma, beta, stats, nullptr, scratch, ns, 0,
                        1.f / ((float)HW * (C / G)), 0.f, nullptr, HW, C, rps, silu, dres, dx);
     AQL_CHECK_LAUNCH("aql_groupnorm_silu_bwd");
@@ -900,6 +1004,39 @@ extern "C" int aql_groupnorm_silu_bwd(const bf16_t* x, const bf16_t* dy, int B, 
   hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(blocks, B), dim3(256), 0, stream, x, dy, gamma, beta, stats, dstats, HW, C,
                      silu, dres, dx);
   AQL_CHECK_LAUNCH("aql_groupnorm_silu_bwd");
+  return AQL_OK;
+}
+
+// GroupNorm(+SiLU) straight behind a split-K convolution / GEMM whose finalize launch was held back (aql_conv3x3_fwd_defer,
+// aql_conv3x3_bwd_data_defer; round 6): the GroupNorm's first pass sums the fp32 partial slabs [splits][B*HW][C] and applies the
+// GEMM's epilogue itself.  Same results as aql_splitk_finalize + aql_groupnorm_silu_fwd / _bwd, bit for bit; one launch instead of two.
+// Returns AQL_NOT_FUSED (100) for maps the one-launch GroupNorm does not take (the caller then runs aql_splitk_finalize and the
+// plain entry point).  Forward: xout receives the finished conv output (saved for backward, read by residual branches).
+extern "C" int aql_groupnorm_silu_fwd_slabs(const float* slabs, int splits, const bf16_t* bias, const bf16_t* rowbias, long rowbias_ld,
+                                            const bf16_t* residual, bf16_t* xout, int B, int HW, int C, const bf16_t* gamma,
+                                            const bf16_t* beta, float eps, int silu, bf16_t* y, float* stats, hipStream_t stream) {
+  AQL_CHECK_ARG(slabs && xout && gamma && beta && y && stats && splits >= 1 && splits <= 64, "aql_groupnorm_silu_fwd_slabs: null operand / bad split count");
+  AQL_CHECK_ARG(C % 8 == 0 && C % G == 0 && C / 8 <= 1024 && (C / G) % 2 == 0, "aql_groupnorm_silu_fwd_slabs: bad C=%d", C);
+  AQL_CHECK_ARG(rowbias == nullptr || rowbias_ld >= C, "aql_groupnorm_silu_fwd_slabs: row-bias leading dimension");
+  if (!gn_use_fused(C, HW)) return 100;
+  GnSlabSrc ss{slabs, splits, (long)B * HW * C, bias, rowbias, rowbias_ld, residual, xout};
+  hipLaunchKernelGGL((gn_fused_kernel<0, 0, 1>), dim3(B * G), dim3(GNF_THREADS), 0, stream, nullptr, nullptr, gamma, beta, stats, HW,
+                     C, eps, silu, nullptr, y, 1, nullptr, ss);
+  AQL_CHECK_LAUNCH("aql_groupnorm_silu_fwd_slabs");
+  return AQL_OK;
+}
+
+// Backward: dy = the sum of the slabs (rounded to bf16 as the finalize launch would have stored it) is consumed in place.
+extern "C" int aql_groupnorm_silu_bwd_slabs(const bf16_t* x, const float* slabs, int splits, int B, int HW, int C, const bf16_t* gamma,
+                                            const bf16_t* beta, int silu, const float* stats, const bf16_t* dres, bf16_t* dx,
+                                            hipStream_t stream) {
+  AQL_CHECK_ARG(x && slabs && gamma && beta && dx && stats && splits >= 1 && splits <= 64, "aql_groupnorm_silu_bwd_slabs: null operand / bad split count");
+  AQL_CHECK_ARG(C % 8 == 0 && C % G == 0 && C / 8 <= 1024 && (C / G) % 2 == 0, "aql_groupnorm_silu_bwd_slabs: bad C=%d", C);
+  if (!gn_use_fused(C, HW, true)) return 100;
+  GnSlabSrc ss{slabs, splits, (long)B * HW * C, nullptr, nullptr, 0, nullptr, nullptr};
+  hipLaunchKernelGGL((gn_fused_kernel<1, 0, 1>), dim3(B * G), dim3(GNF_THREADS), 0, stream, x, nullptr, gamma, beta,
+                     const_cast<float*>(stats), HW, C, 0.f, silu, dres, dx, 1, nullptr, ss);
+  AQL_CHECK_LAUNCH("aql_groupnorm_silu_bwd_slabs");
   return AQL_OK;
 }
 

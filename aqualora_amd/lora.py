@@ -443,9 +443,24 @@ class LoraBank:
                 dims[m] = (r, lay.down.weight.numel() // r, lay.up.weight.numel() // r)
             a = {m: take(dims[m][0] * dims[m][1]).view(dims[m][0], dims[m][1]) for m in members}     # stacked A [r, K]
             b = {m: take(dims[m][2] * dims[m][0]).view(dims[m][2], dims[m][0]) for m in members}     # stacked Bup [N, r]
-            for m in members:
+            r0, K0, N0 = dims[members[0]]
+            wide_trio = len(members) == 3 and not _is_kv(members[0]) and r0 > 32 and all(dims[m] == (r0, K0, N0) for m in members)
+            if wide_trio:
+                # q | k | v at a rank above 32 (ops.GroupedWideFn): the transposed copies are laid out for the grouped backward too --
+                # A^T of the three sites as COLUMN blocks of one [K, 3r] matrix (the B operand of dX += [dT_q | dT_k | dT_v].[A_q; A_k; A_v]),
+                # Bup^T stacked [3r, N] (the B operand of [dTs_q | dTs_k | dTs_v] = dY_g.Bup_g)
+                atc = take(K0 * 3 * r0).view(K0, 3 * r0)
+                btc = take(3 * r0 * N0).view(3 * r0, N0)
+            wide_kv = len(members) >= 2 and _is_kv(members[0]) and r0 > 32   # the text k | v cohort: Bup^T of all members back to back (k, v of one attention adjacent)
+            bt = {m: take(dims[m][2] * dims[m][0]).view(dims[m][0], dims[m][2]) for m in members} if wide_kv else {}
+            for g_, m in enumerate(members):
                 r, K, N = dims[m]
-                views[m] = (a[m], take(r * K).view(K, r), b[m], take(N * r).view(r, N))
+                if wide_trio:
+                    views[m] = (a[m], atc[:, g_ * r:(g_ + 1) * r], b[m], btc[g_ * r:(g_ + 1) * r])
+                elif wide_kv:
+                    views[m] = (a[m], take(r * K).view(K, r), b[m], bt[m])
+                else:
+                    views[m] = (a[m], take(r * K).view(K, r), b[m], take(N * r).view(r, N))
                 done.add(m)
         for key, layer in zip(keys, self.layers):
             site = LoraSite(layer)
@@ -456,7 +471,8 @@ class LoraBank:
             site.a16, site.at16, site.b16, site.bt16 = views[key]
             for w, rows, cols, o, ot in ((layer.down.weight, r, K, site.a16, site.at16),
                                          (layer.up.weight, N, r, site.b16, site.bt16)):
-                desc[di] = (w.data_ptr(), o.data_ptr(), ot.data_ptr(), rows, cols, tile, 0)
+                # (last field: leading dimension of the transposed copy when it is a column block of a wider matrix, 0 = dense)
+                desc[di] = (w.data_ptr(), o.data_ptr(), ot.data_ptr(), rows, cols, tile, 0 if ot.stride(0) == rows else ot.stride(0))
                 tile += ((rows + 31) // 32) * ((cols + 31) // 32)
                 di += 1
             object.__setattr__(layer, "_aql_site", site)

@@ -27,6 +27,61 @@ def _skey(device):
             torch.cuda.current_stream(device).cuda_stream)
 
 
+# ---- a split-K convolution whose finalize launch was held back for the GroupNorm behind it (aql_conv3x3_*_defer, round 6)
+DEFER_FINALIZE = os.environ.get("AQL_DEFER_FINALIZE", "1") != "0"   # A/B hook: 0 = every split-K launch is followed by its finalize launch
+_PENDING = {}     # (device, stream) -> _Pending: at most one per slab buffer (defer_workspace)
+
+
+class _Pending:
+    """`t` (a dense bf16 [M, N] map, channels-last) is still `splits` fp32 partial slabs in the stream's workspace.  Whoever touches
+    the workspace or reads `t` next either consumes the slabs itself (GroupNormSiluFn forward / backward: the finalize is the first
+    pass of the GroupNorm kernel) or runs the finalize launch first (`flush_pending`): nothing ever reads an unfinished tensor."""
+    __slots__ = ("t", "ws", "splits", "M", "N", "bias", "rowbias", "rowbias_ld", "rps", "residual")
+
+    def finalize(self):
+        L.call("aql_splitk_finalize", L.ptr(self.ws), self.splits, self.M, self.N, L.ptr(self.bias), L.ptr(self.rowbias),
+               int(self.rowbias_ld), int(self.rps), L.ptr(self.residual), self.N, L.ptr(self.t), self.N, L.stream_ptr())
+
+
+def flush_pending(device):
+    p = _PENDING.pop(_skey(device), None)
+    if p is not None:
+        p.finalize()
+
+
+def take_pending(t):
+    """The pending record of tensor `t` (matched by storage: twin views share their buffer's), removed from the table; else None."""
+    key = _skey(t.device)
+    p = _PENDING.get(key)
+    if p is not None and p.t.untyped_storage().data_ptr() == t.untyped_storage().data_ptr():
+        return _PENDING.pop(key)
+    return None
+
+
+_WS_DEFER = {}
+
+
+def defer_workspace(device, nfloats=64 << 20):   # (the size of the shared workspace: the split count is chosen against it)
+    """The slab buffer of the held-back launches, per (device, stream), apart from the shared split-K workspace: launches between a
+    deferred convolution and its GroupNorm (the shortcut GEMM's backward runs between conv2's and norm2's) do not touch it.  Asking
+    for it finishes whatever it still holds."""
+    flush_pending(device)
+    key = _skey(device)
+    ws = _WS_DEFER.get(key)
+    if ws is None or ws.numel() < nfloats:
+        if ws is not None:
+            _WS_RETIRED.append(ws)
+        ws = torch.empty(nfloats, dtype=torch.float32, device=device)
+        _WS_DEFER[key] = ws
+    return ws
+
+
+def flush_all_pending():
+    """End of a pass: nothing may stay unfinished (by construction a GroupNorm follows every deferred launch: this is the net)."""
+    for key in list(_PENDING):
+        _PENDING.pop(key).finalize()
+
+
 def workspace(device, nfloats=64 << 20):
     key = _skey(device)
     ws = _WS.get(key)
@@ -97,6 +152,10 @@ def join_branches():
 def _req(t, name):
     if not t.is_cuda:
         raise L.AqlError(f"{name}: the HIP path needs a GPU tensor (got {t.device}); there is no CPU fallback")
+    if _PENDING:
+        p = take_pending(t)
+        if p is not None:      # an op other than the GroupNorm reads a tensor whose finalize was held back: finish it now
+            p.finalize()
     return t
 
 
@@ -1224,6 +1283,141 @@ def _grouped_backward(dys, x2d, T, Ts, S16, packs, sites, rps, ds_accum, want_dx
     return dx, dS_sum
 
 
+# ------------------------------------------------------------- q | k | v at a LoRA rank above 32 (BASELINE config 3: rank 320)
+GROUPED_WIDE = os.environ.get("AQL_GROUPED_WIDE", "1") != "0"   # A/B hook: 0 = q | k | v (and the text k | v) as two-launch LoRA linears per site
+_DSG = {}    # (id(ds_accum), G) -> [[nb, G r] fp32, dirty]: dS of the grouped sites, one column block per member (fold_ds3 adds them up)
+
+
+def _rep_g(S, S16k, G):
+    """[S16k | ... | S16k] ([nb, G r] bf16): the row scale of G stacked down products.  One small launch per step and G, cached on the
+    scale tensor autograd sees (shared by the 16 blocks)."""
+    c = getattr(S, "_aql_rep", None)
+    if c is None:
+        c = S._aql_rep = {}
+    key = (G, S16k.untyped_storage().data_ptr(), S16k.shape[0])
+    t = c.get(key)
+    if t is None:
+        t = c[key] = S16k.repeat(1, G).contiguous()
+    return t
+
+
+def fold_ds3(ds_accum):
+    """dS += the column blocks of the grouped sites' accumulators (then zero them for the next step).  Called by the trainer after the
+    deferred dS launch, before S.backward(ds_accum)."""
+    nb, r = ds_accum.shape
+    for (i, G), t in _DSG.items():
+        if i == id(ds_accum) and t[1]:
+            ds_accum.add_(t[0].view(nb, G, r).sum(dim=1))
+            t[0].zero_()
+            t[1] = False
+
+
+def grouped_wide_ok(x2d, packs, sites, S16, need_dx=True):
+    """aql_gemm_bf16_grouped serves G = 2 or 3 hosts that read the same rows: one rank r > 32 (a multiple of 320: every tile width
+    divides the column groups), equal hosts without bias whose width is a multiple of 320, bf16 copies laid out by lora.LoraBank
+    (A and Bup stacked, Bup^T stacked; with an input gradient also A^T as column blocks of one [K, G r] matrix)."""
+    G = len(sites)
+    if not GROUPED_WIDE or S16 is None or REF_ROUNDING or G not in (2, 3) or any(s is None for s in sites):
+        return False
+    r, C, K = sites[0].rank, packs[0].N, packs[0].K
+    if r <= 32 or r % 320 or C % 320 or K % 8 or any(s.rank != r for s in sites) or any(p.N != C or p.K != K or p.bias is not None for p in packs):
+        return False
+    if any(wside_ok(p, s_, S16, 256) for p, s_ in zip(packs, sites)):
+        return False
+    if not (adjacent([s.a16 for s in sites]) and adjacent([s.b16 for s in sites]) and adjacent([s.bt16 for s in sites])):
+        return False
+    if not need_dx:
+        return True
+    at = [s.at16 for s in sites]
+    e = at[0].element_size()
+    return all(t.stride(0) == G * r and t.stride(1) == 1 and t.data_ptr() == at[0].data_ptr() + g * r * e for g, t in enumerate(at))
+
+
+class GroupedWideFn(torch.autograd.Function):
+    """G = 3: q | k | v of a self-attention, G = 2: k | v of a text-state attention, with a rank-r watermark LoRA, r > 32
+    (utils/lora_modules.py:9-26, 56-62 on the hosts of scripts/lib/original_unet.py:688-704), as FOUR launches where the per-site path
+    runs 4 G:
+        forward    [T_1 | .. | T_G] = X.[A_1; ..; A_G]^T,  Ts = T * [S | .. | S]                 aql_lora_down, r' = G r
+                   [y_1 | .. | y_G] = X.[W_1; ..; W_G]^T + Ts_g.Bup_g^T                          aql_gemm_bf16_grouped (grp_n = C, A2 offset r)
+        backward   [dTs_1 | .. | dTs_G] = dY_g.Bup_g,  dT = dTs * [S | .. | S]                   aql_gemm_bf16_grouped (grp_n = r, A offset C)
+                   dX = [dY_1 | ..].[W_1 | ..] + [dT_1 | ..].[A_1; ..]   (not for the text states)   aql_gemm_bf16_ex, K = G C and G r
+    Forward outputs, T and Ts have the bits of the per-site launches (same accumulation order per element); dX is ONE fp32
+    accumulation where the per-site path rounds on the way (more accurate, not bit-identical).  [dY_1 | .. | dY_G] is the buffer the
+    attention backward wrote (AttentionFn, pack_grads), read in place.  dS goes to a [nb, G r] accumulator folded once per step
+    (fold_ds3); the 2 G weight gradients are queued on the trainer's grouped launch as strided column views."""
+
+    @staticmethod
+    def forward(ctx, x2d, wcat, wcatT, packs, sites, S, S16, rps):
+        _req(x2d, "grouped wide lora_linear")
+        M, K = x2d.shape
+        G, r, C = len(sites), sites[0].rank, packs[0].N
+        dev = x2d.device
+        xk = _full(x2d)
+        twin = xk is not None
+        if not twin:
+            xk = x2d
+        S16k = _need_full(S16, "the LoRA scale") if twin else S16
+        Mk = xk.shape[0]
+        row0 = M if (twin and _TWIN_SKIP) else 0
+        rep = _rep_g(S, S16k, G)
+        Tk = torch.empty(Mk, G * r, dtype=torch.bfloat16, device=dev)
+        Tsk = torch.empty_like(Tk)
+        lora_down(xk[row0:], xk.stride(0), Mk - row0, K, sites[0].a16, G * r, rep[row0 // rps:], rps, Tk[row0:], Tsk[row0:])
+        yk = torch.empty(Mk, G * C, dtype=torch.bfloat16, device=dev)
+        if twin:
+            DUAL.register(yk)
+        ws = workspace(dev)
+        L.call("aql_gemm_bf16_grouped", L.ptr(xk), xk.stride(0), L.ptr(wcat), wcat.stride(0), Mk, G * C, K, L.ptr(Tsk), G * r,
+               L.ptr(sites[0].b16), r, r, C, 0, r, None, None, 0, L.ptr(yk), G * C, None, 0, None, rps, int(row0), L.ptr(ws),
+               ws.numel() * 4, L.stream_ptr())
+        y = yk[M:] if twin else yk
+        ctx.packs, ctx.sites, ctx.rps, ctx.wcatT = packs, sites, rps, wcatT
+        ctx.ds_accum = getattr(S, "_aql_ds_accum", None)
+        ctx.rep = rep[rep.shape[0] - S16.shape[0]:]      # the scale rows of the rows autograd sees
+        ctx.save_for_backward(x2d, Tk[M:] if twin else Tk, Tsk[M:] if twin else Tsk, S16)
+        return tuple(y[:, g * C:(g + 1) * C] for g in range(G))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x2d, T, Ts, S16 = ctx.saved_tensors
+        sites, packs, rps = ctx.sites, ctx.packs, ctx.rps
+        G, r, C = len(sites), sites[0].rank, packs[0].N
+        M, K = x2d.shape
+        dev = x2d.device
+        d0 = dys[0]
+        if d0 is not None and all(d is not None and d.shape == (M, C) and d.stride() == (G * C, 1) and
+                                  d.untyped_storage().data_ptr() == d0.untyped_storage().data_ptr() and
+                                  d.storage_offset() == d0.storage_offset() + g * C for g, d in enumerate(dys)):
+            dcat = d0.as_strided((M, G * C), (G * C, 1), d0.storage_offset())      # the attention backward's [dY_1 | .. | dY_G], in place
+        else:
+            dcat = torch.cat([torch.zeros(M, C, dtype=torch.bfloat16, device=dev) if d is None else d for d in dys], dim=1)
+        dTs = torch.empty(M, G * r, dtype=torch.bfloat16, device=dev)
+        dT = torch.empty_like(dTs)
+        L.call("aql_gemm_bf16_grouped", L.ptr(dcat), G * C, L.ptr(sites[0].bt16), C, M, G * r, C, None, 0, None, 0, 0, r, C, 0, None,
+               None, 0, L.ptr(dTs), G * r, L.ptr(dT), G * r, L.ptr(ctx.rep), rps, 0, None, 0, L.stream_ptr())
+        dx = None
+        if ctx.needs_input_grad[0]:
+            at0 = sites[0].at16
+            acatT = at0.as_strided((K, G * r), (G * r, 1), at0.storage_offset())
+            dx = gemm_bf16(dcat, ctx.wcatT, None, dT, acatT)
+        acc = ctx.ds_accum
+        nb = S16.shape[0]
+        t = _DSG.get((id(acc), G))
+        if t is None or t[0].shape != (nb, G * r) or t[0].device != dev:
+            t = _DSG[(id(acc), G)] = [torch.zeros(nb, G * r, dtype=torch.float32, device=dev), False]
+        t[1] = True
+        if not DEFERRED.add_ds(dTs, T, t[0], nb, rps, G * r):
+            L.call("aql_lora_ds", L.ptr(dTs), L.ptr(T), nb, rps, G * r, L.ptr(t[0]), L.stream_ptr())
+        for g, site in enumerate(sites):
+            DEFERRED.add_tn(dcat[:, g * C:(g + 1) * C], Ts[:, g * r:(g + 1) * r], site.gb)
+            DEFERRED.add_tn(dT[:, g * r:(g + 1) * r], x2d, site.ga)
+        return dx, None, None, None, None, None, None, None
+
+
+def lora_linear_grouped_wide(x2d, wcat, wcatT, packs, sites, S, S16, rps):
+    return GroupedWideFn.apply(x2d, wcat, wcatT, tuple(packs), tuple(sites), S, S16, rps)
+
+
 def grouped_lora_ok(x2d, packs, sites, S16):
     """The one-launch grouped form applies: rank 32 everywhere, 160-column groups, stacked bf16 copies, fused kernel enabled."""
     if S16 is None or os.environ.get("AQL_LORA_FUSED", "1") == "0" or os.environ.get("AQL_GROUPED", "1") == "0" or REF_ROUNDING:
@@ -1495,7 +1689,10 @@ class Conv3x3Fn(torch.autograd.Function):
     Optional per-sample row bias (the ResNet time-embedding add) and residual fused into the epilogue."""
 
     @staticmethod
-    def forward(ctx, x, packed, upsample, rowbias, residual):
+    def forward(ctx, x, packed, upsample, rowbias, residual, gn_next=False, gn_input=False):
+        """gn_next: the ONLY consumer of the output is a GroupNorm called right after (ResnetBlock2D: conv1 -> norm2): a split-K
+        launch leaves its finalize to that GroupNorm's first pass.  gn_input: the input is a GroupNorm's output read by this
+        convolution only: the backward-data launch leaves ITS finalize to that GroupNorm's backward kernel."""
         _req(x, "conv3x3")
         cpad = x.shape[1] != packed.Cin and is_cpad(x, packed.Cin)
         if not cpad:
@@ -1522,11 +1719,27 @@ class Conv3x3Fn(torch.autograd.Function):
         if twin and rowbias is not None and rowbias.shape[0] != Bk:
             raise L.AqlError("twin batch: the per-sample row bias must cover both halves")
         # maps above 1 GiB (the VAE's 256-channel 512 x 512 level at batch 16: 2.1 GiB) go through the kernel in sample chunks
-        for b0, nb in span_chunks(Bk, max(H * W * packed.Cin, Ho * Wo * packed.Cout) * 2):
-            L.call("aql_conv3x3_fwd", L.ptr(xk[b0:b0 + nb]), nb, H, W, packed.Cin, L.ptr(packed.wk), L.ptr(packed.bias), packed.Cout,
-                   packed.stride, int(upsample), L.ptr(None if rowbias is None else rowbias[b0:]),
-                   0 if rowbias is None else rowbias.stride(0), L.ptr(None if resk is None else resk[b0:b0 + nb]),
-                   L.ptr(yk[b0:b0 + nb]), L.ptr(ws), ws.numel() * 4, L.stream_ptr())
+        chunks = span_chunks(Bk, max(H * W * packed.Cin, Ho * Wo * packed.Cout) * 2)
+        if DEFER_FINALIZE and gn_next and len(chunks) == 1 and packed.Cout_real == packed.Cout:
+            import ctypes
+            ns = ctypes.c_int(1)
+            ws = defer_workspace(x.device)
+            L.call("aql_conv3x3_fwd_defer", L.ptr(xk), Bk, H, W, packed.Cin, L.ptr(packed.wk), L.ptr(packed.bias), packed.Cout,
+                   packed.stride, int(upsample), L.ptr(rowbias), 0 if rowbias is None else rowbias.stride(0), L.ptr(resk),
+                   L.ptr(yk), L.ptr(ws), ws.numel() * 4, ctypes.byref(ns), L.stream_ptr())
+            if ns.value > 1:
+                p = _Pending()
+                p.t, p.ws, p.splits, p.M, p.N = yk, ws, ns.value, Bk * Ho * Wo, packed.Cout
+                p.bias, p.rowbias, p.rowbias_ld = packed.bias, rowbias, (0 if rowbias is None else rowbias.stride(0))
+                p.rps, p.residual = Ho * Wo, resk
+                _PENDING[_skey(x.device)] = p
+        else:
+            for b0, nb in chunks:
+                L.call("aql_conv3x3_fwd", L.ptr(xk[b0:b0 + nb]), nb, H, W, packed.Cin, L.ptr(packed.wk), L.ptr(packed.bias), packed.Cout,
+                       packed.stride, int(upsample), L.ptr(None if rowbias is None else rowbias[b0:]),
+                       0 if rowbias is None else rowbias.stride(0), L.ptr(None if resk is None else resk[b0:b0 + nb]),
+                       L.ptr(yk[b0:b0 + nb]), L.ptr(ws), ws.numel() * 4, L.stream_ptr())
+        ctx.defer_bwd = bool(gn_input)
         ctx.packed, ctx.upsample, ctx.in_shape, ctx.c_in = packed, upsample, (B, H, W), C
         ctx.has_rb, ctx.has_res = rowbias is not None, residual is not None
         if packed.Cout_real != packed.Cout:
@@ -1547,9 +1760,23 @@ class Conv3x3Fn(torch.autograd.Function):
             Hl, Wl = (H * 2, W * 2) if ctx.upsample else (H, W)
             ws = workspace(dy.device)
             du = torch.empty((B, packed.Cin, Hl, Wl), dtype=torch.bfloat16, device=dy.device, memory_format=CL)
-            for b0, nb in span_chunks(B, max(Hl * Wl * packed.Cin, dy.shape[2] * dy.shape[3] * packed.Cout) * 2):
-                L.call("aql_conv3x3_bwd_data", L.ptr(dy[b0:b0 + nb]), nb, Hl, Wl, packed.Cin, L.ptr(packed.wt), packed.Cout,
-                       packed.stride, L.ptr(du[b0:b0 + nb]), L.ptr(ws), ws.numel() * 4, L.stream_ptr())
+            chunks = span_chunks(B, max(Hl * Wl * packed.Cin, dy.shape[2] * dy.shape[3] * packed.Cout) * 2)
+            if DEFER_FINALIZE and ctx.defer_bwd and len(chunks) == 1 and not ctx.upsample and ctx.c_in == packed.Cin:
+                import ctypes
+                ns = ctypes.c_int(1)
+                ws = defer_workspace(dy.device)
+                L.call("aql_conv3x3_bwd_data_defer", L.ptr(dy), B, Hl, Wl, packed.Cin, L.ptr(packed.wt), packed.Cout, packed.stride,
+                       L.ptr(du), L.ptr(ws), ws.numel() * 4, ctypes.byref(ns), L.stream_ptr())
+                if ns.value > 1:   # the GroupNorm backward in front of this convolution sums the slabs (GroupNormSiluFn.backward)
+                    p = _Pending()
+                    p.t, p.ws, p.splits, p.M, p.N = du, ws, ns.value, B * Hl * Wl, packed.Cin
+                    p.bias = p.rowbias = p.residual = None
+                    p.rowbias_ld, p.rps = 0, 1
+                    _PENDING[_skey(dy.device)] = p
+            else:
+                for b0, nb in chunks:
+                    L.call("aql_conv3x3_bwd_data", L.ptr(dy[b0:b0 + nb]), nb, Hl, Wl, packed.Cin, L.ptr(packed.wt), packed.Cout,
+                           packed.stride, L.ptr(du[b0:b0 + nb]), L.ptr(ws), ws.numel() * 4, L.stream_ptr())
             if ctx.upsample:
                 dx = torch.empty((B, packed.Cin, H, W), dtype=torch.bfloat16, device=dy.device, memory_format=CL)
                 L.call("aql_upsample2x_bwd", L.ptr(du), B, H, W, packed.Cin, L.ptr(dx), L.stream_ptr())
@@ -1560,11 +1787,11 @@ class Conv3x3Fn(torch.autograd.Function):
         drb = None
         if ctx.has_rb and ctx.needs_input_grad[3]:
             drb = dy.float().sum(dim=(2, 3)).to(torch.bfloat16)
-        return dx, None, None, drb, (dy if ctx.has_res else None)
+        return dx, None, None, drb, (dy if ctx.has_res else None), None, None
 
 
-def conv3x3(x, packed, upsample=False, rowbias=None, residual=None):
-    return Conv3x3Fn.apply(x, packed, upsample, rowbias, residual)
+def conv3x3(x, packed, upsample=False, rowbias=None, residual=None, gn_next=False, gn_input=False):
+    return Conv3x3Fn.apply(x, packed, upsample, rowbias, residual, gn_next, gn_input)
 
 
 # ------------------------------------------------------------------------------ skip-connection concat
@@ -1632,8 +1859,18 @@ class GroupNormSiluFn(torch.autograd.Function):
         Bk = xk.shape[0]
         yk, y = _alloc((B, C, H, W), x.dtype, x.device, twin, cl=True)
         statsk, stats = _alloc((B, 32, 2), torch.float32, x.device, twin)
-        L.call("aql_groupnorm_silu_fwd", L.ptr(xk), Bk, H * W, C, L.ptr(gamma), L.ptr(beta), float(eps), int(silu),
-               L.ptr(yk), L.ptr(statsk), L.ptr(_gn_scratch(x.device, Bk)), L.stream_ptr())
+        p = take_pending(xk) if _PENDING else None
+        if p is not None:   # xk is still the fp32 slabs of the split-K convolution in front: this launch finishes it too
+            rc = L.call_raw("aql_groupnorm_silu_fwd_slabs", L.ptr(p.ws), p.splits, L.ptr(p.bias), L.ptr(p.rowbias), int(p.rowbias_ld),
+                            L.ptr(p.residual), L.ptr(xk), Bk, H * W, C, L.ptr(gamma), L.ptr(beta), float(eps), int(silu), L.ptr(yk),
+                            L.ptr(statsk), L.stream_ptr())
+            if rc == 100:   # a map the one-launch GroupNorm does not take: the finalize launch after all
+                p.finalize()
+            else:
+                L.check(rc, "aql_groupnorm_silu_fwd_slabs")
+        if p is None or rc == 100:
+            L.call("aql_groupnorm_silu_fwd", L.ptr(xk), Bk, H * W, C, L.ptr(gamma), L.ptr(beta), float(eps), int(silu),
+                   L.ptr(yk), L.ptr(statsk), L.ptr(_gn_scratch(x.device, Bk)), L.stream_ptr())
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.silu = silu
         if passthrough:
@@ -1649,8 +1886,18 @@ class GroupNormSiluFn(torch.autograd.Function):
         dy = as_cl(dy)
         dres = None if dres is None else as_cl(dres)
         dx = torch.empty_like(x, memory_format=CL)
-        L.call("aql_groupnorm_silu_bwd", L.ptr(x), L.ptr(dy), B, H * W, C, L.ptr(gamma), L.ptr(beta), int(ctx.silu),
-               L.ptr(stats), L.ptr(dres), L.ptr(dx), L.ptr(_gn_scratch(x.device, B)), L.stream_ptr())
+        p = take_pending(dy) if _PENDING else None
+        rc = 100
+        if p is not None:   # dy is still the fp32 slabs of the backward-data convolution behind: consumed here, never written
+            rc = L.call_raw("aql_groupnorm_silu_bwd_slabs", L.ptr(x), L.ptr(p.ws), p.splits, B, H * W, C, L.ptr(gamma), L.ptr(beta),
+                            int(ctx.silu), L.ptr(stats), L.ptr(dres), L.ptr(dx), L.stream_ptr())
+            if rc == 100:
+                p.finalize()
+            else:
+                L.check(rc, "aql_groupnorm_silu_bwd_slabs")
+        if rc == 100:
+            L.call("aql_groupnorm_silu_bwd", L.ptr(x), L.ptr(dy), B, H * W, C, L.ptr(gamma), L.ptr(beta), int(ctx.silu),
+                   L.ptr(stats), L.ptr(dres), L.ptr(dx), L.ptr(_gn_scratch(x.device, B)), L.stream_ptr())
         return dx, None, None, None, None, None
 
 
@@ -1737,7 +1984,10 @@ class AttentionFn(torch.autograd.Function):
     """softmax(Q K^T / sqrt(d)) V over heads packed along the channel axis: q [B,Nq,H*d], k/v [B,Nk,H*d]."""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads, q_prescaled=False):
+    def forward(ctx, q, k, v, heads, q_prescaled=False, pack_grads=False):
+        """pack_grads (the projections came from ops.GroupedWideFn): 1 = backward writes dq | dk | dv as the column blocks of ONE
+        [B, N, 3C] buffer, 2 = dk | dv as the column blocks of one [B, Nk, 2C] buffer (aql_sdpa_bwd_ex), which the grouped backward of
+        the projections reads in place."""
         _req(q, "attention")
         B, Nq, C = q.shape
         Nk = k.shape[1]
@@ -1755,6 +2005,7 @@ class AttentionFn(torch.autograd.Function):
                qk.shape[0], heads, Nq, Nk, d, float(d ** -0.5), L.ptr(ok), ok.stride(1), L.ptr(lsek), L.stream_ptr())
         ctx.save_for_backward(q, k, v, o, lse)
         ctx.heads, ctx.qpre = heads, bool(q_prescaled)
+        ctx.pack = int(pack_grads) if (int(pack_grads) == 2 or Nq == Nk) else 0      # 1: [dq | dk | dv], 2: [dk | dv]
         return o
 
     @staticmethod
@@ -1766,21 +2017,34 @@ class AttentionFn(torch.autograd.Function):
         heads = ctx.heads
         d = C // heads
         # dense gradients whatever the strides of q / k / v (they may be column views of a grouped projection's output)
-        dq, dk, dv = (torch.empty(t.shape, dtype=t.dtype, device=t.device) for t in (q, k, v))
         delta = torch.empty(B, heads, Nq, dtype=torch.float32, device=q.device)
-        ws = workspace(q.device)
         ws = workspace(q.device)   # split-Q partials of dK/dV when Nk is short (cross-attention)
+        if ctx.pack:
+            if ctx.pack == 1:
+                dqkv = torch.empty(B, Nq, 3 * C, dtype=q.dtype, device=q.device)
+                dq, dk, dv = dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:]
+                ldgq = ldgkv = 3 * C
+            else:
+                dq = torch.empty(B, Nq, C, dtype=q.dtype, device=q.device)
+                dkv = torch.empty(B, Nk, 2 * C, dtype=q.dtype, device=q.device)
+                dk, dv = dkv[..., :C], dkv[..., C:]
+                ldgq, ldgkv = 0, 2 * C
+            L.call("aql_sdpa_bwd_ex", int(ctx.qpre), L.ptr(q), q.stride(1), L.ptr(k), k.stride(1), L.ptr(v), v.stride(1), L.ptr(o),
+                   L.ptr(do), o.stride(1), L.ptr(lse), L.ptr(delta), B, heads, Nq, Nk, d, float(d ** -0.5),
+                   L.ptr(dq), L.ptr(dk), L.ptr(dv), ldgq, ldgkv, L.ptr(ws), ws.numel() * 4, L.stream_ptr())
+            return dq, dk, dv, None, None, None
+        dq, dk, dv = (torch.empty(t.shape, dtype=t.dtype, device=t.device) for t in (q, k, v))
         L.call("aql_sdpa_bwd_qpre" if ctx.qpre else "aql_sdpa_bwd", L.ptr(q), q.stride(1), L.ptr(k), k.stride(1), L.ptr(v), v.stride(1), L.ptr(o),
                L.ptr(do), o.stride(1), L.ptr(lse), L.ptr(delta), B, heads, Nq, Nk, d, float(d ** -0.5),
                L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(ws), ws.numel() * 4, L.stream_ptr())
-        return dq, dk, dv, None, None
+        return dq, dk, dv, None, None, None
 
 
 QPRE = os.environ.get("AQL_QPRE", "1") != "0"   # A/B hook: 0 = attn1.to_q of the chains unscaled, attention on aql_sdpa_fwd / _bwd
 
 
-def attention(q, k, v, heads, q_prescaled=False):
-    return AttentionFn.apply(q, k, v, heads, q_prescaled)
+def attention(q, k, v, heads, q_prescaled=False, pack_grads=False):
+    return AttentionFn.apply(q, k, v, heads, q_prescaled, pack_grads)
 
 
 # ------------------------------------------------------------------------------------------- loss

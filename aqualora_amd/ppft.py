@@ -223,12 +223,14 @@ class PPFTTrainer:
                     main.wait_stream(st)
         finally:
             ops.DEFERRED = None
+            ops.flush_all_pending()     # (a deferred split-K finalize is always consumed by its GroupNorm: this is the net)
             if self.split:
                 self.unet._aql_bwd_hooks = None
         for tns in preds + cleans + losses:
             tns.record_stream(main)
         if self.split:
             self.deferred.flush_ds()
+            ops.fold_ds3(self.ds_accum)      # (rank > 32: the grouped q | k | v sites accumulate dS per member, ops.GroupedWideFn)
             S.backward(self.ds_accum)
             self._late_exchange()
         else:
@@ -236,6 +238,7 @@ class PPFTTrainer:
                 self.deferred.flush()     # ... and run as two grouped launches here
             else:
                 self.deferred.flush_ds()
+            ops.fold_ds3(self.ds_accum)
             S.backward(self.ds_accum)
         loss = losses[0] if len(losses) == 1 else torch.stack(losses).mean()   # one twin batch: no copy + mean launches
         if len(preds) == 1:   # one twin batch: hand the tensors out as they are (torch.cat of one tensor is a copy launch each)

@@ -113,10 +113,13 @@ class ResnetBlock2D(nn.Module):
             tproj = temb_act[id(self)]   # [B, cout] view with row stride = sum of all couts
         else:
             tproj = self.time_emb_proj(temb_act, scale).contiguous()
-        h = ops.conv3x3(h, _packed_conv3(self.conv1), False, tproj, None)
+        # conv1's only consumer is norm2, called next: a split-K conv1 leaves its finalize launch to norm2's first pass; both
+        # convolutions read a GroupNorm output nobody else reads: their backward-data launches leave theirs to the GroupNorm
+        # backward kernels (ops.Conv3x3Fn, aql_conv3x3_*_defer / aql_groupnorm_silu_*_slabs)
+        h = ops.conv3x3(h, _packed_conv3(self.conv1), False, tproj, None, gn_next=True, gn_input=True)
         h = self.norm2(h, silu=True)
         shortcut = x if self.conv_shortcut is None else self.conv_shortcut(x, scale)
-        return ops.conv3x3(h, _packed_conv3(self.conv2), False, None, shortcut)
+        return ops.conv3x3(h, _packed_conv3(self.conv2), False, None, shortcut, gn_input=True)
 
 
 class Downsample2D(nn.Module):
@@ -166,6 +169,16 @@ class Attention(nn.Module):
             object.__setattr__(self, "_aql_qkv", c)
         return c[3]
 
+    def _fused_weights_t(self):
+        """[Wq^T | Wk^T | Wv^T] ([K, 3C], column blocks): the weight-side operand of dX = [dQ | dK | dV].[Wq | Wk | Wv] in the grouped
+        backward of the self-attention projections (ops.GroupedWideFn).  Rebuilt with the packed copies, like _fused_weights."""
+        pks = tuple(_packed_linear(m) for m in (self.to_q, self.to_k, self.to_v))
+        c = getattr(self, "_aql_qkv_t", None)
+        if c is None or c[0] is not pks[0] or c[1] is not pks[1] or c[2] is not pks[2]:
+            c = pks + (torch.cat([p.wt for p in pks], dim=1).contiguous(),)
+            object.__setattr__(self, "_aql_qkv_t", c)
+        return c[3]
+
     def _forward_nolora(self, x, ctx, residual):
         """The frozen 'clean' pass and inference (scale None, no autograd): q|k|v come from ONE GEMM (two launches fewer per
         self-attention, one fewer per cross-attention); the attention kernels read the packed result through row strides.
@@ -205,17 +218,57 @@ class Attention(nn.Module):
         packs = [_packed_linear(m) for m in mods]
         B, N, C = hidden_states.shape
         x2d = hidden_states.reshape(B * N, C)
-        if any(st.rank != 32 for st in sites) or scale.dim() != 2 or scale.shape[1] != 32:
+        r = sites[0].rank
+        if any(st.rank != r for st in sites) or scale.dim() != 2 or scale.shape[1] != r:
             return None
-        S = _scale16(scale, B, 32, x2d.device)
+        S = _scale16(scale, B, r, x2d.device)
         S16 = getattr(S, "_aql_s16", None)
         if S16 is None:
             S16 = S.detach().to(torch.bfloat16).contiguous()
             S._aql_s16 = S16
-        if not x2d.is_contiguous() or not ops.grouped_lora_ok(x2d, packs, sites, S16):
+        if not x2d.is_contiguous():
+            return None
+        if r > 32:
+            # rank 320 (BASELINE config 3): four launches for the three projections and their backward (ops.GroupedWideFn); training runs
+            # need the trainer's deferred weight-gradient / dS machinery, forward-only runs (sampling through the un-fused LoRA) nothing
+            train = torch.is_grad_enabled()
+            if (train and (ops.DEFERRED is None or getattr(S, "_aql_ds_accum", None) is None)) or not ops.grouped_wide_ok(x2d, packs, sites, S16):
+                return None
+            q, k, v = ops.lora_linear_grouped_wide(x2d, self._fused_weights(False), self._fused_weights_t(), packs, sites, S, S16, N)
+            return q.view(B, N, C), k.view(B, N, C), v.view(B, N, C), 1     # (1: the attention backward packs [dQ | dK | dV])
+        if not ops.grouped_lora_ok(x2d, packs, sites, S16):
             return None
         q, k, v = ops.lora_linear_grouped(x2d, self._fused_weights(False), packs, sites, S, S16, N)
         return q.view(B, N, C), k.view(B, N, C), v.view(B, N, C)
+
+    def _grouped_kv_wide(self, ctx, scale):
+        """k | v of a text-state attention at a LoRA rank above 32 as one grouped pair (ops.GroupedWideFn, G = 2; the text states carry
+        no gradient: three launches forward, one backward, where the two sites run four and two).  -> (k, v) or None."""
+        if not torch.is_tensor(scale) or ctx.dim() != 3 or ctx.dtype != torch.bfloat16 or scale.dim() != 2 or not ctx.is_contiguous():
+            return None
+        mods = (self.to_k, self.to_v)
+        if any(m.lora_layer is None or m.bias is not None or _has_alpha(m) for m in mods):
+            return None
+        from .lora import _scale16, _site_of
+        sites = [_site_of(m.lora_layer) for m in mods]
+        r = sites[0].rank
+        if r <= 32 or scale.shape[1] != r or ctx.requires_grad:
+            return None
+        packs = [_packed_linear(m) for m in mods]
+        B, Nc, Cc = ctx.shape
+        x2d = ctx.reshape(B * Nc, Cc)
+        S = _scale16(scale, B, r, x2d.device)
+        S16 = getattr(S, "_aql_s16", None)
+        if S16 is None:
+            S16 = S.detach().to(torch.bfloat16).contiguous()
+            S._aql_s16 = S16
+        train = torch.is_grad_enabled()
+        if (train and (ops.DEFERRED is None or getattr(S, "_aql_ds_accum", None) is None)) or \
+                not ops.grouped_wide_ok(x2d, packs, sites, S16, need_dx=False):
+            return None
+        k, v = ops.lora_linear_grouped_wide(x2d, self._fused_weights(True), None, packs, sites, S, S16, Nc)
+        C = packs[0].N
+        return k.view(B, Nc, C), v.view(B, Nc, C)
 
     def forward(self, hidden_states, encoder_hidden_states=None, scale=1.0, residual=None):
         if (scale is None and not torch.is_grad_enabled() and hidden_states.dim() == 3
@@ -229,12 +282,17 @@ class Attention(nn.Module):
             if cache is not None and id(self) in cache:
                 k, v = cache[id(self)]
                 qkv = (self.to_q(hidden_states, scale), k, v)
+            else:
+                kv = self._grouped_kv_wide(encoder_hidden_states, scale)
+                if kv is not None:
+                    qkv = (self.to_q(hidden_states, scale), kv[0], kv[1], 2)   # (2: the attention backward packs [dK | dV])
         if qkv is None:
             ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
             qkv = ops.parallel([lambda: self.to_q(hidden_states, scale), lambda: self.to_k(ctx, scale),
                                 lambda: self.to_v(ctx, scale)])
-        q, k, v = qkv
-        o = ops.attention(q, k, v, self.heads)
+        pack = qkv[3] if len(qkv) == 4 else 0      # the grouped wide-rank projections read their output gradients as one buffer
+        q, k, v = qkv[:3]
+        o = ops.attention(q, k, v, self.heads, pack_grads=pack)
         return self.to_out[0](o, scale, residual=residual)
 
 
@@ -382,13 +440,16 @@ class Transformer2DModel(nn.Module):
         if not ops.chain_input_ok(o1, x2d):
             raise ops.L.AqlError("Transformer2DModel chains: the self-attention output lost the twin geometry of its input")
         h1, q2 = ops.lora_chain(o1, h0, S, S16, N, a_stages)
+        pack2 = 0
         if kv is not None:
             k2, v2 = kv[id(a2)]
         elif nolora:
             k2, v2 = a2._text_kv(ctx)
-        else:                                   # (rank 320: no grouped k | v launch in front of the U-Net)
-            k2, v2 = a2.to_k(ctx, scale), a2.to_v(ctx, scale)
-        o2 = ops.attention(q2.view(B, N, C), k2, v2, a2.heads).reshape(B * N, C)
+        else:                                   # (rank 320: no grouped k | v launch in front of the U-Net; the pair of this block as one group)
+            kvw = a2._grouped_kv_wide(ctx, scale)
+            pack2 = 2 if kvw is not None else 0
+            k2, v2 = kvw if kvw is not None else (a2.to_k(ctx, scale), a2.to_v(ctx, scale))
+        o2 = ops.attention(q2.view(B, N, C), k2, v2, a2.heads, pack_grads=pack2).reshape(B * N, C)
         if not ops.chain_input_ok(o2, x2d):
             raise ops.L.AqlError("Transformer2DModel chains: the text-state attention output lost the twin geometry of its input")
         h2, n3 = ops.lora_chain(o2, h1, S, S16, N, c_stages)

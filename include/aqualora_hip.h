@@ -141,8 +141,42 @@ int aql_lora_gemm_fused_kgroups(int ng, const void* const* X, const long* ldx, c
  * k|v projections: dTs = dY.Bup, dT = dTs * S (utils/lora_modules.py:13-17 transposed) for all 32 sites at once.        */
 int aql_lora_down_grouped(int n, const bf16_t* const* X, const bf16_t* const* A, const int* K, long M, const bf16_t* S,
                           int rows_per_sample, bf16_t* T, bf16_t* Ts, aql_stream_t stream);
+/* Round 6: aql_gemm_bf16_ex with COLUMN GROUPS -- output columns [g grp_n, (g + 1) grp_n) read A at a column offset of g grp_a
+ * elements and A2 at g grp_a2; B / B2 rows are the output columns.  Block-diagonal products as one launch: at LoRA rank 320
+ * (BASELINE config 3, train/README.md:34-48) the q | k | v projections of a self-attention (utils/lora_modules.py:9-26, 56-62 on
+ * three hosts that read the same tokens; scripts/lib/original_unet.py:688-704) run
+ *   forward    [T_q | T_k | T_v] = X.[A_q; A_k; A_v]^T, Ts = T * S          (aql_lora_down with r = 3 x 320 and S repeated)
+ *              [q | k | v]       = X.[Wq; Wk; Wv]^T + Ts_g.Bup_g^T          (grp_n = C, grp_a2 = r)
+ *   backward   [dTs_q | dTs_k | dTs_v] = dY_g.Bup_g, dT = dTs * S           (grp_n = r, grp_a = C; second output C2 = C * rowscale)
+ *              dX = [dQ | dK | dV].[Wq | Wk | Wv] + [dT_q | dT_k | dT_v].[A_q; A_k; A_v]     (aql_gemm_bf16_ex, K = 3C and 3r)
+ * four launches where twelve ran.  grp_n: a multiple of 320 that divides N; N % 160 == 0.  C2 (optional) = C * rowscale[m / rps][n]. */
+int aql_gemm_bf16_grouped(const bf16_t* A, long lda, const bf16_t* B, long ldb, long M, int N, int K, const bf16_t* A2, long lda2,
+                          const bf16_t* B2, long ldb2, int K2, int grp_n, int grp_a, int grp_a2, const bf16_t* bias,
+                          const bf16_t* residual, long ldr, bf16_t* C, long ldc, bf16_t* C2, long ldc2, const bf16_t* rowscale,
+                          int rows_per_sample, long lora_row0, float* ws, size_t ws_bytes, aql_stream_t stream);
 int aql_conv3x3_bwd_data(const bf16_t* dY, int B, int Hin, int Win, int Cin, const bf16_t* Wt, int Cout, int stride,
                          bf16_t* dX, float* ws, size_t ws_bytes, aql_stream_t stream);
+/* Round 6: a split-K convolution whose finalize launch is left to the GroupNorm behind it.  ResnetBlock2D runs
+ * norm1 -> conv1 -> norm2 -> conv2 (scripts/lib/original_unet.py:423-453); at the 8x8 / 16x16 / 32x32 levels (and at every level of the
+ * CFG batch-2 sampling forward, evaluation/utils_eval.py:107-126) the 3x3 convolutions split K over workgroups and a 5-6 us launch
+ * summed the fp32 partial slabs.  The _defer entry points skip that launch and report the split count: *splits_out = 1 means the
+ * output is complete; s > 1 means ws holds slabs [s][B*Hout*Wout][Cout] (forward; Y untouched) or [s][B*Hin*Win][Cin] (backward
+ * data; dX untouched), to be finished by aql_groupnorm_silu_fwd_slabs / _bwd_slabs (one launch, bit-identical to finalize +
+ * aql_groupnorm_silu_fwd / _bwd; they return 100 for maps the one-launch GroupNorm does not take) or by aql_splitk_finalize
+ * (C = bf16(sum_z slabs[z] + bias) + rowbias[m / rows_per_sample] + residual, the finalize launch on its own).                   */
+int aql_conv3x3_fwd_defer(const bf16_t* X, int B, int Hin, int Win, int Cin, const bf16_t* Wk, const bf16_t* bias, int Cout,
+                          int stride, int upsample, const bf16_t* rowbias, long rowbias_ld, const bf16_t* residual, bf16_t* Y,
+                          float* ws, size_t ws_bytes, int* splits_out, aql_stream_t stream);
+int aql_conv3x3_bwd_data_defer(const bf16_t* dY, int B, int Hin, int Win, int Cin, const bf16_t* Wt, int Cout, int stride,
+                               bf16_t* dX, float* ws, size_t ws_bytes, int* splits_out, aql_stream_t stream);
+int aql_splitk_finalize(const float* slabs, int splits, long M, int N, const bf16_t* bias, const bf16_t* rowbias, long rowbias_ld,
+                        int rows_per_sample, const bf16_t* residual, long ldr, bf16_t* C, long ldc, aql_stream_t stream);
+int aql_groupnorm_silu_fwd_slabs(const float* slabs, int splits, const bf16_t* bias, const bf16_t* rowbias, long rowbias_ld,
+                                 const bf16_t* residual, bf16_t* xout, int B, int HW, int C, const bf16_t* gamma,
+                                 const bf16_t* beta, float eps, int silu, bf16_t* y, float* stats, aql_stream_t stream);
+int aql_groupnorm_silu_bwd_slabs(const bf16_t* x, const float* slabs, int splits, int B, int HW, int C, const bf16_t* gamma,
+                                 const bf16_t* beta, int silu, const float* stats, const bf16_t* dres, bf16_t* dx,
+                                 aql_stream_t stream);
 
 /* C[P,Q] += alpha * U[M,P]^T.V[M,Q] (fp32, atomics over M splits): LoRA weight gradients d(up), d(down) that
  * autograd derives from lora_modules.py:13-19.                                                                   */
@@ -250,6 +284,12 @@ int aql_sdpa_bwd_qpre(const bf16_t* q, long ldq, const bf16_t* k, long ldk, cons
                       const bf16_t* dout, long ldo, const float* lse, float* delta, int B, int H, int Nq, int Nk, int d,
                       float scale, bf16_t* dq, bf16_t* dk, bf16_t* dv, float* ws, size_t ws_bytes, aql_stream_t stream);
 
+/* Round 6: either backward (qpre = 0 / 1) with the gradients at row strides of ldg_q (dq) / ldg_kv (dk, dv) elements (0 = dense):
+ * dq | dk | dv as column blocks of one [B][N][3 H d] buffer, or dk | dv of a text-state attention as column blocks of one
+ * [B][Nk][2 H d] buffer -- read in place by the grouped backward of the projections (aql_gemm_bf16_grouped).                        */
+int aql_sdpa_bwd_ex(int qpre, const bf16_t* q, long ldq, const bf16_t* k, long ldk, const bf16_t* v, long ldv, const bf16_t* o,
+                    const bf16_t* dout, long ldo, const float* lse, float* delta, int B, int H, int Nq, int Nk, int d, float scale,
+                    bf16_t* dq, bf16_t* dk, bf16_t* dv, long ldg_q, long ldg_kv, float* ws, size_t ws_bytes, aql_stream_t stream);
 /* ws (optional, caller-owned, per stream): fp32 scratch for split-Q partials of dK/dV when Nk is too short to fill the
  * chip (cross-attention, Nk = 77); 2*splits*B*H*Nk*d floats are used, NULL disables the split.                    */
 

@@ -228,6 +228,16 @@ def test_lora_down_skinny_every_k_step_count():
             assert float((dS - ds_ref).abs().max() / ds_ref.abs().max()) < 1e-4, (M, K)
 
 
+def test_splitk_finalize_inside_the_groupnorm_is_bit_identical():
+    """Round 6 (tools/probe_defer.py): split-K 3x3 convolutions whose finalize launch is left to the GroupNorm behind them
+    (aql_conv3x3_fwd_defer / _bwd_data_defer + aql_groupnorm_silu_fwd_slabs / _bwd_slabs) against the launch pairs they replace --
+    conv output, normalised map, statistics, GroupNorm input gradient BIT for bit on the U-Net's 8x8 .. 32x32 maps at batch 1 - 8,
+    with bias / row bias / residual epilogues; ResnetBlock2D forward + backward with the deferral on == off (twin and plain);
+    an unconsumed deferred output is finished by the next user of the slab buffer."""
+    text = _run("probe_defer.py")
+    assert text.count("PASS") >= 40
+
+
 def test_row_resident_chain_kernel_is_bit_identical_to_the_launch_sequence():
     """aql_lora_chain_fwd (csrc/aql_chain.hip) against aql_lora_gemm_fused (+ residual) -> aql_layernorm_fwd -> aql_lora_gemm_fused x n on
     the 64 x 64 level's shapes (twin batch, plain batch, two chip-wide rounds): hs, LayerNorm output, statistics, q / k / v, T / Ts of
@@ -337,6 +347,84 @@ def test_transformer_block_through_chains_equals_the_per_launch_block(rank):
     diff = ((g_a - g_d).abs().max() / g_a.abs().max()).item()
     print(f"pre-scaled q: y l2rel {e_y:.2e}, dx l2rel {e_dx:.2e}, weight gradients max-rel {diff:.2e}")
     assert e_y < 8e-3 and e_dx < 1e-2 and diff < 1.5e-2 and ((ds_a - ds_d).abs().max() / ds_a.abs().max()).item() < 1e-2
+
+
+@pytest.mark.parametrize("C,H", [(640, 32), (1280, 16), (320, 32)])
+def test_rank320_grouped_qkv_equals_the_per_site_launches(C, H):
+    """BASELINE config 3 (rank 320) at the 640- / 1280-channel levels (and a 320-channel map below the chains' tile count): q | k | v of
+    the self-attention through ops.GroupedWideFn -- one stacked down product, one column-grouped GEMM (aql_gemm_bf16_grouped), the
+    attention backward writing [dQ | dK | dV] as one buffer (aql_sdpa_bwd_ex), one grouped backward down product, one K-concatenated
+    dX GEMM -- against the twelve per-site launches (AQL_GROUPED_WIDE=0), on a twin batch through the trainer's deferred weight-gradient
+    machinery: block output BIT-identical; input gradient, the LoRA weight gradients and dS equal up to dX's single fp32 accumulation
+    (the per-site path rounds the partial sums of q, k and v to bf16 on the way)."""
+    from aqualora_amd import ops, synth
+    from aqualora_amd.lora import LoraBank, inject_lora
+    from aqualora_amd.unet import Transformer2DModel
+    torch.manual_seed(0)
+    dev, rank, B = "cuda", 320, 4
+    tm = Transformer2DModel(C, 8, 768, device=dev, dtype=torch.bfloat16)
+    with torch.no_grad():
+        for n_, p_ in tm.named_parameters():
+            if p_.dim() >= 2:
+                p_.copy_(synth.normal(n_, p_.shape, p_[0].numel() ** -0.5, 7, dev).to(p_.dtype))
+            elif n_.endswith("bias"):
+                p_.copy_(synth.normal(n_, p_.shape, 0.05, 7, dev).to(p_.dtype))
+    for p_ in tm.parameters():
+        p_.requires_grad_(False)
+    keys = [n_ for n_, m in tm.named_modules() if hasattr(m, "lora_layer") and (n_.startswith("proj") or "attn" in n_ or "ff" in n_)]
+    inject_lora(tm, rank, keys)
+    with torch.no_grad():
+        for k in keys:
+            lay = tm.get_submodule(k).lora_layer
+            lay.down.weight.copy_(synth.normal(k + ".d", lay.down.weight.shape, 1.0 / rank, 7, dev))
+            lay.up.weight.copy_(synth.normal(k + ".u", lay.up.weight.shape, 0.05, 7, dev))
+    bank = LoraBank(tm, keys=keys)
+    x0 = synth.normal("x", (2 * B, C, H, H), 1.0, 7, dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ctx0 = synth.normal("ctx", (2 * B, 77, 768), 1.0, 7, dev).to(torch.bfloat16)
+    S0 = torch.cat([torch.zeros(B, rank, device=dev), synth.normal("S", (B, rank), 1.0, 7, dev)])
+    dy = synth.normal("dy", (B, C, H, H), 1.0, 7, dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    def run(wide):
+        ops.GROUPED_WIDE = wide
+        bank.zero_grad()
+        ds_accum = torch.zeros(B, rank, dtype=torch.float32, device=dev)
+        ops.DEFERRED = ops.DeferredDW(torch.device(dev, 0))
+        ops.dual_begin()
+        try:
+            x = ops.make_twin(x0[:B], x0[B:]).requires_grad_(True)
+            ctx = ops.make_twin(ctx0[:B], ctx0[B:])
+            S = S0[B:].clone().requires_grad_(True)
+            S16f = S0.to(torch.bfloat16).contiguous()
+            ops.DUAL.register(S16f)
+            S._aql_s16 = S16f[B:]
+            S._aql_ds_accum = ds_accum
+            y = tm(x, ctx, S)
+            yk = ops._full(y).detach().clone()
+            y.backward(dy)
+            ops.DEFERRED.flush()
+            ops.fold_ds3(ds_accum)
+            torch.cuda.synchronize()
+            return yk, x.grad.detach().clone(), bank.grad[:bank.numel].clone(), ds_accum.clone()
+        finally:
+            ops.dual_end()
+            ops.DEFERRED = None
+            ops.GROUPED_WIDE = True
+
+    y_a, dx_a, g_a, ds_a = run(False)
+    y_b, dx_b, g_b, ds_b = run(False)
+    y_c, dx_c, g_c, ds_c = run(True)
+    assert torch.isfinite(y_c.float()).all() and torch.isfinite(g_c).all()
+    assert torch.equal(y_a, y_b) and torch.equal(y_a, y_c)              # forward: bit-identical (both halves of the twin batch)
+    e_dx = ((dx_a.float() - dx_c.float()).norm() / dx_a.float().norm()).item()
+    spread = ((g_a - g_b).abs().max() / g_a.abs().max()).item()
+    diff = ((g_a - g_c).abs().max() / g_a.abs().max()).item()
+    l2 = ((g_a - g_c).norm() / g_a.norm()).item()
+    e_ds = ((ds_a - ds_c).abs().max() / ds_a.abs().max()).item()
+    print(f"C={C}: grouped rank-320 q|k|v vs per-site: dx l2rel {e_dx:.2e}, weight gradients max-rel {diff:.2e} l2rel {l2:.2e} "
+          f"(two per-site runs: {spread:.2e}), dS max-rel {e_ds:.2e}")
+    assert e_dx < 4e-3, e_dx
+    assert g_a.abs().max() > 0 and diff < 1e-2 and l2 < 4e-3, (spread, diff, l2)
+    assert e_ds < 5e-3, e_ds
 
 
 @pytest.mark.parametrize("B,N", [(4, 4096), (1, 2048)])   # 256-row (NOF = 4) and 128-row (NOF = 2) workgroups of attn_fwd_kernel

