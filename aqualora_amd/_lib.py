@@ -82,9 +82,12 @@ SIGNATURES = {
     "aql_cast_transpose_batched": [c_p, c_i, c_i, c_p],
     "aql_tn_desc_fill": [c_p, c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_f, c_p, c_l, c_i],
     "aql_tntr_desc_fill": [c_p, c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_f, c_p, c_l, c_i],
+    "aql_tntr160_desc_fill": [c_p, c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_f, c_p, c_l, c_i],
+    "aql_gemm_tn_tr160_grouped": [c_p, c_i, c_i, c_i, c_i, c_p],
     "aql_gemm_tn_grouped": [c_p, c_i, c_i, c_p],
     "aql_gemm_tn_grouped_range": [c_p, c_i, c_i, c_i, c_i, c_p],
     "aql_ds_desc_fill": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i],
+    "aql_ds_desc_fill_ld": [c_p, c_p, c_l, c_p, c_i, c_i, c_i, c_p, c_i],
     "aql_lora_ds_grouped": [c_p, c_i, c_i, c_p],
     "aql_lora_ds": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     "aql_wside_reduce": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_l, c_p, c_p],

@@ -405,7 +405,7 @@ struct DsGroupDesc {
   const bf16_t* T;
   float* dS;
   int nb, rps, r, slabs;
-  int first_block, pad;
+  int first_block, pad;   // pad: row stride of dTs in elements, 0 = r (dense) -- a column block of a stacked [M, G r] product (round 6)
 };
 __global__ __launch_bounds__(256) void lora_ds_grouped_kernel(const DsGroupDesc* __restrict__ descs, int n) {
   __shared__ float acc[1024];
@@ -425,9 +425,9 @@ __global__ __launch_bounds__(256) void lora_ds_grouped_kernel(const DsGroupDesc*
   float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (rr < rp) {
     for (int m = r0 + rr; m < r1; m += rp) {
-      const long off = ((long)b * d.rps + m) * r + col * 8;
+      const long row = (long)b * d.rps + m, off = row * r + col * 8;
       float x[8], y[8];
-      unpack8(*reinterpret_cast<const uint4*>(d.dTs + off), x);
+      unpack8(*reinterpret_cast<const uint4*>(d.dTs + (d.pad > 0 ? row * d.pad + col * 8 : off)), x);
       unpack8(*reinterpret_cast<const uint4*>(d.T + off), y);
 #pragma unroll
       for (int j = 0; j < 8; ++j) a[j] += x[j] * y[j];
@@ -673,9 +673,18 @@ extern "C" int aql_lora_ds(const bf16_t* dTs, const bf16_t* T, int nb, int rows_
   AQL_CHECK_LAUNCH("aql_lora_ds");
   return AQL_OK;
 }
+extern "C" int aql_ds_desc_fill_ld(void* host_desc, const bf16_t* dTs, long ld_dts, const bf16_t* T, int nb, int rows_per_sample,
+                                   int r, float* dS, int first_block);
 extern "C" int aql_ds_desc_fill(void* host_desc, const bf16_t* dTs, const bf16_t* T, int nb, int rows_per_sample,
                                 int r, float* dS, int first_block) {
+  return aql_ds_desc_fill_ld(host_desc, dTs, 0, T, nb, rows_per_sample, r, dS, first_block);
+}
+// ... with dTs at a row stride of ld_dts elements (0 = dense): a column block of the stacked backward down product of a grouped
+// q | k | v (aql_gemm_bf16_grouped)
+extern "C" int aql_ds_desc_fill_ld(void* host_desc, const bf16_t* dTs, long ld_dts, const bf16_t* T, int nb, int rows_per_sample,
+                                   int r, float* dS, int first_block) {
   if (!host_desc || !dTs || !T || !dS || r % 8 || r > 1024 || r / 8 > 256) return 0;
+  if (ld_dts < 0 || ld_dts % 8 || ld_dts > 0x7fffffffL || (ld_dts > 0 && ld_dts < r)) return 0;
   DsGroupDesc d;
   d.dTs = dTs;
   d.T = T;
@@ -687,7 +696,7 @@ extern "C" int aql_ds_desc_fill(void* host_desc, const bf16_t* dTs, const bf16_t
   if (slabs > 32) slabs = 32;
   d.slabs = slabs;
   d.first_block = first_block;
-  d.pad = 0;
+  d.pad = (ld_dts == r) ? 0 : (int)ld_dts;
   memcpy(host_desc, &d, sizeof(d));
   return slabs * nb;
 }

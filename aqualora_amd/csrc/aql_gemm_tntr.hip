@@ -22,16 +22,23 @@ constexpr int BT = 128;     // tile width, both sides
 constexpr int PITCH = 256;  // bytes per LDS row
 
 // conflict-free for the 8-row x 32-byte transpose gathers (same image as aql_attn.hip's row tiles)
-__device__ __forceinline__ int tile_off(int row, int chunk) { return row * PITCH + ((chunk ^ ((row & 7) << 1)) << 4); }
+template <int PB>
+__device__ __forceinline__ int tile_off_p(int row, int chunk) { return row * PB + ((chunk ^ ((row & 7) << 1)) << 4); }
+__device__ __forceinline__ int tile_off(int row, int chunk) { return tile_off_p<PITCH>(row, chunk); }
+// 160-column tiles (round 6): 20 live chunks per row; the XOR moves a chunk by up to 14 places, so the row is 32 chunks (512 bytes)
+// long -- the same bank picture as the 256-byte rows (a row starts on bank 0 either way)
+constexpr int PITCH160 = 512;
+template <int W>
+struct PitchOf { static constexpr int value = W == 160 ? PITCH160 : PITCH; };
 
 __device__ __forceinline__ uint4 mask4(const uint4& v, bool ok) {
   const uint32_t m = 0u - (uint32_t)ok;
   return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
 }
 
-template <int W>  // tile width in columns: 128 (16 chunks per row, 4 slots per thread) or 32 (4 chunks, 1 slot)
+template <int W>  // tile width in columns: 128 (16 chunks per row, 4 slots per thread), 160 (20 chunks, 5 slots) or 32 (4 chunks, 1 slot)
 struct TileStager {
-  static constexpr int CPRW = W / 8, SLOTS = TK * CPRW / 256;
+  static constexpr int CPRW = W / 8, SLOTS = TK * CPRW / 256, PB = PitchOf<W>::value;
   long p[SLOTS];   // element offset from g of the slot in the CURRENT tile
   uint4 v[SLOTS];
   int off[SLOTS];  // LDS byte offset, -1: column past the operand's width (zeroed once)
@@ -46,9 +53,9 @@ struct TileStager {
       const int id = tid + it * 256;
       const int row = id / CPRW, c = id - row * CPRW;
       const bool live = col0 + c * 8 < width;
-      off[it] = live ? tile_off(row, c) : -1;
+      off[it] = live ? tile_off_p<PB>(row, c) : -1;
       p[it] = live ? (m0 + row) * ld + col0 + c * 8 : 0;
-      if (!live) *reinterpret_cast<uint4*>(lds + tile_off(row, c)) = make_uint4(0u, 0u, 0u, 0u);
+      if (!live) *reinterpret_cast<uint4*>(lds + tile_off_p<PB>(row, c)) = make_uint4(0u, 0u, 0u, 0u);
     }
   }
   // full tile: unconditional loads; tail tile (rows past M must read as ZERO: they enter the sum): clamped + masked
@@ -80,12 +87,13 @@ struct TileStager {
 typedef short v4s_t __attribute__((ext_vector_type(4)));
 
 // 16 columns [col0, col0+16) of the row-major tile, tokens 32*s2 .. 32*s2+31, as an MFMA operand (see header)
+template <int PB = PITCH>
 __device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int s2, int col0, int lane) {
   const int p = lane & 15, g = lane >> 4;
   const int row = s2 * 32 + g * 4 + (p >> 2);  // rows row and row+16 share (row & 7): same swizzle
-  const char* base = tile + tile_off(row, (col0 >> 3) + ((p & 3) >> 1)) + (p & 1) * 8;
+  const char* base = tile + tile_off_p<PB>(row, (col0 >> 3) + ((p & 3) >> 1)) + (p & 1) * 8;
   const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3)))*)(base));
-  const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3)))*)(base + 16 * PITCH));
+  const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3)))*)(base + 16 * PB));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
@@ -101,10 +109,13 @@ struct TnArgs {
   int trans;   // 1: the result is written transposed, element (p, q) -> C[q * ldc + p]
 };
 
+// accumulator fragments per wavefront: 64 x 64 (tile 128 x 128), 64 x 80 (128 x 160) or 32 x 32 (128 x 32)
+template <int BQ> struct FragsOf { static constexpr int FM = BQ == 32 ? 2 : 4, FN = BQ == 128 ? 4 : (BQ == 160 ? 5 : 2); };
+
 template <int BQ, bool TRANS>
-__device__ __forceinline__ void tn_tr_store(const TnArgs& a, const f32x4_t (&acc)[BQ == 128 ? 4 : 2][BQ == 128 ? 4 : 2], int p0, int q0,
+__device__ __forceinline__ void tn_tr_store(const TnArgs& a, const f32x4_t (&acc)[FragsOf<BQ>::FM][FragsOf<BQ>::FN], int p0, int q0,
                                             int wm0, int wn0, int lane) {
-  constexpr int FM = BQ == 128 ? 4 : 2, FN = BQ == 128 ? 4 : 2;
+  constexpr int FM = FragsOf<BQ>::FM, FN = FragsOf<BQ>::FN;
   if (!TRANS) {
     // acc[i][j][e]: row P = p0 + wm0 + 16 i + 4 (lane>>4) + e, column Q = q0 + wn0 + 16 j + (lane & 15)
 #pragma unroll
@@ -141,11 +152,11 @@ __device__ __forceinline__ void tn_tr_store(const TnArgs& a, const f32x4_t (&acc
 // so that consecutive lanes still hit consecutive addresses of the transposed output.
 template <int BQ, bool TRANS>
 __device__ __forceinline__ void tn_tr_body(const TnArgs& a, const int tile, const int split, char* sU, char* sV) {
-  constexpr int FM = BQ == 128 ? 4 : 2, FN = BQ == 128 ? 4 : 2;
+  constexpr int FM = FragsOf<BQ>::FM, FN = FragsOf<BQ>::FN, PBV = PitchOf<BQ>::value;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tp = tile / a.tiles_q, tq = tile - tp * a.tiles_q;
   const int p0 = tp * BT, q0 = tq * BQ;
-  const int wm0 = BQ == 128 ? (wave >> 1) * 64 : wave * 32, wn0 = BQ == 128 ? (wave & 1) * 64 : 0;
+  const int wm0 = BQ == 32 ? wave * 32 : (wave >> 1) * 64, wn0 = BQ == 32 ? 0 : (wave & 1) * (BQ / 2);
   const long m_lo = (long)split * a.tiles_per_split * TK;
   long m_hi = m_lo + (long)a.tiles_per_split * TK;
   if (m_hi > a.M) m_hi = a.M;
@@ -180,7 +191,7 @@ __device__ __forceinline__ void tn_tr_body(const TnArgs& a, const int tile, cons
 #pragma unroll
       for (int i = 0; i < FM; ++i) fa[i] = tr_frag(sU, s2, wm0 + i * 16, lane);
 #pragma unroll
-      for (int j = 0; j < FN; ++j) fb[j] = tr_frag(sV, s2, wn0 + j * 16, lane);
+      for (int j = 0; j < FN; ++j) fb[j] = tr_frag<PBV>(sV, s2, wn0 + j * 16, lane);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -203,7 +214,7 @@ constexpr int TNTR_NI = 8;                   // DMA instructions per wavefront p
 
 template <int BQ, bool TRANS, int NST>
 __device__ __forceinline__ void tn_tr_body_dma(const TnArgs& a, const int tile, const int split, char* lds) {
-  constexpr int FM = BQ == 128 ? 4 : 2, FN = BQ == 128 ? 4 : 2;
+  constexpr int FM = FragsOf<BQ>::FM, FN = FragsOf<BQ>::FN;
   constexpr int TILE_B = TK * PITCH, STAGE = 2 * TILE_B;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -372,6 +383,27 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_tr_grouped_kernel(const TnTr
   tn_tr_dispatch<NST>(d.a, local % d.n_tiles, local / d.n_tiles, lds);
 }
 
+// Round 6: the 128 x 160 tile for problems with a side of 320 (the LoRA rank of BASELINE config 3: dB [C, 320] = dY^T.Ts and
+// dA [320, K] = dT^T.X; with 128-wide tiles 320 pads to 384 and 17 % of the MFMAs multiply zeros, and the wider operand is fetched once
+// per THREE column tiles instead of two).  The 320 side is always the Q side (a 320 on the P side swaps the operands and writes the
+// result transposed, like the rank <= 32 tiles): 2 x 2 wavefronts of 64 x 80, 20 accumulator fragments, V tile rows of 512 bytes.
+// Its own kernel (two workgroups per CU: 80 accumulator registers + 5 staging slots do not fit the 168 of three per CU) and its own
+// descriptor table (ops.DeferredDW kind "x").
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_tn_tr160_grouped_kernel(const TnTrDesc* __restrict__ descs, int n, int block_base) {
+  __shared__ __attribute__((aligned(16))) char lds[TK * PITCH + TK * PITCH160];
+  const int bid = xcd_contiguous(blockIdx.x, gridDim.x) + block_base;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].first_block <= bid) lo = mid; else hi = mid - 1;
+  }
+  const TnTrDesc d = descs[lo];
+  const int local = bid - d.first_block;
+  if (d.a.trans) tn_tr_body<160, true>(d.a, local % d.n_tiles, local / d.n_tiles, lds, lds + TK * PITCH);
+  else tn_tr_body<160, false>(d.a, local % d.n_tiles, local / d.n_tiles, lds, lds + TK * PITCH);
+}
+
 // body of the launch: AQL_TNTR_NST = 0 (register prefetch, 2 workgroups per CU; the default), 2 (DMA ring of 64 KB, 2 per CU), 3 / 4
 // (96 / 128 KB, 1 per CU).  Measured (profiles/r02_tntr_dma_ring.txt): alone, on rotating operands, the 2-stage ring is 10-16 %
 // faster than the register body (32768 x 2560 x 320: 141 -> 111 us) and one workgroup per CU with a deeper ring much slower
@@ -428,7 +460,56 @@ inline bool tn_tr_fill(TnArgs* a, const bf16_t* U, long ldu, const bf16_t* V, lo
   return true;
 }
 
+// the 128 x 160 form takes C[P,Q] = U^T V when exactly one side is a multiple of 160 that 128 does not divide (320, 960)
+inline bool tn_tr_fill160(TnArgs* a, const bf16_t* U, long ldu, const bf16_t* V, long ldv, long M, int P, int Q, float alpha,
+                          float* C, long ldc, int* n_tiles, int* n_blocks) {
+  if (!U || !V || !C || M <= 0 || P <= 32 || Q <= 32 || P % 8 || Q % 8 || ldu % 8 || ldv % 8) return false;
+  if ((((uintptr_t)U | (uintptr_t)V) & 15) != 0) return false;
+  const bool q160 = Q % 160 == 0 && Q % 128 != 0, p160 = P % 160 == 0 && P % 128 != 0;
+  if (!q160 && !p160) return false;
+  const bool swap = !q160;
+  a->narrow = 2;
+  a->trans = swap ? 1 : 0;
+  a->U = swap ? V : U; a->V = swap ? U : V;
+  a->ldu = swap ? ldv : ldu; a->ldv = swap ? ldu : ldv;
+  a->M = M; a->P = swap ? Q : P; a->Q = swap ? P : Q;
+  a->alpha = alpha; a->C = C; a->ldc = ldc;
+  a->tiles_q = a->Q / 160;
+  const int tiles = aql_cdiv(a->P, BT) * a->tiles_q;
+  const int ktiles = aql_cdiv(M, TK);
+  int splits = tn_tr_splits(tiles, ktiles, true);
+  a->tiles_per_split = aql_cdiv(ktiles, splits);
+  splits = aql_cdiv(ktiles, a->tiles_per_split);
+  *n_tiles = tiles;
+  *n_blocks = tiles * splits;
+  return true;
+}
+
 }  // namespace
+
+// The 128 x 160 tile (round 6): descriptor fill (0 = the problem has no side of 320 / 960: the caller tries aql_tntr_desc_fill) and
+// the grouped launch over a table of such descriptors.
+extern "C" int aql_tntr160_desc_fill(void* host_desc, const bf16_t* U, long ldu, const bf16_t* V, long ldv, long M, int P, int Q,
+                                     float alpha, float* C, long ldc, int first_block) {
+  static const int en = getenv("AQL_TNTR160") ? atoi(getenv("AQL_TNTR160")) : 1;   // A/B hook: 0 = 128 x 128 tiles everywhere
+  if (host_desc == nullptr || !en) return 0;
+  TnTrDesc d;
+  memset(&d, 0, sizeof(d));
+  int n_tiles = 0, n_blocks = 0;
+  if (!tn_tr_fill160(&d.a, U, ldu, V, ldv, M, P, Q, alpha, C, ldc, &n_tiles, &n_blocks)) return 0;
+  d.first_block = first_block;
+  d.n_tiles = n_tiles;
+  memcpy(host_desc, &d, sizeof(d));
+  return n_blocks;
+}
+
+extern "C" int aql_gemm_tn_tr160_grouped(const void* dev_descs, int first, int n, int block_base, int n_blocks, hipStream_t stream) {
+  AQL_CHECK_ARG(dev_descs && first >= 0 && n > 0 && block_base >= 0 && n_blocks > 0, "aql_gemm_tn_tr160_grouped: bad args");
+  const TnTrDesc* dd = static_cast<const TnTrDesc*>(dev_descs) + first;
+  hipLaunchKernelGGL((gemm_tn_tr160_grouped_kernel<2>), dim3(n_blocks), dim3(256), 0, stream, dd, n, block_base);
+  AQL_CHECK_LAUNCH("aql_gemm_tn_tr160_grouped");
+  return AQL_OK;
+}
 
 // host-side descriptor (96 bytes) for the grouped launch; returns the workgroups it needs, 0 if the problem is not
 // eligible (caller launches it on its own)

@@ -1016,7 +1016,7 @@ extern "C" int aql_groupnorm_silu_fwd_slabs(const float* slabs, int splits, cons
                                             const bf16_t* residual, bf16_t* xout, int B, int HW, int C, const bf16_t* gamma,
                                             const bf16_t* beta, float eps, int silu, bf16_t* y, float* stats, hipStream_t stream) {
   AQL_CHECK_ARG(slabs && xout && gamma && beta && y && stats && splits >= 1 && splits <= 64, "aql_groupnorm_silu_fwd_slabs: null operand / bad split count");
-  AQL_CHECK_ARG(C % 8 == 0 && C % G == 0 && C / 8 <= 1024 && (C / G) % 2 == 0, "aql_groupnorm_silu_fwd_slabs: bad C=%d", C);
+  AQL_CHECK_ARG(C % 8 == 0 && C % G == 0 && C / 8 <= 1024, "aql_groupnorm_silu_fwd_slabs: bad C=%d", C);
   AQL_CHECK_ARG(rowbias == nullptr || rowbias_ld >= C, "aql_groupnorm_silu_fwd_slabs: row-bias leading dimension");
   if (!gn_use_fused(C, HW)) return 100;
   GnSlabSrc ss{slabs, splits, (long)B * HW * C, bias, rowbias, rowbias_ld, residual, xout};
@@ -1031,7 +1031,7 @@ extern "C" int aql_groupnorm_silu_bwd_slabs(const bf16_t* x, const float* slabs,
                                             const bf16_t* beta, int silu, const float* stats, const bf16_t* dres, bf16_t* dx,
                                             hipStream_t stream) {
   AQL_CHECK_ARG(x && slabs && gamma && beta && dx && stats && splits >= 1 && splits <= 64, "aql_groupnorm_silu_bwd_slabs: null operand / bad split count");
-  AQL_CHECK_ARG(C % 8 == 0 && C % G == 0 && C / 8 <= 1024 && (C / G) % 2 == 0, "aql_groupnorm_silu_bwd_slabs: bad C=%d", C);
+  AQL_CHECK_ARG(C % 8 == 0 && C % G == 0 && C / 8 <= 1024, "aql_groupnorm_silu_bwd_slabs: bad C=%d", C);
   if (!gn_use_fused(C, HW, true)) return 100;
   GnSlabSrc ss{slabs, splits, (long)B * HW * C, nullptr, nullptr, 0, nullptr, nullptr};
   hipLaunchKernelGGL((gn_fused_kernel<1, 0, 1>), dim3(B * G), dim3(GNF_THREADS), 0, stream, x, nullptr, gamma, beta,

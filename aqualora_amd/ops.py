@@ -28,7 +28,12 @@ def _skey(device):
 
 
 # ---- a split-K convolution whose finalize launch was held back for the GroupNorm behind it (aql_conv3x3_*_defer, round 6)
-DEFER_FINALIZE = os.environ.get("AQL_DEFER_FINALIZE", "1") != "0"   # A/B hook: 0 = every split-K launch is followed by its finalize launch
+# OFF by default (AQL_DEFER_FINALIZE=1 enables it): measured round 6 on MI355X -- config 2 step 21.13 -> 21.45 ms, config 3 46.27 -> 46.45,
+# config 4 264.7 -> 264.3 ms per image (profiles/r06_defer_finalize.txt).  A kernel boundary inside the captured graph costs ~1.5 us
+# (finalize + GroupNorm back to back: 7.3-12 us, GroupNorm alone 4.1-5.6), while the GroupNorm workgroup -- 20-40 channels of every pixel of
+# ONE (sample, group) -- reads the fp32 slabs as 80-160-byte segments at twice the bytes: 8.1-13 us in one launch on 8 x 8 / 16 x 16 maps,
+# 23-58 us against 15-37 on 32 x 32 maps.  The launch count was never the cost.  Kept as an entry point with its bit-identity test.
+DEFER_FINALIZE = os.environ.get("AQL_DEFER_FINALIZE", "0") == "1"
 _PENDING = {}     # (device, stream) -> _Pending: at most one per slab buffer (defer_workspace)
 
 
@@ -459,7 +464,8 @@ class DeferredDW:
 
     # kind -> (descriptor bytes, byte offset of first_block inside the descriptor, fill entry, grouped launch entry)
     KINDS = {"n": (80, 64, "aql_tn_desc_fill", "aql_gemm_tn_grouped_range"),
-             "w": (96, 88, "aql_tntr_desc_fill", "aql_gemm_tn_tr_grouped")}   # TnTrDesc: 88-byte TnArgs, first_block
+             "w": (96, 88, "aql_tntr_desc_fill", "aql_gemm_tn_tr_grouped"),   # TnTrDesc: 88-byte TnArgs, first_block
+             "x": (96, 88, "aql_tntr160_desc_fill", "aql_gemm_tn_tr160_grouped")}   # round 6: 128 x 160 tiles for a side of 320 / 960 (rank 320)
     DS_BYTES = 48
 
     def __init__(self, device, max_sites=1024, defer_wide=True):
@@ -476,8 +482,8 @@ class DeferredDW:
         self.reset()
 
     def reset(self):
-        self.n = {"n": 0, "w": 0}      # descriptors per table
-        self.blk = {"n": 0, "w": 0}    # workgroups per table
+        self.n = {k: 0 for k in self.KINDS}      # descriptors per table
+        self.blk = {k: 0 for k in self.KINDS}    # workgroups per table
         self.n_ds = self.blk_ds = 0
         self.keep = []
         self.items = []    # (C, kind, nblk, direct args or None) in arrival order; kind "d" = launched on its own
@@ -510,7 +516,7 @@ class DeferredDW:
         self._host_tables_free()
         # the transpose-read kernel takes every problem (128x32 tiles for a rank <= 32 side); the register-transposing
         # kernel is the fallback (AQL_TN_OLD=1 prefers it, for comparison)
-        kinds = ("n", "w") if os.environ.get("AQL_TN_OLD") else ("w", "n")
+        kinds = ("n", "w") if os.environ.get("AQL_TN_OLD") else ("x", "w", "n")
         for k in kinds:
             nbytes, _, fill, _ = self.KINDS[k]
             slot = self.host[k].data_ptr() + self.n[k] * nbytes
@@ -529,7 +535,9 @@ class DeferredDW:
     def add_ds(self, dTs, T, dS, nb, rps, r):
         self._host_tables_free()
         slot = self.ds_host.data_ptr() + self.n_ds * self.DS_BYTES
-        nblk = L.call_raw("aql_ds_desc_fill", L.c_p(slot), L.ptr(dTs), L.ptr(T), nb, rps, r, L.ptr(dS), self.blk_ds)
+        if not T.is_contiguous() or dTs.stride(1) != 1:
+            return False
+        nblk = L.call_raw("aql_ds_desc_fill_ld", L.c_p(slot), L.ptr(dTs), dTs.stride(0), L.ptr(T), nb, rps, r, L.ptr(dS), self.blk_ds)
         if nblk <= 0:
             return False
         self.n_ds += 1
@@ -553,14 +561,14 @@ class DeferredDW:
         L.call(entry, L.ptr(self.dev[k]), first, n, base, nblk, L.stream_ptr())
 
     def flush_tn(self):
-        for k in ("n", "w"):
+        for k in self.KINDS:
             if self.n[k]:
                 self._launch(k, 0, self.n[k], 0, self.blk[k])
         for C, k, _, direct in self.items:
             if k == "d":
                 gemm_tn_acc(direct[0], direct[1], C, direct[2])
-        self.n = {"n": 0, "w": 0}
-        self.blk = {"n": 0, "w": 0}
+        self.n = {k: 0 for k in self.KINDS}
+        self.blk = {k: 0 for k in self.KINDS}
         self.items = []
 
     def flush(self):
@@ -568,10 +576,11 @@ class DeferredDW:
         per-sample dY^T X products of the first launch and queue their dA problems) and a second launch over the NEW descriptors
         only.  The descriptor tables are append-only within a step: under graph capture the H2D copy nodes re-read the pinned host
         tables at every replay, so a slot must never be rewritten between the two launches."""
-        mark = {"n": (0, 0), "w": (0, 0), "items": 0}
+        mark = {k: (0, 0) for k in self.KINDS}
+        mark["items"] = 0
 
         def launch_new():
-            for k in ("n", "w"):
+            for k in self.KINDS:
                 first, base = mark[k]
                 if self.n[k] > first:
                     self._launch(k, first, self.n[k] - first, base, self.blk[k] - base)
@@ -604,7 +613,7 @@ class DeferredDW:
             offs.append(o)
             sizes.append(C.numel())
         groups = plan_buckets(offs, sizes, nbuckets)
-        tbl, old, slot_of, pos, blk = {}, {}, {}, {"n": 0, "w": 0}, {"n": 0, "w": 0}
+        tbl, old, slot_of, pos, blk = {}, {}, {}, {k: 0 for k in self.KINDS}, {k: 0 for k in self.KINDS}
         for k, (nbytes, _, _, _) in self.KINDS.items():
             tbl[k] = self.host[k].numpy()[:self.n[k] * nbytes].reshape(self.n[k], nbytes)
             old[k] = tbl[k].copy()
@@ -625,7 +634,7 @@ class DeferredDW:
                 blk[k] += nblk
             self.buckets.append(dict(lo=lo, hi=hi, direct=direct,
                                      ranges={k: (first[k], pos[k] - first[k], base_blk[k], blk[k] - base_blk[k])
-                                             for k in ("n", "w")}))
+                                             for k in self.KINDS}))
         assert pos == self.n and blk == self.blk
         return [(b["lo"], b["hi"]) for b in self.buckets]
 
@@ -1238,11 +1247,17 @@ class GroupedLoraFn(torch.autograd.Function):
         return dx, None, None, None, dS, None, None
 
 
-def _grouped_backward(dys, x2d, T, Ts, S16, packs, sites, rps, ds_accum, want_dx, ret_ds, s_dtype):
+def _grouped_backward(dys, x2d, T, Ts, S16, packs, sites, rps, ds_accum, want_dx, ret_ds, s_dtype, rep=None):
     """Backward of G LoRA linears that share their input x2d (q | k | v): dX = sum_g dX_g, weight gradients queued.  T / Ts are indexable
-    by group.  -> (dX or None, dS or None)."""
+    by group.  ``rep``: the G-fold repeated scale rows (rank > 32, ChainFn.forward made them) -- enables the two-launch grouped form.
+    -> (dX or None, dS or None)."""
     dx, dS_sum = None, None
     G = len(dys)
+    if (rep is not None and G == 3 and ds_accum is not None and DEFERRED is not None and not ret_ds
+            and grouped_wide_ok(x2d, packs, sites, S16, need_dx=want_dx)):
+        dcat = packed_columns(dys, x2d.shape[0], packs[0].N)
+        if dcat is not None:   # [dQ | dK | dV] as the attention backward wrote it (pack_grads): two launches for the three sites
+            return wide_grouped_backward(dcat, x2d, T, Ts, S16, rep, packs, sites, rps, ds_accum, want_dx), None
     if (want_dx and 2 <= G <= 3 and all(dy is not None for dy in dys) and ds_accum is not None
             and DEFERRED is not None and _KGROUPS and all(s_.rank == 32 for s_ in sites)):   # (dS goes to the trainer's accumulator)
         # q | k | v backward-data as ONE launch: dX = sum_g (dY_g.W_g + ((dY_g.Bup_g) * S).A_g), accumulators in registers
@@ -1333,6 +1348,52 @@ def grouped_wide_ok(x2d, packs, sites, S16, need_dx=True):
     return all(t.stride(0) == G * r and t.stride(1) == 1 and t.data_ptr() == at[0].data_ptr() + g * r * e for g, t in enumerate(at))
 
 
+def wcat_t(packs):
+    """[W_1^T | .. | W_G^T] ([K, G C], column blocks) of frozen packed hosts: the weight-side operand of
+    dX = [dY_1 | .. | dY_G].[W_1 | .. | W_G] in the grouped backward.  Built once, cached on the first host's packed copy."""
+    c = getattr(packs[0], "_aql_wcat_t", None)
+    if c is None or len(c[0]) != len(packs) or any(a is not b for a, b in zip(c[0], packs)):
+        c = (tuple(packs), torch.cat([p.wt for p in packs], dim=1).contiguous())
+        packs[0]._aql_wcat_t = c
+    return c[1]
+
+
+def packed_columns(dys, M, C):
+    """dys as the column blocks of ONE [M, G C] buffer (what AttentionFn's pack_grads writes), viewed in place -- or None."""
+    G, d0 = len(dys), dys[0]
+    if d0 is not None and all(d is not None and d.shape == (M, C) and d.stride() == (G * C, 1) and
+                              d.untyped_storage().data_ptr() == d0.untyped_storage().data_ptr() and
+                              d.storage_offset() == d0.storage_offset() + g * C for g, d in enumerate(dys)):
+        return d0.as_strided((M, G * C), (G * C, 1), d0.storage_offset())
+    return None
+
+
+def wide_grouped_backward(dcat, x2d, T, Ts, S16, rep, packs, sites, rps, ds_accum, want_dx):
+    """Backward of G rank-r (r > 32) LoRA linears that read x2d, whose output gradients are the column blocks of dcat [M, G C] and whose
+    saved T / Ts are per-site dense tensors (the q | k | v stages of a row-resident chain, ops.ChainFn): the two launches of
+    GroupedWideFn.backward; dS and the weight gradients are queued per site (dTs / dT as strided column views).  -> dX or None."""
+    G, r, C = len(sites), sites[0].rank, packs[0].N
+    M, K = x2d.shape
+    dev = x2d.device
+    dTs = torch.empty(M, G * r, dtype=torch.bfloat16, device=dev)
+    dT = torch.empty_like(dTs)
+    L.call("aql_gemm_bf16_grouped", L.ptr(dcat), G * C, L.ptr(sites[0].bt16), C, M, G * r, C, None, 0, None, 0, 0, r, C, 0, None,
+           None, 0, L.ptr(dTs), G * r, L.ptr(dT), G * r, L.ptr(rep), rps, 0, None, 0, L.stream_ptr())
+    dx = None
+    if want_dx:
+        at0 = sites[0].at16
+        acatT = at0.as_strided((K, G * r), (G * r, 1), at0.storage_offset())
+        dx = gemm_bf16(dcat, wcat_t(packs), None, dT, acatT)
+    nb = S16.shape[0]
+    for g, site in enumerate(sites):
+        dTs_g, dT_g = dTs[:, g * r:(g + 1) * r], dT[:, g * r:(g + 1) * r]
+        if not DEFERRED.add_ds(dTs_g, T[g], ds_accum, nb, rps, r):
+            L.call("aql_lora_ds", L.ptr(dTs_g.contiguous()), L.ptr(T[g]), nb, rps, r, L.ptr(ds_accum), L.stream_ptr())
+        DEFERRED.add_tn(dcat[:, g * C:(g + 1) * C], Ts[g], site.gb)
+        DEFERRED.add_tn(dT_g, x2d, site.ga)
+    return dx
+
+
 class GroupedWideFn(torch.autograd.Function):
     """G = 3: q | k | v of a self-attention, G = 2: k | v of a text-state attention, with a rank-r watermark LoRA, r > 32
     (utils/lora_modules.py:9-26, 56-62 on the hosts of scripts/lib/original_unet.py:688-704), as FOUR launches where the per-site path
@@ -1384,12 +1445,8 @@ class GroupedWideFn(torch.autograd.Function):
         G, r, C = len(sites), sites[0].rank, packs[0].N
         M, K = x2d.shape
         dev = x2d.device
-        d0 = dys[0]
-        if d0 is not None and all(d is not None and d.shape == (M, C) and d.stride() == (G * C, 1) and
-                                  d.untyped_storage().data_ptr() == d0.untyped_storage().data_ptr() and
-                                  d.storage_offset() == d0.storage_offset() + g * C for g, d in enumerate(dys)):
-            dcat = d0.as_strided((M, G * C), (G * C, 1), d0.storage_offset())      # the attention backward's [dY_1 | .. | dY_G], in place
-        else:
+        dcat = packed_columns(dys, M, C)      # the attention backward's [dY_1 | .. | dY_G], in place
+        if dcat is None:
             dcat = torch.cat([torch.zeros(M, C, dtype=torch.bfloat16, device=dev) if d is None else d for d in dys], dim=1)
         dTs = torch.empty(M, G * r, dtype=torch.bfloat16, device=dev)
         dT = torch.empty_like(dTs)
@@ -1547,6 +1604,11 @@ class ChainFn(torch.autograd.Function):
         ctx.stages, ctx.meta, ctx.rps = stages, meta, rps
         ctx.ds_accum = getattr(S, "_aql_ds_accum", None)
         ctx.s_dtype = S.dtype
+        # rank > 32: the q | k | v stages' backward as two grouped launches (wide_grouped_backward) needs the scale rows three times over
+        ctx.rep3 = None
+        if rank > 32 and GROUPED_WIDE:
+            rp = _rep_g(S, S16k, 3)
+            ctx.rep3 = rp[rp.shape[0] - S16.shape[0]:]
         ctx.save_for_backward(*saved)
         return tuple(outs)
 
@@ -1651,7 +1713,7 @@ class ChainFn(torch.autograd.Function):
                 want_dx = lo_ > 0 or ctx.needs_input_grad[0]
                 dx, dS = _grouped_backward([d_out[k] for k in run], X[lo_], [T[k] for k in run], [Ts[k] for k in run], S16,
                                            [stages[k].packed for k in run], [stages[k].site for k in run], rps, ctx.ds_accum,
-                                           want_dx, ret_ds, ctx.s_dtype)
+                                           want_dx, ret_ds, ctx.s_dtype, rep=ctx.rep3)
                 dR = add(dR, dx)
                 dS_sum = add(dS_sum, dS)
                 g = lo_ - 1

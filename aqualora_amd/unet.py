@@ -172,12 +172,7 @@ class Attention(nn.Module):
     def _fused_weights_t(self):
         """[Wq^T | Wk^T | Wv^T] ([K, 3C], column blocks): the weight-side operand of dX = [dQ | dK | dV].[Wq | Wk | Wv] in the grouped
         backward of the self-attention projections (ops.GroupedWideFn).  Rebuilt with the packed copies, like _fused_weights."""
-        pks = tuple(_packed_linear(m) for m in (self.to_q, self.to_k, self.to_v))
-        c = getattr(self, "_aql_qkv_t", None)
-        if c is None or c[0] is not pks[0] or c[1] is not pks[1] or c[2] is not pks[2]:
-            c = pks + (torch.cat([p.wt for p in pks], dim=1).contiguous(),)
-            object.__setattr__(self, "_aql_qkv_t", c)
-        return c[3]
+        return ops.wcat_t(tuple(_packed_linear(m) for m in (self.to_q, self.to_k, self.to_v)))
 
     def _forward_nolora(self, x, ctx, residual):
         """The frozen 'clean' pass and inference (scale None, no autograd): q|k|v come from ONE GEMM (two launches fewer per
@@ -436,7 +431,9 @@ class Transformer2DModel(nn.Module):
         if not ops.chain_ok(x2d, d_stages + a_stages + c_stages, S16, N):
             return None
         h0, q, k, v = ops.lora_chain(x2d, None, S, S16, N, d_stages)
-        o1 = ops.attention(q.view(B, N, C), k.view(B, N, C), v.view(B, N, C), a1.heads, q_prescaled=qpre).reshape(B * N, C)
+        # (rank > 32: the attention backward writes [dQ | dK | dV] as one buffer for the grouped backward of the three DIRECT stages)
+        pack1 = 1 if (S16 is not None and S16.shape[1] > 32 and ops.GROUPED_WIDE) else 0
+        o1 = ops.attention(q.view(B, N, C), k.view(B, N, C), v.view(B, N, C), a1.heads, q_prescaled=qpre, pack_grads=pack1).reshape(B * N, C)
         if not ops.chain_input_ok(o1, x2d):
             raise ops.L.AqlError("Transformer2DModel chains: the self-attention output lost the twin geometry of its input")
         h1, q2 = ops.lora_chain(o1, h0, S, S16, N, a_stages)

@@ -192,6 +192,13 @@ int aql_gemm_tn_tr_f32(const bf16_t* U, long ldu, const bf16_t* V, long ldv, lon
 int aql_tntr_desc_fill(void* host_desc, const bf16_t* U, long ldu, const bf16_t* V, long ldv, long M, int P, int Q,
                        float alpha, float* C, long ldc, int first_block);
 int aql_gemm_tn_tr_grouped(const void* dev_descs, int first, int n, int block_base, int n_blocks, aql_stream_t stream);
+/* Round 6: the same grouped launch on 128 x 160 tiles, for problems with a side of 320 or 960 -- the rank-320 weight gradients of
+ * BASELINE config 3 (dB [C, 320], dA [320, K]: on 128-wide tiles 320 pads to 384 and every sixth MFMA multiplies zeros).
+ * aql_tntr160_desc_fill returns 0 for a problem without such a side (the caller then tries aql_tntr_desc_fill); descriptors of the two
+ * forms live in separate tables (ops.DeferredDW kinds "x" and "w").                                                              */
+int aql_tntr160_desc_fill(void* host_desc, const bf16_t* U, long ldu, const bf16_t* V, long ldv, long M, int P, int Q, float alpha,
+                          float* C, long ldc, int first_block);
+int aql_gemm_tn_tr160_grouped(const void* dev_descs, int first, int n, int block_base, int n_blocks, aql_stream_t stream);
 
 /* Grouped form: ONE launch for every LoRA weight gradient of a backward pass (all problems have a rank <= 32 side).
  * aql_tn_desc_fill writes an 80-byte descriptor into HOST memory and returns the workgroups it needs (0 = shape not
@@ -354,6 +361,9 @@ int aql_wside_reduce(const bf16_t* P, const bf16_t* S, const bf16_t* Bup, int B,
 /* grouped form (48-byte host descriptors, same protocol as aql_tn_desc_fill)                                         */
 int aql_ds_desc_fill(void* host_desc, const bf16_t* dTs, const bf16_t* T, int nb, int rows_per_sample, int r, float* dS,
                      int first_block);
+/* ... with dTs at a row stride of ld_dts elements (0 = dense): a column block of a stacked [M, G r] product (round 6)          */
+int aql_ds_desc_fill_ld(void* host_desc, const bf16_t* dTs, long ld_dts, const bf16_t* T, int nb, int rows_per_sample, int r,
+                        float* dS, int first_block);
 int aql_lora_ds_grouped(const void* dev_descs, int n, int total_blocks, aql_stream_t stream);
 /* clip_grad_norm_ + torch.optim.AdamW on flat fp32 buffers  train/ppft_train.py:1059-1066, 779-787                 */
 int aql_sumsq_f32(const float* g, long n, float* out, aql_stream_t stream);
