@@ -1335,13 +1335,13 @@ __global__ __launch_bounds__(256, (DH <= 96 ? 2 : 1)) void attn_ctx_dq_kernel(co
 
 // owner blocks per wavefront: enough workgroups for two per CU, at most `nbmax` (the kernel's register budget) blocks
 inline int ctx_blocks(const AttnArgs& a, int nbmax) {
-  static const int force = getenv("AQL_ATTN_CTX_NB") ? atoi(getenv("AQL_ATTN_CTX_NB")) : 0;   // tuning hook
+  static const int force = AQL_TUNE_INT("AQL_ATTN_CTX_NB", 0);   // tuning hook
   const long wgs1 = (long)aql_cdiv(a.Nq, 4 * OWN) * a.H * a.B;
   int nb = force > 0 ? force : (int)(wgs1 / 512);
   return nb < 1 ? 1 : (nb > nbmax ? nbmax : nb);
 }
 inline bool ctx_on(const AttnArgs& a) {
-  static const int en = getenv("AQL_ATTN_CTX") ? atoi(getenv("AQL_ATTN_CTX")) : 1;   // A/B hook: 0 = the streaming kernels
+  static const int en = AQL_TUNE_INT("AQL_ATTN_CTX", 1);   // A/B hook: 0 = the streaming kernels
   return en && a.Nk <= CTX_ROWS;
 }
 
@@ -1354,8 +1354,8 @@ int launch_fwd(const AttnArgs& a0, hipStream_t st) {
     return 0;
   }
   const AttnArgs& a = a0;
-  static const int force = getenv("AQL_ATTN_NOF") ? atoi(getenv("AQL_ATTN_NOF")) : 0;  // tuning hook
-  static const int ones = getenv("AQL_ATTN_ONES") ? atoi(getenv("AQL_ATTN_ONES")) : 1;  // tuning hook
+  static const int force = AQL_TUNE_INT("AQL_ATTN_NOF", 0);  // tuning hook
+  static const int ones = AQL_TUNE_INT("AQL_ATTN_ONES", 1);  // tuning hook
   static const int fold = getenv("AQL_ATTN_FOLD") ? atoi(getenv("AQL_ATTN_FOLD")) : 1;  // A/B hook: 0 = the running-maximum loop, 2 = the shift in the MFMA
   if constexpr (DH <= 96) {
     if (fold && ones && a.d < DV) {   // the denominator rides in the P.V product: the loop needs no row statistics after its first tile

@@ -965,7 +965,7 @@ int chain_launch(Args& a, long M, const char* name, bool bwd, hipStream_t stream
 #endif
   // 128-row tiles while they fill the chip (the twin forward: 256 tiles), 64-row tiles below that (the backward pass runs on the
   // watermarked half only: 16384 rows = 128 tiles of 128 -- half the CUs idle -- or 256 of 64)
-  static const int force = getenv("AQL_CHAIN_BM") ? atoi(getenv("AQL_CHAIN_BM")) : 0;   // tuning hook
+  static const int force = AQL_TUNE_INT("AQL_CHAIN_BM", 0);   // tuning hook
   const bool small = force == 64 || (force == 0 && (M / 128 < 200 || M % 128 != 0 || a.rps % 128 != 0 || a.row0 % 128 != 0 || nout_odd));
   if (wide) hipLaunchKernelGGL(chain_wide_kernel, dim3((unsigned)(M / 64)), dim3(NTH), LayW::TOTAL, stream, a);   // rank 320: 64-row tiles
   else if (bwd) hipLaunchKernelGGL((chain_kernel<1, true>), dim3((unsigned)(M / 64)), dim3(NTH), Lay<1>::TOTAL, stream, a);   // (64-row tiles only)

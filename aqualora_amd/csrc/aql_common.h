@@ -164,3 +164,14 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 static inline int aql_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Tuning hooks whose A/B is settled (tile pickers, GroupNorm forms, conv row tiles, ring depths ...): environment variables only in
+// -DAQL_EXPERIMENTS builds (tools/build_alt.sh <name> <file.hip> -DAQL_EXPERIMENTS, selected with AQL_LIB=altlib/<name>.so); the product
+// library carries the measured optimum as a constant.  Round 6: ~45 runtime toggles -> the handful DESIGN.md
+// section 6 lists.
+#include <stdlib.h>
+#ifdef AQL_EXPERIMENTS
+#define AQL_TUNE_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define AQL_TUNE_INT(name, dflt) (dflt)
+#endif

@@ -306,9 +306,9 @@ inline bool try_conv_row(const GemmArgs<LA, PlainLoader>& g, int bm, hipStream_t
     H = l.Hin, W = l.Win, C = l.Cin;
   }
   if (C % 64 != 0 || g.N % 8 != 0 || g.epi.geglu_F != 0 || g.ktiles1 != 0) return false;
-  static const int slab_ok = getenv("AQL_CONV_ROW_SLAB") ? atoi(getenv("AQL_CONV_ROW_SLAB")) : 1;   // A/B hook
+  static const int slab_ok = AQL_TUNE_INT("AQL_CONV_ROW_SLAB", 1);   // A/B hook
   if ((g.splits != 1) != SLAB || g.splits > 3 * (C / 64) || (SLAB && !slab_ok)) return false;
-  static const int row32x8 = getenv("AQL_CONV_ROW_32X8") ? atoi(getenv("AQL_CONV_ROW_32X8")) : 1;   // A/B hook
+  static const int row32x8 = AQL_TUNE_INT("AQL_CONV_ROW_32X8", 1);   // A/B hook
   RowArgs a;
   a.x = l.base, a.H = H, a.C = C, a.w = g.b0, a.M = g.M, a.N = g.N, a.m_fast = g.m_fast, a.splits = g.splits, a.epi = g.epi;
   const bool n128 = g.N % 128 == 0 && g.N % 160 != 0;    // the VAE's channel counts

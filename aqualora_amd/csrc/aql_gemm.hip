@@ -143,7 +143,7 @@ struct OutSpec {
 
 inline int pick_splits(int tiles, int kt_total, long M, int N, size_t ws_bytes) {
   // split-K pays only when K is deep (the fp32 slabs cost 8 B per output element per split) and the grid is small
-  static const int deep_kt = getenv("AQL_DEEPKT") ? atoi(getenv("AQL_DEEPKT")) : 32;  // tuning hook
+  static const int deep_kt = AQL_TUNE_INT("AQL_DEEPKT", 32);  // tuning hook
   if (tiles >= 224 || kt_total < deep_kt) return 1;
   int s = (320 + tiles - 1) / tiles;
   if (s > kt_total / 8) s = kt_total / 8;
@@ -178,7 +178,7 @@ void launch_cfg(int cfg, int pd, const GemmArgs<LA, LB>& g, hipStream_t stream) 
   if (pd == 13) return launch_gemm_d<BM, BN, WM, WN, LA, LB, EPI, DEEP>(g, stream);              \
   return launch_gemm_d<BM, BN, WM, WN, LA, LB, EPI, 2>(g, stream);
     if constexpr (std::is_same<LA, ConvFwdLoader>::value && EPI == EPI_BF16) {  // ablation probes, never in production
-      static const int abl = env_int("AQL_ABL", 0);
+      static const int abl = AQL_TUNE_INT("AQL_ABL", 0);
       if (abl && cfg == P_64x160) {
         if (abl == 1) return launch_gemm_d<64, 160, 32, 80, LA, LB, EPI, 2, 1>(g, stream);
         if (abl == 2) return launch_gemm_d<64, 160, 32, 80, LA, LB, EPI, 2, 2>(g, stream);
@@ -191,13 +191,13 @@ void launch_cfg(int cfg, int pd, const GemmArgs<LA, LB>& g, hipStream_t stream) 
                   std::is_same<LB, PlainLoader>::value && (EPI == EPI_BF16 || EPI == EPI_SLAB)) {
       // stride-1 convs on 64- / 32-pixel-wide maps: the row-tile form (one A tile per (kh, channel slab) serves the three kw taps),
       // forward and backward-data, on the 256-row tile (one or two whole rounds) and on the 128-row wave-specialised tile
-      static const int conv_row = env_int("AQL_CONV_ROW", 1);                 // A/B hook (0 = off, 1 = all, 2 = only the 256-row tile)
-      static const int conv_row_rounds = env_int("AQL_CONV_ROW_ROUNDS", 2);   // 256-row tile: grids of up to this many whole rounds
+      static const int conv_row = AQL_TUNE_INT("AQL_CONV_ROW", 1);                 // A/B hook (0 = off, 1 = all, 2 = only the 256-row tile)
+      static const int conv_row_rounds = AQL_TUNE_INT("AQL_CONV_ROW_ROUNDS", 2);   // 256-row tile: grids of up to this many whole rounds
       const int t256 = (g.M / 256) * aql_cdiv(g.N, 160);
       const bool r256 = cfg == P_W256x160 || (std::is_same<LA, ConvFwdLoader>::value && g.M % 256 == 0 && t256 % 256 == 0 &&
                                               t256 / 256 <= conv_row_rounds);
       // the VAE's wide maps (128 / 256 pixels per row, 128-multiples of channels): many rounds of 256-pixel row tiles (AQL_CONV_ROW_WIDE=0: off)
-      static const int conv_row_wide = env_int("AQL_CONV_ROW_WIDE", 1);
+      static const int conv_row_wide = AQL_TUNE_INT("AQL_CONV_ROW_WIDE", 1);
       const bool wide = conv_row_wide && g.splits == 1 && g.M % 256 == 0 && (g.a0.Win == 128 || g.a0.Win == 256 || (g.a0.Win == 512 && g.N % 128 == 0 && g.N % 160 != 0)) && g.M / 256 >= 256;
       if (conv_row && (r256 || wide) && aqlconvrow::try_conv_row<LA, EPI>(g, 256, stream)) return;
       if (conv_row == 1 && cfg == P_W128x160 && g.M % 128 == 0 && aqlconvrow::try_conv_row<LA, EPI>(g, 128, stream)) return;
@@ -253,8 +253,8 @@ inline int pick_cfg(long M, int N, int kt_total, bool can_split, int* tiles) {
 // tiles cover the model; the 64x64 / 128x128 / 128x32 tiles take the odd shapes (LoRA rank, tests).  Measured per shape
 // with tools/probe_gemm.py on MI355X.
 inline void pick_tile(long M, int N, int kt_total, bool can_split, int* cfg, int* tiles, int* pd) {
-  static const int force = env_int("AQL_TILE", 0), force_pd = env_int("AQL_PD", 0);  // tuning hooks
-  static const int deep_kt = env_int("AQL_DEEPKT", 32);  // tuning hook
+  static const int force = env_int("AQL_TILE", 0), force_pd = AQL_TUNE_INT("AQL_PD", 0);  // tuning hooks
+  static const int deep_kt = AQL_TUNE_INT("AQL_DEEPKT", 32);  // tuning hook
   const bool deep = can_split && kt_total >= deep_kt;
   if (N % 160 == 0) {
     const int nt = N / 160;
@@ -267,7 +267,7 @@ inline void pick_tile(long M, int N, int kt_total, bool can_split, int* cfg, int
     else *cfg = P_64x64, *tiles = aql_cdiv(M, 64) * aql_cdiv(N, 64);
     // wave-specialised kernels (one 8-wave workgroup per CU): they win when the grid is a whole number of chip-wide
     // rounds and K is long enough to amortise the un-overlapped prologue / epilogue (measured, tools/tune_gemm.py)
-    static const int use_w = env_int("AQL_W", 1);
+    static const int use_w = AQL_TUNE_INT("AQL_W", 1);
     if (use_w && kt_total >= 8) {
       if (t128 >= 240 && t128 <= 768) *cfg = P_W128x160, *tiles = t128;
       else if (deep && t128 < 240 && use_w != 3) *cfg = P_W128x160, *tiles = t128;  // split K up to one chip-wide round
@@ -279,7 +279,7 @@ inline void pick_tile(long M, int N, int kt_total, bool can_split, int* cfg, int
       *tiles = aql_cdiv(M, force == P_128x160 ? 128 : force == P_64x160 ? 64 : 32) * nt;
     }
     // 12-wave workgroups on 256x160 tiles: ONE chip-wide round (AQL_W256=0 disables)
-    static const int use_w256 = env_int("AQL_W256", 1);
+    static const int use_w256 = AQL_TUNE_INT("AQL_W256", 1);
     const int t256 = aql_cdiv(M, 256) * nt;
     // (round 5: also 176-239 tiles under a short K -- q | k | v at the 16 x 16 / 32 x 32 levels, 2048 x 3840 x 1280 and 4096 x 1920 x 640:
     // 192 tiles in ONE round on three quarters of the chip, 34.2 / 22.4 us against 41.5 / 24.8 on one and a half rounds of 128 x 160;
@@ -972,7 +972,7 @@ extern "C" int aql_lora_down_splitk(const bf16_t* X, long ldx, long M, int K, co
   const long rb = (M + 15) / 16;
   int ks = 1;
   if (r == 32 && K % 32 == 0 && part != nullptr && counters != nullptr && rb * sizeof(int) <= counters_bytes) {
-    static const int target = env_int("AQL_DOWN_SPLIT_WGS", 512);   // tuning hook: workgroups aimed at
+    static const int target = AQL_TUNE_INT("AQL_DOWN_SPLIT_WGS", 512);   // tuning hook: workgroups aimed at
     ks = (int)((target + rb - 1) / rb);
     if (ks > K / 256) ks = K / 256;          // at least 256 columns (two K steps per wavefront) per piece
     if (ks > 32) ks = 32;
@@ -1186,7 +1186,9 @@ extern "C" int aql_gemm_tn_f32(const bf16_t* U, long ldu, const bf16_t* V, long 
   if (splits > g.ktiles0 / 4) splits = g.ktiles0 / 4;
   if (splits > 48) splits = 48;
   if (splits < 1) splits = 1;
+#ifdef AQL_EXPERIMENTS
   if (const char* e = getenv("AQL_TN_SPLITS")) splits = atoi(e) < g.ktiles0 ? atoi(e) : g.ktiles0;  // tuning hook
+#endif
   g.splits = splits;
   launch_cfg<TransLoader, TransLoader, EPI_ATOMIC>(cfg, 1, g, stream);
   AQL_CHECK_LAUNCH("aql_gemm_tn_f32");

@@ -855,7 +855,7 @@ inline PlainLoader plain(const bf16_t* p, long ld, long rows, int K) {
 // kernel's time from 640 tiles up, 1.14-1.46x below 320: profiles/r04_t256_geglu.txt).  AQL_LORA_T256=n moves the threshold
 // (0 = never), AQL_LORA_CFG=t256 forces the tile on every shape it can run, any other AQL_LORA_CFG keeps it off.
 static bool t256_wanted(long M, int F, long ld_max, long ldw_max, long ldg) {
-  static const int min_tiles = getenv("AQL_LORA_T256") ? atoi(getenv("AQL_LORA_T256")) : 512;
+  static const int min_tiles = AQL_TUNE_INT("AQL_LORA_T256", 512);
   const char* cfg = getenv("AQL_LORA_CFG");
   const bool forced = cfg && cfg[0] == 't';
   const bool fits = F > 0 && F % 128 == 0 && ldg % 8 == 0 && M * ld_max < (1L << 31) && 2L * F * ldw_max < (1L << 31);   // 32-bit buffer ranges
@@ -902,7 +902,7 @@ static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long
   // recompute T for a 5-10 tile K loop, and in isolation the two-launch form is faster there (58.3 vs 66.9 us, 50.0 vs
   // 51.2 us, tools/tune_lora_gemm.py) -- but inside the step the saved launch still wins (27.65 vs 27.9 ms/step measured
   // on one box), so they are fused too; AQL_LORA_WIDE=0 restores the exclusion.
-  static const int wide_ok = getenv("AQL_LORA_WIDE") ? atoi(getenv("AQL_LORA_WIDE")) : 1;  // tuning hook
+  static const int wide_ok = AQL_TUNE_INT("AQL_LORA_WIDE", 1);  // tuning hook
   if (!wide_ok && kt <= 10 && N >= 2560) return AQL_NOT_FUSED;
   GemmArgs<PlainLoader, PlainLoader> g;
   g.a0 = plain(X, ldx, M, K);
@@ -957,8 +957,8 @@ static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long
       return AQL_OK;
     }
   }
-  static const int deep_kt = getenv("AQL_DEEPKT") ? atoi(getenv("AQL_DEEPKT")) : 32;
-  static const int force_bm = getenv("AQL_LORA_BM") ? atoi(getenv("AQL_LORA_BM")) : 0;  // tuning hook (160-wide tiles)
+  static const int deep_kt = AQL_TUNE_INT("AQL_DEEPKT", 32);
+  static const int force_bm = AQL_TUNE_INT("AQL_LORA_BM", 0);  // tuning hook (160-wide tiles)
   // tuning hook (tools/tune_lora_cfg.py), re-read on every call: w128 / w64 / w32 = wave-specialised kernel with that tile
   // height, d128 / d64 / d32 = 4-wave kernel (ring depth by grid size), d128s / d64s / d32s = 4-wave kernel, 2 stages
   if (const char* cfg = getenv("AQL_LORA_CFG")) {
@@ -994,16 +994,16 @@ static int lora_gemm_fused_impl(const bf16_t* X, long ldx, const bf16_t* W, long
     // is 32-row tiles, whose weight panel traffic (3.3 MB per workgroup) makes the launch L2-bound -- 86 us against 47 us of the
     // plain split-K GEMM on 128-row tiles (tools/cmp_lora_paths.py).  With aql_lora_down_splitk the two-launch form costs
     // GEMM + ~8 us there.  AQL_LORA_DEEP_T128 = 0 restores the one-launch choice.
-    static const int deep_t128 = getenv("AQL_LORA_DEEP_T128") ? atoi(getenv("AQL_LORA_DEEP_T128")) : 100;
+    static const int deep_t128 = AQL_TUNE_INT("AQL_LORA_DEEP_T128", 100);
     if (kt >= deep_kt && t128 < deep_t128 && !geglu_F && ngroups == 0 && gb_h == nullptr) return AQL_NOT_FUSED;
-    static const int use_w = getenv("AQL_LORA_W") ? atoi(getenv("AQL_LORA_W")) : 1;
+    static const int use_w = AQL_TUNE_INT("AQL_LORA_W", 1);
     // wave-specialised kernels: ONE chip-wide round of 8-wave workgroups (two rounds of the 128-row tile measured slower than
     // the 4-wave kernel: 52.2 vs 40.9 us at 1024x10240x1280)
     if (use_w && kt >= 8 && force_bm == 0) {
       // one round of 128-row tiles: with the weights coming from HBM (the train step: every weight is read once per pass) the
       // 4-wave kernel with a 3-stage ring is 9-15 % faster than the wave-specialised one at K >= 1280 (COLD=1 tools/tune_lora_cfg.py,
       // profiles/r02_tune_lora_cfg_cold_weights.txt); with L2-warm weights it was the other way round by 2-4 %
-      static const int use_w128 = getenv("AQL_LORA_W128") ? atoi(getenv("AQL_LORA_W128")) : 0;
+      static const int use_w128 = AQL_TUNE_INT("AQL_LORA_W128", 0);
       if (t128 >= 240 && t128 <= 288) {
         if (use_w128) launch_w<128, 160, 64, 80, 3>(g, la, lp, stream);
         else launch<128, 160, 64, 80, 3>(g, la, lp, stream);

@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_tr160_grouped_kernel(const T
 // workgroups per CU of the register body: 3 (168 VGPRs, no scratch; the default: config 3 49.53 -> 49.11 ms on one box, config 2
 // unchanged) or 2 (196 VGPRs); 4 would spill 213 VGPRs
 inline int tn_tr_occ() {
-  static const int v = getenv("AQL_TNTR_OCC") ? atoi(getenv("AQL_TNTR_OCC")) : 3;
+  static const int v = AQL_TUNE_INT("AQL_TNTR_OCC", 3);
   return v;
 }
 inline int tn_tr_nst() {
@@ -426,7 +426,7 @@ inline int tn_tr_splits(int tiles, int ktiles, bool grouped) {
   int splits;
   if (force > 0) splits = force;
   else if (grouped) {
-    static const int tps = getenv("AQL_TN_TPS") ? atoi(getenv("AQL_TN_TPS")) : 32;   // token tiles per workgroup (tuning hook)
+    static const int tps = AQL_TUNE_INT("AQL_TN_TPS", 32);   // token tiles per workgroup (tuning hook)
     splits = ktiles / tps;                              // the launch as a whole fills the chip
   }
   else splits = (320 + tiles - 1) / tiles;           // a lone problem: about one workgroup per CU (measured optimum)
@@ -531,7 +531,7 @@ extern "C" int aql_gemm_tn_tr_grouped(const void* dev_descs, int first, int n, i
                                       hipStream_t stream) {
   AQL_CHECK_ARG(dev_descs && first >= 0 && n > 0 && block_base >= 0 && n_blocks > 0, "aql_gemm_tn_tr_grouped: bad args");
   const TnTrDesc* dd = static_cast<const TnTrDesc*>(dev_descs) + first;
-  static const int remap = getenv("AQL_TNTR_REMAP") ? atoi(getenv("AQL_TNTR_REMAP")) : -1;
+  static const int remap = AQL_TUNE_INT("AQL_TNTR_REMAP", -1);
   switch (tn_tr_nst()) {
     case 0:
       if (tn_tr_occ() == 3) hipLaunchKernelGGL((gemm_tn_tr_grouped_kernel<0, 3>), dim3(n_blocks), dim3(256), 0, stream, dd, n, block_base, remap);

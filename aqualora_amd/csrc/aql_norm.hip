@@ -828,7 +828,7 @@ inline int gn_geometry(int HW, int C, int* threads, int* rows_per_slab) {
   *threads = cols * rp;
   // ~32 pixel rows per slab; 64 up to 320 channels (12 rows in flight per workgroup: two rounds of GNA_U loads instead of one short
   // one -- 64x64x320: 21.3 -> 18.3 us forward at 8 samples, 14.3 -> 12.8 at 4; neutral or slower at 640 / 960).  Tuning hook.
-  static const int slab_env = getenv("AQL_GN_SLAB_ROWS") ? atoi(getenv("AQL_GN_SLAB_ROWS")) : 0;
+  static const int slab_env = AQL_TUNE_INT("AQL_GN_SLAB_ROWS", 0);
   const int slab_rows = slab_env > 0 ? slab_env : (C <= 320 ? 64 : 32);
   int nslab = (HW + slab_rows - 1) / slab_rows;
   if (nslab > 128) nslab = 128;
@@ -846,9 +846,9 @@ inline int gn_geometry(int HW, int C, int* threads, int* rows_per_slab) {
 // tools/tune_gn.py: 16.1 -> 12.6 us at 640 channels, 18.9 -> 15.3 at 960, 11.8 -> 9.9 at 320; 1280 / 1920 channels and every
 // forward shape are within 1 us or slower).  AQL_GN_FUSED_MAXHW forces the threshold for all shapes (tuning hook).
 inline bool gn_use_fused(int C, int HW, bool bwd = false) {
-  static const int en = getenv("AQL_GN_FUSED") ? atoi(getenv("AQL_GN_FUSED")) : 1;
+  static const int en = AQL_TUNE_INT("AQL_GN_FUSED", 1);
   if (!en || (C / G) % 2 != 0 || (C / G) / 2 > GNF_THREADS) return false;
-  static const int max_hw = getenv("AQL_GN_FUSED_MAXHW") ? atoi(getenv("AQL_GN_FUSED_MAXHW")) : 0;
+  static const int max_hw = AQL_TUNE_INT("AQL_GN_FUSED_MAXHW", 0);
   if (en == 2) return true;
   if (max_hw > 0) return HW <= max_hw;
   if (bwd && HW > 512 && C <= 960 && C / G >= 8) return false;
@@ -861,7 +861,7 @@ inline bool gn_use_fused(int C, int HW, bool bwd = false) {
 // 40.3 -> 36.6 (960); backward at 4 samples 23.7 -> 17.3, 30.4 -> 26.1, 38.5 -> 34.4; 32x32 backward: 4 samples 10.3 -> 11.5 (kept on the
 // old form), 8 samples 15.1 -> 12.1.  Slabs: ~512 workgroups in all (128 slabs at 4 samples, 64 at 8).
 inline int gn_rowstats_slabs(int B, int HW, int C, int nslab_apply) {
-  static const int en = getenv("AQL_GN_ROWSTATS") ? atoi(getenv("AQL_GN_ROWSTATS")) : 1;
+  static const int en = AQL_TUNE_INT("AQL_GN_ROWSTATS", 1);
   if (en == 0 || (C / G) < 8 || C / 8 > 512) return 0;
   if (en == 1 && HW <= 1024 && B < 8) return 0;
   int ns = en > 1 ? en : 512 / (B > 0 ? B : 1);
@@ -876,7 +876,7 @@ inline int gn_rowstats_slabs(int B, int HW, int C, int nslab_apply) {
 // (64x64, B=4, tools/tune_gn.py: 22.3 vs 26.5 us at 320 channels, 25.4 vs 34.9 at 640, 33.5 vs 41.7 at 960 against the slab
 // form).  0 = use the slab form; AQL_GN_SPLIT=0 disables, =n forces n pieces
 inline int gn_split(int C, int HW) {
-  static const int en = getenv("AQL_GN_SPLIT") ? atoi(getenv("AQL_GN_SPLIT")) : -1;
+  static const int en = AQL_TUNE_INT("AQL_GN_SPLIT", -1);
   if (en == 0 || (C / G) % 2 != 0 || (C / G) / 2 > GNF_THREADS || HW <= 512 || HW > 8192) return 0;   // callers ask only when the one-launch form is off
   if (en > 0) return en > 8 ? 8 : en;
   int ns = HW / 1024;
@@ -903,7 +903,7 @@ extern "C" int aql_groupnorm_silu_fwd(const bf16_t* x, int B, int HW, int C, con
     AQL_CHECK_LAUNCH("aql_groupnorm_silu_fwd");
     return AQL_OK;
   }
-  static const int apply2 = getenv("AQL_GN_APPLY2") ? atoi(getenv("AQL_GN_APPLY2")) : 1;   // A/B hook
+  static const int apply2 = AQL_TUNE_INT("AQL_GN_APPLY2", 1);   // A/B hook
   int threads, rps;
   const int nslab = gn_geometry(HW, C, &threads, &rps);
   const bool a2_ok = apply2 && (C / G) >= 8;
@@ -971,8 +971,8 @@ extern "C" int aql_groupnorm_silu_bwd(const bf16_t* x, const bf16_t* dy, int B, 
   // split form: per-(sample, group, piece) sums in one launch, the coalesced second pass adds the pieces itself -- two launches,
   // no finalize (with the old per-group second pass this form measured 36 vs 32 us at 64x64x320 and was not used).  AQL_GN_BWD_SPLIT=0
   // restores the three-launch slab form
-  static const int bwd_split = getenv("AQL_GN_BWD_SPLIT") ? atoi(getenv("AQL_GN_BWD_SPLIT")) : 1;
-  static const int apply2s = getenv("AQL_GN_APPLY2") ? atoi(getenv("AQL_GN_APPLY2")) : 1;
+  static const int bwd_split = AQL_TUNE_INT("AQL_GN_BWD_SPLIT", 1);
+  static const int apply2s = AQL_TUNE_INT("AQL_GN_APPLY2", 1);
   int ns_b = (bwd_split && apply2s && (C / G) >= 8) ? gn_split(C, HW) : 0;
   // measured (tools/tune_gn.py, 64x64): B=4: 25.1 / 32.7 / 40.2 us against 29.2 / 38.8 / 47.9 at 320 / 640 / 960 channels;
   // B=8: 44.9 / 57.2 / 73.1 against 41.3 / 58.7 / 75.3 -- the split form loses only with > 768 workgroups of 20-byte segments
@@ -1005,7 +1005,7 @@ extern "C" int aql_groupnorm_silu_bwd(const bf16_t* x, const bf16_t* dy, int B, 
                      rps, silu, scratch);
   hipLaunchKernelGGL(gn_finalize_kernel<1>, dim3(B), dim3(256), 0, stream, scratch, nslab,
                      1.f / ((float)HW * (C / G)), 0.f, dstats);
-  static const int apply2 = getenv("AQL_GN_APPLY2") ? atoi(getenv("AQL_GN_APPLY2")) : 1;   // A/B hook
+  static const int apply2 = AQL_TUNE_INT("AQL_GN_APPLY2", 1);   // A/B hook
   if (apply2 && (C / G) >= 8) {
     hipLaunchKernelGGL(gn_apply2_kernel<1>, dim3(nslab, B), dim3(threads), 0, stream, x, dy, gamma, beta, stats, dstats, nullptr, 0, 0,
                        0.f, 0.f, nullptr, HW, C, rps, silu, dres, dx);
@@ -1058,7 +1058,7 @@ extern "C" int aql_layernorm_fwd(const bf16_t* x, long M, int C, const bf16_t* g
                                  bf16_t* y, float* stats, hipStream_t stream) {
   AQL_CHECK_ARG(x && gamma && beta && y && stats, "aql_layernorm_fwd: null operand");
   AQL_CHECK_ARG(C % 8 == 0 && C <= 64 * 8 * LN_MAXC, "aql_layernorm_fwd: unsupported C=%d", C);
-  static const int rows = getenv("AQL_LN_ROWS") ? atoi(getenv("AQL_LN_ROWS")) : 1;   // tuning hook: rows per wavefront (2: measured equal or slower, tools/time_ln.py)
+  static const int rows = AQL_TUNE_INT("AQL_LN_ROWS", 1);   // tuning hook: rows per wavefront (2: measured equal or slower, tools/time_ln.py)
   ln_launch<0>(rows >= 2 && M >= 4096, x, nullptr, gamma, beta, stats, M, C, eps, y, stream);
   AQL_CHECK_LAUNCH("aql_layernorm_fwd");
   return AQL_OK;
@@ -1068,7 +1068,7 @@ extern "C" int aql_layernorm_bwd(const bf16_t* x, const bf16_t* dy, long M, int 
                                  const float* stats, const bf16_t* dres, bf16_t* dx, hipStream_t stream) {
   AQL_CHECK_ARG(x && dy && gamma && dx && stats, "aql_layernorm_bwd: null operand");
   AQL_CHECK_ARG(C % 8 == 0 && C <= 64 * 8 * LN_MAXC, "aql_layernorm_bwd: unsupported C=%d", C);
-  static const int rows = getenv("AQL_LN_ROWS") ? atoi(getenv("AQL_LN_ROWS")) : 1;
+  static const int rows = AQL_TUNE_INT("AQL_LN_ROWS", 1);
   ln_launch<1>(rows >= 2 && M >= 4096, x, dy, gamma, dres, const_cast<float*>(stats), M, C, 0.f, dx, stream);
   AQL_CHECK_LAUNCH("aql_layernorm_bwd");
   return AQL_OK;

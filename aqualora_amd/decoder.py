@@ -67,41 +67,55 @@ class _EfficientNetB1(nn.Module):
         self.classifier = nn.Sequential(nn.Dropout(0.2), nn.Linear(1280, num_out))
 
 
-def train_step_algorithmic_bytes(B, res=512):
+def train_step_algorithmic_bytes(B, res=512, fused=False):
     """HBM bytes of one SecretDecoder training step (forward + backward-data + backward-weight) on B images of res x res, fp32, counted
     OP BY OP with no fusion between ops: forward = every conv / BatchNorm+SiLU / squeeze-excite scale / residual add reads its input(s)
     and writes its output once; backward-data = (dy, saved x) -> dx per op; backward-weight of the convolutions = (dy, x) again.
     Weights, the squeeze-excite vectors and the classifier are negligible beside the maps.  This is the roofline the step as built can
-    reach (bench.py config5.roofline); fusing BatchNorm into its producer / consumer would lower the floor itself."""
+    reach (bench.py config5.roofline); fusing BatchNorm into its producer / consumer would lower the floor itself.
+    ``fused=True``: the floor of a step whose row-local ops ride in their neighbours (round 6) -- train-mode
+    BatchNorm still needs its batch statistics before anything can be normalised, so per BatchNorm one statistics read remains forward
+    (the producing conv's epilogue could carry even that) and one (dy, x) pass backward; BatchNorm-apply + SiLU is recomputed on the fly
+    by the consumer's loader (no normalised map is written or read), the squeeze-excite gate multiplies in the project conv's loader,
+    the residual add sits in its epilogue."""
     total = [0]
 
-    def op(n_in, n_out, conv=False):
+    def op(n_in, n_out, conv=False, kind=None):
+        if fused and not conv:
+            if kind == "bn":         # statistics pass forward; (dy, x) -> sums backward; the apply passes ride in the neighbours
+                total[0] += 4 * (n_in + 2 * n_in)
+            elif kind == "pool":     # squeeze: one read forward, its backward rides in the excite backward
+                total[0] += 4 * n_in
+            # excite / residual add: in the project conv's loader / epilogue (the residual's read is counted there)
+            elif kind == "res":
+                total[0] += 4 * (n_out + n_out)      # forward: the skip tensor read in the epilogue; backward: dy fans out (one extra read)
+            return
         fwd = n_in + n_out
         bwd = n_out + n_in + n_in
         total[0] += 4 * (fwd + bwd + ((n_out + n_in) if conv else 0))
 
     H = res // 2
     op(B * res * res * 3, B * H * H * 32, True)      # stem conv
-    op(B * H * H * 32, B * H * H * 32)               # its BatchNorm + SiLU
+    op(B * H * H * 32, B * H * H * 32, kind="bn")    # its BatchNorm + SiLU
     for (t, k, s, cin, cout, n) in B1_STAGES:
         for i in range(n):
             st, ci = (s if i == 0 else 1), (cin if i == 0 else cout)
             ce, Ho = ci * t, H // st
             if t != 1:
                 op(B * H * H * ci, B * H * H * ce, True)
-                op(B * H * H * ce, B * H * H * ce)
+                op(B * H * H * ce, B * H * H * ce, kind="bn")
             op(B * H * H * ce, B * Ho * Ho * ce, True)   # depthwise
-            op(B * Ho * Ho * ce, B * Ho * Ho * ce)       # BatchNorm + SiLU
-            op(B * Ho * Ho * ce, B * ce)                 # squeeze (pool)
-            op(B * Ho * Ho * ce, B * Ho * Ho * ce)       # excite (scale by the gate)
+            op(B * Ho * Ho * ce, B * Ho * Ho * ce, kind="bn")       # BatchNorm + SiLU
+            op(B * Ho * Ho * ce, B * ce, kind="pool")                 # squeeze (pool)
+            op(B * Ho * Ho * ce, B * Ho * Ho * ce, kind="excite")       # excite (scale by the gate)
             op(B * Ho * Ho * ce, B * Ho * Ho * cout, True)
-            op(B * Ho * Ho * cout, B * Ho * Ho * cout)   # BatchNorm
+            op(B * Ho * Ho * cout, B * Ho * Ho * cout, kind="bn")   # BatchNorm
             if st == 1 and ci == cout:
-                op(2 * B * Ho * Ho * cout, B * Ho * Ho * cout)   # residual add (stochastic depth)
+                op(2 * B * Ho * Ho * cout, B * Ho * Ho * cout, kind="res")   # residual add (stochastic depth)
             H = Ho
     op(B * H * H * 320, B * H * H * 1280, True)
-    op(B * H * H * 1280, B * H * H * 1280)
-    op(B * H * H * 1280, B * 1280)
+    op(B * H * H * 1280, B * H * H * 1280, kind="bn")
+    op(B * H * H * 1280, B * 1280, kind="pool")
     return total[0]
 
 

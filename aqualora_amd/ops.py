@@ -109,7 +109,7 @@ def _gn_scratch(device, B):
 
 
 # ---------------------------------------------------------------------------------- branch-level concurrency
-BRANCH_STREAMS = int(os.environ.get("AQL_BRANCH_STREAMS", "0"))   # >0: independent sibling ops (attention q/k/v projections) are issued on this many side streams.
+BRANCH_STREAMS = 0   # >0: independent sibling ops (attention q/k/v projections) are issued on this many side streams.
 # EXPERIMENTAL, eager only: nested stream forks inside a hipGraph capture crash hipStreamEndCapture on this ROCm
 # (measured round 1), so the captured trainer keeps it at 0.
 _BR = {}
@@ -182,7 +182,7 @@ class _Dual:
 
 
 DUAL = None
-_TWIN_SKIP = os.environ.get("AQL_TWIN_SKIP", "1") != "0"   # skip the LoRA branch on clean tiles (A/B hook)
+_TWIN_SKIP = True   # skip the LoRA branch on clean tiles (module attribute: probes flip it; the environment hook left in round 6)
 
 
 def dual_begin():
@@ -392,7 +392,7 @@ def gemm_tn_acc(U, V, C, alpha=1.0):
     AQL_TN_OLD=1 selects the previous wide path (transpose both operands once + pipelined NT kernels) for comparison."""
     M, P = U.shape
     Q = V.shape[1]
-    if U.stride(1) == 1 and V.stride(1) == 1 and not os.environ.get("AQL_TN_OLD"):
+    if U.stride(1) == 1 and V.stride(1) == 1 and not TN_OLD:
         L.call("aql_gemm_tn_tr_f32", L.ptr(U), U.stride(0), L.ptr(V), V.stride(0), M, P, Q, float(alpha), L.ptr(C),
                C.stride(0), L.stream_ptr())
         return
@@ -516,7 +516,7 @@ class DeferredDW:
         self._host_tables_free()
         # the transpose-read kernel takes every problem (128x32 tiles for a rank <= 32 side); the register-transposing
         # kernel is the fallback (AQL_TN_OLD=1 prefers it, for comparison)
-        kinds = ("n", "w") if os.environ.get("AQL_TN_OLD") else ("x", "w", "n")
+        kinds = ("n", "w") if TN_OLD else ("x", "w", "n")
         for k in kinds:
             nbytes, _, fill, _ = self.KINDS[k]
             slot = self.host[k].data_ptr() + self.n[k] * nbytes
@@ -671,6 +671,7 @@ class SplitDeferred:
 
 
 REF_ROUNDING = os.environ.get("AQL_REF_ROUNDING", "0") == "1"   # see LoraLinearFn.forward
+TN_OLD = False   # True = the older register-transposing weight-gradient kernel (tools/probe_tntr.py times it against the transpose-read one)
 DEFERRED = None  # set by a trainer around backward (ppft.PPFTTrainer); None => every site launches its own kernels
 
 
@@ -1171,7 +1172,8 @@ def adjacent(tensors):
     return True
 
 
-_KGROUPS = os.environ.get("AQL_KGROUPS", "1") != "0"   # A/B hook: 0 = three chained backward-data launches for q | k | v
+_GROUPED = True    # False = every grouped rank-32 launch as per-site launches (module attribute; the environment hook left in round 6)
+_KGROUPS = True   # False = three chained backward-data launches for q | k | v (module attribute; the environment hook left in round 6)
 
 
 class GroupedLoraFn(torch.autograd.Function):
@@ -1221,7 +1223,7 @@ class GroupedLoraFn(torch.autograd.Function):
         x2d, T, Ts, S16 = ctx.saved_tensors
         dx, dS_sum = None, None
         if (not ctx.needs_input_grad[0] and ctx.ds_accum is not None and DEFERRED is not None
-                and all(dy is not None for dy in dys) and os.environ.get("AQL_GROUPED", "1") != "0"):
+                and all(dy is not None for dy in dys) and _GROUPED):
             # input without gradient (the text states): only dTs / dT are needed (for dS, dA, dB) -- ONE grouped skinny launch
             # for all groups instead of one per group, everything else is bookkeeping for the deferred grouped launches
             import ctypes
@@ -1477,7 +1479,7 @@ def lora_linear_grouped_wide(x2d, wcat, wcatT, packs, sites, S, S16, rps):
 
 def grouped_lora_ok(x2d, packs, sites, S16):
     """The one-launch grouped form applies: rank 32 everywhere, 160-column groups, stacked bf16 copies, fused kernel enabled."""
-    if S16 is None or os.environ.get("AQL_LORA_FUSED", "1") == "0" or os.environ.get("AQL_GROUPED", "1") == "0" or REF_ROUNDING:
+    if S16 is None or os.environ.get("AQL_LORA_FUSED", "1") == "0" or not _GROUPED or REF_ROUNDING:
         return False
     if len(sites) > 32 or any(s is None or s.rank != 32 for s in sites) or any(p.N % 160 != 0 or p.bias is not None for p in packs):
         return False
@@ -1499,9 +1501,9 @@ def lora_linear(x2d, packed, site=None, S=None, S16=None, rps=1, residual=None, 
 
 # ------------------------------------------------------------------------- row-resident chains (csrc/aql_chain.hip)
 CHAIN = os.environ.get("AQL_CHAIN", "1") != "0"   # A/B hook: 0 = every linear / LayerNorm of the transformer block as its own launch
-CHAIN_BWD = os.environ.get("AQL_CHAIN_BWD", "1") != "0"   # A/B hook: 0 = the chains' backward as separate launches
-CHAIN_R320 = os.environ.get("AQL_CHAIN_R320", "1") != "0"   # A/B hook: 0 = rank-320 linears as aql_lora_down + aql_gemm_bf16 launches
-CHAIN_MIN_TILES = int(os.environ.get("AQL_CHAIN_MIN_TILES", "128"))   # below this many 128-row tiles the chip is mostly idle: unfused
+CHAIN_BWD = True   # False = the chains' backward as separate launches (module attribute; measured neutral, kept for the launch count)
+CHAIN_R320 = True   # False = rank-320 linears as aql_lora_down + aql_gemm_bf16 launches (module attribute)
+CHAIN_MIN_TILES = 128   # below this many 128-row tiles the chip is mostly idle: unfused (module attribute: tests lower it)
 
 
 class ChainStage:
@@ -1857,7 +1859,7 @@ def conv3x3(x, packed, upsample=False, rowbias=None, residual=None, gn_next=Fals
 
 
 # ------------------------------------------------------------------------------ skip-connection concat
-_CAT_FUSED = os.environ.get("AQL_CAT_FUSED", "1") != "0"   # A/B hook: 0 = two strided torch copies forward, slice views backward
+_CAT_FUSED = True   # False = two strided torch copies forward, slice views backward (module attribute)
 
 
 class CatChannelsFn(torch.autograd.Function):

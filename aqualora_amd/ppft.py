@@ -23,7 +23,8 @@ from . import dp, ops
 from .lora import LoraBank, inject_lora, patch_lora_forwards
 from .watermark import customDDPMScheduler
 
-_PROLOGUE = os.environ.get("AQL_PROLOGUE", "1") != "0"   # A/B hook: 0 = the generic (15-launch) head of the twin step
+_EARLY_DW = False  # True = the split (early / late) weight-gradient launches of the data-parallel form on a single GPU (measured neutral)
+_PROLOGUE = True   # False = the generic (15-launch) head of the twin step (module attribute; the environment hook left in round 6)
 
 VAE_SCALING = 0.18215
 
@@ -104,12 +105,12 @@ class PPFTTrainer:
         # on one MI355X) -- the backward kernels lose more to the contention than the HBM-bound launch hides.  Single GPU: off
         # (nothing to overlap; AQL_EARLY_DW=1 forces the split form for tests / A-B).
         self.split = self.overlap or (not dp.exchange_active(process_group) and max(1, micro_batches) == 1
-                                      and os.environ.get("AQL_EARLY_DW", "0") == "1")
+                                      and _EARLY_DW)
         self.side = torch.cuda.Stream(device=dev) if self.split else None   # forked / joined inside the step (and its graph)
         # backward legs that end with a hook-driven exchange (lora.backward_stage): 3 = up path | mid + down_blocks.3/.2 |
         # down_blocks.1, leaving only down_blocks.0 (+ the grouped text-state projections at rank 32 + the mapper) for the end of
         # backward: 8.8 MB of 54 MB at rank 32, 30 MB of 543 MB at rank 320.  AQL_LEGS=1 restores round 3's single hook.
-        self.n_legs = max(1, min(3, int(os.environ.get("AQL_LEGS", "3"))))
+        self.n_legs = 3
         self._new_deferred()
 
     def _new_deferred(self):
@@ -444,7 +445,7 @@ class PPFTTrainer:
         if self.bucketed:
             return self._capture_bucketed(static, g_fb, g_opt)
         import os
-        if self.split or (not dp.exchange_active(self.pg) and os.environ.get("AQL_ONE_GRAPH", "1") != "0"):
+        if self.split or not dp.exchange_active(self.pg):
             return self._capture_single(static, g_fb)
         # thread_local capture mode: with a process group alive, RCCL's watchdog thread polls hipEventQuery on the
         # warm-up collectives; under the default global mode that call is illegal while ANY thread captures and aborts
@@ -522,8 +523,7 @@ class PPFTTrainer:
         self.exchange_ranges = ranges
 
         import os
-        run_bucket = (lambda k: g_dw[k].replay()) if os.environ.get("AQL_BUCKET_GRAPHS", "1") == "1" \
-            else captured.run_bucket
+        run_bucket = lambda k: g_dw[k].replay()   # noqa: E731
 
         def run(z, msg, eps, t, ctx):
             _feed(static, z, msg, eps, t, ctx)

@@ -105,7 +105,7 @@ def time_kernel(fn, iters=20):
 def dominant_kernels(B, device):
     """HIP-event timings (torch's current stream == the launch stream of the C-ABI calls) of the heaviest launch of each
     kernel family, at the shapes the step runs them.  kernels[0] is the heaviest launch of the TIME-dominant family (the
-    one-launch LoRA linears: 34 % of the step, profiles/r05_families_config2.json): ff.net.0.proj + rank-32 LoRA + GEGLU on the twin
+    one-launch LoRA linears: 34 % of the step, profiles/r06_families_config2.json): ff.net.0.proj + rank-32 LoRA + GEGLU on the twin
     batch of the 64x64 level.  The forward runs both U-Net passes as ONE twin batch of 2B samples (ops._Dual), so forward
     launches see 2B samples; rows of the clean half skip the LoRA branch (lora_row0)."""
     from aqualora_amd import _lib as L
@@ -177,8 +177,33 @@ def dominant_kernels(B, device):
         rc = L.call_raw("aql_lora_gemm_fused", L.ptr(X), 320, L.ptr(Wl), 320, B * 4096, 320, 320, L.ptr(Al), L.ptr(Sl), 4096,
                         L.ptr(Bl), None, None, 0, L.ptr(Yl), 320, L.ptr(Tl), L.ptr(Tsl), 0, L.stream_ptr())
         assert rc == 0, rc
+    Ml = B * 4096
     entry("lora_gemm_kernel attention projection 320->320 + rank-32 LoRA @4096 tok (backward-data shape)", time_kernel(lora_call),
-          2.0 * B * 4096 * 320 * (320 + 32) + 2.0 * B * 4096 * 32 * 320, samples=B)
+          2.0 * Ml * 320 * (320 + 32) + 2.0 * Ml * 32 * 320, samples=B,
+          algorithmic_bytes=2.0 * (2 * Ml * 320 + 2 * Ml * 32 + 320 * 320 + 2 * 32 * 320))
+    # (5) the attention projections of the 64 x 64 level in the FORWARD pass: the row-resident chain  attn1.to_out + residual -> norm2 ->
+    # attn2.to_q  (two LoRA linears + LayerNorm, one launch, twin batch; csrc/aql_chain.hip).  168 FLOP per byte: HBM-bound by shape --
+    # its roof is the 8 TB/s of `hbm_view`, not the matrix pipe
+    Mc, C = 2 * B * 4096, 320
+    rb = lambda n, *sh: synth.normal(n, sh, 0.05, 1, device).to(torch.bfloat16)   # noqa: E731
+    eb = lambda *sh: torch.empty(*sh, dtype=torch.bfloat16, device=device)       # noqa: E731
+    Xc, Rc = synth.normal("k.cx", (Mc, C), 1.0, 1, device).to(torch.bfloat16), synth.normal("k.cr", (Mc, C), 1.0, 1, device).to(torch.bfloat16)
+    Sc = torch.cat([torch.zeros(B, 32, device=device), synth.normal("k.cs", (B, 32), 1.0, 1, device)]).to(torch.bfloat16)
+    lin = lambda t, bias: dict(W=rb(t + "w", C, C), bias=rb(t + "b", C) if bias else None, Ad=rb(t + "a", 32, C), Bup=rb(t + "u", C, 32), ldw=C)   # noqa: E731
+    stg = [dict(lin("k.c0", True), T=eb(Mc, 32), Ts=eb(Mc, 32), res=Rc, ldr=C, out=eb(Mc, C), ldo=C, keep=1, ln=1, gamma=1 + rb("k.cg", C),
+                beta=rb("k.cb", C), eps=1e-5, stats=torch.empty(Mc, 2, device=device), nout=eb(Mc, C), ldn=C, nout_row0=Mc // 2),
+           dict(lin("k.c1", False), T=eb(Mc, 32), Ts=eb(Mc, 32), out=eb(Mc, C), ldo=C, keep=0)]
+    th = time_kernel(lambda: ops.chain_fwd(Xc, C, Mc, 4096, Mc // 2, Sc, stg))
+    fl = 2 * (2.0 * Mc * C * C) + 2 * (Mc // 2) * 2.0 * (C * 32 + 32 * C)
+    # x + residual in, hs + q out on all rows, the LayerNorm output and T / Ts of both linears on the watermarked half, weights
+    alg = 2.0 * (2 * Mc * C + 2 * Mc * C + (Mc // 2) * C + 4 * (Mc // 2) * 32 + 2 * C * C + 4 * 32 * C) + 8.0 * Mc
+    entry(f"chain_kernel<2,false> attn1.to_out + residual -> norm2 -> attn2.to_q (row-resident chain, rank-32 LoRA on both linears), "
+          f"{2 * B} samples x 4096 tokens (twin forward)", th, fl, samples=2 * B, algorithmic_bytes=alg,
+          pmc_key=f"chain a: to_out+res -> LN -> to_q, M={Mc} (twin)")
+    for d in out:   # every launch also against the HBM roof (algorithmic bytes / measured time)
+        if "algorithmic_bytes" in d:
+            d["hbm_view"] = {"achieved_GBps": d["algorithmic_bytes"] / d["ms"] / 1e6, "peak_GBps": 8000.0,
+                             "frac": d["algorithmic_bytes"] / d["ms"] / 1e6 / 8000.0}
     return out
 
 
@@ -194,7 +219,7 @@ def profile_staleness():
     """Which kernel sources changed since the committed profiles (families, PMC traffic, MfmaUtil) were taken: those sections of the
     line are read from files, not measured in this run, and describe an older library when this list is not empty."""
     import hashlib
-    meta = load_profile_json("r05_meta.json")
+    meta = load_profile_json("r06_meta.json")
     if meta is None:
         return {"profile_meta": "missing"}
     changed = []
@@ -559,13 +584,21 @@ def robft_bench(args, device):
                 "value": B / dt, "unit": "images/sec", "ms_per_step": 1e3 * dt, "steps": args.steps, "dtype": "f32", "batch": B,
                 "achieved_tflops_fp32": gf / dt / 1e3, "loss": float(loss), "bit_acc_of_step": float(acc),
                 "finite": bool(torch.isfinite(loss)),
-                **({} if gen is not None else {"roofline": (lambda nb: {
+                **({} if gen is not None else {"roofline": (lambda nb, nbf, tr: {
                     "bound": "hbm", "achieved": nb / dt / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nb / dt / 1e9 / 8000.0,
-                    "traffic": None, "bytes_per_step": nb,
+                    "traffic": None if tr is None else tr.get("traffic_bytes_per_step"),
+                    "traffic_source": None if tr is None else "static, not measured in this run: " + tr.get("_how", "profiles/r06_pmc_robft.json"),
+                    "bytes_per_step": nb,
                     "model": "algorithmic bytes of the decoder step counted op by op, fp32, no fusion between ops "
                              "(aqualora_amd.decoder.train_step_algorithmic_bytes: forward + backward-data + backward-weight of the "
-                             "EfficientNet-B1 maps); the distortion layer and AdamW (26 MB of state) are not counted"})(
-                                 __import__("aqualora_amd.decoder", fromlist=["x"]).train_step_algorithmic_bytes(B, 512))}),
+                             "EfficientNet-B1 maps); the distortion layer and AdamW (26 MB of state) are not counted",
+                    # the floor a FUSED step would have (BatchNorm-apply + SiLU read on the fly by the consumer, the squeeze-excite gate in
+                    # the project conv's loader, the residual add in its epilogue): what `frac` would be against that model
+                    "fused_model": {"bytes_per_step": nbf, "frac": nbf / dt / 1e9 / 8000.0,
+                                    "model": "aqualora_amd.decoder.train_step_algorithmic_bytes(fused=True)"}})(
+                                 __import__("aqualora_amd.decoder", fromlist=["x"]).train_step_algorithmic_bytes(B, 512),
+                                 __import__("aqualora_amd.decoder", fromlist=["x"]).train_step_algorithmic_bytes(B, 512, fused=True),
+                                 load_profile_json("r06_pmc_robft.json"))}),
                 **({"resolutions_drawn": drawn} if gen is not None else {}),
                 **({"generator": f"per-image messages, 20-step DPM-Solver++ sampling (CFG 7.5) through the un-fused rank-{args.rank} "
                                  f"watermark LoRA at {args.robft_res}x{args.robft_res} + VAE decode in front of the step "
@@ -729,8 +762,8 @@ def main():
         # `roofline` = the heaviest launch of the TIME-dominant kernel family (the one-launch LoRA linears, `families` below),
         # timed live with HIP events on the launch stream.  `traffic` = HBM bytes per launch of the same kernel and shape from
         # the rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 2x FETCH correction, tools/pmc_traffic.sh),
-        # read from the committed profiles/r05_pmc_traffic.json -- NOT measured in this run; null without a committed pass.
-        pmc = load_profile_json("r05_pmc_traffic.json") or {}
+        # read from the committed profiles/r06_pmc_traffic.json -- NOT measured in this run; null without a committed pass.
+        pmc = load_profile_json("r06_pmc_traffic.json") or {}
         ent = pmc.get(dom.get("pmc_key", ""))
         traffic = None if ent is None else ent["traffic_bytes"]
         line["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_tflops"],
@@ -738,7 +771,7 @@ def main():
                             "traffic": traffic, "traffic_unit": f"bytes/launch (algorithmic: {dom['algorithmic_bytes']:.4g})",
                             "traffic_source": None if traffic is None else
                             "static, not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel + shape, "
-                            "profiles/r05_pmc_traffic.json",
+                            "profiles/r06_pmc_traffic.json",
                             "flops_per_launch": dom["flops"], "ms_per_launch": dom["ms"], "timing": dom["timing"],
                             "selected_by": "largest ms/step family of the committed kernel trace (families), heaviest launch of it",
                             "hbm_view": {"achieved_GBps": dom["algorithmic_bytes"] / dom["ms"] / 1e6, "peak_GBps": 8000.0,
@@ -747,9 +780,9 @@ def main():
             e = pmc.get(k.get("pmc_key", ""))
             if e is not None:
                 k["traffic_bytes_static"] = e["traffic_bytes"]
-        fam = load_profile_json(f"r05_families_config{args.config}.json")
+        fam = load_profile_json(f"r06_families_config{args.config}.json")
         if fam is not None:
-            line["families"] = {"source": f"static, not measured in this run: profiles/r05_families_config{args.config}.json "
+            line["families"] = {"source": f"static, not measured in this run: profiles/r06_families_config{args.config}.json "
                                           "(tools/prof_families.py over a rocprofv3 --kernel-trace of this command)",
                                 "ms_per_step_profiled": fam.get("ms_per_step"), "launches_per_step": fam.get("launches_per_step"),
                                 "rows": fam.get("families")}
@@ -759,11 +792,13 @@ def main():
         line["kernels"] = ks
         line["static_profile_sections"] = dict(profile_staleness(), sections=["roofline.traffic", "families", "mfma_util_pmc",
                                                                              "kernels[].traffic_bytes_static"])
-        mu = load_profile_json("r05_pmc_mfma_util.json")
+        mu = load_profile_json("r06_pmc_mfma_util.json")
         if mu is not None:   # rocprofv3 MfmaUtil (matrix-pipe busy fraction) of the attention / conv / LoRA kernels: static evidence
-            line["mfma_util_pmc"] = {"source": "static, not measured in this run: profiles/r05_pmc_mfma_util.json (rocprofv3 --pmc pass)",
+            line["mfma_util_pmc"] = {"source": "static, not measured in this run: profiles/r06_pmc_mfma_util.json (rocprofv3 --pmc pass)",
                                      "kernels": {k: v["mfma_util"] for k, v in mu["kernels"].items()},
-                                     "attention_64x64_time_weighted": mu.get("attention_64x64_time_weighted")}
+                                     "attention_64x64_time_weighted": mu.get("attention_64x64_time_weighted"),
+                                     # SURVEY 8(d)'s subset "attention linears + SDPA" at the 64 x 64 level (formula in the file)
+                                     "attention_linears_plus_sdpa_time_weighted": mu.get("attention_linears_plus_sdpa_time_weighted")}
         if world == 1 and not args.no_extras and not (args.pixel_in or args.text_in):
             # the reference's real step boundary: pixels and token ids in (frozen VAE encode + CLIP text encoder inside)
             full = wrap_pixel_text(runner, args, device, rank_id, True, True)

@@ -45,9 +45,9 @@ for (M, P, Q) in [(32768, 320, 320), (32768, 2560, 320), (32768, 320, 1280), (81
     if M >= 512 and max(P, Q) >= 320:
         Z = torch.zeros(P, Q, device=dev)
         t_new = timeit(lambda: tntr(U, V, Z))
-        os.environ["AQL_TN_OLD"] = "1"
+        ops.TN_OLD = True
         t_old = timeit(lambda: ops.gemm_tn_acc(U, V, Z))
-        del os.environ["AQL_TN_OLD"]
+        ops.TN_OLD = False
         print(f"     time: tn_tr {t_new:7.1f} us = {2 * M * P * Q / t_new / 1e6:6.0f} TF/s | transpose+NT path {t_old:7.1f} us")
 # strided operands (column slices of a wider matrix, as the U-Net's packed heads are)
 W = torch.randn(4096, 1024, device=dev).bfloat16()
