@@ -53,3 +53,35 @@ def test_span_chunks_keeps_every_piece_under_the_descriptor_span():
         assert sum(c for _, c in pieces) == n and [r for r, _ in pieces] == sorted(r for r, _ in pieces)
         assert all(r % align == 0 for r, _ in pieces)
         assert all(c * per < ops.DESC_SPAN or c == 1 for _, c in pieces)
+
+
+def test_grouped_wide_gate_and_packed_columns():
+    """Host logic of the rank-320 grouped projections (ops.grouped_wide_ok / ops.packed_columns, round 6): the layout lora.LoraBank
+    gives a q | k | v trio -- A and Bup stacked, Bup^T stacked, A^T as column blocks of one [K, 3r] matrix -- is accepted, anything
+    else stays on the per-site path; the attention backward's packed [dQ | dK | dV] is recognised in place."""
+    r, C = 320, 640
+    x = _x(2048, C)
+    S16 = torch.empty(8, r, dtype=torch.bfloat16)
+    a = torch.empty(3 * r, C, dtype=torch.bfloat16)
+    b = torch.empty(3 * C, r, dtype=torch.bfloat16)
+    bt = torch.empty(3 * r, C, dtype=torch.bfloat16)
+    atc = torch.empty(C, 3 * r, dtype=torch.bfloat16)
+
+    def sites(at_cols=True, rank=r):
+        return [types.SimpleNamespace(rank=rank, a16=a[g * r:(g + 1) * r], b16=b[g * C:(g + 1) * C], bt16=bt[g * r:(g + 1) * r],
+                                      at16=atc[:, g * r:(g + 1) * r] if at_cols else torch.empty(C, r, dtype=torch.bfloat16)) for g in range(3)]
+    packs = [types.SimpleNamespace(N=C, K=C, bias=None) for _ in range(3)]
+    assert ops.grouped_wide_ok(x, packs, sites(), S16)
+    assert ops.grouped_wide_ok(x, packs[:2], sites()[:2], S16, need_dx=False)                  # the text k | v pair
+    assert not ops.grouped_wide_ok(x, packs, sites(at_cols=False), S16)                         # A^T not laid out as column blocks
+    assert ops.grouped_wide_ok(x, packs, sites(at_cols=False), S16, need_dx=False)
+    assert not ops.grouped_wide_ok(x, packs, sites(rank=32), S16)                               # rank 32 has its own grouped kernel
+    assert not ops.grouped_wide_ok(x, packs, list(reversed(sites())), S16)                      # not stacked in this order
+    assert not ops.grouped_wide_ok(x, [types.SimpleNamespace(N=C, K=C, bias=torch.zeros(C))] + packs[1:], sites(), S16)
+    assert not ops.grouped_wide_ok(x, [types.SimpleNamespace(N=480, K=C, bias=None)] * 3, sites(), S16)   # width not a multiple of 320
+    assert not ops.grouped_wide_ok(x, packs, sites(), None)
+    d = torch.empty(4, 512, 3 * C, dtype=torch.bfloat16)
+    dq, dk, dv = (d[..., g * C:(g + 1) * C].reshape(2048, C) for g in range(3))
+    cat = ops.packed_columns((dq, dk, dv), 2048, C)
+    assert cat is not None and cat.data_ptr() == d.data_ptr() and cat.shape == (2048, 3 * C) and cat.stride() == (3 * C, 1)
+    assert ops.packed_columns((dq, dv, dk), 2048, C) is None and ops.packed_columns((dq.contiguous(), dk, dv), 2048, C) is None
