@@ -268,12 +268,32 @@ def test_full_size_sd15_unet_forward_vs_oracle():
     assert lora_effect > 1e-3 and eff < 0.1, (lora_effect, eff)
 
 
-@pytest.mark.parametrize("rank", [32, 320])
-def test_full_size_ppft_gradients_vs_oracle(rank):
+@pytest.mark.parametrize("rank,force_chains", [pytest.param(32, False, id="32"), pytest.param(320, False, id="320"),
+                                               pytest.param(320, True, id="320-chains")])
+def test_full_size_ppft_gradients_vs_oracle(rank, force_chains):
     """BASELINE sizes (config 2: rank 32; configs 3 / 5: rank 320): ONE full PPFT step at batch 1 on the full SD-1.5 U-Net --
     clean forward, watermarked forward, MSE, backward to all 384 LoRA tensors + the mapper -- HIP against the
     bf16-mirroring CPU oracle (oracle.ppft_loss).  Checked: loss, predicted noise (max-norm AND L2), the gradient norm of
-    every one of the 384 tensors, and every full gradient tensor in relative L2 (worst / median stated below)."""
+    every one of the 384 tensors, and every full gradient tensor in relative L2 (worst / median stated below).
+    ``320-chains`` (round 6): the chains' tile-count gate lowered (ops.CHAIN_MIN_TILES) so that at batch 1 the
+    320-channel level runs on the rank-320 row-resident chain kernel (aql_lora_chain_fwd_r320, 15 launches) and its q | k | v stages on the
+    grouped backward -- the kernel meets the oracle DIRECTLY, not only through bit identity with the per-launch path."""
+    import os
+    from aqualora_amd import ops
+    chain_calls = []
+    real_chain_fwd, min_tiles = ops.chain_fwd, ops.CHAIN_MIN_TILES
+    if force_chains:
+        ops.CHAIN_MIN_TILES = 32      # twin batch of 2 x 4096 rows = 128 tiles of 64 >= 2 x 32
+        ops.chain_fwd = lambda *a, **kw: (chain_calls.append(kw.get("rank", a[7] if len(a) > 7 else 32)), real_chain_fwd(*a, **kw))[1]
+    try:
+        _full_size_gradients_vs_oracle(rank)
+    finally:
+        ops.chain_fwd, ops.CHAIN_MIN_TILES = real_chain_fwd, min_tiles
+    if force_chains:
+        assert len(chain_calls) == 15 and all(c == 320 for c in chain_calls), chain_calls
+
+
+def _full_size_gradients_vs_oracle(rank):
     import os
     from aqualora_amd import synth
     from aqualora_amd.lora import inject_lora
