@@ -1302,7 +1302,8 @@ def _grouped_backward(dys, x2d, T, Ts, S16, packs, sites, rps, ds_accum, want_dx
 
 # ------------------------------------------------------------- q | k | v at a LoRA rank above 32 (BASELINE config 3: rank 320)
 GROUPED_WIDE = os.environ.get("AQL_GROUPED_WIDE", "1") != "0"   # A/B hook: 0 = q | k | v (and the text k | v) as two-launch LoRA linears per site
-_DSG = {}    # (id(ds_accum), G) -> [[nb, G r] fp32, dirty]: dS of the grouped sites, one column block per member (fold_ds3 adds them up)
+# dS of the grouped sites: one [nb, G r] fp32 accumulator per group size G (one column block per member), kept ON the trainer's dS
+# accumulator tensor (attribute `_aql_dsg`: {G: [tensor, dirty]}) so that it lives and dies with it; fold_ds3 adds the blocks up
 
 
 def _rep_g(S, S16k, G):
@@ -1322,8 +1323,8 @@ def fold_ds3(ds_accum):
     """dS += the column blocks of the grouped sites' accumulators (then zero them for the next step).  Called by the trainer after the
     deferred dS launch, before S.backward(ds_accum)."""
     nb, r = ds_accum.shape
-    for (i, G), t in _DSG.items():
-        if i == id(ds_accum) and t[1]:
+    for G, t in getattr(ds_accum, "_aql_dsg", {}).items():
+        if t[1]:
             ds_accum.add_(t[0].view(nb, G, r).sum(dim=1))
             t[0].zero_()
             t[1] = False
@@ -1461,9 +1462,12 @@ class GroupedWideFn(torch.autograd.Function):
             dx = gemm_bf16(dcat, ctx.wcatT, None, dT, acatT)
         acc = ctx.ds_accum
         nb = S16.shape[0]
-        t = _DSG.get((id(acc), G))
+        dsg = getattr(acc, "_aql_dsg", None)
+        if dsg is None:
+            dsg = acc._aql_dsg = {}
+        t = dsg.get(G)
         if t is None or t[0].shape != (nb, G * r) or t[0].device != dev:
-            t = _DSG[(id(acc), G)] = [torch.zeros(nb, G * r, dtype=torch.float32, device=dev), False]
+            t = dsg[G] = [torch.zeros(nb, G * r, dtype=torch.float32, device=dev), False]
         t[1] = True
         if not DEFERRED.add_ds(dTs, T, t[0], nb, rps, G * r):
             L.call("aql_lora_ds", L.ptr(dTs), L.ptr(T), nb, rps, G * r, L.ptr(t[0]), L.stream_ptr())
