@@ -127,6 +127,13 @@ def _worker(rank, world, port, q):
     ex.zero_grad()
     ok_mge = ok_mge and float(ex.flat.abs().sum()) == 0.0 and all(p_.grad is not None for p_ in net3.parameters())
     ok_mod = ok_mod and ok_buf and ok_mge
+    # the trainer's choice of exchange (dp.make_comm, round 6: the captured aql_comm_* exchange is the DEFAULT under RCCL): under a
+    # non-RCCL backend every rank gets (None, "backend gloo") -- the torch.distributed fallback -- and AQL_COMM=0 asks for it outright
+    comm, note = dp.make_comm(None)
+    os.environ["AQL_COMM"] = "0"
+    comm0, note0 = dp.make_comm(None)
+    del os.environ["AQL_COMM"]
+    ok_mod = ok_mod and comm is None and note == "backend gloo" and comm0 is None and note0.startswith("AQL_COMM=0")
     q.put((rank, torch.allclose(a, want, atol=1e-6), torch.equal(a, b) and ok_async and ok_mod,
            not torch.equal(gathered[0], gathered[1])))
     dist.destroy_process_group()
@@ -267,3 +274,10 @@ def test_step_input_feed_copies_into_the_static_buffers():
     before = static["eps"].clone()
     _feed(static, new["z"] * 2, new["msg"], static["eps"], new["t"] + 1, new["ctx"])   # eps IS the static buffer: untouched
     assert torch.equal(static["eps"], before) and torch.equal(static["z"], new["z"] * 2) and static["t"].tolist() == [18, 934]
+
+
+def test_make_comm_without_a_process_group_is_no_exchange():
+    """Single process, no torch.distributed group: no exchange at all (whatever AQL_COMM says)."""
+    from aqualora_amd import dp
+    assert dp.make_comm(None) == (None, "no exchange (single rank)")
+    assert not dp.exchange_active(None)
