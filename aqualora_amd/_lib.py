@@ -114,6 +114,8 @@ SIGNATURES = {
     "aql_gemm_f32": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_p, c_l, c_l, c_i, c_l, c_p],
     "aql_bn_train_fwd": [c_p, c_p, c_p, c_l, c_i, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "aql_bn_train_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
+    "aql_bn_train_fwd_res": [c_p, c_p, c_p, c_l, c_i, c_f, c_f, c_i, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "aql_bn_train_bwd_rs": [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_p],
     "aql_dwconv_train": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "aql_stem_train": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "aql_chan_scale": [c_p, c_p, c_i, c_l, c_i, c_p, c_p],

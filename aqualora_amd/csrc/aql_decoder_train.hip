@@ -173,12 +173,15 @@ constexpr int BN_ROWS = 2048;  // rows per partial chunk
 // Lanes = 16 channel quads (16-byte loads) x 4 rows, 4 wavefronts = 16 rows per pass, four passes in flight per thread (the first
 // form -- one 4-byte load per lane and row, one row in flight per wavefront -- ran the 16 x 256 x 256-pixel maps of the rob-finetune
 // step at 0.8 TB/s: 26 of its 92 ms).  The four row lanes are folded with two xor-shuffles, the wavefronts through LDS, in a fixed order.
-template <bool BWD>
+template <bool BWD, bool RS = false>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          int act, long M, int C, float* __restrict__ p0,
-                                                         float* __restrict__ p1) {
+                                                         float* __restrict__ p1, const float* __restrict__ rowscale = nullptr,
+                                                         long rps = 1) {
+  // rowscale (BWD, round 6): dy arrives as the gradient of  rowscale[m / rps] * act(BN(x)) + residual  (stochastic depth + skip of an
+  // MBConv block folded into the BatchNorm, aql_bn_train_fwd_res): the incoming gradient is scaled per sample on the fly
   __shared__ float r0[4][64], r1[4][64];
   const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int q = lane & 15, rl = lane >> 4;
@@ -216,13 +219,21 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
       for (int u = 0; u < 4; ++u) {
         xv[u] = *reinterpret_cast<const float4*>(x + (m + 16 * u) * C + c);
         dv[u] = BWD ? *reinterpret_cast<const float4*>(dy + (m + 16 * u) * C + c) : xv[u];
+        if (BWD && RS) {
+          const float rs = rowscale[(uint32_t)(m + 16 * u) / (uint32_t)rps];
+          dv[u].x *= rs, dv[u].y *= rs, dv[u].z *= rs, dv[u].w *= rs;
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) add(xv[u], dv[u]);
     }
     for (; m < m_end; m += 16) {
       const float4 xv = *reinterpret_cast<const float4*>(x + m * C + c);
-      const float4 dv = BWD ? *reinterpret_cast<const float4*>(dy + m * C + c) : xv;
+      float4 dv = BWD ? *reinterpret_cast<const float4*>(dy + m * C + c) : xv;
+      if (BWD && RS) {
+        const float rs = rowscale[(uint32_t)m / (uint32_t)rps];
+        dv.x *= rs, dv.y *= rs, dv.z *= rs, dv.w *= rs;
+      }
       add(xv, dv);
     }
   }
@@ -299,12 +310,16 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __res
   dgamma[c] = (float)q;
 }
 
-template <bool BWD>
+template <bool BWD, bool RS = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ dbeta, const float* __restrict__ dgamma,
-                                                       int act, long M, int C, float* __restrict__ out) {
+                                                       int act, long M, int C, float* __restrict__ out,
+                                                       const float* __restrict__ res = nullptr,
+                                                       const float* __restrict__ rowscale = nullptr, long rps = 1) {
+  // forward with res / rowscale (round 6):  out = rowscale[m / rps] * act(BN(x)) + res  -- the stochastic-depth scale and the skip
+  // connection of an MBConv block in the BatchNorm's apply pass (two element-wise passes fewer); backward: dy scaled per sample
   const long n = M * (C / 4);
   const float invM = 1.f / (float)M;
   for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x) {
@@ -316,14 +331,27 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, mus[4] = {mu.x, mu.y, mu.z, mu.w}, iss[4] = {is.x, is.y, is.z, is.w};
     const float gs[4] = {g.x, g.y, g.z, g.w}, bs[4] = {bt.x, bt.y, bt.z, bt.w};
     float o[4];
+    float rsc = 1.f;
+    if constexpr (RS) {
+      if (rowscale != nullptr) rsc = rowscale[(uint32_t)(id / (C / 4)) / (uint32_t)rps];      // (M < 2^32 rows: the entry points check)
+    }
     if (!BWD) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float z = gs[i] * (xs[i] - mus[i]) * iss[i] + bs[i];
         o[i] = act ? silu_(z) : z;
       }
+      if (RS && rowscale != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = __fmul_rn(o[i], rsc);      // (two roundings, as the two launches it replaces)
+      }
+      if (RS && res != nullptr) {
+        const float4 rv = *reinterpret_cast<const float4*>(res + off);
+        o[0] = __fadd_rn(o[0], rv.x), o[1] = __fadd_rn(o[1], rv.y), o[2] = __fadd_rn(o[2], rv.z), o[3] = __fadd_rn(o[3], rv.w);
+      }
     } else {
-      const float4 dv = *reinterpret_cast<const float4*>(dy + off);
+      float4 dv = *reinterpret_cast<const float4*>(dy + off);
+      if constexpr (RS) dv.x *= rsc, dv.y *= rsc, dv.z *= rsc, dv.w *= rsc;
       const float4 db = *reinterpret_cast<const float4*>(dbeta + c), dg = *reinterpret_cast<const float4*>(dgamma + c);
       const float ds[4] = {dv.x, dv.y, dv.z, dv.w}, dbs[4] = {db.x, db.y, db.z, db.w}, dgs[4] = {dg.x, dg.y, dg.z, dg.w};
 #pragma unroll
@@ -818,6 +846,47 @@ extern "C" int aql_bn_train_bwd(const float* x, const float* dy, const float* ga
   hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(grid_for(M * (C / 4))), dim3(256), 0, stream, x, dy, mean, invstd, gamma,
                      beta, dbeta, dgamma, act, M, C, dx);
   AQL_CHECK_LAUNCH("aql_bn_train_bwd");
+  return AQL_OK;
+}
+
+// Round 6 (the first fusion of the decoder step).  The last BatchNorm of an MBConv block with a skip connection
+// (torchvision MBConv.forward: result = stochastic_depth(block(x)); result += x; utils/models.py:84-96 builds efficientnet_b1):
+//   y = rowscale[m / rows_per_sample] * BN_train(x) + res        (rowscale: the per-sample survival factor, "row" mode; res: the skip)
+// in the BatchNorm's apply pass -- the chan-scale launch and the residual-add launch (5 map accesses) become 1 extra read -- and its
+// backward: the gradient of x given dy = d(y) (d(res) = dy is the caller's), with the per-sample scale applied on the fly.
+extern "C" int aql_bn_train_fwd_res(const float* x, const float* gamma, const float* beta, long M, int C, float eps, float momentum,
+                                    int act, const float* res, const float* rowscale, long rows_per_sample, float* y, float* mean,
+                                    float* invstd, float* run_mean, float* run_var, float* scratch, hipStream_t stream) {
+  AQL_CHECK_ARG(x && gamma && beta && y && mean && invstd && scratch && M > 0 && C % 4 == 0 && rows_per_sample > 0 &&
+                    M % rows_per_sample == 0 && M < (1L << 32), "aql_bn_train_fwd_res: bad args");
+  const int nchunk = (int)((M + BN_ROWS - 1) / BN_ROWS);
+  float* p0 = scratch;
+  float* p1 = scratch + (long)nchunk * C;
+  hipLaunchKernelGGL(bn_partial_kernel<false>, dim3(nchunk, (C + 63) / 64), dim3(256), 0, stream, x, nullptr, nullptr,
+                     nullptr, nullptr, nullptr, 0, M, C, p0, p1, nullptr, 1L);
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, p0, p1, nchunk, M, C, eps,
+                     momentum, mean, invstd, run_mean, run_var);
+  hipLaunchKernelGGL((bn_apply_kernel<false, true>), dim3(grid_for(M * (C / 4))), dim3(256), 0, stream, x, nullptr, mean, invstd,
+                     gamma, beta, nullptr, nullptr, act, M, C, y, res, rowscale, rows_per_sample);
+  AQL_CHECK_LAUNCH("aql_bn_train_fwd_res");
+  return AQL_OK;
+}
+
+extern "C" int aql_bn_train_bwd_rs(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean,
+                                   const float* invstd, long M, int C, int act, const float* rowscale, long rows_per_sample,
+                                   float* dx, float* dgamma, float* dbeta, float* scratch, hipStream_t stream) {
+  AQL_CHECK_ARG(x && dy && gamma && beta && mean && invstd && dx && dgamma && dbeta && scratch && C % 4 == 0 && rows_per_sample > 0 && M < (1L << 32),
+                "aql_bn_train_bwd_rs: bad args");
+  const int nchunk = (int)((M + BN_ROWS - 1) / BN_ROWS);
+  float* p0 = scratch;
+  float* p1 = scratch + (long)nchunk * C;
+  hipLaunchKernelGGL((bn_partial_kernel<true, true>), dim3(nchunk, (C + 63) / 64), dim3(256), 0, stream, x, dy, mean, invstd,
+                     gamma, beta, act, M, C, p0, p1, rowscale, rows_per_sample);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, p0, p1, nchunk, C, dbeta,
+                     dgamma);
+  hipLaunchKernelGGL((bn_apply_kernel<true, true>), dim3(grid_for(M * (C / 4))), dim3(256), 0, stream, x, dy, mean, invstd, gamma,
+                     beta, dbeta, dgamma, act, M, C, dx, nullptr, rowscale, rows_per_sample);
+  AQL_CHECK_LAUNCH("aql_bn_train_bwd_rs");
   return AQL_OK;
 }
 

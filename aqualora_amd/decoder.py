@@ -220,7 +220,6 @@ class SecretDecoder(nn.Module):
                 g = _ActFn.apply(g, 2)
                 h = _ChanScaleFn.apply(h.view(Bq, Hc * Wc, C), g).view(Bq, Hc, Wc, C)
                 h = _conv1x1(h, lay[i + 2][0].weight, None)
-                h = _bn_act(h, lay[i + 2][1], False)
                 if blk.use_res:
                     p = 0.2 * bi / nblk                                   # torchvision: sd_prob * block_id / total
                     if sd_noise is not None:
@@ -229,9 +228,15 @@ class SecretDecoder(nn.Module):
                         noise = torch.empty(B, device=h.device).bernoulli_(1.0 - p)
                         if p < 1.0:
                             noise = noise / (1.0 - p)
-                    Bq, Hc, Wc, C = h.shape
-                    h = _ChanScaleFn.apply(h.view(Bq, Hc * Wc, C), noise.view(B, 1).expand(B, C).contiguous())
-                    h = h.view(Bq, Hc, Wc, C) + inp
+                    if FUSE_BN_RES:     # BatchNorm + stochastic depth + skip in the BatchNorm's apply pass (round 6)
+                        h = _bn_res(h, lay[i + 2][1], inp, noise)
+                    else:
+                        h = _bn_act(h, lay[i + 2][1], False)
+                        Bq, Hc, Wc, C = h.shape
+                        h = _ChanScaleFn.apply(h.view(Bq, Hc * Wc, C), noise.view(B, 1).expand(B, C).contiguous())
+                        h = h.view(Bq, Hc, Wc, C) + inp
+                else:
+                    h = _bn_act(h, lay[i + 2][1], False)
                 bi += 1
         h = _conv1x1(h, m.features[-1][0].weight, None)
         h = _bn_act(h, m.features[-1][1], True)
@@ -399,6 +404,53 @@ class _BNActFn(torch.autograd.Function):
         L.call("aql_bn_train_bwd", L.ptr(x), L.ptr(dy), L.ptr(g), L.ptr(b), L.ptr(mean), L.ptr(invstd), M, C, ctx.act,
                L.ptr(dx), L.ptr(dg), L.ptr(db), L.ptr(_bn_scratch(M, C, x.device)), L.stream_ptr())
         return dx, dg, db, None, None, None, None, None
+
+
+class _BNResFn(torch.autograd.Function):
+    """The last BatchNorm of an MBConv block with a skip connection, the stochastic-depth scale and the skip folded into its apply pass
+    (torchvision MBConv.forward: ``result = stochastic_depth(block(input)); result += input``):  y = noise[b] * BN_train(x) + res.
+    One launch set (statistics, finalize, apply) where BatchNorm + chan-scale + add ran; backward: d(res) = dy, and the BatchNorm
+    backward scales dy per sample on the fly (aql_bn_train_fwd_res / aql_bn_train_bwd_rs, round 6)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, eps, momentum, res, noise):
+        x, res = x.contiguous(), res.contiguous()
+        C = x.shape[-1]
+        M = x.numel() // C
+        rps = M // x.shape[0]
+        noise = noise.to(x.device, torch.float32).contiguous()
+        y = torch.empty_like(x)
+        mean = torch.empty(C, device=x.device)
+        invstd = torch.empty(C, device=x.device)
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        L.call("aql_bn_train_fwd_res", L.ptr(x), L.ptr(g), L.ptr(b), M, C, float(eps), float(momentum), 0, L.ptr(res), L.ptr(noise), rps,
+               L.ptr(y), L.ptr(mean), L.ptr(invstd), L.ptr(run_mean), L.ptr(run_var), L.ptr(_bn_scratch(M, C, x.device)), L.stream_ptr())
+        ctx.save_for_backward(x, g, b, mean, invstd, noise)
+        ctx.rps = rps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, b, mean, invstd, noise = ctx.saved_tensors
+        dy = dy.contiguous()
+        C = x.shape[-1]
+        M = x.numel() // C
+        dx = torch.empty_like(x)
+        dg = torch.empty(C, device=x.device)
+        db = torch.empty(C, device=x.device)
+        L.call("aql_bn_train_bwd_rs", L.ptr(x), L.ptr(dy), L.ptr(g), L.ptr(b), L.ptr(mean), L.ptr(invstd), M, C, 0, L.ptr(noise), ctx.rps,
+               L.ptr(dx), L.ptr(dg), L.ptr(db), L.ptr(_bn_scratch(M, C, x.device)), L.stream_ptr())
+        return dx, dg, db, None, None, None, None, dy, None
+
+
+FUSE_BN_RES = True    # False = BatchNorm, chan-scale and residual add as three launch sets (module attribute: the parity test flips it)
+
+
+def _bn_res(x, bn, res, noise):
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return _BNResFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                          0.1 if bn.momentum is None else bn.momentum, res, noise)
 
 
 def _bn_act(x, bn, act):

@@ -461,6 +461,17 @@ int aql_bn_train_fwd(const float* x, const float* gamma, const float* beta, long
 int aql_bn_train_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean,
                      const float* invstd, long M, int C, int act, float* dx, float* dgamma, float* dbeta, float* scratch,
                      aql_stream_t stream);
+/* Round 6, the first fusion of the decoder step: the last BatchNorm of an MBConv block with a skip connection (torchvision
+ * MBConv.forward: result = stochastic_depth(block(x)); result += x -- utils/models.py:84-96 builds efficientnet_b1) as
+ *   y = rowscale[m / rows_per_sample] * act(BN_train(x)) + res
+ * in the BatchNorm's apply pass (rowscale [M / rows_per_sample]: the per-sample survival factor, null = 1; res: the skip, null = none),
+ * and its backward for x (dy = d(y); d(res) = dy is the caller's): the per-sample scale multiplies dy on the fly.              */
+int aql_bn_train_fwd_res(const float* x, const float* gamma, const float* beta, long M, int C, float eps, float momentum, int act,
+                         const float* res, const float* rowscale, long rows_per_sample, float* y, float* mean, float* invstd,
+                         float* run_mean, float* run_var, float* scratch, aql_stream_t stream);
+int aql_bn_train_bwd_rs(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean, const float* invstd,
+                        long M, int C, int act, const float* rowscale, long rows_per_sample, float* dx, float* dgamma, float* dbeta,
+                        float* scratch, aql_stream_t stream);
 /* depthwise k x k conv, w packed [k*k][C]: mode 0 forward, 1 backward-data (src = dy), 2 backward-weight (src = x,
  * src2 = dy, dst = dw)                                                                                                   */
 int aql_dwconv_train(const float* src, const float* src2, const float* w, int B, int H, int W, int C, int k, int stride,

@@ -819,6 +819,44 @@ def decoder_training_step_parity(B, H, W, grad_tol=5e-2, image_grad_tol=2e-2):
     return dict(logits=relerr(got, want), image_grad=l2rel(xg.grad, xr.grad), worst_param_grad=worst, n_grads=n)
 
 
+def test_decoder_bn_stochastic_depth_skip_fusion_equals_the_three_launch_sets():
+    """Round 6, the first fusion of the rob-finetune decoder step: the last BatchNorm of an MBConv block with its stochastic-depth scale
+    and skip connection in ONE apply pass (aql_bn_train_fwd_res / aql_bn_train_bwd_rs) against BatchNorm -> chan-scale -> add: logits,
+    running statistics, every parameter gradient and the image gradient within the run-to-run spread of the step's own fp32 atomics
+    (the fused pass rounds where the launches rounded)."""
+    from aqualora_amd import decoder as D
+    torch.manual_seed(0)
+    B, bits = 4, 48
+    dec = _synthetic_decoder(bits).to(DEV).train()
+    state = {k: v.clone() for k, v in dec.state_dict().items()}
+    nblk = 23
+    sd_noise = [torch.bernoulli(torch.full((B,), 1.0 - 0.2 * i / nblk)) / (1.0 - 0.2 * i / nblk) for i in range(nblk)]
+    drop = torch.bernoulli(torch.full((B, 1280), 0.8)) / 0.8
+    x = T("decf.x", (B, 3, 160, 128), 0.5).clamp(-1, 1).to(DEV)
+    target = torch.nn.functional.one_hot((T("decf.m", (B, bits), 1.0) > 0).long(), 2).float().to(DEV)
+
+    def run(fused):
+        D.FUSE_BN_RES = fused
+        dec.load_state_dict(state)
+        for p in dec.parameters():
+            p.grad = None
+        xg = x.clone().requires_grad_(True)
+        got = dec(xg, sd_noise=sd_noise, drop_mask=drop)
+        D.bce_with_logits(got, target).backward()
+        torch.cuda.synchronize()
+        return got.detach().clone(), xg.grad.clone(), torch.cat([p.grad.reshape(-1) for p in dec.parameters()]), \
+            torch.cat([b.float().reshape(-1) for n, b in dec.named_buffers() if "running" in n])
+    try:
+        a, a2, f = run(False), run(False), run(True)
+    finally:
+        D.FUSE_BN_RES = True
+    # (the step's reductions use fp32 atomics: two runs of the SAME form differ in the last bits -- that spread is the yardstick)
+    s_fwd = max(relerr(a2[0], a[0]), relerr(a2[3], a[3]))
+    assert relerr(f[0], a[0]) <= 3 * s_fwd + 1e-6 and relerr(f[3], a[3]) <= 3 * s_fwd + 1e-6, (s_fwd, relerr(f[0], a[0]), relerr(f[3], a[3]))
+    spread = max(l2rel(a2[1], a[1]), l2rel(a2[2], a[2]))
+    assert l2rel(f[1], a[1]) <= 3 * spread + 1e-6 and l2rel(f[2], a[2]) <= 3 * spread + 1e-6, (spread, l2rel(f[1], a[1]), l2rel(f[2], a[2]))
+
+
 def test_distortion_maps_vs_torch():
     """crop+bilinear resize, Gaussian blur (reflect), additive noise: forward and adjoint vs plain torch ops."""
     import torch.nn.functional as F
